@@ -1,0 +1,90 @@
+"""Builds the in-tree native libraries.
+
+* ``lambda_amd/csrc/liblambda_ext.so`` -- the product: gfx950 HIP kernels + the C ABI of include/lambda_ext.h
+  + the C++ host mirror of the reference's extension driver.  Built with ``hipcc --offload-arch=gfx950``
+  (cross-compiles without a GPU).
+* ``oracle/_build/liblx_oracle.so`` -- TEST INFRASTRUCTURE: the CPU restatement used as the parity checker and
+  as bench.py's cpu_baseline leg.  Never linked into the product.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "lambda_amd" / "csrc"
+LIB = CSRC / "liblambda_ext.so"
+ORACLE_DIR = ROOT / "oracle"
+ORACLE_LIB = ORACLE_DIR / "_build" / "liblx_oracle.so"
+
+HIP_SOURCES = ["lx_score.hip", "lx_trace.hip", "lx_prefilter.hip", "lx_api.cpp", "host/lx_driver.cpp"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(d).stat().st_mtime <= t for d in deps)
+
+
+def build_product(force: bool = False, verbose: bool = False) -> Path:
+    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+    deps = list(srcs) + list(CSRC.glob("*.h")) + list((CSRC / "host").glob("*.hpp")) + [ROOT / "include" / "lambda_ext.h"]
+    if not force and _newer(LIB, deps):
+        return LIB
+    objs = []
+    hipcc = _hipcc()
+    common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}",
+              "-Wall", "-Wno-unused-function"]
+    procs = []
+    for s in srcs:
+        o = s.with_suffix(".o")
+        objs.append(o)
+        if not force and _newer(o, [s] + [d for d in deps if d.suffix in (".h", ".hpp")]):
+            continue
+        cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out, file=sys.stderr)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB)]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+def build_oracle(force: bool = False) -> Path:
+    srcs = [ORACLE_DIR / "lx_oracle.c", ORACLE_DIR / "lx_oracle_simd.c", ORACLE_DIR / "lx_oracle.h"]
+    if not force and _newer(ORACLE_LIB, srcs):
+        return ORACLE_LIB
+    r = subprocess.run(["make", "-C", str(ORACLE_DIR)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle build failed:\n{r.stdout}")
+    return ORACLE_LIB
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_product(force=force, verbose=verbose)
+    build_oracle(force=force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print(LIB)
+    print(ORACLE_LIB)

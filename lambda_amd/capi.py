@@ -1,0 +1,186 @@
+"""ctypes binding of the C ABI in include/lambda_ext.h (liblambda_ext.so).
+
+This is the only way Python code reaches the HIP path: tests, bench.py and the smoke test call the same exported
+symbols a C++ maintainer of the reference would link against.  If the shared library is missing
+or no gfx950 device is usable, everything here raises -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "csrc" / "liblambda_ext.so"
+
+LX_ALPH = 32
+LX_OK = 0
+LX_OPT_MAX_QLEN = 1
+LX_OPT_QUERY_RUN = 2
+LX_OPT_WORKSPACE_BYTES = 3
+
+# every symbol include/lambda_ext.h declares (tests/test_abi.py checks that the library exports all of them)
+EXPORTED_SYMBOLS = [
+    "lx_abi_version", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option",
+    "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
+    "lx_align_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_iterate_matches",
+    "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
+    "lx_widen_and_preprocess",
+]
+
+
+class Scoring(C.Structure):
+    _fields_ = [("alphabet_size", C.c_int32), ("gap_open", C.c_int32), ("gap_extend", C.c_int32),
+                ("reserved", C.c_int32), ("matrix", C.c_int8 * (LX_ALPH * LX_ALPH))]
+
+    def matrix_np(self) -> np.ndarray:
+        return np.ctypeslib.as_array(self.matrix).reshape(LX_ALPH, LX_ALPH).copy()
+
+
+EXT_DTYPE = np.dtype([("q_off", "<u8"), ("s_off", "<u8"), ("q_len", "<u4"), ("s_len", "<u4")])
+HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
+                      ("n_ops", "<i4"), ("num_matches", "<i4"), ("num_mismatches", "<i4"), ("num_positives", "<i4"),
+                      ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"), ("reserved", "<i4")])
+MATCH_DTYPE = np.dtype([("qryId", "<u8"), ("subjId", "<u8"), ("qryStart", "<u8"), ("qryEnd", "<u8"),
+                        ("subjStart", "<u8"), ("subjEnd", "<u8")])
+SEED_DTYPE = np.dtype([("q_off", "<u8"), ("s_off", "<u8"), ("q_len", "<u4"), ("s_len", "<u4"),
+                       ("qry_start", "<u4"), ("qry_end", "<u4"), ("subj_start", "<u4"), ("reserved", "<u4")])
+
+_lib = None
+
+
+class LambdaExtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"lambda_ext error {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Loads liblambda_ext.so (raises if it has not been built: the product path must fail loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise FileNotFoundError(f"{LIB_PATH} not built -- run `python -m lambda_amd.build` (needs hipcc)")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
+    lib.lx_abi_version.restype = i32
+    lib.lx_device_count.restype = i32
+    lib.lx_create.argtypes = [i32, C.POINTER(vp)]
+    lib.lx_destroy.argtypes = [vp]
+    lib.lx_destroy.restype = None
+    lib.lx_last_error.argtypes = [vp]
+    lib.lx_last_error.restype = C.c_char_p
+    lib.lx_set_option.argtypes = [vp, i32, u64]
+    lib.lx_set_scoring.argtypes = [vp, i32, C.POINTER(Scoring)]
+    lib.lx_builtin_scoring.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Scoring)]
+    lib.lx_score_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp]
+    lib.lx_score_batch_dev.argtypes = [vp, i32, vp, vp, vp, u64, vp, vp]
+    lib.lx_synchronize.argtypes = [vp]
+    lib.lx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    for name, args in (("lx_align_batch", [vp, i32, vp, u64, vp, u64, vp, u64, vp, vp, vp]),
+                       ("lx_align_batch_dev", [vp, i32, vp, vp, vp, u64, vp, vp, vp, vp]),
+                       ("lx_prefilter_batch", [vp, i32, vp, u64, vp, u64, vp, u64, C.c_uint32, C.c_int32, C.c_double, vp])):
+        if hasattr(lib, name):
+            getattr(lib, name).argtypes = args
+    _lib = lib
+    return lib
+
+
+def builtin_scoring(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Scoring:
+    sc = Scoring()
+    rc = load().lx_builtin_scoring(method, match, mismatch, gap_open, gap_extend, C.byref(sc))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_builtin_scoring")
+    return sc
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Handle:
+    """One lx_handle: one device, one HIP stream (the analogue of the reference's per-thread LocalDataHolder)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.lx_create(device, C.byref(h))
+        if rc != LX_OK:
+            raise LambdaExtError(rc, self.lib.lx_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int):
+        if rc != LX_OK:
+            raise LambdaExtError(rc, self.lib.lx_last_error(self.h).decode())
+
+    def set_option(self, opt: int, value: int):
+        self._check(self.lib.lx_set_option(self.h, opt, value))
+
+    def set_scoring(self, sc: Scoring, slot: int = 0):
+        self._check(self.lib.lx_set_scoring(self.h, slot, C.byref(sc)))
+
+    # ---- host-buffer entry points -------------------------------------------------------------------
+    def score_batch(self, q_res: np.ndarray, s_res: np.ndarray, ext: np.ndarray, slot: int = 0) -> np.ndarray:
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
+        out = np.full(len(ext), -1, dtype=np.int32)
+        self._check(self.lib.lx_score_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext),
+                                            len(ext), _ptr(out)))
+        return out
+
+    def align_batch(self, q_res: np.ndarray, s_res: np.ndarray, ext: np.ndarray, slot: int = 0):
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
+        n = len(ext)
+        sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+        ops_off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=ops_off[1:])
+        hsp = np.zeros(n, dtype=HSP_DTYPE)
+        ops = np.zeros(int(ops_off[-1]) + 1, dtype=np.uint8)
+        self._check(self.lib.lx_align_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext), n,
+                                            _ptr(hsp), _ptr(ops), _ptr(ops_off)))
+        ops_list = [bytes(ops[int(ops_off[i]):int(ops_off[i]) + int(hsp["n_ops"][i])]) for i in range(n)]
+        return hsp, ops_list
+
+    def prefilter_batch(self, q_res, s_res, seeds, seed_length: int, pre_scoring: int, thresh: float, slot: int = 0):
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        seeds = np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
+        keep = np.zeros(len(seeds), dtype=np.uint8)
+        self._check(self.lib.lx_prefilter_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size,
+                                                _ptr(seeds), len(seeds), seed_length, pre_scoring, thresh, _ptr(keep)))
+        return keep
+
+    # ---- device-resident entry points (torch tensors on this handle's device) --------------------------
+    def score_batch_dev(self, d_q, d_s, d_ext, n: int, d_out, stream=None, slot: int = 0):
+        self._check(self.lib.lx_score_batch_dev(self.h, slot, d_q.data_ptr(), d_s.data_ptr(), d_ext.data_ptr(), n,
+                                                d_out.data_ptr(), stream))
+
+    def align_batch_dev(self, d_q, d_s, d_ext, n: int, d_hsp, d_ops, d_ops_off, stream=None, slot: int = 0):
+        self._check(self.lib.lx_align_batch_dev(self.h, slot, d_q.data_ptr(), d_s.data_ptr(), d_ext.data_ptr(), n,
+                                                d_hsp.data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), stream))
+
+    def synchronize(self):
+        self._check(self.lib.lx_synchronize(self.h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._check(self.lib.lx_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,537 @@
+// lx_api.cpp -- host side of the C ABI declared in include/lambda_ext.h (compiled with hipcc).
+//
+// Owns: device selection, the HIP stream, device copies of the scoring schemes, grow-only staging buffers
+// for the host-buffer entry points, the multi-panel carry workspace, HIP-event timing of the kernel sequence,
+// and the binning of extensions into kernel geometries.  No DP arithmetic happens on the host and there is no
+// CPU fallback: without a usable gfx950 device every entry point returns an error.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/lambda_ext.h"
+#include "host/scoring_tables.hpp"
+#include "lx_device.h"
+
+namespace lx
+{
+hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t stream);
+int        score_cfg_panel(int cfg);
+int        score_cfg_groups(int cfg);
+} // namespace lx
+
+static_assert(sizeof(lx_extension) == sizeof(lx::Extension), "ABI mismatch");
+static_assert(sizeof(lx_hsp) == sizeof(lx::Hsp), "ABI mismatch");
+static_assert(sizeof(lx_extension) == 24, "ABI mismatch");
+
+namespace
+{
+
+thread_local std::string g_create_error;
+
+struct DevBuf
+{
+    void * ptr = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct lx_handle
+{
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    bool        timed = false;
+    std::string error;
+
+    bool             have_sc[2] = {false, false};
+    lx_scoring       sc_host[2];
+    lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
+
+    // staging for the host-buffer entry points
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace;
+    // multi-panel carry workspace
+    DevBuf     d_ws;
+    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
+    // options
+    uint64_t opt_max_qlen  = 0;
+    uint64_t opt_query_run = 0;
+    uint64_t opt_ws_bytes  = 64ull << 20;
+};
+
+namespace
+{
+
+int fail(lx_handle * h, int code, char const * fmt, ...)
+{
+    char    buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h)
+        h->error = buf;
+    else
+        g_create_error = buf;
+    return code;
+}
+
+#define LX_HIP(h, call)                                                                                         \
+    do                                                                                                          \
+    {                                                                                                           \
+        hipError_t _e = (call);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return fail((h), _e == hipErrorOutOfMemory ? LX_ENOMEM : LX_EHIP, "%s failed: %s", #call,           \
+                        hipGetErrorString(_e));                                                                 \
+    } while (0)
+
+int ensure(lx_handle * h, DevBuf & b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return LX_OK;
+    if (b.ptr)
+    {
+        LX_HIP(h, hipStreamSynchronize(h->stream));
+        LX_HIP(h, hipFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+    }
+    size_t const want = bytes + bytes / 4 + 4096;
+    LX_HIP(h, hipMalloc(&b.ptr, want));
+    b.cap = want;
+    return LX_OK;
+}
+
+int bind(lx_handle * h)
+{
+    LX_HIP(h, hipSetDevice(h->device));
+    return LX_OK;
+}
+
+// padding of q/s staging buffers so that clamped / prefetching loads never leave the allocation
+constexpr size_t kSlack = 256;
+
+int pick_cfg(uint32_t qlen)
+{
+    if (qlen <= 64)
+        return 1;
+    if (qlen <= 160)
+        return 0;
+    if (qlen <= 320)
+        return 2;
+    return 3;
+}
+
+int check_async_error(lx_handle * h)
+{
+    uint32_t flags[2] = {0, 0};
+    LX_HIP(h, hipMemcpyAsync(flags, h->d_ws_top, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+    if (flags[1] == 1)
+        return fail(h, LX_EOVERFLOW, "multi-panel carry workspace exhausted (raise LX_OPT_WORKSPACE_BYTES)");
+    if (flags[1] == 2)
+        return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
+    if (flags[1] != 0)
+        return fail(h, LX_EHIP, "device reported error flag %u", flags[1]);
+    return LX_OK;
+}
+
+// One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
+// (or need the multi-panel path when wider).
+int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n,
+                      void * d_out, int cfg, bool multi, bool shared, hipStream_t stream)
+{
+    lx::ScoreParams p{};
+    p.q_res          = static_cast<uint8_t const *>(d_q);
+    p.s_res          = static_cast<uint8_t const *>(d_s);
+    p.ext            = static_cast<lx::Extension const *>(d_ext);
+    p.n              = n;
+    p.sc             = h->sc_dev[slot];
+    p.out_score      = static_cast<int32_t *>(d_out);
+    p.ws             = static_cast<int32_t *>(h->d_ws.ptr);
+    p.ws_top         = h->d_ws_top;
+    p.ws_cap         = (uint32_t)std::min<uint64_t>(h->d_ws.cap / 8, 0xffffffffu);
+    p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+    p.shared_profile = shared ? 1 : 0;
+    p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+    LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
+    return LX_OK;
+}
+
+int prepare_workspace(lx_handle * h, hipStream_t stream)
+{
+    int rc = ensure(h, h->d_ws, h->opt_ws_bytes);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, 2 * sizeof(uint32_t), stream));
+    return LX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int lx_abi_version(void)
+{
+    return LX_ABI_VERSION;
+}
+
+int lx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int lx_create(int device_id, lx_handle ** out)
+{
+    if (!out)
+        return fail(nullptr, LX_EINVAL, "lx_create: out is NULL");
+    *out  = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(nullptr, LX_ENODEV, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, LX_EINVAL, "device_id %d out of range [0,%d)", device_id, n);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return fail(nullptr, LX_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, LX_ENODEV, "device %d is %s; this library ships gfx950 (MI355X) code only", device_id,
+                    prop.gcnArchName);
+
+    lx_handle * h = new lx_handle();
+    h->device     = device_id;
+    auto bail     = [&](char const * what, hipError_t err)
+    {
+        int rc = fail(nullptr, LX_EHIP, "%s: %s", what, hipGetErrorString(err));
+        lx_destroy(h);
+        return rc;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess)
+        return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess)
+        return bail("hipEventCreate", e);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 4 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipMalloc", e);
+    if ((e = hipMemset(h->d_ws_top, 0, 4 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipMemset", e);
+    for (int s = 0; s < 2; ++s)
+        if ((e = hipMalloc(reinterpret_cast<void **>(&h->sc_dev[s]), sizeof(lx::ScoringDev))) != hipSuccess)
+            return bail("hipMalloc", e);
+    *out = h;
+    return LX_OK;
+}
+
+void lx_destroy(lx_handle * h)
+{
+    if (!h)
+        return;
+    if (h->device >= 0)
+        (void)hipSetDevice(h->device);
+    if (h->stream)
+        (void)hipStreamSynchronize(h->stream);
+    for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ws})
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    for (int s = 0; s < 2; ++s)
+        if (h->sc_dev[s])
+            (void)hipFree(h->sc_dev[s]);
+    if (h->d_ws_top)
+        (void)hipFree(h->d_ws_top);
+    if (h->ev0)
+        (void)hipEventDestroy(h->ev0);
+    if (h->ev1)
+        (void)hipEventDestroy(h->ev1);
+    if (h->stream)
+        (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+char const * lx_last_error(lx_handle const * h)
+{
+    return h ? h->error.c_str() : g_create_error.c_str();
+}
+
+int lx_set_option(lx_handle * h, int option, uint64_t value)
+{
+    if (!h)
+        return LX_EINVAL;
+    switch (option)
+    {
+        case LX_OPT_MAX_QLEN: h->opt_max_qlen = value; return LX_OK;
+        case LX_OPT_QUERY_RUN: h->opt_query_run = value; return LX_OK;
+        case LX_OPT_WORKSPACE_BYTES: h->opt_ws_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
+        default: return fail(h, LX_EINVAL, "unknown option %d", option);
+    }
+}
+
+int lx_builtin_scoring(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend,
+                       lx_scoring * sc)
+{
+    if (!sc)
+        return LX_EINVAL;
+    try
+    {
+        lambda_amd::builtinScoring(scoring_method, match, mismatch, gap_open_lambda, gap_extend, *sc);
+    }
+    catch (std::exception const &)
+    {
+        return LX_EINVAL;
+    }
+    return LX_OK;
+}
+
+int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
+{
+    if (!h || !sc)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1)
+        return fail(h, LX_EINVAL, "slot must be 0 or 1");
+    if (sc->alphabet_size < 1 || sc->alphabet_size > LX_ALPH - 1)
+        return fail(h, LX_EINVAL, "alphabet_size must be in [1,31]");
+    if (sc->gap_extend >= 0 || sc->gap_open > sc->gap_extend)
+        return fail(h, LX_EINVAL, "need gap_open <= gap_extend < 0 (got %d / %d)", sc->gap_open, sc->gap_extend);
+    if (sc->gap_open < -120 || sc->gap_extend < -27)
+        return fail(h, LX_EINVAL, "gap costs out of the supported range");
+    lx::ScoringDev d{};
+    d.alph = sc->alphabet_size;
+    d.go   = sc->gap_open;
+    d.ge   = sc->gap_extend;
+    d.g2   = sc->gap_open - sc->gap_extend;
+    for (int a = 0; a < lx::kAlph; ++a)
+        for (int b = 0; b < lx::kAlph; ++b)
+        {
+            bool const pad = a >= sc->alphabet_size || b >= sc->alphabet_size;
+            int const  v   = pad ? lx::kNegPad : sc->matrix[a * LX_ALPH + b];
+            if (!pad && (v > 100 || v < -100))
+                return fail(h, LX_EINVAL, "matrix entry [%d][%d]=%d outside [-100,100]", a, b, v);
+            d.mat[a * lx::kAlph + b]     = (int8_t)v;
+            d.mat_adj[a * lx::kAlph + b] = (int8_t)(pad ? lx::kNegPad : v - sc->gap_extend);
+        }
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+    LX_HIP(h, hipMemcpy(h->sc_dev[slot], &d, sizeof(d), hipMemcpyHostToDevice));
+    h->sc_host[slot] = *sc;
+    h->have_sc[slot] = true;
+    return LX_OK;
+}
+
+int lx_synchronize(lx_handle * h)
+{
+    if (!h)
+        return LX_EINVAL;
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    return check_async_error(h);
+}
+
+int lx_last_kernel_ms(lx_handle * h, float * ms)
+{
+    if (!h || !ms)
+        return LX_EINVAL;
+    if (!h->timed)
+        return fail(h, LX_ESTATE, "no timed launch yet");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipEventSynchronize(h->ev1));
+    LX_HIP(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return LX_OK;
+}
+
+int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
+                       uint64_t n, void * d_out_score, void * stream_)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!d_q_res || !d_s_res || !d_ext || !d_out_score)
+        return fail(h, LX_EINVAL, "NULL device pointer");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
+    if ((rc = prepare_workspace(h, stream)))
+        return rc;
+    // geometry from the caller's hints; any geometry is correct for any query length (multi-panel path)
+    int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu)) : 0;
+    bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
+    bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
+    LX_HIP(h, hipEventRecord(h->ev0, stream));
+    if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream)))
+        return rc;
+    LX_HIP(h, hipEventRecord(h->ev1, stream));
+    h->timed = true;
+    return LX_OK;
+}
+
+int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t * out_score)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || (!q_res && q_bytes) || (!s_res && s_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+
+    // ---- validate + bin by kernel geometry; inside a bin order by (q_len, q_off, s_len): same query adjacent
+    // (one profile per wavefront), similar lengths adjacent (the reference sorts for the same reason,
+    // src/search_algo.hpp:1229-1235)
+    std::vector<uint32_t> order[4];
+    uint64_t              carry_pairs = 0;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_extension const & x = ext[i];
+        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
+        if (x.q_len == 0 || x.s_len == 0)
+        {
+            out_score[i] = 0;
+            continue;
+        }
+        int const cfg = pick_cfg(x.q_len);
+        if ((int)x.q_len > lx::score_cfg_panel(cfg))
+            carry_pairs += x.s_len;
+        order[cfg].push_back((uint32_t)i);
+    }
+    if (n > 0xffffffffull)
+        return fail(h, LX_EINVAL, "at most 2^32-1 extensions per call");
+    if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
+        h->opt_ws_bytes = carry_pairs * 8 + 4096;
+
+    std::vector<lx_extension> sorted;
+    sorted.reserve(n);
+    std::vector<uint32_t> perm;
+    perm.reserve(n);
+    struct Seg
+    {
+        int      cfg;
+        uint64_t first, count;
+        bool     multi, shared;
+    };
+    std::vector<Seg> segs;
+    for (int cfg = 0; cfg < 4; ++cfg)
+    {
+        auto & o = order[cfg];
+        if (o.empty())
+            continue;
+        std::sort(o.begin(), o.end(),
+                  [&](uint32_t a, uint32_t b)
+                  {
+                      lx_extension const &x = ext[a], &y = ext[b];
+                      if (x.q_len != y.q_len)
+                          return x.q_len < y.q_len;
+                      if (x.q_off != y.q_off)
+                          return x.q_off < y.q_off;
+                      if (x.s_len != y.s_len)
+                          return x.s_len < y.s_len;
+                      return a < b;
+                  });
+        int const  groups = lx::score_cfg_groups(cfg);
+        bool const multi  = ext[o.back()].q_len > (uint32_t)lx::score_cfg_panel(cfg);
+        // would padding every query run to a multiple of `groups` cost <= 12.5 % extra slots?  then share profiles
+        uint64_t padded = 0, run = 0;
+        for (size_t k = 0; k < o.size(); ++k)
+        {
+            ++run;
+            bool const last = (k + 1 == o.size()) || ext[o[k + 1]].q_off != ext[o[k]].q_off ||
+                              ext[o[k + 1]].q_len != ext[o[k]].q_len;
+            if (last)
+            {
+                padded += (run + groups - 1) / groups * groups;
+                run = 0;
+            }
+        }
+        bool const shared = groups > 1 && padded * 8 <= o.size() * 9;
+        Seg        seg{cfg, sorted.size(), 0, multi, shared};
+        run = 0;
+        for (size_t k = 0; k < o.size(); ++k)
+        {
+            sorted.push_back(ext[o[k]]);
+            perm.push_back(o[k]);
+            ++run;
+            bool const last = (k + 1 == o.size()) || ext[o[k + 1]].q_off != ext[o[k]].q_off ||
+                              ext[o[k + 1]].q_len != ext[o[k]].q_len;
+            if (shared && last)
+            {
+                while (run % groups) // dummy slots keep one query per wavefront
+                {
+                    lx_extension dummy = ext[o[k]];
+                    dummy.s_len        = 0;
+                    sorted.push_back(dummy);
+                    perm.push_back(0xffffffffu);
+                    ++run;
+                }
+                run = 0;
+            }
+        }
+        seg.count = sorted.size() - seg.first;
+        segs.push_back(seg);
+    }
+    if (sorted.empty())
+        return LX_OK;
+
+    // ---- upload
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
+        (rc = ensure(h, h->d_ext, sorted.size() * sizeof(lx_extension))) ||
+        (rc = ensure(h, h->d_out, sorted.size() * sizeof(int32_t))))
+        return rc;
+    if ((rc = prepare_workspace(h, h->stream)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (s_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, sorted.data(), sorted.size() * sizeof(lx_extension), hipMemcpyHostToDevice,
+                             h->stream));
+
+    // ---- launch
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    for (Seg const & seg : segs)
+    {
+        rc = launch_score_list(h, slot, h->d_q.ptr, h->d_s.ptr,
+                               static_cast<lx_extension const *>(h->d_ext.ptr) + seg.first, seg.count,
+                               static_cast<int32_t *>(h->d_out.ptr) + seg.first, seg.cfg, seg.multi, seg.shared,
+                               h->stream);
+        if (rc)
+            return rc;
+    }
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+
+    // ---- download + unpermute
+    std::vector<int32_t> res(sorted.size());
+    LX_HIP(h, hipMemcpyAsync(res.data(), h->d_out.ptr, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    if ((rc = check_async_error(h)))
+        return rc;
+    for (size_t k = 0; k < res.size(); ++k)
+        if (perm[k] != 0xffffffffu)
+            out_score[perm[k]] = res[k];
+    return LX_OK;
+}
+
+} // extern "C"

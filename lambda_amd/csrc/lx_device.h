@@ -1,0 +1,61 @@
+// lx_device.h -- structures shared between the host side of the C ABI and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace lx
+{
+
+constexpr int kAlph    = 32;          // matrix stride (include/lambda_ext.h LX_ALPH)
+constexpr int kNegPad  = -100;        // substitution score of any pad rank: can never start/extend/end a best local alignment
+constexpr int kNegInf  = -(1 << 28);  // "minus infinity" for gap states; far from int32 overflow after any number of additions
+
+// Device copy of one scoring scheme, preprocessed for the row-skewed recurrence (see lx_score.hip).
+struct ScoringDev
+{
+    int32_t alph;     // valid ranks 0..alph-1; rank `alph` is used as the pad letter
+    int32_t go;       // SeqAn scoreGapOpen   (first gap character), negative
+    int32_t ge;       // SeqAn scoreGapExtend (further characters), negative
+    int32_t g2;       // go - ge
+    int8_t  mat[kAlph * kAlph];     // original matrix[q*32+s], pad ranks = kNegPad
+    int8_t  mat_adj[kAlph * kAlph]; // matrix[q*32+s] - ge (diagonal step in the skewed domain), pad ranks = kNegPad
+};
+
+// Mirrors lx_extension in include/lambda_ext.h (static_assert'ed in lx_api.cpp).
+struct Extension
+{
+    uint64_t q_off;
+    uint64_t s_off;
+    uint32_t q_len;
+    uint32_t s_len;
+};
+
+// Mirrors lx_hsp.
+struct Hsp
+{
+    int32_t score;
+    int32_t q_begin, q_end;
+    int32_t s_begin, s_end;
+    int32_t n_ops;
+    int32_t num_matches, num_mismatches, num_positives;
+    int32_t num_gap_opens, num_gap_extensions;
+    int32_t reserved;
+};
+
+struct ScoreParams
+{
+    uint8_t const *    q_res;
+    uint8_t const *    s_res;
+    Extension const *  ext;
+    uint64_t           n;
+    ScoringDev const * sc;
+    int32_t *          out_score;
+    // multi-panel carry workspace (only touched by extensions whose query is wider than one panel)
+    int32_t *          ws;       // int32 pairs
+    uint32_t *         ws_top;   // bump pointer, in int32 pairs
+    uint32_t           ws_cap;   // capacity, in int32 pairs
+    int32_t *          err;      // set to 1 on workspace overflow
+    int32_t            shared_profile; // 1: every group of a wave uses the same query -> one profile slot per wave
+    int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
+};
+
+} // namespace lx

@@ -1,0 +1,159 @@
+"""Synthetic seed-extension workloads (SURVEY.md section 8d / BASELINE.md section 3).
+
+No index is built: candidate windows are generated directly, with the geometry the reference's window builder
+produces (whole query x subject window of Lq + 2*b residues, b = floor(sqrt(Lq)) + 1;
+/root/reference/src/search_misc.hpp:46-50, src/search_algo.hpp:919-938).  Half of the windows hold a mutated
+copy of the query (substitutions + indels) between random flanks, half are random.
+
+Two generators with the same structure: numpy (deterministic fixtures, CPU tests) and torch (full-size batches
+generated directly in HBM for bench.py).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .capi import EXT_DTYPE
+
+# SeqAn AminoAcid ranks ("ABCDEFGHIJKLMNOPQRSTUVWYZX*") of the 20 standard residues ACDEFGHIKLMNPQRSTVWY
+STD20 = np.array([0, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18, 19, 21, 22, 23], dtype=np.uint8)
+
+
+def band_size(lq: int) -> int:
+    return int(math.sqrt(lq)) + 1
+
+
+def window_len(lq: int) -> int:
+    return lq + 2 * band_size(lq)
+
+
+def make_batch_np(n_queries: int, lq: int, windows_per_query: int, seed: int, alphabet: np.ndarray = STD20,
+                  homolog_frac: float = 0.5, sub_rate: float = 0.25, indel_rate: float = 0.02, n_rate: float = 0.0,
+                  n_rank: int = 4, bisulfite: str | None = None):
+    """Returns (q_res, s_res, ext): uint8 residue buffers and the EXT_DTYPE extension list.
+
+    Extensions are ordered query-major (all windows of query 0, then query 1, ...), i.e. runs of
+    `windows_per_query` consecutive entries share one query slice.
+    """
+    rng = np.random.default_rng(seed)
+    b = band_size(lq)
+    ls = lq + 2 * b
+    na = len(alphabet)
+    q_idx = rng.integers(0, na, size=(n_queries, lq), dtype=np.int64)
+    n_ext = n_queries * windows_per_query
+    w_idx = rng.integers(0, na, size=(n_ext, ls), dtype=np.int64)
+
+    homolog = rng.random(n_ext) < homolog_frac
+    nh = int(homolog.sum())
+    if nh:
+        hq = np.repeat(np.arange(n_queries), windows_per_query)[homolog]
+        ev = rng.random((nh, ls))
+        dele = ev < indel_rate / 2           # skip one query residue
+        ins = (ev >= indel_rate / 2) & (ev < indel_rate)  # insert a random residue
+        shift = np.cumsum(dele, axis=1) - np.cumsum(ins, axis=1)
+        src = np.arange(ls)[None, :] - b + shift
+        inside = (src >= 0) & (src < lq) & ~ins
+        copied = q_idx[hq[:, None], np.clip(src, 0, lq - 1)]
+        if bisulfite == "fwd":    # C->T conversion of the read relative to the genome: genome keeps C where the read has T
+            pass
+        sub = rng.random((nh, ls)) < sub_rate
+        keep = inside & ~sub
+        rows = w_idx[homolog]
+        rows[keep] = copied[keep]
+        w_idx[homolog] = rows
+
+    q_res = alphabet[q_idx].astype(np.uint8)
+    s_res = alphabet[w_idx].astype(np.uint8)
+    if n_rate > 0:
+        q_res[rng.random(q_res.shape) < n_rate] = n_rank
+        s_res[rng.random(s_res.shape) < n_rate] = n_rank
+
+    ext = np.zeros(n_ext, dtype=EXT_DTYPE)
+    ext["q_off"] = np.repeat(np.arange(n_queries, dtype=np.uint64) * lq, windows_per_query)
+    ext["q_len"] = lq
+    ext["s_off"] = np.arange(n_ext, dtype=np.uint64) * ls
+    ext["s_len"] = ls
+    return q_res.reshape(-1), s_res.reshape(-1), ext
+
+
+def make_ragged_np(n_ext: int, seed: int, alphabet: np.ndarray = STD20, lq_range=(1, 400), ls_extra=(0, 80),
+                   homolog_frac: float = 0.6, sub_rate: float = 0.2):
+    """Ragged batch for edge-case parity tests: every extension has its own query and window length."""
+    rng = np.random.default_rng(seed)
+    na = len(alphabet)
+    q_parts, s_parts = [], []
+    ext = np.zeros(n_ext, dtype=EXT_DTYPE)
+    qo = so = 0
+    for i in range(n_ext):
+        lq = int(rng.integers(lq_range[0], lq_range[1] + 1))
+        ls = max(1, lq + int(rng.integers(ls_extra[0] - lq // 2, ls_extra[1] + 1)))
+        q = rng.integers(0, na, size=lq)
+        s = rng.integers(0, na, size=ls)
+        if rng.random() < homolog_frac and lq > 4:
+            a = int(rng.integers(0, max(1, ls - lq // 2)))
+            seg = q[: min(lq, ls - a)].copy()
+            mut = rng.random(len(seg)) < sub_rate
+            seg[mut] = rng.integers(0, na, size=int(mut.sum()))
+            # one deletion and one insertion now and then
+            if len(seg) > 10 and rng.random() < 0.5:
+                cut = int(rng.integers(2, len(seg) - 2))
+                seg = np.concatenate([seg[:cut], seg[cut + int(rng.integers(1, 4)):]])
+            s[a:a + len(seg)] = seg[: ls - a]
+        q_parts.append(alphabet[q])
+        s_parts.append(alphabet[s])
+        ext[i] = (qo, so, lq, ls)
+        qo += lq
+        so += ls
+    return np.concatenate(q_parts).astype(np.uint8), np.concatenate(s_parts).astype(np.uint8), ext
+
+
+def make_batch_torch(n_queries: int, lq: int, windows_per_query: int, seed: int, device, alphabet: np.ndarray = STD20,
+                     homolog_frac: float = 0.5, sub_rate: float = 0.25, indel_rate: float = 0.02,
+                     n_rate: float = 0.0, n_rank: int = 4, chunk_queries: int = 8192):
+    """Same workload as make_batch_np, generated directly on `device` (torch).  Returns torch tensors
+    (q_res u8 [n_queries*lq], s_res u8 [n_ext*ls], ext u8 view of EXT_DTYPE records [n_ext*24])."""
+    import torch
+
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    b = band_size(lq)
+    ls = lq + 2 * b
+    alpha = torch.as_tensor(np.asarray(alphabet, dtype=np.int64), device=device)
+    na = len(alphabet)
+    n_ext = n_queries * windows_per_query
+    q_res = torch.empty((n_queries, lq), dtype=torch.uint8, device=device)
+    s_res = torch.empty((n_ext, ls), dtype=torch.uint8, device=device)
+    pos = torch.arange(ls, device=device)[None, :]
+    for q0 in range(0, n_queries, chunk_queries):
+        q1 = min(n_queries, q0 + chunk_queries)
+        nq = q1 - q0
+        q_idx = torch.randint(0, na, (nq, lq), generator=gen, device=device)
+        ne = nq * windows_per_query
+        w_idx = torch.randint(0, na, (ne, ls), generator=gen, device=device)
+        homolog = torch.rand(ne, generator=gen, device=device) < homolog_frac
+        hq = torch.arange(nq, device=device).repeat_interleave(windows_per_query)
+        ev = torch.rand((ne, ls), generator=gen, device=device)
+        dele = ev < indel_rate / 2
+        ins = (ev >= indel_rate / 2) & (ev < indel_rate)
+        shift = torch.cumsum(dele.to(torch.int32), 1) - torch.cumsum(ins.to(torch.int32), 1)
+        src = pos - b + shift
+        inside = (src >= 0) & (src < lq) & ~ins
+        copied = torch.gather(q_idx[hq], 1, src.clamp(0, lq - 1))
+        sub = torch.rand((ne, ls), generator=gen, device=device) < sub_rate
+        keep = inside & ~sub & homolog[:, None]
+        w_idx = torch.where(keep, copied, w_idx)
+        qr = alpha[q_idx].to(torch.uint8)
+        sr = alpha[w_idx].to(torch.uint8)
+        if n_rate > 0:
+            qr[torch.rand(qr.shape, generator=gen, device=device) < n_rate] = n_rank
+            sr[torch.rand(sr.shape, generator=gen, device=device) < n_rate] = n_rank
+        q_res[q0:q1] = qr
+        s_res[q0 * windows_per_query:q1 * windows_per_query] = sr
+    ext = np.zeros(n_ext, dtype=EXT_DTYPE)
+    ext["q_off"] = np.repeat(np.arange(n_queries, dtype=np.uint64) * lq, windows_per_query)
+    ext["q_len"] = lq
+    ext["s_off"] = np.arange(n_ext, dtype=np.uint64) * ls
+    ext["s_len"] = ls
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(device)
+    return q_res.reshape(-1), s_res.reshape(-1), d_ext, ext

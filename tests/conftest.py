@@ -1,0 +1,38 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests import oracle_lib
+
+    return oracle_lib.load()
+
+
+@pytest.fixture(scope="session")
+def lx_lib():
+    from lambda_amd import build, capi
+
+    if not capi.LIB_PATH.exists():
+        build.build_product()
+    return capi.load()
+
+
+@pytest.fixture(scope="session")
+def handle(lx_lib):
+    """A live lx_handle on cuda:0 -- GPU tests only. Fails (not skips) when the HIP path is unusable."""
+    from lambda_amd import capi
+
+    h = capi.Handle(0)
+    yield h
+    h.close()

@@ -1,0 +1,151 @@
+"""GPU parity tests of pass 1 (score only): HIP path (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+from lambda_amd import capi, synth
+from tests import oracle_lib
+from tests.test_oracle import SCHEMES, alphabet_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(handle, oracle, q, s, ext, name):
+    sc_p = SCHEMES[name]
+    handle.set_scoring(sc_p, 0)
+    got = handle.score_batch(q, s, ext)
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} mismatches, first at {bad[:5]}: got {got[bad[:5]]} want {want[bad[:5]]} ext {ext[bad[:5]]}"
+    return got
+
+
+@pytest.mark.parametrize("name", ["blosum62", "nucl", "bs_fwd", "bs_rev"])
+def test_ragged_all_geometries(handle, oracle, name):
+    # query lengths 1..700 exercise all four kernel geometries and the multi-panel carry path (> 640 columns)
+    q, s, ext = synth.make_ragged_np(1500, seed=11, alphabet=alphabet_of(name), lq_range=(1, 700), ls_extra=(0, 90))
+    got = _check(handle, oracle, q, s, ext, name)
+    assert got.max() > 50
+
+
+def test_headline_shape_shared_profiles(handle, oracle):
+    # config-2 geometry: 150 aa queries, 32 windows each of 176 residues -> one profile per wavefront
+    q, s, ext = synth.make_batch_np(300, 150, 32, seed=0x1A3BDA02)
+    got = _check(handle, oracle, q, s, ext, "blosum62")
+    assert (got > 100).mean() > 0.3  # the homologous half scores high
+
+
+def test_config1_shape(handle, oracle):
+    q, s, ext = synth.make_batch_np(200, 100, 7, seed=0x1A3BDA01)  # 7 windows/query: runs not a multiple of 4
+    _check(handle, oracle, q, s, ext, "blosum62")
+
+
+def test_searchn_shape_with_n(handle, oracle):
+    q, s, ext = synth.make_batch_np(400, 150, 8, seed=0x1A3BDA03, alphabet=np.array([0, 1, 2, 4], dtype=np.uint8),
+                                    n_rate=0.01, n_rank=3, sub_rate=0.05, indel_rate=0.01)
+    _check(handle, oracle, q, s, ext, "nucl")
+
+
+def test_edge_cases(handle, oracle):
+    rng = np.random.default_rng(9)
+    q = synth.STD20[rng.integers(0, 20, 5000)].astype(np.uint8)
+    s = synth.STD20[rng.integers(0, 20, 20000)].astype(np.uint8)
+    s[1000:3000] = q[:2000]  # long perfect match: high scores, long subject
+    ext = np.array([
+        (0, 0, 0, 0),            # both empty
+        (0, 0, 10, 0),           # empty subject
+        (0, 0, 0, 10),           # empty query
+        (0, 1000, 1, 1),         # single cell, match
+        (0, 1001, 1, 1),         # single cell, probably mismatch
+        (0, 1000, 2000, 2000),   # 2000x2000 identical: 4 panels of 640, score in the thousands
+        (0, 900, 1999, 2300),    # multi-panel with flanks
+        (100, 1100, 160, 176),   # exactly one panel of geometry 0
+        (100, 1100, 161, 176),   # one column more -> next geometry
+        (100, 1100, 64, 90),     # exactly one panel of geometry 1
+        (100, 1100, 65, 90),
+        (100, 1100, 320, 400),
+        (100, 1100, 321, 400),
+        (100, 1100, 640, 700),
+        (100, 1100, 641, 700),   # two panels, second holds a single column
+        (0, 0, 150, 19000),      # very long subject window
+        (3000, 5000, 1500, 3),   # very short subject, multi-panel query
+    ], dtype=capi.EXT_DTYPE)
+    got = _check(handle, oracle, q, s, ext, "blosum62")
+    assert got[0] == got[1] == got[2] == 0
+    assert got[5] > 5000
+
+
+def test_ties_small_alphabet(handle, oracle):
+    # two-letter sequences: massive score ties and gap/diagonal ties; scores must still match exactly
+    rng = np.random.default_rng(21)
+    n = 600
+    q = rng.integers(0, 2, 64 * n).astype(np.uint8)
+    s = rng.integers(0, 2, 96 * n).astype(np.uint8)
+    ext = np.zeros(n, dtype=capi.EXT_DTYPE)
+    ext["q_off"] = np.arange(n) * 64
+    ext["q_len"] = rng.integers(1, 65, n)
+    ext["s_off"] = np.arange(n) * 96
+    ext["s_len"] = rng.integers(1, 97, n)
+    _check(handle, oracle, q, s, ext, "nucl")
+
+
+def test_device_resident_entry_point(handle, oracle):
+    import torch
+
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_batch_np(256, 150, 32, seed=5)
+    dev = torch.device("cuda:0")
+    d_q = torch.from_numpy(np.concatenate([q, np.zeros(256, np.uint8)])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, np.zeros(256, np.uint8)])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    d_out = torch.full((len(ext),), -7, dtype=torch.int32, device=dev)
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+    torch.cuda.synchronize()
+    for max_qlen, run in ((0, 0), (150, 0), (150, 32), (150, 8)):
+        handle.set_option(capi.LX_OPT_MAX_QLEN, max_qlen)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, run)
+        d_out.fill_(-7)
+        torch.cuda.synchronize()
+        handle.score_batch_dev(d_q, d_s, d_ext, len(ext), d_out)
+        handle.synchronize()
+        assert (d_out.cpu().numpy() == want).all(), (max_qlen, run)
+        assert handle.last_kernel_ms() > 0
+    # a violated LX_OPT_QUERY_RUN promise is reported, not silently mis-scored: 7 windows per query but "runs of 8"
+    q, s, ext = synth.make_batch_np(64, 150, 7, seed=6)
+    d_q = torch.from_numpy(np.concatenate([q, np.zeros(256, np.uint8)])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, np.zeros(256, np.uint8)])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    handle.set_option(capi.LX_OPT_MAX_QLEN, 150)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, 8)
+    handle.score_batch_dev(d_q, d_s, d_ext, len(ext), d_out)
+    with pytest.raises(capi.LambdaExtError):
+        handle.synchronize()
+    handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+    handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+
+
+def test_linearity_property_full_size_rows(handle):
+    # size-independent property at the headline geometry: scaling matrix and gap costs by 2 doubles every score
+    q, s, ext = synth.make_batch_np(2000, 150, 32, seed=77)
+    sc1 = capi.builtin_scoring(62, gap_open=-11, gap_extend=-1)
+    sc2 = capi.builtin_scoring(62, gap_open=-11, gap_extend=-1)
+    m = np.ctypeslib.as_array(sc2.matrix)
+    m *= 2
+    sc2.gap_open *= 2
+    sc2.gap_extend *= 2
+    handle.set_scoring(sc1, 0)
+    a = handle.score_batch(q, s, ext)
+    handle.set_scoring(sc2, 0)
+    b = handle.score_batch(q, s, ext)
+    assert (b == 2 * a).all()
+    # self-alignment of a query scores the sum of its diagonal entries
+    M = sc1.matrix_np()
+    handle.set_scoring(sc1, 0)
+    qq = q.reshape(2000, 150)
+    ext2 = np.zeros(2000, dtype=capi.EXT_DTYPE)
+    ext2["q_off"] = np.arange(2000) * 150
+    ext2["s_off"] = np.arange(2000) * 150
+    ext2["q_len"] = 150
+    ext2["s_len"] = 150
+    got = handle.score_batch(q, q, ext2)
+    assert (got == M[qq, qq].sum(axis=1)).all()
