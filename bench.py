@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the seed-extension hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2 headline"): searchp, BLOSUM62 11/1,
+100 000 synthetic 150-aa queries x 32 candidate windows of Lq + 2b = 176 residues = 3.2 M extensions =
+84.48 Gcells of full-rectangle (parity mode) DP per GPU.  A *step* is one pass of the hot path over that batch:
+pass 1 (score every window) [+ e-value filter + pass 2 traceback of the survivors once --with-trace is on].
+Inputs are resident in HBM before the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the path shards by query with no data-path collective -> weak scaling, every
+rank owns its own 100 k queries; the only collective is the final gather of per-rank result counts/top hits,
+which is outside the hot loop but inside the timed region's last step.
+
+Rank 0 prints ONE JSON line.  `value` = GCUPS = (sum over ranks of Lq*Ls cells of pass 1) * K / max-over-ranks
+seconds / 1e9.  The oracle is used ONLY for the cpu_baseline leg (rank 0, N = 1), never for `value`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+# integer-VALU roofline: 10 algorithmic integer ops per cell (4 add + 6 max, score-only
+# Gotoh) against 256 CU x 128 lanes x 2.4 GHz = 78.6 T int32 lane-ops/s.  See DESIGN.md "Roofline" for the
+# measured per-instruction issue rates (tools/ubench.hip) this peak is compared with.
+ALGO_OPS_PER_CELL = 10
+PEAK_INT32_TOPS = 256 * 128 * 2.4e9 / 1e12
+ALGO_BYTES_PER_EXT_EXTRA = 16 + 4  # extension record read + score written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU")
+    ap.add_argument("--lq", type=int, default=150)
+    ap.add_argument("--windows", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-queries", type=int, default=20_000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, cores: int):
+    """Times the oracle's inter-sequence int16 SIMD batch scorer (the shape of the reference's CPU path,
+    oracle/lx_oracle_simd.c) on a bounded sample of the same workload, on this box's host cores."""
+    from lambda_amd import capi, synth
+    from tests import oracle_lib
+
+    orc = oracle_lib.load()
+    nq = min(args.cpu_sample_queries, args.queries)
+    q, s, ext = synth.make_batch_np(nq, args.lq, args.windows, seed=0x1A3BDA02)
+    sc = oracle_lib.scoring_from(capi.builtin_scoring(62, gap_open=-11, gap_extend=-1))
+    cells = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        orc.score_batch(q, s, ext, sc, threads=cores, simd=True)
+        best = min(best, time.perf_counter() - t0)
+    return {
+        "value": round(cells / best / 1e9, 3),
+        "unit": "GCUPS",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{nq} queries x {args.windows} windows ({len(ext)} extensions, {cells / 1e9:.2f} Gcells), "
+                  f"oracle inter-sequence int16 SIMD restatement (NOT SeqAn), OpenMP, best of 2, {best:.3f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from lambda_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus) and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload, generated directly in HBM; every rank owns different queries (shard by query) ----
+    h = capi.Handle(local_rank)
+    h.set_scoring(capi.builtin_scoring(62, gap_open=-11, gap_extend=-1), 0)
+    h.set_option(capi.LX_OPT_MAX_QLEN, args.lq)
+    h.set_option(capi.LX_OPT_QUERY_RUN, args.windows if args.windows % 8 == 0 else 0)
+    d_q, d_s, d_ext, ext = synth.make_batch_torch(args.queries, args.lq, args.windows, 0x1A3BDA02 + rank, dev)
+    pad = torch.zeros(256, dtype=torch.uint8, device=dev)
+    d_q = torch.cat([d_q, pad])
+    d_s = torch.cat([d_s, pad])
+    n = len(ext)
+    cells_rank = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step():
+        h.score_batch_dev(d_q, d_s, d_ext, n, d_score, stream=stream.cuda_stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    h.synchronize()  # surfaces any device-side error flag before timing
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step()
+        ev[k][1].record(stream)
+    if world > 1:
+        # the path's only exchange: final gather of per-rank hit counts (top-hit gather)
+        cnt = (d_score > 0).sum().to(torch.int64).reshape(1)
+        gathered = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(gathered, cnt)
+    fence()
+    dt = time.perf_counter() - t0
+    h.synchronize()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    if rank == 0:
+        total_cells = cells_rank * world
+        gcups = total_cells * args.steps / dt / 1e9
+        kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9
+        achieved_tops = kern_gcups * ALGO_OPS_PER_CELL / 1e3
+        algo_bytes = float(ext["q_len"].sum()) / args.windows + float(ext["s_len"].sum()) + n * ALGO_BYTES_PER_EXT_EXTRA
+        out = {
+            "metric": "GCUPS (gapped extension, full-rectangle parity mode, pass 1) searchp BLOSUM62",
+            "value": round(gcups, 2),
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"searchp BLOSUM62 gap 11/1, {args.queries} x {args.lq} aa queries x {args.windows} "
+                            f"windows of {synth.window_len(args.lq)} aa per GPU (BASELINE.json configs[1]), "
+                            f"cells = sum Lq*Ls (full rectangle, band off as in the reference)",
+                "extensions_per_gpu": n,
+                "gcells_per_gpu": round(cells_rank / 1e9, 3),
+                "parallelism": f"query-sharded x{world}, no data-path collective",
+                "step": "pass 1 score kernel over the whole batch",
+            },
+            "alignments_per_s": round(n * world * args.steps / dt, 1),
+            "roofline": {
+                "bound": "valu",
+                "kernel": "lx::score_kernel<16,10,false>",
+                "achieved": round(achieved_tops, 3),
+                "peak": round(PEAK_INT32_TOPS, 2),
+                "unit": "Tops/s (int32 lane-ops; 10 algorithmic ops per cell)",
+                "frac": round(achieved_tops / PEAK_INT32_TOPS, 4),
+                "kernel_ms": round(kern_ms, 4),
+                "kernel_gcups": round(kern_gcups, 1),
+                "hbm_algorithmic_GBps": round(algo_bytes / (kern_ms * 1e-3) / 1e9, 2),
+                "hbm_peak_GBps": 8000,
+                "traffic": None,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(args, cores)
+        print(json.dumps(out), flush=True)
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,12 +104,20 @@ char const * lx_last_error(lx_handle const * h); /* h may be NULL: error of the 
  *                          that share one query slice (must be a multiple of 8; 0 = no promise).  Lets a wavefront
  *                          build one LDS profile instead of one per extension.  A violated promise is detected on
  *                          the device and reported as LX_ESTATE by lx_synchronize().
- *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB) */
+ *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB)
+ *   (LX_OPT_BS_MATCH_RULE is the one option that is not a tuning knob: it selects which of the reference's two
+ *   computeAlignmentStats overloads the pass-2 match counts follow.) */
 enum
 {
     LX_OPT_MAX_QLEN        = 1,
     LX_OPT_QUERY_RUN       = 2,
-    LX_OPT_WORKSPACE_BYTES = 3
+    LX_OPT_WORKSPACE_BYTES = 3,
+    LX_OPT_MAX_SLEN        = 4, /* longest subject slice the *_dev calls will see (0 = unknown: measured on the
+                                   device, which costs lx_align_batch_dev one stream synchronisation)          */
+    LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 4 GiB); larger batches are
+                                   processed in chunks, in order, on the same stream                            */
+    LX_OPT_BS_MATCH_RULE   = 6  /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
+                                   (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 
@@ -155,6 +163,77 @@ typedef struct lx_seed
 int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
                        uint64_t s_bytes, lx_seed const * seeds, uint64_t n, uint32_t seed_length,
                        int32_t pre_scoring, double pre_scoring_thresh, uint8_t * out_keep);
+
+
+/* ---- host mirror of the extension driver (one level above the two passes) ---------------------------- */
+/* Karlin-Altschul parameters of a scoring scheme (seqan::BlastScoringScheme; call sites src/search_misc.hpp:73-78,
+ * src/search_algo.hpp:1258).  Tables are NCBI's published values; returns LX_EINVAL for combinations that have
+ * none, which is what makes prepareScoring() throw (src/search_algo.hpp:232-233). */
+typedef struct lx_karlin
+{
+    double lambda, K, H, alpha, beta;
+} lx_karlin;
+int      lx_karlin_params(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend, lx_karlin * out);
+uint64_t lx_length_adjustment(uint64_t db_len, uint64_t q_len, lx_karlin const * ka);
+double   lx_evalue(int32_t score, uint64_t q_len_adj, uint64_t db_len_adj, lx_karlin const * ka);
+double   lx_bitscore(int32_t score, lx_karlin const * ka);
+
+/* _widenAndPreprocessMatches (src/search_algo.hpp:1136-1175), in place; qlens/slens are indexed by the
+ * frame-expanded qryId/subjId.  Returns the new match count. */
+uint64_t lx_widen_and_preprocess(lx_match * m, uint64_t n, uint64_t const * qlens, uint64_t const * slens);
+
+/* Options of iterateMatchesFullSimd that live in LambdaOptions / the BLAST context. */
+typedef struct lx_search_params
+{
+    double    max_evalue;       /* < 0: no e-value filter   (src/search_options.hpp:96-97)          */
+    int32_t   min_bitscore;     /* < 0: no bit-score filter                                           */
+    int32_t   id_cutoff;        /* percent identity cut-off (src/search_algo.hpp:1310-1315)           */
+    uint64_t  db_total_length;  /* context.dbTotalLength    (src/search_algo.hpp:317-319)             */
+    int32_t   query_translated; /* 1: ql /= 3 before the length adjustment (src/search_misc.hpp:70)   */
+    int32_t   qry_num_frames;   /* qryId / qry_num_frames = true query id (src/search_algo.hpp:1210)  */
+    int32_t   sbj_num_frames;
+    int32_t   reserved;
+    lx_karlin karlin;
+} lx_search_params;
+
+/* One finished HSP: the fields of TBlastMatch the writers read (src/search_datastructures.hpp:470-484). */
+typedef struct lx_blast_match
+{
+    uint64_t qry_id, subj_id;   /* frame-expanded ids of the lx_match this HSP came from */
+    uint64_t n_qid, n_sid;      /* true ids (_n_qId/_n_sId)                              */
+    uint64_t q_start, q_end;    /* in the (frame) query sequence, 0-based half-open      */
+    uint64_t s_start, s_end;    /* in the (frame) subject sequence                       */
+    int32_t  score;
+    int32_t  alignment_length;
+    int32_t  num_matches, num_mismatches, num_positives, num_gap_opens, num_gap_extensions;
+    float    identity;
+    double   bit_score, e_value;
+    uint64_t ops_off;           /* into the result's ops buffer */
+    uint32_t n_ops, reserved;
+} lx_blast_match;
+
+typedef struct lx_iterate_stats
+{
+    uint64_t hits_duplicate, failed_bitscore, failed_evalue, failed_identity, num_ext_score, num_ext_ali;
+} lx_iterate_stats;
+
+typedef struct lx_iterate_result lx_iterate_result;
+
+/* iterateMatchesFullSimd (src/search_algo.hpp:1177-1332) for one strand direction: widen/merge the seed hits,
+ * score every window on the GPU, filter by bit score / e-value, trace the survivors on the GPU, expand to
+ * sequence coordinates, apply the identity cut-off.  q_seq_off/q_seq_len (s_*) give, per frame-expanded sequence
+ * id, where that sequence lives in q_res (s_res).  q_orig_len[n_qid] is the untranslated query length used for
+ * the e-value (bm.qLength, src/search_algo.hpp:1213).  `matches` is modified in place (like the reference's span). */
+int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
+                       uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,
+                       uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
+                       uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                       lx_iterate_result ** out);
+uint64_t               lx_iterate_result_count(lx_iterate_result const * r);
+lx_blast_match const * lx_iterate_result_matches(lx_iterate_result const * r);
+uint8_t const *        lx_iterate_result_ops(lx_iterate_result const * r);
+lx_iterate_stats       lx_iterate_result_stats(lx_iterate_result const * r);
+void                   lx_iterate_result_free(lx_iterate_result * r);
 
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Blocks until everything queued on the handle's stream has finished. */

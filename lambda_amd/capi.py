@@ -24,9 +24,38 @@ EXPORTED_SYMBOLS = [
     "lx_abi_version", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_iterate_matches",
+    "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess",
 ]
+
+LX_OPT_MAX_SLEN = 4
+LX_OPT_TRACE_BYTES = 5
+LX_OPT_BS_MATCH_RULE = 6
+
+
+class Karlin(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("K", C.c_double), ("H", C.c_double), ("alpha", C.c_double),
+                ("beta", C.c_double)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("max_evalue", C.c_double), ("min_bitscore", C.c_int32), ("id_cutoff", C.c_int32),
+                ("db_total_length", C.c_uint64), ("query_translated", C.c_int32), ("qry_num_frames", C.c_int32),
+                ("sbj_num_frames", C.c_int32), ("reserved", C.c_int32), ("karlin", Karlin)]
+
+
+class IterateStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity",
+                                          "num_ext_score", "num_ext_ali")]
+
+
+BLAST_MATCH_DTYPE = np.dtype([
+    ("qry_id", "<u8"), ("subj_id", "<u8"), ("n_qid", "<u8"), ("n_sid", "<u8"), ("q_start", "<u8"), ("q_end", "<u8"),
+    ("s_start", "<u8"), ("s_end", "<u8"), ("score", "<i4"), ("alignment_length", "<i4"), ("num_matches", "<i4"),
+    ("num_mismatches", "<i4"), ("num_positives", "<i4"), ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"),
+    ("identity", "<f4"), ("bit_score", "<f8"), ("e_value", "<f8"), ("ops_off", "<u8"), ("n_ops", "<u4"),
+    ("reserved", "<u4")])
 
 
 class Scoring(C.Structure):
@@ -62,6 +91,13 @@ def load():
         return _lib
     if not LIB_PATH.exists():
         raise FileNotFoundError(f"{LIB_PATH} not built -- run `python -m lambda_amd.build` (needs hipcc)")
+    # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one process do not work
+    # (the second one sees no GPU), so if torch is going to be used in this process it must be loaded first; our
+    # library then binds to the runtime that is already resident (same SONAME).  A C++ host links /opt/rocm's.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is plumbing for tests/bench only, never a requirement of the C ABI
+        pass
     lib = C.CDLL(str(LIB_PATH))
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     lib.lx_abi_version.restype = i32
@@ -83,8 +119,45 @@ def load():
                        ("lx_prefilter_batch", [vp, i32, vp, u64, vp, u64, vp, u64, C.c_uint32, C.c_int32, C.c_double, vp])):
         if hasattr(lib, name):
             getattr(lib, name).argtypes = args
+    lib.lx_karlin_params.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Karlin)]
+    lib.lx_length_adjustment.argtypes = [u64, u64, C.POINTER(Karlin)]
+    lib.lx_length_adjustment.restype = u64
+    lib.lx_evalue.argtypes = [C.c_int32, u64, u64, C.POINTER(Karlin)]
+    lib.lx_evalue.restype = C.c_double
+    lib.lx_bitscore.argtypes = [C.c_int32, C.POINTER(Karlin)]
+    lib.lx_bitscore.restype = C.c_double
+    lib.lx_widen_and_preprocess.argtypes = [vp, u64, vp, vp]
+    lib.lx_widen_and_preprocess.restype = u64
+    lib.lx_iterate_matches.argtypes = [vp, i32, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, u64, vp, u64,
+                                       C.POINTER(SearchParams), C.POINTER(vp)]
+    lib.lx_iterate_result_count.argtypes = [vp]
+    lib.lx_iterate_result_count.restype = u64
+    lib.lx_iterate_result_matches.argtypes = [vp]
+    lib.lx_iterate_result_matches.restype = vp
+    lib.lx_iterate_result_ops.argtypes = [vp]
+    lib.lx_iterate_result_ops.restype = vp
+    lib.lx_iterate_result_stats.argtypes = [vp]
+    lib.lx_iterate_result_stats.restype = IterateStats
+    lib.lx_iterate_result_free.argtypes = [vp]
+    lib.lx_iterate_result_free.restype = None
     _lib = lib
     return lib
+
+
+def karlin_params(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Karlin:
+    ka = Karlin()
+    rc = load().lx_karlin_params(method, match, mismatch, gap_open, gap_extend, C.byref(ka))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "no Karlin-Altschul values for this scoring scheme")
+    return ka
+
+
+def widen_and_preprocess(matches: np.ndarray, qlens: np.ndarray, slens: np.ndarray) -> np.ndarray:
+    m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE).copy()
+    qlens = np.ascontiguousarray(qlens, dtype=np.uint64)
+    slens = np.ascontiguousarray(slens, dtype=np.uint64)
+    n = load().lx_widen_and_preprocess(_ptr(m), len(m), _ptr(qlens), _ptr(slens))
+    return m[: int(n)]
 
 
 def builtin_scoring(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Scoring:
@@ -176,6 +249,36 @@ class Handle:
     def align_batch_dev(self, d_q, d_s, d_ext, n: int, d_hsp, d_ops, d_ops_off, stream=None, slot: int = 0):
         self._check(self.lib.lx_align_batch_dev(self.h, slot, d_q.data_ptr(), d_s.data_ptr(), d_ext.data_ptr(), n,
                                                 d_hsp.data_ptr(), d_ops.data_ptr(), d_ops_off.data_ptr(), stream))
+
+    def iterate_matches(self, q_res, q_off, q_len, q_orig_len, s_res, s_off, s_len, matches, params: "SearchParams",
+                        slot: int = 0):
+        """iterateMatchesFullSimd: returns (blast_matches ndarray, list of ops bytes, IterateStats)."""
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint64)
+        s_off = np.ascontiguousarray(s_off, dtype=np.uint64)
+        s_len = np.ascontiguousarray(s_len, dtype=np.uint64)
+        q_orig = np.ascontiguousarray(q_orig_len, dtype=np.uint64)
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE).copy()
+        res = C.c_void_p()
+        self._check(self.lib.lx_iterate_matches(self.h, slot, _ptr(q_res), q_res.size, _ptr(q_off), _ptr(q_len), len(q_off),
+                                                _ptr(q_orig), _ptr(s_res), s_res.size, _ptr(s_off), _ptr(s_len),
+                                                len(s_off), _ptr(m), len(m), C.byref(params), C.byref(res)))
+        try:
+            n = int(self.lib.lx_iterate_result_count(res))
+            stats = self.lib.lx_iterate_result_stats(res)
+            if n == 0:
+                return np.zeros(0, dtype=BLAST_MATCH_DTYPE), [], stats
+            buf = (C.c_char * (n * BLAST_MATCH_DTYPE.itemsize)).from_address(self.lib.lx_iterate_result_matches(res))
+            bms = np.frombuffer(buf, dtype=BLAST_MATCH_DTYPE).copy()
+            total = int(bms["ops_off"][-1]) + int(bms["n_ops"][-1])
+            obuf = (C.c_char * max(total, 1)).from_address(self.lib.lx_iterate_result_ops(res))
+            allops = bytes(obuf)
+            ops = [allops[int(b["ops_off"]):int(b["ops_off"]) + int(b["n_ops"])] for b in bms]
+            return bms, ops, stats
+        finally:
+            self.lib.lx_iterate_result_free(res)
 
     def synchronize(self):
         self._check(self.lib.lx_synchronize(self.h))

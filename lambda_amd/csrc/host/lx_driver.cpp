@@ -1,0 +1,303 @@
+// lx_driver.cpp -- C++ host mirror of the reference's extension driver, exported through the C ABI.
+//
+// Restates, above the two GPU passes, what /root/reference/src/search_algo.hpp does around them:
+//   _widenMatch                  :919-938     (lambda_amd::widenMatch)
+//   _widenAndPreprocessMatches   :1136-1175   (lambda_amd::widenAndPreprocessMatches)
+//   iterateMatchesFullSimd       :1177-1332   (lambda_amd::iterateMatchesFullSimd -> lx_iterate_matches)
+//   _expandAlign (coordinates)   :1032-1035
+// The DP itself never runs here: both passes go to the GPU through lx_score_batch / lx_align_batch.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <tuple>
+#include <vector>
+
+#include "blast_stats.hpp"
+#include "lambda_ext.hpp"
+#include "scoring_tables.hpp"
+
+namespace lambda_amd
+{
+
+// src/search_misc.hpp:46-50
+inline int64_t bandSize(uint64_t const seqLength)
+{
+    return static_cast<int64_t>(std::sqrt(seqLength)) + 1;
+}
+
+// src/search_algo.hpp:919-938
+inline void widenMatch(lx_match & m, uint64_t const qLen, uint64_t const sLen)
+{
+    m.subjStart         = (m.subjStart < m.qryStart) ? 0 : m.subjStart - m.qryStart;
+    m.qryStart          = 0;
+    m.qryEnd            = qLen;
+    uint64_t const band = bandSize(qLen);
+    m.subjEnd           = std::min<uint64_t>(m.subjStart + qLen + band, sLen);
+    m.subjStart         = (band < m.subjStart) ? m.subjStart - band : 0;
+}
+
+inline auto tie(lx_match const & m)
+{
+    return std::tie(m.qryId, m.subjId, m.qryStart, m.qryEnd, m.subjStart, m.subjEnd);
+}
+
+// src/search_algo.hpp:1136-1175; returns the new size, *duplicates gets the number removed (hitsDuplicate)
+inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t const * qLens, uint64_t const * sLens,
+                                          uint64_t * duplicates)
+{
+    uint64_t const before = n;
+    for (uint64_t i = 0; i < n; ++i)
+        widenMatch(m[i], qLens[m[i].qryId], sLens[m[i].subjId]);
+    std::sort(m, m + n, [](lx_match const & a, lx_match const & b) { return tie(a) < tie(b); });
+    if (n > 1)
+    {
+        for (uint64_t i = 0; i + 1 < n; ++i)
+        {
+            lx_match & l = m[i];
+            lx_match & r = m[i + 1];
+            if (l.qryId == r.qryId && l.subjId == r.subjId && l.subjEnd >= r.subjStart)
+            {
+                l.subjEnd   = r.subjEnd;
+                r.subjStart = l.subjStart;
+            }
+        }
+        for (uint64_t i = n - 1; i >= 1; --i)
+        {
+            lx_match & r = m[i];
+            lx_match & l = m[i - 1];
+            if (r.qryId == l.qryId && r.subjId == l.subjId && r.subjStart < l.subjEnd)
+                l = r;
+        }
+        n = std::unique(m, m + n, [](lx_match const & a, lx_match const & b) { return tie(a) == tie(b); }) - m;
+    }
+    if (duplicates)
+        *duplicates += before - n;
+    return n;
+}
+
+} // namespace lambda_amd
+
+struct lx_iterate_result
+{
+    std::vector<lx_blast_match> matches;
+    std::vector<uint8_t>        ops;
+    lx_iterate_stats            stats{};
+};
+
+extern "C" {
+
+int lx_karlin_params(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend, lx_karlin * out)
+{
+    if (!out)
+        return LX_EINVAL;
+    return lambda_amd::karlinParams(scoring_method, match, mismatch, gap_open_lambda, gap_extend, *out) ? LX_OK : LX_EINVAL;
+}
+
+uint64_t lx_length_adjustment(uint64_t db_len, uint64_t q_len, lx_karlin const * ka)
+{
+    return lambda_amd::lengthAdjustment(db_len, q_len, *ka);
+}
+
+double lx_evalue(int32_t score, uint64_t q_len_adj, uint64_t db_len_adj, lx_karlin const * ka)
+{
+    return lambda_amd::computeEValue(score, q_len_adj, db_len_adj, *ka);
+}
+
+double lx_bitscore(int32_t score, lx_karlin const * ka)
+{
+    return lambda_amd::computeBitScore(score, *ka);
+}
+
+uint64_t lx_widen_and_preprocess(lx_match * m, uint64_t n, uint64_t const * qlens, uint64_t const * slens)
+{
+    return lambda_amd::widenAndPreprocessMatches(m, n, qlens, slens, nullptr);
+}
+
+// iterateMatchesFullSimd, src/search_algo.hpp:1177-1332
+int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
+                       uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,
+                       uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
+                       uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                       lx_iterate_result ** out)
+{
+    using namespace lambda_amd;
+    if (!h || !out || !params || (!matches && n_matches))
+        return LX_EINVAL;
+    *out = nullptr;
+    for (uint64_t i = 0; i < n_matches; ++i)
+        if (matches[i].qryId >= n_qseq || matches[i].subjId >= n_sseq)
+            return LX_EINVAL;
+    int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
+
+    auto res = new lx_iterate_result();
+    res->stats.num_ext_score = n_matches; // lH.stats.numExtScore (:1187)
+
+    // pre-sort and filter (:1198)
+    uint64_t const n = widenAndPreprocessMatches(matches, n_matches, q_seq_len, s_seq_len, &res->stats.hits_duplicate);
+
+    // create blast matches from Lambda matches (:1200-1227); the window is the DP's (query slice, subject slice)
+    std::vector<lx_extension> ext(n);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_match const & m = matches[i];
+        ext[i].q_off       = q_seq_off[m.qryId] + m.qryStart;
+        ext[i].q_len       = (uint32_t)(m.qryEnd - m.qryStart);
+        ext[i].s_off       = s_seq_off[m.subjId] + m.subjStart;
+        ext[i].s_len       = (uint32_t)(m.subjEnd - m.subjStart);
+    }
+    // sort by lengths to minimize padding (:1229-1235); std::list::sort is stable
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t b)
+                     { return std::make_tuple(ext[a].q_len, ext[a].s_len) < std::make_tuple(ext[b].q_len, ext[b].s_len); });
+    std::vector<lx_extension> sortedExt(n);
+    for (uint64_t k = 0; k < n; ++k)
+        sortedExt[k] = ext[order[k]];
+
+    // Run extensions WITHOUT ALIGNMENT (:1246)
+    std::vector<int32_t> scores(n, 0);
+    int rc = lx_score_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sortedExt.data(), n, scores.data());
+    if (rc != LX_OK)
+    {
+        delete res;
+        return rc;
+    }
+
+    // compute evalues and filter based on evalue (:1251-1283)
+    EValueContext evalue{params->karlin, params->db_total_length, params->query_translated != 0, {}};
+    struct Survivor
+    {
+        uint32_t idx; // index into `matches`
+        int32_t  score;
+        double   bitScore, eValue;
+    };
+    std::vector<Survivor> surv;
+    surv.reserve(n);
+    for (uint64_t k = 0; k < n; ++k)
+    {
+        Survivor        s{order[k], scores[k], 0.0, 0.0};
+        uint64_t const  nq      = matches[s.idx].qryId / qFrames;
+        uint64_t const  qLength = q_orig_len ? q_orig_len[nq] : q_seq_len[matches[s.idx].qryId];
+        if (params->min_bitscore >= 0)
+        {
+            s.bitScore = computeBitScore(s.score, params->karlin);
+            if (s.bitScore < params->min_bitscore)
+            {
+                ++res->stats.failed_bitscore;
+                continue;
+            }
+        }
+        if (params->max_evalue >= 0)
+        {
+            s.eValue = evalue(s.score, qLength);
+            if (s.eValue > params->max_evalue)
+            {
+                ++res->stats.failed_evalue;
+                continue;
+            }
+        }
+        surv.push_back(s);
+    }
+    if (surv.empty())
+    {
+        *out = res;
+        return LX_OK;
+    }
+    res->stats.num_ext_ali = surv.size(); // :1287
+
+    // Run extensions WITH ALIGNMENT (:1293-1296)
+    std::vector<lx_extension> sExt(surv.size());
+    for (size_t k = 0; k < surv.size(); ++k)
+        sExt[k] = ext[surv[k].idx];
+    std::vector<lx_hsp>   hsp(surv.size());
+    std::vector<uint64_t> opsOff(surv.size());
+    uint64_t              total = 0;
+    for (size_t k = 0; k < surv.size(); ++k)
+    {
+        opsOff[k] = total;
+        total += (uint64_t)sExt[k].q_len + sExt[k].s_len;
+    }
+    std::vector<uint8_t> ops(total + 1, 0);
+    rc = lx_align_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sExt.data(), sExt.size(), hsp.data(), ops.data(), opsOff.data());
+    if (rc != LX_OK)
+    {
+        delete res;
+        return rc;
+    }
+
+    // sort by query (:1299), stable
+    std::vector<uint32_t> sOrder(surv.size());
+    std::iota(sOrder.begin(), sOrder.end(), 0u);
+    std::stable_sort(sOrder.begin(), sOrder.end(),
+                     [&](uint32_t a, uint32_t b)
+                     { return matches[surv[a].idx].qryId / qFrames < matches[surv[b].idx].qryId / qFrames; });
+
+    // compute the rest of the match properties (:1302-1325)
+    for (uint32_t k : sOrder)
+    {
+        Survivor &       s = surv[k];
+        lx_match const & m = matches[s.idx];
+        lx_hsp const &   a = hsp[k];
+        lx_blast_match   bm{};
+        bm.qry_id  = m.qryId;
+        bm.subj_id = m.subjId;
+        bm.n_qid   = m.qryId / qFrames;
+        bm.n_sid   = m.subjId / sFrames;
+        // _expandAlign: positions relative to the infix become positions in the sequence (:1032-1035)
+        bm.q_start = m.qryStart + a.q_begin;
+        bm.q_end   = m.qryStart + a.q_end;
+        bm.s_start = m.subjStart + a.s_begin;
+        bm.s_end   = m.subjStart + a.s_end;
+        bm.score   = a.score;
+        bm.alignment_length   = a.n_ops;
+        bm.num_matches        = a.num_matches;
+        bm.num_mismatches     = a.num_mismatches;
+        bm.num_positives      = a.num_positives;
+        bm.num_gap_opens      = a.num_gap_opens;
+        bm.num_gap_extensions = a.num_gap_extensions;
+        bm.identity = a.n_ops ? (float)(100.0 * static_cast<float>(a.num_matches) / static_cast<float>(a.n_ops)) : 0.0f;
+        if (bm.identity < params->id_cutoff) // :1310-1315
+        {
+            ++res->stats.failed_identity;
+            continue;
+        }
+        uint64_t const qLength = q_orig_len ? q_orig_len[bm.n_qid] : q_seq_len[m.qryId];
+        bm.bit_score = (params->min_bitscore < 0) ? computeBitScore(a.score, params->karlin) : s.bitScore; // :1318-1319
+        bm.e_value   = (params->max_evalue < 0) ? evalue(a.score, qLength) : s.eValue;                        // :1321-1322
+        bm.ops_off   = res->ops.size();
+        bm.n_ops     = (uint32_t)a.n_ops;
+        res->ops.insert(res->ops.end(), ops.begin() + opsOff[k], ops.begin() + opsOff[k] + a.n_ops);
+        res->matches.push_back(bm);
+    }
+    *out = res;
+    return LX_OK;
+}
+
+uint64_t lx_iterate_result_count(lx_iterate_result const * r)
+{
+    return r ? r->matches.size() : 0;
+}
+
+lx_blast_match const * lx_iterate_result_matches(lx_iterate_result const * r)
+{
+    return r ? r->matches.data() : nullptr;
+}
+
+uint8_t const * lx_iterate_result_ops(lx_iterate_result const * r)
+{
+    return r ? r->ops.data() : nullptr;
+}
+
+lx_iterate_stats lx_iterate_result_stats(lx_iterate_result const * r)
+{
+    return r ? r->stats : lx_iterate_stats{};
+}
+
+void lx_iterate_result_free(lx_iterate_result * r)
+{
+    delete r;
+}
+
+} // extern "C"

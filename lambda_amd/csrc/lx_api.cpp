@@ -23,6 +23,11 @@ namespace lx
 hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t stream);
 int        score_cfg_panel(int cfg);
 int        score_cfg_groups(int cfg);
+hipError_t launch_trace(TraceParams const & p, hipStream_t stream);
+hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
+int        trace_panel();
+int        trace_group();
+hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
 static_assert(sizeof(lx_extension) == sizeof(lx::Extension), "ABI mismatch");
@@ -55,7 +60,7 @@ struct lx_handle
     lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
 
     // staging for the host-buffer entry points
-    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace;
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds;
     // multi-panel carry workspace
     DevBuf     d_ws;
     uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
@@ -63,6 +68,9 @@ struct lx_handle
     uint64_t opt_max_qlen  = 0;
     uint64_t opt_query_run = 0;
     uint64_t opt_ws_bytes  = 64ull << 20;
+    uint64_t opt_max_slen  = 0;
+    uint64_t opt_trace_bytes = 4ull << 30;
+    uint64_t opt_bs_rule   = 0;
 };
 
 namespace
@@ -137,6 +145,8 @@ int check_async_error(lx_handle * h)
         return fail(h, LX_EOVERFLOW, "multi-panel carry workspace exhausted (raise LX_OPT_WORKSPACE_BYTES)");
     if (flags[1] == 2)
         return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
+    if (flags[1] == 3)
+        return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or s_len > 65535)");
     if (flags[1] != 0)
         return fail(h, LX_EHIP, "device reported error flag %u", flags[1]);
     return LX_OK;
@@ -242,7 +252,8 @@ void lx_destroy(lx_handle * h)
         (void)hipSetDevice(h->device);
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
-    for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ws})
+    for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ends,
+                       &h->d_hsp, &h->d_seeds, &h->d_ws})
         if (b->ptr)
             (void)hipFree(b->ptr);
     for (int s = 0; s < 2; ++s)
@@ -273,6 +284,9 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_MAX_QLEN: h->opt_max_qlen = value; return LX_OK;
         case LX_OPT_QUERY_RUN: h->opt_query_run = value; return LX_OK;
         case LX_OPT_WORKSPACE_BYTES: h->opt_ws_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
+        case LX_OPT_MAX_SLEN: h->opt_max_slen = value; return LX_OK;
+        case LX_OPT_TRACE_BYTES: h->opt_trace_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
+        case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
         default: return fail(h, LX_EINVAL, "unknown option %d", option);
     }
 }
@@ -531,6 +545,211 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     for (size_t k = 0; k < res.size(); ++k)
         if (perm[k] != 0xffffffffu)
             out_score[perm[k]] = res[k];
+    return LX_OK;
+}
+
+
+// ---- pass 2 ------------------------------------------------------------------------------------------
+
+static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
+                          uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
+                          uint64_t max_q, uint64_t max_s)
+{
+    int const G = lx::trace_group(), P = lx::trace_panel();
+    if (max_s > 65535)
+        return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
+    int maxent = 0;
+    for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
+        for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
+            maxent = std::max<int>(maxent, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+    if ((uint64_t)maxent * std::min(max_q, max_s) >= 65536)
+        return fail(h, LX_EINVAL, "pass 2 packs scores in 16 bits: max entry %d x min(%llu,%llu) residues overflows", maxent,
+                    (unsigned long long)max_q, (unsigned long long)max_s);
+    uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
+    uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 3) & ~3ull);
+    uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G; // uint2 entries
+    uint64_t const per_ext    = stride * 8;
+    uint64_t       chunk      = std::max<uint64_t>(1, h->opt_trace_bytes / std::max<uint64_t>(per_ext, 1));
+    chunk                     = std::min<uint64_t>(chunk, n);
+    chunk                     = std::max<uint64_t>(4, chunk / 4 * 4);
+    int rc;
+    if ((rc = ensure(h, h->d_trace, chunk * per_ext)) || (rc = ensure(h, h->d_ends, chunk * sizeof(lx::EndCell))))
+        return rc;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk)
+    {
+        lx::TraceParams p{};
+        p.q_res         = static_cast<uint8_t const *>(d_q);
+        p.s_res         = static_cast<uint8_t const *>(d_s);
+        p.ext           = d_ext + c0;
+        p.n             = std::min<uint64_t>(chunk, n - c0);
+        p.sc            = h->sc_dev[slot];
+        p.trace         = static_cast<uint2 *>(h->d_trace.ptr);
+        p.slot_stride   = stride;
+        p.steps_cap     = steps_cap;
+        p.panels_cap    = panels_cap;
+        p.ends          = static_cast<lx::EndCell *>(h->d_ends.ptr);
+        p.out_hsp       = d_hsp + c0;
+        p.out_ops       = d_ops;
+        p.ops_off       = d_ops_off + c0;
+        p.ws            = static_cast<int32_t *>(h->d_ws.ptr);
+        p.ws_top        = h->d_ws_top;
+        p.ws_cap        = (uint32_t)std::min<uint64_t>(h->d_ws.cap / 8, 0xffffffffu);
+        p.err           = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+        p.nrows         = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+        p.bs_match_rule = (int32_t)h->opt_bs_rule;
+        if (panels_cap > 1) // each chunk starts with an empty carry workspace
+            LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
+        LX_HIP(h, lx::launch_trace(p, stream));
+    }
+    return LX_OK;
+}
+
+int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
+                       uint64_t n, void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * stream_)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!d_q_res || !d_s_res || !d_ext || !d_out_hsp || !d_out_ops || !d_ops_off)
+        return fail(h, LX_EINVAL, "NULL device pointer");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
+    if ((rc = prepare_workspace(h, stream)))
+        return rc;
+    uint64_t max_q = h->opt_max_qlen, max_s = h->opt_max_slen;
+    if (max_q == 0 || max_s == 0)
+    {
+        // no hints: measure on the device (one small kernel + a stream synchronisation)
+        lx::MaxLens * d_ml = reinterpret_cast<lx::MaxLens *>(h->d_ws_top + 2);
+        LX_HIP(h, lx::launch_max_lens(static_cast<lx::Extension const *>(d_ext), n, d_ml, stream));
+        lx::MaxLens ml{};
+        LX_HIP(h, hipMemcpyAsync(&ml, d_ml, sizeof(ml), hipMemcpyDeviceToHost, stream));
+        LX_HIP(h, hipStreamSynchronize(stream));
+        max_q = std::max<uint64_t>(ml.max_q, 1);
+        max_s = std::max<uint64_t>(ml.max_s, 1);
+    }
+    LX_HIP(h, hipEventRecord(h->ev0, stream));
+    rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(d_ext), n,
+                        static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
+                        static_cast<uint64_t const *>(d_ops_off), stream, max_q, max_s);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipEventRecord(h->ev1, stream));
+    h->timed = true;
+    return LX_OK;
+}
+
+int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, lx_hsp * out_hsp, uint8_t * out_ops,
+                   uint64_t const * ops_off)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_hsp || !out_ops || !ops_off || (!q_res && q_bytes) || (!s_res && s_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    uint64_t max_q = 1, max_s = 1, ops_bytes = 0, carry_pairs = 0;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_extension const & x = ext[i];
+        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
+        max_q     = std::max<uint64_t>(max_q, x.q_len);
+        max_s     = std::max<uint64_t>(max_s, x.s_len);
+        ops_bytes = std::max<uint64_t>(ops_bytes, ops_off[i] + x.q_len + x.s_len);
+        if ((int)x.q_len > lx::trace_panel())
+            carry_pairs += x.s_len;
+    }
+    if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
+        h->opt_ws_bytes = carry_pairs * 8 + 4096;
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
+        (rc = ensure(h, h->d_ext, n * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
+        (rc = ensure(h, h->d_ops, ops_bytes + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
+        return rc;
+    if ((rc = prepare_workspace(h, h->stream)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (s_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, ext, n * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, ops_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
+                        static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
+                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    LX_HIP(h, hipMemcpyAsync(out_hsp, h->d_hsp.ptr, n * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_ops, h->d_ops.ptr, ops_bytes, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = check_async_error(h)))
+        return rc;
+    for (uint64_t i = 0; i < n; ++i)
+        if (out_hsp[i].score < 0)
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced (workspace exhausted)", (unsigned long long)i);
+    return LX_OK;
+}
+
+// ---- pre-extension filter --------------------------------------------------------------------------------
+
+int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                       uint64_t s_bytes, lx_seed const * seeds, uint64_t n, uint32_t seed_length, int32_t pre_scoring,
+                       double pre_scoring_thresh, uint8_t * out_keep)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!seeds || !out_keep || !q_res || !s_res)
+        return fail(h, LX_EINVAL, "NULL argument");
+    static_assert(sizeof(lx_seed) == sizeof(lx::PrefilterSeed), "ABI mismatch");
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_seed const & x = seeds[i];
+        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes || x.qry_end < x.qry_start || x.qry_end > x.q_len ||
+            (uint64_t)x.subj_start + (x.qry_end - x.qry_start) > x.s_len)
+            return fail(h, LX_EINVAL, "seed %llu out of range", (unsigned long long)i);
+    }
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
+        (rc = ensure(h, h->d_seeds, n * sizeof(lx_seed))) || (rc = ensure(h, h->d_keep, n)))
+        return rc;
+    LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_seeds.ptr, seeds, n * sizeof(lx_seed), hipMemcpyHostToDevice, h->stream));
+    lx::PrefilterParams p{};
+    p.q_res              = static_cast<uint8_t const *>(h->d_q.ptr);
+    p.s_res              = static_cast<uint8_t const *>(h->d_s.ptr);
+    p.seeds              = static_cast<lx::PrefilterSeed const *>(h->d_seeds.ptr);
+    p.n                  = n;
+    p.sc                 = h->sc_dev[slot];
+    p.seed_length        = seed_length;
+    p.pre_scoring        = pre_scoring;
+    p.pre_scoring_thresh = pre_scoring_thresh;
+    p.out_keep           = static_cast<uint8_t *>(h->d_keep.ptr);
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    LX_HIP(h, lx::launch_prefilter(p, h->stream));
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    LX_HIP(h, hipMemcpyAsync(out_keep, h->d_keep.ptr, n, hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
     return LX_OK;
 }
 

@@ -58,4 +58,61 @@ struct ScoreParams
     int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
 };
 
+// best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel
+struct EndCell
+{
+    int32_t score;
+    int32_t q_end; // 1-based column of the best cell == half-open end
+    int32_t s_end;
+    int32_t pad;
+};
+
+struct TraceParams
+{
+    uint8_t const *    q_res;
+    uint8_t const *    s_res;
+    Extension const *  ext;   // this chunk's extensions
+    uint64_t           n;     // extensions in this chunk
+    ScoringDev const * sc;
+    uint2 *            trace;       // [n][panels_cap][steps_cap][G] direction words (4 bits per cell)
+    uint64_t           slot_stride; // uint2 entries per extension = panels_cap * steps_cap * G
+    uint32_t           steps_cap;   // bound on (Ls + G - 1) rounded up to 4
+    uint32_t           panels_cap;  // bound on ceil(Lq / panel)
+    EndCell *          ends;        // [n]
+    Hsp *              out_hsp;     // [n]
+    uint8_t *          out_ops;
+    uint64_t const *   ops_off;     // [n] byte offset of each extension's ops slot (slot size q_len + s_len)
+    int32_t *          ws;
+    uint32_t *         ws_top;
+    uint32_t           ws_cap;
+    int32_t *          err;
+    int32_t            nrows;
+    int32_t            bs_match_rule; // computeAlignmentStats variant: 1 = match iff score(c0,c1)==score(c0,c0)
+};
+
+struct MaxLens
+{
+    uint32_t max_q, max_s;
+};
+
+struct PrefilterSeed
+{
+    uint64_t q_off, s_off;
+    uint32_t q_len, s_len;
+    uint32_t qry_start, qry_end, subj_start, reserved;
+};
+
+struct PrefilterParams
+{
+    uint8_t const *       q_res;
+    uint8_t const *       s_res;
+    PrefilterSeed const * seeds;
+    uint64_t              n;
+    ScoringDev const *    sc;
+    uint32_t              seed_length;
+    int32_t               pre_scoring;
+    double                pre_scoring_thresh;
+    uint8_t *             out_keep;
+};
+
 } // namespace lx

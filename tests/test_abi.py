@@ -1,0 +1,84 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU, exports every symbol include/lambda_ext.h
+declares, refuses to create a handle without a device (no CPU fallback), and its host-side mirrors of the
+reference's helpers agree with the oracle."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from lambda_amd import capi
+from tests import oracle_lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    txt = (ROOT / "include" / "lambda_ext.h").read_text()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lx_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(lx_lib):
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    missing = [s for s in decl if not hasattr(lx_lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTED_SYMBOLS) == decl
+    assert lx_lib.lx_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(capi.Scoring) == 16 + 1024
+    assert capi.EXT_DTYPE.itemsize == 24 and capi.HSP_DTYPE.itemsize == 48
+    assert capi.MATCH_DTYPE.itemsize == 48 and capi.SEED_DTYPE.itemsize == 40
+    assert C.sizeof(capi.SearchParams) == 80 and capi.BLAST_MATCH_DTYPE.itemsize == 128
+
+
+def test_no_device_means_loud_failure(lx_lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert lx_lib.lx_device_count() == 0
+    with pytest.raises(capi.LambdaExtError) as ei:
+        capi.Handle(0)
+    assert "no CPU fallback" in str(ei.value) or "HIP" in str(ei.value)
+
+
+def test_widen_and_preprocess_matches_oracle(oracle):
+    rng = np.random.default_rng(42)
+    nq, ns = 30, 40
+    qlens = rng.integers(20, 400, nq).astype(np.uint64)
+    slens = rng.integers(50, 3000, ns).astype(np.uint64)
+    n = 3000
+    m = np.zeros(n, dtype=capi.MATCH_DTYPE)
+    m["qryId"] = rng.integers(0, nq, n)
+    m["subjId"] = rng.integers(0, 6, n)  # few subjects -> many overlapping windows
+    seedlen = rng.integers(8, 15, n)
+    m["qryStart"] = (rng.random(n) * np.maximum(qlens[m["qryId"]].astype(np.int64) - seedlen, 1)).astype(np.uint64)
+    m["qryEnd"] = np.minimum(m["qryStart"] + seedlen.astype(np.uint64), qlens[m["qryId"]])
+    m["subjStart"] = (rng.random(n) * np.maximum(slens[m["subjId"]].astype(np.int64) - seedlen, 1)).astype(np.uint64)
+    m["subjEnd"] = np.minimum(m["subjStart"] + seedlen.astype(np.uint64), slens[m["subjId"]])
+    want = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlens, slens)
+    got = capi.widen_and_preprocess(m, qlens, slens)
+    assert len(got) == len(want) and len(got) < n
+    assert (got.view(np.uint64) == want.view(np.uint64)).all()
+
+
+def test_blast_statistics_match_oracle(oracle):
+    for args, (lam, K) in (((62, 2, -3, -11, -1), (0.267, 0.041)), ((0, 2, -3, -5, -2), (0.625, 0.41))):
+        ka = capi.karlin_params(*args)
+        assert (ka.lambda_, ka.K) == (lam, K)
+        oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
+        lib = capi.load()
+        for db in (10_000, 3_000_000, 205_000_000, 200_000_000_000):
+            for ql in (10, 50, 100, 150, 200, 1000):
+                a = lib.lx_length_adjustment(db, ql, C.byref(ka))
+                assert a == oracle.length_adjustment(db, ql, oka)
+                for sc in (1, 30, 77, 200, 1500):
+                    assert lib.lx_evalue(sc, ql - a if ql > a else 0, db - a, C.byref(ka)) == oracle.evalue(sc, ql - a if ql > a else 0, db - a, oka)
+                    assert lib.lx_bitscore(sc, C.byref(ka)) == oracle.bitscore(sc, oka)
+    with pytest.raises(capi.LambdaExtError):
+        capi.karlin_params(62, gap_open=-3, gap_extend=-3)  # no published values -> prepareScoring would throw

@@ -1,0 +1,181 @@
+"""GPU parity tests of pass 2 (traceback), the pre-extension filter and the whole driver -- HIP path through the C ABI
+vs the CPU oracle, bit-exact on scores / coordinates / ops / counts, exact on doubles computed by the same formulas."""
+import numpy as np
+import pytest
+
+from lambda_amd import capi, synth
+from tests import oracle_driver, oracle_lib
+from tests.test_oracle import SCHEMES, alphabet_of
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_align(handle, oracle, q, s, ext, name, bs_rule=0):
+    sc_p = SCHEMES[name]
+    handle.set_scoring(sc_p, 0)
+    handle.set_option(capi.LX_OPT_BS_MATCH_RULE, bs_rule)
+    hsp, ops = handle.align_batch(q, s, ext)
+    osc = oracle_lib.scoring_from(sc_p)
+    want = oracle.align_batch(q, s, ext, osc)
+    nbad = 0
+    for i, (oh, oops) in enumerate(want):
+        g = hsp[i]
+        got = (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"])
+        exp = (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops)
+        if got != exp or ops[i] != oops:
+            nbad += 1
+            if nbad < 4:
+                print("MISMATCH", i, ext[i], got, exp, ops[i][:60], oops[:60])
+            continue
+        if oh.score > 0:
+            x = ext[i]
+            qq = q[int(x["q_off"]): int(x["q_off"]) + int(x["q_len"])]
+            ss = s[int(x["s_off"]): int(x["s_off"]) + int(x["s_len"])]
+            st = oracle.alignment_stats(qq, ss, oh, oops, osc, bs_rule)
+            assert (g["num_matches"], g["num_mismatches"], g["num_positives"], g["num_gap_opens"], g["num_gap_extensions"]) == \
+                   (st.num_matches, st.num_mismatches, st.num_positives, st.num_gap_opens, st.num_gap_extensions), i
+    assert nbad == 0, f"{nbad} of {len(ext)} alignments differ"
+    handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 0)
+    return hsp, ops
+
+
+@pytest.mark.parametrize("name", ["blosum62", "nucl", "bs_fwd", "bs_rev"])
+def test_align_ragged(handle, oracle, name):
+    q, s, ext = synth.make_ragged_np(500, seed=31, alphabet=alphabet_of(name), lq_range=(1, 400), ls_extra=(0, 90))
+    hsp, _ = _check_align(handle, oracle, q, s, ext, name, bs_rule=int(name.startswith("bs")))
+    assert hsp["n_ops"].max() > 30
+
+
+def test_align_headline_shape(handle, oracle):
+    q, s, ext = synth.make_batch_np(100, 150, 32, seed=0x1A3BDA02)
+    hsp, ops = _check_align(handle, oracle, q, s, ext, "blosum62")
+    assert sum(b"D" in o or b"I" in o for o in ops) > 50  # indels present in the homologous half
+
+
+def test_align_ties_small_alphabet(handle, oracle):
+    # two-letter alphabets: score ties between cells and between diagonal / gap moves everywhere;
+    # end cell, begin cell and every op must follow the documented tie rules
+    rng = np.random.default_rng(22)
+    n = 800
+    q = rng.integers(0, 2, 48 * n).astype(np.uint8)
+    s = rng.integers(0, 2, 64 * n).astype(np.uint8)
+    ext = np.zeros(n, dtype=capi.EXT_DTYPE)
+    ext["q_off"] = np.arange(n) * 48
+    ext["q_len"] = rng.integers(1, 49, n)
+    ext["s_off"] = np.arange(n) * 64
+    ext["s_len"] = rng.integers(1, 65, n)
+    _check_align(handle, oracle, q, s, ext, "nucl")
+
+
+def test_align_edge_cases(handle, oracle):
+    rng = np.random.default_rng(9)
+    q = synth.STD20[rng.integers(0, 20, 3000)].astype(np.uint8)
+    s = synth.STD20[rng.integers(0, 20, 9000)].astype(np.uint8)
+    s[1000:2500] = q[:1500]
+    ext = np.array([
+        (0, 0, 0, 0), (0, 0, 10, 0), (0, 0, 0, 10), (0, 1000, 1, 1), (0, 1001, 1, 1),
+        (0, 1000, 1500, 1500),   # 10 panels, perfect diagonal
+        (0, 900, 700, 1900),     # multi-panel with flanks
+        (100, 1100, 160, 176), (100, 1100, 161, 176), (100, 1050, 320, 500),
+        (0, 0, 150, 8000),       # long subject window
+        (2000, 5000, 900, 3),    # short subject, multi-panel query
+    ], dtype=capi.EXT_DTYPE)
+    hsp, _ = _check_align(handle, oracle, q, s, ext, "blosum62")
+    assert hsp["score"][5] > 5000 and hsp["n_ops"][5] == 1500
+
+
+def test_align_chunked_trace_workspace(handle, oracle):
+    # force several chunks through a tiny direction-bit budget
+    handle.set_option(capi.LX_OPT_TRACE_BYTES, 1 << 20)
+    try:
+        q, s, ext = synth.make_batch_np(40, 150, 8, seed=3)
+        _check_align(handle, oracle, q, s, ext, "blosum62")
+    finally:
+        handle.set_option(capi.LX_OPT_TRACE_BYTES, 4 << 30)
+
+
+def test_prefilter(handle, oracle):
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    rng = np.random.default_rng(5)
+    nq, ns = 50, 20
+    qlen = rng.integers(30, 200, nq)
+    slen = rng.integers(200, 1500, ns)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]])
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]])
+    q = synth.STD20[rng.integers(0, 20, int(qlen.sum()))].astype(np.uint8)
+    s = synth.STD20[rng.integers(0, 20, int(slen.sum()))].astype(np.uint8)
+    n = 4000
+    seeds = np.zeros(n, dtype=capi.SEED_DTYPE)
+    for i in range(n):
+        a, b = int(rng.integers(0, nq)), int(rng.integers(0, ns))
+        L = int(rng.integers(8, 14))
+        qs = int(rng.integers(0, qlen[a] - L + 1))
+        ss = int(rng.integers(0, slen[b] - L + 1))
+        if rng.random() < 0.5:  # plant a diagonal so that about half of the seeds pass
+            lo = min(qs, ss, 15)
+            hi = min(qlen[a] - qs, slen[b] - ss, 25)
+            s[soff[b] + ss - lo: soff[b] + ss + hi] = q[qoff[a] + qs - lo: qoff[a] + qs + hi]
+        seeds[i] = (qoff[a], soff[b], qlen[a], slen[b], qs, qs + L, ss, 0)
+    for seed_length, pre, thr in ((10, 2, 2.0), (11, 2, 2.0), (10, 1, 2.0), (14, 2, 1.4)):
+        got = handle.prefilter_batch(q, s, seeds, seed_length, pre, thr)
+        want = np.array([oracle.seed_looks_promising(q[int(x["q_off"]): int(x["q_off"]) + int(x["q_len"])],
+                                                     s[int(x["s_off"]): int(x["s_off"]) + int(x["s_len"])],
+                                                     int(x["qry_start"]), int(x["qry_end"]), int(x["subj_start"]),
+                                                     seed_length, pre, thr, osc) for x in seeds], dtype=np.uint8)
+        assert (got == want).all()
+        assert 0.05 < got.mean() < 0.95
+
+
+def _driver_case(rng, nq=40, ns=12, hits=600, lq=(60, 220)):
+    qlen = rng.integers(lq[0], lq[1], nq).astype(np.uint64)
+    slen = rng.integers(300, 2500, ns).astype(np.uint64)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint64)
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.uint64)
+    q = synth.STD20[rng.integers(0, 20, int(qlen.sum()))].astype(np.uint8)
+    s = synth.STD20[rng.integers(0, 20, int(slen.sum()))].astype(np.uint8)
+    m = np.zeros(hits, dtype=capi.MATCH_DTYPE)
+    for i in range(hits):
+        a, b = int(rng.integers(0, nq)), int(rng.integers(0, ns))
+        L = 10
+        qs = int(rng.integers(0, int(qlen[a]) - L + 1))
+        ss = int(rng.integers(0, int(slen[b]) - L + 1))
+        if rng.random() < 0.6:  # homologous region around the seed, with substitutions
+            lo = min(qs, ss)
+            hi = min(int(qlen[a]) - qs, int(slen[b]) - ss)
+            seg = q[int(qoff[a]) + qs - lo: int(qoff[a]) + qs + hi].copy()
+            mut = rng.random(len(seg)) < 0.3
+            seg[mut] = synth.STD20[rng.integers(0, 20, int(mut.sum()))]
+            s[int(soff[b]) + ss - lo: int(soff[b]) + ss + hi] = seg
+        m[i] = (a, b, qs, qs + L, ss, ss + L)
+    return q, qoff, qlen, s, soff, slen, m
+
+
+@pytest.mark.parametrize("filters", [(1e-2, -1, 0), (-1.0, 40, 0), (10.0, -1, 35), (-1.0, -1, 0)])
+def test_iterate_matches_driver(handle, oracle, filters):
+    max_e, min_bits, idcut = filters
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    ka = capi.karlin_params(62)
+    oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
+    rng = np.random.default_rng(2024)
+    q, qoff, qlen, s, soff, slen, m = _driver_case(rng)
+    db_total = int(slen.sum())
+    params = capi.SearchParams(max_e, min_bits, idcut, db_total, 0, 1, 1, 0, ka)
+    bms, ops, stats = handle.iterate_matches(q, qoff, qlen, qlen, s, soff, slen, m, params)
+    want, wstats = oracle_driver.iterate_matches(oracle, osc, oka, q, qoff, qlen, qlen, s, soff, slen,
+                                                 m.astype(oracle_lib.MATCH_DTYPE), max_e, min_bits, idcut, db_total)
+    assert (stats.hits_duplicate, stats.failed_bitscore, stats.failed_evalue, stats.failed_identity) == \
+           (wstats["hits_duplicate"], wstats["failed_bitscore"], wstats["failed_evalue"], wstats["failed_identity"])
+    assert len(bms) == len(want) and len(want) > 20
+    for g, w, o in zip(bms, want, ops):
+        for k in ("qry_id", "subj_id", "n_qid", "n_sid", "q_start", "q_end", "s_start", "s_end", "score", "alignment_length",
+                  "num_matches", "num_mismatches", "num_positives", "num_gap_opens", "num_gap_extensions"):
+            assert int(g[k]) == w[k], (k, g, w)
+        assert o == w["ops"]
+        assert g["identity"] == np.float32(w["identity"])
+        # same formulas, same libm: equal to the last bit; the contract is 1e-6 relative
+        assert abs(g["bit_score"] - w["bit_score"]) <= 1e-6 * abs(w["bit_score"])
+        assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])

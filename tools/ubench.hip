@@ -80,6 +80,54 @@ DEF_KERNEL(k_bfe, I_BFE)
 DEF_KERNEL(k_pkmad, I_PKMAD)
 DEF_KERNEL(k_max3f32, I_MAXF32)
 
+
+#define I_SUB(R) "v_sub_u32 " R ", " R ", %8\n"
+#define I_AND(R) "v_and_b32 " R ", " R ", %8\n"
+#define I_OR(R) "v_or_b32 " R ", " R ", %8\n"
+#define I_XOR(R) "v_xor_b32 " R ", " R ", %8\n"
+#define I_MINI(R) "v_min_i32 " R ", " R ", %8\n"
+#define I_MAXU(R) "v_max_u32 " R ", " R ", %8\n"
+#define I_LSHL(R) "v_lshlrev_b32 " R ", 1, " R "\n"
+#define I_MOV(R) "v_mov_b32 " R ", %8\n"
+#define I_ADDF(R) "v_add_f32 " R ", " R ", %8\n"
+#define I_MAXF(R) "v_max_f32 " R ", " R ", %8\n"
+#define I_MULF(R) "v_mul_f32 " R ", " R ", %8\n"
+#define I_FMAF(R) "v_fma_f32 " R ", " R ", %8, %9\n"
+#define I_FMACF(R) "v_fmac_f32 " R ", %8, %9\n"
+#define I_ADDE64(R) "v_add_u32_e64 " R ", " R ", %8\n"
+#define I_ADDU16(R) "v_add_u16 " R ", " R ", %8\n"
+#define I_MAXI16(R) "v_max_i16 " R ", " R ", %8\n"
+#define I_ADDF16(R) "v_add_f16 " R ", " R ", %8\n"
+#define I_MAXF16(R) "v_max_f16 " R ", " R ", %8\n"
+#define I_CVTUB(R) "v_cvt_f32_ubyte1 " R ", " R "\n"
+#define I_CVTI(R) "v_cvt_f32_i32 " R ", " R "\n"
+#define I_MED3(R) "v_med3_i32 " R ", " R ", %8, %9\n"
+#define I_LSHLADD(R) "v_lshl_add_u32 " R ", " R ", 1, %9\n"
+#define I_ADDLSHL(R) "v_add_lshl_u32 " R ", " R ", %8, 1\n"
+#define I_ANDOR(R) "v_and_or_b32 " R ", " R ", %8, %9\n"
+#define I_MIX1(R) "v_add_u32 " R ", " R ", %8\nv_max3_i32 " R ", " R ", %8, %9\n"
+#define I_MIX2(R) "v_add_u32 " R ", " R ", %8\nv_add_u32 " R ", " R ", %9\nv_max3_i32 " R ", " R ", %8, %9\nv_max_i32 " R ", " R ", %8\n"
+#define I_ADDS(R) "v_add_u32 " R ", s4, " R "\n"
+#define I_MAXS(R) "v_max_i32 " R ", s4, " R "\n"
+#define I_SUBREV(R) "v_subrev_u32 " R ", %8, " R "\n"
+#define I_ADDCO(R) "v_add_co_u32 " R ", vcc, " R ", %8\n"
+#define I_MAX3F16(R) "v_max3_f16 " R ", " R ", %8, %9\n"
+#define I_PKMIN(R) "v_pk_min_i16 " R ", " R ", %8\n"
+#define I_PKADDU(R) "v_pk_add_u16 " R ", " R ", %8\n"
+#define I_SAD(R) "v_sad_u32 " R ", " R ", %8, %9\n"
+#define I_ADDFC(R) "v_add_f32 " R ", 1.0, " R "\n"
+
+DEF_KERNEL(k_sub, I_SUB) DEF_KERNEL(k_and, I_AND) DEF_KERNEL(k_or, I_OR) DEF_KERNEL(k_xor, I_XOR)
+DEF_KERNEL(k_mini, I_MINI) DEF_KERNEL(k_maxu, I_MAXU) DEF_KERNEL(k_lshl, I_LSHL) DEF_KERNEL(k_mov, I_MOV)
+DEF_KERNEL(k_addf, I_ADDF) DEF_KERNEL(k_maxf, I_MAXF) DEF_KERNEL(k_mulf, I_MULF) DEF_KERNEL(k_fmaf, I_FMAF)
+DEF_KERNEL(k_fmacf, I_FMACF) DEF_KERNEL(k_adde64, I_ADDE64) DEF_KERNEL(k_addu16, I_ADDU16)
+DEF_KERNEL(k_maxi16, I_MAXI16) DEF_KERNEL(k_addf16, I_ADDF16) DEF_KERNEL(k_maxf16, I_MAXF16)
+DEF_KERNEL(k_cvtub, I_CVTUB) DEF_KERNEL(k_cvti, I_CVTI) DEF_KERNEL(k_med3, I_MED3) DEF_KERNEL(k_lshladd, I_LSHLADD)
+DEF_KERNEL(k_addlshl, I_ADDLSHL) DEF_KERNEL(k_andor, I_ANDOR) DEF_KERNEL(k_mix1, I_MIX1) DEF_KERNEL(k_mix2, I_MIX2)
+DEF_KERNEL(k_adds, I_ADDS) DEF_KERNEL(k_maxs, I_MAXS) DEF_KERNEL(k_subrev, I_SUBREV) DEF_KERNEL(k_addco, I_ADDCO)
+DEF_KERNEL(k_max3f16, I_MAX3F16) DEF_KERNEL(k_pkmin, I_PKMIN) DEF_KERNEL(k_pkaddu, I_PKADDU) DEF_KERNEL(k_sad, I_SAD)
+DEF_KERNEL(k_addfc, I_ADDFC)
+
 // LDS: ds_read_b32 with a lane-linear address pattern
 __global__ __launch_bounds__(256) void k_lds_b32(int * out, int iters, int x, int y)
 {
@@ -124,7 +172,7 @@ static void run(char const * name, kern_t k, int * d_out, int waves_per_simd, do
         if (ms < best)
             best = ms;
     }
-    double const instrs = (double)blocks * 256.0 * iters * 32.0; // lane-instructions
+    double const instrs = (double)blocks * 256.0 * iters * 32.0; // lane-instructions (mix kernels: x2 / x4 more, see name)
     double const rate   = instrs / (best * 1e-3);
     printf("%-12s waves/SIMD=%d  %8.3f ms  %8.2f T lane-instr/s  (%6.2f lanes/clk/CU @2.4GHz)  x%.0f = %7.2f Tops/s\n", name,
            waves_per_simd, best, rate * 1e-12, rate / (cus * 2.4e9), ops_per_instr, rate * ops_per_instr * 1e-12);
@@ -149,8 +197,19 @@ int main()
                {"pk_maximum3_f16", k_pkmax3f, 4}, {"v_perm_b32", k_perm, 1},  {"v_max3_i16", k_max3i16, 2},
                {"v_cndmask", k_cndmask, 1},    {"v_mad_u32_u24", k_madu24, 1}, {"v_lshl_or", k_lshlor, 1},
                {"v_bfe_u32", k_bfe, 1},        {"v_pk_mad_i16", k_pkmad, 2},  {"v_max3_f32", k_max3f32, 2},
-               {"ds_read_b32", k_lds_b32, 1}};
-    for (int w : {1, 2, 4, 8})
+               {"ds_read_b32", k_lds_b32, 1},
+               {"v_sub_u32", k_sub, 1}, {"v_and_b32", k_and, 1}, {"v_or_b32", k_or, 1}, {"v_xor_b32", k_xor, 1},
+               {"v_min_i32", k_mini, 1}, {"v_max_u32", k_maxu, 1}, {"v_lshlrev_b32", k_lshl, 1}, {"v_mov_b32", k_mov, 1},
+               {"v_add_f32", k_addf, 1}, {"v_max_f32", k_maxf, 1}, {"v_mul_f32", k_mulf, 1}, {"v_fma_f32", k_fmaf, 2},
+               {"v_fmac_f32", k_fmacf, 2}, {"v_add_u32_e64", k_adde64, 1}, {"v_add_u16", k_addu16, 1},
+               {"v_max_i16", k_maxi16, 1}, {"v_add_f16", k_addf16, 1}, {"v_max_f16", k_maxf16, 1},
+               {"v_cvt_f32_ubyte1", k_cvtub, 1}, {"v_cvt_f32_i32", k_cvti, 1}, {"v_med3_i32", k_med3, 2},
+               {"v_lshl_add_u32", k_lshladd, 2}, {"v_add_lshl_u32", k_addlshl, 2}, {"v_and_or_b32", k_andor, 2},
+               {"mix_add+max3", k_mix1, 1.5}, {"mix_2add+max3+max", k_mix2, 1.25},
+               {"v_add_u32_sgpr", k_adds, 1}, {"v_max_i32_sgpr", k_maxs, 1}, {"v_subrev_u32", k_subrev, 1},
+               {"v_add_co_u32", k_addco, 1}, {"v_max3_f16", k_max3f16, 2}, {"v_pk_min_i16", k_pkmin, 2},
+               {"v_pk_add_u16", k_pkaddu, 2}, {"v_sad_u32", k_sad, 2}, {"v_add_f32_const", k_addfc, 1}};
+    for (int w : {4, 8})
         for (auto & t : tab)
             run(t.n, t.k, d_out, w, t.ops);
     return 0;
