@@ -241,6 +241,9 @@ int lx_synchronize(lx_handle * h);
 /* Duration in ms of the most recent score / align kernel launch sequence on this handle, measured with HIP
  * events on the launch stream (valid after lx_synchronize or a host-buffer call). */
 int lx_last_kernel_ms(lx_handle * h, float * ms);
+/* Name of the kernel instantiation the most recent pass-1 launch used, e.g. "lx::score_kernel<8,19,false> shared-profile"
+ * (profiling aid: matches the kernel names rocprofv3 reports). */
+char const * lx_last_kernel_name(lx_handle const * h);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ namespace lx
 hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t stream);
 int        score_cfg_panel(int cfg);
 int        score_cfg_groups(int cfg);
+int        score_cfg_count();
 hipError_t launch_trace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
 int        trace_panel();
@@ -54,6 +55,7 @@ struct lx_handle
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
     bool        timed = false;
     std::string error;
+    std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
 
     bool             have_sc[2] = {false, false};
     lx_scoring       sc_host[2];
@@ -125,12 +127,29 @@ int bind(lx_handle * h)
 // padding of q/s staging buffers so that clamped / prefetching loads never leave the allocation
 constexpr size_t kSlack = 256;
 
-int pick_cfg(uint32_t qlen)
+// Smallest panel that holds the query; 8-lane geometries need one shared profile per wavefront (8 profile slots
+// per wavefront would not fit the LDS budget), so without sharing only the 16/32/64-lane geometries are used.
+int pick_cfg(uint32_t qlen, bool shared)
 {
-    if (qlen <= 64)
-        return 1;
+    if (shared)
+    {
+        if (qlen <= 64)
+            return 1;
+        if (qlen <= 104)
+            return 4;
+        if (qlen <= 128)
+            return 5;
+        if (qlen <= 152)
+            return 6;
+    }
+    if (qlen <= 64 && !shared)
+        return 1; // 64 columns: 8 slots of a 64-column profile are small enough
     if (qlen <= 160)
         return 0;
+    if (qlen <= 208)
+        return 7;
+    if (qlen <= 256)
+        return 8;
     if (qlen <= 320)
         return 2;
     return 3;
@@ -171,6 +190,13 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     p.shared_profile = shared ? 1 : 0;
     p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
+    {
+        char buf[96];
+        snprintf(buf, sizeof(buf), "lx::score_kernel<%d,%d,%s>%s", 64 / lx::score_cfg_groups(cfg),
+                 lx::score_cfg_panel(cfg) * lx::score_cfg_groups(cfg) / 64, multi ? "true" : "false",
+                 shared ? " shared-profile" : "");
+        h->last_kernel = buf;
+    }
     return LX_OK;
 }
 
@@ -354,6 +380,11 @@ int lx_synchronize(lx_handle * h)
     return check_async_error(h);
 }
 
+char const * lx_last_kernel_name(lx_handle const * h)
+{
+    return h ? h->last_kernel.c_str() : "";
+}
+
 int lx_last_kernel_ms(lx_handle * h, float * ms)
 {
     if (!h || !ms)
@@ -386,7 +417,8 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     if ((rc = prepare_workspace(h, stream)))
         return rc;
     // geometry from the caller's hints; any geometry is correct for any query length (multi-panel path)
-    int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu)) : 0;
+    bool const want_shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
+    int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu), want_shared) : 0;
     bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
     bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
     LX_HIP(h, hipEventRecord(h->ev0, stream));
@@ -412,11 +444,13 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     if (rc)
         return rc;
 
-    // ---- validate + bin by kernel geometry; inside a bin order by (q_len, q_off, s_len): same query adjacent
-    // (one profile per wavefront), similar lengths adjacent (the reference sorts for the same reason,
-    // src/search_algo.hpp:1229-1235)
-    std::vector<uint32_t> order[4];
-    uint64_t              carry_pairs = 0;
+    // ---- validate; order by (q_len, q_off, s_len): extensions of one query become adjacent (one LDS profile per
+    // wavefront), similar lengths become adjacent (lanes of a wavefront run in lockstep; the reference sorts its
+    // SIMD batches for the same reason, src/search_algo.hpp:1229-1235)
+    if (n > 0xfffffff0ull)
+        return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    std::vector<uint32_t> idx;
+    idx.reserve(n);
     for (uint64_t i = 0; i < n; ++i)
     {
         lx_extension const & x = ext[i];
@@ -427,20 +461,76 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             out_score[i] = 0;
             continue;
         }
-        int const cfg = pick_cfg(x.q_len);
-        if ((int)x.q_len > lx::score_cfg_panel(cfg))
-            carry_pairs += x.s_len;
-        order[cfg].push_back((uint32_t)i);
+        idx.push_back((uint32_t)i);
     }
-    if (n > 0xffffffffull)
-        return fail(h, LX_EINVAL, "at most 2^32-1 extensions per call");
+    std::sort(idx.begin(), idx.end(),
+              [&](uint32_t a, uint32_t b)
+              {
+                  lx_extension const &x = ext[a], &y = ext[b];
+                  if (x.q_len != y.q_len)
+                      return x.q_len < y.q_len;
+                  if (x.q_off != y.q_off)
+                      return x.q_off < y.q_off;
+                  if (x.s_len != y.s_len)
+                      return x.s_len < y.s_len;
+                  return a < b;
+              });
+
+    // ---- bin query runs by kernel geometry.  A run whose padding to a whole number of wavefront slots wastes
+    // <= 25 % goes to a "shared profile" launch (8-lane geometries allowed), the rest to per-extension profiles.
+    int const ncfg = lx::score_cfg_count();
+    struct Bin
+    {
+        std::vector<lx_extension> ext;
+        std::vector<uint32_t>     perm;
+        uint32_t                  max_qlen = 0;
+    };
+    std::vector<Bin> bins((size_t)ncfg * 2);
+    uint64_t         carry_pairs = 0;
+    for (size_t k = 0; k < idx.size();)
+    {
+        size_t k1 = k + 1;
+        while (k1 < idx.size() && ext[idx[k1]].q_off == ext[idx[k]].q_off && ext[idx[k1]].q_len == ext[idx[k]].q_len)
+            ++k1;
+        uint64_t const run  = k1 - k;
+        uint32_t const qlen = ext[idx[k]].q_len;
+        int            cfg  = pick_cfg(qlen, true);
+        uint64_t       grp  = (uint64_t)lx::score_cfg_groups(cfg);
+        uint64_t       pad  = (run + grp - 1) / grp * grp;
+        bool           shared = grp > 1 && (pad - run) * 4 <= pad;
+        if (!shared)
+        {
+            cfg = pick_cfg(qlen, false);
+            grp = (uint64_t)lx::score_cfg_groups(cfg);
+            pad = (run + grp - 1) / grp * grp;
+            shared = grp > 1 && (pad - run) * 4 <= pad;
+        }
+        Bin & bin    = bins[(size_t)cfg * 2 + (shared ? 1 : 0)];
+        bin.max_qlen = std::max(bin.max_qlen, qlen);
+        for (size_t j = k; j < k1; ++j)
+        {
+            bin.ext.push_back(ext[idx[j]]);
+            bin.perm.push_back(idx[j]);
+            if ((int)qlen > lx::score_cfg_panel(cfg))
+                carry_pairs += ext[idx[j]].s_len;
+        }
+        if (shared)
+            for (uint64_t j = run; j < pad; ++j) // dummy slots keep one query per wavefront
+            {
+                lx_extension dummy = ext[idx[k]];
+                dummy.s_len        = 0;
+                bin.ext.push_back(dummy);
+                bin.perm.push_back(0xffffffffu);
+            }
+        k = k1;
+    }
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
         h->opt_ws_bytes = carry_pairs * 8 + 4096;
 
     std::vector<lx_extension> sorted;
-    sorted.reserve(n);
-    std::vector<uint32_t> perm;
-    perm.reserve(n);
+    std::vector<uint32_t>     perm;
+    sorted.reserve(n + 64);
+    perm.reserve(n + 64);
     struct Seg
     {
         int      cfg;
@@ -448,64 +538,16 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         bool     multi, shared;
     };
     std::vector<Seg> segs;
-    for (int cfg = 0; cfg < 4; ++cfg)
-    {
-        auto & o = order[cfg];
-        if (o.empty())
-            continue;
-        std::sort(o.begin(), o.end(),
-                  [&](uint32_t a, uint32_t b)
-                  {
-                      lx_extension const &x = ext[a], &y = ext[b];
-                      if (x.q_len != y.q_len)
-                          return x.q_len < y.q_len;
-                      if (x.q_off != y.q_off)
-                          return x.q_off < y.q_off;
-                      if (x.s_len != y.s_len)
-                          return x.s_len < y.s_len;
-                      return a < b;
-                  });
-        int const  groups = lx::score_cfg_groups(cfg);
-        bool const multi  = ext[o.back()].q_len > (uint32_t)lx::score_cfg_panel(cfg);
-        // would padding every query run to a multiple of `groups` cost <= 12.5 % extra slots?  then share profiles
-        uint64_t padded = 0, run = 0;
-        for (size_t k = 0; k < o.size(); ++k)
+    for (int cfg = 0; cfg < ncfg; ++cfg)
+        for (int sh = 0; sh < 2; ++sh)
         {
-            ++run;
-            bool const last = (k + 1 == o.size()) || ext[o[k + 1]].q_off != ext[o[k]].q_off ||
-                              ext[o[k + 1]].q_len != ext[o[k]].q_len;
-            if (last)
-            {
-                padded += (run + groups - 1) / groups * groups;
-                run = 0;
-            }
+            Bin & bin = bins[(size_t)cfg * 2 + sh];
+            if (bin.ext.empty())
+                continue;
+            segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), bin.max_qlen > (uint32_t)lx::score_cfg_panel(cfg), sh == 1});
+            sorted.insert(sorted.end(), bin.ext.begin(), bin.ext.end());
+            perm.insert(perm.end(), bin.perm.begin(), bin.perm.end());
         }
-        bool const shared = groups > 1 && padded * 8 <= o.size() * 9;
-        Seg        seg{cfg, sorted.size(), 0, multi, shared};
-        run = 0;
-        for (size_t k = 0; k < o.size(); ++k)
-        {
-            sorted.push_back(ext[o[k]]);
-            perm.push_back(o[k]);
-            ++run;
-            bool const last = (k + 1 == o.size()) || ext[o[k + 1]].q_off != ext[o[k]].q_off ||
-                              ext[o[k + 1]].q_len != ext[o[k]].q_len;
-            if (shared && last)
-            {
-                while (run % groups) // dummy slots keep one query per wavefront
-                {
-                    lx_extension dummy = ext[o[k]];
-                    dummy.s_len        = 0;
-                    sorted.push_back(dummy);
-                    perm.push_back(0xffffffffu);
-                    ++run;
-                }
-                run = 0;
-            }
-        }
-        seg.count = sorted.size() - seg.first;
-        segs.push_back(seg);
-    }
     if (sorted.empty())
         return LX_OK;
 

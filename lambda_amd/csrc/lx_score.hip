@@ -217,6 +217,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
                 int const tt  = dg + sub;
                 dg            = Hrow[c];
                 h             = max3i(tt, Ecur, F0[c]);
+                LX_OPAQUE(h); // keeps rowmax a chain over h instead of a wider tree over (tt, E, F0)
                 int const A   = h + g2;
                 F0[c]         = max3i(F0[c], A, zn);
                 LX_OPAQUE(F0[c]);
@@ -338,7 +339,25 @@ static hipError_t launch_score_cfg(ScoreParams const & p, bool multi, hipStream_
     return hipGetLastError();
 }
 
-// cfg: 0 = (16,10) panel 160; 1 = (8,8) panel 64; 2 = (32,10) panel 320; 3 = (64,10) panel 640
+// Kernel geometries (G lanes per extension x C columns per lane).  G = 8 geometries put 8 extensions in a
+// wavefront and are only used with one shared profile per wavefront (LX_OPT_QUERY_RUN / host-side binning).
+struct ScoreCfg
+{
+    int g, c;
+};
+static constexpr ScoreCfg kScoreCfgs[] = {
+    {16, 10}, // 0: 160 columns
+    {8, 8},   // 1:  64
+    {32, 10}, // 2: 320
+    {64, 10}, // 3: 640 (and the multi-panel workhorse for longer queries)
+    {8, 13},  // 4: 104
+    {8, 16},  // 5: 128
+    {8, 19},  // 6: 152
+    {16, 13}, // 7: 208
+    {16, 16}, // 8: 256
+};
+constexpr int kNumScoreCfgs = sizeof(kScoreCfgs) / sizeof(ScoreCfg);
+
 // multi: the batch may hold queries wider than the panel (enables the carry-workspace code path)
 hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t stream)
 {
@@ -348,20 +367,25 @@ hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t 
         case 1: return launch_score_cfg<8, 8>(p, multi, stream);
         case 2: return launch_score_cfg<32, 10>(p, multi, stream);
         case 3: return launch_score_cfg<64, 10>(p, multi, stream);
+        case 4: return launch_score_cfg<8, 13>(p, multi, stream);
+        case 5: return launch_score_cfg<8, 16>(p, multi, stream);
+        case 6: return launch_score_cfg<8, 19>(p, multi, stream);
+        case 7: return launch_score_cfg<16, 13>(p, multi, stream);
+        case 8: return launch_score_cfg<16, 16>(p, multi, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
+int score_cfg_count() { return kNumScoreCfgs; }
+
 int score_cfg_panel(int cfg)
 {
-    static int const panel[4] = {160, 64, 320, 640};
-    return (cfg >= 0 && cfg < 4) ? panel[cfg] : 0;
+    return (cfg >= 0 && cfg < kNumScoreCfgs) ? kScoreCfgs[cfg].g * kScoreCfgs[cfg].c : 0;
 }
 
 int score_cfg_groups(int cfg)
 {
-    static int const groups[4] = {4, 8, 2, 1};
-    return (cfg >= 0 && cfg < 4) ? groups[cfg] : 0;
+    return (cfg >= 0 && cfg < kNumScoreCfgs) ? 64 / kScoreCfgs[cfg].g : 0;
 }
 
 } // namespace lx

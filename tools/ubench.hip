@@ -127,6 +127,12 @@ DEF_KERNEL(k_addlshl, I_ADDLSHL) DEF_KERNEL(k_andor, I_ANDOR) DEF_KERNEL(k_mix1,
 DEF_KERNEL(k_adds, I_ADDS) DEF_KERNEL(k_maxs, I_MAXS) DEF_KERNEL(k_subrev, I_SUBREV) DEF_KERNEL(k_addco, I_ADDCO)
 DEF_KERNEL(k_max3f16, I_MAX3F16) DEF_KERNEL(k_pkmin, I_PKMIN) DEF_KERNEL(k_pkaddu, I_PKADDU) DEF_KERNEL(k_sad, I_SAD)
 DEF_KERNEL(k_addfc, I_ADDFC)
+#define I_CNDS(R) "v_cndmask_b32_e64 " R ", " R ", %8, s[6:7]\n"
+#define I_BFI(R) "v_bfi_b32 " R ", %8, " R ", %9\n"
+#define I_PKADDSEL(R) "v_pk_add_f16 " R ", " R ", %8 op_sel_hi:[1,0]\n"
+#define I_PKFMA(R) "v_pk_fma_f16 " R ", " R ", %8, %9\n"
+#define I_PKADDF32(R) "v_pk_add_f32 v[20:21], v[20:21], v[22:23]\n"
+DEF_KERNEL(k_cnds, I_CNDS) DEF_KERNEL(k_bfi, I_BFI) DEF_KERNEL(k_pkaddsel, I_PKADDSEL) DEF_KERNEL(k_pkfma, I_PKFMA)
 
 // LDS: ds_read_b32 with a lane-linear address pattern
 __global__ __launch_bounds__(256) void k_lds_b32(int * out, int iters, int x, int y)
@@ -208,8 +214,10 @@ int main()
                {"mix_add+max3", k_mix1, 1.5}, {"mix_2add+max3+max", k_mix2, 1.25},
                {"v_add_u32_sgpr", k_adds, 1}, {"v_max_i32_sgpr", k_maxs, 1}, {"v_subrev_u32", k_subrev, 1},
                {"v_add_co_u32", k_addco, 1}, {"v_max3_f16", k_max3f16, 2}, {"v_pk_min_i16", k_pkmin, 2},
-               {"v_pk_add_u16", k_pkaddu, 2}, {"v_sad_u32", k_sad, 2}, {"v_add_f32_const", k_addfc, 1}};
-    for (int w : {4, 8})
+               {"v_pk_add_u16", k_pkaddu, 2}, {"v_sad_u32", k_sad, 2}, {"v_add_f32_const", k_addfc, 1},
+               {"v_cndmask_e64_sgpr", k_cnds, 1}, {"v_bfi_b32", k_bfi, 1}, {"pk_add_f16_opsel", k_pkaddsel, 2},
+               {"v_pk_fma_f16", k_pkfma, 4}};
+    for (int w : {8})
         for (auto & t : tab)
             run(t.n, t.k, d_out, w, t.ops);
     return 0;
