@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--windows", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=20_000)
+    ap.add_argument("--pass1-only", action="store_true", help="time the score kernel alone (no filter, no traceback)")
+    ap.add_argument("--db-length", type=int, default=205_000_000, help="dbTotalLength for the e-value (Swiss-Prot sized)")
+    ap.add_argument("--max-evalue", type=float, default=1e-2)
     ap.add_argument("--hit-cutoff", type=int, default=120, help="raw score a window needs to enter the final gather")
     return ap.parse_args()
 
@@ -127,13 +130,34 @@ def main():
     n = len(ext)
     cells_rank = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
     d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    # pass-2 outputs (worst case sizes: every extension may survive)
+    h.set_option(capi.LX_OPT_MAX_SLEN, int(ext["s_len"].max()))
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    # e-value filter of iterateMatchesFullSimd (maxEValue 1e-2, src/search_options.hpp:96) as an integer score cut-off
+    ka = capi.karlin_params(62, gap_open=-11, gap_extend=-1)
+    lib = capi.load()
+    import ctypes as C
+    adj = lib.lx_length_adjustment(args.db_length, args.lq, C.byref(ka))
+    min_score = 1
+    while lib.lx_evalue(min_score, args.lq - adj, args.db_length - adj, C.byref(ka)) > args.max_evalue:
+        min_score += 1
     # a non-default torch stream: its handle is non-NULL, so the kernels really run on the stream the timing events
     # are recorded on (NULL would select the lx handle's private stream)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
 
     def step():
-        h.score_batch_dev(d_q, d_s, d_ext, n, d_score, stream=stream.cuda_stream)
+        if args.pass1_only:
+            h.score_batch_dev(d_q, d_s, d_ext, n, d_score, stream=stream.cuda_stream)
+        else:
+            h.extend_batch_dev(d_q, d_s, d_ext, n, min_score, d_score, d_hsp, d_ops, d_off, d_count,
+                               stream=stream.cuda_stream)
 
     def fence():
         if world > 1:
@@ -163,6 +187,7 @@ def main():
     dt = time.perf_counter() - t0
     h.synchronize()
     kernel_name = h.last_kernel_name()
+    survivors = int(d_count.cpu()[1]) if not args.pass1_only else 0
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -197,9 +222,14 @@ def main():
                 "extensions_per_gpu": n,
                 "gcells_per_gpu": round(cells_rank / 1e9, 3),
                 "parallelism": f"query-sharded x{world}, no data-path collective",
-                "step": "pass 1 score kernel over the whole batch",
+                "step": ("pass 1 score kernel over the whole batch" if args.pass1_only else
+                         f"pass 1 (score all) -> e-value filter (E<={args.max_evalue:g} at db {args.db_length}, i.e. score>={min_score}) "
+                         f"-> pass 2 (traceback of the {survivors} survivors), all on the GPU; GCUPS counts pass-1 cells only"),
+                "survivors_per_gpu": survivors,
+                "pass2_gcells_per_gpu": round(survivors * args.lq * synth.window_len(args.lq) / 1e9, 3),
             },
             "alignments_per_s": round(n * world * args.steps / dt, 1),
+            "traced_per_s": round(survivors * world * args.steps / dt, 1),
             "roofline": {
                 "bound": "valu",
                 "kernel": kernel_name,

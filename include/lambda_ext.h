@@ -152,6 +152,17 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
                        uint64_t n, void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * stream);
 
+/* ---- both passes fused on the device (the middle of iterateMatchesFullSimd, src/search_algo.hpp:1246-1296) --- */
+/* pass 1 on all n extensions -> keep extension i iff score >= (d_min_score ? d_min_score[i] : min_score_all) [the
+ * bit-score / e-value tests of :1251-1283 expressed as integer score cut-offs, which the host derives from
+ * lx_evalue()/lx_bitscore(); both are monotone in the score] -> pass 2 on the survivors.  Nothing leaves the GPU and
+ * nothing synchronises: d_out_score[n] (int32), d_out_hsp[n] (lx_hsp; filtered-out rows carry the score and n_ops = 0),
+ * ops of extension i at d_out_ops + d_ops_off[i], d_out_count[0] = pass-2 slots used, [1] = survivors (uint64).
+ * Requires LX_OPT_MAX_QLEN and LX_OPT_MAX_SLEN; honours LX_OPT_QUERY_RUN. */
+int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
+                        uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
+                        void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream);
+
 /* ---- pre-extension filter (seedLooksPromising, src/search_algo.hpp:426-481) ------------------ */
 /* One diagonal per item; out_keep[i] = 1 if the ungapped max-segment score reaches the threshold. */
 typedef struct lx_seed

@@ -23,7 +23,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 EXPORTED_SYMBOLS = [
     "lx_abi_version", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
-    "lx_align_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name",
+    "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name",
     "lx_iterate_matches",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
@@ -122,6 +122,7 @@ def load():
                        ("lx_prefilter_batch", [vp, i32, vp, u64, vp, u64, vp, u64, C.c_uint32, C.c_int32, C.c_double, vp])):
         if hasattr(lib, name):
             getattr(lib, name).argtypes = args
+    lib.lx_extend_batch_dev.argtypes = [vp, i32, vp, vp, vp, u64, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     lib.lx_karlin_params.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Karlin)]
     lib.lx_length_adjustment.argtypes = [u64, u64, C.POINTER(Karlin)]
     lib.lx_length_adjustment.restype = u64
@@ -282,6 +283,13 @@ class Handle:
             return bms, ops, stats
         finally:
             self.lib.lx_iterate_result_free(res)
+
+    def extend_batch_dev(self, d_q, d_s, d_ext, n: int, min_score: int, d_score, d_hsp, d_ops, d_ops_off, d_count,
+                         d_min_score=None, stream=None, slot: int = 0):
+        self._check(self.lib.lx_extend_batch_dev(self.h, slot, d_q.data_ptr(), d_s.data_ptr(), d_ext.data_ptr(), n,
+                                                 d_min_score.data_ptr() if d_min_score is not None else None, min_score,
+                                                 d_score.data_ptr(), d_hsp.data_ptr(), d_ops.data_ptr(),
+                                                 d_ops_off.data_ptr(), d_count.data_ptr(), stream))
 
     def synchronize(self):
         self._check(self.lib.lx_synchronize(self.h))

@@ -26,8 +26,10 @@ int        score_cfg_groups(int cfg);
 int        score_cfg_count();
 hipError_t launch_trace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
-int        trace_panel();
-int        trace_group();
+int        trace_cfg_panel(int cfg);
+int        trace_cfg_group(int cfg);
+int        trace_cfg_words(int cfg);
+hipError_t launch_select(SelectParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
@@ -58,11 +60,12 @@ struct lx_handle
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
 
     bool             have_sc[2] = {false, false};
+    bool             trace_ok[2] = {false, false};
     lx_scoring       sc_host[2];
     lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
 
     // staging for the host-buffer entry points
-    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds;
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs;
     // multi-panel carry workspace
     DevBuf     d_ws;
     uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
@@ -279,7 +282,7 @@ void lx_destroy(lx_handle * h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ends,
-                       &h->d_hsp, &h->d_seeds, &h->d_ws})
+                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_ws})
         if (b->ptr)
             (void)hipFree(b->ptr);
     for (int s = 0; s < 2; ++s)
@@ -346,6 +349,7 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
     if (sc->gap_open < -120 || sc->gap_extend < -27)
         return fail(h, LX_EINVAL, "gap costs out of the supported range");
     lx::ScoringDev d{};
+    int            trace_ok = 1;
     d.alph = sc->alphabet_size;
     d.go   = sc->gap_open;
     d.ge   = sc->gap_extend;
@@ -359,7 +363,12 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
                 return fail(h, LX_EINVAL, "matrix entry [%d][%d]=%d outside [-100,100]", a, b, v);
             d.mat[a * lx::kAlph + b]     = (int8_t)v;
             d.mat_adj[a * lx::kAlph + b] = (int8_t)(pad ? lx::kNegPad : v - sc->gap_extend);
+            int const adj                = v - sc->gap_extend;
+            if (!pad && (adj < -31 || adj > 31))
+                trace_ok = 0;
+            d.mat_trace[a * lx::kAlph + b] = (int8_t)(pad || adj < -31 || adj > 31 ? -126 : 4 * adj + 2);
         }
+    d.trace_ok = trace_ok;
     int rc = bind(h);
     if (rc)
         return rc;
@@ -367,6 +376,7 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
     LX_HIP(h, hipMemcpy(h->sc_dev[slot], &d, sizeof(d), hipMemcpyHostToDevice));
     h->sc_host[slot] = *sc;
     h->have_sc[slot] = true;
+    h->trace_ok[slot] = trace_ok != 0;
     return LX_OK;
 }
 
@@ -593,11 +603,16 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 
 // ---- pass 2 ------------------------------------------------------------------------------------------
 
+// Runs pass 2 over a device-resident list of `n` extension slots, in chunks sized to the trace budget.
+// src / d_count are set by the fused path (slots compacted by launch_select): results are then written to
+// out_hsp[src[slot]] / ops_off[src[slot]] and slots beyond *d_count are skipped on the device.
 static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
                           uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
-                          uint64_t max_q, uint64_t max_s)
+                          uint64_t max_q, uint64_t max_s, bool shared, uint32_t const * d_src = nullptr,
+                          uint64_t const * d_count = nullptr)
 {
-    int const G = lx::trace_group(), P = lx::trace_panel();
+    if (!h->trace_ok[slot])
+        return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
     if (max_s > 65535)
         return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
     int maxent = 0;
@@ -607,38 +622,45 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     if ((uint64_t)maxent * std::min(max_q, max_s) >= 65536)
         return fail(h, LX_EINVAL, "pass 2 packs scores in 16 bits: max entry %d x min(%llu,%llu) residues overflows", maxent,
                     (unsigned long long)max_q, (unsigned long long)max_s);
+    int const cfg = (shared && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1 : 0;
+    int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 3) & ~3ull);
-    uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G; // uint2 entries
-    uint64_t const per_ext    = stride * 8;
+    uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
+    uint64_t const per_ext    = stride * 4;
     uint64_t       chunk      = std::max<uint64_t>(1, h->opt_trace_bytes / std::max<uint64_t>(per_ext, 1));
     chunk                     = std::min<uint64_t>(chunk, n);
-    chunk                     = std::max<uint64_t>(4, chunk / 4 * 4);
+    chunk                     = std::max<uint64_t>(8, chunk / 8 * 8);
     int rc;
     if ((rc = ensure(h, h->d_trace, chunk * per_ext)) || (rc = ensure(h, h->d_ends, chunk * sizeof(lx::EndCell))))
         return rc;
     for (uint64_t c0 = 0; c0 < n; c0 += chunk)
     {
         lx::TraceParams p{};
-        p.q_res         = static_cast<uint8_t const *>(d_q);
-        p.s_res         = static_cast<uint8_t const *>(d_s);
-        p.ext           = d_ext + c0;
-        p.n             = std::min<uint64_t>(chunk, n - c0);
-        p.sc            = h->sc_dev[slot];
-        p.trace         = static_cast<uint2 *>(h->d_trace.ptr);
-        p.slot_stride   = stride;
-        p.steps_cap     = steps_cap;
-        p.panels_cap    = panels_cap;
-        p.ends          = static_cast<lx::EndCell *>(h->d_ends.ptr);
-        p.out_hsp       = d_hsp + c0;
-        p.out_ops       = d_ops;
-        p.ops_off       = d_ops_off + c0;
-        p.ws            = static_cast<int32_t *>(h->d_ws.ptr);
-        p.ws_top        = h->d_ws_top;
-        p.ws_cap        = (uint32_t)std::min<uint64_t>(h->d_ws.cap / 8, 0xffffffffu);
-        p.err           = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
-        p.nrows         = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
-        p.bs_match_rule = (int32_t)h->opt_bs_rule;
+        p.q_res          = static_cast<uint8_t const *>(d_q);
+        p.s_res          = static_cast<uint8_t const *>(d_s);
+        p.ext            = d_ext + c0;
+        p.n              = std::min<uint64_t>(chunk, n - c0);
+        p.sc             = h->sc_dev[slot];
+        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr);
+        p.slot_stride    = stride;
+        p.steps_cap      = steps_cap;
+        p.panels_cap     = panels_cap;
+        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
+        p.out_hsp        = d_src ? d_hsp : d_hsp + c0;
+        p.out_ops        = d_ops;
+        p.ops_off        = d_src ? d_ops_off : d_ops_off + c0;
+        p.src            = d_src ? d_src + c0 : nullptr;
+        p.count_ptr      = d_count;
+        p.chunk_start    = c0;
+        p.ws             = static_cast<int32_t *>(h->d_ws.ptr);
+        p.ws_top         = h->d_ws_top;
+        p.ws_cap         = (uint32_t)std::min<uint64_t>(h->d_ws.cap / 8, 0xffffffffu);
+        p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+        p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+        p.bs_match_rule  = (int32_t)h->opt_bs_rule;
+        p.shared_profile = shared ? 1 : 0;
+        p.cfg            = cfg;
         if (panels_cap > 1) // each chunk starts with an empty carry workspace
             LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
         LX_HIP(h, lx::launch_trace(p, stream));
@@ -678,7 +700,7 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     LX_HIP(h, hipEventRecord(h->ev0, stream));
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(d_ext), n,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
-                        static_cast<uint64_t const *>(d_ops_off), stream, max_q, max_s);
+                        static_cast<uint64_t const *>(d_ops_off), stream, max_q, max_s, false);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, stream));
@@ -710,7 +732,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         max_q     = std::max<uint64_t>(max_q, x.q_len);
         max_s     = std::max<uint64_t>(max_s, x.s_len);
         ops_bytes = std::max<uint64_t>(ops_bytes, ops_off[i] + x.q_len + x.s_len);
-        if ((int)x.q_len > lx::trace_panel())
+        if ((int)x.q_len > lx::trace_cfg_panel(0))
             carry_pairs += x.s_len;
     }
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
@@ -730,7 +752,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
     rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
                         static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
-                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s);
+                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, false);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, h->stream));
@@ -742,6 +764,71 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     for (uint64_t i = 0; i < n; ++i)
         if (out_hsp[i].score < 0)
             return fail(h, LX_EOVERFLOW, "extension %llu could not be traced (workspace exhausted)", (unsigned long long)i);
+    return LX_OK;
+}
+
+
+// ---- fused: pass 1 -> survivor selection -> pass 2, all on the device ------------------------------------
+
+int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
+                        uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
+                        void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream_)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!d_q_res || !d_s_res || !d_ext || !d_out_score || !d_out_hsp || !d_out_ops || !d_ops_off || !d_out_count)
+        return fail(h, LX_EINVAL, "NULL device pointer");
+    if (h->opt_max_qlen == 0 || h->opt_max_slen == 0)
+        return fail(h, LX_ESTATE, "lx_extend_batch_dev needs LX_OPT_MAX_QLEN and LX_OPT_MAX_SLEN (it never synchronises)");
+    if (n > 0xfffffff0ull)
+        return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
+
+    // pass 1 (src/search_algo.hpp:1246)
+    LX_HIP(h, hipEventRecord(h->ev0, stream));
+    if ((rc = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream)))
+        return rc;
+
+    // filter (:1251-1283) as an integer cut-off, compaction in input order, runs padded to whole wavefronts
+    bool const     shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
+    uint32_t const run    = shared ? (uint32_t)h->opt_query_run : 1u;
+    uint32_t const pad_to = shared ? 8u : 1u;
+    uint64_t const nruns  = (n + run - 1) / run;
+    uint64_t const cap    = n + (shared ? nruns * 7 : 0);
+    if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
+        (rc = ensure(h, h->d_sel_runs, (nruns + 1) * sizeof(uint64_t))))
+        return rc;
+    lx::SelectParams sp{};
+    sp.ext           = static_cast<lx::Extension const *>(d_ext);
+    sp.score         = static_cast<int32_t const *>(d_out_score);
+    sp.min_score     = static_cast<int32_t const *>(d_min_score);
+    sp.min_score_all = min_score_all;
+    sp.n             = n;
+    sp.run           = run;
+    sp.pad_to        = pad_to;
+    sp.run_slots     = static_cast<uint64_t *>(h->d_sel_runs.ptr);
+    sp.out_ext       = static_cast<lx::Extension *>(h->d_sel_ext.ptr);
+    sp.out_src       = static_cast<uint32_t *>(h->d_sel_src.ptr);
+    sp.out_count     = static_cast<uint64_t *>(d_out_count);
+    sp.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
+    LX_HIP(h, lx::launch_select(sp, stream));
+
+    // pass 2 on the survivors (:1293-1296); the grid covers the worst case, wavefronts beyond *d_out_count exit
+    rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,
+                        static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
+                        static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared,
+                        static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count));
+    if (rc)
+        return rc;
+    LX_HIP(h, hipEventRecord(h->ev1, stream));
+    h->timed = true;
     return LX_OK;
 }
 

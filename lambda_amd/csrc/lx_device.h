@@ -18,6 +18,11 @@ struct ScoringDev
     int32_t g2;       // go - ge
     int8_t  mat[kAlph * kAlph];     // original matrix[q*32+s], pad ranks = kNegPad
     int8_t  mat_adj[kAlph * kAlph]; // matrix[q*32+s] - ge (diagonal step in the skewed domain), pad ranks = kNegPad
+    // pass 2 works on values scaled by 4 whose two low bits carry the traceback tag: 4*(matrix - ge) + 2 (tag
+    // "diagonal"), pad ranks = -126.  Valid when every (matrix - ge) lies in [-31, 31] (trace_ok).
+    int8_t  mat_trace[kAlph * kAlph];
+    int32_t trace_ok;
+    int32_t reserved[3];
 };
 
 // Mirrors lx_extension in include/lambda_ext.h (static_assert'ed in lx_api.cpp).
@@ -72,22 +77,45 @@ struct TraceParams
     uint8_t const *    q_res;
     uint8_t const *    s_res;
     Extension const *  ext;   // this chunk's extensions
-    uint64_t           n;     // extensions in this chunk
+    uint64_t           n;     // extension slots in this chunk
     ScoringDev const * sc;
-    uint2 *            trace;       // [n][panels_cap][steps_cap][G] direction words (4 bits per cell)
-    uint64_t           slot_stride; // uint2 entries per extension = panels_cap * steps_cap * G
+    uint32_t *         trace;       // [n][panels_cap][steps_cap][G][words] direction words
+    uint64_t           slot_stride; // uint32 entries per extension = panels_cap * steps_cap * G * words
     uint32_t           steps_cap;   // bound on (Ls + G - 1) rounded up to 4
     uint32_t           panels_cap;  // bound on ceil(Lq / panel)
     EndCell *          ends;        // [n]
-    Hsp *              out_hsp;     // [n]
+    Hsp *              out_hsp;     // indexed by src[e] when src != nullptr, else by e
     uint8_t *          out_ops;
-    uint64_t const *   ops_off;     // [n] byte offset of each extension's ops slot (slot size q_len + s_len)
+    uint64_t const *   ops_off;     // byte offset of each extension's ops slot (slot size q_len + s_len), same indexing
+    uint32_t const *   src;         // optional: original index of each slot, 0xffffffff = padding slot (skipped)
+    uint64_t const *   count_ptr;   // optional: device-side number of valid slots of the whole list
+    uint64_t           chunk_start; // position of this chunk in that list
     int32_t *          ws;
     uint32_t *         ws_top;
     uint32_t           ws_cap;
     int32_t *          err;
     int32_t            nrows;
     int32_t            bs_match_rule; // computeAlignmentStats variant: 1 = match iff score(c0,c1)==score(c0,c0)
+    int32_t            shared_profile;
+    int32_t            cfg;           // 0 = (16,10), 1 = (8,19)
+};
+
+// survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,
+// with the e-value / bit-score tests turned into per-extension integer score cut-offs by the host)
+struct SelectParams
+{
+    Extension const * ext;
+    int32_t const *   score;
+    int32_t const *   min_score; // per extension, or nullptr -> min_score_all
+    int32_t           min_score_all;
+    uint64_t          n;
+    uint32_t          run;       // extensions come in runs of `run` entries sharing a query (0/1 = no runs)
+    uint32_t          pad_to;    // pad every run's survivors to a multiple of this many slots (1 = no padding)
+    uint64_t *        run_slots; // [nruns + 1] scratch: padded survivor count per run -> exclusive scan
+    Extension *       out_ext;   // [capacity]
+    uint32_t *        out_src;   // [capacity]
+    uint64_t *        out_count; // [0] = total slots, [1] = true survivors
+    Hsp *             out_hsp;   // optional [n]: rows of non-survivors are filled here (score, no alignment)
 };
 
 struct MaxLens

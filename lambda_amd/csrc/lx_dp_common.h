@@ -50,7 +50,7 @@ struct ScoreGeo
 // Build the profile rows for this lane's C columns of the panel starting at column col0 into LDS slot `slot_dw`.
 template <int G, int C>
 __device__ __forceinline__ void build_profile(uint32_t * lds, int slot_dw, int g, uint8_t const * q, int lq, int col0,
-                                              ScoringDev const * sc, int nrows, bool do_write)
+                                              int8_t const * table, int nrows, bool do_write)
 {
     using Geo = ScoreGeo<G, C>;
 #pragma unroll
@@ -65,7 +65,7 @@ __device__ __forceinline__ void build_profile(uint32_t * lds, int slot_dw, int g
             uint32_t  ql = kAlph - 1; // pad rank: row of kNegPad
             if (c < C && j < lq)
                 ql = q[j] & (kAlph - 1);
-            uint4 const * mrow = reinterpret_cast<uint4 const *>(sc->mat_adj + ql * kAlph);
+            uint4 const * mrow = reinterpret_cast<uint4 const *>(table + ql * kAlph);
             uint4 const   lo = mrow[0], hi = mrow[1];
             rows[cc][0] = lo.x; rows[cc][1] = lo.y; rows[cc][2] = lo.z; rows[cc][3] = lo.w;
             rows[cc][4] = hi.x; rows[cc][5] = hi.y; rows[cc][6] = hi.z; rows[cc][7] = hi.w;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
     for (int panel = 0; panel < npanels; ++panel)
     {
         int const col0 = panel * Geo::kPanel + g * C;
-        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc, nrows, !p.shared_profile || grp == 0);
+        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_adj, nrows, !p.shared_profile || grp == 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 

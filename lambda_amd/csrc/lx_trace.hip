@@ -3,21 +3,24 @@
 // Replaces _performAlignment<withTrace=true> (/root/reference/src/search_algo.hpp:1296 -> :1070-1134, config
 // TracebackOn<CompleteTrace, GapsLeft>, :1083) followed by seqan::_adaptTraceSegmentsTo (:1127) and the walk
 // seqan::computeAlignmentStats does over the gapped rows (:1308).  Only survivors of the e-value filter reach
-// this pass (:1251-1283), so it sees far fewer cells than pass 1.
+// this pass (:1251-1283).
 //
-// Kernel A (trace_forward_kernel): the same strip-systolic geometry and row-skewed recurrence as lx_score.hip
-// (G = 16 lanes x C = 10 columns), plus per cell
-//     * 4 direction bits:  code (2) = source of H {0 none (H<=0), 1 diagonal, 2 vertical gap F, 3 horizontal gap E}
-//       with the priority of a GapsLeft traceback (diagonal > vertical > horizontal; [UPSTREAM-RECALL], see
-//       oracle/lx_oracle.c), fx = "F of the row below extends this F" and ex = "E of the next column extends this E"
-//       (extension preferred over opening on ties).  One 64-bit word per lane per step, stored coalesced
-//       (128 B per group per step) to an HBM trace buffer laid out [extension][panel][step][lane].
-//     * the best cell with the reference's tie rule (first strict maximum in column-major order): per column a
-//       packed key  H << 16 | (65535 - row)  maximised with v_max_u32 (2 VALU ops per cell), reduced over
-//       columns / lanes / panels with "higher H, then lower column" at the end.  Limits: H < 65536, Ls < 65536
-//       (checked by the host side).
-// Kernel B (backtrace_kernel): one lane per extension walks the direction words from the best cell to the first
-// cell with code 0, emits one op byte per alignment column ('M','D','I') and the counts of lx_hsp.
+// Kernel A (trace_forward_kernel<G,C>): the strip-systolic geometry and row-skewed recurrence of lx_score.hip.
+// Direction bits cost no compares: every DP value is scaled by 4 and its two low bits carry a TAG, so that the
+// max instructions the recurrence needs anyway also resolve the traceback ties:
+//     tt = Hs[i-1][j-1] + (4(s-ge)+2)        tag 2 = diagonal   (the +2 is baked into the LDS profile)
+//     m  = max(max3(tt, E, F|1), Z|3)         tag 0 = horizontal gap E, 1 = vertical gap F, 3 = none (H <= 0)
+//          -> on equal values the larger tag wins: none > diagonal > vertical > horizontal, which is the priority of
+//             a GapsLeft traceback ([UPSTREAM-RECALL], oracle/lx_oracle.c)
+//     Fr = max(F|2, A|1),  Er = max(E|2, A|1)   A = H + go - ge:  bit 1 of the result = "gap EXTENDED" (extension
+//             wins ties, i.e. gaps are as long as possible where the score allows)
+// The low two bits of m, Fr, Er are funnel-shifted (v_alignbit_b32) into three plane words per lane per step and
+// stored coalesced to an HBM trace buffer [extension][panel][step][lane][plane-word].  The best cell under the
+// reference's tie rule (first strict maximum in column-major order) is tracked per column as a packed key
+// H << 16 | (65535 - row) with v_max_u32.  Limits (checked by the host): H < 65536, Ls < 65536, |s - ge| <= 31.
+//
+// Kernel B (backtrace_kernel): one lane per extension walks the planes from the best cell to the first cell with
+// tag "none", emits one op byte per alignment column ('M','D','I') and the counts of lx_hsp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,13 +30,18 @@
 namespace lx
 {
 
-constexpr int kTG = 16; // lanes per extension
-constexpr int kTC = 10; // columns per lane
-
-__global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
+template <int C>
+struct TraceWords
 {
-    constexpr int G = kTG, C = kTC;
+    static constexpr int kNW    = (C + 15) / 16; // words per plane
+    static constexpr int kWords = 3 * kNW;       // plane m, plane F, plane E
+};
+
+template <int G, int C>
+__global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(TraceParams p)
+{
     using Geo = ScoreGeo<G, C>;
+    using TW  = TraceWords<C>;
     extern __shared__ uint32_t lds[];
 
     int const  lane     = threadIdx.x;
@@ -42,26 +50,50 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
     bool const is_first = (g == 0);
     bool const is_last  = (g == G - 1);
 
-    uint64_t const e      = (uint64_t)blockIdx.x * Geo::kGroups + grp;
-    bool const     active = e < p.n;
+    uint64_t const e     = (uint64_t)blockIdx.x * Geo::kGroups + grp;
+    uint64_t       limit = p.n;
+    if (p.count_ptr)
+    {
+        uint64_t const total = *p.count_ptr;
+        limit = total > p.chunk_start ? min(p.n, total - p.chunk_start) : 0;
+        if ((uint64_t)blockIdx.x * Geo::kGroups >= limit)
+            return; // whole wavefront beyond the device-side survivor count
+    }
+    bool active = e < limit;
+    if (active && p.src && p.src[e] == 0xffffffffu)
+        active = false; // padding slot (keeps one query per wavefront)
 
     ScoringDev const * __restrict__ sc = p.sc;
-    int const      ge    = sc->ge;
-    int const      g2    = sc->g2;
+    int const      ge4   = 4 * sc->ge;
+    int const      g21   = 4 * sc->g2 + 1;
     int const      nrows = p.nrows;
     uint32_t const padt  = (uint32_t)(nrows - 1);
 
     int             lq = 0, ls = 0;
     uint8_t const * q = p.q_res;
     uint8_t const * s = p.s_res;
-    if (active)
+    uint64_t        q_off = 0;
+    bool const      in_list = e < limit;
+    if (in_list)
     {
         Extension const x = p.ext[e];
-        lq = (int)x.q_len;
-        ls = (int)x.s_len;
+        lq    = (int)x.q_len;
+        q_off = x.q_off;
         q += x.q_off;
-        if (ls != 0)
-            s += x.s_off;
+        if (active)
+        {
+            ls = (int)x.s_len;
+            if (ls != 0)
+                s += x.s_off;
+        }
+    }
+    if (p.shared_profile)
+    {
+        uint64_t const q0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q_off >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q_off);
+        int const l0 = __builtin_amdgcn_readfirstlane(lq);
+        if (in_list && (q_off != q0 || lq != l0))
+            atomicExch(p.err, 2);
     }
 
     int       ls_max    = ls;
@@ -88,7 +120,7 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
     {
         uint32_t base = 0;
         int      ok   = 1;
-        if (is_first && my_panels > 1)
+        if (is_first && my_panels > 1 && active)
         {
             base = atomicAdd(p.ws_top, (uint32_t)ls);
             if (base + (uint32_t)ls > p.ws_cap)
@@ -116,26 +148,22 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
         bad = b != 0;
     }
     if (bad)
-    {
-        lq = 0;
         ls = 0;
-    }
 
-    int const          slot_dw   = grp * (nrows * Geo::kRowDw);
+    int const          slot_dw   = p.shared_profile ? 0 : grp * (nrows * Geo::kRowDw);
     uint32_t const     row_base  = (uint32_t)(slot_dw + g) * 4u;
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
     int const          steps     = (ls_max + G - 1 + 3) & ~3;
     uint32_t const     lsc       = (uint32_t)max(ls, 1) - 1u;
 
-    uint2 * tr = p.trace + e * p.slot_stride + g; // + (panel * steps_cap + k) * G
+    uint32_t * tr = p.trace + e * p.slot_stride + (uint32_t)g * TW::kWords; // + (panel * steps_cap + k) * G * kWords
 
-    // best cell so far over all finished panels: (H, column+1, row+1)
     int best_h = 0, best_q = 0, best_s = 0;
 
     for (int panel = 0; panel < npanels; ++panel)
     {
         int const col0 = panel * Geo::kPanel + g * C;
-        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc, nrows, true);
+        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_trace, nrows, !p.shared_profile || grp == 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -143,21 +171,22 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
         bool const do_carry_out = is_last && (panel + 1 < my_panels) && carry != nullptr;
         bool const store_trace  = active && !bad && (panel < my_panels);
 
-        int z = ge * g;
-        int Hrow[C], F0[C];
+        // all values are 4 x (skewed value); Z = 4 z_i
+        int Z = ge4 * g;
+        int Hrow[C], F1[C];
         uint32_t colkey[C];
 #pragma unroll
         for (int c = 0; c < C; ++c)
         {
-            Hrow[c]   = z + ge;
-            F0[c]     = z;
+            Hrow[c]   = Z + ge4;     // "H = 0" of the previous (virtual) row
+            F1[c]     = 4 * kNegInf + 1;
             colkey[c] = 0;
         }
-        int diag0 = z + ge;
-        int sendH = z + ge;
-        int sendE = kNegInf;
+        int diag0 = Z + ge4;
+        int sendH = Z + ge4;
+        int sendE = 4 * kNegInf;
 
-        uint2 * trp = tr + (uint64_t)panel * p.steps_cap * G;
+        uint32_t * trp = tr + (uint64_t)panel * p.steps_cap * (G * TW::kWords);
 
         auto step = [&](int k, uint32_t t)
         {
@@ -168,7 +197,7 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
             for (int d = 0; d < Geo::kD; ++d)
                 pw[d] = prow[d * G];
 
-            int bndH = z, bndE = kNegInf;
+            int bndH = Z, bndE = 4 * kNegInf;
             if (use_carry_in && (unsigned)i < (unsigned)ls)
             {
                 bndH = carry[2 * i];
@@ -180,40 +209,51 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
             int dg = diag0;
             diag0  = recvH;
 
-            int const      zn = z - ge;
-            // key = ((Hs - z) << 16) | (65535 - row)  ==  (Hs << 16) + K   (mod 2^32)
-            uint32_t const K  = (uint32_t)(-z) * 65536u + ((65535u - (uint32_t)i) & 0xffffu);
-            uint32_t       wlo = 0, whi = 0;
-            int            h   = 0;
+            int const      Z3 = Z | 3;
+            // key = ((Hs - z) << 16) | (65535 - row)  ==  (hc << 14) + K   (mod 2^32), hc = 4 Hs
+            uint32_t const K  = (uint32_t)(-Z) * 16384u + ((65535u - (uint32_t)i) & 0xffffu);
+            uint32_t       wm[TW::kNW], wf[TW::kNW], we[TW::kNW];
+#pragma unroll
+            for (int w = 0; w < TW::kNW; ++w)
+                wm[w] = wf[w] = we[w] = 0;
+            int hc = 0;
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
                 int const sub = (int)(int8_t)(pw[c >> 2] >> (8 * (c & 3)));
-                int const tt  = dg + sub;
+                int const tt  = dg + sub;                        // tag 2
                 dg            = Hrow[c];
-                int const f   = F0[c];
-                h             = max3i(tt, Ecur, f);
-                int const A   = h + g2;
-                // direction bits
-                uint32_t const code = (h == z) ? 0u : ((tt == h) ? 1u : ((f == h) ? 2u : 3u));
-                uint32_t const nib  = code | ((f >= A) ? 4u : 0u) | ((Ecur >= A) ? 8u : 0u);
-                if (c < 8)
-                    wlo |= nib << (4 * c);
-                else
-                    whi |= nib << (4 * (c - 8));
-                F0[c]   = max3i(f, A, zn);
-                LX_OPAQUE(F0[c]);
-                Ecur    = max(Ecur, A) + ge;
-                Hrow[c] = h;
-                uint32_t const key = ((uint32_t)h << 16) + K;
+                int m         = max3i(tt, Ecur, F1[c]);          // E tag 0, F tag 1
+                m             = max(m, Z3);                      // none tag 3
+                LX_OPAQUE(m);
+                hc            = m & ~3;
+                int const A1  = hc + g21;                        // open candidate, tag 1
+                int const Fr  = max(F1[c] | 2, A1);              // tag 3 = extended, 1 = opened
+                F1[c]         = Fr & ~2;
+                int const Er  = max(Ecur | 2, A1);               // tag 2 = extended, 1 = opened
+                Ecur          = (Er & ~3) + ge4;
+                wm[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)m, wm[c >> 4], 2);
+                wf[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)Fr, wf[c >> 4], 2);
+                we[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)Er, we[c >> 4], 2);
+                Hrow[c]       = hc;
+                uint32_t const key = ((uint32_t)hc << 14) + K;
                 colkey[c]          = max(colkey[c], key);
             }
-            sendH = h;
+            sendH = hc;
             sendE = Ecur;
-            z     = zn;
+            Z     = Z - ge4;
 
             if (store_trace)
-                trp[(uint32_t)k * G] = make_uint2(wlo, whi);
+            {
+                uint32_t * dst = trp + (uint32_t)k * (G * TW::kWords);
+#pragma unroll
+                for (int w = 0; w < TW::kNW; ++w)
+                {
+                    dst[3 * w + 0] = wm[w];
+                    dst[3 * w + 1] = wf[w];
+                    dst[3 * w + 2] = we[w];
+                }
+            }
             if (do_carry_out && (unsigned)i < (unsigned)ls)
             {
                 carry[2 * i]     = sendH;
@@ -248,7 +288,7 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
             uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
             mask_checked(k0, tc);
             fetch_checked(k0 + 4, tn);
-#pragma unroll
+#pragma unroll 2
             for (int u = 0; u < 4; ++u)
                 step(k0 + u, tc[u]);
         }
@@ -267,8 +307,8 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
 #pragma unroll
         for (int off = 1; off < G; off <<= 1)
         {
-            uint32_t const ok = (uint32_t)__shfl_xor((int)bk, off);
-            int const      oc = __shfl_xor(bcol, off);
+            uint32_t const ok   = (uint32_t)__shfl_xor((int)bk, off);
+            int const      oc   = __shfl_xor(bcol, off);
             bool const     take = ((ok >> 16) > (bk >> 16)) || ((ok >> 16) == (bk >> 16) && oc < bcol);
             bk   = take ? ok : bk;
             bcol = take ? oc : bcol;
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
         __builtin_amdgcn_wave_barrier();
     }
 
-    if (active && is_first)
+    if (in_list && is_first)
     {
         EndCell ec;
         ec.score = bad ? -1 : best_h;
@@ -302,50 +342,67 @@ __global__ __launch_bounds__(64) void trace_forward_kernel(TraceParams p)
 }
 
 // One lane per extension.
+template <int G, int C>
 __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
 {
-    constexpr int G = kTG, C = kTC;
+    using TW        = TraceWords<C>;
     constexpr int P = G * C;
-    uint64_t const e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.n)
+    uint64_t const e     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t       limit = p.n;
+    if (p.count_ptr)
+    {
+        uint64_t const total = *p.count_ptr;
+        limit = total > p.chunk_start ? min(p.n, total - p.chunk_start) : 0;
+    }
+    if (e >= limit)
         return;
+    uint64_t oi = e;
+    if (p.src)
+    {
+        uint32_t const sidx = p.src[e];
+        if (sidx == 0xffffffffu)
+            return; // padding slot
+        oi = sidx;
+    }
     EndCell const   ec = p.ends[e];
     Extension const x  = p.ext[e];
     Hsp             out{};
     if (ec.score <= 0)
     {
         out.score = ec.score < 0 ? -1 : 0;
-        p.out_hsp[e] = out;
+        p.out_hsp[oi] = out;
         return;
     }
-    uint8_t const * q    = p.q_res + x.q_off;
-    uint8_t const * s    = p.s_res + x.s_off;
-    int8_t const *  mat  = p.sc->mat;
-    uint2 const *   tr   = p.trace + e * p.slot_stride;
-    uint8_t *       ops  = p.out_ops + p.ops_off[e];
-    uint32_t const  cap  = x.q_len + x.s_len;
+    uint8_t const *  q   = p.q_res + x.q_off;
+    uint8_t const *  s   = p.s_res + x.s_off;
+    int8_t const *   mat = p.sc->mat;
+    uint32_t const * tr  = p.trace + e * p.slot_stride;
+    uint8_t *        ops = p.out_ops + p.ops_off[oi];
+    uint32_t const   cap = x.q_len + x.s_len;
 
-    auto nibble = [&](int i, int j) -> uint32_t
+    // plane = 0 (H source tag), 1 (F result tag), 2 (E result tag); returns the cell's two tag bits
+    auto tag = [&](int i, int j, int plane) -> uint32_t
     {
-        int const   panel = j / P, r = j - panel * P;
-        int const   g = r / C, c = r - g * C;
-        uint2 const w = tr[((uint64_t)panel * p.steps_cap + (uint32_t)(i + g)) * G + g];
-        return ((c < 8 ? w.x >> (4 * c) : w.y >> (4 * (c - 8)))) & 15u;
+        int const      panel = j / P, r = j - panel * P;
+        int const      g = r / C, c = r - g * C;
+        int const      w = c >> 4, cw = c & 15;
+        int const      cnt = (w == TW::kNW - 1) ? (C - 16 * w) : 16;
+        uint32_t const word = tr[(((uint64_t)panel * p.steps_cap + (uint32_t)(i + g)) * G + g) * TW::kWords + 3 * w + plane];
+        return (word >> (32 - 2 * cnt + 2 * cw)) & 3u;
     };
 
     int      i = ec.s_end - 1, j = ec.q_end - 1;
     int      st = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
     uint32_t n  = 0;
-    int      last = 0; // last op emitted while walking backwards (0 none, 'M', 'D', 'I')
     int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
-    while (i >= 0 && j >= 0)
+    while (i >= 0 && j >= 0 && n < cap)
     {
         if (st == 0)
         {
-            uint32_t const code = nibble(i, j) & 3u;
-            if (code == 0)
-                break;
-            if (code == 1)
+            uint32_t const code = tag(i, j, 0);
+            if (code == 3)
+                break; // trace NONE: H <= 0
+            if (code == 2)
             {
                 uint8_t const c0 = q[j] & (kAlph - 1), c1 = s[i] & (kAlph - 1);
                 int const     v  = mat[c0 * kAlph + c1];
@@ -355,48 +412,42 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
                 np += (v > 0);
                 ops[cap - 1 - n] = 'M';
                 ++n;
-                last = 'M';
                 --i;
                 --j;
             }
             else
-                st = (code == 2) ? 1 : 2;
+                st = (code == 1) ? 1 : 2;
         }
         else if (st == 1)
         {
             ops[cap - 1 - n] = 'D';
             ++n;
-            // walking backwards: a gap run [open, ext, ext...] is met from its end
-            gx += 1; // provisionally an extension; the run's first character is re-labelled as the open below
-            bool const ext = (i >= 1) && ((nibble(i - 1, j) >> 2) & 1u);
+            // F[i][j] was produced at row i-1: bit 1 of that cell's F-plane tag = "extended"
+            bool const ext = (i >= 1) && ((tag(i - 1, j, 1) >> 1) & 1u);
             --i;
-            if (!ext)
+            if (ext)
+                gx += 1;
+            else
             {
-                gx -= 1;
                 go += 1;
                 st = 0;
             }
-            last = 'D';
         }
         else
         {
             ops[cap - 1 - n] = 'I';
             ++n;
-            gx += 1;
-            bool const ext = (j >= 1) && ((nibble(i, j - 1) >> 3) & 1u);
+            bool const ext = (j >= 1) && ((tag(i, j - 1, 2) >> 1) & 1u);
             --j;
-            if (!ext)
+            if (ext)
+                gx += 1;
+            else
             {
-                gx -= 1;
                 go += 1;
                 st = 0;
             }
-            last = 'I';
         }
-        if (n >= cap)
-            break;
     }
-    (void)last;
     // move the ops to the front of the slot, in begin -> end order
     uint32_t const first = cap - n;
     if (first != 0)
@@ -414,7 +465,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     out.num_positives      = np;
     out.num_gap_opens      = go;
     out.num_gap_extensions = gx;
-    p.out_hsp[e]           = out;
+    p.out_hsp[oi]          = out;
 }
 
 __global__ void max_lens_kernel(Extension const * ext, uint64_t n, MaxLens * out)
@@ -440,25 +491,34 @@ __global__ void max_lens_kernel(Extension const * ext, uint64_t n, MaxLens * out
 
 // ---- host-visible launchers ---------------------------------------------------------------------------
 
-int trace_panel() { return kTG * kTC; }
-int trace_group() { return kTG; }
+// trace geometries: cfg 0 = (16,10) [any query length, multi-panel], cfg 1 = (8,19) [<= 152 columns, shared profile]
+int trace_cfg_panel(int cfg) { return cfg == 1 ? 8 * 19 : 16 * 10; }
+int trace_cfg_group(int cfg) { return cfg == 1 ? 8 : 16; }
+int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : TraceWords<10>::kWords; }
+
+template <int G, int C>
+static hipError_t launch_trace_cfg(TraceParams const & p, hipStream_t stream)
+{
+    using Geo = ScoreGeo<G, C>;
+    uint64_t const blocks = (p.n + Geo::kGroups - 1) / Geo::kGroups;
+    if (blocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    int const    slots = p.shared_profile ? 1 : Geo::kGroups;
+    size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    hipLaunchKernelGGL((trace_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    uint64_t const b2 = (p.n + 63) / 64;
+    hipLaunchKernelGGL((backtrace_kernel<G, C>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_trace(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    using Geo = ScoreGeo<kTG, kTC>;
-    uint64_t const blocks = (p.n + Geo::kGroups - 1) / Geo::kGroups;
-    if (blocks > 0x7fffffffull)
-        return hipErrorInvalidValue;
-    size_t const lds = (size_t)Geo::kGroups * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
-    hipLaunchKernelGGL(trace_forward_kernel, dim3((unsigned)blocks), dim3(64), lds, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
-    uint64_t const b2 = (p.n + 63) / 64;
-    hipLaunchKernelGGL(backtrace_kernel, dim3((unsigned)b2), dim3(64), 0, stream, p);
-    return hipGetLastError();
+    return p.cfg == 1 ? launch_trace_cfg<8, 19>(p, stream) : launch_trace_cfg<16, 10>(p, stream);
 }
 
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream)

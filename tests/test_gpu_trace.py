@@ -179,3 +179,56 @@ def test_iterate_matches_driver(handle, oracle, filters):
         # same formulas, same libm: equal to the last bit; the contract is 1e-6 relative
         assert abs(g["bit_score"] - w["bit_score"]) <= 1e-6 * abs(w["bit_score"])
         assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])
+
+
+@pytest.mark.parametrize("wpq,run", [(32, 32), (8, 8), (7, 0)])
+def test_fused_extend_on_device(handle, oracle, wpq, run):
+    """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2."""
+    import torch
+
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_batch_np(90, 150, wpq, seed=1234 + wpq)
+    n = len(ext)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    cutoff = 70
+    handle.set_option(capi.LX_OPT_MAX_QLEN, 150)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, 176)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, run)
+    torch.cuda.synchronize()
+    try:
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    got_score = d_score.cpu().numpy()
+    assert (got_score == want_score).all()
+    surv = np.nonzero(want_score >= cutoff)[0]
+    cnt = d_count.cpu().numpy()
+    assert cnt[1] == len(surv) and cnt[0] >= cnt[1] and 10 < len(surv) < n
+    hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+    ops = d_ops.cpu().numpy()
+    rejected = np.setdiff1d(np.arange(n), surv)
+    assert (hsp["score"][rejected] == want_score[rejected]).all() and (hsp["n_ops"][rejected] == 0).all()
+    want = oracle.align_batch(q, s, ext[surv], osc)
+    for i, (oh, oops) in zip(surv, want):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        assert bytes(ops[int(off[i]): int(off[i]) + oh.n_ops]) == oops
