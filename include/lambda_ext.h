@@ -80,7 +80,8 @@ typedef struct lx_hsp
     int32_t n_ops;          /* alignment columns written to the ops buffer      */
     int32_t num_matches, num_mismatches, num_positives;
     int32_t num_gap_opens, num_gap_extensions;
-    int32_t reserved;
+    int32_t ops_shift;      /* the n_ops bytes start at ops_off[i] + ops_shift (the walk fills the slot back to front;
+                               ops_shift = q_len + s_len - n_ops) */
 } lx_hsp;
 
 /* src/search_datastructures.hpp:46-61 */
@@ -114,7 +115,7 @@ enum
     LX_OPT_WORKSPACE_BYTES = 3,
     LX_OPT_MAX_SLEN        = 4, /* longest subject slice the *_dev calls will see (0 = unknown: measured on the
                                    device, which costs lx_align_batch_dev one stream synchronisation)          */
-    LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 4 GiB); larger batches are
+    LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 32 GiB); larger batches are
                                    processed in chunks, in order, on the same stream                            */
     LX_OPT_BS_MATCH_RULE   = 6  /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
@@ -143,8 +144,9 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
                        uint64_t n, void * d_out_score, void * stream);
 
 /* ---- pass 2: traceback  (replaces _performAlignment<true>, src/search_algo.hpp:1296) --------- */
-/* ops: one byte per alignment column ('M','D','I'; 'D' = gap in the query row), extension i writes
- * out_hsp[i].n_ops bytes starting at out_ops + ops_off[i]; the caller sizes that slot to q_len+s_len. */
+/* ops: one byte per alignment column ('M','D','I'; 'D' = gap in the query row), begin -> end order.  The caller gives
+ * extension i a slot of q_len+s_len bytes at out_ops + ops_off[i]; its out_hsp[i].n_ops bytes are written at the END
+ * of that slot, i.e. they start at out_ops + ops_off[i] + out_hsp[i].ops_shift. */
 int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
                    uint64_t s_bytes, lx_extension const * ext, uint64_t n, lx_hsp * out_hsp, uint8_t * out_ops,
                    uint64_t const * ops_off);

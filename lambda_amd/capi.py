@@ -70,7 +70,7 @@ class Scoring(C.Structure):
 EXT_DTYPE = np.dtype([("q_off", "<u8"), ("s_off", "<u8"), ("q_len", "<u4"), ("s_len", "<u4")])
 HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
                       ("n_ops", "<i4"), ("num_matches", "<i4"), ("num_mismatches", "<i4"), ("num_positives", "<i4"),
-                      ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"), ("reserved", "<i4")])
+                      ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"), ("ops_shift", "<i4")])
 MATCH_DTYPE = np.dtype([("qryId", "<u8"), ("subjId", "<u8"), ("qryStart", "<u8"), ("qryEnd", "<u8"),
                         ("subjStart", "<u8"), ("subjEnd", "<u8")])
 SEED_DTYPE = np.dtype([("q_off", "<u8"), ("s_off", "<u8"), ("q_len", "<u4"), ("s_len", "<u4"),
@@ -233,7 +233,8 @@ class Handle:
         ops = np.zeros(int(ops_off[-1]) + 1, dtype=np.uint8)
         self._check(self.lib.lx_align_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext), n,
                                             _ptr(hsp), _ptr(ops), _ptr(ops_off)))
-        ops_list = [bytes(ops[int(ops_off[i]):int(ops_off[i]) + int(hsp["n_ops"][i])]) for i in range(n)]
+        st = ops_off[:n].astype(np.int64) + hsp["ops_shift"].astype(np.int64)
+        ops_list = [bytes(ops[int(st[i]):int(st[i]) + int(hsp["n_ops"][i])]) for i in range(n)]
         return hsp, ops_list
 
     def prefilter_batch(self, q_res, s_res, seeds, seed_length: int, pre_scoring: int, thresh: float, slot: int = 0):

@@ -268,7 +268,7 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
         bm.e_value   = (params->max_evalue < 0) ? evalue(a.score, qLength) : s.eValue;                        // :1321-1322
         bm.ops_off   = res->ops.size();
         bm.n_ops     = (uint32_t)a.n_ops;
-        res->ops.insert(res->ops.end(), ops.begin() + opsOff[k], ops.begin() + opsOff[k] + a.n_ops);
+        res->ops.insert(res->ops.end(), ops.begin() + opsOff[k] + a.ops_shift, ops.begin() + opsOff[k] + a.ops_shift + a.n_ops);
         res->matches.push_back(bm);
     }
     *out = res;

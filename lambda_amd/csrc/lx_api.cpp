@@ -74,7 +74,7 @@ struct lx_handle
     uint64_t opt_query_run = 0;
     uint64_t opt_ws_bytes  = 64ull << 20;
     uint64_t opt_max_slen  = 0;
-    uint64_t opt_trace_bytes = 4ull << 30;
+    uint64_t opt_trace_bytes = 32ull << 30;
     uint64_t opt_bs_rule   = 0;
 };
 

@@ -43,7 +43,7 @@ struct Hsp
     int32_t n_ops;
     int32_t num_matches, num_mismatches, num_positives;
     int32_t num_gap_opens, num_gap_extensions;
-    int32_t reserved;
+    int32_t ops_shift;
 };
 
 struct ScoreParams

@@ -53,7 +53,7 @@ __device__ __forceinline__ void build_profile(uint32_t * lds, int slot_dw, int g
                                               int8_t const * table, int nrows, bool do_write)
 {
     using Geo = ScoreGeo<G, C>;
-#pragma unroll
+#pragma unroll 1 // one group of 4 columns at a time: unrolled, the 2 x 16 B loads of all C columns would be hoisted (8 C VGPRs)
     for (int d = 0; d < Geo::kD; ++d)
     {
         uint32_t rows[4][8];

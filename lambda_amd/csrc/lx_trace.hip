@@ -12,10 +12,12 @@
 //     m  = max(max3(tt, E, F|1), Z|3)         tag 0 = horizontal gap E, 1 = vertical gap F, 3 = none (H <= 0)
 //          -> on equal values the larger tag wins: none > diagonal > vertical > horizontal, which is the priority of
 //             a GapsLeft traceback ([UPSTREAM-RECALL], oracle/lx_oracle.c)
-//     Fr = max(F|2, A|1),  Er = max(E|2, A|1)   A = H + go - ge:  bit 1 of the result = "gap EXTENDED" (extension
+//     Fr = max(F|1, A),  Er = max(E|1, A)       A = H + go - ge:  bit 0 of the result = "gap EXTENDED" (extension
 //             wins ties, i.e. gaps are as long as possible where the score allows)
-// The low two bits of m, Fr, Er are funnel-shifted (v_alignbit_b32) into three plane words per lane per step and
-// stored coalesced to an HBM trace buffer [extension][panel][step][lane][plane-word].  The best cell under the
+// The two tag bits of m and bit 0 of Fr and Er -- 4 bits per cell -- are funnel-shifted (v_alignbit_b32) into
+// ceil(C/8) words per lane per step and stored to an HBM trace buffer laid out [extension][panel][lane][step][word]:
+// every lane appends to its own stream (L2 write-combines the 8-12 B pieces), and the backtrace, which mostly moves
+// from step k to k-1 in the same lane, finds consecutive steps in the same 64-byte sector.  The best cell under the
 // reference's tie rule (first strict maximum in column-major order) is tracked per column as a packed key
 // H << 16 | (65535 - row) with v_max_u32.  Limits (checked by the host): H < 65536, Ls < 65536, |s - ge| <= 31.
 //
@@ -33,12 +35,11 @@ namespace lx
 template <int C>
 struct TraceWords
 {
-    static constexpr int kNW    = (C + 15) / 16; // words per plane
-    static constexpr int kWords = 3 * kNW;       // plane m, plane F, plane E
+    static constexpr int kWords = (C + 7) / 8; // 4 direction bits per cell, 8 cells per 32-bit word
 };
 
 template <int G, int C>
-__global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(TraceParams p)
+__global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
     using TW  = TraceWords<C>;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge4   = 4 * sc->ge;
-    int const      g21   = 4 * sc->g2 + 1;
+    int const      g20   = 4 * sc->g2;
     int const      nrows = p.nrows;
     uint32_t const padt  = (uint32_t)(nrows - 1);
 
@@ -156,7 +157,8 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
     int const          steps     = (ls_max + G - 1 + 3) & ~3;
     uint32_t const     lsc       = (uint32_t)max(ls, 1) - 1u;
 
-    uint32_t * tr = p.trace + e * p.slot_stride + (uint32_t)g * TW::kWords; // + (panel * steps_cap + k) * G * kWords
+    // trace[e][panel][g][k][word]
+    uint32_t * tr = p.trace + e * p.slot_stride + (uint64_t)g * p.steps_cap * TW::kWords;
 
     int best_h = 0, best_q = 0, best_s = 0;
 
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
         for (int c = 0; c < C; ++c)
         {
             Hrow[c]   = Z + ge4;     // "H = 0" of the previous (virtual) row
-            F1[c]     = 4 * kNegInf + 1;
+            F1[c]     = 4 * kNegInf + 1; // vertical gap state, always carries tag 1
             colkey[c] = 0;
         }
         int diag0 = Z + ge4;
@@ -212,10 +214,10 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
             int const      Z3 = Z | 3;
             // key = ((Hs - z) << 16) | (65535 - row)  ==  (hc << 14) + K   (mod 2^32), hc = 4 Hs
             uint32_t const K  = (uint32_t)(-Z) * 16384u + ((65535u - (uint32_t)i) & 0xffffu);
-            uint32_t       wm[TW::kNW], wf[TW::kNW], we[TW::kNW];
+            uint32_t       w[TW::kWords];
 #pragma unroll
-            for (int w = 0; w < TW::kNW; ++w)
-                wm[w] = wf[w] = we[w] = 0;
+            for (int x = 0; x < TW::kWords; ++x)
+                w[x] = 0;
             int hc = 0;
 #pragma unroll
             for (int c = 0; c < C; ++c)
@@ -227,14 +229,16 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
                 m             = max(m, Z3);                      // none tag 3
                 LX_OPAQUE(m);
                 hc            = m & ~3;
-                int const A1  = hc + g21;                        // open candidate, tag 1
-                int const Fr  = max(F1[c] | 2, A1);              // tag 3 = extended, 1 = opened
-                F1[c]         = Fr & ~2;
-                int const Er  = max(Ecur | 2, A1);               // tag 2 = extended, 1 = opened
+                int const A0  = hc + g20;                        // gap-open candidate, tag 0
+                int const Fr  = max(F1[c], A0);                  // tag 1 = extended (wins ties), 0 = opened
+                F1[c]         = Fr | 1;
+                int const Er  = max(Ecur | 1, A0);               // tag 1 = extended, 0 = opened
                 Ecur          = (Er & ~3) + ge4;
-                wm[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)m, wm[c >> 4], 2);
-                wf[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)Fr, wf[c >> 4], 2);
-                we[c >> 4]    = __builtin_amdgcn_alignbit((uint32_t)Er, we[c >> 4], 2);
+                uint32_t wc   = w[c >> 3];
+                wc            = __builtin_amdgcn_alignbit((uint32_t)m, wc, 2);
+                wc            = __builtin_amdgcn_alignbit((uint32_t)Fr, wc, 1);
+                wc            = __builtin_amdgcn_alignbit((uint32_t)Er, wc, 1);
+                w[c >> 3]     = wc;
                 Hrow[c]       = hc;
                 uint32_t const key = ((uint32_t)hc << 14) + K;
                 colkey[c]          = max(colkey[c], key);
@@ -245,14 +249,10 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
 
             if (store_trace)
             {
-                uint32_t * dst = trp + (uint32_t)k * (G * TW::kWords);
+                uint32_t * dst = trp + (uint32_t)k * TW::kWords;
 #pragma unroll
-                for (int w = 0; w < TW::kNW; ++w)
-                {
-                    dst[3 * w + 0] = wm[w];
-                    dst[3 * w + 1] = wf[w];
-                    dst[3 * w + 2] = we[w];
-                }
+                for (int x = 0; x < TW::kWords; ++x)
+                    dst[x] = w[x];
             }
             if (do_carry_out && (unsigned)i < (unsigned)ls)
             {
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 2)) void trace_forward_kernel(Tr
             uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
             mask_checked(k0, tc);
             fetch_checked(k0 + 4, tn);
-#pragma unroll 2
+#pragma unroll 1 // one step already holds C independent cells; unrolling steps only costs VGPRs (occupancy)
             for (int u = 0; u < 4; ++u)
                 step(k0 + u, tc[u]);
         }
@@ -347,6 +347,10 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
 {
     using TW        = TraceWords<C>;
     constexpr int P = G * C;
+    __shared__ int8_t smat[kAlph * kAlph];
+    for (int x = threadIdx.x; x < kAlph * kAlph / 4; x += blockDim.x)
+        reinterpret_cast<uint32_t *>(smat)[x] = reinterpret_cast<uint32_t const *>(p.sc->mat)[x];
+    __syncthreads();
     uint64_t const e     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t       limit = p.n;
     if (p.count_ptr)
@@ -375,84 +379,136 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     }
     uint8_t const *  q   = p.q_res + x.q_off;
     uint8_t const *  s   = p.s_res + x.s_off;
-    int8_t const *   mat = p.sc->mat;
     uint32_t const * tr  = p.trace + e * p.slot_stride;
     uint8_t *        ops = p.out_ops + p.ops_off[oi];
     uint32_t const   cap = x.q_len + x.s_len;
 
-    // plane = 0 (H source tag), 1 (F result tag), 2 (E result tag); returns the cell's two tag bits
-    auto tag = [&](int i, int j, int plane) -> uint32_t
+    // the cell's 4 direction bits: [1:0] = source of H (3 none, 2 diagonal, 1 vertical gap, 0 horizontal gap),
+    // [2] = the vertical gap of the row below EXTENDS this cell's, [3] = the horizontal gap of the next column does
+    auto nibble = [&](int i, int j) -> uint32_t
     {
         int const      panel = j / P, r = j - panel * P;
         int const      g = r / C, c = r - g * C;
-        int const      w = c >> 4, cw = c & 15;
-        int const      cnt = (w == TW::kNW - 1) ? (C - 16 * w) : 16;
-        uint32_t const word = tr[(((uint64_t)panel * p.steps_cap + (uint32_t)(i + g)) * G + g) * TW::kWords + 3 * w + plane];
-        return (word >> (32 - 2 * cnt + 2 * cw)) & 3u;
+        int const      x = c >> 3, cx = c & 7;
+        int const      cnt = (x == TW::kWords - 1) ? (C - 8 * x) : 8; // cells held by this word
+        uint32_t const word = tr[(((uint64_t)panel * G + g) * p.steps_cap + (uint32_t)(i + g)) * TW::kWords + x];
+        return (word >> (32 - 4 * cnt + 4 * cx)) & 15u;
     };
 
+    // The walk is bound by the number of scattered memory accesses (0.24 G steps per headline batch), so each step
+    // touches as little as possible: one direction word (consecutive steps of a lane share a cache line), residues
+    // from two register-cached aligned dwords (refilled every 4th step), the score matrix from LDS, and the op
+    // bytes collected into whole dwords before they are stored.
+    // mode F / E = "the gap character emitted last still has to be classified": this cell's bit 2 / 3 says
+    // whether that gap EXTENDS this cell's gap state (then this cell is a gap cell too) or OPENED from its H.
     int      i = ec.s_end - 1, j = ec.q_end - 1;
-    int      st = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
-    uint32_t n  = 0;
+    int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
+    uint32_t n    = 0;
     int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
+
+    uintptr_t const qa = reinterpret_cast<uintptr_t>(q), sa = reinterpret_cast<uintptr_t>(s);
+    uintptr_t       qw_at = ~uintptr_t(0), sw_at = ~uintptr_t(0);
+    uint32_t        qw = 0, sw = 0;
+
+    // ops are produced end -> begin; `wpos` is the address of the next byte to write
+    uintptr_t wpos = reinterpret_cast<uintptr_t>(ops) + cap - 1;
+    uint32_t  acc = 0;       // bytes of the dword that contains wpos, collected so far
+    bool      acc_full = (wpos & 3) == 3; // the collection started at the dword's top byte
+    auto emit = [&](uint32_t op)
+    {
+        uint32_t const lane_byte = (uint32_t)(wpos & 3);
+        acc |= op << (8 * lane_byte);
+        if (lane_byte == 0)
+        {
+            if (acc_full)
+                *reinterpret_cast<uint32_t *>(wpos) = acc;
+            else // partial top dword of the slot: the bytes above belong to the next slot
+                for (uintptr_t a = wpos; (a & 3) != 0 || a == wpos; ++a)
+                {
+                    if (a > reinterpret_cast<uintptr_t>(ops) + cap - 1)
+                        break;
+                    *reinterpret_cast<uint8_t *>(a) = (uint8_t)(acc >> (8 * (a & 3)));
+                    if ((a & 3) == 3)
+                        break;
+                }
+            acc      = 0;
+            acc_full = true;
+        }
+        --wpos;
+        ++n;
+    };
+
     while (i >= 0 && j >= 0 && n < cap)
     {
-        if (st == 0)
+        uint32_t const  nib = nibble(i, j);
+        uintptr_t const qaddr = qa + (uint32_t)j, saddr = sa + (uint32_t)i;
+        if ((qaddr & ~uintptr_t(3)) != qw_at)
         {
-            uint32_t const code = tag(i, j, 0);
-            if (code == 3)
-                break; // trace NONE: H <= 0
-            if (code == 2)
-            {
-                uint8_t const c0 = q[j] & (kAlph - 1), c1 = s[i] & (kAlph - 1);
-                int const     v  = mat[c0 * kAlph + c1];
-                bool const isMatch = p.bs_match_rule ? (v == mat[c0 * kAlph + c0]) : (c0 == c1);
-                nm += isMatch;
-                nx += !isMatch;
-                np += (v > 0);
-                ops[cap - 1 - n] = 'M';
-                ++n;
-                --i;
-                --j;
-            }
-            else
-                st = (code == 1) ? 1 : 2;
+            qw_at = qaddr & ~uintptr_t(3);
+            qw    = *reinterpret_cast<uint32_t const *>(qw_at);
         }
-        else if (st == 1)
+        if ((saddr & ~uintptr_t(3)) != sw_at)
         {
-            ops[cap - 1 - n] = 'D';
-            ++n;
-            // F[i][j] was produced at row i-1: bit 1 of that cell's F-plane tag = "extended"
-            bool const ext = (i >= 1) && ((tag(i - 1, j, 1) >> 1) & 1u);
-            --i;
-            if (ext)
-                gx += 1;
-            else
+            sw_at = saddr & ~uintptr_t(3);
+            sw    = *reinterpret_cast<uint32_t const *>(sw_at);
+        }
+        if (mode == 1)
+        {
+            if ((nib >> 2) & 1u)
             {
-                go += 1;
-                st = 0;
+                gx += 1;
+                emit('D');
+                --i;
+                continue;
             }
+            go += 1;
+            mode = 0;
+        }
+        else if (mode == 2)
+        {
+            if ((nib >> 3) & 1u)
+            {
+                gx += 1;
+                emit('I');
+                --j;
+                continue;
+            }
+            go += 1;
+            mode = 0;
+        }
+        uint32_t const code = nib & 3u;
+        if (code == 3)
+            break; // trace NONE: H <= 0
+        if (code == 2)
+        {
+            uint32_t const c0 = (qw >> (8 * (qaddr & 3))) & (kAlph - 1), c1 = (sw >> (8 * (saddr & 3))) & (kAlph - 1);
+            int const      v       = smat[c0 * kAlph + c1];
+            bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
+            nm += isMatch;
+            nx += !isMatch;
+            np += (v > 0);
+            emit('M');
+            --i;
+            --j;
+        }
+        else if (code == 1)
+        {
+            emit('D');
+            --i;
+            mode = 1;
         }
         else
         {
-            ops[cap - 1 - n] = 'I';
-            ++n;
-            bool const ext = (j >= 1) && ((tag(i, j - 1, 2) >> 1) & 1u);
+            emit('I');
             --j;
-            if (ext)
-                gx += 1;
-            else
-            {
-                go += 1;
-                st = 0;
-            }
+            mode = 2;
         }
     }
-    // move the ops to the front of the slot, in begin -> end order
-    uint32_t const first = cap - n;
-    if (first != 0)
-        for (uint32_t k = 0; k < n; ++k)
-            ops[k] = ops[first + k];
+    if (mode != 0)
+        go += 1; // ran into the border right after a gap character: it can only have been an opening
+    // flush the bytes collected in the lowest, partial dword
+    for (uintptr_t a = wpos + 1; (a & 3) != 0 && a <= reinterpret_cast<uintptr_t>(ops) + cap - 1; ++a)
+        *reinterpret_cast<uint8_t *>(a) = (uint8_t)(acc >> (8 * (a & 3)));
 
     out.score              = ec.score;
     out.q_begin            = j + 1;
@@ -465,6 +521,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     out.num_positives      = np;
     out.num_gap_opens      = go;
     out.num_gap_extensions = gx;
+    out.ops_shift          = (int32_t)(cap - n); // the ops occupy the END of the slot (written back to front)
     p.out_hsp[oi]          = out;
 }
 

@@ -231,4 +231,5 @@ def test_fused_extend_on_device(handle, oracle, wpq, run):
         g = hsp[i]
         assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
-        assert bytes(ops[int(off[i]): int(off[i]) + oh.n_ops]) == oops
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops
