@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -24,7 +25,8 @@ hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t 
 int        score_cfg_panel(int cfg);
 int        score_cfg_groups(int cfg);
 int        score_cfg_count();
-hipError_t launch_trace(TraceParams const & p, hipStream_t stream);
+hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
+hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
 int        trace_cfg_panel(int cfg);
 int        trace_cfg_group(int cfg);
@@ -55,6 +57,8 @@ struct lx_handle
     int         device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;                       // backtrace of chunk k overlaps the forward kernel of chunk k+1
+    hipEvent_t  evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evS = nullptr;
     bool        timed = false;
     std::string error;
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
@@ -262,6 +266,11 @@ int lx_create(int device_id, lx_handle ** out)
         return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess)
         return bail("hipEventCreate", e);
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess)
+        return bail("hipStreamCreate", e);
+    for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
+        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
+            return bail("hipEventCreate", e);
     if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 4 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc", e);
     if ((e = hipMemset(h->d_ws_top, 0, 4 * sizeof(uint32_t))) != hipSuccess)
@@ -290,6 +299,14 @@ void lx_destroy(lx_handle * h)
             (void)hipFree(h->sc_dev[s]);
     if (h->d_ws_top)
         (void)hipFree(h->d_ws_top);
+    if (h->stream2)
+    {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
+    for (hipEvent_t ev : {h->evF[0], h->evF[1], h->evB[0], h->evB[1], h->evS})
+        if (ev)
+            (void)hipEventDestroy(ev);
     if (h->ev0)
         (void)hipEventDestroy(h->ev0);
     if (h->ev1)
@@ -608,7 +625,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 // out_hsp[src[slot]] / ops_off[src[slot]] and slots beyond *d_count are skipped on the device.
 static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
                           uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
-                          uint64_t max_q, uint64_t max_s, bool shared, uint32_t const * d_src = nullptr,
+                          uint64_t max_q, uint64_t max_s, int share_slots, uint32_t const * d_src = nullptr,
                           uint64_t const * d_count = nullptr)
 {
     if (!h->trace_ok[slot])
@@ -622,31 +639,43 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     if ((uint64_t)maxent * std::min(max_q, max_s) >= 65536)
         return fail(h, LX_EINVAL, "pass 2 packs scores in 16 bits: max entry %d x min(%llu,%llu) residues overflows", maxent,
                     (unsigned long long)max_q, (unsigned long long)max_s);
-    int const cfg = (shared && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1 : 0;
+    // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
+    // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
+    int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1 : 0;
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 3) & ~3ull);
     uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
-    uint64_t       chunk      = std::max<uint64_t>(1, h->opt_trace_bytes / std::max<uint64_t>(per_ext, 1));
-    chunk                     = std::min<uint64_t>(chunk, n);
-    chunk                     = std::max<uint64_t>(8, chunk / 8 * 8);
+    // Two trace buffers, so that the backtrace of chunk k may run on stream2 while the forward kernel of chunk k+1
+    // runs on `stream`.  Measured on MI355X (config 2) the overlap buys nothing -- both kernels saturate the chip
+    // (46.5 ms/step serial vs 46.9 ms overlapped) -- so it is off unless LX_TRACE_OVERLAP=1.
+    uint64_t       chunk      = std::max<uint64_t>(1, h->opt_trace_bytes / 2 / std::max<uint64_t>(per_ext, 1));
+    uint64_t const want_chunks = getenv("LX_TRACE_CHUNKS") ? (uint64_t)atoi(getenv("LX_TRACE_CHUNKS")) : 2;
+    chunk                     = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
+    bool const overlap        = getenv("LX_TRACE_OVERLAP") && atoi(getenv("LX_TRACE_OVERLAP")) != 0;
+    hipStream_t const bstream = overlap ? h->stream2 : stream;
+    chunk                     = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
     int rc;
-    if ((rc = ensure(h, h->d_trace, chunk * per_ext)) || (rc = ensure(h, h->d_ends, chunk * sizeof(lx::EndCell))))
+    if ((rc = ensure(h, h->d_trace, 2 * chunk * per_ext)) || (rc = ensure(h, h->d_ends, 2 * chunk * sizeof(lx::EndCell))))
         return rc;
-    for (uint64_t c0 = 0; c0 < n; c0 += chunk)
+    LX_HIP(h, hipEventRecord(h->evS, stream));
+    LX_HIP(h, hipStreamWaitEvent(h->stream2, h->evS, 0));
+    uint64_t nchunks = 0;
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk, ++nchunks)
     {
+        int const       b = (int)(nchunks & 1);
         lx::TraceParams p{};
         p.q_res          = static_cast<uint8_t const *>(d_q);
         p.s_res          = static_cast<uint8_t const *>(d_s);
         p.ext            = d_ext + c0;
         p.n              = std::min<uint64_t>(chunk, n - c0);
         p.sc             = h->sc_dev[slot];
-        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr);
+        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr) + (uint64_t)b * chunk * stride;
         p.slot_stride    = stride;
         p.steps_cap      = steps_cap;
         p.panels_cap     = panels_cap;
-        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
+        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr) + (uint64_t)b * chunk;
         p.out_hsp        = d_src ? d_hsp : d_hsp + c0;
         p.out_ops        = d_ops;
         p.ops_off        = d_src ? d_ops_off : d_ops_off + c0;
@@ -659,12 +688,21 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
         p.bs_match_rule  = (int32_t)h->opt_bs_rule;
-        p.shared_profile = shared ? 1 : 0;
+        p.shared_profile = share_slots;
         p.cfg            = cfg;
+        if (nchunks >= 2) // buffer b is free once the backtrace of chunk k-2 has finished
+            LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
         if (panels_cap > 1) // each chunk starts with an empty carry workspace
             LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
-        LX_HIP(h, lx::launch_trace(p, stream));
+        LX_HIP(h, lx::launch_trace_forward(p, stream));
+        LX_HIP(h, hipEventRecord(h->evF[b], stream));
+        LX_HIP(h, hipStreamWaitEvent(bstream, h->evF[b], 0));
+        LX_HIP(h, lx::launch_backtrace(p, bstream));
+        LX_HIP(h, hipEventRecord(h->evB[b], bstream));
     }
+    // rejoin: everything queued on `stream` after this call sees the finished backtraces
+    for (int b = 0; b < 2 && (uint64_t)b < nchunks; ++b)
+        LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
     return LX_OK;
 }
 
@@ -700,7 +738,7 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     LX_HIP(h, hipEventRecord(h->ev0, stream));
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(d_ext), n,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
-                        static_cast<uint64_t const *>(d_ops_off), stream, max_q, max_s, false);
+                        static_cast<uint64_t const *>(d_ops_off), stream, max_q, max_s, 0);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, stream));
@@ -752,7 +790,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
     rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
                         static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
-                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, false);
+                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, 0);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, h->stream));
@@ -799,9 +837,9 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     // filter (:1251-1283) as an integer cut-off, compaction in input order, runs padded to whole wavefronts
     bool const     shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
     uint32_t const run    = shared ? (uint32_t)h->opt_query_run : 1u;
-    uint32_t const pad_to = shared ? 8u : 1u;
+    uint32_t const pad_to = shared ? 4u : 1u; // half a wavefront of the 8-lane geometry, a whole one of the 16-lane
     uint64_t const nruns  = (n + run - 1) / run;
-    uint64_t const cap    = n + (shared ? nruns * 7 : 0);
+    uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
         (rc = ensure(h, h->d_sel_runs, (nruns + 1) * sizeof(uint64_t))))
         return rc;
@@ -823,7 +861,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     // pass 2 on the survivors (:1293-1296); the grid covers the worst case, wavefronts beyond *d_out_count exit
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
-                        static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared,
+                        static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? 4 : 0,
                         static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count));
     if (rc)
         return rc;

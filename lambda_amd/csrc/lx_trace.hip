@@ -88,12 +88,17 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 s += x.s_off;
         }
     }
-    if (p.shared_profile)
+    // p.shared_profile = number of consecutive groups that share one LDS profile (0/1: none).  The compaction
+    // kernel pads every query's survivors to a multiple of that many slots, so the promise holds by construction;
+    // it is verified all the same (first lane of each sharing block vs the others).
+    int const share  = p.shared_profile > 1 ? min(p.shared_profile, Geo::kGroups) : 1;
+    int const leader = (grp / share) * share * G; // first lane of this group's sharing block
+    if (share > 1)
     {
-        uint64_t const q0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q_off >> 32)) << 32) |
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q_off);
-        int const l0 = __builtin_amdgcn_readfirstlane(lq);
-        if (in_list && (q_off != q0 || lq != l0))
+        uint32_t const qlo = (uint32_t)__shfl((int)(uint32_t)q_off, leader), qhi = (uint32_t)__shfl((int)(q_off >> 32), leader);
+        int const      l0  = __shfl(lq, leader);
+        bool const     lead_in = __shfl(in_list ? 1 : 0, leader) != 0;
+        if (in_list && lead_in && (q_off != (((uint64_t)qhi << 32) | qlo) || lq != l0))
             atomicExch(p.err, 2);
     }
 
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     if (bad)
         ls = 0;
 
-    int const          slot_dw   = p.shared_profile ? 0 : grp * (nrows * Geo::kRowDw);
+    int const          slot_dw   = (grp / share) * (nrows * Geo::kRowDw);
     uint32_t const     row_base  = (uint32_t)(slot_dw + g) * 4u;
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
     int const          steps     = (ls_max + G - 1 + 3) & ~3;
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     for (int panel = 0; panel < npanels; ++panel)
     {
         int const col0 = panel * Geo::kPanel + g * C;
-        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_trace, nrows, !p.shared_profile || grp == 0);
+        build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_trace, nrows, grp % share == 0);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
@@ -554,28 +559,41 @@ int trace_cfg_group(int cfg) { return cfg == 1 ? 8 : 16; }
 int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : TraceWords<10>::kWords; }
 
 template <int G, int C>
-static hipError_t launch_trace_cfg(TraceParams const & p, hipStream_t stream)
+static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t stream)
 {
     using Geo = ScoreGeo<G, C>;
     uint64_t const blocks = (p.n + Geo::kGroups - 1) / Geo::kGroups;
     if (blocks > 0x7fffffffull)
         return hipErrorInvalidValue;
-    int const    slots = p.shared_profile ? 1 : Geo::kGroups;
+    int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
+    int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
     hipLaunchKernelGGL((trace_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return e;
+    return hipGetLastError();
+}
+
+template <int G, int C>
+static hipError_t launch_backtrace_cfg(TraceParams const & p, hipStream_t stream)
+{
     uint64_t const b2 = (p.n + 63) / 64;
     hipLaunchKernelGGL((backtrace_kernel<G, C>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
-hipError_t launch_trace(TraceParams const & p, hipStream_t stream)
+// The two halves of pass 2 are launched separately so that the host side can run the backtrace of chunk k on a second
+// stream while the forward kernel of chunk k+1 already runs (double-buffered trace workspace).
+hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return p.cfg == 1 ? launch_trace_cfg<8, 19>(p, stream) : launch_trace_cfg<16, 10>(p, stream);
+    return p.cfg == 1 ? launch_trace_forward_cfg<8, 19>(p, stream) : launch_trace_forward_cfg<16, 10>(p, stream);
+}
+
+hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    return p.cfg == 1 ? launch_backtrace_cfg<8, 19>(p, stream) : launch_backtrace_cfg<16, 10>(p, stream);
 }
 
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream)
