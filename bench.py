@@ -83,18 +83,18 @@ def cpu_baseline(args, cores: int):
 
 
 def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json):
+    """HBM bytes per step of a kernel (kernel_name = substring of its rocprofv3 name) from the committed rocprofv3 PMC passes (profiles/*_pmc.json):
     (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md.
     PMC counters cannot be read from inside a timed run, so this is the figure of the profiled run of the same
     command; None if no profile of this kernel instantiation is committed."""
     try:
         files = sorted((ROOT / "profiles").glob("*_pmc.json"))
-        key = kernel_name.split(" ")[0].replace("lx::score_kernel<", "").rstrip(">").replace(",", ", ")
         for f in reversed(files):
             for name, d in json.loads(f.read_text())["kernels"].items():
-                c = d["counters_per_launch_mean"]
-                if f"score_kernel<{key}>" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0, f"{f.name}: 2*FETCH_SIZE + WRITE_SIZE (KiB) of {name}"
+                c = d.get("counters_per_step_mean", d.get("counters_per_launch_mean", {}))
+                if kernel_name in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                    return ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                            f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per step of {name}")
     except Exception:
         pass
     return None, "no committed PMC profile for this kernel instantiation"
@@ -195,15 +195,37 @@ def main():
     dt = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
+    # device time per phase of the LAST timed step (HIP events recorded by the library on the launch stream, around
+    # each kernel launch): 0 = pass-1 score kernel, 1 = selection, 2 = pass-2 forward kernel, 3 = pass-2 backtrace
+    phase_ms = {ph: h.last_phase_ms(ph) for ph in (0, 1, 2, 3)}
+    trace_kernel_name = h.last_trace_kernel_name()
+
     if rank == 0:
         total_cells = cells_rank * world
         gcups = total_cells * args.steps / dt / 1e9
-        kern_gcups = cells_rank / (kern_ms * 1e-3) / 1e9
-        achieved_tops = kern_gcups * ALGO_OPS_PER_CELL / 1e3
+        lq, ls = args.lq, synth.window_len(args.lq)
+
+        def roofline(kernel, ms, launches, cells, pmc_key):
+            gc = cells / (ms * 1e-3) / 1e9
+            tops = gc * ALGO_OPS_PER_CELL / 1e3
+            traffic, note = pmc_traffic(pmc_key)
+            return {
+                "bound": "valu", "kernel": kernel, "achieved": round(tops, 3), "peak": round(PEAK_INT32_TOPS, 2),
+                "unit": "Tops/s (int32 lane-ops; 10 algorithmic ops per cell)", "frac": round(tops / PEAK_INT32_TOPS, 4),
+                "kernel_ms_per_step": round(ms, 4), "launches_per_step": launches, "kernel_gcups": round(gc, 1),
+                "cells_per_step": cells, "hbm_peak_GBps": 8000, "traffic": traffic, "traffic_note": note,
+            }
+
         algo_bytes = float(ext["q_len"].sum()) / args.windows + float(ext["s_len"].sum()) + n * ALGO_BYTES_PER_EXT_EXTRA
-        traffic, traffic_note = pmc_traffic(kernel_name)
+        r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], cells_rank, "score_kernel")
+        r_score["hbm_algorithmic_GBps"] = round(algo_bytes / (phase_ms[0][0] * 1e-3) / 1e9, 2)
+        rooflines = [r_score]
+        if not args.pass1_only and phase_ms[2][0] > 0:
+            rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], float(survivors) * lq * ls,
+                                      "trace_forward_kernel"))
+        rooflines.sort(key=lambda r: -r["kernel_ms_per_step"])
         out = {
-            "metric": "GCUPS (gapped extension, full-rectangle parity mode, pass 1) searchp BLOSUM62",
+            "metric": "GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) searchp BLOSUM62",
             "value": round(gcups, 2),
             "unit": "GCUPS",
             "n_gpus": world,
@@ -230,20 +252,12 @@ def main():
             },
             "alignments_per_s": round(n * world * args.steps / dt, 1),
             "traced_per_s": round(survivors * world * args.steps / dt, 1),
-            "roofline": {
-                "bound": "valu",
-                "kernel": kernel_name,
-                "achieved": round(achieved_tops, 3),
-                "peak": round(PEAK_INT32_TOPS, 2),
-                "unit": "Tops/s (int32 lane-ops; 10 algorithmic ops per cell)",
-                "frac": round(achieved_tops / PEAK_INT32_TOPS, 4),
-                "kernel_ms": round(kern_ms, 4),
-                "kernel_gcups": round(kern_gcups, 1),
-                "hbm_algorithmic_GBps": round(algo_bytes / (kern_ms * 1e-3) / 1e9, 2),
-                "hbm_peak_GBps": 8000,
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-            },
+            "total_gcups_both_passes": round((cells_rank + float(survivors) * lq * ls) * world * args.steps / dt / 1e9, 2),
+            "phase_ms_last_step": {"score": round(phase_ms[0][0], 3), "select": round(phase_ms[1][0], 3),
+                                   "trace_forward": round(phase_ms[2][0], 3), "backtrace": round(phase_ms[3][0], 3),
+                                   "events_step_ms": round(kern_ms, 3)},
+            "roofline": rooflines[0],           # the kernel that takes most of the step
+            "roofline_other": rooflines[1:],
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

@@ -257,6 +257,10 @@ int lx_last_kernel_ms(lx_handle * h, float * ms);
 /* Name of the kernel instantiation the most recent pass-1 launch used, e.g. "lx::score_kernel<8,19,false> shared-profile"
  * (profiling aid: matches the kernel names rocprofv3 reports). */
 char const * lx_last_kernel_name(lx_handle const * h);
+char const * lx_last_trace_kernel_name(lx_handle const * h);
+/* Device time (HIP events on the launch stream) the most recent call spent in one phase, summed over its launches:
+ * phase 0 = pass-1 score kernel, 1 = survivor selection, 2 = pass-2 forward kernel, 3 = pass-2 backtrace kernel. */
+int lx_last_phase_ms(lx_handle * h, int phase, float * ms, int * launches);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
     objs = []
     hipcc = _hipcc()
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}",
-              "-Wall", "-Wno-unused-function"]
+              "-Wall", "-Wno-unused-function", *os.environ.get("LX_EXTRA_DEFINES", "").split()]
     procs = []
     for s in srcs:
         o = s.with_suffix(".o")

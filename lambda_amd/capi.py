@@ -23,7 +23,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 EXPORTED_SYMBOLS = [
     "lx_abi_version", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
-    "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name",
+    "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
     "lx_iterate_matches",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
@@ -117,6 +117,9 @@ def load():
     lib.lx_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.lx_last_kernel_name.argtypes = [vp]
     lib.lx_last_kernel_name.restype = C.c_char_p
+    lib.lx_last_trace_kernel_name.argtypes = [vp]
+    lib.lx_last_trace_kernel_name.restype = C.c_char_p
+    lib.lx_last_phase_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     for name, args in (("lx_align_batch", [vp, i32, vp, u64, vp, u64, vp, u64, vp, vp, vp]),
                        ("lx_align_batch_dev", [vp, i32, vp, vp, vp, u64, vp, vp, vp, vp]),
                        ("lx_prefilter_batch", [vp, i32, vp, u64, vp, u64, vp, u64, C.c_uint32, C.c_int32, C.c_double, vp])):
@@ -297,6 +300,14 @@ class Handle:
 
     def last_kernel_name(self) -> str:
         return self.lib.lx_last_kernel_name(self.h).decode()
+
+    def last_trace_kernel_name(self) -> str:
+        return self.lib.lx_last_trace_kernel_name(self.h).decode()
+
+    def last_phase_ms(self, phase: int):
+        ms, cnt = C.c_float(), C.c_int()
+        self._check(self.lib.lx_last_phase_ms(self.h, phase, C.byref(ms), C.byref(cnt)))
+        return float(ms.value), int(cnt.value)
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

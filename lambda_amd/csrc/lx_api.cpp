@@ -62,6 +62,16 @@ struct lx_handle
     bool        timed = false;
     std::string error;
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
+    std::string last_trace_kernel;
+    // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
+    struct PhaseEv
+    {
+        int        phase;
+        hipEvent_t a, b;
+    };
+    std::vector<PhaseEv>    phase_ev;      // events recorded by the last call
+    std::vector<hipEvent_t> ev_pool;       // reusable timing events
+    size_t                  ev_pool_used = 0;
 
     bool             have_sc[2] = {false, false};
     bool             trace_ok[2] = {false, false};
@@ -80,6 +90,7 @@ struct lx_handle
     uint64_t opt_max_slen  = 0;
     uint64_t opt_trace_bytes = 32ull << 30;
     uint64_t opt_bs_rule   = 0;
+    bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
 
 namespace
@@ -98,6 +109,45 @@ int fail(lx_handle * h, int code, char const * fmt, ...)
         g_create_error = buf;
     return code;
 }
+
+hipEvent_t pool_event(lx_handle * h)
+{
+    if (h->ev_pool_used == h->ev_pool.size())
+    {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess)
+            return nullptr;
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[h->ev_pool_used++];
+}
+
+// RAII-less phase bracket: records a start event now, the end event on close()
+struct PhaseTimer
+{
+    lx_handle * h;
+    hipStream_t s;
+    int         phase;
+    hipEvent_t  a = nullptr, b = nullptr;
+    PhaseTimer(lx_handle * h_, hipStream_t s_, int phase_) : h(h_), s(s_), phase(phase_)
+    {
+        if (h->phase_ev.size() < 64)
+        {
+            a = pool_event(h);
+            b = pool_event(h);
+            if (a && b)
+                (void)hipEventRecord(a, s);
+        }
+    }
+    void close()
+    {
+        if (a && b)
+        {
+            (void)hipEventRecord(b, s);
+            h->phase_ev.push_back({phase, a, b});
+        }
+    }
+};
 
 #define LX_HIP(h, call)                                                                                         \
     do                                                                                                          \
@@ -307,6 +357,8 @@ void lx_destroy(lx_handle * h)
     for (hipEvent_t ev : {h->evF[0], h->evF[1], h->evB[0], h->evB[1], h->evS})
         if (ev)
             (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : h->ev_pool)
+        (void)hipEventDestroy(ev);
     if (h->ev0)
         (void)hipEventDestroy(h->ev0);
     if (h->ev1)
@@ -412,6 +464,35 @@ char const * lx_last_kernel_name(lx_handle const * h)
     return h ? h->last_kernel.c_str() : "";
 }
 
+char const * lx_last_trace_kernel_name(lx_handle const * h)
+{
+    return h ? h->last_trace_kernel.c_str() : "";
+}
+
+int lx_last_phase_ms(lx_handle * h, int phase, float * ms, int * launches)
+{
+    if (!h || !ms)
+        return LX_EINVAL;
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    float total = 0.f;
+    int   cnt   = 0;
+    for (auto const & pe : h->phase_ev)
+        if (pe.phase == phase)
+        {
+            float t = 0.f;
+            LX_HIP(h, hipEventSynchronize(pe.b));
+            LX_HIP(h, hipEventElapsedTime(&t, pe.a, pe.b));
+            total += t;
+            ++cnt;
+        }
+    *ms = total;
+    if (launches)
+        *launches = cnt;
+    return LX_OK;
+}
+
 int lx_last_kernel_ms(lx_handle * h, float * ms)
 {
     if (!h || !ms)
@@ -448,11 +529,21 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu), want_shared) : 0;
     bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
     bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
-    LX_HIP(h, hipEventRecord(h->ev0, stream));
+    if (!h->in_fused)
+    {
+        h->phase_ev.clear();
+        h->ev_pool_used = 0;
+        LX_HIP(h, hipEventRecord(h->ev0, stream));
+    }
+    PhaseTimer pt(h, stream, 0);
     if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream)))
         return rc;
-    LX_HIP(h, hipEventRecord(h->ev1, stream));
-    h->timed = true;
+    pt.close();
+    if (!h->in_fused)
+    {
+        LX_HIP(h, hipEventRecord(h->ev1, stream));
+        h->timed = true;
+    }
     return LX_OK;
 }
 
@@ -644,7 +735,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1 : 0;
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
-    uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 3) & ~3ull);
+    uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 15) & ~15ull); // multiple of the trace layout block
     uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
     // Two trace buffers, so that the backtrace of chunk k may run on stream2 while the forward kernel of chunk k+1
@@ -694,11 +785,20 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
             LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
         if (panels_cap > 1) // each chunk starts with an empty carry workspace
             LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
+        PhaseTimer ptf(h, stream, 2);
         LX_HIP(h, lx::launch_trace_forward(p, stream));
+        ptf.close();
         LX_HIP(h, hipEventRecord(h->evF[b], stream));
         LX_HIP(h, hipStreamWaitEvent(bstream, h->evF[b], 0));
+        PhaseTimer ptb(h, bstream, 3);
         LX_HIP(h, lx::launch_backtrace(p, bstream));
+        ptb.close();
         LX_HIP(h, hipEventRecord(h->evB[b], bstream));
+        {
+            char buf[96];
+            snprintf(buf, sizeof(buf), "lx::trace_forward_kernel<%d,%d>", G, P / G);
+            h->last_trace_kernel = buf;
+        }
     }
     // rejoin: everything queued on `stream` after this call sees the finished backtraces
     for (int b = 0; b < 2 && (uint64_t)b < nchunks; ++b)
@@ -735,6 +835,8 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
         max_q = std::max<uint64_t>(ml.max_q, 1);
         max_s = std::max<uint64_t>(ml.max_s, 1);
     }
+    h->phase_ev.clear();
+    h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, stream));
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(d_ext), n,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
@@ -787,6 +889,8 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, ext, n * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, ops_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    h->phase_ev.clear();
+    h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
     rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
                         static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
@@ -830,8 +934,13 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
 
     // pass 1 (src/search_algo.hpp:1246)
+    h->phase_ev.clear();
+    h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, stream));
-    if ((rc = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream)))
+    h->in_fused = true;
+    rc          = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream);
+    h->in_fused = false;
+    if (rc)
         return rc;
 
     // filter (:1251-1283) as an integer cut-off, compaction in input order, runs padded to whole wavefronts
@@ -856,7 +965,9 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     sp.out_src       = static_cast<uint32_t *>(h->d_sel_src.ptr);
     sp.out_count     = static_cast<uint64_t *>(d_out_count);
     sp.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
+    PhaseTimer pts(h, stream, 1);
     LX_HIP(h, lx::launch_select(sp, stream));
+    pts.close();
 
     // pass 2 on the survivors (:1293-1296); the grid covers the worst case, wavefronts beyond *d_out_count exit
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,

@@ -32,6 +32,17 @@
 namespace lx
 {
 
+// Trace buffer layout inside one extension slot.  kBlock consecutive steps of one lane are contiguous
+// (kBlock * kWords * 4 bytes), lanes are interleaved at that granularity:
+//     word index = ((panel * steps_cap/kBlock + k / kBlock) * G + g) * kBlock * kWords + (k % kBlock) * kWords + x
+// kBlock = steps_cap would be one private stream per lane (best locality for the backtrace, but lines stay partially
+// written for a long time and the HBM write traffic doubles); kBlock = 1 is fully coalesced per step (backtrace
+// touches a new line every step).
+#ifndef LX_TRACE_BLOCK
+#define LX_TRACE_BLOCK 4
+#endif
+constexpr int kTraceBlock = LX_TRACE_BLOCK;
+
 template <int C>
 struct TraceWords
 {
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     uint32_t const     lsc       = (uint32_t)max(ls, 1) - 1u;
 
     // trace[e][panel][g][k][word]
-    uint32_t * tr = p.trace + e * p.slot_stride + (uint64_t)g * p.steps_cap * TW::kWords;
+    uint32_t * tr = p.trace + e * p.slot_stride + (uint32_t)g * (kTraceBlock * TW::kWords);
 
     int best_h = 0, best_q = 0, best_s = 0;
 
@@ -254,7 +265,8 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
 
             if (store_trace)
             {
-                uint32_t * dst = trp + (uint32_t)k * TW::kWords;
+                uint32_t * dst = trp + ((uint32_t)k / kTraceBlock) * (G * kTraceBlock * TW::kWords) +
+                                 ((uint32_t)k % kTraceBlock) * TW::kWords;
 #pragma unroll
                 for (int x = 0; x < TW::kWords; ++x)
                     dst[x] = w[x];
@@ -396,7 +408,9 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         int const      g = r / C, c = r - g * C;
         int const      x = c >> 3, cx = c & 7;
         int const      cnt = (x == TW::kWords - 1) ? (C - 8 * x) : 8; // cells held by this word
-        uint32_t const word = tr[(((uint64_t)panel * G + g) * p.steps_cap + (uint32_t)(i + g)) * TW::kWords + x];
+        uint32_t const k    = (uint32_t)(i + g);
+        uint32_t const word = tr[(((uint64_t)panel * (p.steps_cap / kTraceBlock) + k / kTraceBlock) * G + g) * (kTraceBlock * TW::kWords) +
+                                 (k % kTraceBlock) * TW::kWords + x];
         return (word >> (32 - 4 * cnt + 4 * cx)) & 15u;
     };
 
