@@ -58,7 +58,7 @@ def parse():
 
 def cpu_baseline(args, cores: int):
     """Times the oracle's inter-sequence int16 SIMD batch scorer (the shape of the reference's CPU path,
-    oracle/lx_oracle_simd.c) on a bounded sample of the same workload, on this box's host cores."""
+    oracle/lx_oracle_simd.cpp) on a bounded sample of the same workload, on this box's host cores."""
     from lambda_amd import capi, synth
     from tests import oracle_lib
 

@@ -70,7 +70,7 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
 
 
 def build_oracle(force: bool = False) -> Path:
-    srcs = [ORACLE_DIR / "lx_oracle.c", ORACLE_DIR / "lx_oracle_simd.c", ORACLE_DIR / "lx_oracle.h"]
+    srcs = [ORACLE_DIR / "lx_oracle.c", ORACLE_DIR / "lx_oracle_simd.cpp", ORACLE_DIR / "lx_oracle.h"]
     if not force and _newer(ORACLE_LIB, srcs):
         return ORACLE_LIB
     r = subprocess.run(["make", "-C", str(ORACLE_DIR)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

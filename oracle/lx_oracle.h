@@ -82,7 +82,7 @@ int lxo_score_batch(uint8_t const * qres, uint8_t const * sres, uint64_t const *
                     uint64_t const * s_off, uint32_t const * s_len, uint64_t n, lxo_scoring const * sc,
                     int32_t * score, int32_t * q_end, int32_t * s_end, int32_t threads);
 
-/* inter-sequence int16 SIMD variant (lx_oracle_simd.c): the shape of the reference's CPU path */
+/* inter-sequence int16 SIMD variant (lx_oracle_simd.cpp): the shape of the reference's CPU path */
 int lxo_score_batch_simd(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
                          uint64_t const * s_off, uint32_t const * s_len, uint64_t n, lxo_scoring const * sc,
                          int32_t * score, int32_t * q_end, int32_t * s_end, int32_t threads);

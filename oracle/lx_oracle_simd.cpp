@@ -1,5 +1,5 @@
 /*
- * lx_oracle_simd.c -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
+ * lx_oracle_simd.cpp -- TEST INFRASTRUCTURE ONLY.  Not part of the product.
  *
  * Inter-sequence int16 SIMD variant of the score-only pass: one alignment per
  * SIMD lane, lanes padded to the longest pair of the group -- the batching design of
@@ -9,25 +9,29 @@
  * reference's CPU path rather than a scalar loop.  It is a restatement ("port"),
  * NOT SeqAn; tests check it against lxo_score() bit for bit.
  */
+extern "C" {
 #include "lx_oracle.h"
+}
 
 #include <stdlib.h>
 #include <string.h>
 
 #define LANES 16
 typedef int16_t v16s __attribute__((vector_size(2 * LANES)));
+typedef int8_t  v16b __attribute__((vector_size(LANES)));
+typedef uint8_t v16u __attribute__((vector_size(LANES)));
 
 #define PAD_RANK 31
 #define NEG16 ((int16_t)-16384)
 
 static inline v16s vsel(v16s mask, v16s a, v16s b) /* mask lanes are 0 / -1 */
 {
-    return (a & mask) | (b & ~mask);
+    return mask ? a : b; /* g++ vector ternary -> pblendvb */
 }
 
 static inline v16s vmax(v16s a, v16s b)
 {
-    return vsel(a > b, a, b);
+    return a > b ? a : b; /* -> pmaxsw */
 }
 
 static inline v16s vsplat(int16_t x)
@@ -39,12 +43,19 @@ static inline v16s vsplat(int16_t x)
 }
 
 /* One group of up to LANES alignments. Returns 0, or 1 if the group must be redone in scalar int32. */
-__attribute__((target_clones("avx2", "default"))) static int
-score_group(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
+__attribute__((target_clones("avx2", "default"))) static int score_group(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
             uint64_t const * s_off, uint32_t const * s_len, uint64_t first, int cnt, lxo_scoring const * sc,
             int8_t const * mat /* padded copy */, int32_t * score, int32_t * q_end, int32_t * s_end,
             uint8_t * qT, uint8_t * sT, v16s * Hcol, v16s * Ecol, int32_t lqmax, int32_t lsmax)
 {
+    /* Do all lanes hold the same query slice?  (The reference sorts matches by query, so SIMD groups usually do.)
+     * Then the per-cell 2-D matrix gather becomes a 32-entry byte-table lookup per query column: two byte shuffles
+     * (pshufb) instead of 16 scalar loads -- the query-profile trick of SWIPE/SSW, applied across sequences. */
+    int same_q = 1;
+    for (int l = 1; l < cnt; ++l)
+        if (q_off[first + (uint64_t)l] != q_off[first] || q_len[first + (uint64_t)l] != q_len[first])
+            same_q = 0;
+
     /* transpose residues: qT[j*LANES + lane], pad with PAD_RANK (the SimdRep of seqan2_to_biocpp.hpp:397-405) */
     memset(qT, PAD_RANK, (size_t)lqmax * LANES);
     memset(sT, PAD_RANK, (size_t)lsmax * LANES);
@@ -72,12 +83,29 @@ score_group(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, 
         uint8_t const * qrow = qT + (size_t)(j - 1) * LANES;
         v16s            diag = zero, up = zero, F = vsplat(NEG16);
         v16s const      jv   = vsplat((int16_t)j);
+        v16b tlo, thi;
+        if (same_q)
+        {
+            memcpy(&tlo, mat + qrow[0] * LXO_ALPH, 16);
+            memcpy(&thi, mat + qrow[0] * LXO_ALPH + 16, 16);
+        }
         for (int32_t i = 1; i <= lsmax; ++i)
         {
             uint8_t const * srow = sT + (size_t)(i - 1) * LANES;
             v16s            sub;
-            for (int l = 0; l < LANES; ++l)
-                sub[l] = mat[qrow[l] * LXO_ALPH + srow[l]];
+            if (same_q)
+            {
+                v16u idx;
+                memcpy(&idx, srow, 16);
+                v16b const lo  = __builtin_shuffle(tlo, (v16b)(idx & 15));
+                v16b const hi  = __builtin_shuffle(thi, (v16b)(idx & 15));
+                v16b const sel = (v16b)(idx > 15);
+                v16b const s8  = sel ? hi : lo;
+                sub            = __builtin_convertvector(s8, v16s);
+            }
+            else
+                for (int l = 0; l < LANES; ++l)
+                    sub[l] = mat[qrow[l] * LXO_ALPH + srow[l]];
             v16s const left = Hcol[i];
             v16s const E    = vmax(Ecol[i] + ge, left + go);
             F               = vmax(F + ge, up + go);
@@ -105,7 +133,7 @@ score_group(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, 
 
 /* Inter-sequence SIMD batch scorer. The caller is expected to have sorted the pairs by
  * (q_len, s_len) like src/search_algo.hpp:1229-1235 does, to minimise padding. */
-int lxo_score_batch_simd(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
+extern "C" int lxo_score_batch_simd(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
                          uint64_t const * s_off, uint32_t const * s_len, uint64_t n, lxo_scoring const * sc,
                          int32_t * score, int32_t * q_end, int32_t * s_end, int32_t threads)
 {

@@ -171,7 +171,7 @@ _oracle = None
 def load() -> Oracle:
     global _oracle
     if _oracle is None:
-        srcs = [ROOT / "oracle" / n for n in ("lx_oracle.c", "lx_oracle_simd.c", "lx_oracle.h")]
+        srcs = [ROOT / "oracle" / n for n in ("lx_oracle.c", "lx_oracle_simd.cpp", "lx_oracle.h")]
         if not LIB.exists() or any(s.exists() and s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
             subprocess.run(["make", "-C", str(ROOT / "oracle")], check=True, capture_output=True)
         _oracle = Oracle(C.CDLL(str(LIB)))
