@@ -248,6 +248,41 @@ uint8_t const *        lx_iterate_result_ops(lx_iterate_result const * r);
 lx_iterate_stats       lx_iterate_result_stats(lx_iterate_result const * r);
 void                   lx_iterate_result_free(lx_iterate_result * r);
 
+
+/* ---- record post-processing and writers (row N2: _writeRecord + BLAST-tabular / SAM output) --------------- */
+/* _writeRecord (src/search_algo.hpp:820-913) for a whole result list: `m` must be grouped by n_qid (the order
+ * lx_iterate_matches returns).  Per query: sort by (n_sid, q_start, q_end, s_start, s_end, frames, bit score
+ * descending), drop duplicates of the same coordinates keeping the best, stable-sort by bit score descending, keep at
+ * most max_matches.  In place; returns the new count. */
+typedef struct lx_record_stats
+{
+    uint64_t qrys_with_hit, hits_duplicate2, hits_abundant, hits_final, pairs;
+} lx_record_stats;
+uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_matches, lx_record_stats * stats);
+
+/* What the writers need to know about the sequences (the reference reads these from lH.qryIds / indexFile.ids). */
+typedef struct lx_seq_names
+{
+    char const * const * q_ids;  /* per true query id (n_qid)   */
+    uint64_t const *     q_lens; /* untranslated query lengths  */
+    char const * const * s_ids;  /* per true subject id (n_sid) */
+    uint64_t const *     s_lens;
+    uint64_t             n_q, n_s;
+} lx_seq_names;
+
+enum
+{
+    LX_OUT_BLAST_TAB          = 0, /* -m8: 12 standard columns (src/search_options.hpp:716-760 default)         */
+    LX_OUT_BLAST_TAB_COMMENTS = 1, /* -m9                                                                        */
+    LX_OUT_SAM                = 2  /* SAM, default tags "AS NM ae ai qf" (src/search_options.hpp:351)            */
+};
+/* Appends header (if write_header) and records to `path` (myWriteHeader / myWriteRecord,
+ * src/search_output.hpp:305-461, :463-733).  `ops` is the ops buffer the matches' ops_off index into; `program` is
+ * "blastp" or "blastn" (the two untranslated programs in scope). */
+int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
+                     uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
+                     uint64_t const * q_ascii_off);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Blocks until everything queued on the handle's stream has finished. */
 int lx_synchronize(lx_handle * h);

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_matches",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
-    "lx_widen_and_preprocess",
+    "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -57,6 +57,18 @@ BLAST_MATCH_DTYPE = np.dtype([
     ("num_mismatches", "<i4"), ("num_positives", "<i4"), ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"),
     ("identity", "<f4"), ("bit_score", "<f8"), ("e_value", "<f8"), ("ops_off", "<u8"), ("n_ops", "<u4"),
     ("reserved", "<u4")])
+
+
+class RecordStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("qrys_with_hit", "hits_duplicate2", "hits_abundant", "hits_final", "pairs")]
+
+
+class SeqNames(C.Structure):
+    _fields_ = [("q_ids", C.POINTER(C.c_char_p)), ("q_lens", C.c_void_p), ("s_ids", C.POINTER(C.c_char_p)),
+                ("s_lens", C.c_void_p), ("n_q", C.c_uint64), ("n_s", C.c_uint64)]
+
+
+LX_OUT_BLAST_TAB, LX_OUT_BLAST_TAB_COMMENTS, LX_OUT_SAM = 0, 1, 2
 
 
 class Scoring(C.Structure):
@@ -147,8 +159,37 @@ def load():
     lib.lx_iterate_result_stats.restype = IterateStats
     lib.lx_iterate_result_free.argtypes = [vp]
     lib.lx_iterate_result_free.restype = None
+    lib.lx_postprocess_records.argtypes = [vp, u64, u64, C.POINTER(RecordStats)]
+    lib.lx_postprocess_records.restype = u64
+    lib.lx_write_records.argtypes = [C.c_char_p, i32, i32, C.c_char_p, vp, u64, vp, C.POINTER(SeqNames), vp, vp]
     _lib = lib
     return lib
+
+
+def postprocess_records(bms: np.ndarray, max_matches: int = 25):
+    """_writeRecord's sort / dedupe / top-N (src/search_algo.hpp:820-913) over a result list grouped by query."""
+    m = np.ascontiguousarray(bms, dtype=BLAST_MATCH_DTYPE).copy()
+    st = RecordStats()
+    n = load().lx_postprocess_records(_ptr(m), len(m), max_matches, C.byref(st))
+    return m[: int(n)], st
+
+
+def write_records(path, fmt: int, bms: np.ndarray, ops: bytes, q_ids, q_lens, s_ids, s_lens, program="blastp",
+                  write_header=True, q_ascii: bytes | None = None, q_ascii_off=None):
+    m = np.ascontiguousarray(bms, dtype=BLAST_MATCH_DTYPE)
+    qa = (C.c_char_p * len(q_ids))(*[x.encode() for x in q_ids])
+    sa = (C.c_char_p * len(s_ids))(*[x.encode() for x in s_ids])
+    ql = np.ascontiguousarray(q_lens, dtype=np.uint64)
+    sl = np.ascontiguousarray(s_lens, dtype=np.uint64)
+    names = SeqNames(qa, ql.ctypes.data, sa, sl.ctypes.data, len(q_ids), len(s_ids))
+    o = np.frombuffer(ops + b"\0", dtype=np.uint8)
+    qasc = np.frombuffer(q_ascii, dtype=np.uint8) if q_ascii else None
+    qoff = np.ascontiguousarray(q_ascii_off, dtype=np.uint64) if q_ascii_off is not None else None
+    rc = load().lx_write_records(str(path).encode(), fmt, 1 if write_header else 0, program.encode(), _ptr(m), len(m),
+                                 _ptr(o), C.byref(names), _ptr(qasc) if qasc is not None else None,
+                                 _ptr(qoff) if qoff is not None else None)
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_write_records")
 
 
 def karlin_params(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Karlin:

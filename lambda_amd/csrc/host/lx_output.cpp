@@ -1,0 +1,224 @@
+// lx_output.cpp -- record post-processing and BLAST-tabular / SAM writers.
+//
+// Host-side C++ mirror of
+//   _writeRecord          /root/reference/src/search_algo.hpp:820-913   (sort, dedupe, bit-score order, top-N)
+//   myWriteHeader         src/search_output.hpp:305-461
+//   myWriteRecord         src/search_output.hpp:463-733                  (tabular via seqan::writeRecord; SAM records)
+//   blastMatchOneCigar    src/search_output.hpp:115-194                  (soft clips, no frame clips for untranslated)
+// Scope: the untranslated programs (BLASTP, BLASTN).  The number formats of the tabular columns are SeqAn2's
+// (source absent): [UPSTREAM-RECALL] pident %.2f, evalue %.1e, bitscore %.1f, 1-based inclusive positions.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/lambda_ext.h"
+
+namespace
+{
+
+std::string firstWord(char const * id)
+{
+    std::string s(id ? id : "");
+    size_t      p = s.find_first_of(" \t");
+    return p == std::string::npos ? s : s.substr(0, p);
+}
+
+// blastMatchOneCigar, src/search_output.hpp:115-194, for transFac = 1 and no frame clips
+std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen, bool hardClip)
+{
+    std::string    c;
+    uint64_t const leftClip = m.q_start, rightClip = qLen - m.q_end;
+    if (leftClip > 0)
+        c += std::to_string(leftClip) + (hardClip ? 'H' : 'S');
+    uint8_t const * o = ops + m.ops_off;
+    for (uint32_t i = 0; i < m.n_ops;)
+    {
+        uint32_t cnt = 0;
+        while (i < m.n_ops && o[i] == 'D') // gap in row0 = deletion in query
+        {
+            ++cnt;
+            ++i;
+        }
+        if (cnt)
+            c += std::to_string(cnt) + 'D';
+        cnt = 0;
+        while (i < m.n_ops && o[i] == 'I')
+        {
+            ++cnt;
+            ++i;
+        }
+        if (cnt)
+            c += std::to_string(cnt) + 'I';
+        cnt = 0;
+        while (i < m.n_ops && o[i] == 'M')
+        {
+            ++cnt;
+            ++i;
+        }
+        if (cnt)
+            c += std::to_string(cnt) + 'M';
+    }
+    if (rightClip > 0)
+        c += std::to_string(rightClip) + (hardClip ? 'H' : 'S');
+    return c;
+}
+
+} // namespace
+
+extern "C" {
+
+uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_matches, lx_record_stats * stats)
+{
+    lx_record_stats st{};
+    uint64_t        w = 0;
+    for (uint64_t lo = 0; lo < n;)
+    {
+        uint64_t hi = lo + 1;
+        while (hi < n && m[hi].n_qid == m[lo].n_qid)
+            ++hi;
+        ++st.qrys_with_hit; // :826
+        std::vector<lx_blast_match> rec(m + lo, m + hi);
+        // sort matches, using an inverted bitScore to have the highest score first (:832-853); frames are 0 here
+        std::stable_sort(rec.begin(), rec.end(),
+                         [](lx_blast_match const & a, lx_blast_match const & b)
+                         {
+                             return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, b.bit_score) <
+                                    std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, a.bit_score);
+                         });
+        // removes duplicates and keeping the ones with the greatest score (:856-862)
+        auto const before = rec.size();
+        rec.erase(std::unique(rec.begin(), rec.end(),
+                              [](lx_blast_match const & a, lx_blast_match const & b)
+                              {
+                                  return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end) ==
+                                         std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end);
+                              }),
+                  rec.end());
+        st.hits_duplicate2 += before - rec.size();
+        // sort by evalue before writing (:865) -- std::list::sort is stable
+        std::stable_sort(rec.begin(), rec.end(),
+                         [](lx_blast_match const & a, lx_blast_match const & b) { return a.bit_score > b.bit_score; });
+        // cutoff abundant (:867-872)
+        if (rec.size() > max_matches)
+        {
+            st.hits_abundant += rec.size() - max_matches;
+            rec.resize(max_matches);
+        }
+        st.hits_final += rec.size();
+        std::set<uint64_t> uniq; // :876-882
+        for (auto const & r : rec)
+            uniq.insert(r.n_sid);
+        st.pairs += uniq.size();
+        for (auto const & r : rec)
+            m[w++] = r;
+        lo = hi;
+    }
+    if (stats)
+        *stats = st;
+    return w;
+}
+
+int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
+                     uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
+                     uint64_t const * q_ascii_off)
+{
+    if (!path || !names || (!m && n) || !program)
+        return LX_EINVAL;
+    bool const  isN = std::strcmp(program, "blastn") == 0;
+    std::FILE * f   = std::fopen(path, write_header ? "w" : "a");
+    if (!f)
+        return LX_EINVAL;
+    std::string const upper = isN ? "BLASTN" : "BLASTP";
+
+    if (format == LX_OUT_SAM)
+    {
+        if (write_header) // src/search_output.hpp:382-460 (SAM without reference header records)
+        {
+            std::fprintf(f, "@HD\tVN:1.4\tGO:query\n");
+            std::fprintf(f, "@CO\tLambda is a high performance BLAST compatible local aligner, please see http://seqan.de/lambda "
+                            "for more information.\n");
+            std::fprintf(f, "@CO\tSAM/BAM dialect documentation is available here: https://github.com/seqan/lambda/wiki/Output-Formats\n");
+            std::fprintf(f, "@CO\tIf you use any results found by Lambda, please cite Hauswedell et al. (2014) doi: "
+                            "10.1093/bioinformatics/btu439\n");
+            std::fprintf(f, "@CO\tOptional tags as follow\tAS:bit score\tNM:edit distance (in protein space unless BLASTN)\tae:expect "
+                            "value\tai:%% identity (in protein space unless BLASTN) \tqf:query frame\n");
+        }
+        for (uint64_t lo = 0; lo < n;)
+        {
+            uint64_t hi = lo + 1;
+            while (hi < n && m[hi].n_qid == m[lo].n_qid)
+                ++hi;
+            for (uint64_t k = lo; k < hi; ++k)
+            {
+                lx_blast_match const & b = m[k];
+                if (b.n_qid >= names->n_q || b.n_sid >= names->n_s)
+                {
+                    std::fclose(f);
+                    return LX_EINVAL;
+                }
+                int const         flag = (k == lo) ? 0 : 256; // all but the first are secondary (:505, :723)
+                std::string const qn = firstWord(names->q_ids[b.n_qid]), sn = firstWord(names->s_ids[b.n_sid]);
+                // BLASTP: no DNA cigar and no SEQ ("*"); BLASTN: cigar with soft clips and, for the first record of a
+                // query region, the read sequence (samBamSeq = uniq, :536-553)
+                std::string cigar = "*", seq = "*";
+                if (isN)
+                {
+                    cigar = cigarOf(b, ops, names->q_lens[b.n_qid], false);
+                    bool writeSeq = (k == lo) || b.q_start != m[k - 1].q_start || b.q_end != m[k - 1].q_end;
+                    if (writeSeq && q_res_ascii && q_ascii_off)
+                        seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], names->q_lens[b.n_qid]);
+                }
+                std::fprintf(f, "%s\t%d\t%s\t%llu\t255\t%s\t*\t0\t0\t%s\t*", qn.c_str(), flag, sn.c_str(),
+                             (unsigned long long)(b.s_start + 1), cigar.c_str(), seq.c_str());
+                // tags in the order of myWriteRecord: ae, AS, ai, qf, NM (:611-716)
+                std::fprintf(f, "\tae:f:%g\tAS:i:%u\tai:i:%u\tqf:i:%d\tNM:i:%u\n", (double)(float)b.e_value,
+                             (unsigned)(uint16_t)b.bit_score, (unsigned)(uint8_t)b.identity, isN ? 1 : 0,
+                             (unsigned)(b.alignment_length - b.num_matches));
+            }
+            lo = hi;
+        }
+    }
+    else
+    {
+        bool const comments = format == LX_OUT_BLAST_TAB_COMMENTS;
+        for (uint64_t lo = 0; lo < n;)
+        {
+            uint64_t hi = lo + 1;
+            while (hi < n && m[hi].n_qid == m[lo].n_qid)
+                ++hi;
+            if (comments)
+            {
+                std::fprintf(f, "# %s 2.2.26+ [created by LAMBDA, see http://seqan.de/lambda and please cite correctly in your academic work]\n",
+                             upper.c_str());
+                std::fprintf(f, "# Query: %s\n# Database: %s\n", names->q_ids[m[lo].n_qid], "lambda_ext");
+                std::fprintf(f, "# Fields: query id, subject id, %% identity, alignment length, mismatches, gap opens, q. start, "
+                                "q. end, s. start, s. end, evalue, bit score\n# %llu hits found\n",
+                             (unsigned long long)(hi - lo));
+            }
+            for (uint64_t k = lo; k < hi; ++k)
+            {
+                lx_blast_match const & b = m[k];
+                if (b.n_qid >= names->n_q || b.n_sid >= names->n_s)
+                {
+                    std::fclose(f);
+                    return LX_EINVAL;
+                }
+                std::fprintf(f, "%s\t%s\t%.2f\t%d\t%d\t%d\t%llu\t%llu\t%llu\t%llu\t%.1e\t%.1f\n",
+                             firstWord(names->q_ids[b.n_qid]).c_str(), firstWord(names->s_ids[b.n_sid]).c_str(),
+                             (double)b.identity, b.alignment_length, b.num_mismatches, b.num_gap_opens,
+                             (unsigned long long)(b.q_start + 1), (unsigned long long)b.q_end,
+                             (unsigned long long)(b.s_start + 1), (unsigned long long)b.s_end, b.e_value, b.bit_score);
+            }
+            lo = hi;
+        }
+    }
+    std::fclose(f);
+    return LX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,81 @@
+"""CPU tests of row N2: _writeRecord semantics (src/search_algo.hpp:820-913) and the BLAST-tabular / SAM writers
+(src/search_output.hpp:463-733).  No GPU needed: the inputs are finished HSP records."""
+import numpy as np
+
+from lambda_amd import capi
+
+
+def rec(n_qid, n_sid, qs, qe, ss, se, bits, score=50, alen=None, nm=None, ops_off=0, n_ops=0, ev=1e-5, ident=80.0):
+    r = np.zeros(1, dtype=capi.BLAST_MATCH_DTYPE)[0]
+    r["n_qid"], r["qry_id"], r["n_sid"], r["subj_id"] = n_qid, n_qid, n_sid, n_sid
+    r["q_start"], r["q_end"], r["s_start"], r["s_end"] = qs, qe, ss, se
+    r["bit_score"], r["score"], r["e_value"], r["identity"] = bits, score, ev, ident
+    r["alignment_length"] = alen if alen is not None else qe - qs
+    r["num_matches"] = nm if nm is not None else (qe - qs) * 8 // 10
+    r["num_mismatches"] = r["alignment_length"] - r["num_matches"]
+    r["ops_off"], r["n_ops"] = ops_off, n_ops
+    return r
+
+
+def test_postprocess_sort_dedupe_topn():
+    m = np.array([
+        rec(0, 5, 0, 50, 10, 60, 40.0),
+        rec(0, 2, 0, 50, 10, 60, 90.0),
+        rec(0, 5, 0, 50, 10, 60, 70.0),   # duplicate coordinates of the first, better score -> this one is kept
+        rec(0, 3, 5, 40, 100, 135, 90.0),  # ties with subject 2 on bit score: stable order after the coordinate sort
+        rec(0, 9, 0, 10, 0, 10, 10.0),
+        rec(1, 1, 0, 20, 0, 20, 30.0),
+        rec(1, 1, 0, 20, 0, 20, 30.0),     # exact duplicate
+    ], dtype=capi.BLAST_MATCH_DTYPE)
+    out, st = capi.postprocess_records(m, max_matches=3)
+    assert (st.qrys_with_hit, st.hits_duplicate2, st.hits_abundant, st.hits_final, st.pairs) == (2, 2, 1, 4, 4)
+    q0 = out[out["n_qid"] == 0]
+    assert list(q0["bit_score"]) == [90.0, 90.0, 70.0]
+    assert list(q0["n_sid"]) == [2, 3, 5]  # equal bit scores keep the (n_sid, ...) order of the first sort
+    q1 = out[out["n_qid"] == 1]
+    assert len(q1) == 1
+
+
+def test_blast_tab_writer(tmp_path):
+    ops = b"M" * 30
+    m = np.array([rec(0, 1, 4, 34, 99, 129, 61.23, alen=30, nm=27, n_ops=30, ev=3.2e-12, ident=90.0),
+                  rec(1, 0, 0, 30, 0, 30, 55.5, alen=30, nm=30, n_ops=30, ev=1.0e-9, ident=100.0)],
+                 dtype=capi.BLAST_MATCH_DTYPE)
+    m["num_gap_opens"] = [0, 0]
+    p = tmp_path / "out.m8"
+    capi.write_records(p, capi.LX_OUT_BLAST_TAB, m, ops, ["q0 desc", "q1"], [40, 30], ["s0", "s1 something"], [300, 400])
+    lines = p.read_text().splitlines()
+    assert lines[0] == "q0\ts1\t90.00\t30\t3\t0\t5\t34\t100\t129\t3.2e-12\t61.2"
+    assert lines[1] == "q1\ts0\t100.00\t30\t0\t0\t1\t30\t1\t30\t1.0e-09\t55.5"
+    p9 = tmp_path / "out.m9"
+    capi.write_records(p9, capi.LX_OUT_BLAST_TAB_COMMENTS, m, ops, ["q0 desc", "q1"], [40, 30], ["s0", "s1"], [300, 400])
+    txt = p9.read_text()
+    assert txt.count("# BLASTP 2.2.26+") == 2 and "# Query: q0 desc" in txt and "# 1 hits found" in txt
+
+
+def test_sam_writer_blastn_cigar_and_tags(tmp_path):
+    # 3 leading query bases unaligned, 10 M, 2 D (gap in the query row), 5 M, 1 I, 4 M, 5 trailing unaligned
+    ops = b"M" * 10 + b"D" * 2 + b"M" * 5 + b"I" + b"M" * 4
+    qlen = 3 + 10 + 5 + 1 + 4 + 5
+    m = np.array([rec(0, 0, 3, 23, 50, 71, 40.9, alen=len(ops), nm=17, n_ops=len(ops), ev=2e-4, ident=77.3),
+                  rec(0, 1, 3, 23, 10, 31, 30.0, alen=len(ops), nm=15, n_ops=len(ops), ev=2e-2, ident=70.0)],
+                 dtype=capi.BLAST_MATCH_DTYPE)
+    read = b"ACGTACGTACGTACGTACGTACGTACGT"[:qlen]
+    p = tmp_path / "out.sam"
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1 x"], [qlen], ["chr1", "chr2"], [1000, 1000], program="blastn",
+                       q_ascii=read, q_ascii_off=[0])
+    lines = [l for l in p.read_text().splitlines() if not l.startswith("@")]
+    f0, f1 = lines[0].split("\t"), lines[1].split("\t")
+    assert f0[:9] == ["read1", "0", "chr1", "51", "255", "3S10M2D5M1I4M5S", "*", "0", "0"]
+    assert f0[9] == read.decode() and f0[10] == "*"
+    assert f0[11:] == ["ae:f:0.0002", "AS:i:40", "ai:i:77", "qf:i:1", f"NM:i:{len(ops) - 17}"]
+    assert f1[1] == "256" and f1[2] == "chr2" and f1[9] == "*"  # secondary; same query region -> sequence not repeated
+    assert p.read_text().startswith("@HD\tVN:1.4\tGO:query\n")
+
+
+def test_sam_writer_blastp_has_no_cigar(tmp_path):
+    m = np.array([rec(0, 0, 0, 20, 5, 25, 50.0, n_ops=20)], dtype=capi.BLAST_MATCH_DTYPE)
+    p = tmp_path / "p.sam"
+    capi.write_records(p, capi.LX_OUT_SAM, m, b"M" * 20, ["q"], [20], ["s"], [100])
+    f = [l for l in p.read_text().splitlines() if not l.startswith("@")][0].split("\t")
+    assert f[5] == "*" and f[9] == "*" and "qf:i:0" in f  # src/search_output.hpp:527-531: no DNA cigar for BLASTP
