@@ -117,8 +117,10 @@ enum
                                    device, which costs lx_align_batch_dev one stream synchronisation)          */
     LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 32 GiB); larger batches are
                                    processed in chunks, in order, on the same stream                            */
-    LX_OPT_BS_MATCH_RULE   = 6  /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
+    LX_OPT_BS_MATCH_RULE   = 6, /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
+    LX_OPT_PACKED_HALF     = 7  /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
+                                   proves it exact (results are bit-identical either way); 0: int32 kernel only */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 

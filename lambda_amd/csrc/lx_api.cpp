@@ -25,6 +25,9 @@ hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t 
 int        score_cfg_panel(int cfg);
 int        score_cfg_groups(int cfg);
 int        score_cfg_count();
+hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream);
+int        score_pair_cfg_for(uint32_t max_qlen);
+int        score_pair_cfg_cols(int cfg);
 hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
@@ -90,6 +93,7 @@ struct lx_handle
     uint64_t opt_max_slen  = 0;
     uint64_t opt_trace_bytes = 32ull << 30;
     uint64_t opt_bs_rule   = 0;
+    uint64_t opt_f16       = 1;
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
 
@@ -231,7 +235,7 @@ int check_async_error(lx_handle * h)
 // One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
 // (or need the multi-panel path when wider).
 int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n,
-                      void * d_out, int cfg, bool multi, bool shared, hipStream_t stream)
+                      void * d_out, int cfg, bool multi, bool shared, hipStream_t stream, int pair_cfg = -1)
 {
     lx::ScoreParams p{};
     p.q_res          = static_cast<uint8_t const *>(d_q);
@@ -246,14 +250,27 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
     p.shared_profile = shared ? 1 : 0;
     p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
-    LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
+    p.fixup          = 0;
+    char buf[128];
+    if (pair_cfg >= 0)
     {
-        char buf[96];
+        // packed-half kernel first (two extensions per lane group); wavefronts whose score bound does not fit half
+        // precision leave the sentinel -1, which the int32 kernel then resolves in fix-up mode
+        LX_HIP(h, lx::launch_score_pair(pair_cfg, p, stream));
+        p.fixup = 1;
+        LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
+        snprintf(buf, sizeof(buf), "lx::score_pair_kernel<8,%d> (+ int32 fix-up lx::score_kernel<%d,%d,%s>)",
+                 lx::score_pair_cfg_cols(pair_cfg), 64 / lx::score_cfg_groups(cfg),
+                 lx::score_cfg_panel(cfg) * lx::score_cfg_groups(cfg) / 64, multi ? "true" : "false");
+    }
+    else
+    {
+        LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
         snprintf(buf, sizeof(buf), "lx::score_kernel<%d,%d,%s>%s", 64 / lx::score_cfg_groups(cfg),
                  lx::score_cfg_panel(cfg) * lx::score_cfg_groups(cfg) / 64, multi ? "true" : "false",
                  shared ? " shared-profile" : "");
-        h->last_kernel = buf;
     }
+    h->last_kernel = buf;
     return LX_OK;
 }
 
@@ -385,6 +402,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_MAX_SLEN: h->opt_max_slen = value; return LX_OK;
         case LX_OPT_TRACE_BYTES: h->opt_trace_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
         case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
+        case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
         default: return fail(h, LX_EINVAL, "unknown option %d", option);
     }
 }
@@ -438,6 +456,26 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
             d.mat_trace[a * lx::kAlph + b] = (int8_t)(pad || adj < -31 || adj > 31 ? -126 : 4 * adj + 2);
         }
     d.trace_ok = trace_ok;
+    d.smax     = 0;
+    for (int a = 0; a < lx::kAlph; ++a)
+    {
+        int rm = 0;
+        for (int b = 0; b < lx::kAlph; ++b)
+        {
+            bool const pad = a >= sc->alphabet_size || b >= sc->alphabet_size;
+            int const  v   = pad ? lx::kNegPad : sc->matrix[a * LX_ALPH + b] - sc->gap_extend;
+            _Float16 const hv = (_Float16)(float)v; // integers of magnitude <= 128: exact
+            uint16_t       bits;
+            std::memcpy(&bits, &hv, 2);
+            d.mat_h[a * lx::kAlph + b] = bits;
+            if (!pad)
+            {
+                rm     = std::max(rm, (int)sc->matrix[a * LX_ALPH + b]);
+                d.smax = std::max(d.smax, (int)sc->matrix[a * LX_ALPH + b] - sc->gap_extend);
+            }
+        }
+        d.rowmax[a] = (int16_t)rm;
+    }
     int rc = bind(h);
     if (rc)
         return rc;
@@ -535,8 +573,12 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
         h->ev_pool_used = 0;
         LX_HIP(h, hipEventRecord(h->ev0, stream));
     }
+    // packed-half path: every wavefront of 16 extensions must share its query and the query must fit one panel
+    int pair_cfg = -1;
+    if (h->opt_f16 && shared && h->opt_query_run % 16 == 0 && h->opt_max_qlen != 0)
+        pair_cfg = lx::score_pair_cfg_for((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu));
     PhaseTimer pt(h, stream, 0);
-    if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream)))
+    if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream, pair_cfg)))
         return rc;
     pt.close();
     if (!h->in_fused)

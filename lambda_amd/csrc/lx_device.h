@@ -22,7 +22,12 @@ struct ScoringDev
     // "diagonal"), pad ranks = -126.  Valid when every (matrix - ge) lies in [-31, 31] (trace_ok).
     int8_t  mat_trace[kAlph * kAlph];
     int32_t trace_ok;
-    int32_t reserved[3];
+    // packed-half pass 1 (lx_score_f16.hip): (matrix - ge) as IEEE half bits, pad ranks = -100; per query rank the
+    // largest positive score of its row (upper bound of what one query column can contribute); largest entry
+    int32_t  smax;
+    int32_t  reserved[2];
+    int16_t  rowmax[kAlph];
+    uint16_t mat_h[kAlph * kAlph];
 };
 
 // Mirrors lx_extension in include/lambda_ext.h (static_assert'ed in lx_api.cpp).
@@ -61,6 +66,7 @@ struct ScoreParams
     int32_t *          err;      // set to 1 on workspace overflow
     int32_t            shared_profile; // 1: every group of a wave uses the same query -> one profile slot per wave
     int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
+    int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
 };
 
 // best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel

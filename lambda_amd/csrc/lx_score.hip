@@ -52,7 +52,14 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
     bool const is_last  = (g == G - 1);
 
     uint64_t const e      = (uint64_t)blockIdx.x * Geo::kGroups + grp;
-    bool const     active = e < p.n;
+    bool           active = e < p.n;
+    if (p.fixup)
+    {
+        // second launch after the packed-half kernel: only the extensions it declined (sentinel -1) are computed
+        active = active && p.out_score[e] < 0;
+        if (__ballot(active) == 0)
+            return;
+    }
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge    = sc->ge;

@@ -1,0 +1,401 @@
+// lx_score_f16.hip -- pass-1 score kernel in packed half precision: two extensions per lane group (gfx950 only).
+//
+// Same strip-systolic mapping and row-skewed recurrence as lx_score.hip (see there for the reference lines), but
+// every VGPR holds the DP value of TWO extensions (A in the low half, B in the high half) that share the query, and
+// the arithmetic is v_pk_add_f16 / v_pk_maximum3_f16.  On gfx950 the packed ops issue at the same rate as the
+// int32 max/max3 (tools/ubench.hip), so a cell costs 7.5 issue slots instead of 11.  Scores are small integers;
+// half precision represents every integer of magnitude <= 2048 exactly and -inf stands in for "minus infinity", so
+// the results are bit-identical to the int32 kernel AS LONG AS no intermediate exceeds 2048.  That is decided per
+// wavefront from an upper bound:
+//         sum_j max(0, max_b s(q_j, b))  +  |ge| * (rows processed)  +  max entry  <=  2046
+// (a local alignment cannot score more than the sum of the best positive score of each query column).  A wavefront
+// that fails the test writes the sentinel -1 for its extensions and the host follows up with the int32 kernel in
+// "fix-up" mode, which recomputes exactly those.  Nothing is approximated.
+//
+// LDS: one query profile per wavefront in half precision, lane-contiguous rows (24 halves = 48 B per lane per subject
+// letter, read with two ds_read_b128 + one ds_read_b64); the two subject letters of a lane give two reads whose
+// halves are interleaved with one v_perm_b32 per column.  All 16 extensions of a wavefront must share the query
+// (LX_OPT_QUERY_RUN multiple of 16, or host-side padding).
+#include <hip/hip_runtime.h>
+
+#include "lx_dp_common.h"
+
+namespace lx
+{
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ h2 hmax3(h2 a, h2 b, h2 c)
+{
+    return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); // v_pk_maximum3_f16
+}
+__device__ __forceinline__ h2 hmax(h2 a, h2 b)
+{
+    return __builtin_elementwise_maximum(a, b);
+}
+__device__ __forceinline__ h2 hsplat(float x)
+{
+    return h2{(_Float16)x, (_Float16)x};
+}
+__device__ __forceinline__ h2 as_h2(uint32_t x)
+{
+    return __builtin_bit_cast(h2, x);
+}
+__device__ __forceinline__ uint32_t as_u32(h2 x)
+{
+    return __builtin_bit_cast(uint32_t, x);
+}
+
+constexpr uint32_t kHalfNegInf2 = 0xfc00fc00u; // (-inf, -inf)
+
+template <int G, int C>
+struct PairGeo
+{
+    static constexpr int kGroups   = 64 / G;                 // lane groups per wavefront, two extensions each
+    static constexpr int kPanel    = G * C;
+    static constexpr int kLaneDw   = 12;                     // 24 halves per lane per profile row (C <= 24)
+    static constexpr int kRowDw    = kLaneDw * G;
+    static constexpr int kUsedDw   = (C + 1) / 2;            // dwords that hold real columns
+};
+
+template <int G, int C>
+__global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
+{
+    static_assert(C <= 24, "profile rows hold 24 halves per lane");
+    using Geo = PairGeo<G, C>;
+    extern __shared__ uint32_t lds[];
+
+    int const  lane     = threadIdx.x;
+    int const  grp      = lane / G;
+    int const  g        = lane % G;
+    bool const is_first = (g == 0);
+
+    uint64_t const pair   = (uint64_t)blockIdx.x * Geo::kGroups + grp;
+    uint64_t const eA     = 2 * pair, eB = 2 * pair + 1;
+    bool const     actA   = eA < p.n, actB = eB < p.n;
+
+    ScoringDev const * __restrict__ sc = p.sc;
+    int const      ge    = sc->ge;
+    int const      nrows = p.nrows;
+    uint32_t const padt  = (uint32_t)(nrows - 1);
+
+    int             lq = 0, lsA = 0, lsB = 0;
+    uint8_t const * q  = p.q_res;
+    uint8_t const * sA = p.s_res;
+    uint8_t const * sB = p.s_res;
+    uint64_t        q_off = 0;
+    if (actA)
+    {
+        Extension const x = p.ext[eA];
+        lq    = (int)x.q_len;
+        q_off = x.q_off;
+        q += x.q_off;
+        lsA = (int)x.s_len;
+        if (lsA != 0)
+            sA += x.s_off;
+    }
+    uint64_t q_offB = q_off;
+    int      lqB    = lq;
+    if (actB)
+    {
+        Extension const x = p.ext[eB];
+        lqB    = (int)x.q_len;
+        q_offB = x.q_off;
+        lsB    = (int)x.s_len;
+        if (lsB != 0)
+            sB += x.s_off;
+    }
+    {
+        // the caller promised one query per wavefront: verify, fail loudly otherwise
+        uint64_t const q0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q_off >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q_off);
+        int const l0 = __builtin_amdgcn_readfirstlane(lq);
+        if ((actA && (q_off != q0 || lq != l0)) || (actB && (q_offB != q0 || lqB != l0)))
+            atomicExch(p.err, 2);
+    }
+
+    int ls_max = max(lsA, lsB);
+    int ls_min = min(actA ? lsA : 0x7fffffff, actB ? lsB : 0x7fffffff);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        ls_max = max(ls_max, __shfl_xor(ls_max, off));
+        ls_min = min(ls_min, __shfl_xor(ls_min, off));
+    }
+    ls_max = __builtin_amdgcn_readfirstlane(ls_max);
+    ls_min = __builtin_amdgcn_readfirstlane(ls_min);
+    int const steps = (ls_max + G - 1 + 3) & ~3;
+
+    // ---- exactness test (wave-uniform): an upper bound of every intermediate must stay <= 2046
+    int const col0 = g * C;
+    int       bound = 0;
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+        int const j = col0 + c;
+        if (j < lq)
+            bound += sc->rowmax[q[j] & (kAlph - 1)];
+    }
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1)
+        bound += __shfl_xor(bound, off);
+    bound              = __builtin_amdgcn_readfirstlane(bound); // lane 0's group = the shared query
+    bool const too_big = (lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046);
+    if (too_big)
+    {
+        if (is_first)
+        {
+            if (actA)
+                p.out_score[eA] = -1;
+            if (actB)
+                p.out_score[eB] = -1;
+        }
+        return;
+    }
+
+    // ---- profile: prof[t][g][h] = (s(q_col, t) - ge) as half, lane-contiguous
+    if (grp == 0)
+    {
+#pragma unroll 1
+        for (int d = 0; d < Geo::kUsedDw; ++d)
+        {
+            uint32_t rows[2][16];
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+            {
+                int const c  = 2 * d + cc;
+                int const j  = col0 + c;
+                uint32_t  ql = kAlph - 1;
+                if (c < C && j < lq)
+                    ql = q[j] & (kAlph - 1);
+                uint4 const * mrow = reinterpret_cast<uint4 const *>(sc->mat_h + ql * kAlph);
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                {
+                    uint4 const v      = mrow[x];
+                    rows[cc][4 * x + 0] = v.x;
+                    rows[cc][4 * x + 1] = v.y;
+                    rows[cc][4 * x + 2] = v.z;
+                    rows[cc][4 * x + 3] = v.w;
+                }
+            }
+            uint32_t * dst = lds + g * Geo::kLaneDw + d;
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+            {
+                if (2 * w < nrows)
+                {
+                    // letters t = 2w (low halves) and 2w+1 (high halves) of both columns
+                    dst[(2 * w) * Geo::kRowDw]     = __builtin_amdgcn_perm(rows[1][w], rows[0][w], 0x05040100u);
+                    dst[(2 * w + 1) * Geo::kRowDw] = __builtin_amdgcn_perm(rows[1][w], rows[0][w], 0x07060302u);
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t const row_base  = (uint32_t)(g * Geo::kLaneDw) * 4u;
+    constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
+
+    h2 const GE = hsplat((float)ge), G2 = hsplat((float)sc->g2), NGE = hsplat((float)-ge);
+    h2       Z  = hsplat((float)(ge * g)); // z_i of the first processed row i = -g
+    h2       Hrow[C], F0[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+        Hrow[c] = Z + GE;
+        F0[c]   = Z;
+    }
+    h2 diag0 = Z + GE;
+    h2 sendH = Z + GE;
+    h2 sendE = as_h2(kHalfNegInf2);
+    h2 best  = hsplat(0.f);
+
+    auto step = [&](uint32_t tA, uint32_t tB)
+    {
+        uint4 const * ra = reinterpret_cast<uint4 const *>(reinterpret_cast<char const *>(lds) + row_base + tA * kRowBytes);
+        uint4 const * rb = reinterpret_cast<uint4 const *>(reinterpret_cast<char const *>(lds) + row_base + tB * kRowBytes);
+        uint32_t      pa[Geo::kLaneDw], pb[Geo::kLaneDw];
+#pragma unroll
+        for (int x = 0; x < (Geo::kUsedDw + 3) / 4; ++x)
+        {
+            if (4 * x + 2 >= Geo::kUsedDw) // only two more dwords are needed: ds_read_b64
+            {
+                uint2 const va = *reinterpret_cast<uint2 const *>(ra + x), vb = *reinterpret_cast<uint2 const *>(rb + x);
+                pa[4 * x] = va.x; pa[4 * x + 1] = va.y;
+                pb[4 * x] = vb.x; pb[4 * x + 1] = vb.y;
+            }
+            else
+            {
+                uint4 const va = ra[x], vb = rb[x];
+                pa[4 * x] = va.x; pa[4 * x + 1] = va.y; pa[4 * x + 2] = va.z; pa[4 * x + 3] = va.w;
+                pb[4 * x] = vb.x; pb[4 * x + 1] = vb.y; pb[4 * x + 2] = vb.z; pb[4 * x + 3] = vb.w;
+            }
+        }
+
+        // left boundary: H[i][-1] = 0 (skewed: z), E = -inf
+        h2 const recvH = as_h2((uint32_t)shift_from_left<G>((int)as_u32(sendH), (int)as_u32(Z), is_first));
+        h2       Ecur  = as_h2((uint32_t)shift_from_left<G>((int)as_u32(sendE), (int)kHalfNegInf2, is_first));
+        h2       dg    = diag0;
+        diag0          = recvH;
+
+        h2 const ZN     = Z + NGE;
+        h2       rowmax = as_h2(kHalfNegInf2);
+        h2       h      = Z;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+            // (score of column c vs letter tA, score of column c vs letter tB)
+            uint32_t const sel = (c & 1) ? 0x07060302u : 0x05040100u;
+            h2 const       sub = as_h2(__builtin_amdgcn_perm(pb[c >> 1], pa[c >> 1], sel));
+            h2 const       tt  = dg + sub;
+            dg                 = Hrow[c];
+            h                  = hmax3(tt, Ecur, F0[c]);
+            uint32_t hb        = as_u32(h);
+            LX_OPAQUE(hb);
+            h                  = as_h2(hb);
+            h2 const A         = h + G2;
+            h2       f         = hmax3(F0[c], A, ZN);
+            uint32_t fb        = as_u32(f);
+            LX_OPAQUE(fb);
+            F0[c]              = as_h2(fb);
+            Ecur               = hmax(Ecur, A) + GE;
+            Hrow[c]            = h;
+            if (c & 1)
+                rowmax = hmax3(rowmax, Hrow[c - 1], h);
+        }
+        if (C & 1)
+            rowmax = hmax(rowmax, h);
+        sendH = h;
+        sendE = Ecur;
+        best  = hmax(best, rowmax - Z);
+        Z     = ZN;
+    };
+
+    uint32_t const lscA = (uint32_t)max(lsA, 1) - 1u, lscB = (uint32_t)max(lsB, 1) - 1u;
+    auto fetch_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
+    {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            uint32_t const i = (uint32_t)(k0 + u - g);
+            ta[u]            = sA[min(i, lscA)];
+            tb[u]            = sB[min(i, lscB)];
+        }
+    };
+    auto mask_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
+    {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            uint32_t const i = (uint32_t)(k0 + u - g);
+            ta[u]            = (i < (uint32_t)lsA) ? (ta[u] & (kAlph - 1)) : padt;
+            tb[u]            = (i < (uint32_t)lsB) ? (tb[u] & (kAlph - 1)) : padt;
+        }
+    };
+
+    int const steady_lo = (G - 1 + 3) & ~3;
+    int const steady_hi = ls_min - 3;
+    uint8_t const * spA = sA - g;
+    uint8_t const * spB = sB - g;
+
+    int      k0 = 0;
+    uint32_t na[4], nb[4];
+    fetch_checked(0, na, nb);
+    while (k0 < steps)
+    {
+        bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
+        if (!cur_steady)
+        {
+            uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
+            mask_checked(k0, ca, cb);
+            fetch_checked(k0 + 4, na, nb);
+#pragma unroll 1
+            for (int u = 0; u < 4; ++u)
+                step(ca[u], cb[u]);
+            k0 += 4;
+        }
+        else
+        {
+            uint32_t wa = *reinterpret_cast<unaligned_u32 const *>(spA + k0);
+            uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
+            while (k0 < steady_hi)
+            {
+                uint32_t const ca = wa, cb = wb;
+                int const      kn = max(min(k0 + 4, ls_min - 4), 0);
+                wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
+                wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
+#pragma unroll 1
+                for (int u = 0; u < 4; ++u)
+                    step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1));
+                k0 += 4;
+            }
+            fetch_checked(k0, na, nb);
+        }
+    }
+
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1)
+        best = hmax(best, as_h2((uint32_t)__shfl_xor((int)as_u32(best), off)));
+
+    if (is_first)
+    {
+        if (actA)
+            p.out_score[eA] = (int)(float)best.x;
+        if (actB)
+            p.out_score[eB] = (int)(float)best.y;
+    }
+}
+
+template <int G, int C>
+static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
+{
+    using Geo = PairGeo<G, C>;
+    uint64_t const per_wave = 2ull * Geo::kGroups;
+    uint64_t const blocks   = (p.n + per_wave - 1) / per_wave;
+    if (blocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    size_t const lds = (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    hipLaunchKernelGGL((score_pair_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+// pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192
+hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    switch (cfg)
+    {
+        case 0: return launch_pair_cfg<8, 19>(p, stream);
+        case 1: return launch_pair_cfg<8, 13>(p, stream);
+        case 2: return launch_pair_cfg<8, 16>(p, stream);
+        case 3: return launch_pair_cfg<8, 8>(p, stream);
+        case 4: return launch_pair_cfg<8, 24>(p, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+int score_pair_cfg_for(uint32_t max_qlen)
+{
+    if (max_qlen <= 64)
+        return 3;
+    if (max_qlen <= 104)
+        return 1;
+    if (max_qlen <= 128)
+        return 2;
+    if (max_qlen <= 152)
+        return 0;
+    if (max_qlen <= 192)
+        return 4;
+    return -1;
+}
+
+int score_pair_cfg_cols(int cfg)
+{
+    static int const c[5] = {19, 13, 16, 8, 24};
+    return (cfg >= 0 && cfg < 5) ? c[cfg] : 0;
+}
+
+} // namespace lx
