@@ -645,7 +645,10 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         std::vector<uint32_t>     perm;
         uint32_t                  max_qlen = 0;
     };
-    std::vector<Bin> bins((size_t)ncfg * 2);
+    // bins[kind][cfg]: kind 0 = per-extension profiles, 1 = one profile per wavefront (int32), 2 = packed half
+    // (16 extensions of one query per wavefront; index = pair geometry)
+    std::vector<Bin> bins((size_t)ncfg * 2 + 8);
+    auto             bin_of = [&](int kind, int cfg) -> Bin & { return kind == 2 ? bins[(size_t)ncfg * 2 + cfg] : bins[(size_t)cfg * 2 + kind]; };
     uint64_t         carry_pairs = 0;
     for (size_t k = 0; k < idx.size();)
     {
@@ -654,34 +657,48 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             ++k1;
         uint64_t const run  = k1 - k;
         uint32_t const qlen = ext[idx[k]].q_len;
-        int            cfg  = pick_cfg(qlen, true);
-        uint64_t       grp  = (uint64_t)lx::score_cfg_groups(cfg);
-        uint64_t       pad  = (run + grp - 1) / grp * grp;
-        bool           shared = grp > 1 && (pad - run) * 4 <= pad;
-        if (!shared)
+        int            kind = 0, cfg = 0;
+        uint64_t       pad  = run;
+        int const      pcfg = h->opt_f16 ? lx::score_pair_cfg_for(qlen) : -1;
+        uint64_t const pad16 = (run + 15) / 16 * 16;
+        if (pcfg >= 0 && (pad16 - run) * 4 <= pad16)
         {
-            cfg = pick_cfg(qlen, false);
-            grp = (uint64_t)lx::score_cfg_groups(cfg);
-            pad = (run + grp - 1) / grp * grp;
-            shared = grp > 1 && (pad - run) * 4 <= pad;
+            kind = 2;
+            cfg  = pcfg;
+            pad  = pad16;
         }
-        Bin & bin    = bins[(size_t)cfg * 2 + (shared ? 1 : 0)];
+        else
+        {
+            cfg          = pick_cfg(qlen, true);
+            uint64_t grp = (uint64_t)lx::score_cfg_groups(cfg);
+            pad          = (run + grp - 1) / grp * grp;
+            kind         = (grp > 1 && (pad - run) * 4 <= pad) ? 1 : 0;
+            if (kind == 0)
+            {
+                cfg  = pick_cfg(qlen, false);
+                grp  = (uint64_t)lx::score_cfg_groups(cfg);
+                pad  = (run + grp - 1) / grp * grp;
+                kind = (grp > 1 && (pad - run) * 4 <= pad) ? 1 : 0;
+                if (kind == 0)
+                    pad = run;
+            }
+        }
+        Bin & bin    = bin_of(kind, cfg);
         bin.max_qlen = std::max(bin.max_qlen, qlen);
         for (size_t j = k; j < k1; ++j)
         {
             bin.ext.push_back(ext[idx[j]]);
             bin.perm.push_back(idx[j]);
-            if ((int)qlen > lx::score_cfg_panel(cfg))
+            if (kind != 2 && (int)qlen > lx::score_cfg_panel(cfg))
                 carry_pairs += ext[idx[j]].s_len;
         }
-        if (shared)
-            for (uint64_t j = run; j < pad; ++j) // dummy slots keep one query per wavefront
-            {
-                lx_extension dummy = ext[idx[k]];
-                dummy.s_len        = 0;
-                bin.ext.push_back(dummy);
-                bin.perm.push_back(0xffffffffu);
-            }
+        for (uint64_t j = run; j < pad; ++j) // dummy slots keep one query per wavefront
+        {
+            lx_extension dummy = ext[idx[k]];
+            dummy.s_len        = 0;
+            bin.ext.push_back(dummy);
+            bin.perm.push_back(0xffffffffu);
+        }
         k = k1;
     }
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
@@ -696,18 +713,30 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         int      cfg;
         uint64_t first, count;
         bool     multi, shared;
+        int      pair_cfg;
     };
     std::vector<Seg> segs;
     for (int cfg = 0; cfg < ncfg; ++cfg)
         for (int sh = 0; sh < 2; ++sh)
         {
-            Bin & bin = bins[(size_t)cfg * 2 + sh];
+            Bin & bin = bin_of(sh, cfg);
             if (bin.ext.empty())
                 continue;
-            segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), bin.max_qlen > (uint32_t)lx::score_cfg_panel(cfg), sh == 1});
+            segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), bin.max_qlen > (uint32_t)lx::score_cfg_panel(cfg), sh == 1, -1});
             sorted.insert(sorted.end(), bin.ext.begin(), bin.ext.end());
             perm.insert(perm.end(), bin.perm.begin(), bin.perm.end());
         }
+    for (int pcfg = 0; pcfg < 8; ++pcfg)
+    {
+        Bin & bin = bin_of(2, pcfg);
+        if (bin.ext.empty())
+            continue;
+        // the int32 fix-up launch over the same list uses the shared-profile geometry of the longest query
+        int const cfg = pick_cfg(bin.max_qlen, true);
+        segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), false, true, pcfg});
+        sorted.insert(sorted.end(), bin.ext.begin(), bin.ext.end());
+        perm.insert(perm.end(), bin.perm.begin(), bin.perm.end());
+    }
     if (sorted.empty())
         return LX_OK;
 
@@ -732,7 +761,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         rc = launch_score_list(h, slot, h->d_q.ptr, h->d_s.ptr,
                                static_cast<lx_extension const *>(h->d_ext.ptr) + seg.first, seg.count,
                                static_cast<int32_t *>(h->d_out.ptr) + seg.first, seg.cfg, seg.multi, seg.shared,
-                               h->stream);
+                               h->stream, seg.pair_cfg);
         if (rc)
             return rc;
     }

@@ -25,6 +25,12 @@ namespace lx
 
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
+#ifndef LX_F16_UNROLL
+#define LX_F16_UNROLL 2 // steps unrolled in the main loop: 2 removes the register-rotation moves at 168 VGPRs
+#endif
+#define LX_PRAGMA(x) _Pragma(#x)
+#define LX_UNROLL(n) LX_PRAGMA(unroll n)
+
 __device__ __forceinline__ h2 hmax3(h2 a, h2 b, h2 c)
 {
     return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); // v_pk_maximum3_f16
@@ -252,14 +258,8 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
             h2 const       tt  = dg + sub;
             dg                 = Hrow[c];
             h                  = hmax3(tt, Ecur, F0[c]);
-            uint32_t hb        = as_u32(h);
-            LX_OPAQUE(hb);
-            h                  = as_h2(hb);
             h2 const A         = h + G2;
-            h2       f         = hmax3(F0[c], A, ZN);
-            uint32_t fb        = as_u32(f);
-            LX_OPAQUE(fb);
-            F0[c]              = as_h2(fb);
+            F0[c]              = hmax3(F0[c], A, ZN); // (floating-point max is not re-associated: no fences needed)
             Ecur               = hmax(Ecur, A) + GE;
             Hrow[c]            = h;
             if (c & 1)
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
                 int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                 wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
                 wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
-#pragma unroll 1
+LX_UNROLL(LX_F16_UNROLL)
                 for (int u = 0; u < 4; ++u)
                     step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1));
                 k0 += 4;

@@ -149,3 +149,72 @@ def test_linearity_property_full_size_rows(handle):
     ext2["s_len"] = 150
     got = handle.score_batch(q, q, ext2)
     assert (got == M[qq, qq].sum(axis=1)).all()
+
+
+def _dev_scores(handle, q, s, ext, max_qlen, run, packed):
+    import torch
+
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    d_out = torch.full((len(ext),), -7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    handle.set_option(capi.LX_OPT_MAX_QLEN, max_qlen)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, run)
+    handle.set_option(capi.LX_OPT_PACKED_HALF, packed)
+    try:
+        handle.score_batch_dev(d_q, d_s, d_ext, len(ext), d_out)
+        handle.synchronize()
+        name = handle.last_kernel_name()
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PACKED_HALF, 1)
+    return d_out.cpu().numpy(), name
+
+
+@pytest.mark.parametrize("lq,wpq", [(150, 32), (100, 16), (64, 16), (120, 48), (190, 16), (33, 16)])
+def test_packed_half_kernel_is_exact(handle, oracle, lq, wpq):
+    """The packed-half pass-1 kernel (lx_score_f16.hip) must be bit-identical to the oracle and to the int32 kernel."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_batch_np(96, lq, wpq, seed=1000 + lq)
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+    got, name = _dev_scores(handle, q, s, ext, lq, wpq, 1)
+    assert "score_pair_kernel" in name
+    assert (got == want).all()
+    got32, name32 = _dev_scores(handle, q, s, ext, lq, wpq, 0)
+    assert "score_pair_kernel" not in name32 and (got32 == want).all()
+
+
+def test_packed_half_declines_when_bound_too_large(handle, oracle):
+    """Tryptophan-rich queries (W/W = 11): the per-wavefront bound exceeds what half precision holds exactly, the
+    packed kernel must leave them to the int32 fix-up launch; mixed with ordinary queries in one batch."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    lq, wpq = 190, 16
+    q, s, ext = synth.make_batch_np(40, lq, wpq, seed=4242)
+    W = 22  # SeqAn rank of 'W'
+    qq = q.reshape(40, lq)
+    ss = s.reshape(40 * wpq, -1)
+    for k in range(0, 40, 3):  # every third query: all W, and its windows too -> scores up to 11 * 190 = 2090 > 2048
+        qq[k, :] = W
+        ss[k * wpq:(k + 1) * wpq, 10:10 + lq] = W
+    q, s = qq.reshape(-1), ss.reshape(-1)
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+    assert want.max() == 11 * lq
+    got, name = _dev_scores(handle, q, s, ext, lq, wpq, 1)
+    assert "score_pair_kernel" in name
+    assert (got == want).all()
+
+
+def test_packed_half_other_schemes(handle, oracle):
+    for name, alpha in (("nucl", np.array([0, 1, 2, 4], dtype=np.uint8)), ("bs_fwd", np.arange(4, dtype=np.uint8))):
+        sc_p = SCHEMES[name]
+        handle.set_scoring(sc_p, 0)
+        q, s, ext = synth.make_batch_np(64, 150, 16, seed=77, alphabet=alpha, sub_rate=0.05, indel_rate=0.02)
+        want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+        got, kn = _dev_scores(handle, q, s, ext, 150, 16, 1)
+        assert "score_pair_kernel" in kn and (got == want).all()
