@@ -1,0 +1,59 @@
+"""Condenses a gpurun_out/<dir> produced by the round's rocprofv3 runs into the tracked summaries under profiles/.
+
+    python tools/collect_profiles.py gpurun_out/r1b r01
+
+Inputs (made on the GPU box):
+    <dir>/stats/bench_kernel_stats.csv          rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...
+    <dir>/pmc_sq|pmc_fetch|pmc_write/pmc_counter_collection.csv   three separate --pmc passes
+    <dir>/bench.log, bench_pass1.log, stats.log  the bench JSON lines of the plain / pass-1-only / profiled runs
+"""
+import collections
+import csv
+import json
+import sys
+from pathlib import Path
+
+src, tag = Path(sys.argv[1]), sys.argv[2]
+out = Path(__file__).resolve().parent.parent / "profiles"
+out.mkdir(exist_ok=True)
+
+rows = list(csv.reader(open(src / "stats" / "bench_kernel_stats.csv")))
+with open(out / f"{tag}_bench_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if "lx::" in r[0] or float(r[4]) > 1.0:
+            w.writerow(r)
+
+steps_profiled = 3  # --steps 2 --warmup 1
+kern = {}
+for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    meta, launches = {}, collections.defaultdict(set)
+    for r in csv.DictReader(open(src / name / "pmc_counter_collection.csv")):
+        k = r["Kernel_Name"]
+        if "lx::" not in k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k].add(r["Dispatch_Id"])
+        meta[k] = {x: r[x] for x in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    for k, v in acc.items():
+        d = kern.setdefault(k, {"dispatch": meta[k], "counters_per_step_mean": {}, "counters_per_launch_mean": {}})
+        for c, x in v.items():
+            d["counters_per_step_mean"][c] = x / steps_profiled
+            d["counters_per_launch_mean"][c] = x / len(launches[k])
+json.dump({
+    "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
+               "(three separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE)",
+    "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced reads "
+            "(MI355X_MICROARCH.md, HBM) -> doubled before use.  The score kernels are launched once per step, the trace "
+            "kernels once per chunk, so per-step means are the comparable figures.",
+    "kernels": kern}, open(out / f"{tag}_bench_pmc.json", "w"), indent=1)
+
+for log, dst in (("bench.log", f"{tag}_bench_line.json"), ("bench_pass1.log", f"{tag}_bench_line_pass1_only.json"),
+                 ("stats.log", f"{tag}_bench_line_under_rocprof.json")):
+    lines = [l for l in open(src / log) if l.startswith('{"metric"')]
+    if lines:
+        (out / dst).write_text(lines[-1])
+for k, d in kern.items():
+    print(k[:60], {c: "%.4g" % x for c, x in d["counters_per_step_mean"].items()})
