@@ -60,6 +60,8 @@ struct PairGeo
     static constexpr int kGroups   = 64 / G;                 // lane groups per wavefront, two extensions each
     static constexpr int kPanel    = G * C;
     static constexpr int kLaneDw   = 12;                     // 24 halves per lane per profile row (C <= 24)
+    // (padding the rows to spread different subject letters over more bank offsets was measured: no effect -- the
+    // kernel is VALU-issue bound, LDS is ~1/3 busy including its bank conflicts)
     static constexpr int kRowDw    = kLaneDw * G;
     static constexpr int kUsedDw   = (C + 1) / 2;            // dwords that hold real columns
 };

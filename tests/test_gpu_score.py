@@ -218,3 +218,50 @@ def test_packed_half_other_schemes(handle, oracle):
         want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
         got, kn = _dev_scores(handle, q, s, ext, 150, 16, 1)
         assert "score_pair_kernel" in kn and (got == want).all()
+
+
+def test_full_size_batch_properties(handle):
+    """BASELINE.json configs[1] at FULL size (100 000 x 150 aa x 32 windows = 3.2 M extensions, 84.5 Gcells), checked
+    through size-independent properties, no oracle: (1) two independent kernels -- packed half and int32 -- agree on
+    every extension (checksum and element-wise); (2) planting the query itself in a window makes the score the sum of the
+    query's diagonal entries; (3) scores are bounded by that sum and non-negative."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    nq, lq, wpq = 100_000, 150, 32
+    d_q, d_s, d_ext, ext = synth.make_batch_torch(nq, lq, wpq, 0x1A3BDA02, dev)
+    ls = synth.window_len(lq)
+    b = synth.band_size(lq)
+    # plant query k verbatim into its window 0 (rows b..b+lq)
+    s2 = d_s.view(nq * wpq, ls)
+    s2[torch.arange(nq, device=dev) * wpq, b:b + lq] = d_q.view(nq, lq)
+    pad = torch.zeros(256, dtype=torch.uint8, device=dev)
+    d_q = torch.cat([d_q, pad])
+    d_s = torch.cat([s2.reshape(-1), pad])
+    n = len(ext)
+    outs = {}
+    for packed in (1, 0):
+        d_out = torch.full((n,), -9, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+        handle.set_option(capi.LX_OPT_PACKED_HALF, packed)
+        try:
+            handle.score_batch_dev(d_q, d_s, d_ext, n, d_out)
+            handle.synchronize()
+            assert ("score_pair_kernel" in handle.last_kernel_name()) == bool(packed)
+        finally:
+            handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+            handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+            handle.set_option(capi.LX_OPT_PACKED_HALF, 1)
+        outs[packed] = d_out
+    assert int(outs[1].sum(dtype=torch.int64)) == int(outs[0].sum(dtype=torch.int64))
+    assert bool((outs[1] == outs[0]).all())
+    M = torch.from_numpy(sc_p.matrix_np().astype(np.int32)).to(dev)
+    qv = d_q[: nq * lq].view(nq, lq).long()
+    selfscore = M[qv, qv].sum(dim=1).to(torch.int32)
+    sc = outs[1].view(nq, wpq)
+    assert bool((sc[:, 0] == selfscore).all())
+    assert bool((sc >= 0).all()) and bool((sc <= selfscore[:, None]).all())
