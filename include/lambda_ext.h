@@ -224,7 +224,8 @@ typedef struct lx_blast_match
     float    identity;
     double   bit_score, e_value;
     uint64_t ops_off;           /* into the result's ops buffer */
-    uint32_t n_ops, reserved;
+    uint32_t n_ops;
+    int32_t  q_frame;           /* qFrameShift: 0 = none (protein query), +1 / -1 = forward / reverse-complement strand */
 } lx_blast_match;
 
 typedef struct lx_iterate_stats

@@ -69,6 +69,22 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+CLI = CSRC / "lambda3"
+
+
+def build_cli(force: bool = False) -> Path:
+    """The minimal `lambda3 searchp|searchn` front end (plumbing for BASELINE.json configs[0])."""
+    src = CSRC / "host" / "lambda3_main.cpp"
+    if not force and _newer(CLI, [src, LIB] + list((CSRC / "host").glob("*.hpp"))):
+        return CLI
+    cmd = [_hipcc(), "-O2", "-std=c++17", "-x", "hip", "--offload-arch=gfx950", f"-I{ROOT / 'include'}", str(src), "-o", str(CLI),
+           f"-L{CSRC}", "-llambda_ext", f"-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"CLI build failed:\n{r.stdout}")
+    return CLI
+
+
 def build_oracle(force: bool = False) -> Path:
     srcs = [ORACLE_DIR / "lx_oracle.c", ORACLE_DIR / "lx_oracle_simd.cpp", ORACLE_DIR / "lx_oracle.h"]
     if not force and _newer(ORACLE_LIB, srcs):
@@ -81,6 +97,7 @@ def build_oracle(force: bool = False) -> Path:
 
 def build_all(force: bool = False, verbose: bool = False) -> None:
     build_product(force=force, verbose=verbose)
+    build_cli(force=force)
     build_oracle(force=force)
 
 

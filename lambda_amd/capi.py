@@ -57,7 +57,7 @@ BLAST_MATCH_DTYPE = np.dtype([
     ("s_start", "<u8"), ("s_end", "<u8"), ("score", "<i4"), ("alignment_length", "<i4"), ("num_matches", "<i4"),
     ("num_mismatches", "<i4"), ("num_positives", "<i4"), ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"),
     ("identity", "<f4"), ("bit_score", "<f8"), ("e_value", "<f8"), ("ops_off", "<u8"), ("n_ops", "<u4"),
-    ("reserved", "<u4")])
+    ("q_frame", "<i4")])
 
 
 class RecordStats(C.Structure):

@@ -1,0 +1,333 @@
+// lambda3_main.cpp -- minimal `lambda3 searchp|searchn` front end around liblambda_ext (SURVEY.md section 7 step 9,
+// section 8f rows N2/N3): plumbing for BASELINE.json configs[0], not a port of the reference's driver.
+//
+//   lambda3 searchp -q queries.fasta -d db.fasta -o out.m8 [-e 1e-2] [-n 25] [--seed-length 10] [--seed-offset 5]
+//
+// What it mirrors from the reference, and what it does not:
+//   * subcommand split and the handful of options of the hot path (src/lambda.cpp:30-118; src/search_options.hpp:88-107,
+//     :290-337): -q, -o (format from the extension, :684-710), -e, -n, --seed-length, --seed-offset, -t (accepted, unused);
+//   * the per-batch flow of realMain (src/search.cpp:389-459): seeding -> seedLooksPromising -> iterateMatches ->
+//     writeRecords, with the three middle stages on the GPU through the C ABI;
+//   * NOT the FM-index: the reference searches an index built by `lambda3 mkindexp` (fmindex-collection, absent here,
+//     out of scope).  This front end takes the database as FASTA (-d) and seeds with an exact k-mer table over a
+//     10-letter reduced alphabet (Murphy-10; the reference's default is Li-10 with one mismatch in the second seed half,
+//     src/search_algo.hpp:537-604), so the candidate set -- and therefore the hit list -- is an approximation of what
+//     the reference's seeding would produce.  Everything after seeding follows the reference.
+#include <algorithm>
+#include <cctype>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "blast_stats.hpp"
+#include "lambda_ext.hpp"
+#include "scoring_tables.hpp"
+
+namespace
+{
+
+struct SeqSet
+{
+    std::vector<std::string> ids;
+    std::vector<uint8_t>     res;   // ranks, concatenated (frame-expanded for nucleotide queries)
+    std::vector<uint64_t>    off, len;
+    std::string              ascii; // original letters of the untranslated sequences, concatenated
+    std::vector<uint64_t>    ascii_off, orig_len;
+};
+
+uint8_t aaRank(char c) // SeqAn2 AminoAcid rank (src/seqan2_to_biocpp.hpp:352-366)
+{
+    char const * p = std::strchr(lambda_amd::kSeqanOrder, std::toupper((unsigned char)c));
+    return p && *p ? (uint8_t)(p - lambda_amd::kSeqanOrder) : 25; // unknown -> X
+}
+
+uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets pass it through, :392-393)
+{
+    switch (std::toupper((unsigned char)c))
+    {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T':
+        case 'U': return 4;
+        default: return 3;
+    }
+}
+
+void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet & out)
+{
+    std::ifstream in(path);
+    if (!in)
+        throw std::runtime_error("cannot open " + path);
+    std::string line, cur;
+    auto flush = [&]()
+    {
+        if (out.ids.size() == out.orig_len.size())
+            return;
+        out.ascii_off.push_back(out.ascii.size());
+        out.orig_len.push_back(cur.size());
+        out.ascii += cur;
+        out.off.push_back(out.res.size());
+        out.len.push_back(cur.size());
+        for (char c : cur)
+            out.res.push_back(protein ? aaRank(c) : dnaRank(c));
+        if (addRevComp) // qryNumFrames = 2 for BLASTN (src/search_datastructures.hpp:380-385)
+        {
+            out.off.push_back(out.res.size());
+            out.len.push_back(cur.size());
+            static uint8_t const comp[5] = {4, 2, 1, 3, 0};
+            for (size_t i = cur.size(); i-- > 0;)
+                out.res.push_back(comp[dnaRank(cur[i])]);
+        }
+        cur.clear();
+    };
+    while (std::getline(in, line))
+    {
+        if (!line.empty() && line.back() == '\r')
+            line.pop_back();
+        if (line.empty())
+            continue;
+        if (line[0] == '>')
+        {
+            flush();
+            out.ids.push_back(line.substr(1));
+        }
+        else
+            for (char c : line)
+                if (!std::isspace((unsigned char)c))
+                    cur.push_back(c);
+    }
+    flush();
+}
+
+// Murphy et al. 10-letter reduction over SeqAn ranks "ABCDEFGHIJKLMNOPQRSTUVWYZX*"
+uint8_t const kMurphy10[27] = {/*A*/ 2, /*B*/ 7, /*C*/ 1, /*D*/ 7, /*E*/ 7, /*F*/ 6, /*G*/ 3, /*H*/ 9, /*I*/ 0, /*J*/ 0,
+                               /*K*/ 8, /*L*/ 0, /*M*/ 0, /*N*/ 7, /*O*/ 8, /*P*/ 5, /*Q*/ 7, /*R*/ 8, /*S*/ 4, /*T*/ 4,
+                               /*U*/ 1, /*V*/ 0, /*W*/ 6, /*Y*/ 6, /*Z*/ 7, /*X*/ 2, /***/ 2};
+
+struct Options
+{
+    std::string cmd, query, db, output = "output.m8";
+    double      maxEValue   = 1e-2; // src/search_options.hpp:97
+    uint64_t    maxMatches  = 25;   // :99
+    int         seedLength  = 0, seedOffset = 0;
+    int         preScoring  = 2;    // :104
+    double      preScoringThresh = 2.0;
+    int         idCutOff    = 0;
+    int         device      = 0;
+};
+
+Options parse(int argc, char ** argv)
+{
+    Options o;
+    if (argc < 2)
+        throw std::runtime_error("usage: lambda3 searchp|searchn -q QUERY.fasta -d DB.fasta -o OUT.{m8,m9,sam} [-e EVALUE] [-n N]");
+    o.cmd = argv[1];
+    if (o.cmd != "searchp" && o.cmd != "searchn")
+        throw std::runtime_error("unknown subcommand '" + o.cmd + "' (searchp and searchn are in scope)");
+    bool const prot = o.cmd == "searchp";
+    // per-domain defaults, src/search_options.hpp:309-337
+    o.seedLength       = prot ? 10 : 14;
+    o.seedOffset       = prot ? 5 : 9;
+    o.preScoringThresh = prot ? 2.0 : 1.4;
+    for (int i = 2; i < argc; ++i)
+    {
+        std::string a = argv[i];
+        auto        val = [&]() -> std::string
+        {
+            if (i + 1 >= argc)
+                throw std::runtime_error("missing value for " + a);
+            return argv[++i];
+        };
+        if (a == "-q" || a == "--query")
+            o.query = val();
+        else if (a == "-d" || a == "--database" || a == "-i" || a == "--index")
+            o.db = val();
+        else if (a == "-o" || a == "--output")
+            o.output = val();
+        else if (a == "-e" || a == "--e-value")
+            o.maxEValue = std::stod(val());
+        else if (a == "-n" || a == "--num-matches")
+            o.maxMatches = std::stoull(val());
+        else if (a == "--seed-length")
+            o.seedLength = std::stoi(val());
+        else if (a == "--seed-offset")
+            o.seedOffset = std::stoi(val());
+        else if (a == "--percent-identity")
+            o.idCutOff = std::stoi(val());
+        else if (a == "--device")
+            o.device = std::stoi(val());
+        else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbosity" || a == "--version-to-outputfile" || a == "-p" ||
+                 a == "--profile")
+            (void)val(); // accepted for command-line compatibility, no effect here
+        else
+            throw std::runtime_error("unknown option " + a);
+    }
+    if (o.query.empty() || o.db.empty())
+        throw std::runtime_error("-q and -d are required");
+    return o;
+}
+
+} // namespace
+
+int main(int argc, char ** argv)
+{
+    try
+    {
+        Options const opt  = parse(argc, argv);
+        bool const    prot = opt.cmd == "searchp";
+        int const     qFrames = prot ? 1 : 2;
+
+        SeqSet qs, db;
+        readFasta(opt.query, prot, !prot, qs);
+        readFasta(opt.db, prot, false, db);
+        if (qs.ids.empty() || db.ids.empty())
+            throw std::runtime_error("empty query or database file");
+
+        // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234)
+        lx_scoring sc;
+        int const  gapOpen = prot ? -11 : -5, gapExtend = prot ? -1 : -2;
+        lambda_amd::builtinScoring(prot ? 62 : 0, 2, -3, gapOpen, gapExtend, sc);
+        lx_karlin ka;
+        if (!lambda_amd::karlinParams(prot ? 62 : 0, 2, -3, gapOpen, gapExtend, ka))
+            throw std::runtime_error("Could not compute Karlin-Altschul-Values for Scoring Scheme."); // :232-233
+        lambda_amd::Engine eng(opt.device);
+        eng.setScoring(sc, 0);
+
+        // ---- seeding: exact k-mers of the (reduced) sequences, window of seedLength every seedOffset (:635-669)
+        int const K = opt.seedLength;
+        auto      code = [&](uint8_t const * p, bool & ok) -> uint64_t
+        {
+            uint64_t c = 0;
+            ok         = true;
+            for (int k = 0; k < K; ++k)
+            {
+                uint8_t r = p[k];
+                if (prot)
+                {
+                    if (r >= 25) // X, *: never seed through them
+                        ok = false;
+                    r = kMurphy10[r];
+                    c = c * 10 + r;
+                }
+                else
+                {
+                    if (r == 3) // N
+                        ok = false;
+                    c = c * 5 + r;
+                }
+            }
+            return c;
+        };
+        std::unordered_map<uint64_t, std::vector<std::pair<uint32_t, uint32_t>>> table;
+        for (size_t s = 0; s < db.ids.size(); ++s)
+            for (uint64_t p = 0; p + K <= db.len[s]; ++p)
+            {
+                bool     ok;
+                uint64_t c = code(&db.res[db.off[s] + p], ok);
+                if (ok)
+                    table[c].emplace_back((uint32_t)s, (uint32_t)p);
+            }
+        std::vector<lx_match> matches;
+        for (size_t qf = 0; qf < qs.off.size(); ++qf)
+            for (uint64_t p = 0; p + K <= qs.len[qf]; p += (uint64_t)opt.seedOffset)
+            {
+                bool     ok;
+                uint64_t c = code(&qs.res[qs.off[qf] + p], ok);
+                if (!ok)
+                    continue;
+                auto it = table.find(c);
+                if (it == table.end() || it->second.size() > 10 * opt.maxMatches) // abundant seeds are dropped (:729)
+                    continue;
+                for (auto const & hit : it->second)
+                    matches.push_back(lx_match{qf, hit.first, p, p + (uint64_t)K, hit.second, hit.second + (uint64_t)K});
+            }
+        size_t const nSeeds = matches.size();
+
+        // ---- seedLooksPromising on the GPU (:744-751)
+        if (!matches.empty())
+        {
+            std::vector<lx_seed> seeds(matches.size());
+            for (size_t i = 0; i < matches.size(); ++i)
+            {
+                lx_match const & m = matches[i];
+                seeds[i] = lx_seed{qs.off[m.qryId], db.off[m.subjId], (uint32_t)qs.len[m.qryId], (uint32_t)db.len[m.subjId],
+                                   (uint32_t)m.qryStart, (uint32_t)m.qryEnd, (uint32_t)m.subjStart, 0};
+            }
+            std::vector<uint8_t> keep(matches.size());
+            eng.check(lx_prefilter_batch(eng.raw(), 0, qs.res.data(), qs.res.size(), db.res.data(), db.res.size(), seeds.data(),
+                                         seeds.size(), (uint32_t)K, opt.preScoring, opt.preScoringThresh, keep.data()));
+            size_t w = 0;
+            for (size_t i = 0; i < matches.size(); ++i)
+                if (keep[i])
+                    matches[w++] = matches[i];
+            matches.resize(w);
+        }
+
+        // ---- extension (iterateMatches) on the GPU
+        uint64_t dbTotal = 0;
+        for (auto l : db.len)
+            dbTotal += l;
+        lx_search_params sp{};
+        sp.max_evalue       = opt.maxEValue;
+        sp.min_bitscore     = -1;
+        sp.id_cutoff        = opt.idCutOff;
+        sp.db_total_length  = dbTotal;
+        sp.query_translated = 0;
+        sp.qry_num_frames   = qFrames;
+        sp.sbj_num_frames   = 1;
+        sp.karlin           = ka;
+        lx_iterate_result * res = nullptr;
+        eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
+                                     qs.orig_len.data(), db.res.data(), db.res.size(), db.off.data(), db.len.data(),
+                                     db.off.size(), matches.data(), matches.size(), &sp, &res));
+        uint64_t const              nHsp = lx_iterate_result_count(res);
+        std::vector<lx_blast_match> bms(lx_iterate_result_matches(res), lx_iterate_result_matches(res) + nHsp);
+        std::vector<uint8_t>        ops(lx_iterate_result_ops(res),
+                                 lx_iterate_result_ops(res) + (nHsp ? bms.back().ops_off + bms.back().n_ops : 0));
+        lx_iterate_stats const      ist = lx_iterate_result_stats(res);
+        lx_iterate_result_free(res);
+        for (auto & b : bms) // frame of the query strand: +1 forward, -1 reverse complement (_setFrames, :768-814)
+            b.q_frame = prot ? 0 : ((b.qry_id % 2) ? -1 : 1);
+
+        // ---- _writeRecord + writer
+        lx_record_stats rst{};
+        uint64_t const  nOut = lx_postprocess_records(bms.data(), bms.size(), opt.maxMatches, &rst);
+        std::vector<char const *> qid, sid;
+        for (auto const & s : qs.ids)
+            qid.push_back(s.c_str());
+        for (auto const & s : db.ids)
+            sid.push_back(s.c_str());
+        lx_seq_names names{qid.data(), qs.orig_len.data(), sid.data(), db.len.data(), qid.size(), sid.size()};
+        int          fmt = LX_OUT_BLAST_TAB;
+        auto         ends = [&](char const * suf)
+        { return opt.output.size() >= std::strlen(suf) && opt.output.compare(opt.output.size() - std::strlen(suf), std::string::npos, suf) == 0; };
+        if (ends(".m9"))
+            fmt = LX_OUT_BLAST_TAB_COMMENTS;
+        else if (ends(".sam"))
+            fmt = LX_OUT_SAM;
+        else if (!ends(".m8"))
+            throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
+        eng.check(lx_write_records(opt.output.c_str(), fmt, 1, prot ? "blastp" : "blastn", bms.data(), nOut, ops.data(), &names,
+                                   reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data()));
+
+        std::fprintf(stderr,
+                     "lambda3 %s: %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> windows %llu -> traced %llu -> "
+                     "HSPs %llu -> written %llu (queries with hit: %llu)\n",
+                     opt.cmd.c_str(), qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, matches.size(),
+                     (unsigned long long)(ist.num_ext_score - ist.hits_duplicate), (unsigned long long)ist.num_ext_ali,
+                     (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
+        return 0;
+    }
+    catch (std::exception const & e)
+    {
+        std::cerr << "\nERROR: " << e.what() << "\n";
+        return -1; // src/search.cpp:98-125
+    }
+}

@@ -8,6 +8,7 @@
 // Scope: the untranslated programs (BLASTP, BLASTN).  The number formats of the tabular columns are SeqAn2's
 // (source absent): [UPSTREAM-RECALL] pident %.2f, evalue %.1e, bitscore %.1f, 1-based inclusive positions.
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -83,20 +84,20 @@ uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_mat
             ++hi;
         ++st.qrys_with_hit; // :826
         std::vector<lx_blast_match> rec(m + lo, m + hi);
-        // sort matches, using an inverted bitScore to have the highest score first (:832-853); frames are 0 here
+        // sort matches, using an inverted bitScore to have the highest score first (:832-853); subject frames are 0 here
         std::stable_sort(rec.begin(), rec.end(),
                          [](lx_blast_match const & a, lx_blast_match const & b)
                          {
-                             return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, b.bit_score) <
-                                    std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, a.bit_score);
+                             return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame, b.bit_score) <
+                                    std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame, a.bit_score);
                          });
         // removes duplicates and keeping the ones with the greatest score (:856-862)
         auto const before = rec.size();
         rec.erase(std::unique(rec.begin(), rec.end(),
                               [](lx_blast_match const & a, lx_blast_match const & b)
                               {
-                                  return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end) ==
-                                         std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end);
+                                  return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame) ==
+                                         std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame);
                               }),
                   rec.end());
         st.hits_duplicate2 += before - rec.size();
@@ -161,7 +162,7 @@ int lx_write_records(char const * path, int format, int write_header, char const
                     std::fclose(f);
                     return LX_EINVAL;
                 }
-                int const         flag = (k == lo) ? 0 : 256; // all but the first are secondary (:505, :723)
+                int const         flag = ((k == lo) ? 0 : 256) | (b.q_frame < 0 ? 16 : 0); // secondary (:505, :723), RC (:506-507)
                 std::string const qn = firstWord(names->q_ids[b.n_qid]), sn = firstWord(names->s_ids[b.n_sid]);
                 // BLASTP: no DNA cigar and no SEQ ("*"); BLASTN: cigar with soft clips and, for the first record of a
                 // query region, the read sequence (samBamSeq = uniq, :536-553)
@@ -169,15 +170,31 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 if (isN)
                 {
                     cigar = cigarOf(b, ops, names->q_lens[b.n_qid], false);
-                    bool writeSeq = (k == lo) || b.q_start != m[k - 1].q_start || b.q_end != m[k - 1].q_end;
+                    bool writeSeq = (k == lo) || b.q_frame != m[k - 1].q_frame || b.q_start != m[k - 1].q_start ||
+                                    b.q_end != m[k - 1].q_end; // samBamSeq = uniq (:536-553)
                     if (writeSeq && q_res_ascii && q_ascii_off)
+                    {
                         seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], names->q_lens[b.n_qid]);
+                        if (b.q_frame < 0) // the aligned sequence is the reverse-complement frame
+                        {
+                            std::reverse(seq.begin(), seq.end());
+                            for (char & ch : seq)
+                                switch (std::toupper((unsigned char)ch))
+                                {
+                                    case 'A': ch = 'T'; break;
+                                    case 'C': ch = 'G'; break;
+                                    case 'G': ch = 'C'; break;
+                                    case 'T': case 'U': ch = 'A'; break;
+                                    default: ch = 'N';
+                                }
+                        }
+                    }
                 }
                 std::fprintf(f, "%s\t%d\t%s\t%llu\t255\t%s\t*\t0\t0\t%s\t*", qn.c_str(), flag, sn.c_str(),
                              (unsigned long long)(b.s_start + 1), cigar.c_str(), seq.c_str());
                 // tags in the order of myWriteRecord: ae, AS, ai, qf, NM (:611-716)
                 std::fprintf(f, "\tae:f:%g\tAS:i:%u\tai:i:%u\tqf:i:%d\tNM:i:%u\n", (double)(float)b.e_value,
-                             (unsigned)(uint16_t)b.bit_score, (unsigned)(uint8_t)b.identity, isN ? 1 : 0,
+                             (unsigned)(uint16_t)b.bit_score, (unsigned)(uint8_t)b.identity, (int)b.q_frame,
                              (unsigned)(b.alignment_length - b.num_matches));
             }
             lo = hi;
@@ -208,11 +225,20 @@ int lx_write_records(char const * path, int format, int write_header, char const
                     std::fclose(f);
                     return LX_EINVAL;
                 }
+                // 1-based inclusive; a hit of the reverse-complemented query is reported BLAST-style on the forward query
+                // strand with descending subject coordinates
+                unsigned long long qs = b.q_start + 1, qe = b.q_end, ss = b.s_start + 1, se = b.s_end;
+                if (b.q_frame < 0)
+                {
+                    unsigned long long const ql = names->q_lens[b.n_qid];
+                    qs = ql - b.q_end + 1;
+                    qe = ql - b.q_start;
+                    std::swap(ss, se);
+                }
                 std::fprintf(f, "%s\t%s\t%.2f\t%d\t%d\t%d\t%llu\t%llu\t%llu\t%llu\t%.1e\t%.1f\n",
                              firstWord(names->q_ids[b.n_qid]).c_str(), firstWord(names->s_ids[b.n_sid]).c_str(),
-                             (double)b.identity, b.alignment_length, b.num_mismatches, b.num_gap_opens,
-                             (unsigned long long)(b.q_start + 1), (unsigned long long)b.q_end,
-                             (unsigned long long)(b.s_start + 1), (unsigned long long)b.s_end, b.e_value, b.bit_score);
+                             (double)b.identity, b.alignment_length, b.num_mismatches, b.num_gap_opens, qs, qe, ss, se,
+                             b.e_value, b.bit_score);
             }
             lo = hi;
         }

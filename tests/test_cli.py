@@ -1,0 +1,148 @@
+"""The minimal lambda3 front end (plumbing, BASELINE.json configs[0]): FASTA in, .m8 / .sam out, seeding -> prefilter ->
+extension -> records, middle stages on the GPU.  CPU part: the binary exists and fails loudly without a device."""
+import math
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from lambda_amd import build, capi, synth
+from tests import oracle_lib
+
+ORDER = "ABCDEFGHIJKLMNOPQRSTUVWYZX*"
+STD = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def _cli():
+    return build.build_cli()
+
+
+def _fasta(path, ids, seqs):
+    with open(path, "w") as f:
+        for i, s in zip(ids, seqs):
+            f.write(f">{i}\n")
+            for k in range(0, len(s), 60):
+                f.write(s[k:k + 60] + "\n")
+
+
+def _make_config1(tmp, nq=1000, ndb=10000, lq=100, seed=0x1A3BDA01):
+    """DB lengths log-normal (mu = ln 300, sigma 0.6, clamp 50..2000), uniform over the 20
+    standard residues; 30 % of the queries are mutated copies of DB regions (25 % substitutions, 2 % indels)."""
+    rng = np.random.default_rng(seed)
+    lens = np.clip(np.exp(rng.normal(math.log(300), 0.6, ndb)).astype(int), 50, 2000)
+    db = ["".join(STD[i] for i in rng.integers(0, 20, L)) for L in lens]
+    qs, truth = [], {}
+    for k in range(nq):
+        if rng.random() < 0.3:
+            while True:
+                j = int(rng.integers(0, ndb))
+                if lens[j] >= lq + 10:
+                    break
+            a = int(rng.integers(0, lens[j] - lq - 5))
+            src = db[j][a:a + lq + 5]
+            out = []
+            for ch in src:
+                r = rng.random()
+                if r < 0.01:
+                    continue                      # deletion
+                if r < 0.02:
+                    out.append(STD[int(rng.integers(0, 20))])  # insertion
+                out.append(STD[int(rng.integers(0, 20))] if rng.random() < 0.25 else ch)
+            qs.append("".join(out)[:lq].ljust(lq, "A"))
+            truth[k] = j
+        else:
+            qs.append("".join(STD[i] for i in rng.integers(0, 20, lq)))
+    _fasta(tmp / "db.fasta", [f"sp{j} protein {j}" for j in range(ndb)], db)
+    _fasta(tmp / "q.fasta", [f"q{k} len={lq}" for k in range(nq)], qs)
+    return qs, db, truth
+
+
+def test_cli_fails_loudly_without_gpu(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _fasta(tmp_path / "q.fasta", ["q"], ["ACDEFGHIKLMNPQRSTVWY" * 3])
+    _fasta(tmp_path / "d.fasta", ["s"], ["ACDEFGHIKLMNPQRSTVWY" * 5])
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "d.fasta"), "-o",
+                        str(tmp_path / "o.m8")], capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR" in r.stderr and not (tmp_path / "o.m8").exists()
+    r = subprocess.run([str(_cli()), "mkindexp"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown subcommand" in r.stderr
+
+
+@pytest.mark.gpu
+def test_searchp_config1_end_to_end(tmp_path, oracle):
+    qs, db, truth = _make_config1(tmp_path)
+    out = tmp_path / "out.m8"
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "db.fasta"), "-o",
+                        str(out), "-t", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split("\t") for l in out.read_text().splitlines()]
+    assert len(rows) > 200 and all(len(x) == 12 for x in rows)
+    best = {}
+    for x in rows:
+        best.setdefault(x[0], x)  # records are sorted by bit score within a query: the first one is the best
+    found = sum(1 for k, j in truth.items() if best.get(f"q{k}", [None, None])[1] == f"sp{j}")
+    assert found >= 0.9 * len(truth), (found, len(truth))
+    # per query: at most 25 hits, descending bit score
+    per = {}
+    for x in rows:
+        per.setdefault(x[0], []).append(float(x[11]))
+    assert all(len(v) <= 25 and v == sorted(v, reverse=True) for v in per.values())
+    # every reported HSP re-scores on the oracle: the local alignment of exactly the reported ranges has that bit score
+    sc_p = capi.builtin_scoring(62)
+    osc = oracle_lib.scoring_from(sc_p)
+    ka = capi.karlin_params(62)
+    rank = {c: i for i, c in enumerate(ORDER)}
+    enc = lambda s: np.array([rank[c] for c in s], dtype=np.uint8)
+    for x in rows[:400]:
+        k, j = int(x[0][1:]), int(x[1][2:])
+        qa, qb, sa, sb = int(x[6]) - 1, int(x[7]), int(x[8]) - 1, int(x[9])
+        s_, qe, se = oracle.score(enc(qs[k][qa:qb]), enc(db[j][sa:sb]), osc)
+        bits = (ka.lambda_ * s_ - math.log(ka.K)) / math.log(2)
+        assert abs(bits - float(x[11])) <= 0.051, (x, s_, bits)
+        assert (qe, se) == (qb - qa, sb - sa)
+        assert float(x[10]) <= 1e-2
+    # SAM output of the same search
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "db.fasta"), "-o",
+                        str(tmp_path / "out.sam")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sam = [l for l in (tmp_path / "out.sam").read_text().splitlines() if not l.startswith("@")]
+    assert len(sam) == len(rows) and sam[0].split("\t")[1] == "0"
+
+
+@pytest.mark.gpu
+def test_searchn_both_strands(tmp_path):
+    rng = np.random.default_rng(5)
+    genome = ["".join("ACGT"[i] for i in rng.integers(0, 4, 20000)) for _ in range(3)]
+    comp = str.maketrans("ACGT", "TGCA")
+    reads, truth = [], []
+    for k in range(60):
+        c, a = int(rng.integers(0, 3)), int(rng.integers(0, 19800))
+        r = list(genome[c][a:a + 150])
+        for p in rng.integers(0, 150, 4):
+            r[p] = "ACGT"[int(rng.integers(0, 4))]
+        r = "".join(r)
+        minus = k % 2 == 1
+        reads.append(r.translate(comp)[::-1] if minus else r)
+        truth.append((c, a, minus))
+    _fasta(tmp_path / "g.fasta", [f"chr{i}" for i in range(3)], genome)
+    _fasta(tmp_path / "r.fasta", [f"read{k}" for k in range(60)], reads)
+    out = tmp_path / "o.m8"
+    r = subprocess.run([str(_cli()), "searchn", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "g.fasta"), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    best = {}
+    for l in out.read_text().splitlines():
+        x = l.split("\t")
+        best.setdefault(x[0], x)
+    ok = 0
+    for k, (c, a, minus) in enumerate(truth):
+        x = best.get(f"read{k}")
+        if x and x[1] == f"chr{c}":
+            ss, se = int(x[8]), int(x[9])
+            if (ss > se) == minus and abs(min(ss, se) - 1 - a) <= 10:
+                ok += 1
+    assert ok >= 57, ok

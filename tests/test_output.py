@@ -5,7 +5,7 @@ import numpy as np
 from lambda_amd import capi
 
 
-def rec(n_qid, n_sid, qs, qe, ss, se, bits, score=50, alen=None, nm=None, ops_off=0, n_ops=0, ev=1e-5, ident=80.0):
+def rec(n_qid, n_sid, qs, qe, ss, se, bits, score=50, alen=None, nm=None, ops_off=0, n_ops=0, ev=1e-5, ident=80.0, frame=0):
     r = np.zeros(1, dtype=capi.BLAST_MATCH_DTYPE)[0]
     r["n_qid"], r["qry_id"], r["n_sid"], r["subj_id"] = n_qid, n_qid, n_sid, n_sid
     r["q_start"], r["q_end"], r["s_start"], r["s_end"] = qs, qe, ss, se
@@ -14,6 +14,7 @@ def rec(n_qid, n_sid, qs, qe, ss, se, bits, score=50, alen=None, nm=None, ops_of
     r["num_matches"] = nm if nm is not None else (qe - qs) * 8 // 10
     r["num_mismatches"] = r["alignment_length"] - r["num_matches"]
     r["ops_off"], r["n_ops"] = ops_off, n_ops
+    r["q_frame"] = frame
     return r
 
 
@@ -57,8 +58,8 @@ def test_sam_writer_blastn_cigar_and_tags(tmp_path):
     # 3 leading query bases unaligned, 10 M, 2 D (gap in the query row), 5 M, 1 I, 4 M, 5 trailing unaligned
     ops = b"M" * 10 + b"D" * 2 + b"M" * 5 + b"I" + b"M" * 4
     qlen = 3 + 10 + 5 + 1 + 4 + 5
-    m = np.array([rec(0, 0, 3, 23, 50, 71, 40.9, alen=len(ops), nm=17, n_ops=len(ops), ev=2e-4, ident=77.3),
-                  rec(0, 1, 3, 23, 10, 31, 30.0, alen=len(ops), nm=15, n_ops=len(ops), ev=2e-2, ident=70.0)],
+    m = np.array([rec(0, 0, 3, 23, 50, 71, 40.9, alen=len(ops), nm=17, n_ops=len(ops), ev=2e-4, ident=77.3, frame=1),
+                  rec(0, 1, 3, 23, 10, 31, 30.0, alen=len(ops), nm=15, n_ops=len(ops), ev=2e-2, ident=70.0, frame=1)],
                  dtype=capi.BLAST_MATCH_DTYPE)
     read = b"ACGTACGTACGTACGTACGTACGTACGT"[:qlen]
     p = tmp_path / "out.sam"
