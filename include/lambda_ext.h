@@ -207,7 +207,9 @@ typedef struct lx_search_params
     int32_t   query_translated; /* 1: ql /= 3 before the length adjustment (src/search_misc.hpp:70)   */
     int32_t   qry_num_frames;   /* qryId / qry_num_frames = true query id (src/search_algo.hpp:1210)  */
     int32_t   sbj_num_frames;
-    int32_t   reserved;
+    int32_t   bisulfite;        /* 1: iterateMatches' bisulfite branch (src/search_algo.hpp:1367-1379): matches on even subject
+                                   frames are extended with slot 0 (forward scheme), odd ones with slot 1 (reverse scheme);
+                                   the `slot` argument is ignored                                                          */
     lx_karlin karlin;
 } lx_search_params;
 
@@ -238,7 +240,7 @@ typedef struct lx_iterate_result lx_iterate_result;
 /* iterateMatchesFullSimd (src/search_algo.hpp:1177-1332) for one strand direction: widen/merge the seed hits,
  * score every window on the GPU, filter by bit score / e-value, trace the survivors on the GPU, expand to
  * sequence coordinates, apply the identity cut-off.  q_seq_off/q_seq_len (s_*) give, per frame-expanded sequence
- * id, where that sequence lives in q_res (s_res).  q_orig_len[n_qid] is the untranslated query length used for
+  * id, where that sequence lives in q_res (s_res).  q_orig_len[n_qid] is the untranslated query length used for
  * the e-value (bm.qLength, src/search_algo.hpp:1213).  `matches` is modified in place (like the reference's span). */
 int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
                        uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,

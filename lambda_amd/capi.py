@@ -44,7 +44,7 @@ class Karlin(C.Structure):
 class SearchParams(C.Structure):
     _fields_ = [("max_evalue", C.c_double), ("min_bitscore", C.c_int32), ("id_cutoff", C.c_int32),
                 ("db_total_length", C.c_uint64), ("query_translated", C.c_int32), ("qry_num_frames", C.c_int32),
-                ("sbj_num_frames", C.c_int32), ("reserved", C.c_int32), ("karlin", Karlin)]
+                ("sbj_num_frames", C.c_int32), ("bisulfite", C.c_int32), ("karlin", Karlin)]
 
 
 class IterateStats(C.Structure):

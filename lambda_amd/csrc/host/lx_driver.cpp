@@ -114,24 +114,18 @@ uint64_t lx_widen_and_preprocess(lx_match * m, uint64_t n, uint64_t const * qlen
     return lambda_amd::widenAndPreprocessMatches(m, n, qlens, slens, nullptr);
 }
 
-// iterateMatchesFullSimd, src/search_algo.hpp:1177-1332
-int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
-                       uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,
-                       uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
-                       uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
-                       lx_iterate_result ** out)
+} // extern "C"
+
+// iterateMatchesFullSimd, src/search_algo.hpp:1177-1332, for one strand direction (= one scoring slot); appends to *res
+static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
+                                  uint64_t const * q_seq_len, uint64_t const * q_orig_len, uint8_t const * s_res,
+                                  uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
+                                  lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                                  lx_iterate_result * res)
 {
     using namespace lambda_amd;
-    if (!h || !out || !params || (!matches && n_matches))
-        return LX_EINVAL;
-    *out = nullptr;
-    for (uint64_t i = 0; i < n_matches; ++i)
-        if (matches[i].qryId >= n_qseq || matches[i].subjId >= n_sseq)
-            return LX_EINVAL;
     int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
-
-    auto res = new lx_iterate_result();
-    res->stats.num_ext_score = n_matches; // lH.stats.numExtScore (:1187)
+    res->stats.num_ext_score += n_matches; // lH.stats.numExtScore (:1187)
 
     // pre-sort and filter (:1198)
     uint64_t const n = widenAndPreprocessMatches(matches, n_matches, q_seq_len, s_seq_len, &res->stats.hits_duplicate);
@@ -160,10 +154,7 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     std::vector<int32_t> scores(n, 0);
     int rc = lx_score_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sortedExt.data(), n, scores.data());
     if (rc != LX_OK)
-    {
-        delete res;
         return rc;
-    }
 
     // compute evalues and filter based on evalue (:1251-1283)
     EValueContext evalue{params->karlin, params->db_total_length, params->query_translated != 0, {}};
@@ -201,11 +192,8 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
         surv.push_back(s);
     }
     if (surv.empty())
-    {
-        *out = res;
         return LX_OK;
-    }
-    res->stats.num_ext_ali = surv.size(); // :1287
+    res->stats.num_ext_ali += surv.size(); // :1287
 
     // Run extensions WITH ALIGNMENT (:1293-1296)
     std::vector<lx_extension> sExt(surv.size());
@@ -222,10 +210,7 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     std::vector<uint8_t> ops(total + 1, 0);
     rc = lx_align_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sExt.data(), sExt.size(), hsp.data(), ops.data(), opsOff.data());
     if (rc != LX_OK)
-    {
-        delete res;
         return rc;
-    }
 
     // sort by query (:1299), stable
     std::vector<uint32_t> sOrder(surv.size());
@@ -270,6 +255,54 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
         bm.n_ops     = (uint32_t)a.n_ops;
         res->ops.insert(res->ops.end(), ops.begin() + opsOff[k] + a.ops_shift, ops.begin() + opsOff[k] + a.ops_shift + a.n_ops);
         res->matches.push_back(bm);
+    }
+    return LX_OK;
+}
+
+extern "C" {
+
+// iterateMatches, src/search_algo.hpp:1364-1385
+int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
+                       uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,
+                       uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
+                       uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                       lx_iterate_result ** out)
+{
+    if (!h || !out || !params || (!matches && n_matches))
+        return LX_EINVAL;
+    *out = nullptr;
+    for (uint64_t i = 0; i < n_matches; ++i)
+        if (matches[i].qryId >= n_qseq || matches[i].subjId >= n_sseq)
+            return LX_EINVAL;
+    auto res = new lx_iterate_result();
+    int  rc;
+    if (params->bisulfite)
+    {
+        // sort by (subjId % 2, Match); even subject frames use the forward scheme (slot 0), odd ones the reverse scheme
+        // (slot 1); finally the HSPs are stably re-sorted by query (:1367-1379)
+        std::sort(matches, matches + n_matches,
+                  [](lx_match const & l, lx_match const & r)
+                  { return std::make_tuple(l.subjId % 2, lambda_amd::tie(l)) < std::make_tuple(r.subjId % 2, lambda_amd::tie(r)); });
+        lx_match * mid = std::find_if(matches, matches + n_matches, [](lx_match const & m) { return m.subjId % 2; });
+        rc = iterateMatchesFullSimd(h, 0, q_res, q_bytes, q_seq_off, q_seq_len, q_orig_len, s_res, s_bytes, s_seq_off, s_seq_len,
+                                    matches, (uint64_t)(mid - matches), params, res);
+        if (rc == LX_OK)
+            rc = iterateMatchesFullSimd(h, 1, q_res, q_bytes, q_seq_off, q_seq_len, q_orig_len, s_res, s_bytes, s_seq_off,
+                                        s_seq_len, mid, (uint64_t)(matches + n_matches - mid), params, res);
+        if (rc == LX_OK)
+        {
+            // the ops offsets stay valid: only the records move
+            std::stable_sort(res->matches.begin(), res->matches.end(),
+                             [](lx_blast_match const & a, lx_blast_match const & b) { return a.n_qid < b.n_qid; });
+        }
+    }
+    else
+        rc = iterateMatchesFullSimd(h, slot, q_res, q_bytes, q_seq_off, q_seq_len, q_orig_len, s_res, s_bytes, s_seq_off, s_seq_len,
+                                    matches, n_matches, params, res);
+    if (rc != LX_OK)
+    {
+        delete res;
+        return rc;
     }
     *out = res;
     return LX_OK;

@@ -233,3 +233,57 @@ def test_fused_extend_on_device(handle, oracle, wpq, run):
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops
+
+
+def test_iterate_matches_bisulfite(handle, oracle):
+    """iterateMatches' bisulfite branch (src/search_algo.hpp:1367-1379): even subject frames with the forward scheme,
+    odd ones with the reverse scheme, result stably re-sorted by query."""
+    fwd, rev = SCHEMES["bs_fwd"], SCHEMES["bs_rev"]
+    handle.set_scoring(fwd, 0)
+    handle.set_scoring(rev, 1)
+    handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 1)
+    ka = capi.karlin_params(0, 2, -3, -5, -2)
+    oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
+    rng = np.random.default_rng(77)
+    nq, ns = 24, 8  # 4 query frames per read, 2 subject frames per reference (search_datastructures.hpp:380-385)
+    qlen = np.full(nq, 100, dtype=np.uint64)
+    slen = rng.integers(400, 900, ns).astype(np.uint64)
+    qoff = (np.arange(nq) * 100).astype(np.uint64)
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.uint64)
+    q = rng.integers(0, 4, int(qlen.sum())).astype(np.uint8)
+    s = rng.integers(0, 4, int(slen.sum())).astype(np.uint8)
+    m = np.zeros(160, dtype=capi.MATCH_DTYPE)
+    for i in range(len(m)):
+        a, b = int(rng.integers(0, nq)), int(rng.integers(0, ns))
+        qs_ = int(rng.integers(0, 80))
+        ss_ = int(rng.integers(0, int(slen[b]) - 110))
+        seg = q[int(qoff[a]): int(qoff[a]) + 100].copy()
+        # bisulfite conversion in the direction the subject frame expects: C->T reads vs fwd, G->A vs rev
+        if b % 2 == 0:
+            ref = seg.copy(); conv = (seg == 3) & (rng.random(100) < 0.5); ref[conv] = 1   # read T where the genome has C
+        else:
+            ref = seg.copy(); conv = (seg == 0) & (rng.random(100) < 0.5); ref[conv] = 2   # read A where the genome has G
+        lo = min(qs_, ss_)
+        s[int(soff[b]) + ss_ - lo: int(soff[b]) + ss_ - lo + 100 - (qs_ - lo)] = ref[qs_ - lo:]
+        m[i] = (a, b, qs_, qs_ + 17, ss_, ss_ + 17)
+    db_total = int(slen.sum())
+    params = capi.SearchParams(1e-9, -1, 0, db_total, 0, 4, 2, 1, ka)
+    try:
+        bms, ops, stats = handle.iterate_matches(q, qoff, qlen, np.full(nq // 4, 100, np.uint64), s, soff, slen, m, params)
+    finally:
+        handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 0)
+    mo = m.astype(oracle_lib.MATCH_DTYPE)
+    want = []
+    for parity, scheme in ((0, fwd), (1, rev)):
+        sel = mo[mo["subjId"] % 2 == parity]
+        w, _ = oracle_driver.iterate_matches(oracle, oracle_lib.scoring_from(scheme), oka, q, qoff, qlen, np.full(nq // 4, 100),
+                                             s, soff, slen, sel, 1e-9, -1, 0, db_total, q_frames=4, s_frames=2, bs_rule=1)
+        want += w
+    want.sort(key=lambda r: r["n_qid"])  # stable
+    assert len(bms) == len(want) and len(want) > 20
+    assert any(r["subj_id"] % 2 for r in want) and any(r["subj_id"] % 2 == 0 for r in want)
+    for g, w, o in zip(bms, want, ops):
+        for k in ("qry_id", "subj_id", "n_qid", "n_sid", "q_start", "q_end", "s_start", "s_end", "score", "alignment_length",
+                  "num_matches", "num_mismatches", "num_gap_opens", "num_gap_extensions"):
+            assert int(g[k]) == w[k], (k, g, w)
+        assert o == w["ops"]
