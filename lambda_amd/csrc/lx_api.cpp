@@ -82,7 +82,7 @@ struct lx_handle
     lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
 
     // staging for the host-buffer entry points
-    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs;
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score;
     // multi-panel carry workspace
     DevBuf     d_ws;
     uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
@@ -358,7 +358,7 @@ void lx_destroy(lx_handle * h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ends,
-                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_ws})
+                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_sel_score, &h->d_trace_score, &h->d_ws})
         if (b->ptr)
             (void)hipFree(b->ptr);
     for (int s = 0; s < 2; ++s)
@@ -788,7 +788,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
                           uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
                           uint64_t max_q, uint64_t max_s, int share_slots, uint32_t const * d_src = nullptr,
-                          uint64_t const * d_count = nullptr)
+                          uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr)
 {
     if (!h->trace_ok[slot])
         return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
@@ -809,6 +809,19 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 15) & ~15ull); // multiple of the trace layout block
     uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
+    // The forward kernel finds the end cell cheaply when it knows each extension's best score; the fused path hands
+    // over pass 1's scores, a stand-alone traceback call computes them first (a fraction of the traceback's cost).
+    if (!d_score_in)
+    {
+        int rc0;
+        if ((rc0 = ensure(h, h->d_trace_score, n * sizeof(int32_t))))
+            return rc0;
+        int const  scfg  = pick_cfg((uint32_t)std::min<uint64_t>(max_q, 0xffffffffu), false);
+        bool const multi = max_q > (uint64_t)lx::score_cfg_panel(scfg);
+        if ((rc0 = launch_score_list(h, slot, d_q, d_s, d_ext, n, h->d_trace_score.ptr, scfg, multi, false, stream)))
+            return rc0;
+        d_score_in = static_cast<int32_t const *>(h->d_trace_score.ptr);
+    }
     // Two trace buffers, so that the backtrace of chunk k may run on stream2 while the forward kernel of chunk k+1
     // runs on `stream`.  Measured on MI355X (config 2) the overlap buys nothing -- both kernels saturate the chip
     // (46.5 ms/step serial vs 46.9 ms overlapped) -- so it is off unless LX_TRACE_OVERLAP=1.
@@ -842,6 +855,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.out_ops        = d_ops;
         p.ops_off        = d_src ? d_ops_off : d_ops_off + c0;
         p.src            = d_src ? d_src + c0 : nullptr;
+        p.score_in       = d_score_in + c0;
         p.count_ptr      = d_count;
         p.chunk_start    = c0;
         p.ws             = static_cast<int32_t *>(h->d_ws.ptr);
@@ -1021,7 +1035,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     uint64_t const nruns  = (n + run - 1) / run;
     uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
-        (rc = ensure(h, h->d_sel_runs, (nruns + 1) * sizeof(uint64_t))))
+        (rc = ensure(h, h->d_sel_runs, (nruns + 1) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
         return rc;
     lx::SelectParams sp{};
     sp.ext           = static_cast<lx::Extension const *>(d_ext);
@@ -1034,6 +1048,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     sp.run_slots     = static_cast<uint64_t *>(h->d_sel_runs.ptr);
     sp.out_ext       = static_cast<lx::Extension *>(h->d_sel_ext.ptr);
     sp.out_src       = static_cast<uint32_t *>(h->d_sel_src.ptr);
+    sp.out_score     = static_cast<int32_t *>(h->d_sel_score.ptr);
     sp.out_count     = static_cast<uint64_t *>(d_out_count);
     sp.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
     PhaseTimer pts(h, stream, 1);
@@ -1044,7 +1059,8 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
                         static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? 4 : 0,
-                        static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count));
+                        static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count),
+                        static_cast<int32_t const *>(h->d_sel_score.ptr));
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, stream));

@@ -93,6 +93,7 @@ struct TraceParams
     Hsp *              out_hsp;     // indexed by src[e] when src != nullptr, else by e
     uint8_t *          out_ops;
     uint64_t const *   ops_off;     // byte offset of each extension's ops slot (slot size q_len + s_len), same indexing
+    int32_t const *    score_in;    // optional: best score of each slot (pass 1) -> cheaper end-cell search
     uint32_t const *   src;         // optional: original index of each slot, 0xffffffff = padding slot (skipped)
     uint64_t const *   count_ptr;   // optional: device-side number of valid slots of the whole list
     uint64_t           chunk_start; // position of this chunk in that list
@@ -119,6 +120,7 @@ struct SelectParams
     uint32_t          pad_to;    // pad every run's survivors to a multiple of this many slots (1 = no padding)
     uint64_t *        run_slots; // [nruns + 1] scratch: padded survivor count per run -> exclusive scan
     Extension *       out_ext;   // [capacity]
+    int32_t *         out_score; // [capacity] score of each slot (0 for padding slots)
     uint32_t *        out_src;   // [capacity]
     uint64_t *        out_count; // [0] = total slots, [1] = true survivors
     Hsp *             out_hsp;   // optional [n]: rows of non-survivors are filled here (score, no alignment)

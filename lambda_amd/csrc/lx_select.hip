@@ -90,8 +90,9 @@ __global__ __launch_bounds__(256) void select_write_kernel(SelectParams p, uint6
         if (keep)
         {
             last         = p.ext[i];
-            p.out_ext[o] = last;
-            p.out_src[o] = (uint32_t)i;
+            p.out_ext[o]   = last;
+            p.out_src[o]   = (uint32_t)i;
+            p.out_score[o] = p.score[i];
             ++o;
             ++c;
         }
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(256) void select_write_kernel(SelectParams p, uint6
     last.s_len            = 0;
     for (uint32_t k = c; k < padded; ++k, ++o)
     {
-        p.out_ext[o] = last; // same query slice, empty window
-        p.out_src[o] = 0xffffffffu;
+        p.out_ext[o]   = last; // same query slice, empty window
+        p.out_src[o]   = 0xffffffffu;
+        p.out_score[o] = 0;
     }
 }
 

@@ -49,7 +49,10 @@ struct TraceWords
     static constexpr int kWords = (C + 7) / 8; // 4 direction bits per cell, 8 cells per 32-bit word
 };
 
-template <int G, int C>
+// KNOWN = the best score of every extension is already known (p.score_in, from pass 1): the end cell is then the
+// first cell in column-major order whose H equals it, found with one max3 per two cells plus a rare slow path,
+// instead of the per-column packed-key maximum (saves 3 of the 27 issue slots per cell).
+template <int G, int C, bool KNOWN>
 __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -177,6 +180,9 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     uint32_t * tr = p.trace + e * p.slot_stride + (uint32_t)g * (kTraceBlock * TW::kWords);
 
     int best_h = 0, best_q = 0, best_s = 0;
+    // KNOWN: target score (x4) and the best (lowest) column / its first row seen so far in this lane
+    int const tgt4 = (KNOWN && active) ? 4 * p.score_in[e] : 0;
+    int       kcol = 0x7fffffff, krow = 0;
 
     for (int panel = 0; panel < npanels; ++panel)
     {
@@ -230,6 +236,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             int const      Z3 = Z | 3;
             // key = ((Hs - z) << 16) | (65535 - row)  ==  (hc << 14) + K   (mod 2^32), hc = 4 Hs
             uint32_t const K  = (uint32_t)(-Z) * 16384u + ((65535u - (uint32_t)i) & 0xffffu);
+            int            rm = Z; // KNOWN: running maximum of this row's cells
             uint32_t       w[TW::kWords];
 #pragma unroll
             for (int x = 0; x < TW::kWords; ++x)
@@ -255,9 +262,34 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 wc            = __builtin_amdgcn_alignbit((uint32_t)Fr, wc, 1);
                 wc            = __builtin_amdgcn_alignbit((uint32_t)Er, wc, 1);
                 w[c >> 3]     = wc;
-                Hrow[c]       = hc;
-                uint32_t const key = ((uint32_t)hc << 14) + K;
-                colkey[c]          = max(colkey[c], key);
+                if constexpr (KNOWN)
+                {
+                    if (c & 1)
+                        rm = max3i(rm, Hrow[c - 1], hc); // Hrow[c-1] already holds this row's value
+                    else if (c == C - 1)
+                        rm = max(rm, hc);
+                }
+                else
+                {
+                    uint32_t const key = ((uint32_t)hc << 14) + K;
+                    colkey[c]          = max(colkey[c], key);
+                }
+                Hrow[c] = hc;
+            }
+            if constexpr (KNOWN)
+            {
+                // rare: some cell of this row reaches the extension's best score -> remember the lowest such column
+                // (rows are visited in increasing order, so the first hit of a column is its lowest row)
+                if (tgt4 > 0 && rm == tgt4 + Z && (unsigned)i < (unsigned)ls)
+                {
+#pragma unroll
+                    for (int c = C - 1; c >= 0; --c)
+                        if (Hrow[c] == rm && col0 + c < kcol)
+                        {
+                            kcol = col0 + c;
+                            krow = i;
+                        }
+                }
             }
             sendH = hc;
             sendE = Ecur;
@@ -310,32 +342,35 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 step(k0 + u, tc[u]);
         }
 
-        // best cell of this panel: higher H wins, ties go to the lower column (then the key's lower row)
-        uint32_t bk = 0;
-        int      bc = 0;
+        if constexpr (!KNOWN)
+        {
+            // best cell of this panel: higher H wins, ties go to the lower column (then the key's lower row)
+            uint32_t bk = 0;
+            int      bc = 0;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            if ((colkey[c] >> 16) > (bk >> 16))
+            for (int c = 0; c < C; ++c)
+                if ((colkey[c] >> 16) > (bk >> 16))
+                {
+                    bk = colkey[c];
+                    bc = c;
+                }
+            int bcol = col0 + bc; // 0-based global column
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1)
             {
-                bk = colkey[c];
-                bc = c;
+                uint32_t const ok   = (uint32_t)__shfl_xor((int)bk, off);
+                int const      oc   = __shfl_xor(bcol, off);
+                bool const     take = ((ok >> 16) > (bk >> 16)) || ((ok >> 16) == (bk >> 16) && oc < bcol);
+                bk   = take ? ok : bk;
+                bcol = take ? oc : bcol;
             }
-        int bcol = col0 + bc; // 0-based global column
-#pragma unroll
-        for (int off = 1; off < G; off <<= 1)
-        {
-            uint32_t const ok   = (uint32_t)__shfl_xor((int)bk, off);
-            int const      oc   = __shfl_xor(bcol, off);
-            bool const     take = ((ok >> 16) > (bk >> 16)) || ((ok >> 16) == (bk >> 16) && oc < bcol);
-            bk   = take ? ok : bk;
-            bcol = take ? oc : bcol;
-        }
-        int const ph = (int)(bk >> 16);
-        if (ph > best_h) // strict: earlier panels hold the lower columns
-        {
-            best_h = ph;
-            best_q = bcol + 1;
-            best_s = (int)(65535u - (bk & 0xffffu)) + 1;
+            int const ph = (int)(bk >> 16);
+            if (ph > best_h) // strict: earlier panels hold the lower columns
+            {
+                best_h = ph;
+                best_q = bcol + 1;
+                best_s = (int)(65535u - (bk & 0xffffu)) + 1;
+            }
         }
 
         if (npanels > 1)
@@ -345,6 +380,30 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __builtin_amdgcn_wave_barrier();
+    }
+
+    if constexpr (KNOWN)
+    {
+        // lowest column over the lanes of the group (every lane owns different columns), with its row
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1)
+        {
+            int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
+            bool const take = oc < kcol;
+            kcol = take ? oc : kcol;
+            krow = take ? orow : krow;
+        }
+        if (tgt4 > 0)
+        {
+            if (kcol == 0x7fffffff)
+                bad = true; // the score of pass 1 was not reproduced: never return a wrong alignment silently
+            else
+            {
+                best_h = tgt4 / 4;
+                best_q = kcol + 1;
+                best_s = krow + 1;
+            }
+        }
     }
 
     if (in_list && is_first)
@@ -582,7 +641,10 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
     int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
     int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
-    hipLaunchKernelGGL((trace_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    if (p.score_in)
+        hipLaunchKernelGGL((trace_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((trace_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
