@@ -141,7 +141,9 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
                    uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t * out_score);
 
 /* Device-resident variant: every pointer is a device pointer on the handle's device; asynchronous on
- * `stream` (a hipStream_t; NULL = the handle's own stream).  This is what bench.py times. */
+ * `stream` (a hipStream_t; NULL = the handle's own stream).  This is what bench.py times.
+ * The residue buffers must start 16-byte aligned (hipMalloc's do) and keep 256 readable bytes after the last
+ * residue: the kernels fetch residues in aligned groups. */
 int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
                        uint64_t n, void * d_out_score, void * stream);
 

@@ -792,6 +792,8 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
 {
     if (!h->trace_ok[slot])
         return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
+    if ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_s)) & 15)
+        return fail(h, LX_EINVAL, "pass 2 reads residues in aligned 16-byte groups: the residue buffers must be 16-byte aligned");
     if (max_s > 65535)
         return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
     int maxent = 0;

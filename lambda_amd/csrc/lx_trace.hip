@@ -42,6 +42,7 @@ namespace lx
 #define LX_TRACE_BLOCK 4
 #endif
 constexpr int kTraceBlock = LX_TRACE_BLOCK;
+static_assert(kTraceBlock == 4, "the backtrace reads one uint4 = word x of four consecutive steps");
 
 template <int C>
 struct TraceWords
@@ -177,7 +178,10 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     uint32_t const     lsc       = (uint32_t)max(ls, 1) - 1u;
 
     // trace[e][panel][g][k][word]
-    uint32_t * tr = p.trace + e * p.slot_stride + (uint32_t)g * (kTraceBlock * TW::kWords);
+    uint32_t * tr = p.trace + e * p.slot_stride;
+    // LDS staging block of this group, behind the profile slots
+    constexpr int kStageDw = G * kTraceBlock * TW::kWords + 4; // + 4: spreads the groups over the banks
+    uint32_t *    stage    = lds + ((Geo::kGroups + share - 1) / share) * (nrows * Geo::kRowDw) + grp * kStageDw;
 
     int best_h = 0, best_q = 0, best_s = 0;
     // KNOWN: target score (x4) and the best (lowest) column / its first row seen so far in this lane
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         for (int c = 0; c < C; ++c)
         {
             Hrow[c]   = Z + ge4;     // "H = 0" of the previous (virtual) row
-            F1[c]     = 4 * kNegInf + 1; // vertical gap state, always carries tag 1
+            F1[c]     = Z | 3;       // vertical gap state (tag 1) with the row's zero floor folded in (tag 3 = none)
             colkey[c] = 0;
         }
         int diag0 = Z + ge4;
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             int dg = diag0;
             diag0  = recvH;
 
-            int const      Z3 = Z | 3;
+            int const      ZN3 = (Z - ge4) | 3; // zero floor of the next row, tag 3 = none
             // key = ((Hs - z) << 16) | (65535 - row)  ==  (hc << 14) + K   (mod 2^32), hc = 4 Hs
             uint32_t const K  = (uint32_t)(-Z) * 16384u + ((65535u - (uint32_t)i) & 0xffffu);
             int            rm = Z; // KNOWN: running maximum of this row's cells
@@ -248,12 +252,13 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 int const sub = (int)(int8_t)(pw[c >> 2] >> (8 * (c & 3)));
                 int const tt  = dg + sub;                        // tag 2
                 dg            = Hrow[c];
-                int m         = max3i(tt, Ecur, F1[c]);          // E tag 0, F tag 1
-                m             = max(m, Z3);                      // none tag 3
+                int m         = max3i(tt, Ecur, F1[c]);          // E tag 0, F tag 1, floor (inside F1) tag 3
                 LX_OPAQUE(m);
                 hc            = m & ~3;
                 int const A0  = hc + g20;                        // gap-open candidate, tag 0
-                int const Fr  = max(F1[c], A0);                  // tag 1 = extended (wins ties), 0 = opened
+                // tag 1 = extended (wins ties), 0 = opened, 3 = the next row's floor is higher than both: that F is
+                // then never chosen as a source (H takes the floor's own tag 3), so its flag is never read
+                int const Fr  = max3i(F1[c], A0, ZN3);
                 F1[c]         = Fr | 1;
                 int const Er  = max(Ecur | 1, A0);               // tag 1 = extended, 0 = opened
                 Ecur          = (Er & ~3) + ge4;
@@ -295,13 +300,12 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             sendE = Ecur;
             Z     = Z - ge4;
 
-            if (store_trace)
+            // direction words go to the LDS staging block first: [lane][word][step % 4], the layout of the trace
             {
-                uint32_t * dst = trp + ((uint32_t)k / kTraceBlock) * (G * kTraceBlock * TW::kWords) +
-                                 ((uint32_t)k % kTraceBlock) * TW::kWords;
+                uint32_t * st = stage + g * (kTraceBlock * TW::kWords) + ((uint32_t)k % kTraceBlock);
 #pragma unroll
                 for (int x = 0; x < TW::kWords; ++x)
-                    dst[x] = w[x];
+                    st[x * kTraceBlock] = w[x];
             }
             if (do_carry_out && (unsigned)i < (unsigned)ls)
             {
@@ -340,6 +344,18 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
 #pragma unroll 1 // one step already holds C independent cells; unrolling steps only costs VGPRs (occupancy)
             for (int u = 0; u < 4; ++u)
                 step(k0 + u, tc[u]);
+            // flush the staged block of 4 steps: the group's G lanes write G consecutive 16-byte quads per store
+            // instruction (whole cache lines), instead of every lane its own 12 bytes per step
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (store_trace)
+            {
+                uint4 * dst = reinterpret_cast<uint4 *>(trp + ((uint32_t)k0 / kTraceBlock) * (G * kTraceBlock * TW::kWords));
+#pragma unroll
+                for (int x = 0; x < TW::kWords; ++x)
+                    dst[x * G + g] = reinterpret_cast<uint4 const *>(stage)[x * G + g];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
 
         if constexpr (!KNOWN)
@@ -461,15 +477,26 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
 
     // the cell's 4 direction bits: [1:0] = source of H (3 none, 2 diagonal, 1 vertical gap, 0 horizontal gap),
     // [2] = the vertical gap of the row below EXTENDS this cell's, [3] = the horizontal gap of the next column does
+    // one 16-byte load holds word x of the kTraceBlock (= 4) consecutive steps of a lane: a diagonal or vertical move
+    // goes one step back in the same lane, so the cached quad serves up to four moves
+    uint64_t tq_at = ~uint64_t(0);
+    uint4    tq{};
     auto nibble = [&](int i, int j) -> uint32_t
     {
         int const      panel = j / P, r = j - panel * P;
         int const      g = r / C, c = r - g * C;
         int const      x = c >> 3, cx = c & 7;
         int const      cnt = (x == TW::kWords - 1) ? (C - 8 * x) : 8; // cells held by this word
-        uint32_t const k    = (uint32_t)(i + g);
-        uint32_t const word = tr[(((uint64_t)panel * (p.steps_cap / kTraceBlock) + k / kTraceBlock) * G + g) * (kTraceBlock * TW::kWords) +
-                                 (k % kTraceBlock) * TW::kWords + x];
+        uint32_t const k   = (uint32_t)(i + g);
+        uint64_t const at  = (((uint64_t)panel * (p.steps_cap / kTraceBlock) + k / kTraceBlock) * G + g) * TW::kWords + x;
+        if (at != tq_at)
+        {
+            tq_at = at;
+            tq    = reinterpret_cast<uint4 const *>(tr)[at];
+        }
+        uint32_t const kk   = k % kTraceBlock;
+        uint32_t const lo   = (kk & 1) ? tq.y : tq.x, hi = (kk & 1) ? tq.w : tq.z;
+        uint32_t const word = (kk & 2) ? hi : lo;
         return (word >> (32 - 4 * cnt + 4 * cx)) & 15u;
     };
 
@@ -486,7 +513,13 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
 
     uintptr_t const qa = reinterpret_cast<uintptr_t>(q), sa = reinterpret_cast<uintptr_t>(s);
     uintptr_t       qw_at = ~uintptr_t(0), sw_at = ~uintptr_t(0);
-    uint32_t        qw = 0, sw = 0;
+    uint4           qw{}, sw{}; // 16 residues each, aligned (device buffers are 256-byte aligned: never before the base)
+    auto byte_of = [](uint4 const & v, uintptr_t addr) -> uint32_t
+    {
+        uint32_t const d  = (uint32_t)(addr >> 2) & 3u;
+        uint32_t const lo = (d & 1) ? v.y : v.x, hi = (d & 1) ? v.w : v.z;
+        return (((d & 2) ? hi : lo) >> (8 * (addr & 3))) & (kAlph - 1);
+    };
 
     // ops are produced end -> begin; `wpos` is the address of the next byte to write
     uintptr_t wpos = reinterpret_cast<uintptr_t>(ops) + cap - 1;
@@ -520,15 +553,15 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     {
         uint32_t const  nib = nibble(i, j);
         uintptr_t const qaddr = qa + (uint32_t)j, saddr = sa + (uint32_t)i;
-        if ((qaddr & ~uintptr_t(3)) != qw_at)
+        if ((qaddr & ~uintptr_t(15)) != qw_at)
         {
-            qw_at = qaddr & ~uintptr_t(3);
-            qw    = *reinterpret_cast<uint32_t const *>(qw_at);
+            qw_at = qaddr & ~uintptr_t(15);
+            qw    = *reinterpret_cast<uint4 const *>(qw_at);
         }
-        if ((saddr & ~uintptr_t(3)) != sw_at)
+        if ((saddr & ~uintptr_t(15)) != sw_at)
         {
-            sw_at = saddr & ~uintptr_t(3);
-            sw    = *reinterpret_cast<uint32_t const *>(sw_at);
+            sw_at = saddr & ~uintptr_t(15);
+            sw    = *reinterpret_cast<uint4 const *>(sw_at);
         }
         if (mode == 1)
         {
@@ -559,7 +592,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
             break; // trace NONE: H <= 0
         if (code == 2)
         {
-            uint32_t const c0 = (qw >> (8 * (qaddr & 3))) & (kAlph - 1), c1 = (sw >> (8 * (saddr & 3))) & (kAlph - 1);
+            uint32_t const c0 = byte_of(qw, qaddr), c1 = byte_of(sw, saddr);
             int const      v       = smat[c0 * kAlph + c1];
             bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
             nm += isMatch;
@@ -640,7 +673,8 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
         return hipErrorInvalidValue;
     int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
     int const    slots = (Geo::kGroups + share - 1) / share;
-    size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + (size_t)Geo::kGroups * (G * kTraceBlock * TraceWords<C>::kWords + 4)) *
+                       sizeof(uint32_t);
     if (p.score_in)
         hipLaunchKernelGGL((trace_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
