@@ -453,7 +453,7 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
             int const adj                = v - sc->gap_extend;
             if (!pad && (adj < -31 || adj > 31))
                 trace_ok = 0;
-            d.mat_trace[a * lx::kAlph + b] = (int8_t)(pad || adj < -31 || adj > 31 ? -126 : 4 * adj + 2);
+            d.mat_trace[a * lx::kAlph + b] = (int8_t)(pad || adj < -31 || adj > 31 ? -125 : 4 * adj + 3);
         }
     d.trace_ok = trace_ok;
     d.smax     = 0;

@@ -18,8 +18,8 @@ struct ScoringDev
     int32_t g2;       // go - ge
     int8_t  mat[kAlph * kAlph];     // original matrix[q*32+s], pad ranks = kNegPad
     int8_t  mat_adj[kAlph * kAlph]; // matrix[q*32+s] - ge (diagonal step in the skewed domain), pad ranks = kNegPad
-    // pass 2 works on values scaled by 4 whose two low bits carry the traceback tag: 4*(matrix - ge) + 2 (tag
-    // "diagonal"), pad ranks = -126.  Valid when every (matrix - ge) lies in [-31, 31] (trace_ok).
+    // pass 2 works on values scaled by 4 whose two low bits carry the traceback tag: 4*(matrix - ge) + 3 (tag
+    // "diagonal"), pad ranks = -125.  Valid when every (matrix - ge) lies in [-31, 31] (trace_ok).
     int8_t  mat_trace[kAlph * kAlph];
     int32_t trace_ok;
     // packed-half pass 1 (lx_score_f16.hip): (matrix - ge) as IEEE half bits, pad ranks = -100; per query rank the

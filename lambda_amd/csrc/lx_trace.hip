@@ -8,21 +8,25 @@
 // Kernel A (trace_forward_kernel<G,C>): the strip-systolic geometry and row-skewed recurrence of lx_score.hip.
 // Direction bits cost no compares: every DP value is scaled by 4 and its two low bits carry a TAG, so that the
 // max instructions the recurrence needs anyway also resolve the traceback ties:
-//     tt = Hs[i-1][j-1] + (4(s-ge)+2)        tag 2 = diagonal   (the +2 is baked into the LDS profile)
-//     m  = max(max3(tt, E, F|1), Z|3)         tag 0 = horizontal gap E, 1 = vertical gap F, 3 = none (H <= 0)
-//          -> on equal values the larger tag wins: none > diagonal > vertical > horizontal, which is the priority of
-//             a GapsLeft traceback ([UPSTREAM-RECALL], oracle/lx_oracle.c)
-//     Fr = max(F|1, A),  Er = max(E|1, A)       A = H + go - ge:  bit 0 of the result = "gap EXTENDED" (extension
-//             wins ties, i.e. gaps are as long as possible where the score allows)
-// The two tag bits of m and bit 0 of Fr and Er -- 4 bits per cell -- are funnel-shifted (v_alignbit_b32) into
-// ceil(C/8) words per lane per step and stored to an HBM trace buffer laid out [extension][panel][lane][step][word]:
-// every lane appends to its own stream (L2 write-combines the 8-12 B pieces), and the backtrace, which mostly moves
-// from step k to k-1 in the same lane, finds consecutive steps in the same 64-byte sector.  The best cell under the
-// reference's tie rule (first strict maximum in column-major order) is tracked per column as a packed key
-// H << 16 | (65535 - row) with v_max_u32.  Limits (checked by the host): H < 65536, Ls < 65536, |s - ge| <= 31.
+//     tt = Hs[i-1][j-1] + (4(s-ge)+3)        tag 3 = diagonal   (the +3 is baked into the LDS profile)
+//     m  = max3(tt, E, F)                     E always carries tag 1 (horizontal gap), F tag 2 (vertical gap)
+//          -> on equal values the larger tag wins: diagonal > vertical > horizontal, the priority of a GapsLeft
+//             traceback ([UPSTREAM-RECALL], oracle/lx_oracle.c)
+//     Fr = max3(F, A, Z')   A = H + go - ge (tag 0), Z' = zero floor of the next row (tag 0);  F' = Fr | 2
+//     Er = max(E, A)        E' = (Er & ~3) + 4 ge + 1
+//          -> bit 1 of Fr / bit 0 of Er = "the gap EXTENDED" (extension wins ties, i.e. gaps are as long as possible
+//             where the score allows).  The zero floor rides in F (max3 costs what max does); a cell whose H is the
+//             floor therefore reads "vertical", but no walk ever looks at it: the backtrace adds up the score of
+//             the columns it emits and stops when the sum reaches the extension's score, i.e. exactly where H = 0.
+// The two tag bits of m and (Fr | Er) & 3 -- 4 bits per cell, 19 issue slots per cell all told -- are funnel-shifted
+// (v_alignbit_b32) into ceil(C/8) words per lane per step, staged in LDS for 4 steps and written to the HBM trace
+// buffer as whole 16-byte quads, G lanes covering G consecutive quads (layout below).  The end cell under the
+// reference's tie rule (first strict maximum in column-major order) is the first cell in that order whose H equals
+// the extension's best score, which pass 1 already delivered (p.score_in): one max3 per two cells keeps the row
+// maximum, a rare slow path records the column.  Limits (checked by the host): Ls < 65536, |s - ge| <= 31.
 //
-// Kernel B (backtrace_kernel): one lane per extension walks the planes from the best cell to the first cell with
-// tag "none", emits one op byte per alignment column ('M','D','I') and the counts of lx_hsp.
+// Kernel B (backtrace_kernel): one lane per extension walks from the end cell to the first cell with H = 0, emits
+// one op byte per alignment column ('M','D','I') and the counts of lx_hsp.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -32,12 +36,11 @@
 namespace lx
 {
 
-// Trace buffer layout inside one extension slot.  kBlock consecutive steps of one lane are contiguous
-// (kBlock * kWords * 4 bytes), lanes are interleaved at that granularity:
-//     word index = ((panel * steps_cap/kBlock + k / kBlock) * G + g) * kBlock * kWords + (k % kBlock) * kWords + x
-// kBlock = steps_cap would be one private stream per lane (best locality for the backtrace, but lines stay partially
-// written for a long time and the HBM write traffic doubles); kBlock = 1 is fully coalesced per step (backtrace
-// touches a new line every step).
+// Trace buffer layout inside one extension slot: word x of kTraceBlock = 4 consecutive steps of one lane forms a
+// 16-byte quad, the quads of a step block are ordered [lane][x]:
+//     uint4 index = ((panel * steps_cap/4 + k/4) * G + g) * kWords + x,   component k % 4
+// The forward kernel writes G consecutive quads per store instruction (whole cache lines); the backtrace, which
+// mostly moves from step k to k-1 in the same lane, gets up to four moves out of one 16-byte load.
 #ifndef LX_TRACE_BLOCK
 #define LX_TRACE_BLOCK 4
 #endif
@@ -50,10 +53,7 @@ struct TraceWords
     static constexpr int kWords = (C + 7) / 8; // 4 direction bits per cell, 8 cells per 32-bit word
 };
 
-// KNOWN = the best score of every extension is already known (p.score_in, from pass 1): the end cell is then the
-// first cell in column-major order whose H equals it, found with one max3 per two cells plus a rare slow path,
-// instead of the per-column packed-key maximum (saves 3 of the 27 issue slots per cell).
-template <int G, int C, bool KNOWN>
+template <int G, int C>
 __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge4   = 4 * sc->ge;
     int const      g20   = 4 * sc->g2;
+    int const      ge41  = ge4 + 1; // a horizontal step: + gap_extend, and the E state's tag 1
     int const      nrows = p.nrows;
     uint32_t const padt  = (uint32_t)(nrows - 1);
 
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     uint32_t *    stage    = lds + ((Geo::kGroups + share - 1) / share) * (nrows * Geo::kRowDw) + grp * kStageDw;
 
     int best_h = 0, best_q = 0, best_s = 0;
-    // KNOWN: target score (x4) and the best (lowest) column / its first row seen so far in this lane
-    int const tgt4 = (KNOWN && active) ? 4 * p.score_in[e] : 0;
+    // target score (x4) and the best (lowest) column / its first row seen so far in this lane
+    int const tgt4 = active ? 4 * p.score_in[e] : 0;
     int       kcol = 0x7fffffff, krow = 0;
 
     for (int panel = 0; panel < npanels; ++panel)
@@ -202,17 +203,15 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         // all values are 4 x (skewed value); Z = 4 z_i
         int Z = ge4 * g;
         int Hrow[C], F1[C];
-        uint32_t colkey[C];
 #pragma unroll
         for (int c = 0; c < C; ++c)
         {
-            Hrow[c]   = Z + ge4;     // "H = 0" of the previous (virtual) row
-            F1[c]     = Z | 3;       // vertical gap state (tag 1) with the row's zero floor folded in (tag 3 = none)
-            colkey[c] = 0;
+            Hrow[c] = Z + ge4; // "H = 0" of the previous (virtual) row
+            F1[c]   = Z | 2;   // vertical gap state (tag 2) with the row's zero floor folded in
         }
         int diag0 = Z + ge4;
         int sendH = Z + ge4;
-        int sendE = 4 * kNegInf;
+        int sendE = 4 * kNegInf + 1; // horizontal gap state, always carries tag 1
 
         uint32_t * trp = tr + (uint64_t)panel * p.steps_cap * (G * TW::kWords);
 
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             for (int d = 0; d < Geo::kD; ++d)
                 pw[d] = prow[d * G];
 
-            int bndH = Z, bndE = 4 * kNegInf;
+            int bndH = Z, bndE = 4 * kNegInf + 1;
             if (use_carry_in && (unsigned)i < (unsigned)ls)
             {
                 bndH = carry[2 * i];
@@ -237,11 +236,9 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             int dg = diag0;
             diag0  = recvH;
 
-            int const      ZN3 = (Z - ge4) | 3; // zero floor of the next row, tag 3 = none
-            // key = ((Hs - z) << 16) | (65535 - row)  ==  (hc << 14) + K   (mod 2^32), hc = 4 Hs
-            uint32_t const K  = (uint32_t)(-Z) * 16384u + ((65535u - (uint32_t)i) & 0xffffu);
-            int            rm = Z; // KNOWN: running maximum of this row's cells
-            uint32_t       w[TW::kWords];
+            int const ZN = Z - ge4; // zero floor of the next row (tag 0)
+            int       rm = Z;       // running maximum of this row's cells
+            uint32_t  w[TW::kWords];
 #pragma unroll
             for (int x = 0; x < TW::kWords; ++x)
                 w[x] = 0;
@@ -250,51 +247,39 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             for (int c = 0; c < C; ++c)
             {
                 int const sub = (int)(int8_t)(pw[c >> 2] >> (8 * (c & 3)));
-                int const tt  = dg + sub;                        // tag 2
+                int const tt  = dg + sub;                        // tag 3 (in the profile)
                 dg            = Hrow[c];
-                int m         = max3i(tt, Ecur, F1[c]);          // E tag 0, F tag 1, floor (inside F1) tag 3
+                int m         = max3i(tt, Ecur, F1[c]);          // E tag 1 < F tag 2 < diagonal tag 3
                 LX_OPAQUE(m);
                 hc            = m & ~3;
                 int const A0  = hc + g20;                        // gap-open candidate, tag 0
-                // tag 1 = extended (wins ties), 0 = opened, 3 = the next row's floor is higher than both: that F is
-                // then never chosen as a source (H takes the floor's own tag 3), so its flag is never read
-                int const Fr  = max3i(F1[c], A0, ZN3);
-                F1[c]         = Fr | 1;
-                int const Er  = max(Ecur | 1, A0);               // tag 1 = extended, 0 = opened
-                Ecur          = (Er & ~3) + ge4;
+                // F of the next row: tag 2 = extended (wins ties), 0 = opened or the next row's zero floor.  A floor
+                // that wins makes that cell's H = 0, where every walk has already stopped: its flag is never read.
+                int const Fr  = max3i(F1[c], A0, ZN);
+                F1[c]         = Fr | 2;
+                int const Er  = max(Ecur, A0);                   // tag 1 = extended (wins ties), 0 = opened
+                Ecur          = (Er & ~3) + ge41;
                 uint32_t wc   = w[c >> 3];
                 wc            = __builtin_amdgcn_alignbit((uint32_t)m, wc, 2);
-                wc            = __builtin_amdgcn_alignbit((uint32_t)Fr, wc, 1);
-                wc            = __builtin_amdgcn_alignbit((uint32_t)Er, wc, 1);
+                wc            = __builtin_amdgcn_alignbit((uint32_t)(Fr | Er), wc, 2); // bit 0 = E extended, bit 1 = F
                 w[c >> 3]     = wc;
-                if constexpr (KNOWN)
-                {
-                    if (c & 1)
-                        rm = max3i(rm, Hrow[c - 1], hc); // Hrow[c-1] already holds this row's value
-                    else if (c == C - 1)
-                        rm = max(rm, hc);
-                }
-                else
-                {
-                    uint32_t const key = ((uint32_t)hc << 14) + K;
-                    colkey[c]          = max(colkey[c], key);
-                }
+                if (c & 1)
+                    rm = max3i(rm, Hrow[c - 1], hc); // Hrow[c-1] already holds this row's value
+                else if (c == C - 1)
+                    rm = max(rm, hc);
                 Hrow[c] = hc;
             }
-            if constexpr (KNOWN)
+            // rare: some cell of this row reaches the extension's best score -> remember the lowest such column
+            // (rows are visited in increasing order, so the first hit of a column is its lowest row)
+            if (tgt4 > 0 && rm == tgt4 + Z && (unsigned)i < (unsigned)ls)
             {
-                // rare: some cell of this row reaches the extension's best score -> remember the lowest such column
-                // (rows are visited in increasing order, so the first hit of a column is its lowest row)
-                if (tgt4 > 0 && rm == tgt4 + Z && (unsigned)i < (unsigned)ls)
-                {
 #pragma unroll
-                    for (int c = C - 1; c >= 0; --c)
-                        if (Hrow[c] == rm && col0 + c < kcol)
-                        {
-                            kcol = col0 + c;
-                            krow = i;
-                        }
-                }
+                for (int c = C - 1; c >= 0; --c)
+                    if (Hrow[c] == rm && col0 + c < kcol)
+                    {
+                        kcol = col0 + c;
+                        krow = i;
+                    }
             }
             sendH = hc;
             sendE = Ecur;
@@ -358,37 +343,6 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             __builtin_amdgcn_wave_barrier();
         }
 
-        if constexpr (!KNOWN)
-        {
-            // best cell of this panel: higher H wins, ties go to the lower column (then the key's lower row)
-            uint32_t bk = 0;
-            int      bc = 0;
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                if ((colkey[c] >> 16) > (bk >> 16))
-                {
-                    bk = colkey[c];
-                    bc = c;
-                }
-            int bcol = col0 + bc; // 0-based global column
-#pragma unroll
-            for (int off = 1; off < G; off <<= 1)
-            {
-                uint32_t const ok   = (uint32_t)__shfl_xor((int)bk, off);
-                int const      oc   = __shfl_xor(bcol, off);
-                bool const     take = ((ok >> 16) > (bk >> 16)) || ((ok >> 16) == (bk >> 16) && oc < bcol);
-                bk   = take ? ok : bk;
-                bcol = take ? oc : bcol;
-            }
-            int const ph = (int)(bk >> 16);
-            if (ph > best_h) // strict: earlier panels hold the lower columns
-            {
-                best_h = ph;
-                best_q = bcol + 1;
-                best_s = (int)(65535u - (bk & 0xffffu)) + 1;
-            }
-        }
-
         if (npanels > 1)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -398,27 +352,24 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         __builtin_amdgcn_wave_barrier();
     }
 
-    if constexpr (KNOWN)
-    {
-        // lowest column over the lanes of the group (every lane owns different columns), with its row
+    // lowest column over the lanes of the group (every lane owns different columns), with its row
 #pragma unroll
-        for (int off = 1; off < G; off <<= 1)
+    for (int off = 1; off < G; off <<= 1)
+    {
+        int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
+        bool const take = oc < kcol;
+        kcol = take ? oc : kcol;
+        krow = take ? orow : krow;
+    }
+    if (tgt4 > 0)
+    {
+        if (kcol == 0x7fffffff)
+            bad = true; // the score of pass 1 was not reproduced: never return a wrong alignment silently
+        else
         {
-            int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
-            bool const take = oc < kcol;
-            kcol = take ? oc : kcol;
-            krow = take ? orow : krow;
-        }
-        if (tgt4 > 0)
-        {
-            if (kcol == 0x7fffffff)
-                bad = true; // the score of pass 1 was not reproduced: never return a wrong alignment silently
-            else
-            {
-                best_h = tgt4 / 4;
-                best_q = kcol + 1;
-                best_s = krow + 1;
-            }
+            best_h = tgt4 / 4;
+            best_q = kcol + 1;
+            best_s = krow + 1;
         }
     }
 
@@ -475,8 +426,8 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     uint8_t *        ops = p.out_ops + p.ops_off[oi];
     uint32_t const   cap = x.q_len + x.s_len;
 
-    // the cell's 4 direction bits: [1:0] = source of H (3 none, 2 diagonal, 1 vertical gap, 0 horizontal gap),
-    // [2] = the vertical gap of the row below EXTENDS this cell's, [3] = the horizontal gap of the next column does
+    // the cell's 4 direction bits: [1:0] = source of H (3 diagonal, 2 vertical gap, 1 horizontal gap),
+    // [2] = the horizontal gap of the next column EXTENDS this cell's, [3] = the vertical gap of the row below does
     // one 16-byte load holds word x of the kTraceBlock (= 4) consecutive steps of a lane: a diagonal or vertical move
     // goes one step back in the same lane, so the cached quad serves up to four moves
     uint64_t tq_at = ~uint64_t(0);
@@ -504,10 +455,12 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     // touches as little as possible: one direction word (consecutive steps of a lane share a cache line), residues
     // from two register-cached aligned dwords (refilled every 4th step), the score matrix from LDS, and the op
     // bytes collected into whole dwords before they are stored.
-    // mode F / E = "the gap character emitted last still has to be classified": this cell's bit 2 / 3 says
+    // mode F / E = "the gap character emitted last still has to be classified": this cell's bit 3 / 2 says
     // whether that gap EXTENDS this cell's gap state (then this cell is a gap cell too) or OPENED from its H.
     int      i = ec.s_end - 1, j = ec.q_end - 1;
     int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
+    int      left = ec.score;                        // score not yet accounted for by the emitted columns
+    int const ge = p.sc->ge, g2 = p.sc->g2;          // a gap of k characters costs g2 + k ge
     uint32_t n    = 0;
     int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
 
@@ -565,32 +518,36 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         }
         if (mode == 1)
         {
-            if ((nib >> 2) & 1u)
+            if ((nib >> 3) & 1u)
             {
                 gx += 1;
+                left -= ge;
                 emit('D');
                 --i;
                 continue;
             }
             go += 1;
+            left -= g2;
             mode = 0;
         }
         else if (mode == 2)
         {
-            if ((nib >> 3) & 1u)
+            if ((nib >> 2) & 1u)
             {
                 gx += 1;
+                left -= ge;
                 emit('I');
                 --j;
                 continue;
             }
             go += 1;
+            left -= g2;
             mode = 0;
         }
+        if (left <= 0)
+            break; // the emitted columns add up to the score: H of this cell is 0, the alignment begins after it
         uint32_t const code = nib & 3u;
         if (code == 3)
-            break; // trace NONE: H <= 0
-        if (code == 2)
         {
             uint32_t const c0 = byte_of(qw, qaddr), c1 = byte_of(sw, saddr);
             int const      v       = smat[c0 * kAlph + c1];
@@ -598,18 +555,21 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
             nm += isMatch;
             nx += !isMatch;
             np += (v > 0);
+            left -= v;
             emit('M');
             --i;
             --j;
         }
-        else if (code == 1)
+        else if (code == 2)
         {
+            left -= ge;
             emit('D');
             --i;
             mode = 1;
         }
         else
         {
+            left -= ge;
             emit('I');
             --j;
             mode = 2;
@@ -675,10 +635,9 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
     int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + (size_t)Geo::kGroups * (G * kTraceBlock * TraceWords<C>::kWords + 4)) *
                        sizeof(uint32_t);
-    if (p.score_in)
-        hipLaunchKernelGGL((trace_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
-    else
-        hipLaunchKernelGGL((trace_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    if (!p.score_in)
+        return hipErrorInvalidValue; // the end cell is located through the known best score
+    hipLaunchKernelGGL((trace_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
