@@ -45,6 +45,12 @@ namespace lx
 #define LX_TRACE_BLOCK 4
 #endif
 constexpr int kTraceBlock = LX_TRACE_BLOCK;
+#ifndef LX_TRACE_UNROLL
+#define LX_TRACE_UNROLL 1
+#endif
+#define LX_TRACE_PRAGMA(x) _Pragma(#x)
+#define LX_TRACE_UNROLL_N(n) LX_TRACE_PRAGMA(unroll n)
+#define LX_TRACE_UNROLL_PRAGMA LX_TRACE_UNROLL_N(LX_TRACE_UNROLL)
 static_assert(kTraceBlock == 4, "the backtrace reads one uint4 = word x of four consecutive steps");
 
 template <int C>
@@ -53,7 +59,8 @@ struct TraceWords
     static constexpr int kWords = (C + 7) / 8; // 4 direction bits per cell, 8 cells per 32-bit word
 };
 
-template <int G, int C>
+// MULTI = queries may be wider than one panel of G*C columns (boundary columns are carried through p.ws)
+template <int G, int C, bool MULTI>
 __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -83,6 +90,11 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
     int const      ge4   = 4 * sc->ge;
     int const      g20   = 4 * sc->g2;
     int const      ge41  = ge4 + 1; // a horizontal step: + gap_extend, and the E state's tag 1
+    // VALU instructions with an SGPR operand issue at half rate on gfx950 (tools/ubench.hip): keep the two constants
+    // of the inner loop in VGPRs
+    int g20v = g20, ge41v = ge41;
+    LX_OPAQUE(g20v);
+    LX_OPAQUE(ge41v);
     int const      nrows = p.nrows;
     uint32_t const padt  = (uint32_t)(nrows - 1);
 
@@ -128,17 +140,17 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         npanels = max(npanels, __shfl_xor(npanels, off));
     }
     ls_max  = __builtin_amdgcn_readfirstlane(ls_max);
-    npanels = __builtin_amdgcn_readfirstlane(npanels);
+    npanels = MULTI ? __builtin_amdgcn_readfirstlane(npanels) : 1;
 
     bool bad = false;
-    if (active && ((uint32_t)my_panels > p.panels_cap || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
+    if (active && ((uint32_t)my_panels > p.panels_cap || (!MULTI && my_panels > 1) || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
     {
         bad = true; // the host sized the trace slots too small for this extension: report, never write out of bounds
         atomicExch(p.err, 3);
     }
 
     int32_t * carry = nullptr;
-    if (npanels > 1)
+    if (MULTI && npanels > 1)
     {
         uint32_t base = 0;
         int      ok   = 1;
@@ -173,9 +185,8 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         ls = 0;
 
     int const          slot_dw   = (grp / share) * (nrows * Geo::kRowDw);
-    uint32_t const     row_base  = (uint32_t)(slot_dw + g) * 4u;
-    constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
-    int const          steps     = (ls_max + G - 1 + 3) & ~3;
+    uint32_t const row_base_dw = (uint32_t)(slot_dw + g);
+    int const      steps       = (ls_max + G - 1 + 3) & ~3;
     uint32_t const     lsc       = (uint32_t)max(ls, 1) - 1u;
 
     // trace[e][panel][g][k][word]
@@ -196,8 +207,8 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
-        bool const use_carry_in = is_first && (panel > 0) && (panel < my_panels) && carry != nullptr;
-        bool const do_carry_out = is_last && (panel + 1 < my_panels) && carry != nullptr;
+        bool const use_carry_in = MULTI && is_first && (panel > 0) && (panel < my_panels) && carry != nullptr;
+        bool const do_carry_out = MULTI && is_last && (panel + 1 < my_panels) && carry != nullptr;
         bool const store_trace  = active && !bad && (panel < my_panels);
 
         // all values are 4 x (skewed value); Z = 4 z_i
@@ -218,18 +229,19 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
         auto step = [&](int k, uint32_t t)
         {
             int const        i    = k - g;
-            uint32_t const * prow = reinterpret_cast<uint32_t const *>(reinterpret_cast<char const *>(lds) + row_base + t * kRowBytes);
+            uint32_t const * prow = lds + (row_base_dw + t * (uint32_t)Geo::kRowDw);
             uint32_t         pw[Geo::kD];
 #pragma unroll
             for (int d = 0; d < Geo::kD; ++d)
                 pw[d] = prow[d * G];
 
             int bndH = Z, bndE = 4 * kNegInf + 1;
-            if (use_carry_in && (unsigned)i < (unsigned)ls)
-            {
-                bndH = carry[2 * i];
-                bndE = carry[2 * i + 1];
-            }
+            if constexpr (MULTI)
+                if (use_carry_in && (unsigned)i < (unsigned)ls)
+                {
+                    bndH = carry[2 * i];
+                    bndE = carry[2 * i + 1];
+                }
             int const recvH = shift_from_left<G>(sendH, bndH, is_first);
             int       Ecur  = shift_from_left<G>(sendE, bndE, is_first);
 
@@ -252,13 +264,13 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 int m         = max3i(tt, Ecur, F1[c]);          // E tag 1 < F tag 2 < diagonal tag 3
                 LX_OPAQUE(m);
                 hc            = m & ~3;
-                int const A0  = hc + g20;                        // gap-open candidate, tag 0
+                int const A0  = hc + g20v;                       // gap-open candidate, tag 0
                 // F of the next row: tag 2 = extended (wins ties), 0 = opened or the next row's zero floor.  A floor
                 // that wins makes that cell's H = 0, where every walk has already stopped: its flag is never read.
                 int const Fr  = max3i(F1[c], A0, ZN);
                 F1[c]         = Fr | 2;
                 int const Er  = max(Ecur, A0);                   // tag 1 = extended (wins ties), 0 = opened
-                Ecur          = (Er & ~3) + ge41;
+                Ecur          = (Er & ~3) + ge41v;
                 uint32_t wc   = w[c >> 3];
                 wc            = __builtin_amdgcn_alignbit((uint32_t)m, wc, 2);
                 wc            = __builtin_amdgcn_alignbit((uint32_t)(Fr | Er), wc, 2); // bit 0 = E extended, bit 1 = F
@@ -292,11 +304,12 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
                 for (int x = 0; x < TW::kWords; ++x)
                     st[x * kTraceBlock] = w[x];
             }
-            if (do_carry_out && (unsigned)i < (unsigned)ls)
-            {
-                carry[2 * i]     = sendH;
-                carry[2 * i + 1] = sendE;
-            }
+            if constexpr (MULTI)
+                if (do_carry_out && (unsigned)i < (unsigned)ls)
+                {
+                    carry[2 * i]     = sendH;
+                    carry[2 * i + 1] = sendE;
+                }
         };
 
         auto fetch_checked = [&](int k0, uint32_t (&t)[4])
@@ -326,9 +339,10 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
             mask_checked(k0, tc);
             fetch_checked(k0 + 4, tn);
-#pragma unroll 1 // one step already holds C independent cells; unrolling steps only costs VGPRs (occupancy)
+            uint32_t const tcp = tc[0] | (tc[1] << 8) | (tc[2] << 16) | (tc[3] << 24);
+LX_TRACE_UNROLL_PRAGMA // one step already holds C independent cells; unrolling steps mostly costs VGPRs (occupancy)
             for (int u = 0; u < 4; ++u)
-                step(k0 + u, tc[u]);
+                step(k0 + u, (tcp >> (8 * u)) & 0xffu);
             // flush the staged block of 4 steps: the group's G lanes write G consecutive 16-byte quads per store
             // instruction (whole cache lines), instead of every lane its own 12 bytes per step
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(Tr
             __builtin_amdgcn_wave_barrier();
         }
 
-        if (npanels > 1)
+        if (MULTI && npanels > 1)
         {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);
@@ -637,7 +651,10 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
                        sizeof(uint32_t);
     if (!p.score_in)
         return hipErrorInvalidValue; // the end cell is located through the known best score
-    hipLaunchKernelGGL((trace_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    if (p.panels_cap > 1)
+        hipLaunchKernelGGL((trace_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((trace_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
