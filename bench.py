@@ -168,8 +168,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather():
+        # the path's only exchange: gather of the per-rank top hits (SURVEY.md section 8e), RCCL over xGMI.
+        # Records = (global extension id, score) of the windows that clear a score cut-off.
+        hit = torch.nonzero(d_score >= args.hit_cutoff).flatten()
+        rec = torch.stack([hit + rank * n, d_score[hit].to(torch.int64)], dim=1)
+        return shard.gather_hits(rec)
+
     for _ in range(args.warmup):
         step()
+    if use_dist and args.warmup > 0:
+        torch.cuda.synchronize()
+        gather()  # untimed: the first collective of each kind sets up RCCL's channels
     fence()
     h.synchronize()  # surfaces any device-side error flag before timing
 
@@ -181,11 +191,8 @@ def main():
         step()
         ev[k][1].record(stream)
     if use_dist:
-        # the path's only exchange: gather of the per-rank top hits (SURVEY.md section 8e), RCCL over xGMI.
-        # Records = (global extension id, score) of the windows that clear a score cut-off.
-        hit = torch.nonzero(d_score >= args.hit_cutoff).flatten()
-        rec = torch.stack([hit + rank * n, d_score[hit].to(torch.int64)], dim=1)
-        all_hits = shard.gather_hits(rec)
+        stream.synchronize()
+        all_hits = gather()
         n_hits_total = int(all_hits.shape[0])
     fence()
     dt = time.perf_counter() - t0

@@ -883,7 +883,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         LX_HIP(h, hipEventRecord(h->evB[b], bstream));
         {
             char buf[96];
-            snprintf(buf, sizeof(buf), "lx::trace_forward_kernel<%d,%d>", G, P / G);
+            snprintf(buf, sizeof(buf), "lx::trace_forward_kernel<%d,%d,%s>", G, P / G, panels_cap > 1 ? "true" : "false");
             h->last_trace_kernel = buf;
         }
     }
