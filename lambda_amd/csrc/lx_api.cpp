@@ -28,6 +28,7 @@ int        score_cfg_count();
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream);
 int        score_pair_cfg_for(uint32_t max_qlen);
 int        score_pair_cfg_cols(int cfg);
+int        score_pair_cfg_group(int cfg);
 hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
@@ -259,8 +260,8 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
         LX_HIP(h, lx::launch_score_pair(pair_cfg, p, stream));
         p.fixup = 1;
         LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
-        snprintf(buf, sizeof(buf), "lx::score_pair_kernel<8,%d> (+ int32 fix-up lx::score_kernel<%d,%d,%s>)",
-                 lx::score_pair_cfg_cols(pair_cfg), 64 / lx::score_cfg_groups(cfg),
+        snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d> (+ int32 fix-up lx::score_kernel<%d,%d,%s>)",
+                 lx::score_pair_cfg_group(pair_cfg), lx::score_pair_cfg_cols(pair_cfg), 64 / lx::score_cfg_groups(cfg),
                  lx::score_cfg_panel(cfg) * lx::score_cfg_groups(cfg) / 64, multi ? "true" : "false");
     }
     else
@@ -805,7 +806,9 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
                     (unsigned long long)max_q, (unsigned long long)max_s);
     // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
     // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
-    int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1 : 0;
+    int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
+                    : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
+                                                                                      : 0;
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 15) & ~15ull); // multiple of the trace layout block

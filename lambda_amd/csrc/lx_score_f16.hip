@@ -14,7 +14,7 @@
 //
 // LDS: one query profile per wavefront in half precision, lane-contiguous rows (24 halves = 48 B per lane per subject
 // letter, read with two ds_read_b128 + one ds_read_b64); the two subject letters of a lane give two reads whose
-// halves are interleaved with one v_perm_b32 per column.  All 16 extensions of a wavefront must share the query
+// halves are interleaved with one v_perm_b32 per column.  All extensions of a wavefront (16, or 8 for G = 16) must share the query
 // (LX_OPT_QUERY_RUN multiple of 16, or host-side padding).
 #include <hip/hip_runtime.h>
 
@@ -59,11 +59,11 @@ struct PairGeo
 {
     static constexpr int kGroups   = 64 / G;                 // lane groups per wavefront, two extensions each
     static constexpr int kPanel    = G * C;
-    static constexpr int kLaneDw   = 12;                     // 24 halves per lane per profile row (C <= 24)
+    static constexpr int kUsedDw   = (C + 1) / 2;            // dwords that hold real columns
+    static constexpr int kLaneDw   = (kUsedDw + 3) & ~3;     // halves of a lane's columns per profile row, 16-byte granules
     // (padding the rows to spread different subject letters over more bank offsets was measured: no effect -- the
     // kernel is VALU-issue bound, LDS is ~1/3 busy including its bank conflicts)
     static constexpr int kRowDw    = kLaneDw * G;
-    static constexpr int kUsedDw   = (C + 1) / 2;            // dwords that hold real columns
 };
 
 template <int G, int C>
@@ -363,7 +363,7 @@ static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
     return hipGetLastError();
 }
 
-// pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192
+// pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192, 5 = (16,13) 208
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
@@ -375,6 +375,7 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
         case 2: return launch_pair_cfg<8, 16>(p, stream);
         case 3: return launch_pair_cfg<8, 8>(p, stream);
         case 4: return launch_pair_cfg<8, 24>(p, stream);
+        case 5: return launch_pair_cfg<16, 13>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -391,13 +392,17 @@ int score_pair_cfg_for(uint32_t max_qlen)
         return 0;
     if (max_qlen <= 192)
         return 4;
+    if (max_qlen <= 208)
+        return 5;
     return -1;
 }
 
 int score_pair_cfg_cols(int cfg)
 {
-    static int const c[5] = {19, 13, 16, 8, 24};
-    return (cfg >= 0 && cfg < 5) ? c[cfg] : 0;
+    static int const c[6] = {19, 13, 16, 8, 24, 13};
+    return (cfg >= 0 && cfg < 6) ? c[cfg] : 0;
 }
+
+int score_pair_cfg_group(int cfg) { return cfg == 5 ? 16 : 8; }
 
 } // namespace lx

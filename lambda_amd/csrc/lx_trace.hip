@@ -61,7 +61,7 @@ struct TraceWords
 
 // MULTI = queries may be wider than one panel of G*C columns (boundary columns are carried through p.ws)
 template <int G, int C, bool MULTI>
-__global__ __launch_bounds__(64, (C <= 10 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
+__global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
     using TW  = TraceWords<C>;
@@ -634,9 +634,10 @@ __global__ void max_lens_kernel(Extension const * ext, uint64_t n, MaxLens * out
 // ---- host-visible launchers ---------------------------------------------------------------------------
 
 // trace geometries: cfg 0 = (16,10) [any query length, multi-panel], cfg 1 = (8,19) [<= 152 columns, shared profile]
-int trace_cfg_panel(int cfg) { return cfg == 1 ? 8 * 19 : 16 * 10; }
+// (cfg 2 = (16,13) [<= 208 columns, shared profile])
+int trace_cfg_panel(int cfg) { return cfg == 1 ? 8 * 19 : cfg == 2 ? 16 * 13 : 16 * 10; }
 int trace_cfg_group(int cfg) { return cfg == 1 ? 8 : 16; }
-int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : TraceWords<10>::kWords; }
+int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : cfg == 2 ? TraceWords<13>::kWords : TraceWords<10>::kWords; }
 
 template <int G, int C>
 static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t stream)
@@ -672,14 +673,18 @@ hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return p.cfg == 1 ? launch_trace_forward_cfg<8, 19>(p, stream) : launch_trace_forward_cfg<16, 10>(p, stream);
+    return p.cfg == 1   ? launch_trace_forward_cfg<8, 19>(p, stream)
+           : p.cfg == 2 ? launch_trace_forward_cfg<16, 13>(p, stream)
+                        : launch_trace_forward_cfg<16, 10>(p, stream);
 }
 
 hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return p.cfg == 1 ? launch_backtrace_cfg<8, 19>(p, stream) : launch_backtrace_cfg<16, 10>(p, stream);
+    return p.cfg == 1   ? launch_backtrace_cfg<8, 19>(p, stream)
+           : p.cfg == 2 ? launch_backtrace_cfg<16, 13>(p, stream)
+                        : launch_backtrace_cfg<16, 10>(p, stream);
 }
 
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream)

@@ -175,7 +175,7 @@ def _dev_scores(handle, q, s, ext, max_qlen, run, packed):
     return d_out.cpu().numpy(), name
 
 
-@pytest.mark.parametrize("lq,wpq", [(150, 32), (100, 16), (64, 16), (120, 48), (190, 16), (33, 16)])
+@pytest.mark.parametrize("lq,wpq", [(150, 32), (100, 16), (64, 16), (120, 48), (190, 16), (33, 16), (200, 32), (208, 16)])
 def test_packed_half_kernel_is_exact(handle, oracle, lq, wpq):
     """The packed-half pass-1 kernel (lx_score_f16.hip) must be bit-identical to the oracle and to the int32 kernel."""
     sc_p = SCHEMES["blosum62"]

@@ -181,15 +181,16 @@ def test_iterate_matches_driver(handle, oracle, filters):
         assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])
 
 
-@pytest.mark.parametrize("wpq,run", [(32, 32), (8, 8), (7, 0)])
-def test_fused_extend_on_device(handle, oracle, wpq, run):
-    """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2."""
+@pytest.mark.parametrize("wpq,run,lq", [(32, 32, 150), (8, 8, 150), (7, 0, 150), (32, 32, 200), (16, 16, 100)])
+def test_fused_extend_on_device(handle, oracle, wpq, run, lq):
+    """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2.
+    lq = 200 is the shape of BASELINE.json configs[3] (200 aa queries, 230 aa windows: the (16,13) geometries)."""
     import torch
 
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
     osc = oracle_lib.scoring_from(sc_p)
-    q, s, ext = synth.make_batch_np(90, 150, wpq, seed=1234 + wpq)
+    q, s, ext = synth.make_batch_np(90, lq, wpq, seed=1234 + wpq + lq)
     n = len(ext)
     dev = torch.device("cuda:0")
     pad = np.zeros(256, np.uint8)
@@ -205,8 +206,8 @@ def test_fused_extend_on_device(handle, oracle, wpq, run):
     d_score = torch.zeros(n, dtype=torch.int32, device=dev)
     d_count = torch.zeros(2, dtype=torch.int64, device=dev)
     cutoff = 70
-    handle.set_option(capi.LX_OPT_MAX_QLEN, 150)
-    handle.set_option(capi.LX_OPT_MAX_SLEN, 176)
+    handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, int(ext["s_len"].max()))
     handle.set_option(capi.LX_OPT_QUERY_RUN, run)
     torch.cuda.synchronize()
     try:
