@@ -29,6 +29,7 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 int        score_pair_cfg_for(uint32_t max_qlen);
 int        score_pair_cfg_cols(int cfg);
 int        score_pair_cfg_group(int cfg);
+size_t     score_pair_profile_bytes(int cfg, int nrows);
 hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
@@ -236,7 +237,7 @@ int check_async_error(lx_handle * h)
 // One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
 // (or need the multi-panel path when wider).
 int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n,
-                      void * d_out, int cfg, bool multi, bool shared, hipStream_t stream, int pair_cfg = -1)
+                      void * d_out, int cfg, bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0)
 {
     lx::ScoreParams p{};
     p.q_res          = static_cast<uint8_t const *>(d_q);
@@ -252,6 +253,7 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     p.shared_profile = shared ? 1 : 0;
     p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     p.fixup          = 0;
+    p.pair_share     = pair_share;
     char buf[128];
     if (pair_cfg >= 0)
     {
@@ -574,12 +576,28 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
         h->ev_pool_used = 0;
         LX_HIP(h, hipEventRecord(h->ev0, stream));
     }
-    // packed-half path: every wavefront of 16 extensions must share its query and the query must fit one panel
-    int pair_cfg = -1;
-    if (h->opt_f16 && shared && h->opt_query_run % 16 == 0 && h->opt_max_qlen != 0)
-        pair_cfg = lx::score_pair_cfg_for((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu));
+    // packed-half path: the extensions of a wavefront (or, where two LDS profiles fit, of each half of it) must
+    // share their query and the query must fit one panel
+    int pair_cfg = -1, pair_share = 0;
+    if (h->opt_f16 && shared && h->opt_max_qlen != 0)
+    {
+        int const pc = lx::score_pair_cfg_for((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu));
+        if (pc >= 0)
+        {
+            int const      groups   = 64 / lx::score_pair_cfg_group(pc);
+            uint64_t const per_wave = 2ull * groups;
+            int const      nrows    = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+            if (h->opt_query_run % per_wave == 0)
+                pair_cfg = pc;
+            else if (groups >= 2 && h->opt_query_run % (per_wave / 2) == 0 && 2 * lx::score_pair_profile_bytes(pc, nrows) <= 13 * 1024)
+            {
+                pair_cfg   = pc;
+                pair_share = groups / 2;
+            }
+        }
+    }
     PhaseTimer pt(h, stream, 0);
-    if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream, pair_cfg)))
+    if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream, pair_cfg, pair_share)))
         return rc;
     pt.close();
     if (!h->in_fused)

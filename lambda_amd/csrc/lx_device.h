@@ -67,6 +67,7 @@ struct ScoreParams
     int32_t            shared_profile; // 1: every group of a wave uses the same query -> one profile slot per wave
     int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
     int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
+    int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
 };
 
 // best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel

@@ -113,12 +113,16 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
         if (lsB != 0)
             sB += x.s_off;
     }
+    // p.pair_share lane groups (0 = all of them) use one LDS profile: the extensions of such a block share the query
+    int const share_g = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
+    int const blk     = grp / share_g;
     {
-        // the caller promised one query per wavefront: verify, fail loudly otherwise
-        uint64_t const q0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(q_off >> 32)) << 32) |
-                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)q_off);
-        int const l0 = __builtin_amdgcn_readfirstlane(lq);
-        if ((actA && (q_off != q0 || lq != l0)) || (actB && (q_offB != q0 || lqB != l0)))
+        // the caller promised one query per block: verify against the block's first lane, fail loudly otherwise
+        int const      leader = blk * share_g * G;
+        uint64_t const q0     = ((uint64_t)(uint32_t)__shfl((int)(q_off >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)q_off, leader);
+        int const      l0     = __shfl(lq, leader);
+        bool const     lead_in = __shfl(actA ? 1 : 0, leader) != 0;
+        if (lead_in && ((actA && (q_off != q0 || lq != l0)) || (actB && (q_offB != q0 || lqB != l0))))
             atomicExch(p.err, 2);
     }
 
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1)
         bound += __shfl_xor(bound, off);
-    bound              = __builtin_amdgcn_readfirstlane(bound); // lane 0's group = the shared query
-    bool const too_big = (lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046);
+    // (every group summed its own query; one block over the limit sends the whole wavefront to the fix-up launch)
+    bool const too_big = __ballot((lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046)) != 0;
     if (too_big)
     {
         if (is_first)
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
     }
 
     // ---- profile: prof[t][g][h] = (s(q_col, t) - ge) as half, lane-contiguous
-    if (grp == 0)
+    int const slot_dw = blk * (nrows * Geo::kRowDw);
+    if (grp % share_g == 0)
     {
 #pragma unroll 1
         for (int d = 0; d < Geo::kUsedDw; ++d)
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
                     rows[cc][4 * x + 3] = v.w;
                 }
             }
-            uint32_t * dst = lds + g * Geo::kLaneDw + d;
+            uint32_t * dst = lds + slot_dw + g * Geo::kLaneDw + d;
 #pragma unroll
             for (int w = 0; w < 16; ++w)
             {
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    uint32_t const row_base  = (uint32_t)(g * Geo::kLaneDw) * 4u;
+    uint32_t const row_base  = (uint32_t)(slot_dw + g * Geo::kLaneDw) * 4u;
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
 
     h2 const GE = hsplat((float)ge), G2 = hsplat((float)sc->g2), NGE = hsplat((float)-ge);
@@ -358,7 +363,10 @@ static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
     uint64_t const blocks   = (p.n + per_wave - 1) / per_wave;
     if (blocks > 0x7fffffffull)
         return hipErrorInvalidValue;
-    size_t const lds = (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    int const    slots = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? Geo::kGroups / p.pair_share : 1;
+    if (slots * p.pair_share != Geo::kGroups && slots != 1)
+        return hipErrorInvalidValue;
+    size_t const lds = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
     hipLaunchKernelGGL((score_pair_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
@@ -404,5 +412,12 @@ int score_pair_cfg_cols(int cfg)
 }
 
 int score_pair_cfg_group(int cfg) { return cfg == 5 ? 16 : 8; }
+
+// LDS bytes of one profile (the kernel's occupancy allows about 13 KB per wavefront)
+size_t score_pair_profile_bytes(int cfg, int nrows)
+{
+    int const G = score_pair_cfg_group(cfg), C = score_pair_cfg_cols(cfg);
+    return (size_t)nrows * (size_t)((((C + 1) / 2 + 3) & ~3) * G) * sizeof(uint32_t);
+}
 
 } // namespace lx

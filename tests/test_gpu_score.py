@@ -220,6 +220,22 @@ def test_packed_half_other_schemes(handle, oracle):
         assert "score_pair_kernel" in kn and (got == want).all()
 
 
+def test_packed_half_runs_of_8(handle, oracle):
+    """BASELINE.json configs[2]/[4] shape: 8 windows per read.  Small alphabets fit two LDS profiles per wavefront, so
+    the packed kernel runs with one query per HALF wavefront; protein profiles do not fit twice and stay on int32."""
+    for name, alpha, want_pair in (("nucl", np.array([0, 1, 2, 4, 3], dtype=np.uint8), True),
+                                   ("bs_rev", np.arange(4, dtype=np.uint8), True),
+                                   ("blosum62", synth.STD20, False)):
+        sc_p = SCHEMES[name]
+        handle.set_scoring(sc_p, 0)
+        q, s, ext = synth.make_batch_np(203, 150, 8, seed=99, alphabet=alpha, sub_rate=0.06, indel_rate=0.02)
+        want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+        got, kn = _dev_scores(handle, q, s, ext, 150, 8, 1)
+        assert ("score_pair_kernel" in kn) == want_pair, kn
+        assert (got == want).all()
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+
+
 def test_full_size_batch_properties(handle):
     """BASELINE.json configs[1] at FULL size (100 000 x 150 aa x 32 windows = 3.2 M extensions, 84.5 Gcells), checked
     through size-independent properties, no oracle: (1) two independent kernels -- packed half and int32 -- agree on
