@@ -195,6 +195,20 @@ uint64_t lx_length_adjustment(uint64_t db_len, uint64_t q_len, lx_karlin const *
 double   lx_evalue(int32_t score, uint64_t q_len_adj, uint64_t db_len_adj, lx_karlin const * ka);
 double   lx_bitscore(int32_t score, lx_karlin const * ka);
 
+/* Rank bridge (seqan2_to_rank_inner / biocpp_rank_to_seqan2rank, src/seqan2_to_biocpp.hpp:352-366, :382-395): turns
+ * n BioC++ ranks into the ranks the scoring tables of this library are indexed by.  in == out is allowed.
+ *   LX_RANKS_AA27      aa27 (A..W, X, Y, Z, '*')  ->  SeqAn AminoAcid order (.. W, Y, Z, X, '*')
+ *   LX_RANKS_DNA5_BS   dna5 (A, C, G, N, T)       ->  SeqAn Dna5 order (A, C, G, T, N); bisulfite mode only
+ *   LX_RANKS_SIMPLE    alphabets scored by match/mismatch keep their BioC++ rank (plain copy)
+ * Returns LX_EINVAL for an unknown kind or a rank outside the alphabet. */
+enum
+{
+    LX_RANKS_AA27    = 0,
+    LX_RANKS_DNA5_BS = 1,
+    LX_RANKS_SIMPLE  = 2
+};
+int lx_convert_ranks(int kind, uint8_t const * in, uint64_t n, uint8_t * out);
+
 /* _widenAndPreprocessMatches (src/search_algo.hpp:1136-1175), in place; qlens/slens are indexed by the
  * frame-expanded qryId/subjId.  Returns the new match count. */
 uint64_t lx_widen_and_preprocess(lx_match * m, uint64_t n, uint64_t const * qlens, uint64_t const * slens);

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_matches",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
-    "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records",
+    "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -146,6 +146,7 @@ def load():
     lib.lx_evalue.restype = C.c_double
     lib.lx_bitscore.argtypes = [C.c_int32, C.POINTER(Karlin)]
     lib.lx_bitscore.restype = C.c_double
+    lib.lx_convert_ranks.argtypes = [i32, vp, u64, vp]
     lib.lx_widen_and_preprocess.argtypes = [vp, u64, vp, vp]
     lib.lx_widen_and_preprocess.restype = u64
     lib.lx_iterate_matches.argtypes = [vp, i32, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, u64, vp, u64,
@@ -207,6 +208,19 @@ def widen_and_preprocess(matches: np.ndarray, qlens: np.ndarray, slens: np.ndarr
     slens = np.ascontiguousarray(slens, dtype=np.uint64)
     n = load().lx_widen_and_preprocess(_ptr(m), len(m), _ptr(qlens), _ptr(slens))
     return m[: int(n)]
+
+
+LX_RANKS_AA27, LX_RANKS_DNA5_BS, LX_RANKS_SIMPLE = 0, 1, 2
+
+
+def convert_ranks(kind: int, ranks: np.ndarray) -> np.ndarray:
+    """BioC++ ranks -> the ranks the scoring tables use (src/seqan2_to_biocpp.hpp:352-395)."""
+    src = np.ascontiguousarray(ranks, dtype=np.uint8)
+    out = np.empty_like(src)
+    rc = load().lx_convert_ranks(kind, _ptr(src), src.size, _ptr(out))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_convert_ranks: unknown kind or rank outside the alphabet")
+    return out
 
 
 def builtin_scoring(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Scoring:

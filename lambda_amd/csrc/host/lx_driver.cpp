@@ -109,6 +109,55 @@ double lx_bitscore(int32_t score, lx_karlin const * ka)
     return lambda_amd::computeBitScore(score, *ka);
 }
 
+// seqan2_to_rank_inner, src/seqan2_to_biocpp.hpp:382-395: aa27 and (bisulfite) dna5 go through a permutation, every
+// other alphabet keeps its rank.  The two permutations move X behind Z and N behind T.
+int lx_convert_ranks(int kind, uint8_t const * in, uint64_t n, uint8_t * out)
+{
+    if ((!in || !out) && n != 0)
+        return LX_EINVAL;
+    if (kind == LX_RANKS_SIMPLE)
+    {
+        if (in != out)
+            std::memmove(out, in, n);
+        return LX_OK;
+    }
+    if (kind != LX_RANKS_AA27 && kind != LX_RANKS_DNA5_BS)
+        return LX_EINVAL;
+    uint8_t  table[32];
+    unsigned size = 0;
+    if (kind == LX_RANKS_AA27)
+    {
+        size = 27;
+        for (unsigned r = 0; r < 27; ++r)
+            table[r] = (uint8_t)r;
+        table[23] = 25; // X
+        table[24] = 23; // Y
+        table[25] = 24; // Z
+    }
+    else
+    {
+        size     = 5;
+        table[0] = 0;
+        table[1] = 1;
+        table[2] = 2;
+        table[3] = 4; // N
+        table[4] = 3; // T
+    }
+    int rc = LX_OK;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        uint8_t const r = in[i];
+        if (r >= size)
+        {
+            rc     = LX_EINVAL;
+            out[i] = (uint8_t)(size - 1);
+        }
+        else
+            out[i] = table[r];
+    }
+    return rc;
+}
+
 uint64_t lx_widen_and_preprocess(lx_match * m, uint64_t n, uint64_t const * qlens, uint64_t const * slens)
 {
     return lambda_amd::widenAndPreprocessMatches(m, n, qlens, slens, nullptr);

@@ -82,3 +82,28 @@ def test_blast_statistics_match_oracle(oracle):
                     assert lib.lx_bitscore(sc, C.byref(ka)) == oracle.bitscore(sc, oka)
     with pytest.raises(capi.LambdaExtError):
         capi.karlin_params(62, gap_open=-3, gap_extend=-3)  # no published values -> prepareScoring would throw
+
+
+def test_rank_bridge():
+    """lx_convert_ranks = seqan2_to_rank_inner (src/seqan2_to_biocpp.hpp:352-395): aa27 moves X behind Z, bisulfite
+    dna5 moves N behind T, match/mismatch alphabets pass through; out-of-alphabet ranks are an error."""
+    import numpy as np
+    import pytest
+
+    aa_bio = "ABCDEFGHIJKLMNOPQRSTUVWXYZ*"   # BioC++ aa27 rank order
+    aa_seqan = "ABCDEFGHIJKLMNOPQRSTUVWYZX*"  # SeqAn AminoAcid rank order (the order of the scoring tables)
+    got = capi.convert_ranks(capi.LX_RANKS_AA27, np.arange(27, dtype=np.uint8))
+    assert [aa_seqan[r] for r in got] == list(aa_bio)
+    dna_bio, dna_seqan = "ACGNT", "ACGTN"
+    got = capi.convert_ranks(capi.LX_RANKS_DNA5_BS, np.arange(5, dtype=np.uint8))
+    assert [dna_seqan[r] for r in got] == list(dna_bio)
+    x = np.array([4, 3, 2, 1, 0, 3], dtype=np.uint8)
+    assert (capi.convert_ranks(capi.LX_RANKS_SIMPLE, x) == x).all()
+    # the BLOSUM62 table is indexed by SeqAn ranks: W/W = 11, Y/Y = 7, X/X = -1 after the bridge
+    m = capi.builtin_scoring(62).matrix_np()
+    w, y, xx = capi.convert_ranks(capi.LX_RANKS_AA27, np.array([aa_bio.index(c) for c in "WYX"], dtype=np.uint8))
+    assert (m[w, w], m[y, y], m[xx, xx]) == (11, 7, -1)
+    with pytest.raises(capi.LambdaExtError):
+        capi.convert_ranks(capi.LX_RANKS_AA27, np.array([27], dtype=np.uint8))
+    with pytest.raises(capi.LambdaExtError):
+        capi.convert_ranks(7, np.array([0], dtype=np.uint8))
