@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--pass1-only", action="store_true", help="time the score kernel alone (no filter, no traceback)")
     ap.add_argument("--db-length", type=int, default=205_000_000, help="dbTotalLength for the e-value (Swiss-Prot sized)")
     ap.add_argument("--max-evalue", type=float, default=1e-2)
-    ap.add_argument("--hit-cutoff", type=int, default=120, help="raw score a window needs to enter the final gather")
+    ap.add_argument("--max-matches", type=int, default=25, help="HSPs kept per query for the final gather (maxMatches)")
     return ap.parse_args()
 
 
@@ -169,10 +169,20 @@ def main():
         torch.cuda.synchronize()
 
     def gather():
-        # the path's only exchange: gather of the per-rank top hits, RCCL over xGMI.
-        # Records = (global extension id, score) of the windows that clear a score cut-off.
-        hit = torch.nonzero(d_score >= args.hit_cutoff).flatten()
-        rec = torch.stack([hit + rank * n, d_score[hit].to(torch.int64)], dim=1)
+        # the path's only exchange: every rank keeps, per query, its best `maxMatches` = 25
+        # HSPs (src/search_options.hpp:99) among the survivors of the e-value filter, then one gather of fixed-size
+        # records [global extension id, lx_hsp (48 B)] = 56 B each -- RCCL over xGMI.  Query ranges are disjoint, so
+        # rank order is the final order.
+        if args.pass1_only or args.windows <= 0:
+            hit = torch.nonzero(d_score >= min_score).flatten()
+            return shard.gather_hits(torch.stack([hit + rank * n, d_score[hit].to(torch.int64)], dim=1))
+        sc2 = d_score.view(args.queries, args.windows)
+        k = min(args.max_matches, args.windows)
+        top, idx = torch.topk(sc2, k, dim=1)
+        keep = top >= min_score
+        ext_id = (idx + torch.arange(args.queries, device=dev).unsqueeze(1) * args.windows)[keep]
+        hsp64 = d_hsp.view(torch.int64).view(n, 6)[ext_id]
+        rec = torch.cat([(ext_id + rank * n).unsqueeze(1), hsp64], dim=1)
         return shard.gather_hits(rec)
 
     for _ in range(args.warmup):
@@ -190,6 +200,7 @@ def main():
         ev[k][0].record(stream)
         step()
         ev[k][1].record(stream)
+    n_hits_total = None
     if use_dist:
         stream.synchronize()
         all_hits = gather()
@@ -258,7 +269,9 @@ def main():
                             f"cells = sum Lq*Ls (full rectangle, band off as in the reference)",
                 "extensions_per_gpu": n,
                 "gcells_per_gpu": round(cells_rank / 1e9, 3),
-                "parallelism": f"query-sharded x{world}, no data-path collective",
+                "parallelism": f"query-sharded x{world}, no data-path collective; one gather of the per-query top-"
+                               f"{args.max_matches} HSP records (56 B) after the last step"
+                               + (f" ({n_hits_total} records)" if n_hits_total is not None else ""),
                 "step": ("pass 1 score kernel over the whole batch" if args.pass1_only else
                          f"pass 1 (score all) -> e-value filter (E<={args.max_evalue:g} at db {args.db_length}, i.e. score>={min_score}) "
                          f"-> pass 2 (traceback of the {survivors} survivors), all on the GPU; GCUPS counts pass-1 cells only"),
