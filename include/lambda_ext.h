@@ -226,8 +226,40 @@ typedef struct lx_search_params
     int32_t   bisulfite;        /* 1: iterateMatches' bisulfite branch (src/search_algo.hpp:1367-1379): matches on even subject
                                    frames are extended with slot 0 (forward scheme), odd ones with slot 1 (reverse scheme);
                                    the `slot` argument is ignored                                                          */
+    int32_t   q_frame_mode;     /* LX_FRAMES_*: how _setFrames derives qFrameShift from the frame-expanded qryId            */
+    int32_t   s_frame_mode;     /* same for sFrameShift / subjId                                                            */
     lx_karlin karlin;
 } lx_search_params;
+
+/* ---- frame bookkeeping (_setFrames, _untrueQryId, _untrueSubjId; src/search_algo.hpp:768-814, :940-996) ------------
+ * The reference expands every sequence into its frames (translate_join: 6, add_reverse_complement: 2, bisulfite
+ * query: 4 / subject: 2; src/shared_definitions.hpp:246-281) and numbers them id * numFrames + k.  The mode says
+ * which expansion a side uses:
+ *   LX_FRAMES_NONE        frame 0                                        (protein sequences)
+ *   LX_FRAMES_REVCOMP     k = 0 -> +1, k = 1 -> -1                       (blastn query)
+ *   LX_FRAMES_TRANSLATED  k = 0..2 -> +1..+3, k = 3..5 -> -1..-3         (blastx / tblastx query, tblastn / tblastx subject)
+ *   LX_FRAMES_BISULFITE   query: k = 0..3 -> +1, +2, -1, -2;  subject: k = 0, 1 -> +1, +2 */
+enum
+{
+    LX_FRAMES_NONE       = 0,
+    LX_FRAMES_REVCOMP    = 1,
+    LX_FRAMES_TRANSLATED = 2,
+    LX_FRAMES_BISULFITE  = 3
+};
+void     lx_set_frames(int q_mode, int s_mode, uint64_t qry_id, uint64_t subj_id, int32_t * q_frame, int32_t * s_frame);
+/* the frame-expanded id whose sequence an HSP with this frame was aligned on (the bisulfite duplicates are identical
+ * sequences, so the reference maps them onto the first copy) */
+uint64_t lx_untrue_qry_id(int q_mode, uint64_t n_qid, int32_t q_frame);
+uint64_t lx_untrue_subj_id(int s_mode, uint64_t n_sid, int32_t s_frame);
+
+/* Six-frame translation (what bio::views::translate_join hands to the extension in the translated programs,
+ * src/shared_definitions.hpp:246-281): `dna5` holds n BioC++ dna5 ranks (A, C, G, N, T).  Writes the frames
+ * +1, +2, +3, -1, -2, -3 back to back into `out` (SeqAn AminoAcid ranks; 2n bytes are always enough) and their
+ * offsets/lengths into frame_off/frame_len.  A codon with N becomes the amino acid all its completions agree on,
+ * else X.  genetic_code: 1 (the canonical code; the reference's default, src/search_options.hpp:170).
+ * Returns LX_EINVAL for other codes, bad ranks or a too small `out`. */
+int lx_translate_six_frames(uint8_t const * dna5, uint64_t n, int genetic_code, uint8_t * out, uint64_t out_capacity,
+                            uint64_t * frame_off, uint64_t * frame_len);
 
 /* One finished HSP: the fields of TBlastMatch the writers read (src/search_datastructures.hpp:470-484). */
 typedef struct lx_blast_match
@@ -243,7 +275,8 @@ typedef struct lx_blast_match
     double   bit_score, e_value;
     uint64_t ops_off;           /* into the result's ops buffer */
     uint32_t n_ops;
-    int32_t  q_frame;           /* qFrameShift: 0 = none (protein query), +1 / -1 = forward / reverse-complement strand */
+    int16_t  q_frame;           /* qFrameShift (lx_set_frames): 0 = none, +-1 strands, +-1..3 translation frames */
+    int16_t  s_frame;           /* sFrameShift                                                                    */
 } lx_blast_match;
 
 typedef struct lx_iterate_stats
@@ -299,7 +332,9 @@ enum
 };
 /* Appends header (if write_header) and records to `path` (myWriteHeader / myWriteRecord,
  * src/search_output.hpp:305-461, :463-733).  `ops` is the ops buffer the matches' ops_off index into; `program` is
- * "blastp" or "blastn" (the two untranslated programs in scope). */
+ * "blastp", "blastn", or -- tabular formats only -- "blastx", "tblastn", "tblastx": positions of a translated side
+ * are reported in nucleotide coordinates of the original sequence (names->q_lens / s_lens = untranslated lengths),
+ * start > end on the minus strand. */
 int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
                      uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                      uint64_t const * q_ascii_off);

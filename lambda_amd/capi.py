@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
+    "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -44,7 +45,8 @@ class Karlin(C.Structure):
 class SearchParams(C.Structure):
     _fields_ = [("max_evalue", C.c_double), ("min_bitscore", C.c_int32), ("id_cutoff", C.c_int32),
                 ("db_total_length", C.c_uint64), ("query_translated", C.c_int32), ("qry_num_frames", C.c_int32),
-                ("sbj_num_frames", C.c_int32), ("bisulfite", C.c_int32), ("karlin", Karlin)]
+                ("sbj_num_frames", C.c_int32), ("bisulfite", C.c_int32), ("q_frame_mode", C.c_int32),
+                ("s_frame_mode", C.c_int32), ("karlin", Karlin)]
 
 
 class IterateStats(C.Structure):
@@ -57,7 +59,7 @@ BLAST_MATCH_DTYPE = np.dtype([
     ("s_start", "<u8"), ("s_end", "<u8"), ("score", "<i4"), ("alignment_length", "<i4"), ("num_matches", "<i4"),
     ("num_mismatches", "<i4"), ("num_positives", "<i4"), ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"),
     ("identity", "<f4"), ("bit_score", "<f8"), ("e_value", "<f8"), ("ops_off", "<u8"), ("n_ops", "<u4"),
-    ("q_frame", "<i4")])
+    ("q_frame", "<i2"), ("s_frame", "<i2")])
 
 
 class RecordStats(C.Structure):
@@ -147,6 +149,13 @@ def load():
     lib.lx_bitscore.argtypes = [C.c_int32, C.POINTER(Karlin)]
     lib.lx_bitscore.restype = C.c_double
     lib.lx_convert_ranks.argtypes = [i32, vp, u64, vp]
+    lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.lx_set_frames.restype = None
+    lib.lx_untrue_qry_id.argtypes = [i32, u64, i32]
+    lib.lx_untrue_qry_id.restype = u64
+    lib.lx_untrue_subj_id.argtypes = [i32, u64, i32]
+    lib.lx_untrue_subj_id.restype = u64
+    lib.lx_translate_six_frames.argtypes = [vp, u64, i32, vp, u64, vp, vp]
     lib.lx_widen_and_preprocess.argtypes = [vp, u64, vp, vp]
     lib.lx_widen_and_preprocess.restype = u64
     lib.lx_iterate_matches.argtypes = [vp, i32, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, u64, vp, u64,
@@ -211,6 +220,26 @@ def widen_and_preprocess(matches: np.ndarray, qlens: np.ndarray, slens: np.ndarr
 
 
 LX_RANKS_AA27, LX_RANKS_DNA5_BS, LX_RANKS_SIMPLE = 0, 1, 2
+LX_FRAMES_NONE, LX_FRAMES_REVCOMP, LX_FRAMES_TRANSLATED, LX_FRAMES_BISULFITE = 0, 1, 2, 3
+
+
+def set_frames(q_mode: int, s_mode: int, qry_id: int, subj_id: int) -> tuple[int, int]:
+    """_setFrames (src/search_algo.hpp:768-814): (qFrameShift, sFrameShift) of a frame-expanded id pair."""
+    qf, sf = C.c_int32(), C.c_int32()
+    load().lx_set_frames(q_mode, s_mode, qry_id, subj_id, C.byref(qf), C.byref(sf))
+    return qf.value, sf.value
+
+
+def translate_six_frames(dna5: np.ndarray, genetic_code: int = 1) -> list[np.ndarray]:
+    """Six-frame translation of BioC++ dna5 ranks into SeqAn AminoAcid ranks, frames +1 +2 +3 -1 -2 -3."""
+    src = np.ascontiguousarray(dna5, dtype=np.uint8)
+    out = np.zeros(2 * src.size + 8, dtype=np.uint8)
+    off, ln = np.zeros(6, dtype=np.uint64), np.zeros(6, dtype=np.uint64)
+    rc = load().lx_translate_six_frames(_ptr(src), src.size, genetic_code, _ptr(out), out.size, _ptr(off), _ptr(ln))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_translate_six_frames")
+    return [out[int(o): int(o) + int(l)].copy() for o, l in zip(off, ln)]
+
 
 
 def convert_ranks(kind: int, ranks: np.ndarray) -> np.ndarray:

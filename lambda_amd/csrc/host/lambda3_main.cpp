@@ -60,7 +60,8 @@ uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets p
     }
 }
 
-void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet & out)
+// translate = six protein frames per nucleotide sequence (BLASTX queries: qryNumFrames = 6, translate_join)
+void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet & out, bool translate = false)
 {
     std::ifstream in(path);
     if (!in)
@@ -73,6 +74,24 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
         out.ascii_off.push_back(out.ascii.size());
         out.orig_len.push_back(cur.size());
         out.ascii += cur;
+        if (translate)
+        {
+            std::vector<uint8_t> nt(cur.size());
+            for (size_t i = 0; i < cur.size(); ++i)
+                nt[i] = dnaRank(cur[i]);
+            std::vector<uint8_t> aa(2 * cur.size() + 8);
+            uint64_t             fo[6], fl[6];
+            if (lx_translate_six_frames(nt.data(), nt.size(), 1, aa.data(), aa.size(), fo, fl) != LX_OK)
+                throw std::runtime_error("translation failed for " + out.ids.back());
+            for (int f = 0; f < 6; ++f)
+            {
+                out.off.push_back(out.res.size());
+                out.len.push_back(fl[f]);
+                out.res.insert(out.res.end(), aa.begin() + fo[f], aa.begin() + fo[f] + fl[f]);
+            }
+            cur.clear();
+            return;
+        }
         out.off.push_back(out.res.size());
         out.len.push_back(cur.size());
         for (char c : cur)
@@ -121,7 +140,30 @@ struct Options
     double      preScoringThresh = 2.0;
     int         idCutOff    = 0;
     int         device      = 0;
+    std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
 };
+
+// the reference lets BioC++ detect the query alphabet (src/search_options.hpp); here: nucleotide if >= 90 % of the
+// letters of the first sequences are ACGTUN
+bool looksLikeDna(std::string const & path)
+{
+    std::ifstream in(path);
+    std::string   line;
+    uint64_t      nuc = 0, all = 0;
+    while (std::getline(in, line) && all < 100000)
+    {
+        if (line.empty() || line[0] == '>')
+            continue;
+        for (char c : line)
+        {
+            if (std::isspace((unsigned char)c))
+                continue;
+            ++all;
+            nuc += std::strchr("ACGTUNacgtun", c) != nullptr;
+        }
+    }
+    return all > 0 && nuc * 10 >= all * 9;
+}
 
 Options parse(int argc, char ** argv)
 {
@@ -163,6 +205,12 @@ Options parse(int argc, char ** argv)
             o.idCutOff = std::stoi(val());
         else if (a == "--device")
             o.device = std::stoi(val());
+        else if (a == "-a" || a == "--query-alphabet")
+        {
+            o.qryAlphabet = val();
+            if (o.qryAlphabet != "auto" && o.qryAlphabet != "dna5" && o.qryAlphabet != "aminoacid")
+                throw std::runtime_error("--query-alphabet takes auto, dna5 or aminoacid");
+        }
         else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbosity" || a == "--version-to-outputfile" || a == "-p" ||
                  a == "--profile")
             (void)val(); // accepted for command-line compatibility, no effect here
@@ -182,10 +230,13 @@ int main(int argc, char ** argv)
     {
         Options const opt  = parse(argc, argv);
         bool const    prot = opt.cmd == "searchp";
-        int const     qFrames = prot ? 1 : 2;
+        // searchp with nucleotide queries is BLASTX: six translated frames per query against the protein database
+        bool const    blastx = prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
+        int const     qFrames = blastx ? 6 : prot ? 1 : 2;
+        char const *  program = blastx ? "blastx" : prot ? "blastp" : "blastn";
 
         SeqSet qs, db;
-        readFasta(opt.query, prot, !prot, qs);
+        readFasta(opt.query, prot, !prot, qs, blastx);
         readFasta(opt.db, prot, false, db);
         if (qs.ids.empty() || db.ids.empty())
             throw std::runtime_error("empty query or database file");
@@ -279,9 +330,11 @@ int main(int argc, char ** argv)
         sp.min_bitscore     = -1;
         sp.id_cutoff        = opt.idCutOff;
         sp.db_total_length  = dbTotal;
-        sp.query_translated = 0;
+        sp.query_translated = blastx ? 1 : 0;
         sp.qry_num_frames   = qFrames;
         sp.sbj_num_frames   = 1;
+        sp.q_frame_mode     = blastx ? LX_FRAMES_TRANSLATED : prot ? LX_FRAMES_NONE : LX_FRAMES_REVCOMP; // _setFrames, :768-814
+        sp.s_frame_mode     = LX_FRAMES_NONE;
         sp.karlin           = ka;
         lx_iterate_result * res = nullptr;
         eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
@@ -293,8 +346,6 @@ int main(int argc, char ** argv)
                                  lx_iterate_result_ops(res) + (nHsp ? bms.back().ops_off + bms.back().n_ops : 0));
         lx_iterate_stats const      ist = lx_iterate_result_stats(res);
         lx_iterate_result_free(res);
-        for (auto & b : bms) // frame of the query strand: +1 forward, -1 reverse complement (_setFrames, :768-814)
-            b.q_frame = prot ? 0 : ((b.qry_id % 2) ? -1 : 1);
 
         // ---- _writeRecord + writer
         lx_record_stats rst{};
@@ -314,13 +365,15 @@ int main(int argc, char ** argv)
             fmt = LX_OUT_SAM;
         else if (!ends(".m8"))
             throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
-        eng.check(lx_write_records(opt.output.c_str(), fmt, 1, prot ? "blastp" : "blastn", bms.data(), nOut, ops.data(), &names,
+        if (blastx && fmt == LX_OUT_SAM)
+            throw std::runtime_error("SAM output of translated searches is not implemented; use .m8 or .m9");
+        eng.check(lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
                                    reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data()));
 
         std::fprintf(stderr,
-                     "lambda3 %s: %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> windows %llu -> traced %llu -> "
+                     "lambda3 %s (%s): %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> windows %llu -> traced %llu -> "
                      "HSPs %llu -> written %llu (queries with hit: %llu)\n",
-                     opt.cmd.c_str(), qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, matches.size(),
+                     opt.cmd.c_str(), program, qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, matches.size(),
                      (unsigned long long)(ist.num_ext_score - ist.hits_duplicate), (unsigned long long)ist.num_ext_ali,
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
         return 0;

@@ -279,6 +279,12 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         bm.subj_id = m.subjId;
         bm.n_qid   = m.qryId / qFrames;
         bm.n_sid   = m.subjId / sFrames;
+        {
+            int32_t qf = 0, sf = 0; // _setFrames, :1223
+            lx_set_frames(params->q_frame_mode, params->s_frame_mode, m.qryId, m.subjId, &qf, &sf);
+            bm.q_frame = (int16_t)qf;
+            bm.s_frame = (int16_t)sf;
+        }
         // _expandAlign: positions relative to the infix become positions in the sequence (:1032-1035)
         bm.q_start = m.qryStart + a.q_begin;
         bm.q_end   = m.qryStart + a.q_end;

@@ -5,7 +5,7 @@
 //   myWriteHeader         src/search_output.hpp:305-461
 //   myWriteRecord         src/search_output.hpp:463-733                  (tabular via seqan::writeRecord; SAM records)
 //   blastMatchOneCigar    src/search_output.hpp:115-194                  (soft clips, no frame clips for untranslated)
-// Scope: the untranslated programs (BLASTP, BLASTN).  The number formats of the tabular columns are SeqAn2's
+// Scope: BLASTP, BLASTN in all formats; BLASTX / TBLASTN / TBLASTX in the tabular formats (nucleotide coordinates).  The number formats of the tabular columns are SeqAn2's
 // (source absent): [UPSTREAM-RECALL] pident %.2f, evalue %.1e, bitscore %.1f, 1-based inclusive positions.
 #include <algorithm>
 #include <cctype>
@@ -84,20 +84,20 @@ uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_mat
             ++hi;
         ++st.qrys_with_hit; // :826
         std::vector<lx_blast_match> rec(m + lo, m + hi);
-        // sort matches, using an inverted bitScore to have the highest score first (:832-853); subject frames are 0 here
+        // sort matches, using an inverted bitScore to have the highest score first (:832-853)
         std::stable_sort(rec.begin(), rec.end(),
                          [](lx_blast_match const & a, lx_blast_match const & b)
                          {
-                             return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame, b.bit_score) <
-                                    std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame, a.bit_score);
+                             return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame, a.s_frame, b.bit_score) <
+                                    std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame, b.s_frame, a.bit_score);
                          });
         // removes duplicates and keeping the ones with the greatest score (:856-862)
         auto const before = rec.size();
         rec.erase(std::unique(rec.begin(), rec.end(),
                               [](lx_blast_match const & a, lx_blast_match const & b)
                               {
-                                  return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame) ==
-                                         std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame);
+                                  return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame, a.s_frame) ==
+                                         std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame, b.s_frame);
                               }),
                   rec.end());
         st.hits_duplicate2 += before - rec.size();
@@ -130,11 +130,19 @@ int lx_write_records(char const * path, int format, int write_header, char const
 {
     if (!path || !names || (!m && n) || !program)
         return LX_EINVAL;
-    bool const  isN = std::strcmp(program, "blastn") == 0;
-    std::FILE * f   = std::fopen(path, write_header ? "w" : "a");
+    bool const isN    = std::strcmp(program, "blastn") == 0;
+    bool const qTrans = std::strcmp(program, "blastx") == 0 || std::strcmp(program, "tblastx") == 0;  // qIsTranslated
+    bool const sTrans = std::strcmp(program, "tblastn") == 0 || std::strcmp(program, "tblastx") == 0; // sIsTranslated
+    if (!isN && !qTrans && !sTrans && std::strcmp(program, "blastp") != 0)
+        return LX_EINVAL;
+    if ((qTrans || sTrans) && format == LX_OUT_SAM)
+        return LX_EINVAL; // the frame-clipped protein/DNA CIGARs of src/search_output.hpp:196-300 are not implemented
+    std::FILE * f = std::fopen(path, write_header ? "w" : "a");
     if (!f)
         return LX_EINVAL;
-    std::string const upper = isN ? "BLASTN" : "BLASTP";
+    std::string upper(program);
+    for (char & c : upper)
+        c = (char)std::toupper((unsigned char)c);
 
     if (format == LX_OUT_SAM)
     {
@@ -228,13 +236,36 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 // 1-based inclusive; a hit of the reverse-complemented query is reported BLAST-style on the forward query
                 // strand with descending subject coordinates
                 unsigned long long qs = b.q_start + 1, qe = b.q_end, ss = b.s_start + 1, se = b.s_end;
-                if (b.q_frame < 0)
+                // a translated side is reported in nucleotide positions of the original sequence ([UPSTREAM-RECALL]
+                // seqan blast module, _untranslatePositions): protein [a, e) of frame f covers the nucleotides
+                // [3a + |f| - 1, 3e + |f| - 1) of the strand that was read; on the minus strand the positions are mirrored
+                // and start > end
+                auto untranslate = [](uint64_t a, uint64_t e, int frame, uint64_t len, unsigned long long & first, unsigned long long & last)
+                {
+                    uint64_t const shift = (uint64_t)std::abs(frame) - 1;
+                    uint64_t const lo = 3 * a + shift, hi = 3 * e + shift;
+                    if (frame >= 0)
+                    {
+                        first = lo + 1;
+                        last  = hi;
+                    }
+                    else
+                    {
+                        first = len - lo;
+                        last  = len - hi + 1;
+                    }
+                };
+                if (qTrans)
+                    untranslate(b.q_start, b.q_end, b.q_frame, names->q_lens[b.n_qid], qs, qe);
+                else if (b.q_frame < 0)
                 {
                     unsigned long long const ql = names->q_lens[b.n_qid];
                     qs = ql - b.q_end + 1;
                     qe = ql - b.q_start;
                     std::swap(ss, se);
                 }
+                if (sTrans)
+                    untranslate(b.s_start, b.s_end, b.s_frame, names->s_lens[b.n_sid], ss, se);
                 std::fprintf(f, "%s\t%s\t%.2f\t%d\t%d\t%d\t%llu\t%llu\t%llu\t%llu\t%.1e\t%.1f\n",
                              firstWord(names->q_ids[b.n_qid]).c_str(), firstWord(names->s_ids[b.n_sid]).c_str(),
                              (double)b.identity, b.alignment_length, b.num_mismatches, b.num_gap_opens, qs, qe, ss, se,

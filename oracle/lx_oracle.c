@@ -567,3 +567,101 @@ int lxo_alignment_stats(uint8_t const * q, uint8_t const * s, lxo_hsp const * hs
     }
     return 0;
 }
+
+
+/* ---- frames and translation ------------------------------------------------------------------------- */
+
+/* _setFrames, /root/reference/src/search_algo.hpp:768-814 */
+int32_t lxo_frame_of(int mode, uint64_t id, int is_subject)
+{
+    if (mode == 2) /* qIsTranslated / sIsTranslated, :772-776, :795-799 */
+    {
+        int32_t f = (int32_t)(id % 3) + 1;
+        if (id % 6 > 2)
+            f = -f;
+        return f;
+    }
+    if (mode == 3) /* DNA3BS, :778-782, :801-803 */
+    {
+        int32_t f = (int32_t)(id % 2) + 1;
+        if (!is_subject && id % 4 > 1)
+            f = -f;
+        return f;
+    }
+    if (mode == 1) /* qHasRevComp / sHasRevComp, :784-788, :805-809 */
+        return (id % 2) ? -1 : 1;
+    return 0;
+}
+
+/* _untrueQryId / _untrueSubjId, src/search_algo.hpp:940-996 */
+uint64_t lxo_untrue_id(int mode, uint64_t n_id, int32_t frame, int is_subject)
+{
+    if (mode == 2)
+        return frame > 0 ? n_id * 6 + (uint64_t)frame - 1 : n_id * 6 + (uint64_t)(-frame) + 2;
+    if (mode == 3 && !is_subject)
+        return frame > 0 ? n_id * 4 : n_id * 4 + 2;
+    if (mode == 1 || mode == 3)
+        return frame > 0 ? n_id * 2 : n_id * 2 + 1;
+    return n_id;
+}
+
+/* The canonical genetic code spelled out codon by codon in A, C, G, T order (index 16 a + 4 b + c); independent of
+ * the T, C, A, G string the product uses. */
+static char const lxo_codons[64] = {
+    /* AAA */ 'K', 'N', 'K', 'N', /* ACA */ 'T', 'T', 'T', 'T', /* AGA */ 'R', 'S', 'R', 'S', /* ATA */ 'I', 'I', 'M', 'I',
+    /* CAA */ 'Q', 'H', 'Q', 'H', /* CCA */ 'P', 'P', 'P', 'P', /* CGA */ 'R', 'R', 'R', 'R', /* CTA */ 'L', 'L', 'L', 'L',
+    /* GAA */ 'E', 'D', 'E', 'D', /* GCA */ 'A', 'A', 'A', 'A', /* GGA */ 'G', 'G', 'G', 'G', /* GTA */ 'V', 'V', 'V', 'V',
+    /* TAA */ '*', 'Y', '*', 'Y', /* TCA */ 'S', 'S', 'S', 'S', /* TGA */ '*', 'C', 'W', 'C', /* TTA */ 'L', 'F', 'L', 'F'};
+
+static uint8_t lxo_aa_rank(char c)
+{
+    static char const order[] = "ABCDEFGHIJKLMNOPQRSTUVWYZX*"; /* SeqAn AminoAcid order, src/seqan2_to_biocpp.hpp:352-366 */
+    uint8_t r = 0;
+    while (order[r] != c)
+        ++r;
+    return r;
+}
+
+/* one codon in A,C,G,T indices 0..3, 4 = N: the amino acid every completion agrees on, else X */
+static uint8_t lxo_translate_codon(int a, int b, int c)
+{
+    int  first = -1;
+    for (int x = 0; x < 4; ++x)
+        for (int y = 0; y < 4; ++y)
+            for (int z = 0; z < 4; ++z)
+            {
+                if ((a != 4 && a != x) || (b != 4 && b != y) || (c != 4 && c != z))
+                    continue;
+                int const aa = lxo_codons[16 * x + 4 * y + z];
+                if (first < 0)
+                    first = aa;
+                else if (first != aa)
+                    return lxo_aa_rank('X');
+            }
+    return lxo_aa_rank((char)first);
+}
+
+uint64_t lxo_translate_frame(uint8_t const * dna5, uint64_t n, int frame, uint8_t * out)
+{
+    /* BioC++ dna5 rank A,C,G,N,T -> A,C,G,T index with N = 4 */
+    static int const acgt[5] = {0, 1, 2, 4, 3};
+    int const      shift = (frame > 0 ? frame : -frame) - 1;
+    uint64_t const len   = n >= (uint64_t)shift ? (n - (uint64_t)shift) / 3 : 0;
+    for (uint64_t k = 0; k < len; ++k)
+    {
+        int b[3];
+        for (int t = 0; t < 3; ++t)
+        {
+            uint64_t const p = (uint64_t)shift + 3 * k + (uint64_t)t; /* position on the strand that is read */
+            if (frame > 0)
+                b[t] = acgt[dna5[p]];
+            else
+            {
+                int const x = acgt[dna5[n - 1 - p]]; /* reverse strand: complement of the mirrored position */
+                b[t]        = x == 4 ? 4 : 3 - x;    /* A<->T, C<->G in A,C,G,T indices */
+            }
+        }
+        out[k] = lxo_translate_codon(b[0], b[1], b[2]);
+    }
+    return len;
+}

@@ -107,6 +107,14 @@ double   lxo_bitscore(int32_t score, lxo_karlin const * ka);
 int lxo_alignment_stats(uint8_t const * q, uint8_t const * s, lxo_hsp const * hsp, uint8_t const * ops,
                         lxo_scoring const * sc, int32_t bisulfite_match_rule, lxo_align_stats * out);
 
+/* ---- frames and six-frame translation (src/search_algo.hpp:768-814, :940-996; src/shared_definitions.hpp:246-281;
+ *      the translation itself is BioC++'s translate_join, [UPSTREAM-RECALL] for its treatment of N) ----
+ * modes: 0 none, 1 reverse complement, 2 translated, 3 bisulfite */
+int32_t  lxo_frame_of(int mode, uint64_t id, int is_subject);
+uint64_t lxo_untrue_id(int mode, uint64_t n_id, int32_t frame, int is_subject);
+/* dna5 = BioC++ ranks A,C,G,N,T; frame in {+1,+2,+3,-1,-2,-3}; out = SeqAn AminoAcid ranks; returns the length */
+uint64_t lxo_translate_frame(uint8_t const * dna5, uint64_t n, int frame, uint8_t * out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,12 @@ class Oracle:
         lib.lxo_bitscore.argtypes = [i32, C.POINTER(Karlin)]
         lib.lxo_bitscore.restype = C.c_double
         lib.lxo_alignment_stats.argtypes = [vp, vp, C.POINTER(Hsp), vp, C.POINTER(Scoring), i32, C.POINTER(AlignStats)]
+        lib.lxo_frame_of.argtypes = [C.c_int, u64, C.c_int]
+        lib.lxo_frame_of.restype = i32
+        lib.lxo_untrue_id.argtypes = [C.c_int, u64, i32, C.c_int]
+        lib.lxo_untrue_id.restype = u64
+        lib.lxo_translate_frame.argtypes = [vp, u64, C.c_int, vp]
+        lib.lxo_translate_frame.restype = u64
 
     @staticmethod
     def _p(a):
@@ -163,6 +169,19 @@ class Oracle:
         rc = self.lib.lxo_alignment_stats(self._p(q), self._p(s), C.byref(hsp), self._p(o), C.byref(sc), bs_rule, C.byref(st))
         assert rc == 0, rc
         return st
+
+
+    def frame_of(self, mode: int, ident: int, is_subject: bool) -> int:
+        return int(self.lib.lxo_frame_of(mode, ident, 1 if is_subject else 0))
+
+    def untrue_id(self, mode: int, n_id: int, frame: int, is_subject: bool) -> int:
+        return int(self.lib.lxo_untrue_id(mode, n_id, frame, 1 if is_subject else 0))
+
+    def translate_frame(self, dna5: np.ndarray, frame: int) -> np.ndarray:
+        d = np.ascontiguousarray(dna5, dtype=np.uint8)
+        out = np.zeros(d.size // 3 + 1, dtype=np.uint8)
+        n = int(self.lib.lxo_translate_frame(self._p(d), d.size, frame, self._p(out)))
+        return out[:n]
 
 
 _oracle = None

@@ -148,3 +148,75 @@ def test_searchn_both_strands(tmp_path):
             if (ss > se) == minus and abs(min(ss, se) - 1 - a) <= 10:
                 ok += 1
     assert ok >= 57, ok
+
+
+CODONS = {"A": ["GCT", "GCC", "GCA", "GCG"], "C": ["TGT", "TGC"], "D": ["GAT", "GAC"], "E": ["GAA", "GAG"], "F": ["TTT", "TTC"],
+          "G": ["GGT", "GGC", "GGA", "GGG"], "H": ["CAT", "CAC"], "I": ["ATT", "ATC", "ATA"], "K": ["AAA", "AAG"],
+          "L": ["TTA", "TTG", "CTT", "CTC", "CTA", "CTG"], "M": ["ATG"], "N": ["AAT", "AAC"], "P": ["CCT", "CCC", "CCA", "CCG"],
+          "Q": ["CAA", "CAG"], "R": ["CGT", "CGC", "CGA", "CGG", "AGA", "AGG"], "S": ["TCT", "TCC", "TCA", "TCG", "AGT", "AGC"],
+          "T": ["ACT", "ACC", "ACA", "ACG"], "V": ["GTT", "GTC", "GTA", "GTG"], "W": ["TGG"], "Y": ["TAT", "TAC"]}
+
+
+@pytest.mark.gpu
+def test_searchp_blastx_frames_and_coordinates(tmp_path):
+    """searchp with nucleotide queries = BLASTX: reads that encode a database protein
+    segment in a known frame / strand must come back with that subject, 100 % identity, the frame's nucleotide
+    coordinates (start > end on the minus strand) and the protein coordinates of the segment."""
+    rng = np.random.default_rng(11)
+    db = ["".join(STD[i] for i in rng.integers(0, 20, int(L))) for L in rng.integers(120, 400, 300)]
+    comp = str.maketrans("ACGT", "TGCA")
+    reads, truth = [], []
+    for k in range(48):
+        j = int(rng.integers(0, len(db)))
+        a = int(rng.integers(0, len(db[j]) - 60))
+        seg = db[j][a:a + 50]
+        nt = "".join(CODONS[c][int(rng.integers(0, len(CODONS[c])))] for c in seg)
+        left = int(rng.integers(0, 3)) + 3 * int(rng.integers(0, 3))   # frame shift 0..2 (+ whole codons of noise)
+        right = int(rng.integers(0, 9))
+        # the flanks end in a stop codon next to the segment, so that the alignment cannot run on into them
+        lf = "".join("ACGT"[i] for i in rng.integers(0, 4, left))
+        lf = (lf[:-3] + "TAA") if left >= 3 else lf
+        rt = "TAA" + "".join("ACGT"[i] for i in rng.integers(0, 4, right))
+        read = lf + nt + rt
+        minus = k % 2 == 1
+        L = len(read)
+        if minus:
+            qstart, qend = L - left, L - left - 150 + 1      # as reported on the original (reverse-complemented) read
+            read = read.translate(comp)[::-1]
+        else:
+            qstart, qend = left + 1, left + 150
+        reads.append(read)
+        truth.append((j, a, qstart, qend))
+    _fasta(tmp_path / "db.fasta", [f"sp{j}" for j in range(len(db))], db)
+    _fasta(tmp_path / "r.fasta", [f"read{k}" for k in range(len(reads))], reads)
+    out = tmp_path / "o.m8"
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "db.fasta"), "-o", str(out),
+                        "--seed-offset", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "blastx" in r.stderr
+    best = {}
+    for l in out.read_text().splitlines():
+        x = l.split("\t")
+        best.setdefault(x[0], x)
+    assert len(best) == len(reads)
+    exact = 0
+    for k, (j, a, qstart, qend) in enumerate(truth):
+        x = best[f"read{k}"]
+        assert x[1] == f"sp{j}" and float(x[2]) >= 90.0, x
+        qs_, qe_, ss_, se_ = int(x[6]), int(x[7]), int(x[8]), int(x[9])
+        if int(x[3]) == 50 and float(x[2]) == 100.0:
+            exact += 1
+            assert (qs_, qe_) == (qstart, qend), (x, qstart, qend)
+            assert (ss_, se_) == (a + 1, a + 50), x
+        else:
+            # a strong residue behind the stop codon can pull the local alignment a few columns further: same frame
+            # and strand, planted interval contained
+            assert (qs_ < qe_) == (qstart < qend) and (qs_ - qstart) % 3 == 0 and (qe_ - qend) % 3 == 0, (x, qstart, qend)
+            assert min(qs_, qe_) <= min(qstart, qend) and max(qs_, qe_) >= max(qstart, qend)
+            assert abs(qs_ - qstart) <= 12 and abs(qe_ - qend) <= 12 and ss_ <= a + 1 and se_ >= a + 50
+        assert abs(qe_ - qs_) + 1 == 3 * (int(x[3]) - int(x[5]) * 0) or int(x[5]) > 0  # ungapped: 3 nt per column
+    assert exact >= 0.7 * len(truth), exact
+    # SAM is refused for translated searches rather than written wrong
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "db.fasta"), "-o",
+                        str(tmp_path / "o.sam")], capture_output=True, text=True)
+    assert r.returncode != 0 and "not implemented" in r.stderr

@@ -163,7 +163,7 @@ def test_iterate_matches_driver(handle, oracle, filters):
     rng = np.random.default_rng(2024)
     q, qoff, qlen, s, soff, slen, m = _driver_case(rng)
     db_total = int(slen.sum())
-    params = capi.SearchParams(max_e, min_bits, idcut, db_total, 0, 1, 1, 0, ka)
+    params = capi.SearchParams(max_e, min_bits, idcut, db_total, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
     bms, ops, stats = handle.iterate_matches(q, qoff, qlen, qlen, s, soff, slen, m, params)
     want, wstats = oracle_driver.iterate_matches(oracle, osc, oka, q, qoff, qlen, qlen, s, soff, slen,
                                                  m.astype(oracle_lib.MATCH_DTYPE), max_e, min_bits, idcut, db_total)
@@ -268,7 +268,7 @@ def test_iterate_matches_bisulfite(handle, oracle):
         s[int(soff[b]) + ss_ - lo: int(soff[b]) + ss_ - lo + 100 - (qs_ - lo)] = ref[qs_ - lo:]
         m[i] = (a, b, qs_, qs_ + 17, ss_, ss_ + 17)
     db_total = int(slen.sum())
-    params = capi.SearchParams(1e-9, -1, 0, db_total, 0, 4, 2, 1, ka)
+    params = capi.SearchParams(1e-9, -1, 0, db_total, 0, 4, 2, 1, capi.LX_FRAMES_BISULFITE, capi.LX_FRAMES_BISULFITE, ka)
     try:
         bms, ops, stats = handle.iterate_matches(q, qoff, qlen, np.full(nq // 4, 100, np.uint64), s, soff, slen, m, params)
     finally:
@@ -288,3 +288,6 @@ def test_iterate_matches_bisulfite(handle, oracle):
                   "num_matches", "num_mismatches", "num_gap_opens", "num_gap_extensions"):
             assert int(g[k]) == w[k], (k, g, w)
         assert o == w["ops"]
+        # _setFrames in bisulfite mode (src/search_algo.hpp:778-782, :801-803)
+        qid, sid = int(g["qry_id"]), int(g["subj_id"])
+        assert int(g["q_frame"]) == (qid % 2 + 1) * (-1 if qid % 4 > 1 else 1) and int(g["s_frame"]) == sid % 2 + 1
