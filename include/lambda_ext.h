@@ -152,8 +152,12 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
  * extension i a slot of q_len+s_len bytes at out_ops + ops_off[i]; its out_hsp[i].n_ops bytes are written at the END
  * of that slot, i.e. they start at out_ops + ops_off[i] + out_hsp[i].ops_shift. */
 int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
-                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, lx_hsp * out_hsp, uint8_t * out_ops,
-                   uint64_t const * ops_off);
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t const * known_score, lx_hsp * out_hsp,
+                   uint8_t * out_ops, uint64_t const * ops_off);
+/* known_score: NULL, or the pass-1 score of every extension (the reference runs pass 2 on survivors of pass 1, so the
+ * caller has them): pass 2 locates the end cell through the best score and computes it itself when not given.  A wrong
+ * score is detected (LX_EOVERFLOW), never turned into a wrong alignment.  Extensions of one query should be adjacent
+ * (lambda's lists are): runs of the same query slice then share one LDS profile. */
 
 int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
                        uint64_t n, void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * stream);

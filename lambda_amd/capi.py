@@ -135,7 +135,7 @@ def load():
     lib.lx_last_trace_kernel_name.argtypes = [vp]
     lib.lx_last_trace_kernel_name.restype = C.c_char_p
     lib.lx_last_phase_ms.argtypes = [vp, i32, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    for name, args in (("lx_align_batch", [vp, i32, vp, u64, vp, u64, vp, u64, vp, vp, vp]),
+    for name, args in (("lx_align_batch", [vp, i32, vp, u64, vp, u64, vp, u64, vp, vp, vp, vp]),
                        ("lx_align_batch_dev", [vp, i32, vp, vp, vp, u64, vp, vp, vp, vp]),
                        ("lx_prefilter_batch", [vp, i32, vp, u64, vp, u64, vp, u64, C.c_uint32, C.c_int32, C.c_double, vp])):
         if hasattr(lib, name):
@@ -309,7 +309,10 @@ class Handle:
                                             len(ext), _ptr(out)))
         return out
 
-    def align_batch(self, q_res: np.ndarray, s_res: np.ndarray, ext: np.ndarray, slot: int = 0):
+    def align_batch(self, q_res: np.ndarray, s_res: np.ndarray, ext: np.ndarray, slot: int = 0, known_score=None,
+                    raw: bool = False):
+        """lx_align_batch; known_score = the pass-1 scores of `ext` if the caller has them (saves the score pre-pass).
+        raw=True returns (hsp, ops buffer, ops_off) without building the per-extension bytes objects."""
         q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
         s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
         ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
@@ -319,8 +322,11 @@ class Handle:
         np.cumsum(sizes, out=ops_off[1:])
         hsp = np.zeros(n, dtype=HSP_DTYPE)
         ops = np.zeros(int(ops_off[-1]) + 1, dtype=np.uint8)
+        ks = None if known_score is None else np.ascontiguousarray(known_score, dtype=np.int32)
         self._check(self.lib.lx_align_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext), n,
-                                            _ptr(hsp), _ptr(ops), _ptr(ops_off)))
+                                            None if ks is None else _ptr(ks), _ptr(hsp), _ptr(ops), _ptr(ops_off)))
+        if raw:
+            return hsp, ops, ops_off
         st = ops_off[:n].astype(np.int64) + hsp["ops_shift"].astype(np.int64)
         ops_list = [bytes(ops[int(st[i]):int(st[i]) + int(hsp["n_ops"][i])]) for i in range(n)]
         return hsp, ops_list

@@ -53,7 +53,7 @@ public:
         }
         ops.assign(total + 1, 0);
         hsp.assign(ext.size(), lx_hsp{});
-        check(lx_align_batch(h_, slot, q, qBytes, s, sBytes, ext.data(), ext.size(), hsp.data(), ops.data(), opsOff.data()));
+        check(lx_align_batch(h_, slot, q, qBytes, s, sBytes, ext.data(), ext.size(), nullptr, hsp.data(), ops.data(), opsOff.data()));
     }
 
 private:

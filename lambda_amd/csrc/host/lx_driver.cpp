@@ -244,22 +244,33 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         return LX_OK;
     res->stats.num_ext_ali += surv.size(); // :1287
 
-    // Run extensions WITH ALIGNMENT (:1293-1296)
+    // Run extensions WITH ALIGNMENT (:1293-1296).  The GPU wants the windows of one query next to each other (one LDS
+    // profile per query), so the call goes out in match order -- the span is sorted by query since widen/merge -- and
+    // the results are put back into the survivor order, which is the one the reference's later stable sort sees.
+    std::vector<uint32_t> byMatch(surv.size());
+    std::iota(byMatch.begin(), byMatch.end(), 0u);
+    std::sort(byMatch.begin(), byMatch.end(), [&](uint32_t a, uint32_t b) { return surv[a].idx < surv[b].idx; });
     std::vector<lx_extension> sExt(surv.size());
-    for (size_t k = 0; k < surv.size(); ++k)
-        sExt[k] = ext[surv[k].idx];
-    std::vector<lx_hsp>   hsp(surv.size());
-    std::vector<uint64_t> opsOff(surv.size());
-    uint64_t              total = 0;
+    std::vector<int32_t>      sScore(surv.size());
+    std::vector<uint64_t>     opsOff(surv.size()), opsOffCall(surv.size());
+    uint64_t                  total = 0;
     for (size_t k = 0; k < surv.size(); ++k)
     {
-        opsOff[k] = total;
+        Survivor const & sv = surv[byMatch[k]];
+        sExt[k]             = ext[sv.idx];
+        sScore[k]           = sv.score;
+        opsOffCall[k]       = total;
+        opsOff[byMatch[k]]  = total;
         total += (uint64_t)sExt[k].q_len + sExt[k].s_len;
     }
+    std::vector<lx_hsp>  hspCall(surv.size()), hsp(surv.size());
     std::vector<uint8_t> ops(total + 1, 0);
-    rc = lx_align_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sExt.data(), sExt.size(), hsp.data(), ops.data(), opsOff.data());
+    rc = lx_align_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sExt.data(), sExt.size(), sScore.data(), hspCall.data(), ops.data(),
+                        opsOffCall.data());
     if (rc != LX_OK)
         return rc;
+    for (size_t k = 0; k < surv.size(); ++k)
+        hsp[byMatch[k]] = hspCall[k];
 
     // sort by query (:1299), stable
     std::vector<uint32_t> sOrder(surv.size());

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,35 @@ hipEvent_t pool_event(lx_handle * h)
     }
     return h->ev_pool[h->ev_pool_used++];
 }
+
+// Wall-clock marks of the host-buffer entry points, printed when LX_HOST_TIMING is set (development aid).
+struct HostMarks
+{
+    bool                                                               on;
+    char const *                                                       what;
+    std::chrono::steady_clock::time_point                              t0, last;
+    std::string                                                        line;
+    explicit HostMarks(char const * w) : on(std::getenv("LX_HOST_TIMING") != nullptr), what(w)
+    {
+        t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(char const * name)
+    {
+        if (!on)
+            return;
+        auto const now = std::chrono::steady_clock::now();
+        char       buf[96];
+        snprintf(buf, sizeof(buf), " %s %.1f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~HostMarks()
+    {
+        if (on)
+            fprintf(stderr, "[lx host ms] %s:%s | total %.1f\n", what, line.c_str(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // RAII-less phase bracket: records a start event now, the end event on close()
 struct PhaseTimer
@@ -623,13 +653,26 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     if (rc)
         return rc;
 
+    HostMarks hm("lx_score_batch");
     // ---- validate; order by (q_len, q_off, s_len): extensions of one query become adjacent (one LDS profile per
     // wavefront), similar lengths become adjacent (lanes of a wavefront run in lockstep; the reference sorts its
     // SIMD batches for the same reason, src/search_algo.hpp:1229-1235)
     if (n > 0xfffffff0ull)
         return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    auto before = [&](uint32_t a, uint32_t b)
+    {
+        lx_extension const &x = ext[a], &y = ext[b];
+        if (x.q_len != y.q_len)
+            return x.q_len < y.q_len;
+        if (x.q_off != y.q_off)
+            return x.q_off < y.q_off;
+        if (x.s_len != y.s_len)
+            return x.s_len < y.s_len;
+        return a < b;
+    };
     std::vector<uint32_t> idx;
     idx.reserve(n);
+    bool ordered = true; // lambda hands its matches over sorted by query: then the sort is skipped
     for (uint64_t i = 0; i < n; ++i)
     {
         lx_extension const & x = ext[i];
@@ -640,35 +683,30 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             out_score[i] = 0;
             continue;
         }
+        if (ordered && !idx.empty() && before((uint32_t)i, idx.back()))
+            ordered = false;
         idx.push_back((uint32_t)i);
     }
-    std::sort(idx.begin(), idx.end(),
-              [&](uint32_t a, uint32_t b)
-              {
-                  lx_extension const &x = ext[a], &y = ext[b];
-                  if (x.q_len != y.q_len)
-                      return x.q_len < y.q_len;
-                  if (x.q_off != y.q_off)
-                      return x.q_off < y.q_off;
-                  if (x.s_len != y.s_len)
-                      return x.s_len < y.s_len;
-                  return a < b;
-              });
+    if (!ordered)
+        std::sort(idx.begin(), idx.end(), before);
+    hm.mark("validate+sort");
 
     // ---- bin query runs by kernel geometry.  A run whose padding to a whole number of wavefront slots wastes
     // <= 25 % goes to a "shared profile" launch (8-lane geometries allowed), the rest to per-extension profiles.
-    int const ncfg = lx::score_cfg_count();
-    struct Bin
+    // bin index: kind 0 = per-extension profiles, 1 = one profile per wavefront (int32): cfg * 2 + kind;
+    // kind 2 = packed half (16 extensions of one query per wavefront): ncfg * 2 + pair geometry
+    int const    ncfg  = lx::score_cfg_count();
+    size_t const nbins = (size_t)ncfg * 2 + 8;
+    struct Run
     {
-        std::vector<lx_extension> ext;
-        std::vector<uint32_t>     perm;
-        uint32_t                  max_qlen = 0;
+        uint64_t first, count, pad; // positions in idx, padded slot count
+        uint32_t bin;
     };
-    // bins[kind][cfg]: kind 0 = per-extension profiles, 1 = one profile per wavefront (int32), 2 = packed half
-    // (16 extensions of one query per wavefront; index = pair geometry)
-    std::vector<Bin> bins((size_t)ncfg * 2 + 8);
-    auto             bin_of = [&](int kind, int cfg) -> Bin & { return kind == 2 ? bins[(size_t)ncfg * 2 + cfg] : bins[(size_t)cfg * 2 + kind]; };
-    uint64_t         carry_pairs = 0;
+    std::vector<Run>      runs;
+    std::vector<uint64_t> bin_slots(nbins, 0);
+    std::vector<uint32_t> bin_maxq(nbins, 0);
+    uint64_t              carry_pairs = 0;
+    runs.reserve(idx.size() / 8 + 16);
     for (size_t k = 0; k < idx.size();)
     {
         size_t k1 = k + 1;
@@ -702,31 +740,18 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
                     pad = run;
             }
         }
-        Bin & bin    = bin_of(kind, cfg);
-        bin.max_qlen = std::max(bin.max_qlen, qlen);
-        for (size_t j = k; j < k1; ++j)
-        {
-            bin.ext.push_back(ext[idx[j]]);
-            bin.perm.push_back(idx[j]);
-            if (kind != 2 && (int)qlen > lx::score_cfg_panel(cfg))
+        uint32_t const bin = kind == 2 ? (uint32_t)(ncfg * 2 + cfg) : (uint32_t)(cfg * 2 + kind);
+        runs.push_back(Run{k, run, pad, bin});
+        bin_slots[bin] += pad;
+        bin_maxq[bin] = std::max(bin_maxq[bin], qlen);
+        if (kind != 2 && (int)qlen > lx::score_cfg_panel(cfg))
+            for (size_t j = k; j < k1; ++j)
                 carry_pairs += ext[idx[j]].s_len;
-        }
-        for (uint64_t j = run; j < pad; ++j) // dummy slots keep one query per wavefront
-        {
-            lx_extension dummy = ext[idx[k]];
-            dummy.s_len        = 0;
-            bin.ext.push_back(dummy);
-            bin.perm.push_back(0xffffffffu);
-        }
         k = k1;
     }
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
         h->opt_ws_bytes = carry_pairs * 8 + 4096;
 
-    std::vector<lx_extension> sorted;
-    std::vector<uint32_t>     perm;
-    sorted.reserve(n + 64);
-    perm.reserve(n + 64);
     struct Seg
     {
         int      cfg;
@@ -734,31 +759,48 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         bool     multi, shared;
         int      pair_cfg;
     };
-    std::vector<Seg> segs;
-    for (int cfg = 0; cfg < ncfg; ++cfg)
-        for (int sh = 0; sh < 2; ++sh)
-        {
-            Bin & bin = bin_of(sh, cfg);
-            if (bin.ext.empty())
-                continue;
-            segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), bin.max_qlen > (uint32_t)lx::score_cfg_panel(cfg), sh == 1, -1});
-            sorted.insert(sorted.end(), bin.ext.begin(), bin.ext.end());
-            perm.insert(perm.end(), bin.perm.begin(), bin.perm.end());
-        }
-    for (int pcfg = 0; pcfg < 8; ++pcfg)
+    std::vector<Seg>      segs;
+    std::vector<uint64_t> bin_cursor(nbins, 0);
+    uint64_t              total_slots = 0;
+    for (size_t b = 0; b < nbins; ++b)
     {
-        Bin & bin = bin_of(2, pcfg);
-        if (bin.ext.empty())
+        if (!bin_slots[b])
             continue;
-        // the int32 fix-up launch over the same list uses the shared-profile geometry of the longest query
-        int const cfg = pick_cfg(bin.max_qlen, true);
-        segs.push_back(Seg{cfg, sorted.size(), bin.ext.size(), false, true, pcfg});
-        sorted.insert(sorted.end(), bin.ext.begin(), bin.ext.end());
-        perm.insert(perm.end(), bin.perm.begin(), bin.perm.end());
+        bin_cursor[b] = total_slots;
+        if (b < (size_t)ncfg * 2)
+        {
+            int const cfg = (int)(b / 2);
+            segs.push_back(Seg{cfg, total_slots, bin_slots[b], bin_maxq[b] > (uint32_t)lx::score_cfg_panel(cfg), (b & 1) == 1, -1});
+        }
+        else // the int32 fix-up launch over the same list uses the shared-profile geometry of the longest query
+            segs.push_back(Seg{pick_cfg(bin_maxq[b], true), total_slots, bin_slots[b], false, true, (int)(b - (size_t)ncfg * 2)});
+        total_slots += bin_slots[b];
+    }
+    // every slot is written exactly once: straight into the upload buffer, no per-bin copies
+    std::vector<lx_extension> sorted(total_slots);
+    std::vector<uint32_t>     perm(total_slots);
+    for (Run const & r : runs)
+    {
+        uint64_t o = bin_cursor[r.bin];
+        for (uint64_t j = 0; j < r.count; ++j, ++o)
+        {
+            uint32_t const src = idx[r.first + j];
+            sorted[o]          = ext[src];
+            perm[o]            = src;
+        }
+        lx_extension dummy = ext[idx[r.first]]; // dummy slots keep one query per wavefront
+        dummy.s_len        = 0;
+        for (uint64_t j = r.count; j < r.pad; ++j, ++o)
+        {
+            sorted[o] = dummy;
+            perm[o]   = 0xffffffffu;
+        }
+        bin_cursor[r.bin] = o;
     }
     if (sorted.empty())
         return LX_OK;
 
+    hm.mark("bin");
     // ---- upload
     if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
         (rc = ensure(h, h->d_ext, sorted.size() * sizeof(lx_extension))) ||
@@ -773,6 +815,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, sorted.data(), sorted.size() * sizeof(lx_extension), hipMemcpyHostToDevice,
                              h->stream));
 
+    hm.mark("upload-issue");
     // ---- launch
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
     for (Seg const & seg : segs)
@@ -790,11 +833,14 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     // ---- download + unpermute
     std::vector<int32_t> res(sorted.size());
     LX_HIP(h, hipMemcpyAsync(res.data(), h->d_out.ptr, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    hm.mark("launch");
     if ((rc = check_async_error(h)))
         return rc;
+    hm.mark("wait");
     for (size_t k = 0; k < res.size(); ++k)
         if (perm[k] != 0xffffffffu)
             out_score[perm[k]] = res[k];
+    hm.mark("unpermute");
     return LX_OK;
 }
 
@@ -957,8 +1003,8 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
 }
 
 int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
-                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, lx_hsp * out_hsp, uint8_t * out_ops,
-                   uint64_t const * ops_off)
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t const * known_score, lx_hsp * out_hsp,
+                   uint8_t * out_ops, uint64_t const * ops_off)
 {
     if (!h)
         return LX_EINVAL;
@@ -968,10 +1014,15 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return LX_OK;
     if (!ext || !out_hsp || !out_ops || !ops_off || (!q_res && q_bytes) || (!s_res && s_bytes))
         return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull)
+        return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
     int rc = bind(h);
     if (rc)
         return rc;
-    uint64_t max_q = 1, max_s = 1, ops_bytes = 0, carry_pairs = 0;
+    HostMarks hm("lx_align_batch");
+    // ---- validate; find the runs of consecutive extensions that share their query slice (lambda's lists are grouped by
+    // query).  If padding every run to a multiple of 4 slots costs <= 25 %, pass 2 runs the shared-profile geometries.
+    uint64_t max_q = 1, max_s = 1, ops_bytes = 0, carry_pairs = 0, padded = 0, run = 0;
     for (uint64_t i = 0; i < n; ++i)
     {
         lx_extension const & x = ext[i];
@@ -982,38 +1033,101 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         ops_bytes = std::max<uint64_t>(ops_bytes, ops_off[i] + x.q_len + x.s_len);
         if ((int)x.q_len > lx::trace_cfg_panel(0))
             carry_pairs += x.s_len;
+        if (i > 0 && (x.q_off != ext[i - 1].q_off || x.q_len != ext[i - 1].q_len))
+        {
+            padded += (run + 3) / 4 * 4;
+            run = 0;
+        }
+        ++run;
     }
+    padded += (run + 3) / 4 * 4;
+    bool const share = max_q <= (uint64_t)lx::trace_cfg_panel(2) && (padded - n) * 4 <= padded && padded <= 0xfffffff0ull;
+    uint64_t const slots = share ? padded : n;
+
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
         h->opt_ws_bytes = carry_pairs * 8 + 4096;
     if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
-        (rc = ensure(h, h->d_ext, n * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
+        (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
         (rc = ensure(h, h->d_ops, ops_bytes + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
+        return rc;
+    if ((share && (rc = ensure(h, h->d_sel_src, slots * sizeof(uint32_t)))) ||
+        (known_score && (rc = ensure(h, h->d_sel_score, slots * sizeof(int32_t)))))
         return rc;
     if ((rc = prepare_workspace(h, h->stream)))
         return rc;
+    hm.mark("validate+alloc");
+
+    // ---- slot list: the extensions in input order, every run followed by its padding slots (empty window, src = none)
+    std::vector<lx_extension> slot_ext;
+    std::vector<uint32_t>     slot_src;
+    std::vector<int32_t>      slot_score;
+    if (share)
+    {
+        slot_ext.reserve(slots);
+        slot_src.reserve(slots);
+        if (known_score)
+            slot_score.reserve(slots);
+        for (uint64_t i = 0; i < n;)
+        {
+            uint64_t i1 = i + 1;
+            while (i1 < n && ext[i1].q_off == ext[i].q_off && ext[i1].q_len == ext[i].q_len)
+                ++i1;
+            for (uint64_t j = i; j < i1; ++j)
+            {
+                slot_ext.push_back(ext[j]);
+                slot_src.push_back((uint32_t)j);
+                if (known_score)
+                    slot_score.push_back(known_score[j]);
+            }
+            lx_extension dummy = ext[i];
+            dummy.s_len        = 0;
+            for (uint64_t j = i1 - i; j % 4 != 0; ++j)
+            {
+                slot_ext.push_back(dummy);
+                slot_src.push_back(0xffffffffu);
+                if (known_score)
+                    slot_score.push_back(0);
+            }
+            i = i1;
+        }
+    }
+    hm.mark("slots");
+
     if (q_bytes)
         LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
     if (s_bytes)
         LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
-    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, ext, n * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, share ? slot_ext.data() : ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, ops_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    if (share)
+        LX_HIP(h, hipMemcpyAsync(h->d_sel_src.ptr, slot_src.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if (known_score)
+        LX_HIP(h, hipMemcpyAsync(h->d_sel_score.ptr, share ? slot_score.data() : known_score, slots * sizeof(int32_t),
+                                 hipMemcpyHostToDevice, h->stream));
+    hm.mark("upload-issue");
     h->phase_ev.clear();
     h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
-    rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
+    rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), slots,
                         static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
-                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, 0);
+                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, share ? 4 : 0,
+                        share ? static_cast<uint32_t const *>(h->d_sel_src.ptr) : nullptr, nullptr,
+                        known_score ? static_cast<int32_t const *>(h->d_sel_score.ptr) : nullptr);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
+    hm.mark("launch");
     LX_HIP(h, hipMemcpyAsync(out_hsp, h->d_hsp.ptr, n * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
     LX_HIP(h, hipMemcpyAsync(out_ops, h->d_ops.ptr, ops_bytes, hipMemcpyDeviceToHost, h->stream));
+    hm.mark("download-issue");
     if ((rc = check_async_error(h)))
         return rc;
+    hm.mark("wait");
     for (uint64_t i = 0; i < n; ++i)
         if (out_hsp[i].score < 0)
-            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced (workspace exhausted)", (unsigned long long)i);
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced (workspace exhausted, or known_score is not its score)",
+                        (unsigned long long)i);
     return LX_OK;
 }
 

@@ -84,6 +84,32 @@ def test_align_edge_cases(handle, oracle):
     assert hsp["score"][5] > 5000 and hsp["n_ops"][5] == 1500
 
 
+def test_align_host_path_known_scores_and_sharing(handle, oracle):
+    """lx_align_batch on host buffers: runs of one query share LDS profiles (padding slots are invisible to the caller),
+    scores handed over by the caller give the same result as letting pass 2 compute them, and a wrong score is
+    reported instead of producing a wrong alignment."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_batch_np(61, 150, 7, seed=4321)   # runs of 7: every run gets one padding slot
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    keep = np.nonzero(want_score >= 1)[0]                    # (nearly) all 7 of a run: 12.5 % padding, shared path
+    assert len(keep) > 400
+    es, ks = ext[keep], want_score[keep]
+    want = oracle.align_batch(q, s, es, osc)
+    for known in (None, ks):
+        hsp, ops = handle.align_batch(q, s, es, known_score=known)
+        assert "trace_forward_kernel<8,19" in handle.last_trace_kernel_name()
+        for g, (oh, oops), o in zip(hsp, want, ops):
+            assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+                   (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops)
+            assert o == oops
+    bad = ks.copy()
+    bad[5] += 3
+    with pytest.raises(capi.LambdaExtError):
+        handle.align_batch(q, s, es, known_score=bad)
+
+
 def test_align_chunked_trace_workspace(handle, oracle):
     # force several chunks through a tiny direction-bit budget
     handle.set_option(capi.LX_OPT_TRACE_BYTES, 1 << 20)
