@@ -134,6 +134,13 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc);
 int lx_builtin_scoring(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend,
                        lx_scoring * sc);
 
+/* ---- resident subjects -------------------------------------------------------------------------------------------
+ * The subject sequences of a search do not change between query batches (the reference holds them in its index file,
+ * src/shared_definitions.hpp:343-379).  lx_set_subjects uploads the (frame-expanded, rank-encoded) subject residues
+ * once; afterwards every host-buffer call (lx_score_batch, lx_align_batch, lx_prefilter_batch, lx_iterate_matches)
+ * may pass s_res = NULL, s_bytes = 0 to use the resident copy instead of uploading its own.  s_bytes = 0 drops it. */
+int lx_set_subjects(lx_handle * h, uint8_t const * s_res, uint64_t s_bytes);
+
 /* ---- pass 1: score only  (replaces _performAlignment<false>, src/search_algo.hpp:1246) ------- */
 /* Host buffers in, host buffers out; copies through pinned staging, runs on the handle's stream, returns
  * after the results have landed. out_score[i] is what the reference stores at :1129. */

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
-    "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -149,6 +149,7 @@ def load():
     lib.lx_bitscore.argtypes = [C.c_int32, C.POINTER(Karlin)]
     lib.lx_bitscore.restype = C.c_double
     lib.lx_convert_ranks.argtypes = [i32, vp, u64, vp]
+    lib.lx_set_subjects.argtypes = [vp, vp, u64]
     lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lx_set_frames.restype = None
     lib.lx_untrue_qry_id.argtypes = [i32, u64, i32]
@@ -260,6 +261,14 @@ def builtin_scoring(method: int, match: int = 2, mismatch: int = -3, gap_open: i
     return sc
 
 
+def _sptr(a):
+    return None if a is None else _ptr(a)
+
+
+def _ssize(a) -> int:
+    return 0 if a is None else int(a.size)
+
+
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
 
@@ -302,10 +311,10 @@ class Handle:
     # ---- host-buffer entry points -------------------------------------------------------------------
     def score_batch(self, q_res: np.ndarray, s_res: np.ndarray, ext: np.ndarray, slot: int = 0) -> np.ndarray:
         q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
-        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)  # None: resident subjects
         ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
         out = np.full(len(ext), -1, dtype=np.int32)
-        self._check(self.lib.lx_score_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext),
+        self._check(self.lib.lx_score_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext),
                                             len(ext), _ptr(out)))
         return out
 
@@ -314,7 +323,7 @@ class Handle:
         """lx_align_batch; known_score = the pass-1 scores of `ext` if the caller has them (saves the score pre-pass).
         raw=True returns (hsp, ops buffer, ops_off) without building the per-extension bytes objects."""
         q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
-        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)  # None: resident subjects
         ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
         n = len(ext)
         sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
@@ -323,7 +332,7 @@ class Handle:
         hsp = np.zeros(n, dtype=HSP_DTYPE)
         ops = np.zeros(int(ops_off[-1]) + 1, dtype=np.uint8)
         ks = None if known_score is None else np.ascontiguousarray(known_score, dtype=np.int32)
-        self._check(self.lib.lx_align_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size, _ptr(ext), n,
+        self._check(self.lib.lx_align_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext), n,
                                             None if ks is None else _ptr(ks), _ptr(hsp), _ptr(ops), _ptr(ops_off)))
         if raw:
             return hsp, ops, ops_off
@@ -333,12 +342,20 @@ class Handle:
 
     def prefilter_batch(self, q_res, s_res, seeds, seed_length: int, pre_scoring: int, thresh: float, slot: int = 0):
         q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
-        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)  # None: resident subjects
         seeds = np.ascontiguousarray(seeds, dtype=SEED_DTYPE)
         keep = np.zeros(len(seeds), dtype=np.uint8)
-        self._check(self.lib.lx_prefilter_batch(self.h, slot, _ptr(q_res), q_res.size, _ptr(s_res), s_res.size,
+        self._check(self.lib.lx_prefilter_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res),
                                                 _ptr(seeds), len(seeds), seed_length, pre_scoring, thresh, _ptr(keep)))
         return keep
+
+    def set_subjects(self, s_res):
+        """lx_set_subjects: keep the subject residues on the device; later host-buffer calls may pass s_res=None."""
+        if s_res is None:
+            self._check(self.lib.lx_set_subjects(self.h, None, 0))
+            return
+        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        self._check(self.lib.lx_set_subjects(self.h, _sptr(s_res), _ssize(s_res)))
 
     # ---- device-resident entry points (torch tensors on this handle's device) --------------------------
     def score_batch_dev(self, d_q, d_s, d_ext, n: int, d_out, stream=None, slot: int = 0):
@@ -353,7 +370,7 @@ class Handle:
                         slot: int = 0):
         """iterateMatchesFullSimd: returns (blast_matches ndarray, list of ops bytes, IterateStats)."""
         q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
-        s_res = np.ascontiguousarray(s_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)  # None: resident subjects
         q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
         q_len = np.ascontiguousarray(q_len, dtype=np.uint64)
         s_off = np.ascontiguousarray(s_off, dtype=np.uint64)
@@ -362,7 +379,7 @@ class Handle:
         m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE).copy()
         res = C.c_void_p()
         self._check(self.lib.lx_iterate_matches(self.h, slot, _ptr(q_res), q_res.size, _ptr(q_off), _ptr(q_len), len(q_off),
-                                                _ptr(q_orig), _ptr(s_res), s_res.size, _ptr(s_off), _ptr(s_len),
+                                                _ptr(q_orig), _sptr(s_res), _ssize(s_res), _ptr(s_off), _ptr(s_len),
                                                 len(s_off), _ptr(m), len(m), C.byref(params), C.byref(res)))
         try:
             n = int(self.lib.lx_iterate_result_count(res))

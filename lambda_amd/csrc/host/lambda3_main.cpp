@@ -250,6 +250,8 @@ int main(int argc, char ** argv)
             throw std::runtime_error("Could not compute Karlin-Altschul-Values for Scoring Scheme."); // :232-233
         lambda_amd::Engine eng(opt.device);
         eng.setScoring(sc, 0);
+        // the database stays on the GPU for the whole run (the reference keeps it in the index file it maps at start-up)
+        eng.check(lx_set_subjects(eng.raw(), db.res.data(), db.res.size()));
 
         // ---- seeding: exact k-mers of the (reduced) sequences, window of seedLength every seedOffset (:635-669)
         int const K = opt.seedLength;
@@ -312,7 +314,7 @@ int main(int argc, char ** argv)
                                    (uint32_t)m.qryStart, (uint32_t)m.qryEnd, (uint32_t)m.subjStart, 0};
             }
             std::vector<uint8_t> keep(matches.size());
-            eng.check(lx_prefilter_batch(eng.raw(), 0, qs.res.data(), qs.res.size(), db.res.data(), db.res.size(), seeds.data(),
+            eng.check(lx_prefilter_batch(eng.raw(), 0, qs.res.data(), qs.res.size(), nullptr, 0, seeds.data(),
                                          seeds.size(), (uint32_t)K, opt.preScoring, opt.preScoringThresh, keep.data()));
             size_t w = 0;
             for (size_t i = 0; i < matches.size(); ++i)
@@ -338,7 +340,7 @@ int main(int argc, char ** argv)
         sp.karlin           = ka;
         lx_iterate_result * res = nullptr;
         eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
-                                     qs.orig_len.data(), db.res.data(), db.res.size(), db.off.data(), db.len.data(),
+                                     qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(),
                                      db.off.size(), matches.data(), matches.size(), &sp, &res));
         uint64_t const              nHsp = lx_iterate_result_count(res);
         std::vector<lx_blast_match> bms(lx_iterate_result_matches(res), lx_iterate_result_matches(res) + nHsp);

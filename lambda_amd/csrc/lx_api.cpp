@@ -85,7 +85,7 @@ struct lx_handle
     lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
 
     // staging for the host-buffer entry points
-    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score;
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_db;
     // multi-panel carry workspace
     DevBuf     d_ws;
     uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
@@ -97,6 +97,7 @@ struct lx_handle
     uint64_t opt_trace_bytes = 32ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
+    uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
 
@@ -391,7 +392,7 @@ void lx_destroy(lx_handle * h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ends,
-                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_sel_score, &h->d_trace_score, &h->d_ws})
+                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_sel_score, &h->d_trace_score, &h->d_db, &h->d_ws})
         if (b->ptr)
             (void)hipFree(b->ptr);
     for (int s = 0; s < 2; ++s)
@@ -638,6 +639,52 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     return LX_OK;
 }
 
+// Subject side of a host-buffer call: either the caller's buffer, uploaded into d_s, or -- s_res == NULL, s_bytes == 0
+// after lx_set_subjects -- the resident copy.
+struct SubjectRef
+{
+    void *   dev   = nullptr;
+    uint64_t bytes = 0;
+    bool     upload = false;
+};
+static int resolve_subjects(lx_handle * h, uint8_t const * s_res, uint64_t s_bytes, SubjectRef & out)
+{
+    if (!s_res && s_bytes == 0 && h->db_bytes)
+    {
+        out.dev   = h->d_db.ptr;
+        out.bytes = h->db_bytes;
+        return LX_OK;
+    }
+    if (!s_res && s_bytes)
+        return fail(h, LX_EINVAL, "NULL argument");
+    int rc = ensure(h, h->d_s, s_bytes + kSlack);
+    if (rc)
+        return rc;
+    out.dev    = h->d_s.ptr;
+    out.bytes  = s_bytes;
+    out.upload = s_bytes != 0;
+    return LX_OK;
+}
+
+int lx_set_subjects(lx_handle * h, uint8_t const * s_res, uint64_t s_bytes)
+{
+    if (!h || (!s_res && s_bytes))
+        return LX_EINVAL;
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    h->db_bytes = 0;
+    if (s_bytes == 0)
+        return LX_OK;
+    if ((rc = ensure(h, h->d_db, s_bytes + kSlack)))
+        return rc;
+    LX_HIP(h, hipMemcpyAsync(h->d_db.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemsetAsync(static_cast<uint8_t *>(h->d_db.ptr) + s_bytes, 0, kSlack, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+    h->db_bytes = s_bytes;
+    return LX_OK;
+}
+
 int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
                    uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t * out_score)
 {
@@ -647,11 +694,15 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (n == 0)
         return LX_OK;
-    if (!ext || !out_score || (!q_res && q_bytes) || (!s_res && s_bytes))
+    if (!ext || !out_score || (!q_res && q_bytes))
         return fail(h, LX_EINVAL, "NULL argument");
     int rc = bind(h);
     if (rc)
         return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
 
     HostMarks hm("lx_score_batch");
     // ---- validate; order by (q_len, q_off, s_len): extensions of one query become adjacent (one LDS profile per
@@ -802,16 +853,15 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 
     hm.mark("bin");
     // ---- upload
-    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
-        (rc = ensure(h, h->d_ext, sorted.size() * sizeof(lx_extension))) ||
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, sorted.size() * sizeof(lx_extension))) ||
         (rc = ensure(h, h->d_out, sorted.size() * sizeof(int32_t))))
         return rc;
     if ((rc = prepare_workspace(h, h->stream)))
         return rc;
     if (q_bytes)
         LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
-    if (s_bytes)
-        LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, sorted.data(), sorted.size() * sizeof(lx_extension), hipMemcpyHostToDevice,
                              h->stream));
 
@@ -820,7 +870,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
     for (Seg const & seg : segs)
     {
-        rc = launch_score_list(h, slot, h->d_q.ptr, h->d_s.ptr,
+        rc = launch_score_list(h, slot, h->d_q.ptr, sref.dev,
                                static_cast<lx_extension const *>(h->d_ext.ptr) + seg.first, seg.count,
                                static_cast<int32_t *>(h->d_out.ptr) + seg.first, seg.cfg, seg.multi, seg.shared,
                                h->stream, seg.pair_cfg);
@@ -1012,13 +1062,17 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (n == 0)
         return LX_OK;
-    if (!ext || !out_hsp || !out_ops || !ops_off || (!q_res && q_bytes) || (!s_res && s_bytes))
+    if (!ext || !out_hsp || !out_ops || !ops_off || (!q_res && q_bytes))
         return fail(h, LX_EINVAL, "NULL argument");
     if (n > 0xfffffff0ull)
         return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
     int rc = bind(h);
     if (rc)
         return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
     HostMarks hm("lx_align_batch");
     // ---- validate; find the runs of consecutive extensions that share their query slice (lambda's lists are grouped by
     // query).  If padding every run to a multiple of 4 slots costs <= 25 %, pass 2 runs the shared-profile geometries.
@@ -1046,7 +1100,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
         h->opt_ws_bytes = carry_pairs * 8 + 4096;
-    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) ||
         (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
         (rc = ensure(h, h->d_ops, ops_bytes + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
         return rc;
@@ -1095,8 +1149,8 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 
     if (q_bytes)
         LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
-    if (s_bytes)
-        LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, share ? slot_ext.data() : ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, ops_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
     if (share)
@@ -1108,7 +1162,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     h->phase_ev.clear();
     h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, h->stream));
-    rc = align_dev_impl(h, slot, h->d_q.ptr, h->d_s.ptr, static_cast<lx::Extension const *>(h->d_ext.ptr), slots,
+    rc = align_dev_impl(h, slot, h->d_q.ptr, sref.dev, static_cast<lx::Extension const *>(h->d_ext.ptr), slots,
                         static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
                         static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, share ? 4 : 0,
                         share ? static_cast<uint32_t const *>(h->d_sel_src.ptr) : nullptr, nullptr,
@@ -1217,8 +1271,18 @@ int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (n == 0)
         return LX_OK;
-    if (!seeds || !out_keep || !q_res || !s_res)
+    if (!seeds || !out_keep || !q_res)
         return fail(h, LX_EINVAL, "NULL argument");
+    SubjectRef sref;
+    {
+        int const rc0 = bind(h);
+        if (rc0)
+            return rc0;
+        int const rc1 = resolve_subjects(h, s_res, s_bytes, sref);
+        if (rc1)
+            return rc1;
+        s_bytes = sref.bytes;
+    }
     static_assert(sizeof(lx_seed) == sizeof(lx::PrefilterSeed), "ABI mismatch");
     for (uint64_t i = 0; i < n; ++i)
     {
@@ -1230,15 +1294,15 @@ int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     int rc = bind(h);
     if (rc)
         return rc;
-    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_s, s_bytes + kSlack)) ||
-        (rc = ensure(h, h->d_seeds, n * sizeof(lx_seed))) || (rc = ensure(h, h->d_keep, n)))
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_seeds, n * sizeof(lx_seed))) || (rc = ensure(h, h->d_keep, n)))
         return rc;
     LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
-    LX_HIP(h, hipMemcpyAsync(h->d_s.ptr, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemcpyAsync(h->d_seeds.ptr, seeds, n * sizeof(lx_seed), hipMemcpyHostToDevice, h->stream));
     lx::PrefilterParams p{};
     p.q_res              = static_cast<uint8_t const *>(h->d_q.ptr);
-    p.s_res              = static_cast<uint8_t const *>(h->d_s.ptr);
+    p.s_res              = static_cast<uint8_t const *>(sref.dev);
     p.seeds              = static_cast<lx::PrefilterSeed const *>(h->d_seeds.ptr);
     p.n                  = n;
     p.sc                 = h->sc_dev[slot];

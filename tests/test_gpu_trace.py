@@ -110,6 +110,30 @@ def test_align_host_path_known_scores_and_sharing(handle, oracle):
         handle.align_batch(q, s, es, known_score=bad)
 
 
+def test_resident_subjects(handle, oracle):
+    """lx_set_subjects: the subject buffer is uploaded once; host-buffer calls with s_res = NULL use the resident copy and
+    give the same results; without a resident copy a NULL subject buffer is an error."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_batch_np(40, 120, 8, seed=99)
+    want = handle.score_batch(q, s, ext)
+    hsp_w, ops_w = handle.align_batch(q, s, ext[:64], known_score=want[:64])
+    handle.set_subjects(s)
+    try:
+        got = handle.score_batch(q, None, ext)
+        assert (got == want).all()
+        hsp_g, ops_g = handle.align_batch(q, None, ext[:64])
+        assert (hsp_g == hsp_w).all() and ops_g == ops_w
+        bad = ext.copy()
+        bad["s_off"][3] = len(s)  # beyond the resident buffer
+        with pytest.raises(capi.LambdaExtError):
+            handle.score_batch(q, None, bad)
+    finally:
+        handle.set_subjects(None)
+    with pytest.raises(capi.LambdaExtError):
+        handle.score_batch(q, None, ext)
+
+
 def test_align_chunked_trace_workspace(handle, oracle):
     # force several chunks through a tiny direction-bit budget
     handle.set_option(capi.LX_OPT_TRACE_BYTES, 1 << 20)
