@@ -341,3 +341,75 @@ def test_iterate_matches_bisulfite(handle, oracle):
         # _setFrames in bisulfite mode (src/search_algo.hpp:778-782, :801-803)
         qid, sid = int(g["qry_id"]), int(g["subj_id"])
         assert int(g["q_frame"]) == (qid % 2 + 1) * (-1 if qid % 4 > 1 else 1) and int(g["s_frame"]) == sid % 2 + 1
+
+
+def test_full_size_fused_step_properties(handle, oracle):
+    """BASELINE.json configs[1] at FULL size through lx_extend_batch_dev (3.2 M extensions, 1.6 M traced), checked by
+    size-independent properties on the device and by the oracle on a sample:
+    (1) the survivor count equals the number of scores at or above the cut-off and no extension is flagged (-1);
+    (2) every traced HSP carries the pass-1 score; rejected rows carry the score and no alignment;
+    (3) per HSP, the column counts add up: n_ops = matches + mismatches + gap columns, the query/subject spans equal the
+        number of non-gap columns of their row;
+    (4) the self-planted window of every query (the query copied into its first window) aligns end to end without gaps;
+    (5) 4 000 sampled survivors are bit-identical to the oracle (coordinates, ops)."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    nq, lq, wpq = 100_000, 150, 32
+    d_q, d_s, d_ext, ext = synth.make_batch_torch(nq, lq, wpq, 0x1A3BDA02, dev)
+    ls, b = synth.window_len(lq), synth.band_size(lq)
+    s2 = d_s.view(nq * wpq, ls)
+    s2[torch.arange(nq, device=dev) * wpq, b:b + lq] = d_q.view(nq, lq)
+    pad = torch.zeros(256, dtype=torch.uint8, device=dev)
+    d_q = torch.cat([d_q, pad])
+    d_s = torch.cat([s2.reshape(-1), pad])
+    n = len(ext)
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    cutoff = 91
+    handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, ls)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+    torch.cuda.synchronize()
+    try:
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+    hsp = d_hsp.view(torch.int32).view(n, 12)  # lx_hsp: score q_begin q_end s_begin s_end n_ops matches mismatches positives opens extensions shift
+    surv = d_score >= cutoff
+    cnt = d_count.cpu().numpy()
+    assert int(cnt[1]) == int(surv.sum()) and int(cnt[1]) > n // 3                      # (1)
+    assert bool((hsp[:, 0] == d_score).all())                                             # (1) no -1, (2)
+    assert bool((hsp[~surv][:, 5] == 0).all())
+    t = hsp[surv].long()
+    gaps = t[:, 9] + t[:, 10]
+    assert bool((t[:, 5] == t[:, 6] + t[:, 7] + gaps).all())                              # (3)
+    assert bool(((t[:, 2] - t[:, 1]) + (t[:, 4] - t[:, 3]) == 2 * (t[:, 6] + t[:, 7]) + gaps).all())
+    assert bool((t[:, 5] > 0).all()) and bool((t[:, 8] >= t[:, 6]).all())
+    first = hsp[torch.arange(nq, device=dev) * wpq].long()                                # (4)
+    assert bool((first[:, 1] == 0).all()) and bool((first[:, 2] == lq).all()) and bool((first[:, 3] == b).all())
+    assert bool((first[:, 5] == lq).all()) and bool((first[:, 6] == lq).all()) and bool((first[:, 9] == 0).all())
+    # (5) a sample against the oracle
+    rng = np.random.default_rng(3)
+    sidx = np.sort(rng.choice(np.nonzero(surv.cpu().numpy())[0], 4000, replace=False))
+    hs = hsp[torch.from_numpy(sidx).to(dev)].cpu().numpy()
+    q_np, s_np = d_q.cpu().numpy(), d_s.cpu().numpy()
+    want = oracle.align_batch(q_np, s_np, ext[sidx], osc)
+    ops_np = None
+    for row, i, (oh, oops) in zip(hs, sidx, want):
+        assert tuple(int(x) for x in row[:6]) == (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        st = int(off[i]) + int(row[11])
+        got = bytes(d_ops[st: st + oh.n_ops].cpu().numpy())
+        assert got == oops, i
