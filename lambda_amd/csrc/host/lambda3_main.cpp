@@ -141,6 +141,7 @@ struct Options
     int         idCutOff    = 0;
     int         device      = 0;
     std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
+    std::string dbAlphabet  = "auto"; // searchp: "dna5" = six-frame translated subjects (TBLASTN / TBLASTX)
 };
 
 // the reference lets BioC++ detect the query alphabet (src/search_options.hpp); here: nucleotide if >= 90 % of the
@@ -205,6 +206,12 @@ Options parse(int argc, char ** argv)
             o.idCutOff = std::stoi(val());
         else if (a == "--device")
             o.device = std::stoi(val());
+        else if (a == "--db-alphabet")
+        {
+            o.dbAlphabet = val();
+            if (o.dbAlphabet != "auto" && o.dbAlphabet != "dna5" && o.dbAlphabet != "aminoacid")
+                throw std::runtime_error("--db-alphabet takes auto, dna5 or aminoacid");
+        }
         else if (a == "-a" || a == "--query-alphabet")
         {
             o.qryAlphabet = val();
@@ -232,12 +239,15 @@ int main(int argc, char ** argv)
         bool const    prot = opt.cmd == "searchp";
         // searchp with nucleotide queries is BLASTX: six translated frames per query against the protein database
         bool const    blastx = prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
+        // searchp against a nucleotide database translates the subjects instead (TBLASTN), or both sides (TBLASTX)
+        bool const    sTrans  = prot && (opt.dbAlphabet == "dna5" || (opt.dbAlphabet == "auto" && looksLikeDna(opt.db)));
         int const     qFrames = blastx ? 6 : prot ? 1 : 2;
-        char const *  program = blastx ? "blastx" : prot ? "blastp" : "blastn";
+        int const     sFrames = sTrans ? 6 : 1;
+        char const *  program = blastx ? (sTrans ? "tblastx" : "blastx") : sTrans ? "tblastn" : prot ? "blastp" : "blastn";
 
         SeqSet qs, db;
         readFasta(opt.query, prot, !prot, qs, blastx);
-        readFasta(opt.db, prot, false, db);
+        readFasta(opt.db, prot, false, db, sTrans);
         if (qs.ids.empty() || db.ids.empty())
             throw std::runtime_error("empty query or database file");
 
@@ -279,7 +289,7 @@ int main(int argc, char ** argv)
             return c;
         };
         std::unordered_map<uint64_t, std::vector<std::pair<uint32_t, uint32_t>>> table;
-        for (size_t s = 0; s < db.ids.size(); ++s)
+        for (size_t s = 0; s < db.off.size(); ++s) // every (frame-expanded) subject sequence
             for (uint64_t p = 0; p + K <= db.len[s]; ++p)
             {
                 bool     ok;
@@ -334,9 +344,9 @@ int main(int argc, char ** argv)
         sp.db_total_length  = dbTotal;
         sp.query_translated = blastx ? 1 : 0;
         sp.qry_num_frames   = qFrames;
-        sp.sbj_num_frames   = 1;
+        sp.sbj_num_frames   = sFrames;
         sp.q_frame_mode     = blastx ? LX_FRAMES_TRANSLATED : prot ? LX_FRAMES_NONE : LX_FRAMES_REVCOMP; // _setFrames, :768-814
-        sp.s_frame_mode     = LX_FRAMES_NONE;
+        sp.s_frame_mode     = sTrans ? LX_FRAMES_TRANSLATED : LX_FRAMES_NONE;
         sp.karlin           = ka;
         lx_iterate_result * res = nullptr;
         eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
@@ -357,7 +367,7 @@ int main(int argc, char ** argv)
             qid.push_back(s.c_str());
         for (auto const & s : db.ids)
             sid.push_back(s.c_str());
-        lx_seq_names names{qid.data(), qs.orig_len.data(), sid.data(), db.len.data(), qid.size(), sid.size()};
+        lx_seq_names names{qid.data(), qs.orig_len.data(), sid.data(), db.orig_len.data(), qid.size(), sid.size()};
         int          fmt = LX_OUT_BLAST_TAB;
         auto         ends = [&](char const * suf)
         { return opt.output.size() >= std::strlen(suf) && opt.output.compare(opt.output.size() - std::strlen(suf), std::string::npos, suf) == 0; };
@@ -367,7 +377,7 @@ int main(int argc, char ** argv)
             fmt = LX_OUT_SAM;
         else if (!ends(".m8"))
             throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
-        if (blastx && fmt == LX_OUT_SAM)
+        if ((blastx || sTrans) && fmt == LX_OUT_SAM)
             throw std::runtime_error("SAM output of translated searches is not implemented; use .m8 or .m9");
         eng.check(lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
                                    reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data()));

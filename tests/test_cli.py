@@ -220,3 +220,51 @@ def test_searchp_blastx_frames_and_coordinates(tmp_path):
     r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "db.fasta"), "-o",
                         str(tmp_path / "o.sam")], capture_output=True, text=True)
     assert r.returncode != 0 and "not implemented" in r.stderr
+
+
+@pytest.mark.gpu
+def test_searchp_tblastn_translated_subjects(tmp_path):
+    """searchp against a nucleotide database = TBLASTN: contigs that carry the coding sequence of a query protein in a
+    known frame / strand come back with the contig as subject and the nucleotide coordinates of the coding segment
+    (start > end on the minus strand)."""
+    rng = np.random.default_rng(23)
+    comp = str.maketrans("ACGT", "TGCA")
+    prots, contigs, truth = [], [], []
+    for k in range(24):
+        p = "".join(STD[i] for i in rng.integers(0, 20, 70))
+        nt = "".join(CODONS[c][int(rng.integers(0, len(CODONS[c])))] for c in p)
+        left, right = int(rng.integers(30, 200)), int(rng.integers(30, 200))
+        lf = "".join("ACGT"[i] for i in rng.integers(0, 4, left))[:-3] + "TAA"
+        rt = "TAA" + "".join("ACGT"[i] for i in rng.integers(0, 4, right))
+        contig = lf + nt + rt
+        L = len(contig)
+        if k % 2:
+            sstart, send = L - left, L - left - 210 + 1
+            contig = contig.translate(comp)[::-1]
+        else:
+            sstart, send = left + 1, left + 210
+        prots.append(p)
+        contigs.append(contig)
+        truth.append((sstart, send))
+    _fasta(tmp_path / "q.fasta", [f"prot{k}" for k in range(len(prots))], prots)
+    _fasta(tmp_path / "db.fasta", [f"contig{k}" for k in range(len(contigs))], contigs)
+    out = tmp_path / "o.m8"
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "db.fasta"), "-o", str(out),
+                        "--seed-offset", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "tblastn" in r.stderr
+    best = {}
+    for l in out.read_text().splitlines():
+        x = l.split("\t")
+        best.setdefault(x[0], x)
+    assert len(best) == len(prots)
+    exact = 0
+    for k, (sstart, send) in enumerate(truth):
+        x = best[f"prot{k}"]
+        assert x[1] == f"contig{k}" and float(x[2]) >= 90.0, x
+        ss_, se_ = int(x[8]), int(x[9])
+        assert (ss_ < se_) == (sstart < send) and (ss_ - sstart) % 3 == 0 and (se_ - send) % 3 == 0, (x, sstart, send)
+        if int(x[3]) == 70 and float(x[2]) == 100.0:
+            exact += 1
+            assert (ss_, se_) == (sstart, send) and (int(x[6]), int(x[7])) == (1, 70), (x, sstart, send)
+    assert exact >= 0.7 * len(truth), exact
