@@ -911,13 +911,6 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         return fail(h, LX_EINVAL, "pass 2 reads residues in aligned 16-byte groups: the residue buffers must be 16-byte aligned");
     if (max_s > 65535)
         return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
-    int maxent = 0;
-    for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
-        for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
-            maxent = std::max<int>(maxent, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-    if ((uint64_t)maxent * std::min(max_q, max_s) >= 65536)
-        return fail(h, LX_EINVAL, "pass 2 packs scores in 16 bits: max entry %d x min(%llu,%llu) residues overflows", maxent,
-                    (unsigned long long)max_q, (unsigned long long)max_s);
     // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
     // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
     int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
