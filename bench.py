@@ -58,7 +58,24 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, cores: int):
+def usable_cpus() -> tuple[int, str]:
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose all
+    256 hardware threads but `cpu.max` grants 16 CPUs' worth of time -- oversubscribing them only gets throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} hardware threads visible"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(int(quota) / int(period) + 0.5))
+            if q < n:
+                note += f", cgroup cpu.max = {quota}/{period} -> {q} CPUs"
+                n = q
+    except Exception:
+        pass
+    return n, note
+
+
+def cpu_baseline(args, cores: int, note: str = ""):
     """Times the oracle's inter-sequence int16 SIMD batch scorer (the shape of the reference's CPU path,
     oracle/lx_oracle_simd.cpp) on a bounded sample of the same workload, on this box's host cores."""
     from lambda_amd import capi, synth
@@ -80,7 +97,8 @@ def cpu_baseline(args, cores: int):
         "cores": cores,
         "kind": "port",
         "sample": f"{nq} queries x {args.windows} windows ({len(ext)} extensions, {cells / 1e9:.2f} Gcells), "
-                  f"oracle inter-sequence int16 SIMD restatement (NOT SeqAn), OpenMP, best of 3, {best:.3f} s",
+                  f"oracle inter-sequence int16 SIMD restatement (NOT SeqAn), OpenMP with {cores} threads ({note}), "
+                  f"best of 3, {best:.3f} s",
     }
 
 
@@ -288,8 +306,8 @@ def main():
             "roofline_other": rooflines[1:],
         }
         if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(args, cores)
+            cores, note = usable_cpus()
+            out["cpu_baseline"] = cpu_baseline(args, cores, note)
         print(json.dumps(out), flush=True)
     h.close()
     if use_dist:

@@ -29,6 +29,7 @@ int        score_cfg_count();
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream);
 int        score_pair_cfg_for(uint32_t max_qlen);
 int        score_pair_cfg_cols(int cfg);
+int        score_pair_cfg_for_runs_of_8(uint32_t max_qlen);
 int        score_pair_cfg_group(int cfg);
 size_t     score_pair_profile_bytes(int cfg, int nrows);
 hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
@@ -625,6 +626,8 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
                 pair_cfg   = pc;
                 pair_share = groups / 2;
             }
+            else if (h->opt_query_run % 8 == 0) // two profiles do not fit: a 16-lane geometry holds 8 extensions per wavefront
+                pair_cfg = lx::score_pair_cfg_for_runs_of_8((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu));
         }
     }
     PhaseTimer pt(h, stream, 0);

@@ -371,7 +371,8 @@ static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
     return hipGetLastError();
 }
 
-// pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192, 5 = (16,13) 208
+// pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192, 5 = (16,13) 208,
+// 6 = (16,10) 160 [8 extensions per wavefront: for query runs that are a multiple of 8 but not of 16]
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
@@ -384,6 +385,7 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
         case 3: return launch_pair_cfg<8, 8>(p, stream);
         case 4: return launch_pair_cfg<8, 24>(p, stream);
         case 5: return launch_pair_cfg<16, 13>(p, stream);
+        case 6: return launch_pair_cfg<16, 10>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -405,13 +407,23 @@ int score_pair_cfg_for(uint32_t max_qlen)
     return -1;
 }
 
-int score_pair_cfg_cols(int cfg)
+// geometries with 16-lane groups (8 extensions per wavefront)
+int score_pair_cfg_for_runs_of_8(uint32_t max_qlen)
 {
-    static int const c[6] = {19, 13, 16, 8, 24, 13};
-    return (cfg >= 0 && cfg < 6) ? c[cfg] : 0;
+    if (max_qlen <= 160)
+        return 6;
+    if (max_qlen <= 208)
+        return 5;
+    return -1;
 }
 
-int score_pair_cfg_group(int cfg) { return cfg == 5 ? 16 : 8; }
+int score_pair_cfg_cols(int cfg)
+{
+    static int const c[7] = {19, 13, 16, 8, 24, 13, 10};
+    return (cfg >= 0 && cfg < 7) ? c[cfg] : 0;
+}
+
+int score_pair_cfg_group(int cfg) { return (cfg == 5 || cfg == 6) ? 16 : 8; }
 
 // LDS bytes of one profile (the kernel's occupancy allows about 13 KB per wavefront)
 size_t score_pair_profile_bytes(int cfg, int nrows)
