@@ -940,21 +940,25 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     // Two trace buffers, so that the backtrace of chunk k may run on stream2 while the forward kernel of chunk k+1
     // runs on `stream`.  Measured on MI355X (config 2) the overlap buys nothing -- both kernels saturate the chip
     // (46.5 ms/step serial vs 46.9 ms overlapped) -- so it is off unless LX_TRACE_OVERLAP=1.
-    uint64_t       chunk      = std::max<uint64_t>(1, h->opt_trace_bytes / 2 / std::max<uint64_t>(per_ext, 1));
-    uint64_t const want_chunks = getenv("LX_TRACE_CHUNKS") ? (uint64_t)atoi(getenv("LX_TRACE_CHUNKS")) : 2;
-    chunk                     = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
-    bool const overlap        = getenv("LX_TRACE_OVERLAP") && atoi(getenv("LX_TRACE_OVERLAP")) != 0;
-    hipStream_t const bstream = overlap ? h->stream2 : stream;
-    chunk                     = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
+    // Without the overlap one buffer is enough, so a chunk may use the whole budget: as few launches (and kernel
+    // tails) as the budget allows.  In the fused path `n` is the capacity of the survivor list; launches beyond the
+    // device-side count exit at once.
+    bool const     overlap     = getenv("LX_TRACE_OVERLAP") && atoi(getenv("LX_TRACE_OVERLAP")) != 0;
+    uint64_t const nbuf        = overlap ? 2 : 1;
+    uint64_t       chunk       = std::max<uint64_t>(1, h->opt_trace_bytes / nbuf / std::max<uint64_t>(per_ext, 1));
+    uint64_t const want_chunks = getenv("LX_TRACE_CHUNKS") ? (uint64_t)atoi(getenv("LX_TRACE_CHUNKS")) : 1;
+    chunk                      = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
+    hipStream_t const bstream  = overlap ? h->stream2 : stream;
+    chunk                      = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
     int rc;
-    if ((rc = ensure(h, h->d_trace, 2 * chunk * per_ext)) || (rc = ensure(h, h->d_ends, 2 * chunk * sizeof(lx::EndCell))))
+    if ((rc = ensure(h, h->d_trace, nbuf * chunk * per_ext)) || (rc = ensure(h, h->d_ends, nbuf * chunk * sizeof(lx::EndCell))))
         return rc;
     LX_HIP(h, hipEventRecord(h->evS, stream));
     LX_HIP(h, hipStreamWaitEvent(h->stream2, h->evS, 0));
     uint64_t nchunks = 0;
     for (uint64_t c0 = 0; c0 < n; c0 += chunk, ++nchunks)
     {
-        int const       b = (int)(nchunks & 1);
+        int const       b = overlap ? (int)(nchunks & 1) : 0; // one buffer without the overlap (stream order protects it)
         lx::TraceParams p{};
         p.q_res          = static_cast<uint8_t const *>(d_q);
         p.s_res          = static_cast<uint8_t const *>(d_s);
