@@ -28,6 +28,7 @@ int        score_cfg_groups(int cfg);
 int        score_cfg_count();
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream);
 int        score_pair_cfg_for(uint32_t max_qlen);
+uint64_t   select_blocks(uint64_t nruns);
 int        score_pair_cfg_cols(int cfg);
 int        score_pair_cfg_for_runs_of_8(uint32_t max_qlen);
 int        score_pair_cfg_group(int cfg);
@@ -1226,7 +1227,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     uint64_t const nruns  = (n + run - 1) / run;
     uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
-        (rc = ensure(h, h->d_sel_runs, (nruns + 1) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
+        (rc = ensure(h, h->d_sel_runs, (nruns + 2 * lx::select_blocks(nruns) + 2) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
         return rc;
     lx::SelectParams sp{};
     sp.ext           = static_cast<lx::Extension const *>(d_ext);
@@ -1237,6 +1238,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     sp.run           = run;
     sp.pad_to        = pad_to;
     sp.run_slots     = static_cast<uint64_t *>(h->d_sel_runs.ptr);
+    sp.block_tot     = sp.run_slots + nruns;
     sp.out_ext       = static_cast<lx::Extension *>(h->d_sel_ext.ptr);
     sp.out_src       = static_cast<uint32_t *>(h->d_sel_src.ptr);
     sp.out_score     = static_cast<int32_t *>(h->d_sel_score.ptr);

@@ -119,7 +119,8 @@ struct SelectParams
     uint64_t          n;
     uint32_t          run;       // extensions come in runs of `run` entries sharing a query (0/1 = no runs)
     uint32_t          pad_to;    // pad every run's survivors to a multiple of this many slots (1 = no padding)
-    uint64_t *        run_slots; // [nruns + 1] scratch: padded survivor count per run -> exclusive scan
+    uint64_t *        run_slots; // [nruns] scratch: padded survivor count per run
+    uint64_t *        block_tot; // [2 * select_blocks(nruns)] scratch: per workgroup (slots, survivors) -> slot offset
     Extension *       out_ext;   // [capacity]
     int32_t *         out_score; // [capacity] score of each slot (0 for padding slots)
     uint32_t *        out_src;   // [capacity]

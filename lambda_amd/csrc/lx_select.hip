@@ -5,7 +5,8 @@
 // (src/search_misc.hpp:77-78), so the host turns them into an integer score cut-off per extension (or one for all)
 // and the test becomes `score >= cutoff` -- bit-identical decisions without moving scores to the host.
 //
-// Output: a compacted extension list in input order (deterministic: count -> exclusive scan -> write), the original
+// Output: a compacted extension list in input order (deterministic: count per run + per-workgroup totals -> scan of
+// the totals -> in-workgroup scan + write), the original
 // index of every slot, and -- when the input comes in runs of `run` extensions per query -- each run's survivors padded
 // with empty slots to a multiple of `pad_to`, so that every wavefront of pass 2 works on a single query (one LDS
 // profile).  HBM-bound integer work: 28 B read per candidate, 28 B written per survivor.
@@ -22,66 +23,136 @@ __device__ __forceinline__ bool survives(SelectParams const & p, uint64_t i)
     return p.score[i] >= cut && p.ext[i].q_len != 0 && p.ext[i].s_len != 0;
 }
 
-// one thread per run: padded survivor count
-__global__ __launch_bounds__(256) void select_count_kernel(SelectParams p, uint64_t nruns)
+constexpr int kSelBlock = 256; // runs per workgroup of the count / write kernels
+
+// exclusive scan of one value per thread over a workgroup of kSelBlock threads; returns the workgroup total in `total`
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t * wave_sums, uint32_t & total)
 {
-    uint64_t const r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nruns)
-        return;
-    uint64_t const lo = r * p.run, hi = min(p.n, lo + p.run);
-    uint32_t       c  = 0;
-    for (uint64_t i = lo; i < hi; ++i)
-        c += survives(p, i) ? 1u : 0u;
-    p.run_slots[r] = (uint64_t)((c + p.pad_to - 1) / p.pad_to) * p.pad_to | ((uint64_t)c << 40);
+    int const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t  incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        uint32_t const up = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off)
+            incl += up;
+    }
+    if (lane == 63)
+        wave_sums[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kSelBlock / 64; ++w)
+    {
+        uint32_t const ws = wave_sums[w];
+        base += (w < wave) ? ws : 0u;
+        tot += ws;
+    }
+    total = tot;
+    return base + incl - v;
 }
 
-// single workgroup exclusive scan over the per-run slot counts (nruns is a few 1e5 at most)
-__global__ __launch_bounds__(1024) void select_scan_kernel(SelectParams p, uint64_t nruns)
+// one thread per run: padded survivor count; one (slots, survivors) total per workgroup
+__global__ __launch_bounds__(kSelBlock) void select_count_kernel(SelectParams p, uint64_t nruns)
 {
-    __shared__ uint64_t part[1024];
-    __shared__ uint64_t part_true[1024];
-    uint64_t const per = (nruns + 1023) / 1024;
-    uint64_t const lo = threadIdx.x * per, hi = min(nruns, lo + per);
-    uint64_t       sum = 0, tsum = 0;
-    for (uint64_t r = lo; r < hi; ++r)
+    __shared__ uint32_t wave_sums[kSelBlock / 64], wave_true[kSelBlock / 64];
+    uint64_t const r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t       c = 0;
+    if (r < nruns)
     {
-        sum += p.run_slots[r] & 0xffffffffffull;
-        tsum += p.run_slots[r] >> 40;
+        uint64_t const lo = r * p.run, hi = min(p.n, lo + p.run);
+        for (uint64_t i = lo; i < hi; ++i)
+            c += survives(p, i) ? 1u : 0u;
     }
-    part[threadIdx.x]      = sum;
-    part_true[threadIdx.x] = tsum;
+    uint32_t const padded = (c + p.pad_to - 1) / p.pad_to * p.pad_to;
+    if (r < nruns)
+        p.run_slots[r] = padded; // the write kernel recounts nothing: it only needs the padded size for its in-block scan
+    uint32_t sp = padded, st = c;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        sp += (uint32_t)__shfl_xor((int)sp, off);
+        st += (uint32_t)__shfl_xor((int)st, off);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        wave_sums[threadIdx.x >> 6] = sp;
+        wave_true[threadIdx.x >> 6] = st;
+    }
     __syncthreads();
     if (threadIdx.x == 0)
     {
-        uint64_t acc = 0, tacc = 0;
-        for (int t = 0; t < 1024; ++t)
+        uint64_t a = 0, t = 0;
+        for (int w = 0; w < kSelBlock / 64; ++w)
         {
-            uint64_t const v = part[t];
-            part[t]          = acc;
-            acc += v;
-            tacc += part_true[t];
+            a += wave_sums[w];
+            t += wave_true[w];
         }
-        p.out_count[0] = acc;
-        p.out_count[1] = tacc;
+        p.block_tot[2 * (uint64_t)blockIdx.x]     = a;
+        p.block_tot[2 * (uint64_t)blockIdx.x + 1] = t;
     }
+}
+
+// single workgroup: exclusive scan over the per-workgroup totals (a few hundred to a few thousand values)
+__global__ __launch_bounds__(1024) void select_scan_kernel(SelectParams p, uint64_t nblocks)
+{
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry[2];
+    if (threadIdx.x == 0)
+        carry[0] = carry[1] = 0;
     __syncthreads();
-    uint64_t acc = part[threadIdx.x];
-    for (uint64_t r = lo; r < hi; ++r)
+    for (uint64_t base = 0; base < nblocks; base += 1024)
     {
-        uint64_t const v = p.run_slots[r] & 0xffffffffffull;
-        p.run_slots[r]   = acc;
-        acc += v;
+        uint64_t const b = base + threadIdx.x;
+        uint64_t const v = b < nblocks ? p.block_tot[2 * b] : 0, t = b < nblocks ? p.block_tot[2 * b + 1] : 0;
+        // Hillis-Steele over the tile in LDS (10 rounds; the tile count is tiny)
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1)
+        {
+            uint64_t const add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint64_t const incl = part[threadIdx.x], c0 = carry[0];
+        if (b < nblocks)
+            p.block_tot[2 * b] = c0 + incl - v; // exclusive offset of this workgroup's first slot
+        __syncthreads();
+        // survivors: plain tree sum
+        part[threadIdx.x] = t;
+        __syncthreads();
+        for (int off = 512; off >= 1; off >>= 1)
+        {
+            if (threadIdx.x < (unsigned)off)
+                part[threadIdx.x] += part[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 1023)
+            carry[0] = c0 + incl;
+        if (threadIdx.x == 0)
+            carry[1] += part[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        p.out_count[0] = carry[0];
+        p.out_count[1] = carry[1];
     }
 }
 
 // one thread per run: write survivors (input order) + padding slots
-__global__ __launch_bounds__(256) void select_write_kernel(SelectParams p, uint64_t nruns)
+__global__ __launch_bounds__(kSelBlock) void select_write_kernel(SelectParams p, uint64_t nruns)
 {
-    uint64_t const r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t wave_sums[kSelBlock / 64];
+    uint64_t const r      = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t const mine   = r < nruns ? (uint32_t)p.run_slots[r] : 0u;
+    uint32_t       total  = 0;
+    uint32_t const before = block_exclusive_scan(mine, wave_sums, total);
     if (r >= nruns)
         return;
     uint64_t const lo = r * p.run, hi = min(p.n, lo + p.run);
-    uint64_t       o  = p.run_slots[r];
+    uint64_t       o  = p.block_tot[2 * (uint64_t)blockIdx.x] + before;
     uint32_t       c  = 0;
     Extension      last{};
     for (uint64_t i = lo; i < hi; ++i)
@@ -113,15 +184,18 @@ __global__ __launch_bounds__(256) void select_write_kernel(SelectParams p, uint6
     }
 }
 
+// workgroups of the count / write kernels = entries of SelectParams::block_tot (two uint64 each)
+uint64_t select_blocks(uint64_t nruns) { return (nruns + kSelBlock - 1) / kSelBlock; }
+
 hipError_t launch_select(SelectParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipMemsetAsync(p.out_count, 0, 2 * sizeof(uint64_t), stream);
     uint64_t const nruns = (p.n + p.run - 1) / p.run;
-    unsigned const b     = (unsigned)((nruns + 255) / 256);
-    hipLaunchKernelGGL(select_count_kernel, dim3(b), dim3(256), 0, stream, p, nruns);
-    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, stream, p, nruns);
-    hipLaunchKernelGGL(select_write_kernel, dim3(b), dim3(256), 0, stream, p, nruns);
+    unsigned const b     = (unsigned)select_blocks(nruns);
+    hipLaunchKernelGGL(select_count_kernel, dim3(b), dim3(kSelBlock), 0, stream, p, nruns);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(1), dim3(1024), 0, stream, p, (uint64_t)b);
+    hipLaunchKernelGGL(select_write_kernel, dim3(b), dim3(kSelBlock), 0, stream, p, nruns);
     return hipGetLastError();
 }
 
