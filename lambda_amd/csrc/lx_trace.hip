@@ -434,41 +434,19 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         p.out_hsp[oi] = out;
         return;
     }
-    uint8_t const *  q   = p.q_res + x.q_off;
-    uint8_t const *  s   = p.s_res + x.s_off;
     uint32_t const * tr  = p.trace + e * p.slot_stride;
     uint8_t *        ops = p.out_ops + p.ops_off[oi];
     uint32_t const   cap = x.q_len + x.s_len;
 
+    // The walk is serial per extension and every lane of the wavefront is at a different point of its own walk, so
+    // a step must cost few instructions (all branches of a step are executed by the wavefront) and few scattered memory
+    // requests: the position is kept as (panel, lane g, column c in the lane) and updated incrementally; one 16-byte
+    // quad of direction words serves up to four moves (a diagonal or vertical move goes one step back in the same lane);
+    // residues come from two register-cached aligned 16-byte groups, the matrix from LDS; op bytes are collected into
+    // whole dwords before they are stored; all bookkeeping is 32-bit offsets.
+    //
     // the cell's 4 direction bits: [1:0] = source of H (3 diagonal, 2 vertical gap, 1 horizontal gap),
-    // [2] = the horizontal gap of the next column EXTENDS this cell's, [3] = the vertical gap of the row below does
-    // one 16-byte load holds word x of the kTraceBlock (= 4) consecutive steps of a lane: a diagonal or vertical move
-    // goes one step back in the same lane, so the cached quad serves up to four moves
-    uint64_t tq_at = ~uint64_t(0);
-    uint4    tq{};
-    auto nibble = [&](int i, int j) -> uint32_t
-    {
-        int const      panel = j / P, r = j - panel * P;
-        int const      g = r / C, c = r - g * C;
-        int const      x = c >> 3, cx = c & 7;
-        int const      cnt = (x == TW::kWords - 1) ? (C - 8 * x) : 8; // cells held by this word
-        uint32_t const k   = (uint32_t)(i + g);
-        uint64_t const at  = (((uint64_t)panel * (p.steps_cap / kTraceBlock) + k / kTraceBlock) * G + g) * TW::kWords + x;
-        if (at != tq_at)
-        {
-            tq_at = at;
-            tq    = reinterpret_cast<uint4 const *>(tr)[at];
-        }
-        uint32_t const kk   = k % kTraceBlock;
-        uint32_t const lo   = (kk & 1) ? tq.y : tq.x, hi = (kk & 1) ? tq.w : tq.z;
-        uint32_t const word = (kk & 2) ? hi : lo;
-        return (word >> (32 - 4 * cnt + 4 * cx)) & 15u;
-    };
-
-    // The walk is bound by the number of scattered memory accesses (0.24 G steps per headline batch), so each step
-    // touches as little as possible: one direction word (consecutive steps of a lane share a cache line), residues
-    // from two register-cached aligned dwords (refilled every 4th step), the score matrix from LDS, and the op
-    // bytes collected into whole dwords before they are stored.
+    // [2] = the horizontal gap of the next column EXTENDS this cell's, [3] = the vertical gap of the row below does.
     // mode F / E = "the gap character emitted last still has to be classified": this cell's bit 3 / 2 says
     // whether that gap EXTENDS this cell's gap state (then this cell is a gap cell too) or OPENED from its H.
     int      i = ec.s_end - 1, j = ec.q_end - 1;
@@ -478,61 +456,77 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     uint32_t n    = 0;
     int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
 
-    uintptr_t const qa = reinterpret_cast<uintptr_t>(q), sa = reinterpret_cast<uintptr_t>(s);
-    uintptr_t       qw_at = ~uintptr_t(0), sw_at = ~uintptr_t(0);
-    uint4           qw{}, sw{}; // 16 residues each, aligned (device buffers are 256-byte aligned: never before the base)
-    auto byte_of = [](uint4 const & v, uintptr_t addr) -> uint32_t
-    {
-        uint32_t const d  = (uint32_t)(addr >> 2) & 3u;
-        uint32_t const lo = (d & 1) ? v.y : v.x, hi = (d & 1) ? v.w : v.z;
-        return (((d & 2) ? hi : lo) >> (8 * (addr & 3))) & (kAlph - 1);
-    };
+    // position of column j in the strip geometry
+    int panel = j / P;
+    int g     = (j - panel * P) / C;
+    int c     = j - panel * P - g * C;
+    uint32_t const blocks_per_panel = p.steps_cap / kTraceBlock;
 
-    // ops are produced end -> begin; `wpos` is the address of the next byte to write
-    uintptr_t wpos = reinterpret_cast<uintptr_t>(ops) + cap - 1;
-    uint32_t  acc = 0;       // bytes of the dword that contains wpos, collected so far
-    bool      acc_full = (wpos & 3) == 3; // the collection started at the dword's top byte
+    uint32_t tq_at = 0xffffffffu; // index of the cached quad (uint4 units inside the slot)
+    uint4    tq{};
+
+    // residues: aligned 16-byte groups, addressed by 32-bit offsets from the aligned base (device buffers are 16-byte
+    // aligned: never before the base)
+    uintptr_t const q_al = reinterpret_cast<uintptr_t>(p.q_res + x.q_off) & ~uintptr_t(15), s_al = reinterpret_cast<uintptr_t>(p.s_res + x.s_off) & ~uintptr_t(15);
+    uint32_t const  q_sh = (uint32_t)(reinterpret_cast<uintptr_t>(p.q_res + x.q_off) & 15), s_sh = (uint32_t)(reinterpret_cast<uintptr_t>(p.s_res + x.s_off) & 15);
+    uint32_t        qg_at = 0xffffffffu, sg_at = 0xffffffffu;
+    uint32_t        qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0;
+
+    // ops are produced end -> begin into the slot [0, cap); `pos` is the slot offset of the next byte to write and
+    // `a0` the misalignment of the slot start, so that (a0 + pos) & 3 is the byte lane inside its aligned dword
+    uint32_t const  a0     = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
+    uint8_t * const ops_al = ops - a0;
+    uint32_t        apos   = a0 + cap - 1; // a0 + pos
+    uint32_t        acc    = 0;            // bytes of the dword that contains the write position, collected so far
     auto emit = [&](uint32_t op)
     {
-        uint32_t const lane_byte = (uint32_t)(wpos & 3);
-        acc |= op << (8 * lane_byte);
-        if (lane_byte == 0)
+        acc |= op << (8 * (apos & 3));
+        if ((apos & 3) == 0)
         {
-            if (acc_full)
-                *reinterpret_cast<uint32_t *>(wpos) = acc;
-            else // partial top dword of the slot: the bytes above belong to the next slot
-                for (uintptr_t a = wpos; (a & 3) != 0 || a == wpos; ++a)
-                {
-                    if (a > reinterpret_cast<uintptr_t>(ops) + cap - 1)
-                        break;
-                    *reinterpret_cast<uint8_t *>(a) = (uint8_t)(acc >> (8 * (a & 3)));
-                    if ((a & 3) == 3)
-                        break;
-                }
-            acc      = 0;
-            acc_full = true;
+            // whole dword collected; only the topmost dword of the slot can reach beyond the slot end
+            if (apos + 3 <= a0 + cap - 1)
+                *reinterpret_cast<uint32_t *>(ops_al + apos) = acc;
+            else
+                for (uint32_t b = 0; b < 4 && apos + b <= a0 + cap - 1; ++b)
+                    ops_al[apos + b] = (uint8_t)(acc >> (8 * b));
+            acc = 0;
         }
-        --wpos;
+        --apos;
         ++n;
+    };
+    auto step_left = [&]() // j - 1
+    {
+        --j;
+        if (--c < 0)
+        {
+            c = C - 1;
+            if (--g < 0)
+            {
+                g = G - 1;
+                --panel;
+            }
+        }
     };
 
     while (i >= 0 && j >= 0 && n < cap)
     {
-        uint32_t const  nib = nibble(i, j);
-        uintptr_t const qaddr = qa + (uint32_t)j, saddr = sa + (uint32_t)i;
-        if ((qaddr & ~uintptr_t(15)) != qw_at)
+        // ---- this cell's nibble
+        int const      xw  = c >> 3;
+        uint32_t const k   = (uint32_t)(i + g);
+        uint32_t const at  = (((uint32_t)panel * blocks_per_panel + k / kTraceBlock) * G + (uint32_t)g) * TW::kWords + (uint32_t)xw;
+        if (at != tq_at)
         {
-            qw_at = qaddr & ~uintptr_t(15);
-            qw    = *reinterpret_cast<uint4 const *>(qw_at);
+            tq_at = at;
+            tq    = reinterpret_cast<uint4 const *>(tr)[at];
         }
-        if ((saddr & ~uintptr_t(15)) != sw_at)
-        {
-            sw_at = saddr & ~uintptr_t(15);
-            sw    = *reinterpret_cast<uint4 const *>(sw_at);
-        }
+        uint32_t const lo2  = (k & 1) ? tq.y : tq.x, hi2 = (k & 1) ? tq.w : tq.z;
+        uint32_t const word = (k & 2) ? hi2 : lo2;
+        int const      cnt  = (xw == TW::kWords - 1) ? (C - 8 * xw) : 8; // cells held by this word
+        uint32_t const nib  = (word >> (32 - 4 * cnt + 4 * (c & 7))) & 15u;
+
         if (mode == 1)
         {
-            if ((nib >> 3) & 1u)
+            if (nib & 8u)
             {
                 gx += 1;
                 left -= ge;
@@ -546,12 +540,12 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         }
         else if (mode == 2)
         {
-            if ((nib >> 2) & 1u)
+            if (nib & 4u)
             {
                 gx += 1;
                 left -= ge;
                 emit('I');
-                --j;
+                step_left();
                 continue;
             }
             go += 1;
@@ -563,7 +557,22 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         uint32_t const code = nib & 3u;
         if (code == 3)
         {
-            uint32_t const c0 = byte_of(qw, qaddr), c1 = byte_of(sw, saddr);
+            uint32_t const qi = q_sh + (uint32_t)j, si = s_sh + (uint32_t)i;
+            if ((qi >> 4) != qg_at)
+            {
+                qg_at = qi >> 4;
+                uint4 const v = *reinterpret_cast<uint4 const *>(q_al + ((uintptr_t)qg_at << 4));
+                qw0 = v.x; qw1 = v.y; qw2 = v.z; qw3 = v.w;
+            }
+            if ((si >> 4) != sg_at)
+            {
+                sg_at = si >> 4;
+                uint4 const v = *reinterpret_cast<uint4 const *>(s_al + ((uintptr_t)sg_at << 4));
+                sw0 = v.x; sw1 = v.y; sw2 = v.z; sw3 = v.w;
+            }
+            uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
+            uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
+            uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
             int const      v       = smat[c0 * kAlph + c1];
             bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
             nm += isMatch;
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
             left -= v;
             emit('M');
             --i;
-            --j;
+            step_left();
         }
         else if (code == 2)
         {
@@ -585,15 +594,16 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         {
             left -= ge;
             emit('I');
-            --j;
+            step_left();
             mode = 2;
         }
     }
     if (mode != 0)
         go += 1; // ran into the border right after a gap character: it can only have been an opening
     // flush the bytes collected in the lowest, partial dword
-    for (uintptr_t a = wpos + 1; (a & 3) != 0 && a <= reinterpret_cast<uintptr_t>(ops) + cap - 1; ++a)
-        *reinterpret_cast<uint8_t *>(a) = (uint8_t)(acc >> (8 * (a & 3)));
+    if ((apos & 3) != 3)
+        for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
+            ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
 
     out.score              = ec.score;
     out.q_begin            = j + 1;
