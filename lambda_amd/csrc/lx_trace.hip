@@ -52,6 +52,19 @@ constexpr int kTraceBlock = LX_TRACE_BLOCK;
 #define LX_TRACE_UNROLL_N(n) LX_TRACE_PRAGMA(unroll n)
 #define LX_TRACE_UNROLL_PRAGMA LX_TRACE_UNROLL_N(LX_TRACE_UNROLL)
 static_assert(kTraceBlock == 4, "the backtrace reads one uint4 = word x of four consecutive steps");
+// kLaneBlocks consecutive step blocks of one lane are adjacent in memory (kLaneBlocks * kWords quads).  With 2 or 4
+// the backtrace finds its next quads in the cache line it already fetched (2.83 -> 2.79 / 2.68 ms on the headline
+// batch) but a store instruction of the forward kernel touches more lines (17.5 -> 18.0 / 18.9 ms): 1 it is.
+#ifndef LX_TRACE_LANE_BLOCKS
+#define LX_TRACE_LANE_BLOCKS 1
+#endif
+constexpr int kLaneBlocks = LX_TRACE_LANE_BLOCKS;
+// index (uint4 units inside one panel of a slot) of word x of step block kb of lane g
+template <int G, int kWords>
+__device__ __forceinline__ uint32_t quad_index(uint32_t kb, uint32_t g, uint32_t x)
+{
+    return ((kb / kLaneBlocks) * G + g) * (kLaneBlocks * kWords) + (kb % kLaneBlocks) * kWords + x;
+}
 
 template <int C>
 struct TraceWords
@@ -349,10 +362,14 @@ LX_TRACE_UNROLL_PRAGMA // one step already holds C independent cells; unrolling 
             __builtin_amdgcn_wave_barrier();
             if (store_trace)
             {
-                uint4 * dst = reinterpret_cast<uint4 *>(trp + ((uint32_t)k0 / kTraceBlock) * (G * kTraceBlock * TW::kWords));
+                uint4 * dst = reinterpret_cast<uint4 *>(trp);
 #pragma unroll
                 for (int x = 0; x < TW::kWords; ++x)
-                    dst[x * G + g] = reinterpret_cast<uint4 const *>(stage)[x * G + g];
+                {
+                    uint32_t const ch = (uint32_t)(x * G + g); // staged quad ch = word ch % kWords of lane ch / kWords
+                    dst[quad_index<G, TW::kWords>((uint32_t)k0 / kTraceBlock, ch / TW::kWords, ch % TW::kWords)] =
+                        reinterpret_cast<uint4 const *>(stage)[ch];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -513,7 +530,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         // ---- this cell's nibble
         int const      xw  = c >> 3;
         uint32_t const k   = (uint32_t)(i + g);
-        uint32_t const at  = (((uint32_t)panel * blocks_per_panel + k / kTraceBlock) * G + (uint32_t)g) * TW::kWords + (uint32_t)xw;
+        uint32_t const at  = (uint32_t)panel * (blocks_per_panel * G * TW::kWords) + quad_index<G, TW::kWords>(k / kTraceBlock, (uint32_t)g, (uint32_t)xw);
         if (at != tq_at)
         {
             tq_at = at;
@@ -524,19 +541,27 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         int const      cnt  = (xw == TW::kWords - 1) ? (C - 8 * xw) : 8; // cells held by this word
         uint32_t const nib  = (word >> (32 - 4 * cnt + 4 * (c & 7))) & 15u;
 
+        // one emit and one position update per iteration, whatever the move: the wavefront executes every branch some
+        // lane takes, so the branches only pick small values
+        uint32_t op      = 0;
+        bool     up      = false, lft = false; // i - 1, j - 1
+        bool     decided = false;
         if (mode == 1)
         {
             if (nib & 8u)
             {
                 gx += 1;
                 left -= ge;
-                emit('D');
-                --i;
-                continue;
+                op      = 'D';
+                up      = true;
+                decided = true;
             }
-            go += 1;
-            left -= g2;
-            mode = 0;
+            else
+            {
+                go += 1;
+                left -= g2;
+                mode = 0;
+            }
         }
         else if (mode == 2)
         {
@@ -544,59 +569,64 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
             {
                 gx += 1;
                 left -= ge;
-                emit('I');
-                step_left();
-                continue;
+                op      = 'I';
+                lft     = true;
+                decided = true;
             }
-            go += 1;
-            left -= g2;
-            mode = 0;
-        }
-        if (left <= 0)
-            break; // the emitted columns add up to the score: H of this cell is 0, the alignment begins after it
-        uint32_t const code = nib & 3u;
-        if (code == 3)
-        {
-            uint32_t const qi = q_sh + (uint32_t)j, si = s_sh + (uint32_t)i;
-            if ((qi >> 4) != qg_at)
+            else
             {
-                qg_at = qi >> 4;
-                uint4 const v = *reinterpret_cast<uint4 const *>(q_al + ((uintptr_t)qg_at << 4));
-                qw0 = v.x; qw1 = v.y; qw2 = v.z; qw3 = v.w;
+                go += 1;
+                left -= g2;
+                mode = 0;
             }
-            if ((si >> 4) != sg_at)
+        }
+        if (!decided)
+        {
+            if (left <= 0)
+                break; // the emitted columns add up to the score: H of this cell is 0, the alignment begins after it
+            uint32_t const code = nib & 3u;
+            if (code == 3)
             {
-                sg_at = si >> 4;
-                uint4 const v = *reinterpret_cast<uint4 const *>(s_al + ((uintptr_t)sg_at << 4));
-                sw0 = v.x; sw1 = v.y; sw2 = v.z; sw3 = v.w;
+                uint32_t const qi = q_sh + (uint32_t)j, si = s_sh + (uint32_t)i;
+                if ((qi >> 4) != qg_at)
+                {
+                    qg_at = qi >> 4;
+                    uint4 const v = *reinterpret_cast<uint4 const *>(q_al + ((uintptr_t)qg_at << 4));
+                    qw0 = v.x; qw1 = v.y; qw2 = v.z; qw3 = v.w;
+                }
+                if ((si >> 4) != sg_at)
+                {
+                    sg_at = si >> 4;
+                    uint4 const v = *reinterpret_cast<uint4 const *>(s_al + ((uintptr_t)sg_at << 4));
+                    sw0 = v.x; sw1 = v.y; sw2 = v.z; sw3 = v.w;
+                }
+                uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
+                uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
+                uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
+                int const      v       = smat[c0 * kAlph + c1];
+                bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
+                nm += isMatch;
+                nx += !isMatch;
+                np += (v > 0);
+                left -= v;
+                op  = 'M';
+                up  = true;
+                lft = true;
             }
-            uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
-            uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
-            uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
-            int const      v       = smat[c0 * kAlph + c1];
-            bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
-            nm += isMatch;
-            nx += !isMatch;
-            np += (v > 0);
-            left -= v;
-            emit('M');
-            --i;
+            else
+            {
+                left -= ge;
+                bool const vert = code == 2;
+                op   = vert ? 'D' : 'I';
+                up   = vert;
+                lft  = !vert;
+                mode = vert ? 1 : 2;
+            }
+        }
+        emit(op);
+        i -= up ? 1 : 0;
+        if (lft)
             step_left();
-        }
-        else if (code == 2)
-        {
-            left -= ge;
-            emit('D');
-            --i;
-            mode = 1;
-        }
-        else
-        {
-            left -= ge;
-            emit('I');
-            step_left();
-            mode = 2;
-        }
     }
     if (mode != 0)
         go += 1; // ran into the border right after a gap character: it can only have been an opening
