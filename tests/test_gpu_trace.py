@@ -413,3 +413,36 @@ def test_full_size_fused_step_properties(handle, oracle):
         st = int(off[i]) + int(row[11])
         got = bytes(d_ops[st: st + oh.n_ops].cpu().numpy())
         assert got == oops, i
+
+
+def test_published_smith_waterman_example(handle):
+    """The worked example of the Smith-Waterman article (TGTTACGG vs GGTTGACTA, +3 / -3, linear gap penalty 2): score 13,
+    alignment GTT-AC / GTTGAC -- through the HIP kernels with a caller-supplied matrix, both orientations, and in a
+    batch long enough to use the packed-half and shared-profile geometries as well."""
+    import ctypes as C
+
+    sc = capi.Scoring()
+    sc.alphabet_size, sc.gap_open, sc.gap_extend = 4, -2, -2
+    m = np.full((capi.LX_ALPH, capi.LX_ALPH), 0, dtype=np.int8)
+    m[:4, :4] = -3
+    m[np.arange(4), np.arange(4)] = 3
+    C.memmove(sc.matrix, m.ctypes.data, m.nbytes)
+    handle.set_scoring(sc, 0)
+    try:
+        idx = {c: i for i, c in enumerate("ACGT")}
+        q = np.array([idx[c] for c in "TGTTACGG"], dtype=np.uint8)
+        s = np.array([idx[c] for c in "GGTTGACTA"], dtype=np.uint8)
+        res = np.concatenate([q, s])
+        ext = np.zeros(32, dtype=capi.EXT_DTYPE)
+        ext["q_off"], ext["q_len"], ext["s_off"], ext["s_len"] = 0, 8, 8, 9
+        ext[16:]["q_off"], ext[16:]["q_len"], ext[16:]["s_off"], ext[16:]["s_len"] = 8, 9, 0, 8   # roles swapped
+        scores = handle.score_batch(res, res, ext)
+        assert (scores == 13).all()
+        hsp, ops = handle.align_batch(res, res, ext, known_score=scores)
+        for k in range(16):
+            assert tuple(int(hsp[k][f]) for f in ("score", "q_begin", "q_end", "s_begin", "s_end")) == (13, 1, 6, 1, 7)
+            assert ops[k] == b"MMMDMM"
+            assert tuple(int(hsp[16 + k][f]) for f in ("score", "q_begin", "q_end", "s_begin", "s_end")) == (13, 1, 7, 1, 6)
+            assert ops[16 + k] == b"MMMIMM"
+    finally:
+        handle.set_scoring(SCHEMES["blosum62"], 0)

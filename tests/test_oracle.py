@@ -242,3 +242,34 @@ def test_blast_statistics(oracle):
     assert abs(oracle.bitscore(100, ka) - (0.267 * 100 - math.log(0.041)) / math.log(2)) < 1e-12
     # tiny search space: c < 0 -> no adjustment
     assert oracle.length_adjustment(10, 5, ka) == 0
+
+
+def test_published_known_answers(oracle):
+    """Known answers from outside this repository (the reference's own goldens are not on disk):
+    (1) the worked Smith-Waterman example of the textbook / Wikipedia article -- TGTTACGG vs GGTTGACTA, match +3,
+        mismatch -3, linear gap penalty 2 -- whose optimal local alignment is GTT-AC / GTTGAC with score 13;
+    (2) raw score / bit score pairs every BLASTP report with BLOSUM62, gaps 11/1 shows (lambda 0.267, K 0.041):
+        "28.9 bits (63)", "32.0 bits (71)", "47.8 bits (112)"."""
+    idx = {c: i for i, c in enumerate("ACGT")}
+    enc = lambda t: np.array([idx[c] for c in t], dtype=np.uint8)
+    m = np.full((4, 4), -3, dtype=np.int8)
+    np.fill_diagonal(m, 3)
+    sc = oracle_lib.make_scoring(4, m, -2, -2)  # linear gap penalty 2 = first character -2, every further one -2
+    q, s = enc("TGTTACGG"), enc("GGTTGACTA")
+    hsp, ops = oracle.align(q, s, sc)
+    assert hsp.score == 13 and ops == b"MMMDMM"  # the gap is in the query row (GTT-AC)
+    assert (hsp.q_begin, hsp.q_end, hsp.s_begin, hsp.s_end) == (1, 6, 1, 7)
+    assert oracle.score(q, s, sc)[0] == 13 and int(brute.sw_general(q, s, m.astype(int), -2, -2).max()) == 13
+    # the same with the roles swapped: the gap moves to the subject row
+    hsp2, ops2 = oracle.align(s, q, sc)
+    assert hsp2.score == 13 and ops2 == b"MMMIMM"
+
+    ka = oracle_lib.Karlin(0.267, 0.041, 0.14, 1.9, -30.0)
+    cka = capi.karlin_params(62, gap_open=-11, gap_extend=-1)
+    assert (cka.lambda_, cka.K) == (0.267, 0.041)
+    lib = capi.load()
+    import ctypes as C
+    lib.lx_bitscore.restype = C.c_double
+    for raw, bits in ((63, 28.9), (71, 32.0), (112, 47.8)):
+        assert round(oracle.bitscore(raw, ka), 1) == bits
+        assert round(lib.lx_bitscore(raw, C.byref(cka)), 1) == bits
