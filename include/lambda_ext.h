@@ -119,8 +119,12 @@ enum
                                    processed in chunks, in order, on the same stream                            */
     LX_OPT_BS_MATCH_RULE   = 6, /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
-    LX_OPT_PACKED_HALF     = 7  /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
+    LX_OPT_PACKED_HALF     = 7, /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
                                    proves it exact (results are bit-identical either way); 0: int32 kernel only */
+    LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical either way):
+                                   0 = 4 direction bits per cell; 1 = strip boundaries + row checkpoints, tiles recomputed
+                                   by the backtrace -- used where its limits hold (query within one panel of a
+                                   shared-profile geometry, scores below 32000), the direction bits otherwise */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 

@@ -35,6 +35,7 @@ LX_OPT_MAX_SLEN = 4
 LX_OPT_TRACE_BYTES = 5
 LX_OPT_BS_MATCH_RULE = 6
 LX_OPT_PACKED_HALF = 7
+LX_OPT_PASS2_MODE = 8
 
 
 class Karlin(C.Structure):

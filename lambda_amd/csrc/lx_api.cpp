@@ -40,6 +40,9 @@ int        trace_cfg_panel(int cfg);
 int        trace_cfg_group(int cfg);
 int        trace_cfg_words(int cfg);
 hipError_t launch_select(SelectParams const & p, hipStream_t stream);
+uint64_t   ckpt_slot_dwords(int cfg, uint32_t steps_cap);
+hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
+hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
@@ -99,6 +102,7 @@ struct lx_handle
     uint64_t opt_trace_bytes = 32ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
+    uint64_t opt_pass2     = 0; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip) where applicable
     uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
@@ -356,6 +360,8 @@ int lx_create(int device_id, lx_handle ** out)
                     prop.gcnArchName);
 
     lx_handle * h = new lx_handle();
+    if (char const * m = getenv("LX_PASS2_MODE")) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
+        h->opt_pass2 = atoi(m) ? 1 : 0;
     h->device     = device_id;
     auto bail     = [&](char const * what, hipError_t err)
     {
@@ -439,6 +445,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_TRACE_BYTES: h->opt_trace_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
         case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
+        case LX_OPT_PASS2_MODE: h->opt_pass2 = value ? 1 : 0; return LX_OK;
         default: return fail(h, LX_EINVAL, "unknown option %d", option);
     }
 }
@@ -923,7 +930,13 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 15) & ~15ull); // multiple of the trace layout block
-    uint64_t const stride     = (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
+    // checkpoint mode (lx_ckpt.hip): single-panel shared-profile geometries, scores that fit int16
+    int smax_entry = 0;
+    for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
+        for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
+            smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+    bool const ckpt = h->opt_pass2 == 1 && cfg != 0 && panels_cap == 1 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
+    uint64_t const stride     = ckpt ? lx::ckpt_slot_dwords(cfg, steps_cap) : (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
     // The forward kernel finds the end cell cheaply when it knows each extension's best score; the fused path hands
     // over pass 1's scores, a stand-alone traceback call computes them first (a fraction of the traceback's cost).
@@ -991,17 +1004,20 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         if (panels_cap > 1) // each chunk starts with an empty carry workspace
             LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
         PhaseTimer ptf(h, stream, 2);
-        LX_HIP(h, lx::launch_trace_forward(p, stream));
+        LX_HIP(h, ckpt ? lx::launch_ckpt_forward(p, stream) : lx::launch_trace_forward(p, stream));
         ptf.close();
         LX_HIP(h, hipEventRecord(h->evF[b], stream));
         LX_HIP(h, hipStreamWaitEvent(bstream, h->evF[b], 0));
         PhaseTimer ptb(h, bstream, 3);
-        LX_HIP(h, lx::launch_backtrace(p, bstream));
+        LX_HIP(h, ckpt ? lx::launch_ckpt_backtrace(p, bstream) : lx::launch_backtrace(p, bstream));
         ptb.close();
         LX_HIP(h, hipEventRecord(h->evB[b], bstream));
         {
             char buf[96];
-            snprintf(buf, sizeof(buf), "lx::trace_forward_kernel<%d,%d,%s>", G, P / G, panels_cap > 1 ? "true" : "false");
+            if (ckpt)
+                snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d>", G, P / G);
+            else
+                snprintf(buf, sizeof(buf), "lx::trace_forward_kernel<%d,%d,%s>", G, P / G, panels_cap > 1 ? "true" : "false");
             h->last_trace_kernel = buf;
         }
     }

@@ -1,0 +1,677 @@
+// lx_ckpt.hip -- pass 2 by checkpoints: an untagged forward DP that stores strip boundaries and periodic row
+// checkpoints, and a backtrace that recomputes one small tile at a time (gfx950 only).
+//
+// Same reference seam as lx_trace.hip (_performAlignment<withTrace=true>, /root/reference/src/search_algo.hpp:1296 ->
+// :1070-1134, TracebackOn<CompleteTrace, GapsLeft>, :1083; _adaptTraceSegmentsTo :1127; computeAlignmentStats :1308).
+// lx_trace.hip pays 18 of its 40 clocks per cell for tags and direction bits of cells no walk ever visits (42 G cells
+// computed, 0.27 G visited on the headline batch).  Here the forward kernel runs the plain row-skewed recurrence of
+// lx_score.hip (int32, 22 clocks per cell) and keeps just enough to restart the DP anywhere:
+//   * boundary array: for every strip (= lane g, C query columns) and every row i the pair
+//         H(i, last column of the strip),  E(i, first column of the next strip)     as two int16, un-skewed;
+//     a lane collects four steps in registers and stores one 16-byte quad -- the G lanes of a group write G
+//     consecutive quads, no LDS staging;
+//   * row checkpoints: every 16 STEPS each lane stores H(i, c) and F(i+1, c) of its C columns (int16 pairs).  Step
+//     k is row k - g for lane g, so every strip has its own row grid and no lane-divergent branch is needed.
+// The end cell is found through the known best score exactly as in lx_trace.hip.  The backtrace kernel (one lane per
+// extension) recomputes the 16 x C tile around its current cell from the checkpoint above it and the boundary array of
+// the strip to its left -- the same recurrence including the floor folded into F, so every value and every tie of
+// the forward pass is reproduced -- keeps the tile's direction nibbles in LDS and walks them with the rules of
+// lx_trace.hip's backtrace until it leaves the tile.
+//
+// Limits (checked by the host, which otherwise uses the direction-bit path): query fits one panel, scores < 32768.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "lx_dp_common.h"
+
+namespace lx
+{
+
+constexpr int kCkptEvery = 16; // steps between two row checkpoints
+
+// slot layout in uint32 units: boundary quads [step / 4][lane] (4 dwords each), then row checkpoints
+// [checkpoint][lane][kCkDw]
+template <int G, int C>
+struct CkptLayout
+{
+    static constexpr int kCkDw = (C + 3) / 4 * 4; // dwords per lane per row checkpoint, whole quads
+    __host__ __device__ static constexpr uint64_t bnd_dwords(uint32_t steps_cap) { return (uint64_t)steps_cap * G; }
+    __host__ __device__ static constexpr uint64_t slot_dwords(uint32_t steps_cap)
+    {
+        return bnd_dwords(steps_cap) + (uint64_t)(steps_cap / kCkptEvery) * G * kCkDw;
+    }
+};
+
+__device__ __forceinline__ uint32_t pack16(int lo, int hi)
+{
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+}
+
+template <int G, int C>
+__global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
+{
+    using Geo = ScoreGeo<G, C>;
+    using Lay = CkptLayout<G, C>;
+    extern __shared__ uint32_t lds[];
+
+    int const  lane     = threadIdx.x;
+    int const  grp      = lane / G;
+    int const  g        = lane % G;
+    bool const is_first = (g == 0);
+
+    uint64_t const e     = (uint64_t)blockIdx.x * Geo::kGroups + grp;
+    uint64_t       limit = p.n;
+    if (p.count_ptr)
+    {
+        uint64_t const total = *p.count_ptr;
+        limit = total > p.chunk_start ? min(p.n, total - p.chunk_start) : 0;
+        if ((uint64_t)blockIdx.x * Geo::kGroups >= limit)
+            return; // whole wavefront beyond the device-side survivor count
+    }
+    bool active = e < limit;
+    if (active && p.src && p.src[e] == 0xffffffffu)
+        active = false; // padding slot (keeps one query per sharing block)
+
+    ScoringDev const * __restrict__ sc = p.sc;
+    int const      ge    = sc->ge;
+    int const      g2    = sc->g2;
+    int const      nrows = p.nrows;
+    uint32_t const padt  = (uint32_t)(nrows - 1);
+
+    int             lq = 0, ls = 0;
+    uint8_t const * q = p.q_res;
+    uint8_t const * s = p.s_res;
+    uint64_t        q_off = 0;
+    bool const      in_list = e < limit;
+    if (in_list)
+    {
+        Extension const x = p.ext[e];
+        lq    = (int)x.q_len;
+        q_off = x.q_off;
+        q += x.q_off;
+        if (active)
+        {
+            ls = (int)x.s_len;
+            if (ls != 0)
+                s += x.s_off;
+        }
+    }
+    // groups that share one LDS profile (see lx_trace.hip): verified against the first lane of the sharing block
+    int const share  = p.shared_profile > 1 ? min(p.shared_profile, Geo::kGroups) : 1;
+    int const leader = (grp / share) * share * G;
+    if (share > 1)
+    {
+        uint32_t const qlo = (uint32_t)__shfl((int)(uint32_t)q_off, leader), qhi = (uint32_t)__shfl((int)(q_off >> 32), leader);
+        int const      l0  = __shfl(lq, leader);
+        bool const     lead_in = __shfl(in_list ? 1 : 0, leader) != 0;
+        if (in_list && lead_in && (q_off != (((uint64_t)qhi << 32) | qlo) || lq != l0))
+            atomicExch(p.err, 2);
+    }
+
+    int ls_max = ls, ls_min = active ? ls : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        ls_max = max(ls_max, __shfl_xor(ls_max, off));
+        ls_min = min(ls_min, __shfl_xor(ls_min, off));
+    }
+    ls_max = __builtin_amdgcn_readfirstlane(ls_max);
+    ls_min = __builtin_amdgcn_readfirstlane(ls_min);
+
+    bool bad = false;
+    if (active && (lq > Geo::kPanel || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
+    {
+        bad = true; // the host sized the slots too small for this extension: report, never write out of bounds
+        atomicExch(p.err, 3);
+    }
+    if (bad)
+        ls = 0;
+
+    int const      slot_dw     = (grp / share) * (nrows * Geo::kRowDw);
+    uint32_t const row_base_dw = (uint32_t)(slot_dw + g);
+    int const      steps       = (ls_max + G - 1 + 3) & ~3;
+    int const      steady_lo   = (G - 1 + 3) & ~3;
+    int const      steady_hi   = ls_min - 3;
+    uint32_t const lsc         = (uint32_t)max(ls, 1) - 1u;
+
+    uint32_t * const slot  = p.trace + e * p.slot_stride;
+    uint4 * const    bnd   = reinterpret_cast<uint4 *>(slot);
+    uint4 * const    rowck = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
+    bool const       store_ok = active && !bad;
+
+    // target score and the best (lowest) column / its first row seen so far in this lane
+    int const tgt  = active ? p.score_in[e] : 0;
+    int       kcol = 0x7fffffff, krow = 0;
+
+    int const col0 = g * C;
+    build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_adj, nrows, grp % share == 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // state as of (virtual) row i = -g - 1: every cell is "H = 0" (lx_score.hip)
+    int z = ge * g;
+    int Hrow[C], F0[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+    {
+        Hrow[c] = z + ge;
+        F0[c]   = z;
+    }
+    int diag0 = z + ge;
+    int sendH = z + ge;
+    int sendE = kNegInf;
+    int g2v = g2, gev = ge; // loop constants in VGPRs: an SGPR operand halves the issue rate (tools/ubench.hip)
+    LX_OPAQUE(g2v);
+    LX_OPAQUE(gev);
+
+    uint8_t const * sp = s - g;
+
+    // one DP step; returns the boundary word of this lane's strip for row k - g
+    auto step = [&](int k, uint32_t t) -> uint32_t
+    {
+        int const        i    = k - g;
+        uint32_t const * prow = lds + (row_base_dw + t * (uint32_t)Geo::kRowDw);
+        uint32_t         pw[Geo::kD];
+#pragma unroll
+        for (int d = 0; d < Geo::kD; ++d)
+            pw[d] = prow[d * G];
+
+        int const recvH = shift_from_left<G>(sendH, z, is_first);
+        int       Ecur  = shift_from_left<G>(sendE, kNegInf, is_first);
+        int       dg    = diag0;
+        diag0           = recvH;
+
+        int const zn     = z - gev;
+        int       rowmax = z;
+        int       h      = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+            int const sub = (int)(int8_t)(pw[c >> 2] >> (8 * (c & 3)));
+            int const tt  = dg + sub;
+            dg            = Hrow[c];
+            h             = max3i(tt, Ecur, F0[c]);
+            LX_OPAQUE(h);
+            int const A   = h + g2v;
+            F0[c]         = max3i(F0[c], A, zn);
+            LX_OPAQUE(F0[c]);
+            Ecur          = max(Ecur, A) + gev;
+            if (c & 1)
+                rowmax = max3i(rowmax, Hrow[c - 1], h); // Hrow[c-1] already holds this row's value
+            else if (c == C - 1)
+                rowmax = max(rowmax, h);
+            Hrow[c] = h;
+        }
+        // rare: some cell of this row reaches the extension's best score -> remember the lowest such column (rows are
+        // visited in increasing order, so the first hit of a column is its lowest row)
+        if (tgt > 0 && rowmax == tgt + z && (unsigned)i < (unsigned)ls)
+        {
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c)
+                if (Hrow[c] == rowmax && col0 + c < kcol)
+                {
+                    kcol = col0 + c;
+                    krow = i;
+                }
+        }
+        sendH = h;
+        sendE = Ecur;
+        // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it
+        int const      eb = max(Ecur - z, -32768);
+        uint32_t const bw = pack16(h - z, eb);
+        z                 = zn;
+        return bw;
+    };
+    // row checkpoint after step k: H(i, c) and the folded F(i+1, c), un-skewed (z already is z_{i+1} here)
+    auto checkpoint = [&](int k)
+    {
+        if (!store_ok)
+            return;
+        uint4 * dst = rowck + ((uint32_t)(k / kCkptEvery) * G + (uint32_t)g) * (Lay::kCkDw / 4);
+        uint32_t w[Lay::kCkDw];
+#pragma unroll
+        for (int c = 0; c < Lay::kCkDw; ++c)
+            w[c] = c < C ? pack16(Hrow[c] - (z + gev), F0[c] - z) : 0u;
+#pragma unroll
+        for (int x = 0; x < Lay::kCkDw / 4; ++x)
+            dst[x] = make_uint4(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3]);
+    };
+
+    auto fetch_checked = [&](int k0, uint32_t (&t)[4])
+    {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            uint32_t const i   = (uint32_t)(k0 + u - g);
+            uint32_t const idx = min(i, lsc);
+            t[u]               = s[idx];
+        }
+    };
+    auto mask_checked = [&](int k0, uint32_t (&t)[4])
+    {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+        {
+            uint32_t const i = (uint32_t)(k0 + u - g);
+            t[u]             = (i < (uint32_t)ls) ? (t[u] & (kAlph - 1)) : padt;
+        }
+    };
+    auto chunk_done = [&](int k0, uint32_t const (&bw)[4])
+    {
+        if (store_ok)
+            bnd[(uint32_t)(k0 / 4) * G + (uint32_t)g] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+        if (((k0 + 3) % kCkptEvery) == kCkptEvery - 1)
+            checkpoint(k0 + 3);
+    };
+
+    int      k0 = 0;
+    uint32_t tn[4];
+    fetch_checked(0, tn);
+    while (k0 < steps)
+    {
+        bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
+        if (!cur_steady)
+        {
+            uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
+            mask_checked(k0, tc);
+            fetch_checked(k0 + 4, tn);
+            uint32_t bw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                bw[u] = step(k0 + u, tc[u]);
+            chunk_done(k0, bw);
+            k0 += 4;
+        }
+        else
+        {
+            uint32_t wn = *reinterpret_cast<unaligned_u32 const *>(sp + k0);
+            while (k0 < steady_hi)
+            {
+                uint32_t const wc = wn;
+                int const      kn = min(k0 + 4, ls_min - 4);
+                wn                = *reinterpret_cast<unaligned_u32 const *>(sp + max(kn, 0));
+                uint32_t bw[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    bw[u] = step(k0 + u, (wc >> (8 * u)) & (kAlph - 1));
+                chunk_done(k0, bw);
+                k0 += 4;
+            }
+            fetch_checked(k0, tn);
+        }
+    }
+
+    // lowest column over the lanes of the group (every lane owns different columns), with its row
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1)
+    {
+        int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
+        bool const take = oc < kcol;
+        kcol = take ? oc : kcol;
+        krow = take ? orow : krow;
+    }
+    if (in_list && is_first)
+    {
+        EndCell ec{};
+        if (bad || (tgt > 0 && kcol == 0x7fffffff))
+            ec.score = -1; // the score of pass 1 was not reproduced: never return a wrong alignment silently
+        else if (tgt > 0)
+        {
+            ec.score = tgt;
+            ec.q_end = kcol + 1;
+            ec.s_end = krow + 1;
+        }
+        p.ends[e] = ec;
+    }
+}
+
+// One lane per extension: recompute the tile around the current cell, walk it, repeat.
+template <int G, int C>
+__global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
+{
+    using Lay               = CkptLayout<G, C>;
+    constexpr int kNibDw    = (C + 7) / 8; // dwords of direction nibbles per tile row
+    constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions
+    __shared__ int8_t   smat[kAlph * kAlph];
+    __shared__ uint32_t tiles[kCkptEvery * kNibDw * 64]; // [tile row][word][lane]: lane-minor, conflict-free
+    for (int x = threadIdx.x; x < kAlph * kAlph / 4; x += blockDim.x)
+        reinterpret_cast<uint32_t *>(smat)[x] = reinterpret_cast<uint32_t const *>(p.sc->mat)[x];
+    __syncthreads();
+    uint32_t const lane  = threadIdx.x;
+    uint64_t const e     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t       limit = p.n;
+    if (p.count_ptr)
+    {
+        uint64_t const total = *p.count_ptr;
+        limit = total > p.chunk_start ? min(p.n, total - p.chunk_start) : 0;
+    }
+    if (e >= limit)
+        return;
+    uint64_t oi = e;
+    if (p.src)
+    {
+        uint32_t const sidx = p.src[e];
+        if (sidx == 0xffffffffu)
+            return; // padding slot
+        oi = sidx;
+    }
+    EndCell const   ec = p.ends[e];
+    Extension const x  = p.ext[e];
+    Hsp             out{};
+    if (ec.score <= 0)
+    {
+        out.score = ec.score < 0 ? -1 : 0;
+        p.out_hsp[oi] = out;
+        return;
+    }
+    uint32_t const * slot  = p.trace + e * p.slot_stride;
+    uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);
+    uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + Lay::bnd_dwords(p.steps_cap));
+    uint8_t const *  q     = p.q_res + x.q_off;
+    uint8_t const *  s     = p.s_res + x.s_off;
+    uint8_t *        ops   = p.out_ops + p.ops_off[oi];
+    uint32_t const   cap   = x.q_len + x.s_len;
+    int const        lq    = (int)x.q_len;
+    int const        ge = p.sc->ge, go_first = p.sc->go, g2 = p.sc->g2; // a gap of k characters costs g2 + k ge = go_first + (k-1) ge
+
+    int      i = ec.s_end - 1, j = ec.q_end - 1;
+    int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
+    int      left = ec.score;
+    uint32_t n    = 0;
+    int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
+
+    // residues for the match / mismatch counts: aligned 16-byte groups (see lx_trace.hip)
+    uintptr_t const q_al = reinterpret_cast<uintptr_t>(q) & ~uintptr_t(15), s_al = reinterpret_cast<uintptr_t>(s) & ~uintptr_t(15);
+    uint32_t const  q_sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 15), s_sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 15);
+    uint32_t        qg_at = 0xffffffffu, sg_at = 0xffffffffu;
+    uint32_t        qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0;
+
+    uint32_t const  a0     = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
+    uint8_t * const ops_al = ops - a0;
+    uint32_t        apos   = a0 + cap - 1;
+    uint32_t        acc    = 0;
+    auto emit = [&](uint32_t op)
+    {
+        acc |= op << (8 * (apos & 3));
+        if ((apos & 3) == 0)
+        {
+            if (apos + 3 <= a0 + cap - 1)
+                *reinterpret_cast<uint32_t *>(ops_al + apos) = acc;
+            else
+                for (uint32_t b = 0; b < 4 && apos + b <= a0 + cap - 1; ++b)
+                    ops_al[apos + b] = (uint8_t)(acc >> (8 * b));
+            acc = 0;
+        }
+        --apos;
+        ++n;
+    };
+
+    bool done = false;
+    while (!done && i >= 0 && j >= 0 && n < cap)
+    {
+        // ---- the tile of the current cell: strip st, step block m (step k = row + strip)
+        int const st = j / C, j0 = st * C;
+        int const m  = (i + st) / kCkptEvery;
+        int const k_base = m * kCkptEvery;  // first step of the block
+        int const r_base = k_base - st;     // row of tile row 0 (may be negative in block 0: virtual rows)
+
+        // top edge: H(r_base - 1, c) and the folded F(r_base, c)
+        int Hp[C], F[C];
+        if (m == 0)
+        {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+            {
+                Hp[c] = 0;
+                F[c]  = 0;
+            }
+        }
+        else
+        {
+            uint4 const * src = rowck + ((uint32_t)(m - 1) * G + (uint32_t)st) * (Lay::kCkDw / 4);
+            uint32_t      w[Lay::kCkDw];
+#pragma unroll
+            for (int xq = 0; xq < Lay::kCkDw / 4; ++xq)
+            {
+                uint4 const v = src[xq];
+                w[4 * xq] = v.x; w[4 * xq + 1] = v.y; w[4 * xq + 2] = v.z; w[4 * xq + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+            {
+                Hp[c] = (int)(int16_t)(w[c] & 0xffffu);
+                F[c]  = (int)(int16_t)(w[c] >> 16);
+            }
+        }
+        // LDS offsets of the matrix rows of this strip's query residues (columns beyond the query use the pad rank)
+        uint32_t qoff[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+            uint32_t const r = (j0 + c < lq) ? (uint32_t)(q[j0 + c] & (kAlph - 1)) : (uint32_t)(kAlph - 1);
+            qoff[c]          = r * kAlph;
+        }
+        // left edge: the boundary words of strip st - 1 for the steps k_base - 2 ... (word of step k - 1 holds E for
+        // this strip's row k - st, the word of step k - 2 the diagonal H); quads are indexed by step / 4
+        bool const has_left = st > 0;
+        auto load_bq = [&](int qd) -> uint4 // quad of steps 4 qd .. 4 qd + 3 of strip st - 1
+        {
+            if (!has_left || qd < 0)
+                return make_uint4(0, 0, 0, 0);
+            return bnd[(uint32_t)qd * G + (uint32_t)(st - 1)];
+        };
+        int const qd0   = k_base / 4; // quad that holds step k_base
+        uint4     qprev = load_bq(qd0 - 1), qcur = load_bq(qd0);
+
+        bool rows_left = true;
+#pragma unroll 1
+        for (int t = 0; t < kCkptEvery / 4 && rows_left; ++t)
+        {
+            uint4 const qnext = load_bq(qd0 + t + 1); // needed by the next iteration
+            // subject letters of the 4 rows r_base + 4t ... (rows < 0 are virtual and skipped)
+            int const      row0 = r_base + 4 * t;
+            int const      lb   = max(row0, 0);
+            uint32_t const sdw  = *reinterpret_cast<unaligned_u32 const *>(s + lb);
+            // boundary words by tile row u: (left word = step k-1, diagonal word = step k-2)
+            uint32_t const lw[4] = {qprev.w, qcur.x, qcur.y, qcur.z};
+            uint32_t const dw[4] = {qprev.z, qprev.w, qcur.x, qcur.y};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                int const row = row0 + u;
+                if (row > i)
+                {
+                    rows_left = false;
+                    break;
+                }
+                if (row < 0)
+                    continue; // virtual row of block 0: H = 0, F = floor stay as they are
+                uint32_t const tl = (sdw >> (8 * (row - lb))) & (kAlph - 1);
+                int            E  = has_left ? (int)(int16_t)(lw[u] >> 16) : kFar;
+                int            Hd = (has_left && row > 0) ? (int)(int16_t)(dw[u] & 0xffffu) : 0;
+                uint32_t       w[kNibDw];
+#pragma unroll
+                for (int xw = 0; xw < kNibDw; ++xw)
+                    w[xw] = 0;
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                {
+                    int const sc_ = smat[qoff[c] + tl];
+                    int const tt  = Hd + sc_;
+                    int const H   = max3i(tt, E, F[c]);
+                    uint32_t  nib = (tt == H) ? 3u : ((F[c] == H) ? 2u : 1u);
+                    int const A   = H + go_first;
+                    int const Fe  = F[c] + ge, Ee = E + ge;
+                    nib |= (Ee >= A) ? 4u : 0u; // the horizontal gap of the next column extends this cell's
+                    nib |= (Fe >= A) ? 8u : 0u; // the vertical gap of the row below extends this cell's
+                    F[c] = max3i(Fe, A, 0);
+                    E    = max(Ee, A);
+                    Hd   = Hp[c];
+                    Hp[c] = H;
+                    w[c >> 3] |= nib << (4 * (c & 7));
+                }
+                int const kk = 4 * t + u;
+#pragma unroll
+                for (int xw = 0; xw < kNibDw; ++xw)
+                    tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
+            }
+            qprev = qcur;
+            qcur  = qnext;
+        }
+
+        // ---- walk inside the tile
+        while (i >= 0 && j >= j0 && i >= r_base && n < cap)
+        {
+            int const      kk  = i - r_base, c = j - j0;
+            uint32_t const nib = (tiles[(kk * kNibDw + (c >> 3)) * 64 + lane] >> (4 * (c & 7))) & 15u;
+            uint32_t op      = 0;
+            bool     up      = false, lft = false;
+            bool     decided = false;
+            if (mode == 1)
+            {
+                if (nib & 8u)
+                {
+                    gx += 1;
+                    left -= ge;
+                    op      = 'D';
+                    up      = true;
+                    decided = true;
+                }
+                else
+                {
+                    go += 1;
+                    left -= g2;
+                    mode = 0;
+                }
+            }
+            else if (mode == 2)
+            {
+                if (nib & 4u)
+                {
+                    gx += 1;
+                    left -= ge;
+                    op      = 'I';
+                    lft     = true;
+                    decided = true;
+                }
+                else
+                {
+                    go += 1;
+                    left -= g2;
+                    mode = 0;
+                }
+            }
+            if (!decided)
+            {
+                if (left <= 0)
+                {
+                    done = true; // H of this cell is 0: the alignment begins after it
+                    break;
+                }
+                uint32_t const code = nib & 3u;
+                if (code == 3)
+                {
+                    uint32_t const qi = q_sh + (uint32_t)j, si = s_sh + (uint32_t)i;
+                    if ((qi >> 4) != qg_at)
+                    {
+                        qg_at = qi >> 4;
+                        uint4 const v = *reinterpret_cast<uint4 const *>(q_al + ((uintptr_t)qg_at << 4));
+                        qw0 = v.x; qw1 = v.y; qw2 = v.z; qw3 = v.w;
+                    }
+                    if ((si >> 4) != sg_at)
+                    {
+                        sg_at = si >> 4;
+                        uint4 const v = *reinterpret_cast<uint4 const *>(s_al + ((uintptr_t)sg_at << 4));
+                        sw0 = v.x; sw1 = v.y; sw2 = v.z; sw3 = v.w;
+                    }
+                    uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
+                    uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
+                    uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
+                    int const      v       = smat[c0 * kAlph + c1];
+                    bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
+                    nm += isMatch;
+                    nx += !isMatch;
+                    np += (v > 0);
+                    left -= v;
+                    op  = 'M';
+                    up  = true;
+                    lft = true;
+                }
+                else
+                {
+                    left -= ge;
+                    bool const vert = code == 2;
+                    op   = vert ? 'D' : 'I';
+                    up   = vert;
+                    lft  = !vert;
+                    mode = vert ? 1 : 2;
+                }
+            }
+            emit(op);
+            i -= up ? 1 : 0;
+            j -= lft ? 1 : 0;
+        }
+    }
+    if (mode != 0)
+        go += 1; // ran into the border right after a gap character: it can only have been an opening
+    if ((apos & 3) != 3)
+        for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
+            ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
+
+    out.score              = ec.score;
+    out.q_begin            = j + 1;
+    out.q_end              = ec.q_end;
+    out.s_begin            = i + 1;
+    out.s_end              = ec.s_end;
+    out.n_ops              = (int32_t)n;
+    out.num_matches        = nm;
+    out.num_mismatches     = nx;
+    out.num_positives      = np;
+    out.num_gap_opens      = go;
+    out.num_gap_extensions = gx;
+    out.ops_shift          = (int32_t)(cap - n);
+    p.out_hsp[oi]          = out;
+}
+
+// ---- host-visible launchers: checkpoint geometries follow the trace geometries (cfg 1 = (8,19), cfg 2 = (16,13)) --------
+
+uint64_t ckpt_slot_dwords(int cfg, uint32_t steps_cap)
+{
+    return cfg == 2 ? CkptLayout<16, 13>::slot_dwords(steps_cap) : CkptLayout<8, 19>::slot_dwords(steps_cap);
+}
+
+template <int G, int C>
+static hipError_t launch_ckpt_forward_cfg(TraceParams const & p, hipStream_t stream)
+{
+    using Geo = ScoreGeo<G, C>;
+    uint64_t const blocks = (p.n + Geo::kGroups - 1) / Geo::kGroups;
+    if (blocks > 0x7fffffffull || !p.score_in || p.steps_cap % kCkptEvery != 0)
+        return hipErrorInvalidValue;
+    int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
+    int const    slots = (Geo::kGroups + share - 1) / share;
+    size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    hipLaunchKernelGGL((ckpt_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    return p.cfg == 2 ? launch_ckpt_forward_cfg<16, 13>(p, stream) : launch_ckpt_forward_cfg<8, 19>(p, stream);
+}
+
+hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    uint64_t const b2 = (p.n + 63) / 64;
+    if (p.cfg == 2)
+        hipLaunchKernelGGL((ckpt_backtrace_kernel<16, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    else
+        hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 19>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace lx
