@@ -327,16 +327,25 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
 }
 
 // One lane per extension: recompute the tile around the current cell, walk it, repeat.
+// The tile DP uses the tagged arithmetic of lx_trace.hip (values x 4, the two low bits resolve the traceback ties) in
+// its plain, un-skewed form:  tt = 4 H(i-1,j-1) + (4 s + 3);  m = max3(tt, E|1, F|2);  H = m & ~3;  A = H + 4 go;
+// Fr = max3(F + 4 ge, A, 0), F' = Fr | 2;  Er = max(E + 4 ge, A), E' = Er | 1;  nibble = tag(m) | (Fr|Er)&3 << 2.
 template <int G, int C>
-__global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
+__global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 {
     using Lay               = CkptLayout<G, C>;
     constexpr int kNibDw    = (C + 7) / 8; // dwords of direction nibbles per tile row
-    constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions
-    __shared__ int8_t   smat[kAlph * kAlph];
+    constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions (multiple of 4)
+    __shared__ int8_t   smat[kAlph * kAlph];  // plain scores: match counts of the walk
+    __shared__ int8_t   smat4[kAlph * kAlph]; // 4 s + 3: diagonal step of the tile DP with its tag
     __shared__ uint32_t tiles[kCkptEvery * kNibDw * 64]; // [tile row][word][lane]: lane-minor, conflict-free
     for (int x = threadIdx.x; x < kAlph * kAlph / 4; x += blockDim.x)
         reinterpret_cast<uint32_t *>(smat)[x] = reinterpret_cast<uint32_t const *>(p.sc->mat)[x];
+    for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x)
+    {
+        int const v = p.sc->mat[x];
+        smat4[x]    = (int8_t)((v < -32 || v > 31) ? -125 : 4 * v + 3); // pad ranks (and entries pass 2 does not admit) far down
+    }
     __syncthreads();
     uint32_t const lane  = threadIdx.x;
     uint64_t const e     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,7 +382,8 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
     uint8_t *        ops   = p.out_ops + p.ops_off[oi];
     uint32_t const   cap   = x.q_len + x.s_len;
     int const        lq    = (int)x.q_len;
-    int const        ge = p.sc->ge, go_first = p.sc->go, g2 = p.sc->g2; // a gap of k characters costs g2 + k ge = go_first + (k-1) ge
+    int const        ge = p.sc->ge, g2 = p.sc->g2;    // a gap of k characters costs g2 + k ge
+    int              ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go; // tile DP: values x 4 (go = first gap character)
 
     int      i = ec.s_end - 1, j = ec.q_end - 1;
     int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
             for (int c = 0; c < C; ++c)
             {
                 Hp[c] = 0;
-                F[c]  = 0;
+                F[c]  = 2; // folded floor, tag "vertical"
             }
         }
         else
@@ -440,17 +450,23 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
-                Hp[c] = (int)(int16_t)(w[c] & 0xffffu);
-                F[c]  = (int)(int16_t)(w[c] >> 16);
+                Hp[c] = 4 * (int)(int16_t)(w[c] & 0xffffu);
+                F[c]  = (4 * (int)(int16_t)(w[c] >> 16)) | 2;
             }
         }
         // LDS offsets of the matrix rows of this strip's query residues (columns beyond the query use the pad rank)
         uint32_t qoff[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c)
         {
-            uint32_t const r = (j0 + c < lq) ? (uint32_t)(q[j0 + c] & (kAlph - 1)) : (uint32_t)(kAlph - 1);
-            qoff[c]          = r * kAlph;
+            uint32_t qd[(C + 3) / 4];
+#pragma unroll
+            for (int d = 0; d < (C + 3) / 4; ++d)
+                qd[d] = *reinterpret_cast<unaligned_u32 const *>(q + j0 + 4 * d); // 256 bytes of slack behind the residues
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+            {
+                uint32_t const r = (j0 + c < lq) ? ((qd[c >> 2] >> (8 * (c & 3))) & (kAlph - 1)) : (uint32_t)(kAlph - 1);
+                qoff[c]          = r * kAlph;
+            }
         }
         // left edge: the boundary words of strip st - 1 for the steps k_base - 2 ... (word of step k - 1 holds E for
         // this strip's row k - st, the word of step k - 2 the diagonal H); quads are indexed by step / 4
@@ -488,8 +504,8 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
                 if (row < 0)
                     continue; // virtual row of block 0: H = 0, F = floor stay as they are
                 uint32_t const tl = (sdw >> (8 * (row - lb))) & (kAlph - 1);
-                int            E  = has_left ? (int)(int16_t)(lw[u] >> 16) : kFar;
-                int            Hd = (has_left && row > 0) ? (int)(int16_t)(dw[u] & 0xffffu) : 0;
+                int            E  = has_left ? ((4 * (int)(int16_t)(lw[u] >> 16)) | 1) : (kFar | 1);
+                int            Hd = (has_left && row > 0) ? 4 * (int)(int16_t)(dw[u] & 0xffffu) : 0;
                 uint32_t       w[kNibDw];
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
@@ -497,19 +513,20 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                 {
-                    int const sc_ = smat[qoff[c] + tl];
-                    int const tt  = Hd + sc_;
-                    int const H   = max3i(tt, E, F[c]);
-                    uint32_t  nib = (tt == H) ? 3u : ((F[c] == H) ? 2u : 1u);
-                    int const A   = H + go_first;
-                    int const Fe  = F[c] + ge, Ee = E + ge;
-                    nib |= (Ee >= A) ? 4u : 0u; // the horizontal gap of the next column extends this cell's
-                    nib |= (Fe >= A) ? 8u : 0u; // the vertical gap of the row below extends this cell's
-                    F[c] = max3i(Fe, A, 0);
-                    E    = max(Ee, A);
-                    Hd   = Hp[c];
-                    Hp[c] = H;
-                    w[c >> 3] |= nib << (4 * (c & 7));
+                    int const tt  = Hd + (int)smat4[qoff[c] + tl];      // tag 3
+                    Hd            = Hp[c];
+                    int const m   = max3i(tt, E, F[c]);                 // E tag 1 < F tag 2 < diagonal tag 3
+                    int const H4  = m & ~3;
+                    int const A   = H4 + go4;                           // gap-open candidate, tag 0
+                    int const Fr  = max3i(F[c] + ge4, A, 0);            // tag 2 = the vertical gap extends (wins ties)
+                    int const Er  = max(E + ge4, A);                    // tag 1 = the horizontal gap extends (wins ties)
+                    F[c]          = Fr | 2;
+                    E             = Er | 1;
+                    Hp[c]         = H4;
+                    uint32_t wc   = w[c >> 3];
+                    wc            = __builtin_amdgcn_alignbit((uint32_t)m, wc, 2);
+                    wc            = __builtin_amdgcn_alignbit((uint32_t)(Fr | Er), wc, 2); // bit 0 = E extended, bit 1 = F
+                    w[c >> 3]     = wc;
                 }
                 int const kk = 4 * t + u;
 #pragma unroll
@@ -524,7 +541,9 @@ __global__ __launch_bounds__(64) void ckpt_backtrace_kernel(TraceParams p)
         while (i >= 0 && j >= j0 && i >= r_base && n < cap)
         {
             int const      kk  = i - r_base, c = j - j0;
-            uint32_t const nib = (tiles[(kk * kNibDw + (c >> 3)) * 64 + lane] >> (4 * (c & 7))) & 15u;
+            int const      xw  = c >> 3;
+            int const      cnt = (xw == kNibDw - 1) ? (C - 8 * xw) : 8; // cells held by this word (funnel-shifted in from the top)
+            uint32_t const nib = (tiles[(kk * kNibDw + xw) * 64 + lane] >> (32 - 4 * cnt + 4 * (c & 7))) & 15u;
             uint32_t op      = 0;
             bool     up      = false, lft = false;
             bool     decided = false;
