@@ -29,6 +29,9 @@ namespace lx
 {
 
 constexpr int kCkptEvery = 16; // steps between two row checkpoints
+#ifndef LX_CKPT_FWD_WAVES
+#define LX_CKPT_FWD_WAVES 4
+#endif
 
 // slot layout in uint32 units: boundary quads [step / 4][lane] (4 dwords each), then row checkpoints
 // [checkpoint][lane][kCkDw]
@@ -49,7 +52,7 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi)
 }
 
 template <int G, int C>
-__global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
+__global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
     using Lay = CkptLayout<G, C>;
@@ -109,15 +112,11 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
             atomicExch(p.err, 2);
     }
 
-    int ls_max = ls, ls_min = active ? ls : 0x7fffffff;
+    int ls_max = ls;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
-    {
         ls_max = max(ls_max, __shfl_xor(ls_max, off));
-        ls_min = min(ls_min, __shfl_xor(ls_min, off));
-    }
     ls_max = __builtin_amdgcn_readfirstlane(ls_max);
-    ls_min = __builtin_amdgcn_readfirstlane(ls_min);
 
     bool bad = false;
     if (active && (lq > Geo::kPanel || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
@@ -131,12 +130,9 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
     int const      slot_dw     = (grp / share) * (nrows * Geo::kRowDw);
     uint32_t const row_base_dw = (uint32_t)(slot_dw + g);
     int const      steps       = (ls_max + G - 1 + 3) & ~3;
-    int const      steady_lo   = (G - 1 + 3) & ~3;
-    int const      steady_hi   = ls_min - 3;
     uint32_t const lsc         = (uint32_t)max(ls, 1) - 1u;
 
     uint32_t * const slot  = p.trace + e * p.slot_stride;
-    uint4 * const    bnd   = reinterpret_cast<uint4 *>(slot);
     uint4 * const    rowck = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
     bool const       store_ok = active && !bad;
 
@@ -165,10 +161,10 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
     LX_OPAQUE(g2v);
     LX_OPAQUE(gev);
 
-    uint8_t const * sp = s - g;
+    uint32_t * const bnd_dw = slot + (uint32_t)g * 4u; // this lane's quad inside a step block, one dword per step
 
-    // one DP step; returns the boundary word of this lane's strip for row k - g
-    auto step = [&](int k, uint32_t t) -> uint32_t
+    // one DP step; stores the boundary word of this lane's strip for row k - g
+    auto step = [&](int k, uint32_t t)
     {
         int const        i    = k - g;
         uint32_t const * prow = lds + (row_base_dw + t * (uint32_t)Geo::kRowDw);
@@ -217,11 +213,11 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
         }
         sendH = h;
         sendE = Ecur;
-        // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it
-        int const      eb = max(Ecur - z, -32768);
-        uint32_t const bw = pack16(h - z, eb);
-        z                 = zn;
-        return bw;
+        // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it.  The G
+        // lanes of a group write into one 16 G-byte block per four steps: whole lines, one dword per lane and step
+        if (store_ok)
+            bnd_dw[((uint32_t)k / 4) * (4 * G) + ((uint32_t)k & 3)] = pack16(h - z, max(Ecur - z, -32768));
+        z = zn;
     };
     // row checkpoint after step k: H(i, c) and the folded F(i+1, c), un-skewed (z already is z_{i+1} here)
     auto checkpoint = [&](int k)
@@ -229,13 +225,18 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
         if (!store_ok)
             return;
         uint4 * dst = rowck + ((uint32_t)(k / kCkptEvery) * G + (uint32_t)g) * (Lay::kCkDw / 4);
-        uint32_t w[Lay::kCkDw];
-#pragma unroll
-        for (int c = 0; c < Lay::kCkDw; ++c)
-            w[c] = c < C ? pack16(Hrow[c] - (z + gev), F0[c] - z) : 0u;
 #pragma unroll
         for (int x = 0; x < Lay::kCkDw / 4; ++x)
-            dst[x] = make_uint4(w[4 * x], w[4 * x + 1], w[4 * x + 2], w[4 * x + 3]);
+        {
+            uint32_t w[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+            {
+                int const c = 4 * x + b;
+                w[b]        = c < C ? pack16(Hrow[c < C ? c : 0] - (z + gev), F0[c < C ? c : 0] - z) : 0u;
+            }
+            dst[x] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
     };
 
     auto fetch_checked = [&](int k0, uint32_t (&t)[4])
@@ -257,49 +258,20 @@ __global__ __launch_bounds__(64) void ckpt_forward_kernel(TraceParams p)
             t[u]             = (i < (uint32_t)ls) ? (t[u] & (kAlph - 1)) : padt;
         }
     };
-    auto chunk_done = [&](int k0, uint32_t const (&bw)[4])
-    {
-        if (store_ok)
-            bnd[(uint32_t)(k0 / 4) * G + (uint32_t)g] = make_uint4(bw[0], bw[1], bw[2], bw[3]);
-        if (((k0 + 3) % kCkptEvery) == kCkptEvery - 1)
-            checkpoint(k0 + 3);
-    };
 
-    int      k0 = 0;
     uint32_t tn[4];
     fetch_checked(0, tn);
-    while (k0 < steps)
+    for (int k0 = 0; k0 < steps; k0 += 4)
     {
-        bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
-        if (!cur_steady)
-        {
-            uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
-            mask_checked(k0, tc);
-            fetch_checked(k0 + 4, tn);
-            uint32_t bw[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                bw[u] = step(k0 + u, tc[u]);
-            chunk_done(k0, bw);
-            k0 += 4;
-        }
-        else
-        {
-            uint32_t wn = *reinterpret_cast<unaligned_u32 const *>(sp + k0);
-            while (k0 < steady_hi)
-            {
-                uint32_t const wc = wn;
-                int const      kn = min(k0 + 4, ls_min - 4);
-                wn                = *reinterpret_cast<unaligned_u32 const *>(sp + max(kn, 0));
-                uint32_t bw[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    bw[u] = step(k0 + u, (wc >> (8 * u)) & (kAlph - 1));
-                chunk_done(k0, bw);
-                k0 += 4;
-            }
-            fetch_checked(k0, tn);
-        }
+        uint32_t tc[4] = {tn[0], tn[1], tn[2], tn[3]};
+        mask_checked(k0, tc);
+        fetch_checked(k0 + 4, tn);
+        uint32_t const tcp = tc[0] | (tc[1] << 8) | (tc[2] << 16) | (tc[3] << 24);
+#pragma unroll 1 // one step already holds C independent cells; unrolling steps mostly costs VGPRs (occupancy)
+        for (int u = 0; u < 4; ++u)
+            step(k0 + u, (tcp >> (8 * u)) & 0xffu);
+        if (((k0 + 3) % kCkptEvery) == kCkptEvery - 1)
+            checkpoint(k0 + 3);
     }
 
     // lowest column over the lanes of the group (every lane owns different columns), with its row
