@@ -33,8 +33,13 @@ constexpr int kCkptEvery = 16; // steps between two row checkpoints
 #define LX_CKPT_FWD_WAVES 4
 #endif
 
-// slot layout in uint32 units: boundary quads [step / 4][lane] (4 dwords each), then row checkpoints
-// [checkpoint][lane][kCkDw]
+// slot layout in uint32 units: boundary quads (4 steps = 4 dwords each) [step / 16][lane][(step / 4) % 4] -- the 16 steps
+// of a lane that one tile needs sit in one 64-byte chunk --, then row checkpoints [checkpoint][lane][kCkDw]
+template <int G>
+__host__ __device__ constexpr uint32_t bnd_quad_index(uint32_t quad, uint32_t g)
+{
+    return ((quad / 4) * G + g) * 4 + (quad % 4);
+}
 template <int G, int C>
 struct CkptLayout
 {
@@ -161,7 +166,9 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
     LX_OPAQUE(g2v);
     LX_OPAQUE(gev);
 
-    uint32_t * const bnd_dw = slot + (uint32_t)g * 4u; // this lane's quad inside a step block, one dword per step
+    // boundary words are staged in a lane-private 16-byte LDS slot and leave as one quad every four steps
+    uint32_t * const stage = lds + ((Geo::kGroups + share - 1) / share) * (nrows * Geo::kRowDw) + lane * 4;
+    uint4 * const    bnd   = reinterpret_cast<uint4 *>(slot);
 
     // one DP step; stores the boundary word of this lane's strip for row k - g
     auto step = [&](int k, uint32_t t)
@@ -213,11 +220,9 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
         }
         sendH = h;
         sendE = Ecur;
-        // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it.  The G
-        // lanes of a group write into one 16 G-byte block per four steps: whole lines, one dword per lane and step
-        if (store_ok)
-            bnd_dw[((uint32_t)k / 4) * (4 * G) + ((uint32_t)k & 3)] = pack16(h - z, max(Ecur - z, -32768));
-        z = zn;
+        // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it
+        stage[k & 3] = pack16(h - z, max(Ecur - z, -32768));
+        z            = zn;
     };
     // row checkpoint after step k: H(i, c) and the folded F(i+1, c), un-skewed (z already is z_{i+1} here)
     auto checkpoint = [&](int k)
@@ -270,6 +275,8 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
 #pragma unroll 1 // one step already holds C independent cells; unrolling steps mostly costs VGPRs (occupancy)
         for (int u = 0; u < 4; ++u)
             step(k0 + u, (tcp >> (8 * u)) & 0xffu);
+        if (store_ok)
+            bnd[bnd_quad_index<G>((uint32_t)k0 / 4, (uint32_t)g)] = *reinterpret_cast<uint4 const *>(stage);
         if (((k0 + 3) % kCkptEvery) == kCkptEvery - 1)
             checkpoint(k0 + 3);
     }
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         {
             if (!has_left || qd < 0)
                 return make_uint4(0, 0, 0, 0);
-            return bnd[(uint32_t)qd * G + (uint32_t)(st - 1)];
+            return bnd[bnd_quad_index<G>((uint32_t)qd, (uint32_t)(st - 1))];
         };
         int const qd0   = k_base / 4; // quad that holds step k_base
         uint4     qprev = load_bq(qd0 - 1), qcur = load_bq(qd0);
@@ -482,10 +489,15 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     w[xw] = 0;
+                // all the row's matrix entries first: one LDS round trip per row instead of one per cell
+                int sub4[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    sub4[c] = (int)smat4[qoff[c] + tl];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                 {
-                    int const tt  = Hd + (int)smat4[qoff[c] + tl];      // tag 3
+                    int const tt  = Hd + sub4[c];                       // tag 3
                     Hd            = Hp[c];
                     int const m   = max3i(tt, E, F[c]);                 // E tag 1 < F tag 2 < diagonal tag 3
                     int const H4  = m & ~3;
@@ -641,7 +653,7 @@ static hipError_t launch_ckpt_forward_cfg(TraceParams const & p, hipStream_t str
         return hipErrorInvalidValue;
     int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
     int const    slots = (Geo::kGroups + share - 1) / share;
-    size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
+    size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + 64 * 4) * sizeof(uint32_t);
     hipLaunchKernelGGL((ckpt_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
