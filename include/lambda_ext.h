@@ -122,8 +122,8 @@ enum
     LX_OPT_PACKED_HALF     = 7, /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
                                    proves it exact (results are bit-identical either way); 0: int32 kernel only */
     LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical either way):
-                                   0 = 4 direction bits per cell; 1 = strip boundaries + row checkpoints, tiles recomputed
-                                   by the backtrace -- used where its limits hold (query within one panel of a
+                                   0 = 4 direction bits per cell; 1 (default) = strip boundaries + row checkpoints, tiles
+                                   recomputed by the backtrace -- used where its limits hold (query within one panel of a
                                    shared-profile geometry, scores below 32000), the direction bits otherwise */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);

@@ -97,9 +97,13 @@ def test_align_host_path_known_scores_and_sharing(handle, oracle):
     assert len(keep) > 400
     es, ks = ext[keep], want_score[keep]
     want = oracle.align_batch(q, s, es, osc)
-    for known in (None, ks):
-        hsp, ops = handle.align_batch(q, s, es, known_score=known)
-        assert "_forward_kernel<8,19" in handle.last_trace_kernel_name()  # direction bits or checkpoints (LX_OPT_PASS2_MODE)
+    for known, mode in ((None, 1), (ks, 1), (None, 0), (ks, 0)):
+        handle.set_option(capi.LX_OPT_PASS2_MODE, mode)
+        try:
+            hsp, ops = handle.align_batch(q, s, es, known_score=known)
+        finally:
+            handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        assert ("ckpt_forward_kernel<8,19" if mode else "trace_forward_kernel<8,19") in handle.last_trace_kernel_name()
         for g, (oh, oops), o in zip(hsp, want, ops):
             assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
                    (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops)
@@ -231,8 +235,9 @@ def test_iterate_matches_driver(handle, oracle, filters):
         assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])
 
 
+@pytest.mark.parametrize("pass2_mode", [1, 0])
 @pytest.mark.parametrize("wpq,run,lq", [(32, 32, 150), (8, 8, 150), (7, 0, 150), (32, 32, 200), (16, 16, 100)])
-def test_fused_extend_on_device(handle, oracle, wpq, run, lq):
+def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
     """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2.
     lq = 200 is the shape of BASELINE.json configs[3] (200 aa queries, 230 aa windows: the (16,13) geometries)."""
     import torch
@@ -259,14 +264,18 @@ def test_fused_extend_on_device(handle, oracle, wpq, run, lq):
     handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
     handle.set_option(capi.LX_OPT_MAX_SLEN, int(ext["s_len"].max()))
     handle.set_option(capi.LX_OPT_QUERY_RUN, run)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, pass2_mode)
     torch.cuda.synchronize()
     try:
         handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
         handle.synchronize()
+        if run % 8 == 0 and run > 0:  # shared-profile geometries: the mode decides the kernel pair
+            assert ("ckpt_forward_kernel" in handle.last_trace_kernel_name()) == (pass2_mode == 1)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
         handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
     want_score = oracle.score_batch(q, s, ext, osc, threads=8)
     got_score = d_score.cpu().numpy()
     assert (got_score == want_score).all()
@@ -343,7 +352,8 @@ def test_iterate_matches_bisulfite(handle, oracle):
         assert int(g["q_frame"]) == (qid % 2 + 1) * (-1 if qid % 4 > 1 else 1) and int(g["s_frame"]) == sid % 2 + 1
 
 
-def test_full_size_fused_step_properties(handle, oracle):
+@pytest.mark.parametrize("pass2_mode", [1, 0])
+def test_full_size_fused_step_properties(handle, oracle, pass2_mode):
     """BASELINE.json configs[1] at FULL size through lx_extend_batch_dev (3.2 M extensions, 1.6 M traced), checked by
     size-independent properties on the device and by the oracle on a sample:
     (1) the survivor count equals the number of scores at or above the cut-off and no extension is flagged (-1);
@@ -379,14 +389,17 @@ def test_full_size_fused_step_properties(handle, oracle):
     handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
     handle.set_option(capi.LX_OPT_MAX_SLEN, ls)
     handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, pass2_mode)
     torch.cuda.synchronize()
     try:
         handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
         handle.synchronize()
+        assert ("ckpt_forward_kernel" in handle.last_trace_kernel_name()) == (pass2_mode == 1)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
         handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
     hsp = d_hsp.view(torch.int32).view(n, 12)  # lx_hsp: score q_begin q_end s_begin s_end n_ops matches mismatches positives opens extensions shift
     surv = d_score >= cutoff
     cnt = d_count.cpu().numpy()
