@@ -274,8 +274,16 @@ def main():
         rooflines = [r_score]
         if not args.pass1_only and phase_ms[2][0] > 0:
             cells2 = float(survivors) * lq * ls
-            algo2 = cells2 / 2 + survivors * (ls + lq / 4.0 + ALGO_BYTES_PER_EXT_EXTRA + 4)
-            rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], cells2, "trace_forward_kernel", algo2))
+            if "ckpt" in trace_kernel_name:
+                # checkpoint mode: one 4-byte boundary pair per strip and row + one 4-byte pair per column every 16 rows
+                strips = -(-lq // 19)
+                stored = ls * strips * 4 + (ls / 16.0) * lq * 4
+                pmc_key = "ckpt_forward_kernel"
+            else:
+                stored = lq * ls / 2.0  # 4 direction bits per cell
+                pmc_key = "trace_forward_kernel"
+            algo2 = survivors * (stored + ls + lq / 4.0 + ALGO_BYTES_PER_EXT_EXTRA + 4)
+            rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], cells2, pmc_key, algo2))
         rooflines.sort(key=lambda r: -r["kernel_ms_per_step"])
         out = {
             "metric": "GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) searchp BLOSUM62",

@@ -28,7 +28,18 @@
 namespace lx
 {
 
-constexpr int kCkptEvery = 16; // steps between two row checkpoints
+#ifndef LX_CKPT_EVERY
+#define LX_CKPT_EVERY 16
+#endif
+// steps between two row checkpoints (multiple of 4).  Headline batch, forward + backtrace: 8 -> 12.8 + 6.0 ms,
+// 16 -> 11.2 + 6.5 ms, 32 -> 10.7 + 9.7 ms
+constexpr int kCkptEvery = LX_CKPT_EVERY;
+#ifndef LX_CKPT_UNROLL
+#define LX_CKPT_UNROLL 4 // steps unrolled in the forward kernel (11.9 / 11.5 / 11.3 ms for 1, 2, 4 on the headline batch)
+#endif
+#define LX_CKPT_PRAGMA(x) _Pragma(#x)
+#define LX_CKPT_UNROLL_N(n) LX_CKPT_PRAGMA(unroll n)
+#define LX_CKPT_UNROLL_PRAGMA LX_CKPT_UNROLL_N(LX_CKPT_UNROLL)
 #ifndef LX_CKPT_FWD_WAVES
 #define LX_CKPT_FWD_WAVES 4
 #endif
@@ -272,7 +283,7 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
         mask_checked(k0, tc);
         fetch_checked(k0 + 4, tn);
         uint32_t const tcp = tc[0] | (tc[1] << 8) | (tc[2] << 16) | (tc[3] << 24);
-#pragma unroll 1 // one step already holds C independent cells; unrolling steps mostly costs VGPRs (occupancy)
+LX_CKPT_UNROLL_PRAGMA
         for (int u = 0; u < 4; ++u)
             step(k0 + u, (tcp >> (8 * u)) & 0xffu);
         if (store_ok)
