@@ -326,11 +326,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     using Lay               = CkptLayout<G, C>;
     constexpr int kNibDw    = (C + 7) / 8; // dwords of direction nibbles per tile row
     constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions (multiple of 4)
-    __shared__ int8_t   smat[kAlph * kAlph];  // plain scores: match counts of the walk
-    __shared__ int8_t   smat4[kAlph * kAlph]; // 4 s + 3: diagonal step of the tile DP with its tag
+    __shared__ int8_t   smat4[kAlph * kAlph]; // 4 s + 3: diagonal step of the tile DP with its tag (the walk divides it back)
     __shared__ uint32_t tiles[kCkptEvery * kNibDw * 64]; // [tile row][word][lane]: lane-minor, conflict-free
-    for (int x = threadIdx.x; x < kAlph * kAlph / 4; x += blockDim.x)
-        reinterpret_cast<uint32_t *>(smat)[x] = reinterpret_cast<uint32_t const *>(p.sc->mat)[x];
     for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x)
     {
         int const v = p.sc->mat[x];
@@ -602,8 +599,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                     uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
                     uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
                     uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
-                    int const      v       = smat[c0 * kAlph + c1];
-                    bool const     isMatch = p.bs_match_rule ? (v == smat[c0 * kAlph + c0]) : (c0 == c1);
+                    int const      v       = ((int)smat4[c0 * kAlph + c1] - 3) >> 2;
+                    bool const     isMatch = p.bs_match_rule ? (smat4[c0 * kAlph + c1] == smat4[c0 * kAlph + c0]) : (c0 == c1);
                     nm += isMatch;
                     nx += !isMatch;
                     np += (v > 0);
