@@ -115,7 +115,7 @@ enum
     LX_OPT_WORKSPACE_BYTES = 3,
     LX_OPT_MAX_SLEN        = 4, /* longest subject slice the *_dev calls will see (0 = unknown: measured on the
                                    device, which costs lx_align_batch_dev one stream synchronisation)          */
-    LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 32 GiB); larger batches are
+    LX_OPT_TRACE_BYTES     = 5, /* HBM budget for direction bits in pass 2 (default 64 GiB); larger batches are
                                    processed in chunks, in order, on the same stream                            */
     LX_OPT_BS_MATCH_RULE   = 6, /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */

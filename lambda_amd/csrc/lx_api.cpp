@@ -99,7 +99,7 @@ struct lx_handle
     uint64_t opt_query_run = 0;
     uint64_t opt_ws_bytes  = 64ull << 20;
     uint64_t opt_max_slen  = 0;
-    uint64_t opt_trace_bytes = 32ull << 30;
+    uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
     uint64_t opt_pass2     = 1; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip) where applicable
@@ -361,7 +361,7 @@ int lx_create(int device_id, lx_handle ** out)
 
     lx_handle * h = new lx_handle();
     if (char const * m = getenv("LX_PASS2_MODE")) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
-        h->opt_pass2 = atoi(m) ? 1 : 0;
+        h->opt_pass2 = (uint64_t)std::min(std::max(atoi(m), 0), 2);
     h->device     = device_id;
     auto bail     = [&](char const * what, hipError_t err)
     {
@@ -445,7 +445,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_TRACE_BYTES: h->opt_trace_bytes = std::max<uint64_t>(value, 1 << 20); return LX_OK;
         case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
-        case LX_OPT_PASS2_MODE: h->opt_pass2 = value ? 1 : 0; return LX_OK;
+        case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
         default: return fail(h, LX_EINVAL, "unknown option %d", option);
     }
 }
@@ -935,7 +935,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
         for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
             smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-    bool const ckpt = h->opt_pass2 == 1 && cfg != 0 && panels_cap == 1 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
+    bool const ckpt = h->opt_pass2 >= 1 && cfg != 0 && panels_cap == 1 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
     uint64_t const stride     = ckpt ? lx::ckpt_slot_dwords(cfg, steps_cap) : (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
     // The forward kernel finds the end cell cheaply when it knows each extension's best score; the fused path hands
@@ -1226,20 +1226,79 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
 
-    // pass 1 (src/search_algo.hpp:1246)
     h->phase_ev.clear();
     h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, stream));
-    h->in_fused = true;
-    rc          = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream);
-    h->in_fused = false;
-    if (rc)
-        return rc;
+    bool const shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
+
+    // Single sweep (LX_OPT_PASS2_MODE = 2): the checkpoint forward kernel runs once over ALL extensions -- it is pass 1
+    // and the forward half of pass 2 at the same time -- and the backtrace reads the checkpoints of the survivors in
+    // place.  Needs the checkpoints of the whole batch inside the trace budget and a shared-profile geometry.
+    bool sweep = false;
+    int  sweep_cfg = 0;
+    uint32_t sweep_steps = 0;
+    uint64_t sweep_stride = 0;
+    if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
+    {
+        sweep_cfg = h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(1) ? 1 : h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(2) ? 2 : 0;
+        int smax_entry = 0;
+        for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
+            for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
+                smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+        if (sweep_cfg != 0 && (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535)
+        {
+            int const G  = lx::trace_cfg_group(sweep_cfg);
+            sweep_steps  = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
+            sweep_stride = lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            // whole-wavefront profile sharing needs runs of 8 (G = 8) / 4 (G = 16) extensions: `shared` guarantees 8
+            sweep = n * sweep_stride * 4 <= h->opt_trace_bytes;
+        }
+    }
+    if (sweep)
+    {
+        if ((rc = ensure(h, h->d_trace, n * sweep_stride * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
+            return rc;
+        if ((rc = prepare_workspace(h, stream)))
+            return rc;
+        lx::TraceParams p{};
+        p.q_res          = static_cast<uint8_t const *>(d_q_res);
+        p.s_res          = static_cast<uint8_t const *>(d_s_res);
+        p.ext            = static_cast<lx::Extension const *>(d_ext);
+        p.n              = n;
+        p.sc             = h->sc_dev[slot];
+        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr);
+        p.slot_stride    = sweep_stride;
+        p.steps_cap      = sweep_steps;
+        p.panels_cap     = 1;
+        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
+        p.score_out      = static_cast<int32_t *>(d_out_score);
+        p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+        p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+        p.shared_profile = 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query
+        p.cfg            = sweep_cfg;
+        PhaseTimer pt0(h, stream, 0);
+        LX_HIP(h, lx::launch_ckpt_forward(p, stream));
+        pt0.close();
+        char buf[96];
+        snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", lx::trace_cfg_group(sweep_cfg),
+                 lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
+        h->last_kernel       = buf;
+        h->last_trace_kernel = buf;
+    }
+    else
+    {
+        // pass 1 (src/search_algo.hpp:1246)
+        h->in_fused = true;
+        rc          = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream);
+        h->in_fused = false;
+        if (rc)
+            return rc;
+    }
 
     // filter (:1251-1283) as an integer cut-off, compaction in input order, runs padded to whole wavefronts
-    bool const     shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
     uint32_t const run    = shared ? (uint32_t)h->opt_query_run : 1u;
-    uint32_t const pad_to = shared ? 4u : 1u; // half a wavefront of the 8-lane geometry, a whole one of the 16-lane
+    // half a wavefront of the 8-lane geometry, a whole one of the 16-lane; the single sweep's backtrace needs no padding
+    uint32_t const pad_to = (shared && !sweep) ? 4u : 1u;
     uint64_t const nruns  = (n + run - 1) / run;
     uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
@@ -1263,6 +1322,39 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     PhaseTimer pts(h, stream, 1);
     LX_HIP(h, lx::launch_select(sp, stream));
     pts.close();
+
+    if (sweep)
+    {
+        // backtrace of the survivors straight from the checkpoints of the sweep (slots and end cells by original index)
+        lx::TraceParams p{};
+        p.q_res         = static_cast<uint8_t const *>(d_q_res);
+        p.s_res         = static_cast<uint8_t const *>(d_s_res);
+        p.ext           = static_cast<lx::Extension const *>(h->d_sel_ext.ptr);
+        p.n             = cap;
+        p.sc            = h->sc_dev[slot];
+        p.trace         = static_cast<uint32_t *>(h->d_trace.ptr);
+        p.slot_stride   = sweep_stride;
+        p.steps_cap     = sweep_steps;
+        p.panels_cap    = 1;
+        p.ends          = static_cast<lx::EndCell *>(h->d_ends.ptr);
+        p.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
+        p.out_ops       = static_cast<uint8_t *>(d_out_ops);
+        p.ops_off       = static_cast<uint64_t const *>(d_ops_off);
+        p.src           = static_cast<uint32_t const *>(h->d_sel_src.ptr);
+        p.count_ptr     = static_cast<uint64_t const *>(d_out_count);
+        p.chunk_start   = 0;
+        p.err           = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+        p.nrows         = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+        p.bs_match_rule = (int32_t)h->opt_bs_rule;
+        p.cfg           = sweep_cfg;
+        p.slot_by_src   = 1;
+        PhaseTimer ptb(h, stream, 3);
+        LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));
+        ptb.close();
+        LX_HIP(h, hipEventRecord(h->ev1, stream));
+        h->timed = true;
+        return LX_OK;
+    }
 
     // pass 2 on the survivors (:1293-1296); the grid covers the worst case, wavefronts beyond *d_out_count exit
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,

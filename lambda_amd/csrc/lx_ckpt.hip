@@ -67,8 +67,12 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi)
     return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
 }
 
-template <int G, int C>
-__global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(TraceParams p)
+// KNOWN = the best score of every extension is given (p.score_in): the end cell is the first cell in column-major order
+// that reaches it.  !KNOWN = single sweep over all extensions: the kernel also IS pass 1 -- every lane keeps the best
+// value of its strip, the first row that reached it and whether a later row reached it again; the group then reports
+// score, strip and row, and the backtrace resolves the column (and, if the strip tied, the row) from the checkpoints.
+template <int G, int C, bool KNOWN>
+__global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
     using Lay = CkptLayout<G, C>;
@@ -152,9 +156,13 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
     uint4 * const    rowck = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
     bool const       store_ok = active && !bad;
 
-    // target score and the best (lowest) column / its first row seen so far in this lane
-    int const tgt  = active ? p.score_in[e] : 0;
-    int       kcol = 0x7fffffff, krow = 0;
+    // KNOWN: target score and the best (lowest) column / its first row seen so far in this lane
+    int tgt = 0;
+    if constexpr (KNOWN)
+        tgt = active ? p.score_in[e] : 0;
+    int kcol = 0x7fffffff, krow = 0;
+    // !KNOWN: best value of this lane's strip, first row that reached it, "reached again later"
+    int lbest = 0, lrow = 0, ltie = 0;
 
     int const col0 = g * C;
     build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_adj, nrows, grp % share == 0);
@@ -217,17 +225,30 @@ __global__ __launch_bounds__(64, LX_CKPT_FWD_WAVES) void ckpt_forward_kernel(Tra
                 rowmax = max(rowmax, h);
             Hrow[c] = h;
         }
-        // rare: some cell of this row reaches the extension's best score -> remember the lowest such column (rows are
-        // visited in increasing order, so the first hit of a column is its lowest row)
-        if (tgt > 0 && rowmax == tgt + z && (unsigned)i < (unsigned)ls)
+        if constexpr (KNOWN)
         {
+            // rare: some cell of this row reaches the extension's best score -> remember the lowest such column (rows
+            // are visited in increasing order, so the first hit of a column is its lowest row)
+            if (tgt > 0 && rowmax == tgt + z && (unsigned)i < (unsigned)ls)
+            {
 #pragma unroll
-            for (int c = C - 1; c >= 0; --c)
-                if (Hrow[c] == rowmax && col0 + c < kcol)
-                {
-                    kcol = col0 + c;
-                    krow = i;
-                }
+                for (int c = C - 1; c >= 0; --c)
+                    if (Hrow[c] == rowmax && col0 + c < kcol)
+                    {
+                        kcol = col0 + c;
+                        krow = i;
+                    }
+            }
+        }
+        else
+        {
+            // rows beyond the window and columns beyond the query score strictly below the best real cell, so they
+            // can neither raise nor tie a positive maximum: no validity test needed
+            int const  cand = rowmax - z;
+            bool const gt   = cand > lbest;
+            ltie            = gt ? 0 : (ltie | (cand == lbest ? 1 : 0));
+            lrow            = gt ? i : lrow;
+            lbest           = max(lbest, cand);
         }
         sendH = h;
         sendE = Ecur;
@@ -292,27 +313,61 @@ LX_CKPT_UNROLL_PRAGMA
             checkpoint(k0 + 3);
     }
 
-    // lowest column over the lanes of the group (every lane owns different columns), with its row
+    if constexpr (KNOWN)
+    {
+        // lowest column over the lanes of the group (every lane owns different columns), with its row
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1)
-    {
-        int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
-        bool const take = oc < kcol;
-        kcol = take ? oc : kcol;
-        krow = take ? orow : krow;
-    }
-    if (in_list && is_first)
-    {
-        EndCell ec{};
-        if (bad || (tgt > 0 && kcol == 0x7fffffff))
-            ec.score = -1; // the score of pass 1 was not reproduced: never return a wrong alignment silently
-        else if (tgt > 0)
+        for (int off = 1; off < G; off <<= 1)
         {
-            ec.score = tgt;
-            ec.q_end = kcol + 1;
-            ec.s_end = krow + 1;
+            int const  oc = __shfl_xor(kcol, off), orow = __shfl_xor(krow, off);
+            bool const take = oc < kcol;
+            kcol = take ? oc : kcol;
+            krow = take ? orow : krow;
         }
-        p.ends[e] = ec;
+        if (in_list && is_first)
+        {
+            EndCell ec{};
+            if (bad || (tgt > 0 && kcol == 0x7fffffff))
+                ec.score = -1; // the score of pass 1 was not reproduced: never return a wrong alignment silently
+            else if (tgt > 0)
+            {
+                ec.score = tgt;
+                ec.q_end = kcol + 1;
+                ec.s_end = krow + 1;
+            }
+            p.ends[e] = ec;
+        }
+    }
+    else
+    {
+        // best strip value over the group; among equal ones the lowest strip (its columns come first)
+        int gbest = lbest, gstrip = g, grow = lrow, gtie = ltie;
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1)
+        {
+            int const  ob = __shfl_xor(gbest, off), os = __shfl_xor(gstrip, off), orow = __shfl_xor(grow, off), ot = __shfl_xor(gtie, off);
+            bool const take = ob > gbest || (ob == gbest && os < gstrip);
+            gbest  = take ? ob : gbest;
+            gstrip = take ? os : gstrip;
+            grow   = take ? orow : grow;
+            gtie   = take ? ot : gtie;
+        }
+        if (in_list && is_first)
+        {
+            EndCell ec{};
+            if (bad)
+                ec.score = -1;
+            else if (active && gbest > 0)
+            {
+                ec.score = gbest;
+                ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
+                ec.s_end = grow + 1;
+                ec.flags = gtie ? kEndAmbiguous : 0;
+            }
+            p.ends[e] = ec;
+            if (p.score_out)
+                p.score_out[e] = bad ? -1 : (active ? gbest : 0);
+        }
     }
 }
 
@@ -352,7 +407,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             return; // padding slot
         oi = sidx;
     }
-    EndCell const   ec = p.ends[e];
+    uint64_t const  se = p.slot_by_src ? oi : e; // single-sweep mode: checkpoints and end cells sit at the original index
+    EndCell         ec = p.ends[se];
     Extension const x  = p.ext[e];
     Hsp             out{};
     if (ec.score <= 0)
@@ -361,7 +417,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         p.out_hsp[oi] = out;
         return;
     }
-    uint32_t const * slot  = p.trace + e * p.slot_stride;
+    uint32_t const * slot  = p.trace + se * p.slot_stride;
     uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);
     uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + Lay::bnd_dwords(p.steps_cap));
     uint8_t const *  q     = p.q_res + x.q_off;
@@ -373,6 +429,83 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     int              ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go; // tile DP: values x 4 (go = first gap character)
 
     int      i = ec.s_end - 1, j = ec.q_end - 1;
+    // single-sweep mode: only the strip of the end cell is known (ec.q_end = -(strip + 1)).  The column is read off the
+    // first tile (its last computed row is the end row); if the strip reached the best score in several rows, a plain
+    // re-run of the strip from the checkpoint above the first such row finds the cell the tie rule wants first.
+    bool need_col = ec.q_end < 0;
+    if (need_col)
+    {
+        int const st = -ec.q_end - 1;
+        j            = st * C + (C - 1); // provisional: the whole strip is computed
+        if (ec.flags & kEndAmbiguous)
+        {
+            int const go1 = p.sc->go;
+            int const m0  = (i + st) / kCkptEvery;
+            int       Hp[C], F[C];
+            if (m0 == 0)
+            {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    Hp[c] = F[c] = 0;
+            }
+            else
+            {
+                uint32_t const * src = reinterpret_cast<uint32_t const *>(rowck + ((uint32_t)(m0 - 1) * G + (uint32_t)st) * (Lay::kCkDw / 4));
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                {
+                    uint32_t const w = src[c];
+                    Hp[c]            = (int)(int16_t)(w & 0xffffu);
+                    F[c]             = (int)(int16_t)(w >> 16);
+                }
+            }
+            int qr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                qr[c] = (st * C + c < lq) ? (int)(q[st * C + c] & (kAlph - 1)) * kAlph : (kAlph - 1) * kAlph;
+            auto bnd_word = [&](int k) -> uint32_t // boundary word of strip st - 1 at step k
+            { return slot[bnd_quad_index<G>((uint32_t)k / 4, (uint32_t)(st - 1)) * 4 + ((uint32_t)k & 3)]; };
+            int const target = ec.score;
+            int       kcol = C, krow = i;
+            for (int r = max(m0 * kCkptEvery - st, 0); r < (int)x.s_len; ++r)
+            {
+                int const tl = s[r] & (kAlph - 1);
+                int       E  = kFar, Hd = 0;
+                if (st > 0)
+                {
+                    E = (int)(int16_t)(bnd_word(r + st - 1) >> 16);
+                    if (r > 0)
+                        Hd = (int)(int16_t)(bnd_word(r + st - 2) & 0xffffu);
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                {
+                    int const v  = ((int)smat4[qr[c] + tl] - 3) >> 2;
+                    int const tt = Hd + v;
+                    Hd           = Hp[c];
+                    int const H  = max3i(tt, E, F[c]);
+                    int const A  = H + go1;
+                    F[c]         = max3i(F[c] + ge, A, 0);
+                    E            = max(E + ge, A);
+                    Hp[c]        = H;
+                    if (H == target && c < kcol) // lowest column wins; rows ascend, so its first hit is its lowest row
+                    {
+                        kcol = c;
+                        krow = r;
+                    }
+                }
+            }
+            if (kcol < C)
+            {
+                i        = krow;
+                j        = st * C + kcol;
+                need_col = false;
+            }
+            // (kcol == C cannot happen: the forward pass saw the score in this strip; the tile path below then flags it)
+        }
+    }
+    int const end_i = i; // the end cell's row is final here, its column once need_col is false
+    int       end_j = j;
     int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
     int      left = ec.score;
     uint32_t n    = 0;
@@ -529,6 +662,25 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             qcur  = qnext;
         }
 
+        if (need_col)
+        {
+            // Hp[] holds 4 H of the last computed row = the end row: its first column that carries the best score
+            need_col = false;
+            int found = -1;
+#pragma unroll
+            for (int c = C - 1; c >= 0; --c)
+                if (Hp[c] == 4 * ec.score)
+                    found = c;
+            if (found < 0)
+            {
+                done     = true; // the forward pass saw this score in this row of the strip: never guess
+                left     = -1;
+                ec.score = -1;
+                break;
+            }
+            j     = j0 + found;
+            end_j = j;
+        }
         // ---- walk inside the tile
         while (i >= 0 && j >= j0 && i >= r_base && n < cap)
         {
@@ -630,11 +782,18 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
             ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
 
+    if (ec.score < 0)
+    {
+        Hsp failed{};
+        failed.score  = -1;
+        p.out_hsp[oi] = failed;
+        return;
+    }
     out.score              = ec.score;
     out.q_begin            = j + 1;
-    out.q_end              = ec.q_end;
+    out.q_end              = end_j + 1;
     out.s_begin            = i + 1;
-    out.s_end              = ec.s_end;
+    out.s_end              = end_i + 1;
     out.n_ops              = (int32_t)n;
     out.num_matches        = nm;
     out.num_mismatches     = nx;
@@ -657,12 +816,15 @@ static hipError_t launch_ckpt_forward_cfg(TraceParams const & p, hipStream_t str
 {
     using Geo = ScoreGeo<G, C>;
     uint64_t const blocks = (p.n + Geo::kGroups - 1) / Geo::kGroups;
-    if (blocks > 0x7fffffffull || !p.score_in || p.steps_cap % kCkptEvery != 0)
+    if (blocks > 0x7fffffffull || (!p.score_in && !p.score_out) || p.steps_cap % kCkptEvery != 0)
         return hipErrorInvalidValue;
     int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
     int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + 64 * 4) * sizeof(uint32_t);
-    hipLaunchKernelGGL((ckpt_forward_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    if (p.score_in)
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -74,10 +74,11 @@ struct ScoreParams
 struct EndCell
 {
     int32_t score;
-    int32_t q_end; // 1-based column of the best cell == half-open end
+    int32_t q_end; // 1-based column of the best cell == half-open end; -(strip + 1) while only the strip is known
     int32_t s_end;
-    int32_t pad;
+    int32_t flags; // kEndAmbiguous: the strip reaches the best score in more than one row
 };
+constexpr int32_t kEndAmbiguous = 1;
 
 struct TraceParams
 {
@@ -106,6 +107,11 @@ struct TraceParams
     int32_t            bs_match_rule; // computeAlignmentStats variant: 1 = match iff score(c0,c1)==score(c0,c0)
     int32_t            shared_profile;
     int32_t            cfg;           // 0 = (16,10), 1 = (8,19)
+    // single-sweep mode (lx_ckpt.hip): the forward kernel runs over ALL extensions without a known score, writes the
+    // best score here and an end cell whose column is still to be resolved; the backtrace then addresses checkpoint
+    // slots and end cells by src[e] instead of by e
+    int32_t *          score_out;
+    int32_t            slot_by_src;
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

@@ -410,7 +410,7 @@ LX_TRACE_UNROLL_PRAGMA // one step already holds C independent cells; unrolling 
         ec.score = bad ? -1 : best_h;
         ec.q_end = best_q;
         ec.s_end = best_s;
-        ec.pad   = 0;
+        ec.flags = 0;
         p.ends[e] = ec;
     }
 }

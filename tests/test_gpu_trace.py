@@ -235,7 +235,7 @@ def test_iterate_matches_driver(handle, oracle, filters):
         assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])
 
 
-@pytest.mark.parametrize("pass2_mode", [1, 0])
+@pytest.mark.parametrize("pass2_mode", [1, 0, 2])
 @pytest.mark.parametrize("wpq,run,lq", [(32, 32, 150), (8, 8, 150), (7, 0, 150), (32, 32, 200), (16, 16, 100)])
 def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
     """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2.
@@ -269,8 +269,9 @@ def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
     try:
         handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
         handle.synchronize()
-        if run % 8 == 0 and run > 0:  # shared-profile geometries: the mode decides the kernel pair
-            assert ("ckpt_forward_kernel" in handle.last_trace_kernel_name()) == (pass2_mode == 1)
+        if run % 8 == 0 and run > 0:  # shared-profile geometries: the mode decides the kernels
+            name = handle.last_trace_kernel_name()
+            assert ("ckpt_forward_kernel" in name) == (pass2_mode >= 1) and ("single sweep" in name) == (pass2_mode == 2)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
@@ -352,7 +353,7 @@ def test_iterate_matches_bisulfite(handle, oracle):
         assert int(g["q_frame"]) == (qid % 2 + 1) * (-1 if qid % 4 > 1 else 1) and int(g["s_frame"]) == sid % 2 + 1
 
 
-@pytest.mark.parametrize("pass2_mode", [1, 0])
+@pytest.mark.parametrize("pass2_mode", [1, 0, 2])
 def test_full_size_fused_step_properties(handle, oracle, pass2_mode):
     """BASELINE.json configs[1] at FULL size through lx_extend_batch_dev (3.2 M extensions, 1.6 M traced), checked by
     size-independent properties on the device and by the oracle on a sample:
@@ -390,16 +391,19 @@ def test_full_size_fused_step_properties(handle, oracle, pass2_mode):
     handle.set_option(capi.LX_OPT_MAX_SLEN, ls)
     handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
     handle.set_option(capi.LX_OPT_PASS2_MODE, pass2_mode)
+    handle.set_option(capi.LX_OPT_TRACE_BYTES, 64 << 30)  # the single sweep keeps the checkpoints of all 3.2 M extensions (43 GB)
     torch.cuda.synchronize()
     try:
         handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
         handle.synchronize()
-        assert ("ckpt_forward_kernel" in handle.last_trace_kernel_name()) == (pass2_mode == 1)
+        name = handle.last_trace_kernel_name()
+        assert ("ckpt_forward_kernel" in name) == (pass2_mode >= 1) and ("single sweep" in name) == (pass2_mode == 2)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
         handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
         handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_option(capi.LX_OPT_TRACE_BYTES, 4 << 30)
     hsp = d_hsp.view(torch.int32).view(n, 12)  # lx_hsp: score q_begin q_end s_begin s_end n_ops matches mismatches positives opens extensions shift
     surv = d_score >= cutoff
     cnt = d_count.cpu().numpy()
