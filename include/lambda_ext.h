@@ -121,10 +121,15 @@ enum
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
     LX_OPT_PACKED_HALF     = 7, /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
                                    proves it exact (results are bit-identical either way); 0: int32 kernel only */
-    LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical either way):
-                                   0 = 4 direction bits per cell; 1 (default) = strip boundaries + row checkpoints, tiles
-                                   recomputed by the backtrace -- used where its limits hold (query within one panel of a
-                                   shared-profile geometry, scores below 32000), the direction bits otherwise */
+    LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical in every mode):
+                                   0 = 4 direction bits per cell of every survivor;
+                                   1 = strip boundaries + row checkpoints of every survivor, tiles recomputed by the
+                                       backtrace -- where its limits hold (query within one panel of a shared-profile
+                                       geometry, scores below 32000), else mode 0;
+                                   2 (default) = single sweep in lx_extend_batch_dev: one checkpointing kernel over ALL
+                                       extensions is pass 1 and the forward half of pass 2 at once -- where mode 1
+                                       applies, LX_OPT_QUERY_RUN is a multiple of 8 and the checkpoints of the whole
+                                       batch (13.5 KB per 150 x 176 extension) fit LX_OPT_TRACE_BYTES, else mode 1 */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 

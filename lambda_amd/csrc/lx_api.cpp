@@ -102,7 +102,7 @@ struct lx_handle
     uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
-    uint64_t opt_pass2     = 1; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip) where applicable
+    uint64_t opt_pass2     = 2; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip), 2 = single sweep; each where applicable
     uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };

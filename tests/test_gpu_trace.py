@@ -463,3 +463,68 @@ def test_published_smith_waterman_example(handle):
             assert ops[16 + k] == b"MMMIMM"
     finally:
         handle.set_scoring(SCHEMES["blosum62"], 0)
+
+
+@pytest.mark.parametrize("pass2_mode", [2, 1, 0])
+def test_fused_ties_two_letter_alphabet(handle, oracle, pass2_mode):
+    """The fused step on two-letter sequences: best scores are reached in many cells, rows and strips at once, so the
+    end-cell tie rule (first maximum in column-major order), the single sweep's strip / row bookkeeping with its
+    ambiguity re-scan, and the traceback ties are all exercised; every survivor must equal the oracle."""
+    import torch
+
+    sc_p = SCHEMES["nucl"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    rng = np.random.default_rng(123 + pass2_mode)
+    nq, wpq, lq, ls = 96, 8, 120, 150
+    q = rng.integers(0, 2, nq * lq).astype(np.uint8)
+    s = rng.integers(0, 2, nq * wpq * ls).astype(np.uint8)
+    # periodic inserts make equal-scoring alternatives more frequent still
+    s.reshape(nq * wpq, ls)[::3, 20:20 + 60] = np.tile(q.reshape(nq, lq)[:, 10:70], (wpq, 1)).reshape(nq * wpq, 60)[::3]
+    ext = np.zeros(nq * wpq, dtype=capi.EXT_DTYPE)
+    ext["q_off"] = np.repeat(np.arange(nq) * lq, wpq)
+    ext["q_len"] = lq
+    ext["s_off"] = np.arange(nq * wpq) * ls
+    ext["s_len"] = ls
+    n = len(ext)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    cutoff = 20
+    handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, ls)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, pass2_mode)
+    torch.cuda.synchronize()
+    try:
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+        assert ("single sweep" in handle.last_trace_kernel_name()) == (pass2_mode == 2)
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_scoring(SCHEMES["blosum62"], 0)
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    assert (d_score.cpu().numpy() == want_score).all()
+    surv = np.nonzero(want_score >= cutoff)[0]
+    assert len(surv) > n // 2
+    hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+    ops = d_ops.cpu().numpy()
+    for i, (oh, oops) in zip(surv, oracle.align_batch(q, s, ext[surv], osc)):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops
