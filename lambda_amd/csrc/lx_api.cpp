@@ -1276,12 +1276,36 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
         p.shared_profile = 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query
         p.cfg            = sweep_cfg;
+        // packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query
+        // per wavefront); wavefronts it declines leave the sentinel -1 and the int32 kernel fills those in
+        bool const half_sweep = h->opt_f16 && sweep_cfg == 1 && h->opt_query_run % 16 == 0;
         PhaseTimer pt0(h, stream, 0);
+        if (half_sweep)
+        {
+            lx::ScoreParams sp1{};
+            sp1.q_res       = p.q_res;
+            sp1.s_res       = p.s_res;
+            sp1.ext         = p.ext;
+            sp1.n           = n;
+            sp1.sc          = p.sc;
+            sp1.out_score   = static_cast<int32_t *>(d_out_score);
+            sp1.err         = p.err;
+            sp1.nrows       = p.nrows;
+            sp1.ckpt        = p.trace;
+            sp1.ckpt_stride = sweep_stride;
+            sp1.steps_cap   = sweep_steps;
+            sp1.ends        = p.ends;
+            LX_HIP(h, lx::launch_score_pair(0, sp1, stream));
+            p.fixup = 1;
+        }
         LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
-        char buf[96];
-        snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", lx::trace_cfg_group(sweep_cfg),
-                 lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
+        char buf[128];
+        if (half_sweep)
+            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<8,19,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<8,19,false>)");
+        else
+            snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", lx::trace_cfg_group(sweep_cfg),
+                     lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
         h->last_kernel       = buf;
         h->last_trace_kernel = buf;
     }

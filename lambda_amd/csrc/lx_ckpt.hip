@@ -95,6 +95,19 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
     bool active = e < limit;
     if (active && p.src && p.src[e] == 0xffffffffu)
         active = false; // padding slot (keeps one query per sharing block)
+    bool in_list = e < limit;
+    if constexpr (!KNOWN)
+    {
+        if (p.fixup)
+        {
+            // second launch of the single sweep: only the extensions the packed-half kernel declined (sentinel -1)
+            bool const mine = in_list && p.score_out[e] == -1;
+            if (__ballot(mine) == 0)
+                return;
+            active  = active && mine;
+            in_list = mine;
+        }
+    }
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge    = sc->ge;
@@ -106,8 +119,7 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
     uint8_t const * q = p.q_res;
     uint8_t const * s = p.s_res;
     uint64_t        q_off = 0;
-    bool const      in_list = e < limit;
-    if (in_list)
+    if (e < limit)
     {
         Extension const x = p.ext[e];
         lq    = (int)x.q_len;
@@ -417,6 +429,16 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         p.out_hsp[oi] = out;
         return;
     }
+    // checkpoint values are int16, or half-precision bit patterns when the packed-half sweep wrote the slot
+    bool const half_enc = (ec.flags & kEndHalf) != 0;
+    auto dec = [&](uint32_t bits16) -> int
+    {
+        if (!half_enc)
+            return (int)(int16_t)bits16;
+        if ((bits16 & 0xffffu) == 0xfc00u)
+            return -(1 << 24); // -inf: "no gap state yet" (a multiple of 4 far below every real value)
+        return (int)(float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+    };
     uint32_t const * slot  = p.trace + se * p.slot_stride;
     uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);
     uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + Lay::bnd_dwords(p.steps_cap));
@@ -455,8 +477,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 for (int c = 0; c < C; ++c)
                 {
                     uint32_t const w = src[c];
-                    Hp[c]            = (int)(int16_t)(w & 0xffffu);
-                    F[c]             = (int)(int16_t)(w >> 16);
+                    Hp[c]            = dec(w & 0xffffu);
+                    F[c]             = dec(w >> 16);
                 }
             }
             int qr[C];
@@ -473,9 +495,9 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 int       E  = kFar, Hd = 0;
                 if (st > 0)
                 {
-                    E = (int)(int16_t)(bnd_word(r + st - 1) >> 16);
+                    E = dec(bnd_word(r + st - 1) >> 16);
                     if (r > 0)
-                        Hd = (int)(int16_t)(bnd_word(r + st - 2) & 0xffffu);
+                        Hd = dec(bnd_word(r + st - 2) & 0xffffu);
                 }
 #pragma unroll
                 for (int c = 0; c < C; ++c)
@@ -570,8 +592,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
-                Hp[c] = 4 * (int)(int16_t)(w[c] & 0xffffu);
-                F[c]  = (4 * (int)(int16_t)(w[c] >> 16)) | 2;
+                Hp[c] = 4 * dec(w[c] & 0xffffu);
+                F[c]  = (4 * dec(w[c] >> 16)) | 2;
             }
         }
         // LDS offsets of the matrix rows of this strip's query residues (columns beyond the query use the pad rank)
@@ -624,8 +646,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 if (row < 0)
                     continue; // virtual row of block 0: H = 0, F = floor stay as they are
                 uint32_t const tl = (sdw >> (8 * (row - lb))) & (kAlph - 1);
-                int            E  = has_left ? ((4 * (int)(int16_t)(lw[u] >> 16)) | 1) : (kFar | 1);
-                int            Hd = (has_left && row > 0) ? 4 * (int)(int16_t)(dw[u] & 0xffffu) : 0;
+                int            E  = has_left ? ((4 * dec(lw[u] >> 16)) | 1) : (kFar | 1);
+                int            Hd = (has_left && row > 0) ? 4 * dec(dw[u] & 0xffffu) : 0;
                 uint32_t       w[kNibDw];
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)

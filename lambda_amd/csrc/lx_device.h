@@ -68,6 +68,12 @@ struct ScoreParams
     int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
     int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
     int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
+    // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
+    // (as half-precision bit patterns) and the end cell of every extension
+    uint32_t *         ckpt;        // [n] slots of ckpt_stride uint32
+    uint64_t           ckpt_stride;
+    uint32_t           steps_cap;
+    struct EndCell *   ends;        // [n]
 };
 
 // best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel
@@ -79,6 +85,7 @@ struct EndCell
     int32_t flags; // kEndAmbiguous: the strip reaches the best score in more than one row
 };
 constexpr int32_t kEndAmbiguous = 1;
+constexpr int32_t kEndHalf      = 2; // the slot's checkpoints are half-precision bit patterns, not int16
 
 struct TraceParams
 {
@@ -112,6 +119,7 @@ struct TraceParams
     // slots and end cells by src[e] instead of by e
     int32_t *          score_out;
     int32_t            slot_by_src;
+    int32_t            fixup;         // single sweep, int32 kernel: only extensions whose score_out is the sentinel -1
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

@@ -66,8 +66,11 @@ struct PairGeo
     static constexpr int kRowDw    = kLaneDw * G;
 };
 
-template <int G, int C>
-__global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
+// CKPT = single sweep: the kernel additionally writes what pass 2's backtrace needs (layout and meaning as in
+// lx_ckpt.hip: strip boundaries per step, row checkpoints every 16 steps, here as half-precision bit patterns) and
+// keeps, per strip and extension, the best value, the first row that reached it and whether a later row tied.
+template <int G, int C, bool CKPT>
+__global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScoreParams p)
 {
     static_assert(C <= 24, "profile rows hold 24 halves per lane");
     using Geo = PairGeo<G, C>;
@@ -161,6 +164,15 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
                 p.out_score[eA] = -1;
             if (actB)
                 p.out_score[eB] = -1;
+            if constexpr (CKPT)
+            {
+                EndCell none{};
+                none.score = -1; // until the int32 fix-up launch has been here
+                if (actA)
+                    p.ends[eA] = none;
+                if (actB)
+                    p.ends[eB] = none;
+            }
         }
         return;
     }
@@ -224,6 +236,15 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
     h2 sendH = Z + GE;
     h2 sendE = as_h2(kHalfNegInf2);
     h2 best  = hsplat(0.f);
+    // CKPT: first row that reached this strip's best value, "a later row reached it again" (bit 0 = A, bit 1 = B)
+    int      rowA = 0, rowB = 0;
+    uint32_t tie  = 0;
+    int      krow = -g; // row of the step being processed
+    int      krow_slot = 0; // step % 4
+    constexpr int kCkDw   = (C + 3) / 4 * 4;
+    uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride : nullptr;
+    uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride : nullptr;
+    uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane * 8; // 2 quads per lane
 
     auto step = [&](uint32_t tA, uint32_t tB)
     {
@@ -276,8 +297,70 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
             rowmax = hmax(rowmax, h);
         sendH = h;
         sendE = Ecur;
-        best  = hmax(best, rowmax - Z);
-        Z     = ZN;
+        h2 const cand = rowmax - Z;
+        h2 const nb   = hmax(best, cand);
+        if constexpr (CKPT)
+        {
+            // per half: did the best rise (then this is its first row), or was it met again (a tie for the end cell)?
+            // Rows beyond the window and columns beyond the query stay strictly below a positive best: no validity test.
+            uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cand) ^ as_u32(best);
+            bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
+            bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
+            rowA = gtA ? krow : rowA;
+            rowB = gtB ? krow : rowB;
+            tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
+            tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+            // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
+            // re-paired per extension and staged for one 16-byte store per four steps
+            h2 const hb = h - Z, eb = Ecur - Z;
+            stage[krow_slot]     = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
+            stage[4 + krow_slot] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+            krow_slot            = (krow_slot + 1) & 3;
+            ++krow;
+        }
+        best = nb;
+        Z    = ZN;
+    };
+    // CKPT: after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
+    auto chunk_done = [&](int k0)
+    {
+        if constexpr (CKPT)
+        {
+            uint32_t const qi = (((uint32_t)k0 / 16) * G + (uint32_t)g) * 4 + (((uint32_t)k0 / 4) & 3);
+            if (actA)
+                reinterpret_cast<uint4 *>(slotA)[qi] = *reinterpret_cast<uint4 const *>(stage);
+            if (actB)
+                reinterpret_cast<uint4 *>(slotB)[qi] = *reinterpret_cast<uint4 const *>(stage + 4);
+            if (((k0 + 3) & 15) == 15)
+            {
+                // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's
+                h2 const zi = Z + GE;
+                uint64_t const base = (uint64_t)p.steps_cap * G + ((uint64_t)((k0 + 3) / 16) * G + (uint64_t)g) * kCkDw;
+                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA + base), * const dB = reinterpret_cast<uint4 *>(slotB + base);
+#pragma unroll
+                for (int x = 0; x < kCkDw / 4; ++x)
+                {
+                    uint32_t wa[4], wb[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                    {
+                        int const c = 4 * x + b;
+                        if (c < C)
+                        {
+                            h2 const hu = Hrow[c < C ? c : 0] - zi, fu = F0[c < C ? c : 0] - Z;
+                            wa[b] = __builtin_amdgcn_perm(as_u32(fu), as_u32(hu), 0x05040100u);
+                            wb[b] = __builtin_amdgcn_perm(as_u32(fu), as_u32(hu), 0x07060302u);
+                        }
+                        else
+                            wa[b] = wb[b] = 0;
+                    }
+                    if (actA)
+                        dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                    if (actB)
+                        dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                }
+            }
+        }
     };
 
     uint32_t const lscA = (uint32_t)max(lsA, 1) - 1u, lscB = (uint32_t)max(lsB, 1) - 1u;
@@ -321,6 +404,7 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
 #pragma unroll 1
             for (int u = 0; u < 4; ++u)
                 step(ca[u], cb[u]);
+            chunk_done(k0);
             k0 += 4;
         }
         else
@@ -336,26 +420,63 @@ __global__ __launch_bounds__(64) void score_pair_kernel(ScoreParams p)
 LX_UNROLL(LX_F16_UNROLL)
                 for (int u = 0; u < 4; ++u)
                     step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1));
+                chunk_done(k0);
                 k0 += 4;
             }
             fetch_checked(k0, na, nb);
         }
     }
 
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1)
-        best = hmax(best, as_h2((uint32_t)__shfl_xor((int)as_u32(best), off)));
-
-    if (is_first)
+    if constexpr (!CKPT)
     {
-        if (actA)
-            p.out_score[eA] = (int)(float)best.x;
-        if (actB)
-            p.out_score[eB] = (int)(float)best.y;
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1)
+            best = hmax(best, as_h2((uint32_t)__shfl_xor((int)as_u32(best), off)));
+
+        if (is_first)
+        {
+            if (actA)
+                p.out_score[eA] = (int)(float)best.x;
+            if (actB)
+                p.out_score[eB] = (int)(float)best.y;
+        }
+    }
+    else
+    {
+        // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first)
+        auto finish = [&](int lbest, int lrow, int ltie, bool act, uint64_t e)
+        {
+            int gbest = lbest, gstrip = g, grow = lrow, gtie = ltie;
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1)
+            {
+                int const  ob = __shfl_xor(gbest, off), os = __shfl_xor(gstrip, off), orow = __shfl_xor(grow, off), ot = __shfl_xor(gtie, off);
+                bool const take = ob > gbest || (ob == gbest && os < gstrip);
+                gbest  = take ? ob : gbest;
+                gstrip = take ? os : gstrip;
+                grow   = take ? orow : grow;
+                gtie   = take ? ot : gtie;
+            }
+            if (is_first && act)
+            {
+                EndCell ec{};
+                if (gbest > 0)
+                {
+                    ec.score = gbest;
+                    ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
+                    ec.s_end = grow + 1;
+                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndHalf;
+                }
+                p.ends[e]      = ec;
+                p.out_score[e] = gbest;
+            }
+        };
+        finish((int)(float)best.x, rowA, (int)(tie & 1u), actA, eA);
+        finish((int)(float)best.y, rowB, (int)((tie >> 1) & 1u), actB, eB);
     }
 }
 
-template <int G, int C>
+template <int G, int C, bool CKPT = false>
 static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
 {
     using Geo = PairGeo<G, C>;
@@ -366,8 +487,8 @@ static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
     int const    slots = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? Geo::kGroups / p.pair_share : 1;
     if (slots * p.pair_share != Geo::kGroups && slots != 1)
         return hipErrorInvalidValue;
-    size_t const lds = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
-    hipLaunchKernelGGL((score_pair_kernel<G, C>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    size_t const lds = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + (CKPT ? 64 * 8 : 0)) * sizeof(uint32_t);
+    hipLaunchKernelGGL((score_pair_kernel<G, C, CKPT>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -377,6 +498,8 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
+    if (p.ckpt) // single sweep: the (8,19) geometry of lx_ckpt.hip's layout
+        return (cfg == 0 && p.ends && p.steps_cap % 16 == 0) ? launch_pair_cfg<8, 19, true>(p, stream) : hipErrorInvalidValue;
     switch (cfg)
     {
         case 0: return launch_pair_cfg<8, 19>(p, stream);

@@ -271,7 +271,8 @@ def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
         handle.synchronize()
         if run % 8 == 0 and run > 0:  # shared-profile geometries: the mode decides the kernels
             name = handle.last_trace_kernel_name()
-            assert ("ckpt_forward_kernel" in name) == (pass2_mode >= 1) and ("single sweep" in name) == (pass2_mode == 2)
+            assert (("ckpt_forward_kernel" in name) or ("score_pair_kernel<8,19,true>" in name)) == (pass2_mode >= 1)
+            assert ("single sweep" in name) == (pass2_mode == 2)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
@@ -398,6 +399,7 @@ def test_full_size_fused_step_properties(handle, oracle, pass2_mode):
         handle.synchronize()
         name = handle.last_trace_kernel_name()
         assert ("ckpt_forward_kernel" in name) == (pass2_mode >= 1) and ("single sweep" in name) == (pass2_mode == 2)
+        assert ("score_pair_kernel<8,19,true>" in name) == (pass2_mode == 2)  # packed-half sweep on the headline shape
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
