@@ -44,12 +44,20 @@ constexpr int kCkptEvery = LX_CKPT_EVERY;
 #define LX_CKPT_FWD_WAVES 4
 #endif
 
-// slot layout in uint32 units: boundary quads (4 steps = 4 dwords each) [step / 16][lane][(step / 4) % 4] -- the 16 steps
-// of a lane that one tile needs sit in one 64-byte chunk --, then row checkpoints [checkpoint][lane][kCkDw]
+// slot layout in uint32 units: boundary quads (4 steps = 4 dwords each) [step / 4][lane], then row checkpoints
+// [checkpoint][quad of 4 columns][lane] -- both lane-minor: the G lanes of a group write G consecutive 16-byte quads per
+// store instruction, i.e. whole cache lines (the forward kernels are sensitive to the number of lines a store touches,
+// the backtrace is not sensitive to the number it reads)
 template <int G>
 __host__ __device__ constexpr uint32_t bnd_quad_index(uint32_t quad, uint32_t g)
 {
-    return ((quad / 4) * G + g) * 4 + (quad % 4);
+    return quad * G + g;
+}
+// uint4 index of quad x of lane g's row checkpoint m
+template <int G, int kCkDw>
+__host__ __device__ constexpr uint32_t rowck_quad_index(uint32_t m, uint32_t g, uint32_t x)
+{
+    return (m * (kCkDw / 4) + x) * G + g;
 }
 template <int G, int C>
 struct CkptLayout
@@ -273,7 +281,6 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
     {
         if (!store_ok)
             return;
-        uint4 * dst = rowck + ((uint32_t)(k / kCkptEvery) * G + (uint32_t)g) * (Lay::kCkDw / 4);
 #pragma unroll
         for (int x = 0; x < Lay::kCkDw / 4; ++x)
         {
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
                 int const c = 4 * x + b;
                 w[b]        = c < C ? pack16(Hrow[c < C ? c : 0] - (z + gev), F0[c < C ? c : 0] - z) : 0u;
             }
-            dst[x] = make_uint4(w[0], w[1], w[2], w[3]);
+            rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(k / kCkptEvery), (uint32_t)g, (uint32_t)x)] = make_uint4(w[0], w[1], w[2], w[3]);
         }
     };
 
@@ -472,11 +479,11 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             }
             else
             {
-                uint32_t const * src = reinterpret_cast<uint32_t const *>(rowck + ((uint32_t)(m0 - 1) * G + (uint32_t)st) * (Lay::kCkDw / 4));
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                 {
-                    uint32_t const w = src[c];
+                    uint32_t const w = reinterpret_cast<uint32_t const *>(
+                        rowck + rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)(c / 4)))[c % 4];
                     Hp[c]            = dec(w & 0xffffu);
                     F[c]             = dec(w >> 16);
                 }
@@ -581,12 +588,11 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         }
         else
         {
-            uint4 const * src = rowck + ((uint32_t)(m - 1) * G + (uint32_t)st) * (Lay::kCkDw / 4);
             uint32_t      w[Lay::kCkDw];
 #pragma unroll
             for (int xq = 0; xq < Lay::kCkDw / 4; ++xq)
             {
-                uint4 const v = src[xq];
+                uint4 const v = rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
                 w[4 * xq] = v.x; w[4 * xq + 1] = v.y; w[4 * xq + 2] = v.z; w[4 * xq + 3] = v.w;
             }
 #pragma unroll

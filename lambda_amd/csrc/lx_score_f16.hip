@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     {
         if constexpr (CKPT)
         {
-            uint32_t const qi = (((uint32_t)k0 / 16) * G + (uint32_t)g) * 4 + (((uint32_t)k0 / 4) & 3);
+            uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g; // lx_ckpt.hip: bnd_quad_index
             if (actA)
                 reinterpret_cast<uint4 *>(slotA)[qi] = *reinterpret_cast<uint4 const *>(stage);
             if (actB)
@@ -335,8 +335,9 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
             {
                 // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's
                 h2 const zi = Z + GE;
-                uint64_t const base = (uint64_t)p.steps_cap * G + ((uint64_t)((k0 + 3) / 16) * G + (uint64_t)g) * kCkDw;
-                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA + base), * const dB = reinterpret_cast<uint4 *>(slotB + base);
+                // lx_ckpt.hip: rowck_quad_index -- quad x of checkpoint m sits at (m * kCkDw/4 + x) * G + g behind the boundary quads
+                uint64_t const base = (uint64_t)p.steps_cap * G / 4 + (uint64_t)((k0 + 3) / 16) * (kCkDw / 4) * G + (uint64_t)g;
+                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
                 for (int x = 0; x < kCkDw / 4; ++x)
                 {
@@ -355,9 +356,9 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
                             wa[b] = wb[b] = 0;
                     }
                     if (actA)
-                        dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                        dA[x * G] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
                     if (actB)
-                        dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                        dB[x * G] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
                 }
             }
         }
