@@ -244,7 +244,8 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     constexpr int kCkDw   = (C + 3) / 4 * 4;
     uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride : nullptr;
     uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride : nullptr;
-    uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane * 8; // 2 quads per lane
+    // staging of the boundary words: [extension A / B][step % 4][lane] -- lane-minor, free of bank conflicts
+    uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane;
 
     auto step = [&](uint32_t tA, uint32_t tB)
     {
@@ -313,8 +314,8 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
             // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
             // re-paired per extension and staged for one 16-byte store per four steps
             h2 const hb = h - Z, eb = Ecur - Z;
-            stage[krow_slot]     = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
-            stage[4 + krow_slot] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+            stage[krow_slot * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
+            stage[(4 + krow_slot) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
             krow_slot            = (krow_slot + 1) & 3;
             ++krow;
         }
@@ -328,15 +329,21 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
         {
             uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g; // lx_ckpt.hip: bnd_quad_index
             if (actA)
-                reinterpret_cast<uint4 *>(slotA)[qi] = *reinterpret_cast<uint4 const *>(stage);
+                reinterpret_cast<uint4 *>(slotA)[qi] = make_uint4(stage[0], stage[64], stage[128], stage[192]);
             if (actB)
-                reinterpret_cast<uint4 *>(slotB)[qi] = *reinterpret_cast<uint4 const *>(stage + 4);
+                reinterpret_cast<uint4 *>(slotB)[qi] = make_uint4(stage[256], stage[320], stage[384], stage[448]);
             if (((k0 + 3) & 15) == 15)
             {
                 // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's
                 h2 const zi = Z + GE;
                 // lx_ckpt.hip: rowck_quad_index -- quad x of checkpoint m sits at (m * kCkDw/4 + x) * G + g behind the boundary quads
-                uint64_t const base = (uint64_t)p.steps_cap * G / 4 + (uint64_t)((k0 + 3) / 16) * (kCkDw / 4) * G + (uint64_t)g;
+#ifndef LX_CKPT_ROWCK_LANE_MAJOR
+#define LX_CKPT_ROWCK_LANE_MAJOR 1
+#endif
+                constexpr uint64_t kXStride = LX_CKPT_ROWCK_LANE_MAJOR ? 1 : G;
+                uint64_t const base = (uint64_t)p.steps_cap * G / 4 +
+                                      (LX_CKPT_ROWCK_LANE_MAJOR ? ((uint64_t)((k0 + 3) / 16) * G + (uint64_t)g) * (kCkDw / 4)
+                                                                : (uint64_t)((k0 + 3) / 16) * (kCkDw / 4) * G + (uint64_t)g);
                 uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
                 for (int x = 0; x < kCkDw / 4; ++x)
@@ -356,9 +363,9 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
                             wa[b] = wb[b] = 0;
                     }
                     if (actA)
-                        dA[x * G] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                        dA[x * kXStride] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
                     if (actB)
-                        dB[x * G] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                        dB[x * kXStride] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
                 }
             }
         }
