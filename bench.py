@@ -269,6 +269,10 @@ def main():
         # algorithmic bytes: pass 1 reads every window once, every query once per run, one 24-byte record per extension and
         # writes one int32 score; pass 2 forward reads the same per survivor (+ its score) and writes 4 direction bits per cell
         algo_bytes = float(ext["q_len"].sum()) / args.windows + float(ext["s_len"].sum()) + n * ALGO_BYTES_PER_EXT_EXTRA
+        if "single sweep" in kernel_name:
+            # the sweep also writes the checkpoints of every extension: one 4-byte boundary pair per strip and row, one
+            # 4-byte pair per column every 16 rows, and a 16-byte end record
+            algo_bytes += n * (ls * (-(-lq // 19)) * 4 + (ls / 16.0) * lq * 4 + 16)
         r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], cells_rank,
                            "score_pair_kernel" if "pair_kernel" in kernel_name else "score_kernel", algo_bytes)
         rooflines = [r_score]
@@ -308,6 +312,7 @@ def main():
                                f"{args.max_matches} HSP records (56 B) after the last step"
                                + (f" ({n_hits_total} records)" if n_hits_total is not None else ""),
                 "step": ("pass 1 score kernel over the whole batch" if args.pass1_only else
+                         ("single sweep: " if "single sweep" in kernel_name else "") +
                          f"pass 1 (score all) -> e-value filter (E<={args.max_evalue:g} at db {args.db_length}, i.e. score>={min_score}) "
                          f"-> pass 2 (traceback of the {survivors} survivors), all on the GPU; GCUPS counts pass-1 cells only"),
                 "survivors_per_gpu": survivors,
