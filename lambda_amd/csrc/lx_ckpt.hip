@@ -537,8 +537,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             // (kcol == C cannot happen: the forward pass saw the score in this strip; the tile path below then flags it)
         }
     }
-    int const end_i = i; // the end cell's row is final here, its column once need_col is false
-    int       end_j = j;
+    int end_i = i, end_j = j; // final once need_col is false
+    int res_col = C, res_row = 0x7fffffff; // resolution of the end cell inside the first tile
     int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
     int      left = ec.score;
     uint32_t n    = 0;
@@ -689,6 +689,16 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
+                if (need_col && row >= i - 3 && row < (int)x.s_len)
+                {
+#pragma unroll
+                    for (int c = C - 1; c >= 0; --c)
+                        if (Hp[c] == 4 * ec.score && c <= res_col && (c < res_col || row < res_row))
+                        {
+                            res_col = c;
+                            res_row = row;
+                        }
+                }
             }
             qprev = qcur;
             qcur  = qnext;
@@ -696,21 +706,19 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 
         if (need_col)
         {
-            // Hp[] holds 4 H of the last computed row = the end row: its first column that carries the best score
+            // the end row is one of the last four computed rows (the packed-half sweep reports the chunk, the int32 sweep
+            // the exact row -- earlier rows of the strip then do not carry the score): lowest column, then lowest row
             need_col = false;
-            int found = -1;
-#pragma unroll
-            for (int c = C - 1; c >= 0; --c)
-                if (Hp[c] == 4 * ec.score)
-                    found = c;
-            if (found < 0)
+            if (res_col >= C)
             {
-                done     = true; // the forward pass saw this score in this row of the strip: never guess
+                done     = true; // the forward pass saw this score in these rows of the strip: never guess
                 left     = -1;
                 ec.score = -1;
                 break;
             }
-            j     = j0 + found;
+            i     = res_row;
+            j     = j0 + res_col;
+            end_i = i;
             end_j = j;
         }
         // ---- walk inside the tile

@@ -241,6 +241,7 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     uint32_t tie  = 0;
     int      krow = -g; // row of the step being processed
     int      krow_slot = 0; // step % 4
+    h2       cmax = as_h2(kHalfNegInf2); // best un-skewed row maximum of the current chunk
     constexpr int kCkDw   = (C + 3) / 4 * 4;
     uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride : nullptr;
     uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride : nullptr;
@@ -299,34 +300,41 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
         sendH = h;
         sendE = Ecur;
         h2 const cand = rowmax - Z;
-        h2 const nb   = hmax(best, cand);
         if constexpr (CKPT)
         {
-            // per half: did the best rise (then this is its first row), or was it met again (a tie for the end cell)?
-            // Rows beyond the window and columns beyond the query stay strictly below a positive best: no validity test.
-            uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cand) ^ as_u32(best);
-            bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
-            bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
-            rowA = gtA ? krow : rowA;
-            rowB = gtB ? krow : rowB;
-            tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
-            tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+            cmax = hmax(cmax, cand); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
             // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
             // re-paired per extension and staged for one 16-byte store per four steps
             h2 const hb = h - Z, eb = Ecur - Z;
             stage[krow_slot * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
             stage[(4 + krow_slot) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
-            krow_slot            = (krow_slot + 1) & 3;
+            krow_slot                   = (krow_slot + 1) & 3;
             ++krow;
         }
-        best = nb;
-        Z    = ZN;
+        else
+            best = hmax(best, cand);
+        Z = ZN;
     };
     // CKPT: after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
     auto chunk_done = [&](int k0)
     {
         if constexpr (CKPT)
         {
+            // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
+            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and
+            // columns beyond the query stay strictly below a positive best: no validity test.
+            {
+                h2 const       nb   = hmax(best, cmax);
+                uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
+                bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
+                bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
+                rowA = gtA ? krow - 1 : rowA; // krow - 1 = the chunk's last row
+                rowB = gtB ? krow - 1 : rowB;
+                tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
+                tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+                best = nb;
+                cmax = as_h2(kHalfNegInf2);
+            }
             uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g; // lx_ckpt.hip: bnd_quad_index
             if (actA)
                 reinterpret_cast<uint4 *>(slotA)[qi] = make_uint4(stage[0], stage[64], stage[128], stage[192]);
