@@ -1278,7 +1278,15 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         p.cfg            = sweep_cfg;
         // packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query
         // per wavefront); wavefronts it declines leave the sentinel -1 and the int32 kernel fills those in
-        bool const half_sweep = h->opt_f16 && sweep_cfg == 1 && h->opt_query_run % 16 == 0;
+        // (runs of 8: one query per half wavefront where two LDS profiles fit, i.e. for the small alphabets)
+        int        sweep_share = 0;
+        bool       half_sweep  = h->opt_f16 && sweep_cfg == 1 && h->opt_query_run % 16 == 0;
+        if (h->opt_f16 && sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
+            2 * lx::score_pair_profile_bytes(0, p.nrows) + 64 * 8 * 4 <= 13 * 1024)
+        {
+            half_sweep  = true;
+            sweep_share = 4;
+        }
         PhaseTimer pt0(h, stream, 0);
         if (half_sweep)
         {
@@ -1295,6 +1303,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
             sp1.ckpt_stride = sweep_stride;
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
+            sp1.pair_share  = sweep_share;
             LX_HIP(h, lx::launch_score_pair(0, sp1, stream));
             p.fixup = 1;
         }
