@@ -1280,7 +1280,8 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         // per wavefront); wavefronts it declines leave the sentinel -1 and the int32 kernel fills those in
         // (runs of 8: one query per half wavefront where two LDS profiles fit, i.e. for the small alphabets)
         int        sweep_share = 0;
-        bool       half_sweep  = h->opt_f16 && sweep_cfg == 1 && h->opt_query_run % 16 == 0;
+        int const  sweep_pair  = sweep_cfg == 1 ? 0 : 5; // pair geometry with the same (G, C): (8,19) / (16,13)
+        bool       half_sweep  = h->opt_f16 && ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
         if (h->opt_f16 && sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
             2 * lx::score_pair_profile_bytes(0, p.nrows) + 64 * 8 * 4 <= 13 * 1024)
         {
@@ -1304,14 +1305,16 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
-            LX_HIP(h, lx::launch_score_pair(0, sp1, stream));
+            LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
             p.fixup = 1;
         }
         LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
         char buf[128];
         if (half_sweep)
-            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<8,19,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<8,19,false>)");
+            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
+                     lx::trace_cfg_group(sweep_cfg), lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg),
+                     lx::trace_cfg_group(sweep_cfg), lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
         else
             snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", lx::trace_cfg_group(sweep_cfg),
                      lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));

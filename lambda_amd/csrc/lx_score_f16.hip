@@ -514,8 +514,12 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    if (p.ckpt) // single sweep: the (8,19) geometry of lx_ckpt.hip's layout
-        return (cfg == 0 && p.ends && p.steps_cap % 16 == 0) ? launch_pair_cfg<8, 19, true>(p, stream) : hipErrorInvalidValue;
+    if (p.ckpt) // single sweep: the geometries lx_ckpt.hip's layout is instantiated for
+    {
+        if (!p.ends || p.steps_cap % 16 != 0)
+            return hipErrorInvalidValue;
+        return cfg == 0 ? launch_pair_cfg<8, 19, true>(p, stream) : cfg == 5 ? launch_pair_cfg<16, 13, true>(p, stream) : hipErrorInvalidValue;
+    }
     switch (cfg)
     {
         case 0: return launch_pair_cfg<8, 19>(p, stream);
