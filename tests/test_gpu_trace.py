@@ -530,3 +530,71 @@ def test_fused_ties_two_letter_alphabet(handle, oracle, pass2_mode):
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_fused_fuzz_shapes_and_modes(handle, oracle, seed):
+    """Random shapes through the fused step: query length 20..208 (all sweep geometries and the fall-backs beyond),
+    runs of 8 / 16 / 24 / 32 windows, ragged window lengths (including empty and very short ones), protein and
+    nucleotide schemes, random cut-offs -- every pass-2 mode must reproduce the oracle for every survivor."""
+    import torch
+
+    rng = np.random.default_rng(1000 + seed)
+    name = ["blosum62", "nucl", "blosum62", "bs_fwd", "blosum62", "nucl"][seed - 1]
+    lq = int([33, 150, 208, 97, 152, 61][seed - 1] if seed <= 6 else rng.integers(20, 209))
+    wpq = int([8, 16, 24, 32, 8, 16][seed - 1])
+    alpha = synth.STD20 if name == "blosum62" else np.arange(4, dtype=np.uint8)
+    sc_p = SCHEMES[name]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    nq = 24
+    q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=77 + seed, alphabet=alpha, sub_rate=0.15 if name == "blosum62" else 0.05,
+                                    indel_rate=0.03)
+    ext = ext.copy()
+    full = ext["s_len"].copy()
+    cut = rng.random(len(ext))
+    ext["s_len"] = np.where(cut < 0.05, 0, np.where(cut < 0.15, rng.integers(1, 12, len(ext)),
+                            np.where(cut < 0.5, (full * rng.uniform(0.4, 1.0, len(ext))).astype(np.uint32), full))).astype(np.uint32)
+    n = len(ext)
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    cutoff = int(np.percentile(want_score, 45)) + 1
+    surv = np.nonzero((want_score >= cutoff) & (ext["s_len"] > 0))[0]
+    want = oracle.align_batch(q, s, ext[surv], osc)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    sizes = ext["q_len"].astype(np.uint64) + full.astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    for mode in (2, 1, 0):
+        d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+        d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+        d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+        handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, int(full.max()))
+        handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, mode)
+        torch.cuda.synchronize()
+        try:
+            handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+            handle.synchronize()
+        finally:
+            handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+            handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+            handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+            handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        assert (d_score.cpu().numpy() == want_score).all(), (mode, handle.last_kernel_name())
+        assert int(d_count.cpu()[1]) == len(surv)
+        hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+        ops = d_ops.cpu().numpy()
+        for i, (oh, oops) in zip(surv, want):
+            g = hsp[i]
+            assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+                   (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (mode, i, handle.last_trace_kernel_name())
+            st = int(off[i]) + int(g["ops_shift"])
+            assert bytes(ops[st: st + oh.n_ops]) == oops, (mode, i)
+    handle.set_scoring(SCHEMES["blosum62"], 0)
