@@ -155,7 +155,10 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     for (int off = G / 2; off >= 1; off >>= 1)
         bound += __shfl_xor(bound, off);
     // (every group summed its own query; one block over the limit sends the whole wavefront to the fix-up launch)
-    bool const too_big = __ballot((lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046)) != 0;
+    bool too_big = __ballot((lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046)) != 0;
+    if constexpr (CKPT)
+        too_big = too_big || (uint32_t)steps > p.steps_cap; // LX_OPT_MAX_SLEN promise broken: the int32 launch reports it
+
     if (too_big)
     {
         if (is_first)

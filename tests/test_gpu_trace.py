@@ -598,3 +598,40 @@ def test_fused_fuzz_shapes_and_modes(handle, oracle, seed):
             st = int(off[i]) + int(g["ops_shift"])
             assert bytes(ops[st: st + oh.n_ops]) == oops, (mode, i)
     handle.set_scoring(SCHEMES["blosum62"], 0)
+
+
+def test_fused_rejects_broken_length_promise(handle):
+    """LX_OPT_MAX_SLEN / LX_OPT_MAX_QLEN size the checkpoint slots; a window or query longer than promised must be
+    reported (never written past its slot), in every pass-2 mode."""
+    import torch
+
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    q, s, ext = synth.make_batch_np(16, 150, 16, seed=5)
+    n = len(ext)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    for mode in (2, 1, 0):
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 150)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 100)  # the windows are 176 long
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 16)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, mode)
+        try:
+            handle.extend_batch_dev(d_q, d_s, d_ext, n, 60, d_score, d_hsp, d_ops, d_off, d_count)
+            with pytest.raises(capi.LambdaExtError):
+                handle.synchronize()
+        finally:
+            handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+            handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+            handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+            handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
