@@ -189,6 +189,15 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
                         uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
                         void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream);
 
+/* The same on host buffers (what lx_iterate_matches uses).  Extension order is free; extensions of one query slice are
+ * best adjacent (lambda's lists are).  out_score[n] as in pass 1; out_hsp[n]: filtered-out rows carry the score and
+ * n_ops = 0; the ops of a survivor i are *out_ops + out_ops_off[i] + out_hsp[i].ops_shift (the callee lays the slots out
+ * compactly; the buffer belongs to the handle and stays valid until its next lx_extend_batch call).  One
+ * synchronisation between the passes: only the survivors' records and ops cross PCIe. */
+int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                    lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                    lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
+
 /* ---- pre-extension filter (seedLooksPromising, src/search_algo.hpp:426-481) ------------------ */
 /* One diagonal per item; out_keep[i] = 1 if the ungapped max-segment score reaches the threshold. */
 typedef struct lx_seed

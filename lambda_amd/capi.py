@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -151,6 +151,7 @@ def load():
     lib.lx_bitscore.restype = C.c_double
     lib.lx_convert_ranks.argtypes = [i32, vp, u64, vp]
     lib.lx_set_subjects.argtypes = [vp, vp, u64]
+    lib.lx_extend_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
     lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lx_set_frames.restype = None
     lib.lx_untrue_qry_id.argtypes = [i32, u64, i32]
@@ -349,6 +350,27 @@ class Handle:
         self._check(self.lib.lx_prefilter_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res),
                                                 _ptr(seeds), len(seeds), seed_length, pre_scoring, thresh, _ptr(keep)))
         return keep
+
+    def extend_batch(self, q_res, s_res, ext, min_score, slot: int = 0, copy_ops: bool = True):
+        """lx_extend_batch: both passes on host buffers.  min_score = int cut-off for all, or an int32 array per
+        extension.  Returns (scores, hsp, ops_off, ops) -- ops is a copy of the handle-owned buffer (copy_ops=False: a
+        view that the next call invalidates)."""
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)
+        ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
+        n = len(ext)
+        per = None if np.isscalar(min_score) else np.ascontiguousarray(min_score, dtype=np.int32)
+        score = np.zeros(n, dtype=np.int32)
+        hsp = np.zeros(n, dtype=HSP_DTYPE)
+        off = np.zeros(n, dtype=np.uint64)
+        p, nb = C.c_void_p(), C.c_uint64()
+        self._check(self.lib.lx_extend_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext), n,
+                                             None if per is None else _ptr(per), 0 if per is not None else int(min_score),
+                                             _ptr(score), _ptr(hsp), _ptr(off), C.byref(p), C.byref(nb)))
+        if not nb.value:
+            return score, hsp, off, np.zeros(1, np.uint8)
+        ops = np.ctypeslib.as_array((C.c_uint8 * int(nb.value)).from_address(p.value))
+        return score, hsp, off, ops.copy() if copy_ops else ops
 
     def set_subjects(self, s_res):
         """lx_set_subjects: keep the subject residues on the device; later host-buffer calls may pass s_res=None."""

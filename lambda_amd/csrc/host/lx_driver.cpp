@@ -5,7 +5,7 @@
 //   _widenAndPreprocessMatches   :1136-1175   (lambda_amd::widenAndPreprocessMatches)
 //   iterateMatchesFullSimd       :1177-1332   (lambda_amd::iterateMatchesFullSimd -> lx_iterate_matches)
 //   _expandAlign (coordinates)   :1032-1035
-// The DP itself never runs here: both passes go to the GPU through lx_score_batch / lx_align_batch.
+// The DP itself never runs here: both passes go to the GPU through lx_extend_batch.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -189,102 +189,90 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         ext[i].s_off       = s_seq_off[m.subjId] + m.subjStart;
         ext[i].s_len       = (uint32_t)(m.subjEnd - m.subjStart);
     }
-    // sort by lengths to minimize padding (:1229-1235); std::list::sort is stable
-    std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](uint32_t a, uint32_t b)
-                     { return std::make_tuple(ext[a].q_len, ext[a].s_len) < std::make_tuple(ext[b].q_len, ext[b].s_len); });
-    std::vector<lx_extension> sortedExt(n);
-    for (uint64_t k = 0; k < n; ++k)
-        sortedExt[k] = ext[order[k]];
-
-    // Run extensions WITHOUT ALIGNMENT (:1246)
-    std::vector<int32_t> scores(n, 0);
-    int rc = lx_score_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sortedExt.data(), n, scores.data());
+    // The reference sorts the list by lengths to minimise SIMD padding (:1229-1235), runs the extensions WITHOUT
+    // alignment (:1246), filters by bit score and e-value (:1251-1283), runs the survivors WITH alignment (:1293-1296)
+    // and stably re-sorts by query (:1299).  Here both passes are one call: bit score and e-value are monotone in the
+    // raw score for a given query length (src/search_misc.hpp:77-78), so the filter goes to the device as an integer
+    // cut-off per extension -- found with the very double formulas below, hence identical decisions -- and the list
+    // stays in match order (sorted by query since widen/merge: one LDS profile per run).  The reference's two stable
+    // sorts only fix the order of the survivors, which is restored afterwards: (query, lengths, list position).
+    EValueContext evalue{params->karlin, params->db_total_length, params->query_translated != 0, {}};
+    auto passes = [&](int32_t score, uint64_t qLength)
+    {
+        if (params->min_bitscore >= 0 && computeBitScore(score, params->karlin) < params->min_bitscore)
+            return false;
+        if (params->max_evalue >= 0 && evalue(score, qLength) > params->max_evalue)
+            return false;
+        return true;
+    };
+    std::unordered_map<uint64_t, int32_t> cutOffs; // by query length
+    auto cutOffFor = [&](uint64_t qLength)
+    {
+        auto it = cutOffs.find(qLength);
+        if (it != cutOffs.end())
+            return it->second;
+        int32_t const top = 1 << 30;
+        int32_t       cut = 0x7fffffff;
+        if (passes(0, qLength))
+            cut = 0;
+        else if (passes(top, qLength))
+        {
+            int32_t lo = 0, hi = top; // passes(lo) false, passes(hi) true
+            while (hi - lo > 1)
+            {
+                int32_t const mid = lo + (hi - lo) / 2;
+                (passes(mid, qLength) ? hi : lo) = mid;
+            }
+            cut = hi;
+        }
+        cutOffs.emplace(qLength, cut);
+        return cut;
+    };
+    std::vector<int32_t>  minScore(n);
+    std::vector<uint64_t> qLengthOf(n);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        uint64_t const nq = matches[i].qryId / qFrames;
+        qLengthOf[i]      = q_orig_len ? q_orig_len[nq] : q_seq_len[matches[i].qryId];
+        minScore[i]       = cutOffFor(qLengthOf[i]);
+    }
+    std::vector<int32_t>  scores(n, 0);
+    std::vector<lx_hsp>   hspAll(n);
+    std::vector<uint64_t> opsOffAll(n);
+    uint8_t const *       ops      = nullptr;
+    uint64_t              opsBytes = 0;
+    int rc = lx_extend_batch(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), hspAll.data(),
+                             opsOffAll.data(), &ops, &opsBytes);
     if (rc != LX_OK)
         return rc;
 
-    // compute evalues and filter based on evalue (:1251-1283)
-    EValueContext evalue{params->karlin, params->db_total_length, params->query_translated != 0, {}};
-    struct Survivor
-    {
-        uint32_t idx; // index into `matches`
-        int32_t  score;
-        double   bitScore, eValue;
-    };
-    std::vector<Survivor> surv;
+    // the filter's statistics (:1260, :1274) from the scores of pass 1
+    std::vector<uint32_t> surv; // indices into `matches`
     surv.reserve(n);
-    for (uint64_t k = 0; k < n; ++k)
+    for (uint64_t i = 0; i < n; ++i)
     {
-        Survivor        s{order[k], scores[k], 0.0, 0.0};
-        uint64_t const  nq      = matches[s.idx].qryId / qFrames;
-        uint64_t const  qLength = q_orig_len ? q_orig_len[nq] : q_seq_len[matches[s.idx].qryId];
-        if (params->min_bitscore >= 0)
-        {
-            s.bitScore = computeBitScore(s.score, params->karlin);
-            if (s.bitScore < params->min_bitscore)
-            {
-                ++res->stats.failed_bitscore;
-                continue;
-            }
-        }
-        if (params->max_evalue >= 0)
-        {
-            s.eValue = evalue(s.score, qLength);
-            if (s.eValue > params->max_evalue)
-            {
-                ++res->stats.failed_evalue;
-                continue;
-            }
-        }
-        surv.push_back(s);
+        if (scores[i] >= minScore[i])
+            surv.push_back((uint32_t)i);
+        else if (params->min_bitscore >= 0 && computeBitScore(scores[i], params->karlin) < params->min_bitscore)
+            ++res->stats.failed_bitscore;
+        else
+            ++res->stats.failed_evalue;
     }
     if (surv.empty())
         return LX_OK;
     res->stats.num_ext_ali += surv.size(); // :1287
-
-    // Run extensions WITH ALIGNMENT (:1293-1296).  The GPU wants the windows of one query next to each other (one LDS
-    // profile per query), so the call goes out in match order -- the span is sorted by query since widen/merge -- and
-    // the results are put back into the survivor order, which is the one the reference's later stable sort sees.
-    std::vector<uint32_t> byMatch(surv.size());
-    std::iota(byMatch.begin(), byMatch.end(), 0u);
-    std::sort(byMatch.begin(), byMatch.end(), [&](uint32_t a, uint32_t b) { return surv[a].idx < surv[b].idx; });
-    std::vector<lx_extension> sExt(surv.size());
-    std::vector<int32_t>      sScore(surv.size());
-    std::vector<uint64_t>     opsOff(surv.size()), opsOffCall(surv.size());
-    uint64_t                  total = 0;
-    for (size_t k = 0; k < surv.size(); ++k)
-    {
-        Survivor const & sv = surv[byMatch[k]];
-        sExt[k]             = ext[sv.idx];
-        sScore[k]           = sv.score;
-        opsOffCall[k]       = total;
-        opsOff[byMatch[k]]  = total;
-        total += (uint64_t)sExt[k].q_len + sExt[k].s_len;
-    }
-    std::vector<lx_hsp>  hspCall(surv.size()), hsp(surv.size());
-    std::vector<uint8_t> ops(total + 1, 0);
-    rc = lx_align_batch(h, slot, q_res, q_bytes, s_res, s_bytes, sExt.data(), sExt.size(), sScore.data(), hspCall.data(), ops.data(),
-                        opsOffCall.data());
-    if (rc != LX_OK)
-        return rc;
-    for (size_t k = 0; k < surv.size(); ++k)
-        hsp[byMatch[k]] = hspCall[k];
-
-    // sort by query (:1299), stable
-    std::vector<uint32_t> sOrder(surv.size());
-    std::iota(sOrder.begin(), sOrder.end(), 0u);
-    std::stable_sort(sOrder.begin(), sOrder.end(),
-                     [&](uint32_t a, uint32_t b)
-                     { return matches[surv[a].idx].qryId / qFrames < matches[surv[b].idx].qryId / qFrames; });
+    std::sort(surv.begin(), surv.end(),
+              [&](uint32_t a, uint32_t b)
+              {
+                  return std::make_tuple(matches[a].qryId / qFrames, ext[a].q_len, ext[a].s_len, a) <
+                         std::make_tuple(matches[b].qryId / qFrames, ext[b].q_len, ext[b].s_len, b);
+              });
 
     // compute the rest of the match properties (:1302-1325)
-    for (uint32_t k : sOrder)
+    for (uint32_t k : surv)
     {
-        Survivor &       s = surv[k];
-        lx_match const & m = matches[s.idx];
-        lx_hsp const &   a = hsp[k];
+        lx_match const & m = matches[k];
+        lx_hsp const &   a = hspAll[k];
         lx_blast_match   bm{};
         bm.qry_id  = m.qryId;
         bm.subj_id = m.subjId;
@@ -314,12 +302,14 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
             ++res->stats.failed_identity;
             continue;
         }
-        uint64_t const qLength = q_orig_len ? q_orig_len[bm.n_qid] : q_seq_len[m.qryId];
-        bm.bit_score = (params->min_bitscore < 0) ? computeBitScore(a.score, params->karlin) : s.bitScore; // :1318-1319
-        bm.e_value   = (params->max_evalue < 0) ? evalue(a.score, qLength) : s.eValue;                        // :1321-1322
+        // the reference keeps the values of the filter where it computed them and computes the others now (:1318-1322):
+        // the same formulas on the same score either way
+        bm.bit_score = computeBitScore(a.score, params->karlin);
+        bm.e_value   = evalue(a.score, qLengthOf[k]);
         bm.ops_off   = res->ops.size();
         bm.n_ops     = (uint32_t)a.n_ops;
-        res->ops.insert(res->ops.end(), ops.begin() + opsOff[k] + a.ops_shift, ops.begin() + opsOff[k] + a.ops_shift + a.n_ops);
+        uint8_t const * const first = ops + opsOffAll[k] + a.ops_shift;
+        res->ops.insert(res->ops.end(), first, first + a.n_ops);
         res->matches.push_back(bm);
     }
     return LX_OK;

@@ -14,7 +14,10 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
+
+#include <sched.h>
 
 #include "../../include/lambda_ext.h"
 #include "host/scoring_tables.hpp"
@@ -72,6 +75,13 @@ struct lx_handle
     hipEvent_t  evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evS = nullptr;
     bool        timed = false;
     std::string error;
+    // lx_extend_batch: host staging that keeps its pages between calls
+    std::vector<uint32_t>     xb_idx, xb_src, xb_sel;
+    std::vector<uint64_t>     xb_grp, xb_off;
+    std::vector<lx_extension> xb_ext;
+    std::vector<int32_t>      xb_min, xb_score;
+    std::vector<lx_hsp>  ext_hsp; // lx_extend_batch: the survivors' records and ops of the last call (handed out by pointer)
+    std::vector<uint8_t> ext_ops;
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
     std::string last_trace_kernel;
     // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
@@ -324,6 +334,42 @@ int prepare_workspace(lx_handle * h, hipStream_t stream)
 }
 
 } // namespace
+
+// a few host threads for the per-extension loops of the host-buffer entry point (none below a quarter million items)
+static unsigned host_threads(uint64_t n)
+{
+    if (n < 250000)
+        return 1;
+    static unsigned const avail = []()
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
+        if (char const * e = getenv("LX_HOST_THREADS"))
+            c = (unsigned)std::max(1, atoi(e));
+        return std::max(1u, std::min(c, 8u));
+    }();
+    return avail;
+}
+
+template <typename F>
+static void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
+{
+    if (nthreads <= 1 || n < 2 * (uint64_t)nthreads)
+    {
+        for (unsigned t = 0; t < nthreads; ++t) // keep the per-thread slots of the callers meaningful
+            body(t, t == 0 ? 0 : n, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads - 1);
+    uint64_t const step = (n + nthreads - 1) / nthreads;
+    for (unsigned t = 1; t < nthreads; ++t)
+        pool.emplace_back([&body, t, step, n]() { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
+    body(0, 0, std::min(n, step));
+    for (std::thread & th : pool)
+        th.join();
+}
 
 extern "C" {
 
@@ -914,7 +960,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
                           uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
                           uint64_t max_q, uint64_t max_s, int share_slots, uint32_t const * d_src = nullptr,
-                          uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr)
+                          uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr, bool by_pos = false)
 {
     if (!h->trace_ok[slot])
         return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
@@ -984,9 +1030,10 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.steps_cap      = steps_cap;
         p.panels_cap     = panels_cap;
         p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr) + (uint64_t)b * chunk;
-        p.out_hsp        = d_src ? d_hsp : d_hsp + c0;
+        p.out_hsp        = (d_src && !by_pos) ? d_hsp : d_hsp + c0;
         p.out_ops        = d_ops;
-        p.ops_off        = d_src ? d_ops_off : d_ops_off + c0;
+        p.ops_off        = (d_src && !by_pos) ? d_ops_off : d_ops_off + c0;
+        p.out_by_pos     = by_pos ? 1 : 0;
         p.src            = d_src ? d_src + c0 : nullptr;
         p.score_in       = d_score_in + c0;
         p.count_ptr      = d_count;
@@ -1205,9 +1252,12 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 
 // ---- fused: pass 1 -> survivor selection -> pass 2, all on the device ------------------------------------
 
-int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
-                        uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
-                        void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream_)
+// phases: 1 = pass 1 (or the sweep) + selection, 2 = pass 2 (or the sweep's backtrace), 3 = both.  by_pos: records and
+// ops offsets are indexed by the position in the survivor list instead of by extension (the host entry point assigns
+// compact ops offsets between the two phases and downloads only the survivors' records).
+static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext, uint64_t n,
+                      void const * d_min_score, int32_t min_score_all, void * d_out_score, void * d_out_hsp, void * d_out_ops,
+                      void const * d_ops_off, void * d_out_count, void * stream_, int phases, bool by_pos)
 {
     if (!h)
         return LX_EINVAL;
@@ -1215,7 +1265,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (n == 0)
         return LX_OK;
-    if (!d_q_res || !d_s_res || !d_ext || !d_out_score || !d_out_hsp || !d_out_ops || !d_ops_off || !d_out_count)
+    if (!d_q_res || !d_s_res || !d_ext || !d_out_score || !d_out_count || ((phases & 2) && (!d_out_hsp || !d_out_ops || !d_ops_off)))
         return fail(h, LX_EINVAL, "NULL device pointer");
     if (h->opt_max_qlen == 0 || h->opt_max_slen == 0)
         return fail(h, LX_ESTATE, "lx_extend_batch_dev needs LX_OPT_MAX_QLEN and LX_OPT_MAX_SLEN (it never synchronises)");
@@ -1226,9 +1276,12 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
 
-    h->phase_ev.clear();
-    h->ev_pool_used = 0;
-    LX_HIP(h, hipEventRecord(h->ev0, stream));
+    if (phases & 1)
+    {
+        h->phase_ev.clear();
+        h->ev_pool_used = 0;
+        LX_HIP(h, hipEventRecord(h->ev0, stream));
+    }
     bool const shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
 
     // Single sweep (LX_OPT_PASS2_MODE = 2): the checkpoint forward kernel runs once over ALL extensions -- it is pass 1
@@ -1254,7 +1307,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
             sweep = n * sweep_stride * 4 <= h->opt_trace_bytes;
         }
     }
-    if (sweep)
+    if (sweep && (phases & 1))
     {
         if ((rc = ensure(h, h->d_trace, n * sweep_stride * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
             return rc;
@@ -1321,7 +1374,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         h->last_kernel       = buf;
         h->last_trace_kernel = buf;
     }
-    else
+    else if (phases & 1)
     {
         // pass 1 (src/search_algo.hpp:1246)
         h->in_fused = true;
@@ -1340,6 +1393,8 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
         (rc = ensure(h, h->d_sel_runs, (nruns + 2 * lx::select_blocks(nruns) + 2) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
         return rc;
+    if (phases & 1)
+    {
     lx::SelectParams sp{};
     sp.ext           = static_cast<lx::Extension const *>(d_ext);
     sp.score         = static_cast<int32_t const *>(d_out_score);
@@ -1354,10 +1409,13 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
     sp.out_src       = static_cast<uint32_t *>(h->d_sel_src.ptr);
     sp.out_score     = static_cast<int32_t *>(h->d_sel_score.ptr);
     sp.out_count     = static_cast<uint64_t *>(d_out_count);
-    sp.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
+    sp.out_hsp       = by_pos ? nullptr : static_cast<lx::Hsp *>(d_out_hsp); // rows of the filtered-out extensions
     PhaseTimer pts(h, stream, 1);
     LX_HIP(h, lx::launch_select(sp, stream));
     pts.close();
+    }
+    if (!(phases & 2))
+        return LX_OK;
 
     if (sweep)
     {
@@ -1384,6 +1442,7 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
         p.bs_match_rule = (int32_t)h->opt_bs_rule;
         p.cfg           = sweep_cfg;
         p.slot_by_src   = 1;
+        p.out_by_pos    = by_pos ? 1 : 0;
         PhaseTimer ptb(h, stream, 3);
         LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));
         ptb.close();
@@ -1397,11 +1456,310 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
                         static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? 4 : 0,
                         static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count),
-                        static_cast<int32_t const *>(h->d_sel_score.ptr));
+                        static_cast<int32_t const *>(h->d_sel_score.ptr), by_pos);
     if (rc)
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, stream));
     h->timed = true;
+    return LX_OK;
+}
+
+int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
+                        uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
+                        void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream_)
+{
+    return fused_impl(h, slot, d_q_res, d_s_res, d_ext, n, d_min_score, min_score_all, d_out_score, d_out_hsp, d_out_ops, d_ops_off,
+                      d_out_count, stream_, 3, false);
+}
+
+// Both passes on host buffers.  The extensions are grouped by query slice (sorted if the caller's list is not grouped),
+// every run is padded to 16 slots so that the device path may promise LX_OPT_QUERY_RUN = 16, and the two phases of the
+// fused step are split by one synchronisation: after pass 1 + selection the host knows the survivors and hands out compact
+// ops offsets, so that only the survivors' records and ops cross PCIe.
+int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                    lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                    lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (out_ops)
+        *out_ops = nullptr;
+    if (out_ops_bytes)
+        *out_ops_bytes = 0;
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || !out_hsp || !out_ops_off || !out_ops || !out_ops_bytes || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    HostMarks hm("lx_extend_batch");
+
+    // ---- validate, group by query slice.  Every maximal run of adjacent extensions of one slice is a group; only a
+    // list that is badly grouped (the padding would cost more than half of the work) is sorted first.  The loops over
+    // the list are spread over a few host threads: at millions of extensions per call they would otherwise cost more
+    // than the kernels.
+    unsigned const nthreads = host_threads(n);
+    struct Part
+    {
+        uint64_t max_q = 1, max_s = 1, live = 0, bad = ~0ull;
+    };
+    std::vector<Part> parts(nthreads);
+    parallel_ranges(n, nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        Part & pt = parts[t];
+                        for (uint64_t i = lo; i < hi; ++i)
+                        {
+                            lx_extension const & x = ext[i];
+                            if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+                            {
+                                pt.bad = std::min(pt.bad, i);
+                                continue;
+                            }
+                            if (x.q_len == 0 || x.s_len == 0)
+                            {
+                                out_score[i]   = 0;
+                                out_hsp[i]     = lx_hsp{};
+                                out_ops_off[i] = 0;
+                                continue;
+                            }
+                            pt.max_q = std::max<uint64_t>(pt.max_q, x.q_len);
+                            pt.max_s = std::max<uint64_t>(pt.max_s, x.s_len);
+                            ++pt.live;
+                        }
+                    });
+    uint64_t max_q = 1, max_s = 1, live = 0;
+    for (Part const & pt : parts)
+    {
+        if (pt.bad != ~0ull)
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
+        max_q = std::max(max_q, pt.max_q);
+        max_s = std::max(max_s, pt.max_s);
+        live += pt.live;
+    }
+    if (live == 0)
+        return LX_OK;
+    std::vector<uint32_t> & idx = h->xb_idx;
+    idx.resize(live);
+    {
+        std::vector<uint64_t> first(nthreads + 1, 0);
+        for (unsigned t = 0; t < nthreads; ++t)
+            first[t + 1] = first[t] + parts[t].live;
+        parallel_ranges(n, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = first[t];
+                            for (uint64_t i = lo; i < hi; ++i)
+                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                                    idx[o++] = (uint32_t)i;
+                        });
+    }
+    constexpr uint64_t kRun = 16;
+    auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
+    // groups: first list position and first slot of every run (+ a sentinel)
+    std::vector<uint64_t> & grp = h->xb_grp;
+    auto find_groups = [&]()
+    {
+        grp.clear();
+        uint64_t total = 0;
+        for (size_t k = 0; k < idx.size();)
+        {
+            size_t k1 = k + 1;
+            while (k1 < idx.size() && same_slice(idx[k1], idx[k]))
+                ++k1;
+            grp.push_back(k);
+            grp.push_back(total);
+            total += (k1 - k + kRun - 1) / kRun * kRun;
+            k = k1;
+        }
+        grp.push_back(idx.size());
+        grp.push_back(total);
+        return total;
+    };
+    uint64_t slots = find_groups();
+    if (slots > idx.size() + idx.size() / 2 + 4 * kRun)
+    {
+        std::sort(idx.begin(), idx.end(),
+                  [&](uint32_t a, uint32_t b)
+                  {
+                      lx_extension const &x = ext[a], &y = ext[b];
+                      return x.q_off != y.q_off ? x.q_off < y.q_off : x.q_len != y.q_len ? x.q_len < y.q_len : a < b;
+                  });
+        slots = find_groups();
+    }
+    std::vector<lx_extension> & slot_ext = h->xb_ext;
+    std::vector<uint32_t> &     slot_src = h->xb_src;
+    std::vector<int32_t> &      slot_min = h->xb_min;
+    slot_ext.resize(slots);
+    slot_src.resize(slots);
+    slot_min.resize(slots);
+    uint64_t const ngroups = grp.size() / 2 - 1;
+    parallel_ranges(ngroups, nthreads,
+                    [&](unsigned, uint64_t glo, uint64_t ghi)
+                    {
+                        for (uint64_t g = glo; g < ghi; ++g)
+                        {
+                            uint64_t const k0 = grp[2 * g], k1 = grp[2 * g + 2], o1 = grp[2 * g + 3];
+                            uint64_t       o = grp[2 * g + 1];
+                            for (uint64_t j = k0; j < k1; ++j, ++o)
+                            {
+                                slot_ext[o] = ext[idx[j]];
+                                slot_src[o] = idx[j];
+                                slot_min[o] = min_score ? min_score[idx[j]] : min_score_all;
+                            }
+                            lx_extension dummy = ext[idx[k0]];
+                            dummy.s_len        = 0;
+                            for (; o < o1; ++o)
+                            {
+                                slot_ext[o] = dummy;
+                                slot_src[o] = 0xffffffffu;
+                                slot_min[o] = 0x7fffffff; // never survives
+                            }
+                        }
+                    });
+    hm.mark("group");
+
+    // ---- upload, phase 1
+    uint64_t const cap_sel = (slots + slots / kRun * 3 + 7) / 8 * 8 + 8;
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) ||
+        (rc = ensure(h, h->d_out, slots * sizeof(int32_t))) || (rc = ensure(h, h->d_keep, slots * sizeof(int32_t) + 64)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, slot_ext.data(), slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    // d_keep: [2 x uint64 count][int32 min score per slot]
+    uint64_t * const d_count = static_cast<uint64_t *>(h->d_keep.ptr);
+    int32_t * const  d_min   = reinterpret_cast<int32_t *>(d_count + 2);
+    LX_HIP(h, hipMemcpyAsync(d_min, slot_min.data(), slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    uint64_t const sv_qlen = h->opt_max_qlen, sv_slen = h->opt_max_slen, sv_run = h->opt_query_run;
+    h->opt_max_qlen  = max_q;
+    h->opt_max_slen  = max_s;
+    h->opt_query_run = kRun;
+    auto restore = [&]()
+    {
+        h->opt_max_qlen  = sv_qlen;
+        h->opt_max_slen  = sv_slen;
+        h->opt_query_run = sv_run;
+    };
+    rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, nullptr, nullptr, nullptr, d_count,
+                    h->stream, 1, true);
+    if (rc)
+    {
+        restore();
+        return rc;
+    }
+    hm.mark("phase1-issue");
+    uint64_t             count[2] = {0, 0};
+    std::vector<int32_t> & slot_score = h->xb_score;
+    slot_score.resize(slots);
+    if (hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipMemcpyAsync(slot_score.data(), h->d_out.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        (rc = check_async_error(h)))
+    {
+        restore();
+        return rc ? rc : fail(h, LX_EHIP, "download after pass 1 failed");
+    }
+    hm.mark("phase1-wait");
+    if (count[0] > cap_sel)
+    {
+        restore();
+        return fail(h, LX_ESTATE, "survivor list longer than its capacity");
+    }
+    std::vector<uint32_t> & sel_src = h->xb_sel;
+    sel_src.resize(count[0]);
+    if (count[0])
+        LX_HIP(h, hipMemcpyAsync(sel_src.data(), h->d_sel_src.ptr, count[0] * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+
+    // ---- compact ops offsets by survivor position, phase 2
+    std::vector<uint64_t> & pos_off = h->xb_off;
+    pos_off.resize(count[0] + 1);
+    uint64_t total = 0;
+    for (uint64_t e = 0; e < count[0]; ++e)
+    {
+        pos_off[e] = total;
+        if (sel_src[e] != 0xffffffffu)
+            total += (uint64_t)slot_ext[sel_src[e]].q_len + slot_ext[sel_src[e]].s_len;
+    }
+    h->ext_hsp.resize(count[0]);
+    h->ext_ops.resize(total + 16);
+    if (count[0])
+    {
+        if ((rc = ensure(h, h->d_hsp, count[0] * sizeof(lx_hsp))) || (rc = ensure(h, h->d_ops, total + 16)) ||
+            (rc = ensure(h, h->d_opsoff, count[0] * sizeof(uint64_t))))
+        {
+            restore();
+            return rc;
+        }
+        LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, pos_off.data(), count[0] * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, h->d_hsp.ptr, h->d_ops.ptr,
+                        h->d_opsoff.ptr, d_count, h->stream, 2, true);
+        if (rc)
+        {
+            restore();
+            return rc;
+        }
+        hm.mark("phase2-issue");
+        LX_HIP(h, hipMemcpyAsync(h->ext_hsp.data(), h->d_hsp.ptr, count[0] * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
+        if (total)
+            LX_HIP(h, hipMemcpyAsync(h->ext_ops.data(), h->d_ops.ptr, total, hipMemcpyDeviceToHost, h->stream));
+        rc = check_async_error(h);
+        hm.mark("phase2-wait");
+    }
+    restore();
+    if (rc)
+        return rc;
+
+    // ---- results back to the caller's order
+    parallel_ranges(slots, nthreads,
+                    [&](unsigned, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t o = lo; o < hi; ++o)
+                            if (slot_src[o] != 0xffffffffu)
+                            {
+                                lx_hsp r{};
+                                r.score                  = slot_score[o];
+                                out_score[slot_src[o]]   = slot_score[o];
+                                out_hsp[slot_src[o]]     = r;
+                                out_ops_off[slot_src[o]] = 0;
+                            }
+                    });
+    std::vector<uint64_t> untraced(nthreads, ~0ull);
+    parallel_ranges(count[0], nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t e = lo; e < hi; ++e)
+                        {
+                            if (sel_src[e] == 0xffffffffu)
+                                continue;
+                            uint32_t const orig = slot_src[sel_src[e]];
+                            lx_hsp const & r    = h->ext_hsp[e];
+                            if (r.score < 0)
+                            {
+                                untraced[t] = std::min<uint64_t>(untraced[t], orig);
+                                continue;
+                            }
+                            out_hsp[orig]     = r;
+                            out_ops_off[orig] = pos_off[e];
+                        }
+                    });
+    for (uint64_t u : untraced)
+        if (u != ~0ull)
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
+    *out_ops       = h->ext_ops.data();
+    *out_ops_bytes = total;
+    hm.mark("scatter");
     return LX_OK;
 }
 

@@ -430,6 +430,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             return; // padding slot
         oi = sidx;
     }
+    uint64_t const po = p.out_by_pos ? e : oi; // where this extension's record and ops slot are
     uint64_t const  se = p.slot_by_src ? oi : e; // single-sweep mode: checkpoints and end cells sit at the original index
     EndCell         ec = p.ends[se];
     Extension const x  = p.ext[e];
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     if (ec.score <= 0)
     {
         out.score = ec.score < 0 ? -1 : 0;
-        p.out_hsp[oi] = out;
+        p.out_hsp[po] = out;
         return;
     }
     // checkpoint values are int16, or half-precision bit patterns when the packed-half sweep wrote the slot
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + Lay::bnd_dwords(p.steps_cap));
     uint8_t const *  q     = p.q_res + x.q_off;
     uint8_t const *  s     = p.s_res + x.s_off;
-    uint8_t *        ops   = p.out_ops + p.ops_off[oi];
+    uint8_t *        ops   = p.out_ops + p.ops_off[po];
     uint32_t const   cap   = x.q_len + x.s_len;
     int const        lq    = (int)x.q_len;
     int const        ge = p.sc->ge, g2 = p.sc->g2;    // a gap of k characters costs g2 + k ge
@@ -826,7 +827,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     {
         Hsp failed{};
         failed.score  = -1;
-        p.out_hsp[oi] = failed;
+        p.out_hsp[po] = failed;
         return;
     }
     out.score              = ec.score;
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     out.num_gap_opens      = go;
     out.num_gap_extensions = gx;
     out.ops_shift          = (int32_t)(cap - n);
-    p.out_hsp[oi]          = out;
+    p.out_hsp[po]          = out;
 }
 
 // ---- host-visible launchers: checkpoint geometries follow the trace geometries (cfg 1 = (8,19), cfg 2 = (16,13)) --------

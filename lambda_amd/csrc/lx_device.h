@@ -120,6 +120,7 @@ struct TraceParams
     int32_t *          score_out;
     int32_t            slot_by_src;
     int32_t            fixup;         // single sweep, int32 kernel: only extensions whose score_out is the sentinel -1
+    int32_t            out_by_pos;    // backtrace: write out_hsp / read ops_off by list position e instead of by src[e]
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

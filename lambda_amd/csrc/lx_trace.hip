@@ -442,17 +442,18 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
             return; // padding slot
         oi = sidx;
     }
+    uint64_t const po = p.out_by_pos ? e : oi; // where this extension's record and ops slot are
     EndCell const   ec = p.ends[e];
     Extension const x  = p.ext[e];
     Hsp             out{};
     if (ec.score <= 0)
     {
         out.score = ec.score < 0 ? -1 : 0;
-        p.out_hsp[oi] = out;
+        p.out_hsp[po] = out;
         return;
     }
     uint32_t const * tr  = p.trace + e * p.slot_stride;
-    uint8_t *        ops = p.out_ops + p.ops_off[oi];
+    uint8_t *        ops = p.out_ops + p.ops_off[po];
     uint32_t const   cap = x.q_len + x.s_len;
 
     // The walk is serial per extension and every lane of the wavefront is at a different point of its own walk, so
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
     out.num_gap_opens      = go;
     out.num_gap_extensions = gx;
     out.ops_shift          = (int32_t)(cap - n); // the ops occupy the END of the slot (written back to front)
-    p.out_hsp[oi]          = out;
+    p.out_hsp[po]          = out;
 }
 
 __global__ void max_lens_kernel(Extension const * ext, uint64_t n, MaxLens * out)

@@ -635,3 +635,60 @@ def test_fused_rejects_broken_length_promise(handle):
             handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
             handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
             handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+
+
+@pytest.mark.parametrize("pass2_mode", [2, 1, 0])
+@pytest.mark.parametrize("order", ["grouped", "shuffled"])
+def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
+    """lx_extend_batch: both passes on host buffers with a synchronisation in between.  Queries of several lengths in one
+    call, ragged runs (not multiples of 16), empty windows, per-extension cut-offs, grouped and shuffled lists: scores of
+    all extensions and the alignment of every survivor must equal the oracle's, ops compact and addressed by offset."""
+    rng = np.random.default_rng(4242)
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    qs, ss, exts = [], [], []
+    qo = so = 0
+    for k, (lq, wpq) in enumerate([(150, 37), (97, 16), (150, 5), (33, 50), (200, 21)]):
+        q, s, ext = synth.make_batch_np(6, lq, wpq, seed=500 + k, sub_rate=0.2, indel_rate=0.03)
+        ext = ext.copy()
+        ext["q_off"] += qo
+        ext["s_off"] += so
+        qo += len(q)
+        so += len(s)
+        qs.append(q), ss.append(s), exts.append(ext)
+    q, s, ext = np.concatenate(qs), np.concatenate(ss), np.concatenate(exts)
+    cut = rng.random(len(ext))
+    ext["s_len"] = np.where(cut < 0.04, 0, np.where(cut < 0.3, (ext["s_len"] * 0.6).astype(np.uint32), ext["s_len"])).astype(np.uint32)
+    if order == "shuffled":
+        ext = ext[rng.permutation(len(ext))]
+    n = len(ext)
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    mins = (np.percentile(want_score, 50) + rng.integers(-6, 7, n)).astype(np.int32)
+    surv = np.nonzero((want_score >= mins) & (ext["s_len"] > 0) & (ext["q_len"] > 0))[0]
+    want = oracle.align_batch(q, s, ext[surv], osc)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, pass2_mode)
+    try:
+        score, hsp, off, ops = handle.extend_batch(q, s, ext, mins)
+        # resident subjects + one cut-off for all
+        handle.set_subjects(s)
+        score2, hsp2, off2, ops2 = handle.extend_batch(q, None, ext, int(np.percentile(want_score, 50)))
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+        handle.set_subjects(None)
+    assert (score == want_score).all(), handle.last_kernel_name()
+    assert (score2 == want_score).all()
+    assert (hsp["score"] == want_score).all()
+    gone = np.setdiff1d(np.arange(n), surv)
+    assert (hsp["n_ops"][gone] == 0).all()
+    total = 0
+    for i, (oh, oops) in zip(surv, want):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, handle.last_trace_kernel_name())
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, i
+        total += int(ext["q_len"][i]) + int(ext["s_len"][i])
+    assert len(ops) == max(total, 1)  # compact: exactly the survivors' slots
+    surv2 = np.nonzero((want_score >= int(np.percentile(want_score, 50))) & (ext["s_len"] > 0))[0]
+    assert (np.nonzero(hsp2["n_ops"])[0] == surv2[want_score[surv2] > 0]).all()

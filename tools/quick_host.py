@@ -29,3 +29,7 @@ for resident in (False, True):
         t0 = time.perf_counter(); hsp, ops, _ = h.align_batch(q, sarg, es, known_score=sc[keep], raw=True); best2 = min(best2, time.perf_counter() - t0)
     print(f"lx_align_batch, {tag}: {len(es)} ext, {c2/1e9:.1f} Gcells in {best2*1e3:.1f} ms = {c2/best2/1e9:.0f} GCUPS (kernel {h.last_kernel_ms():.2f} ms)")
     print(f"  both calls: {cells/(best+best2)/1e9:.0f} GCUPS of pass-1 cells, PCIe and host work included")
+    best3 = 1e9
+    for rep in range(3):
+        t0 = time.perf_counter(); r = h.extend_batch(q, sarg, ext, 91, copy_ops=False); best3 = min(best3, time.perf_counter() - t0)
+    print(f"lx_extend_batch, {tag}: {len(ext)} ext in {best3*1e3:.1f} ms = {cells/best3/1e9:.0f} GCUPS of pass-1 cells (survivors {int((r[1]['n_ops']>0).sum())})")
