@@ -7,11 +7,12 @@ or no gfx950 device is usable, everything here raises -- there is no CPU fallbac
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
-LIB_PATH = Path(__file__).resolve().parent / "csrc" / "liblambda_ext.so"
+LIB_PATH = Path(os.environ.get("LX_LIB_PATH") or Path(__file__).resolve().parent / "csrc" / "liblambda_ext.so")  # (override: kernel variants during development)
 
 LX_ALPH = 32
 LX_OK = 0

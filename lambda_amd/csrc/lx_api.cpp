@@ -44,6 +44,7 @@ int        trace_cfg_group(int cfg);
 int        trace_cfg_words(int cfg);
 hipError_t launch_select(SelectParams const & p, hipStream_t stream);
 uint64_t   ckpt_slot_dwords(int cfg, uint32_t steps_cap);
+uint64_t   ckpt16_slot_dwords(int cfg, uint32_t steps_cap);
 hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
@@ -103,7 +104,7 @@ struct lx_handle
     DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_db;
     // multi-panel carry workspace
     DevBuf     d_ws;
-    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag
+    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag, [2..3] = MaxLens, [4] = overflow checkpoint slots handed out
     // options
     uint64_t opt_max_qlen  = 0;
     uint64_t opt_query_run = 0;
@@ -276,6 +277,9 @@ int check_async_error(lx_handle * h)
         return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
     if (flags[1] == 3)
         return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or s_len > 65535)");
+    if (flags[1] == 4)
+        return fail(h, LX_EOVERFLOW, "single sweep: no checkpoint slot left for an extension the packed-half kernel declined "
+                                     "(raise LX_OPT_TRACE_BYTES, or set LX_OPT_PASS2_MODE to 1)");
     if (flags[1] != 0)
         return fail(h, LX_EHIP, "device reported error flag %u", flags[1]);
     return LX_OK;
@@ -426,9 +430,9 @@ int lx_create(int device_id, lx_handle ** out)
     for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
-    if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 4 * sizeof(uint32_t))) != hipSuccess)
+    if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc", e);
-    if ((e = hipMemset(h->d_ws_top, 0, 4 * sizeof(uint32_t))) != hipSuccess)
+    if ((e = hipMemset(h->d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMemset", e);
     for (int s = 0; s < 2; ++s)
         if ((e = hipMalloc(reinterpret_cast<void **>(&h->sc_dev[s]), sizeof(lx::ScoringDev))) != hipSuccess)
@@ -1290,7 +1294,12 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     bool sweep = false;
     int  sweep_cfg = 0;
     uint32_t sweep_steps = 0;
-    uint64_t sweep_stride = 0;
+    uint64_t sweep_stride = 0;   // uint32 per slot of the batch
+    uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
+    uint64_t ovf_cap = 0;
+    int      sweep_share = 0;
+    bool     half_sweep = false;
+    int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
     {
         sweep_cfg = h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(1) ? 1 : h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(2) ? 2 : 0;
@@ -1300,19 +1309,49 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
                 smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
         if (sweep_cfg != 0 && (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535)
         {
-            int const G  = lx::trace_cfg_group(sweep_cfg);
-            sweep_steps  = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
-            sweep_stride = lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
-            // whole-wavefront profile sharing needs runs of 8 (G = 8) / 4 (G = 16) extensions: `shared` guarantees 8
-            sweep = n * sweep_stride * 4 <= h->opt_trace_bytes;
+            int const G    = lx::trace_cfg_group(sweep_cfg);
+            sweep_steps    = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
+            sweep_stride32 = lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            // Packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query per
+            // wavefront, or runs of 8 with one query per half wavefront where two LDS profiles fit, i.e. for the small
+            // alphabets; (16,13): 8 extensions) and a gap's first character costs at most 31 (the compact checkpoint codes
+            // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
+            half_sweep = h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
+                         ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
+            if (h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
+                sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
+                2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= 13 * 1024)
+            {
+                half_sweep  = true;
+                sweep_share = 4;
+            }
+            if (half_sweep)
+            {
+                // compact slots for the batch (+ the spare slot idle halves write to), int16-pair slots for what the
+                // packed kernel declines in whatever the budget leaves
+                sweep_stride = lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+                sweep        = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
+                // (the packed kernel's exactness gate, lx_score_f16.hip: it cannot decline when even the worst query passes)
+                int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) +
+                                      (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) + smax_entry + 2;
+                if (sweep && worst > 2046)
+                    ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
+            }
+            else
+            {
+                sweep_stride = sweep_stride32;
+                sweep        = n * sweep_stride * 4 <= h->opt_trace_bytes;
+            }
         }
     }
     if (sweep && (phases & 1))
     {
-        if ((rc = ensure(h, h->d_trace, n * sweep_stride * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
+        uint64_t const batch_dw = half_sweep ? (n + 1) * sweep_stride : n * sweep_stride;
+        if ((rc = ensure(h, h->d_trace, (batch_dw + ovf_cap * sweep_stride32) * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
             return rc;
         if ((rc = prepare_workspace(h, stream)))
             return rc;
+        LX_HIP(h, hipMemsetAsync(h->d_ws_top + 4, 0, sizeof(uint32_t), stream));
         lx::TraceParams p{};
         p.q_res          = static_cast<uint8_t const *>(d_q_res);
         p.s_res          = static_cast<uint8_t const *>(d_s_res);
@@ -1326,21 +1365,17 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
         p.score_out      = static_cast<int32_t *>(d_out_score);
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
-        p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
+        p.nrows          = nrows_sc;
         p.shared_profile = 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query
         p.cfg            = sweep_cfg;
-        // packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query
-        // per wavefront); wavefronts it declines leave the sentinel -1 and the int32 kernel fills those in
-        // (runs of 8: one query per half wavefront where two LDS profiles fit, i.e. for the small alphabets)
-        int        sweep_share = 0;
-        int const  sweep_pair  = sweep_cfg == 1 ? 0 : 5; // pair geometry with the same (G, C): (8,19) / (16,13)
-        bool       half_sweep  = h->opt_f16 && ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
-        if (h->opt_f16 && sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
-            2 * lx::score_pair_profile_bytes(0, p.nrows) + 64 * 8 * 4 <= 13 * 1024)
+        if (half_sweep)
         {
-            half_sweep  = true;
-            sweep_share = 4;
+            p.ovf        = p.trace + batch_dw;
+            p.ovf_stride = sweep_stride32;
+            p.ovf_cap    = (uint32_t)ovf_cap;
+            p.ovf_count  = h->d_ws_top + 4;
         }
+        int const sweep_pair = sweep_cfg == 1 ? 0 : 5; // pair geometry with the same (G, C): (8,19) / (16,13)
         PhaseTimer pt0(h, stream, 0);
         if (half_sweep)
         {
@@ -1443,6 +1478,11 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.cfg           = sweep_cfg;
         p.slot_by_src   = 1;
         p.out_by_pos    = by_pos ? 1 : 0;
+        if (half_sweep)
+        {
+            p.ovf        = p.trace + (n + 1) * sweep_stride; // int16-pair slots of what the packed kernel declined
+            p.ovf_stride = sweep_stride32;
+        }
         PhaseTimer ptb(h, stream, 3);
         LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));
         ptb.close();

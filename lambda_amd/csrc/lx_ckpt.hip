@@ -176,9 +176,30 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
     int const      steps       = (ls_max + G - 1 + 3) & ~3;
     uint32_t const lsc         = (uint32_t)max(ls, 1) - 1u;
 
-    uint32_t * const slot  = p.trace + e * p.slot_stride;
-    uint4 * const    rowck = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
-    bool const       store_ok = active && !bad;
+    uint32_t * slot = p.trace + e * p.slot_stride;
+    uint32_t   ovf_tag = 0; // 1 + index of this extension's slot in the overflow area
+    if constexpr (!KNOWN)
+    {
+        if (p.fixup && p.ovf_count)
+        {
+            // the batch's slots are the compact ones of the packed-half kernel: what it declined gets an int16-pair slot
+            // of the overflow area (handed out per extension; the backtrace finds it through the end cell's flags)
+            uint32_t idx = 0;
+            if (is_first && active && !bad)
+                idx = atomicAdd(p.ovf_count, 1u);
+            idx = (uint32_t)__shfl((int)idx, grp * G);
+            if (active && !bad && idx >= p.ovf_cap)
+            {
+                bad = true; // no room left: reported, never written out of bounds
+                ls  = 0;
+                atomicExch(p.err, 4);
+            }
+            ovf_tag = idx + 1;
+            slot    = p.ovf + (uint64_t)(bad ? 0 : idx) * p.ovf_stride;
+        }
+    }
+    uint4 * const rowck    = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
+    bool const    store_ok = active && !bad;
 
     // KNOWN: target score and the best (lowest) column / its first row seen so far in this lane
     int tgt = 0;
@@ -385,7 +406,7 @@ LX_CKPT_UNROLL_PRAGMA
                 ec.score = gbest;
                 ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
                 ec.s_end = grow + 1;
-                ec.flags = gtie ? kEndAmbiguous : 0;
+                ec.flags = (gtie ? kEndAmbiguous : 0) | (int32_t)(ovf_tag << kEndOverflowShift);
             }
             p.ends[e] = ec;
             if (p.score_out)
@@ -441,19 +462,34 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         p.out_hsp[po] = out;
         return;
     }
-    // checkpoint values are int16, or half-precision bit patterns when the packed-half sweep wrote the slot
-    bool const half_enc = (ec.flags & kEndHalf) != 0;
-    auto dec = [&](uint32_t bits16) -> int
+    // Checkpoint words are int16 pairs (value, gap state).  Slots written by the packed-half sweep hold the compact
+    // codes of Ckpt16Layout instead: the loaders below expand them to the same pairs.  An extension that sweep declined
+    // has an int16-pair slot of its own in the overflow area.
+    using L16            = Ckpt16Layout<G, C>;
+    bool const     c16   = (ec.flags & kEndHalf) != 0;
+    uint32_t const ovf   = (uint32_t)ec.flags >> kEndOverflowShift;
+    auto dec = [](uint32_t bits16) -> int { return (int)(int16_t)bits16; };
+    auto expand = [](uint32_t code16) -> uint32_t
     {
-        if (!half_enc)
-            return (int)(int16_t)bits16;
-        if ((bits16 & 0xffffu) == 0xfc00u)
-            return -(1 << 24); // -inf: "no gap state yet" (a multiple of 4 far below every real value)
-        return (int)(float)__builtin_bit_cast(_Float16, (uint16_t)bits16);
+        uint32_t const v = (code16 + kC16Bias) & 0xffffu, H = v & 0x7ffu;
+        return H | ((H - (v >> 11)) << 16);
     };
-    uint32_t const * slot  = p.trace + se * p.slot_stride;
+    uint32_t const * slot  = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
     uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);
-    uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + Lay::bnd_dwords(p.steps_cap));
+    uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + (c16 ? L16::bnd_dwords(p.steps_cap) : Lay::bnd_dwords(p.steps_cap)));
+    // word (H, F) of column c of strip st's row checkpoint m; word (H, E) of strip st's boundary at step k
+    auto rowck_word = [&](uint32_t m, uint32_t st, uint32_t c) -> uint32_t
+    {
+        if (c16)
+            return expand(reinterpret_cast<uint16_t const *>(rowck + L16::rowck_quad_index(m, st, 0))[c]);
+        return reinterpret_cast<uint32_t const *>(rowck + rowck_quad_index<G, Lay::kCkDw>(m, st, c / 4))[c % 4];
+    };
+    auto bnd_word_of = [&](uint32_t st, uint32_t k) -> uint32_t
+    {
+        if (c16)
+            return expand(reinterpret_cast<uint16_t const *>(bnd + L16::bnd_oct_index(k / 8, st))[k & 7]);
+        return slot[bnd_quad_index<G>(k / 4, st) * 4 + (k & 3)];
+    };
     uint8_t const *  q     = p.q_res + x.q_off;
     uint8_t const *  s     = p.s_res + x.s_off;
     uint8_t *        ops   = p.out_ops + p.ops_off[po];
@@ -487,8 +523,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                 {
-                    uint32_t const w = reinterpret_cast<uint32_t const *>(
-                        rowck + rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)(c / 4)))[c % 4];
+                    uint32_t const w = rowck_word((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)c);
                     Hp[c]            = dec(w & 0xffffu);
                     F[c]             = dec(w >> 16);
                 }
@@ -498,7 +533,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             for (int c = 0; c < C; ++c)
                 qr[c] = (st * C + c < lq) ? (int)(q[st * C + c] & (kAlph - 1)) * kAlph : (kAlph - 1) * kAlph;
             auto bnd_word = [&](int k) -> uint32_t // boundary word of strip st - 1 at step k
-            { return slot[bnd_quad_index<G>((uint32_t)k / 4, (uint32_t)(st - 1)) * 4 + ((uint32_t)k & 3)]; };
+            { return bnd_word_of((uint32_t)(st - 1), (uint32_t)k); };
             int const target = ec.score;
             int       kcol = C, krow = i;
             for (int r = max(m0 * kCkptEvery - st, 0); r < (int)x.s_len; ++r)
@@ -594,11 +629,32 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         else
         {
             uint32_t      w[Lay::kCkDw];
-#pragma unroll
-            for (int xq = 0; xq < Lay::kCkDw / 4; ++xq)
+            if (c16)
             {
-                uint4 const v = rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
-                w[4 * xq] = v.x; w[4 * xq + 1] = v.y; w[4 * xq + 2] = v.z; w[4 * xq + 3] = v.w;
+#pragma unroll
+                for (int xq = 0; xq < L16::kCkDw / 4; ++xq)
+                {
+                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
+                    uint32_t const d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                    {
+                        int const c = 2 * (4 * xq + b);
+                        if (c < Lay::kCkDw)
+                            w[c] = expand(d[b] & 0xffffu);
+                        if (c + 1 < Lay::kCkDw)
+                            w[c + 1] = expand(d[b] >> 16);
+                    }
+                }
+            }
+            else
+            {
+#pragma unroll
+                for (int xq = 0; xq < Lay::kCkDw / 4; ++xq)
+                {
+                    uint4 const v = rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
+                    w[4 * xq] = v.x; w[4 * xq + 1] = v.y; w[4 * xq + 2] = v.z; w[4 * xq + 3] = v.w;
+                }
             }
 #pragma unroll
             for (int c = 0; c < C; ++c)
@@ -628,6 +684,12 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         {
             if (!has_left || qd < 0)
                 return make_uint4(0, 0, 0, 0);
+            if (c16)
+            {
+                // half of the 16-byte group of eight steps
+                uint2 const v = reinterpret_cast<uint2 const *>(bnd + L16::bnd_oct_index((uint32_t)qd / 2, (uint32_t)(st - 1)))[qd & 1];
+                return make_uint4(expand(v.x & 0xffffu), expand(v.x >> 16), expand(v.y & 0xffffu), expand(v.y >> 16));
+            }
             return bnd[bnd_quad_index<G>((uint32_t)qd, (uint32_t)(st - 1))];
         };
         int const qd0   = k_base / 4; // quad that holds step k_base
@@ -850,6 +912,12 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 uint64_t ckpt_slot_dwords(int cfg, uint32_t steps_cap)
 {
     return cfg == 2 ? CkptLayout<16, 13>::slot_dwords(steps_cap) : CkptLayout<8, 19>::slot_dwords(steps_cap);
+}
+
+// compact slots of the packed-half sweep
+uint64_t ckpt16_slot_dwords(int cfg, uint32_t steps_cap)
+{
+    return cfg == 2 ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap) : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
 }
 
 template <int G, int C>

@@ -85,7 +85,32 @@ struct EndCell
     int32_t flags; // kEndAmbiguous: the strip reaches the best score in more than one row
 };
 constexpr int32_t kEndAmbiguous = 1;
-constexpr int32_t kEndHalf      = 2; // the slot's checkpoints are half-precision bit patterns, not int16
+constexpr int32_t kEndHalf      = 2; // the slot was written by the packed-half sweep: compact 16-bit codes (Ckpt16Layout)
+constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extension's slot in the overflow area (0 = none)
+
+// Compact checkpoint slots of the packed-half single sweep (lx_score_f16.hip writes, lx_ckpt.hip's backtrace reads).
+// A boundary pair (H of a strip's last column, E entering the next strip) and a row-checkpoint pair (H of a cell, the
+// folded F entering the cell below) always satisfy  0 <= H - other <= |cost of a gap's first character|  (E >= H + go and
+// E <= H + ge because E of the same cell is <= H; likewise F), and the packed-half kernel only runs when every value
+// is <= 2046 -- so a pair is the 16-bit code  H | (H - other) << 11  (11 + 5 bits; needs go >= -31).  The kernel stores
+// code - 0x3800 (mod 2^16): that is what falls out of its half-precision bit arithmetic.
+//   boundary codes:  [step / 8][lane] 16-byte groups of 8 steps (lane-minor: the G lanes of a group fill whole lines);
+//   row checkpoints: [checkpoint][lane][quad], two columns per dword, every 16 steps (lane-major).
+constexpr uint32_t kC16Bias = 0x3800u;
+constexpr int      kC16MaxGap = 31;
+template <int G, int C>
+struct Ckpt16Layout
+{
+    static constexpr int kCkDw = ((C + 1) / 2 + 3) / 4 * 4; // dwords per lane per row checkpoint, whole quads
+    __host__ __device__ static constexpr uint64_t bnd_dwords(uint32_t steps_cap) { return (uint64_t)steps_cap / 2 * G; }
+    __host__ __device__ static constexpr uint64_t slot_dwords(uint32_t steps_cap)
+    {
+        return bnd_dwords(steps_cap) + (uint64_t)(steps_cap / 16) * G * kCkDw;
+    }
+    // uint4 index of the group of steps 8 o .. 8 o + 7 of lane g / of quad x of lane g's row checkpoint m
+    __host__ __device__ static constexpr uint32_t bnd_oct_index(uint32_t o, uint32_t g) { return o * G + g; }
+    __host__ __device__ static constexpr uint32_t rowck_quad_index(uint32_t m, uint32_t g, uint32_t x) { return (m * G + g) * (kCkDw / 4) + x; }
+};
 
 struct TraceParams
 {
@@ -121,6 +146,11 @@ struct TraceParams
     int32_t            slot_by_src;
     int32_t            fixup;         // single sweep, int32 kernel: only extensions whose score_out is the sentinel -1
     int32_t            out_by_pos;    // backtrace: write out_hsp / read ops_off by list position e instead of by src[e]
+    // single sweep with compact slots: the extensions the packed-half kernel declined get int16-pair slots here
+    uint32_t *         ovf;           // overflow area: ovf_cap slots of ovf_stride uint32
+    uint64_t           ovf_stride;
+    uint32_t           ovf_cap;
+    uint32_t *         ovf_count;     // device counter of handed-out overflow slots
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

@@ -54,6 +54,23 @@ __device__ __forceinline__ uint32_t as_u32(h2 x)
 
 constexpr uint32_t kHalfNegInf2 = 0xfc00fc00u; // (-inf, -inf)
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// Ckpt16Layout code of (value, value - other) for both halves, minus kC16Bias: integers 0 .. 2046 and 0 .. 31 held in
+// half precision become bit fields without a conversion instruction.  x + 1024 lands in the binade [1024, 2048] whose
+// ulp is 1 -- its bit pattern is 0x6400 + x -- for x <= 1024, and x itself lies there for x >= 1024; so
+// bits(min(x, 1024) + 1024) + bits(max(x, 1024)) = 2 * 0x6400 + x for every x in 0 .. 2047.  The difference goes to
+// bits 11-15 by a 16-bit multiply-add whose 0x6400 * 2048 vanishes mod 2^16.
+__device__ __forceinline__ uint32_t c16_code(h2 value, h2 diff)
+{
+    h2 const    K = h2{(_Float16)1024.f, (_Float16)1024.f};
+    h2 const    a = __builtin_elementwise_minimum(value, K) + K;
+    h2 const    b = __builtin_elementwise_maximum(value, K);
+    u16x2 const s = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
+    u16x2 const t = __builtin_bit_cast(u16x2, diff + K);
+    u16x2 const m = u16x2{2048, 2048};
+    return __builtin_bit_cast(uint32_t, (u16x2)(t * m + s));
+}
+
 template <int G, int C>
 struct PairGeo
 {
@@ -243,12 +260,13 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     int      rowA = 0, rowB = 0;
     uint32_t tie  = 0;
     int      krow = -g; // row of the step being processed
-    int      krow_slot = 0; // step % 4
+    int      krow_slot = 0; // step % 8
     h2       cmax = as_h2(kHalfNegInf2); // best un-skewed row maximum of the current chunk
-    constexpr int kCkDw   = (C + 3) / 4 * 4;
-    uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride : nullptr;
-    uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride : nullptr;
-    // staging of the boundary words: [extension A / B][step % 4][lane] -- lane-minor, free of bank conflicts
+    using Lay = Ckpt16Layout<G, C>;
+    // (slot p.n is a spare one that idle halves write to)
+    uint32_t * const slotA = CKPT ? p.ckpt + (actA ? eA : p.n) * p.ckpt_stride : nullptr;
+    uint32_t * const slotB = CKPT ? p.ckpt + (actB ? eB : p.n) * p.ckpt_stride : nullptr;
+    // staging of the boundary codes: [step % 8][lane] -- lane-minor, free of bank conflicts
     uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane;
 
     auto step = [&](uint32_t tA, uint32_t tB)
@@ -306,19 +324,34 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
         if constexpr (CKPT)
         {
             cmax = hmax(cmax, cand); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
-            // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
-            // re-paired per extension and staged for one 16-byte store per four steps
-            h2 const hb = h - Z, eb = Ecur - Z;
-            stage[krow_slot * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
-            stage[(4 + krow_slot) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
-            krow_slot                   = (krow_slot + 1) & 3;
+            // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
+            // Ckpt16Layout codes of both extensions, staged for one 16-byte store per extension every eight steps
+            stage[krow_slot * 64] = c16_code(h - Z, h - Ecur);
+            krow_slot             = (krow_slot + 1) & 7;
             ++krow;
         }
         else
             best = hmax(best, cand);
         Z = ZN;
     };
-    // CKPT: after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
+    // CKPT: the staged codes of the eight steps up to k0 + 3 leave, re-paired per extension.  Unconditional (an idle half
+    // owns the spare slot behind the batch): whole 128-byte lines per lane group, no branch around the stores.
+    auto flush_codes = [&](int k0)
+    {
+        if constexpr (CKPT)
+        {
+            uint32_t cw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                cw[u] = stage[u * 64];
+            uint32_t const oi = Lay::bnd_oct_index((uint32_t)k0 / 8, (uint32_t)g);
+            reinterpret_cast<uint4 *>(slotA)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x05040100u), __builtin_amdgcn_perm(cw[3], cw[2], 0x05040100u),
+                                                              __builtin_amdgcn_perm(cw[5], cw[4], 0x05040100u), __builtin_amdgcn_perm(cw[7], cw[6], 0x05040100u));
+            reinterpret_cast<uint4 *>(slotB)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x07060302u), __builtin_amdgcn_perm(cw[3], cw[2], 0x07060302u),
+                                                              __builtin_amdgcn_perm(cw[5], cw[4], 0x07060302u), __builtin_amdgcn_perm(cw[7], cw[6], 0x07060302u));
+        }
+    };
+    // CKPT: after every fourth step the best-value bookkeeping, after every eighth the staged boundary codes leave
     auto chunk_done = [&](int k0)
     {
         if constexpr (CKPT)
@@ -338,46 +371,38 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
                 best = nb;
                 cmax = as_h2(kHalfNegInf2);
             }
-            uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g; // lx_ckpt.hip: bnd_quad_index
-            if (actA)
-                reinterpret_cast<uint4 *>(slotA)[qi] = make_uint4(stage[0], stage[64], stage[128], stage[192]);
-            if (actB)
-                reinterpret_cast<uint4 *>(slotB)[qi] = make_uint4(stage[256], stage[320], stage[384], stage[448]);
-            if (((k0 + 3) & 15) == 15)
+            if (k0 & 4)
+                flush_codes(k0);
+        }
+    };
+    // CKPT: the row checkpoint behind step k0 + 3 (k0 % 16 == 12).  Issued at the top of the next chunk, before that
+    // chunk's loads, so that these stores never stand between a load and its wait (see chunk_done).
+    auto rowck_store = [&](int k0)
+    {
+        if constexpr (CKPT)
+        {
+            // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's:
+            // H - F un-skewed = (Hrow - z_i) - (F0 - Z) = Hrow - F0 - ge
+            h2 const zi = Z + GE;
+            uint32_t code[2 * Lay::kCkDw];
+#pragma unroll
+            for (int c = 0; c < 2 * Lay::kCkDw; ++c)
+                code[c] = c < C ? c16_code(Hrow[c < C ? c : 0] - zi, (Hrow[c < C ? c : 0] - F0[c < C ? c : 0]) - GE) : 0u;
+            uint32_t const base = (uint32_t)(Lay::bnd_dwords(p.steps_cap) / 4) + Lay::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, 0);
+            uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+#pragma unroll
+            for (int x = 0; x < Lay::kCkDw / 4; ++x)
             {
-                // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's
-                h2 const zi = Z + GE;
-                // lx_ckpt.hip: rowck_quad_index -- quad x of checkpoint m sits at (m * kCkDw/4 + x) * G + g behind the boundary quads
-#ifndef LX_CKPT_ROWCK_LANE_MAJOR
-#define LX_CKPT_ROWCK_LANE_MAJOR 1
-#endif
-                constexpr uint64_t kXStride = LX_CKPT_ROWCK_LANE_MAJOR ? 1 : G;
-                uint64_t const base = (uint64_t)p.steps_cap * G / 4 +
-                                      (LX_CKPT_ROWCK_LANE_MAJOR ? ((uint64_t)((k0 + 3) / 16) * G + (uint64_t)g) * (kCkDw / 4)
-                                                                : (uint64_t)((k0 + 3) / 16) * (kCkDw / 4) * G + (uint64_t)g);
-                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+                uint32_t wa[4], wb[4];
 #pragma unroll
-                for (int x = 0; x < kCkDw / 4; ++x)
+                for (int b = 0; b < 4; ++b)
                 {
-                    uint32_t wa[4], wb[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                    {
-                        int const c = 4 * x + b;
-                        if (c < C)
-                        {
-                            h2 const hu = Hrow[c < C ? c : 0] - zi, fu = F0[c < C ? c : 0] - Z;
-                            wa[b] = __builtin_amdgcn_perm(as_u32(fu), as_u32(hu), 0x05040100u);
-                            wb[b] = __builtin_amdgcn_perm(as_u32(fu), as_u32(hu), 0x07060302u);
-                        }
-                        else
-                            wa[b] = wb[b] = 0;
-                    }
-                    if (actA)
-                        dA[x * kXStride] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
-                    if (actB)
-                        dB[x * kXStride] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                    int const c = 2 * (4 * x + b); // columns c, c + 1 of extension A (low halves) / B (high halves)
+                    wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
+                    wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
                 }
+                dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
             }
         }
     };
@@ -417,6 +442,8 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
         bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
         if (!cur_steady)
         {
+            if (k0 != 0 && (k0 & 15) == 0)
+                rowck_store(k0 - 4);
             uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
             mask_checked(k0, ca, cb);
             fetch_checked(k0 + 4, na, nb);
@@ -432,6 +459,8 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
             uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
             while (k0 < steady_hi)
             {
+                if ((k0 & 15) == 0) // (k0 >= steady_lo > 0)
+                    rowck_store(k0 - 4);
                 uint32_t const ca = wa, cb = wb;
                 int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                 wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
@@ -445,6 +474,10 @@ LX_UNROLL(LX_F16_UNROLL)
             fetch_checked(k0, na, nb);
         }
     }
+    if (steps != 0 && (steps & 15) == 0)
+        rowck_store(steps - 4);
+    if (steps & 4)
+        flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
 
     if constexpr (!CKPT)
     {
@@ -484,7 +517,7 @@ LX_UNROLL(LX_F16_UNROLL)
                     ec.score = gbest;
                     ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
                     ec.s_end = grow + 1;
-                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndHalf;
+                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndHalf; // compact slot
                 }
                 p.ends[e]      = ec;
                 p.out_score[e] = gbest;
