@@ -471,8 +471,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     auto dec = [](uint32_t bits16) -> int { return (int)(int16_t)bits16; };
     auto expand = [](uint32_t code16) -> uint32_t
     {
-        uint32_t const v = (code16 + kC16Bias) & 0xffffu, H = v & 0x7ffu;
-        return H | ((H - (v >> 11)) << 16);
+        uint32_t const H = code16 & 0x7ffu;
+        return H | ((H - (code16 >> 11)) << 16);
     };
     uint32_t const * slot  = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
     uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);

@@ -92,11 +92,9 @@ constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extens
 // A boundary pair (H of a strip's last column, E entering the next strip) and a row-checkpoint pair (H of a cell, the
 // folded F entering the cell below) always satisfy  0 <= H - other <= |cost of a gap's first character|  (E >= H + go and
 // E <= H + ge because E of the same cell is <= H; likewise F), and the packed-half kernel only runs when every value
-// is <= 2046 -- so a pair is the 16-bit code  H | (H - other) << 11  (11 + 5 bits; needs go >= -31).  The kernel stores
-// code - 0x3800 (mod 2^16): that is what falls out of its half-precision bit arithmetic.
+// is <= 2046 -- so a pair is the 16-bit code  H | (H - other) << 11  (11 + 5 bits; needs go >= -31).
 //   boundary codes:  [step / 8][lane] 16-byte groups of 8 steps (lane-minor: the G lanes of a group fill whole lines);
 //   row checkpoints: [checkpoint][lane][quad], two columns per dword, every 16 steps (lane-major).
-constexpr uint32_t kC16Bias = 0x3800u;
 constexpr int      kC16MaxGap = 31;
 template <int G, int C>
 struct Ckpt16Layout

@@ -54,21 +54,14 @@ __device__ __forceinline__ uint32_t as_u32(h2 x)
 
 constexpr uint32_t kHalfNegInf2 = 0xfc00fc00u; // (-inf, -inf)
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-// Ckpt16Layout code of (value, value - other) for both halves, minus kC16Bias: integers 0 .. 2046 and 0 .. 31 held in
-// half precision become bit fields without a conversion instruction.  x + 1024 lands in the binade [1024, 2048] whose
-// ulp is 1 -- its bit pattern is 0x6400 + x -- for x <= 1024, and x itself lies there for x >= 1024; so
-// bits(min(x, 1024) + 1024) + bits(max(x, 1024)) = 2 * 0x6400 + x for every x in 0 .. 2047.  The difference goes to
-// bits 11-15 by a 16-bit multiply-add whose 0x6400 * 2048 vanishes mod 2^16.
-__device__ __forceinline__ uint32_t c16_code(h2 value, h2 diff)
+// Ckpt16Layout codes without a conversion instruction: an integer n in 0 .. 2047 scaled by 2^-24 is a half-precision
+// subnormal (n < 1024) or lies in the first binade (spacing 2^-24 as well), so the bit pattern of n * 2^-24 is n itself
+// (FP16 denormals are on in the kernel descriptor, the compiler's default).  Scaling by a power of two and adding
+// multiples of 2^-24 below 2048 * 2^-24 is exact.
+constexpr uint32_t kHalfTwoPowMinus24x2 = 0x00010001u; // (2^-24, 2^-24)
+__device__ __forceinline__ uint32_t c16_pack(h2 value_scaled, h2 diff_scaled)
 {
-    h2 const    K = h2{(_Float16)1024.f, (_Float16)1024.f};
-    h2 const    a = __builtin_elementwise_minimum(value, K) + K;
-    h2 const    b = __builtin_elementwise_maximum(value, K);
-    u16x2 const s = __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b);
-    u16x2 const t = __builtin_bit_cast(u16x2, diff + K);
-    u16x2 const m = u16x2{2048, 2048};
-    return __builtin_bit_cast(uint32_t, (u16x2)(t * m + s));
+    return (as_u32(diff_scaled) << 11) | as_u32(value_scaled); // both halves at once: diff < 32 stays inside its half
 }
 
 template <int G, int C>
@@ -261,6 +254,8 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
     uint32_t tie  = 0;
     int      krow = -g; // row of the step being processed
     int      krow_slot = 0; // step % 8
+    h2 const C24 = as_h2(kHalfTwoPowMinus24x2), NC24 = -C24, GEc = GE * C24;
+    h2       nZc = -(Z * C24); // -Z 2^-24, kept in step with Z
     h2       cmax = as_h2(kHalfNegInf2); // best un-skewed row maximum of the current chunk
     using Lay = Ckpt16Layout<G, C>;
     // (slot p.n is a spare one that idle halves write to)
@@ -326,7 +321,9 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
             cmax = hmax(cmax, cand); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
             // Ckpt16Layout codes of both extensions, staged for one 16-byte store per extension every eight steps
-            stage[krow_slot * 64] = c16_code(h - Z, h - Ecur);
+            h2 const hc           = h * C24;
+            stage[krow_slot * 64] = c16_pack(hc + nZc, __builtin_elementwise_fma(Ecur, NC24, hc));
+            nZc                   = nZc + GEc; // Z grows by -ge per step
             krow_slot             = (krow_slot + 1) & 7;
             ++krow;
         }
@@ -383,11 +380,13 @@ __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScorePar
         {
             // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's:
             // H - F un-skewed = (Hrow - z_i) - (F0 - Z) = Hrow - F0 - ge
-            h2 const zi = Z + GE;
+            h2 const nzic = nZc - GEc, nGEc = -GEc; // -(Z + ge) 2^-24, -ge 2^-24
             uint32_t code[2 * Lay::kCkDw];
 #pragma unroll
             for (int c = 0; c < 2 * Lay::kCkDw; ++c)
-                code[c] = c < C ? c16_code(Hrow[c < C ? c : 0] - zi, (Hrow[c < C ? c : 0] - F0[c < C ? c : 0]) - GE) : 0u;
+                code[c] = c < C ? c16_pack(__builtin_elementwise_fma(Hrow[c < C ? c : 0], C24, nzic),
+                                           __builtin_elementwise_fma(Hrow[c < C ? c : 0] - F0[c < C ? c : 0], C24, nGEc))
+                                : 0u;
             uint32_t const base = (uint32_t)(Lay::bnd_dwords(p.steps_cap) / 4) + Lay::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, 0);
             uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
