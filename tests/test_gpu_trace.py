@@ -692,3 +692,84 @@ def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
     assert len(ops) == max(total, 1)  # compact: exactly the survivors' slots
     surv2 = np.nonzero((want_score >= int(np.percentile(want_score, 50))) & (ext["s_len"] > 0))[0]
     assert (np.nonzero(hsp2["n_ops"])[0] == surv2[want_score[surv2] > 0]).all()
+
+
+def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle):
+    """Single sweep with compact slots: wavefronts whose query fails the packed-half exactness gate (tryptophan-rich 200 aa
+    queries: the bound on the intermediates exceeds 2046, real scores beyond 2047 occur) go to the int32 kernel and get
+    int16-pair slots in the overflow area; their neighbours keep the compact ones.  Both must reproduce the oracle."""
+    rng = np.random.default_rng(99)
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    lq, wpq, nq = 200, 16, 10
+    q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=4711, sub_rate=0.1, indel_rate=0.02)
+    q, s = q.copy(), s.copy()
+    W = 22
+    heavy = [1, 4, 5, 8]
+    for k in heavy:
+        x0 = ext[k * wpq]
+        qs = slice(int(x0["q_off"]), int(x0["q_off"]) + lq)
+        q[qs] = np.where(rng.random(lq) < 0.97, W, q[qs])
+        for w, x in enumerate(ext[k * wpq: (k + 1) * wpq: 2]):  # every other window: a copy of the query, the first one exact
+            ls = int(x["s_len"])
+            b = (ls - lq) // 2
+            win = s[int(x["s_off"]): int(x["s_off"]) + ls]
+            win[b: b + lq] = np.where(rng.random(lq) < (1.0 if w == 0 else 0.9), q[qs], win[b: b + lq])
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    assert want_score.max() > 2047  # beyond what a compact code can hold
+    cutoff = 60
+    surv = np.nonzero(want_score >= cutoff)[0]
+    want = oracle.align_batch(q, s, ext[surv], osc)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    score, hsp, off, ops = handle.extend_batch(q, s, ext, cutoff)
+    assert "single sweep" in handle.last_trace_kernel_name() and "score_pair_kernel<16,13,true>" in handle.last_trace_kernel_name()
+    assert (score == want_score).all()
+    heavy_surv = 0
+    for i, (oh, oops) in zip(surv, want):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, i
+        heavy_surv += (i // wpq) in heavy
+    assert heavy_surv >= 8 and len(surv) - heavy_surv >= 8  # both kinds of slots were walked
+    # a trace budget that leaves too small an overflow area: the call must fail loudly, not return wrong alignments
+    steps = (int(ext["s_len"].max()) + 16 - 1 + 15) & ~15
+    compact, pairs = steps * 16 // 2 + steps // 16 * 16 * 8, steps * 16 + steps // 16 * 16 * 16  # uint32 per slot, (16,13)
+    handle.set_option(capi.LX_OPT_TRACE_BYTES, ((len(ext) + 1) * compact + 10 * pairs) * 4)
+    try:
+        with pytest.raises(capi.LambdaExtError, match="checkpoint slot"):
+            handle.extend_batch(q, s, ext, cutoff)
+    finally:
+        handle.set_option(capi.LX_OPT_TRACE_BYTES, 64 << 30)
+    score, hsp, off, ops = handle.extend_batch(q, s, ext, cutoff)  # and the handle is usable afterwards
+    assert (score == want_score).all()
+
+
+@pytest.mark.parametrize("gap_open,gap_extend", [(-38, -2), (-30, -1), (0, -3)])
+def test_sweep_unusual_gap_costs(handle, oracle, gap_open, gap_extend):
+    """The compact checkpoint codes hold (value - gap state) in 5 bits: a first gap character dearer than 31 sends the
+    sweep to the int32 kernel (int16 pairs), exactly 31 still packs, and gapOpen = 0 (linear gaps) is the other edge."""
+    sc_p = capi.builtin_scoring(62, gap_open=gap_open, gap_extend=gap_extend)
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_batch_np(12, 150, 16, seed=31337, sub_rate=0.15, indel_rate=0.05)
+    want_score = oracle.score_batch(q, s, ext, osc, threads=8)
+    cutoff = int(np.percentile(want_score, 40)) + 1
+    surv = np.nonzero(want_score >= cutoff)[0]
+    want = oracle.align_batch(q, s, ext[surv], osc)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    try:
+        score, hsp, off, ops = handle.extend_batch(q, s, ext, cutoff)
+        name = handle.last_trace_kernel_name()
+    finally:
+        handle.set_scoring(SCHEMES["blosum62"], 0)
+    assert "single sweep" in name and ("score_pair_kernel" in name) == (-(gap_open + gap_extend) <= 31)
+    assert (score == want_score).all()
+    for i, (oh, oops) in zip(surv, want):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, name)
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, i
