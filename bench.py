@@ -270,9 +270,11 @@ def main():
         # writes one int32 score; pass 2 forward reads the same per survivor (+ its score) and writes 4 direction bits per cell
         algo_bytes = float(ext["q_len"].sum()) / args.windows + float(ext["s_len"].sum()) + n * ALGO_BYTES_PER_EXT_EXTRA
         if "single sweep" in kernel_name:
-            # the sweep also writes the checkpoints of every extension: one 4-byte boundary pair per strip and row, one
-            # 4-byte pair per column every 16 rows, and a 16-byte end record
-            algo_bytes += n * (ls * (-(-lq // 19)) * 4 + (ls / 16.0) * lq * 4 + 16)
+            # the sweep also writes the checkpoints of every extension: one boundary pair per strip and row, one pair per
+            # column every 16 rows -- 2-byte codes from the packed-half kernel, int16 pairs from the int32 kernel -- and a
+            # 16-byte end record
+            pair_bytes = 2 if "pair_kernel" in kernel_name else 4
+            algo_bytes += n * (ls * (-(-lq // 19)) * pair_bytes + (ls / 16.0) * lq * pair_bytes + 16)
         r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], cells_rank,
                            "score_pair_kernel" if "pair_kernel" in kernel_name else "score_kernel", algo_bytes)
         rooflines = [r_score]
