@@ -361,9 +361,10 @@ enum
 };
 /* Appends header (if write_header) and records to `path` (myWriteHeader / myWriteRecord,
  * src/search_output.hpp:305-461, :463-733).  `ops` is the ops buffer the matches' ops_off index into; `program` is
- * "blastp", "blastn", or -- tabular formats only -- "blastx", "tblastn", "tblastx": positions of a translated side
- * are reported in nucleotide coordinates of the original sequence (names->q_lens / s_lens = untranslated lengths),
- * start > end on the minus strand. */
+ * "blastp", "blastn", "blastx", "tblastn" or "tblastx": positions of a translated side are reported in nucleotide
+ * coordinates of the original sequence (names->q_lens / s_lens = untranslated lengths), start > end on the minus
+ * strand in the tabular formats; SAM of a translated query carries the nucleotide-space CIGAR (runs x 3, frame
+ * clips as H, reversed on the minus strand) and the covered part of the untranslated read. */
 int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
                      uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                      uint64_t const * q_ascii_off);

@@ -377,8 +377,6 @@ int main(int argc, char ** argv)
             fmt = LX_OUT_SAM;
         else if (!ends(".m8"))
             throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
-        if ((blastx || sTrans) && fmt == LX_OUT_SAM)
-            throw std::runtime_error("SAM output of translated searches is not implemented; use .m8 or .m9");
         eng.check(lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
                                    reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data()));
 

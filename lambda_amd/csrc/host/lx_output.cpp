@@ -29,13 +29,29 @@ std::string firstWord(char const * id)
     return p == std::string::npos ? s : s.substr(0, p);
 }
 
-// blastMatchOneCigar, src/search_output.hpp:115-194, for transFac = 1 and no frame clips
-std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen, bool hardClip)
+// blastMatchOneCigar, src/search_output.hpp:115-194.  qLen = length of the untranslated query; a translated query
+// (qTrans) is reported in nucleotide space: every run x 3 (:124), the nucleotides in front of the frame and the
+// incomplete codon behind it as hard clips (:126-127), the whole element list reversed on the minus strand (:192-193).
+std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen, bool hardClip, bool qTrans = false)
 {
-    std::string    c;
-    uint64_t const leftClip = m.q_start, rightClip = qLen - m.q_end;
-    if (leftClip > 0)
-        c += std::to_string(leftClip) + (hardClip ? 'H' : 'S');
+    std::vector<std::pair<char, uint64_t>> el;
+    uint64_t const transFac       = qTrans ? 3 : 1;
+    uint64_t const leftFrameClip  = (uint64_t)std::abs((int)m.q_frame) - (m.q_frame != 0 ? 1 : 0);
+    uint64_t const rightFrameClip = qTrans ? (qLen - leftFrameClip) % 3 : 0;
+    uint64_t const frameLen       = qTrans ? (qLen - leftFrameClip) / 3 : qLen; // length(source(alignRow0))
+    uint64_t const leftClip = m.q_start * transFac, rightClip = (frameLen - m.q_end) * transFac;
+    if (hardClip)
+    {
+        if ((qTrans ? leftFrameClip : 0) + leftClip > 0)
+            el.emplace_back('H', (qTrans ? leftFrameClip : 0) + leftClip);
+    }
+    else
+    {
+        if (qTrans && leftFrameClip > 0)
+            el.emplace_back('H', leftFrameClip);
+        if (leftClip > 0)
+            el.emplace_back('S', leftClip);
+    }
     uint8_t const * o = ops + m.ops_off;
     for (uint32_t i = 0; i < m.n_ops;)
     {
@@ -46,7 +62,7 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
             ++i;
         }
         if (cnt)
-            c += std::to_string(cnt) + 'D';
+            el.emplace_back('D', cnt * transFac);
         cnt = 0;
         while (i < m.n_ops && o[i] == 'I')
         {
@@ -54,7 +70,7 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
             ++i;
         }
         if (cnt)
-            c += std::to_string(cnt) + 'I';
+            el.emplace_back('I', cnt * transFac);
         cnt = 0;
         while (i < m.n_ops && o[i] == 'M')
         {
@@ -62,11 +78,40 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
             ++i;
         }
         if (cnt)
-            c += std::to_string(cnt) + 'M';
+            el.emplace_back('M', cnt * transFac);
     }
-    if (rightClip > 0)
-        c += std::to_string(rightClip) + (hardClip ? 'H' : 'S');
+    if (hardClip)
+    {
+        if (rightFrameClip + rightClip > 0)
+            el.emplace_back('H', rightFrameClip + rightClip);
+    }
+    else
+    {
+        if (rightClip > 0)
+            el.emplace_back('S', rightClip);
+        if (rightFrameClip > 0)
+            el.emplace_back('H', rightFrameClip);
+    }
+    if (qTrans && m.q_frame < 0)
+        std::reverse(el.begin(), el.end());
+    std::string c;
+    for (auto const & e : el)
+        c += std::to_string(e.second) + e.first;
     return c;
+}
+
+void reverseComplementAscii(std::string & seq)
+{
+    std::reverse(seq.begin(), seq.end());
+    for (char & ch : seq)
+        switch (std::toupper((unsigned char)ch))
+        {
+            case 'A': ch = 'T'; break;
+            case 'C': ch = 'G'; break;
+            case 'G': ch = 'C'; break;
+            case 'T': case 'U': ch = 'A'; break;
+            default: ch = 'N';
+        }
 }
 
 } // namespace
@@ -135,8 +180,6 @@ int lx_write_records(char const * path, int format, int write_header, char const
     bool const sTrans = std::strcmp(program, "tblastn") == 0 || std::strcmp(program, "tblastx") == 0; // sIsTranslated
     if (!isN && !qTrans && !sTrans && std::strcmp(program, "blastp") != 0)
         return LX_EINVAL;
-    if ((qTrans || sTrans) && format == LX_OUT_SAM)
-        return LX_EINVAL; // the frame-clipped protein/DNA CIGARs of src/search_output.hpp:196-300 are not implemented
     std::FILE * f = std::fopen(path, write_header ? "w" : "a");
     if (!f)
         return LX_EINVAL;
@@ -175,31 +218,50 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 // BLASTP: no DNA cigar and no SEQ ("*"); BLASTN: cigar with soft clips and, for the first record of a
                 // query region, the read sequence (samBamSeq = uniq, :536-553)
                 std::string cigar = "*", seq = "*";
+                // samBamSeq = uniq (:536-553): the sequence once per query region and frame
+                bool const writeSeq = (k == lo) || b.q_frame != m[k - 1].q_frame || b.q_start != m[k - 1].q_start ||
+                                      b.q_end != m[k - 1].q_end;
+                uint64_t const qLen = names->q_lens[b.n_qid];
                 if (isN)
                 {
-                    cigar = cigarOf(b, ops, names->q_lens[b.n_qid], false);
-                    bool writeSeq = (k == lo) || b.q_frame != m[k - 1].q_frame || b.q_start != m[k - 1].q_start ||
-                                    b.q_end != m[k - 1].q_end; // samBamSeq = uniq (:536-553)
+                    cigar = cigarOf(b, ops, qLen, false);
                     if (writeSeq && q_res_ascii && q_ascii_off)
                     {
-                        seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], names->q_lens[b.n_qid]);
+                        seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], qLen);
                         if (b.q_frame < 0) // the aligned sequence is the reverse-complement frame
-                        {
-                            std::reverse(seq.begin(), seq.end());
-                            for (char & ch : seq)
-                                switch (std::toupper((unsigned char)ch))
-                                {
-                                    case 'A': ch = 'T'; break;
-                                    case 'C': ch = 'G'; break;
-                                    case 'G': ch = 'C'; break;
-                                    case 'T': case 'U': ch = 'A'; break;
-                                    default: ch = 'N';
-                                }
-                        }
+                            reverseComplementAscii(seq);
                     }
                 }
+                else if (qTrans)
+                {
+                    // nucleotide-space CIGAR (:528-531) and the part of the untranslated read that the frame covers,
+                    // soft-clip mode of _untranslateSequence (:84-109, :590-598): [|f| - 1, 3 L + |f| - 1) from the read's
+                    // start on the plus strand, from its end (then reverse-complemented) on the minus strand
+                    cigar = cigarOf(b, ops, qLen, false, true);
+                    if (writeSeq && q_res_ascii && q_ascii_off && b.q_frame != 0)
+                    {
+                        uint64_t const fc = (uint64_t)std::abs((int)b.q_frame) - 1, L = (qLen - fc) / 3;
+                        char const *   src = reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid];
+                        if (b.q_frame > 0)
+                            seq.assign(src + fc, 3 * L);
+                        else
+                        {
+                            seq.assign(src + (qLen - (3 * L + fc)), 3 * L);
+                            reverseComplementAscii(seq);
+                        }
+                    }
+                } // BLASTP / TBLASTN: the query is protein -- no DNA cigar (:526-531), no SEQ (:599)
+                // POS: a translated subject is reported in nucleotide space (:493-499; the minus-strand branch there
+                // subtracts from the QUERY length -- restated as it stands)
+                uint64_t pos = b.s_start;
+                if (sTrans)
+                {
+                    pos = b.s_start * 3 + (uint64_t)std::abs((int)b.s_frame) - (b.s_frame != 0 ? 1 : 0);
+                    if (b.s_frame < 0)
+                        pos = qLen - pos;
+                }
                 std::fprintf(f, "%s\t%d\t%s\t%llu\t255\t%s\t*\t0\t0\t%s\t*", qn.c_str(), flag, sn.c_str(),
-                             (unsigned long long)(b.s_start + 1), cigar.c_str(), seq.c_str());
+                             (unsigned long long)(pos + 1), cigar.c_str(), seq.c_str());
                 // tags in the order of myWriteRecord: ae, AS, ai, qf, NM (:611-716)
                 std::fprintf(f, "\tae:f:%g\tAS:i:%u\tai:i:%u\tqf:i:%d\tNM:i:%u\n", (double)(float)b.e_value,
                              (unsigned)(uint16_t)b.bit_score, (unsigned)(uint8_t)b.identity, (int)b.q_frame,

@@ -216,10 +216,29 @@ def test_searchp_blastx_frames_and_coordinates(tmp_path):
             assert abs(qs_ - qstart) <= 12 and abs(qe_ - qend) <= 12 and ss_ <= a + 1 and se_ >= a + 50
         assert abs(qe_ - qs_) + 1 == 3 * (int(x[3]) - int(x[5]) * 0) or int(x[5]) > 0  # ungapped: 3 nt per column
     assert exact >= 0.7 * len(truth), exact
-    # SAM is refused for translated searches rather than written wrong
+    # the same search as SAM: nucleotide-space CIGAR whose clips and runs add up to the read, strand flag, covered SEQ
+    import re
     r = subprocess.run([str(_cli()), "searchp", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "db.fasta"), "-o",
-                        str(tmp_path / "o.sam")], capture_output=True, text=True)
-    assert r.returncode != 0 and "not implemented" in r.stderr
+                        str(tmp_path / "o.sam"), "--seed-offset", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    first = {}
+    for l in (tmp_path / "o.sam").read_text().splitlines():
+        if not l.startswith("@"):
+            x = l.split("\t")
+            first.setdefault(x[0], x)
+    assert len(first) == len(reads)
+    for k, (j, a, qstart, qend) in enumerate(truth):
+        x = first[f"read{k}"]
+        assert x[2] == f"sp{j}" and (int(x[1]) & 16 != 0) == (qstart > qend), x
+        el = [(int(n), c) for n, c in re.findall(r"(\d+)([MIDSH])", x[5])]
+        assert sum(n for n, c in el if c in "MISH") == len(reads[k]), x      # every nucleotide of the read is accounted for
+        assert all(n % 3 == 0 for n, c in el if c in "MIDS")                    # codon-sized runs; only frame clips are free
+        assert len(x[9]) == sum(n for n, c in el if c in "MIS")                 # SEQ = the read minus the hard clips
+        frame = int([t for t in x if t.startswith("qf:i:")][0][5:])
+        if frame > 0:
+            assert x[9] == reads[k][frame - 1: frame - 1 + len(x[9])]
+        else:
+            assert x[9] == reads[k].translate(comp)[::-1][-frame - 1: -frame - 1 + len(x[9])]
 
 
 @pytest.mark.gpu

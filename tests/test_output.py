@@ -80,3 +80,42 @@ def test_sam_writer_blastp_has_no_cigar(tmp_path):
     capi.write_records(p, capi.LX_OUT_SAM, m, b"M" * 20, ["q"], [20], ["s"], [100])
     f = [l for l in p.read_text().splitlines() if not l.startswith("@")][0].split("\t")
     assert f[5] == "*" and f[9] == "*" and "qf:i:0" in f  # src/search_output.hpp:527-531: no DNA cigar for BLASTP
+
+
+def test_sam_writer_translated_query_cigar_clips_and_sequence(tmp_path):
+    """BLASTX / TBLASTX records in SAM (src/search_output.hpp:115-194, :84-109, :493-499): nucleotide-space CIGAR (runs x 3,
+    the nucleotides outside the frame as hard clips, reversed on the minus strand), the covered part of the untranslated
+    read as SEQ, translated subject positions x 3 + frame offset."""
+    read = b"ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAG"  # 32 nt
+    qlen = len(read)
+    ops = b"MMMMDMMM"  # protein space: 4 M, one gap in the query row, 3 M -> query columns [2, 9)
+    # frame +2: one nucleotide in front of the frame, (32 - 1) % 3 = 1 behind it, frame length 10 codons
+    plus = rec(0, 0, 2, 9, 5, 13, 40.0, alen=len(ops), nm=6, n_ops=len(ops), frame=2)
+    # frame -3: two nucleotides clipped in front (of the reverse strand), none behind, frame length 10 codons
+    minus = rec(0, 1, 2, 9, 5, 13, 39.0, alen=len(ops), nm=6, n_ops=len(ops), frame=-3)
+    plus["s_frame"], minus["s_frame"] = 3, -1
+    m = np.array([plus, minus], dtype=capi.BLAST_MATCH_DTYPE)
+    p = tmp_path / "x.sam"
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1"], [qlen], ["s0", "s1"], [900, 900], program="tblastx",
+                       q_ascii=read, q_ascii_off=[0])
+    f0, f1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
+    assert f0[1] == "0" and f0[5] == "1H6S12M3D9M3S1H"
+    assert f0[9] == read[1:31].decode()
+    assert f0[3] == str(5 * 3 + 2 + 1)  # s_frame +3: 3 s_start + |frame| - 1, 1-based in the file
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    assert f1[1] == "272" and f1[5] == "3S9M3D12M6S2H"  # secondary + reverse strand; element list reversed
+    assert f1[9] == "".join(comp[c] for c in reversed(read[0:30].decode()))
+    assert f1[3] == str(qlen - (5 * 3 + 0) + 1)  # the reference's minus-strand branch, restated as it stands
+    assert "qf:i:2" in f0 and "qf:i:-3" in f1
+    # BLASTX: the subject is protein -- plain position
+    capi.write_records(p, capi.LX_OUT_SAM, m[:1], ops, ["read1"], [qlen], ["s0", "s1"], [900, 900], program="blastx",
+                       q_ascii=read, q_ascii_off=[0])
+    g = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")][0]
+    assert g[3] == "6" and g[5] == "1H6S12M3D9M3S1H"
+    # TBLASTN: protein query -- no DNA cigar, no sequence, translated subject position
+    t = rec(0, 0, 2, 9, 5, 13, 40.0, alen=len(ops), nm=6, n_ops=len(ops), frame=0)
+    t["s_frame"] = 2
+    capi.write_records(p, capi.LX_OUT_SAM, np.array([t], dtype=capi.BLAST_MATCH_DTYPE), ops, ["prot1"], [10], ["s0"], [900],
+                       program="tblastn")
+    g = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")][0]
+    assert g[5] == "*" and g[9] == "*" and g[3] == str(5 * 3 + 1 + 1)
