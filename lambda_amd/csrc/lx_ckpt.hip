@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     // codes of Ckpt16Layout instead: the loaders below expand them to the same pairs.  An extension that sweep declined
     // has an int16-pair slot of its own in the overflow area.
     using L16            = Ckpt16Layout<G, C>;
-    bool const     c16   = (ec.flags & kEndHalf) != 0;
+    bool const     c16   = (ec.flags & kEndCompact) != 0;
     uint32_t const ovf   = (uint32_t)ec.flags >> kEndOverflowShift;
     auto dec = [](uint32_t bits16) -> int { return (int)(int16_t)bits16; };
     auto expand = [](uint32_t code16) -> uint32_t

@@ -69,8 +69,8 @@ struct ScoreParams
     int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
     int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
     // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
-    // (as half-precision bit patterns) and the end cell of every extension
-    uint32_t *         ckpt;        // [n] slots of ckpt_stride uint32
+    // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
+    uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)
     uint64_t           ckpt_stride;
     uint32_t           steps_cap;
     struct EndCell *   ends;        // [n]
@@ -85,7 +85,7 @@ struct EndCell
     int32_t flags; // kEndAmbiguous: the strip reaches the best score in more than one row
 };
 constexpr int32_t kEndAmbiguous = 1;
-constexpr int32_t kEndHalf      = 2; // the slot was written by the packed-half sweep: compact 16-bit codes (Ckpt16Layout)
+constexpr int32_t kEndCompact      = 2; // the slot was written by the packed-half sweep: compact 16-bit codes (Ckpt16Layout)
 constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extension's slot in the overflow area (0 = none)
 
 // Compact checkpoint slots of the packed-half single sweep (lx_score_f16.hip writes, lx_ckpt.hip's backtrace reads).

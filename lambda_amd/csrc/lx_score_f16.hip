@@ -77,7 +77,7 @@ struct PairGeo
 };
 
 // CKPT = single sweep: the kernel additionally writes what pass 2's backtrace needs (layout and meaning as in
-// lx_ckpt.hip: strip boundaries per step, row checkpoints every 16 steps, here as half-precision bit patterns) and
+// lx_ckpt.hip: strip boundaries per step, row checkpoints every 16 steps, here as the compact codes of Ckpt16Layout) and
 // keeps, per strip and extension, the best value, the first row that reached it and whether a later row tied.
 template <int G, int C, bool CKPT>
 __global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScoreParams p)
@@ -516,7 +516,7 @@ LX_UNROLL(LX_F16_UNROLL)
                     ec.score = gbest;
                     ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
                     ec.s_end = grow + 1;
-                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndHalf; // compact slot
+                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndCompact; // compact slot
                 }
                 p.ends[e]      = ec;
                 p.out_score[e] = gbest;
