@@ -580,12 +580,6 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     uint32_t n    = 0;
     int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
 
-    // residues for the match / mismatch counts: aligned 16-byte groups (see lx_trace.hip)
-    uintptr_t const q_al = reinterpret_cast<uintptr_t>(q) & ~uintptr_t(15), s_al = reinterpret_cast<uintptr_t>(s) & ~uintptr_t(15);
-    uint32_t const  q_sh = (uint32_t)(reinterpret_cast<uintptr_t>(q) & 15), s_sh = (uint32_t)(reinterpret_cast<uintptr_t>(s) & 15);
-    uint32_t        qg_at = 0xffffffffu, sg_at = 0xffffffffu;
-    uint32_t        qw0 = 0, qw1 = 0, qw2 = 0, qw3 = 0, sw0 = 0, sw1 = 0, sw2 = 0, sw3 = 0;
-
     uint32_t const  a0     = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
     uint8_t * const ops_al = ops - a0;
     uint32_t        apos   = a0 + cap - 1;
@@ -665,8 +659,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         }
         // LDS offsets of the matrix rows of this strip's query residues (columns beyond the query use the pad rank)
         uint32_t qoff[C];
+        uint32_t qd[(C + 3) / 4]; // the strip's query residues: the walk picks its column's letter from these
         {
-            uint32_t qd[(C + 3) / 4];
 #pragma unroll
             for (int d = 0; d < (C + 3) / 4; ++d)
                 qd[d] = *reinterpret_cast<unaligned_u32 const *>(q + j0 + 4 * d); // 256 bytes of slack behind the residues
@@ -749,6 +743,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                     w[c >> 3]     = wc;
                 }
                 int const kk = 4 * t + u;
+                w[kNibDw - 1] |= tl; // the row's subject letter rides in the spare low bits of the last word (for the walk)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
@@ -784,99 +779,48 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             end_i = i;
             end_j = j;
         }
-        // ---- walk inside the tile
+        // ---- walk inside the tile.  Written with selects instead of nested branches: one data-dependent exit (the
+        // alignment's first cell), everything else is arithmetic on the nibble -- bit 3 / bit 2 = the vertical /
+        // horizontal gap state extends, low two bits = where H came from (3 diagonal, 2 vertical, 1 horizontal).
+        static_assert(32 - 4 * (C - 8 * (kNibDw - 1)) >= 5, "the last nibble word needs 5 spare bits for the subject letter");
         while (i >= 0 && j >= j0 && i >= r_base && n < cap)
         {
-            int const      kk  = i - r_base, c = j - j0;
-            int const      xw  = c >> 3;
-            int const      cnt = (xw == kNibDw - 1) ? (C - 8 * xw) : 8; // cells held by this word (funnel-shifted in from the top)
-            uint32_t const nib = (tiles[(kk * kNibDw + xw) * 64 + lane] >> (32 - 4 * cnt + 4 * (c & 7))) & 15u;
-            uint32_t op      = 0;
-            bool     up      = false, lft = false;
-            bool     decided = false;
-            if (mode == 1)
+            int const      kk   = i - r_base, c = j - j0;
+            int const      xw   = c >> 3;
+            int const      cnt  = (xw == kNibDw - 1) ? (C - 8 * xw) : 8; // cells held by this word (funnel-shifted in from the top)
+            uint32_t const word = tiles[(kk * kNibDw + xw) * 64 + lane];
+            uint32_t const last = tiles[(kk * kNibDw + (kNibDw - 1)) * 64 + lane];
+            uint32_t const nib  = (word >> (32 - 4 * cnt + 4 * (c & 7))) & 15u;
+            bool const     in_v = mode == 1, in_h = mode == 2;
+            bool const     cont = (in_v && (nib & 8u)) || (in_h && (nib & 4u)); // the gap goes on through this cell
+            bool const     leave = (in_v || in_h) && !cont;                      // the gap was opened from this cell's H
+            go += leave ? 1 : 0;
+            left -= leave ? g2 : 0;
+            if (!cont && left <= 0)
             {
-                if (nib & 8u)
-                {
-                    gx += 1;
-                    left -= ge;
-                    op      = 'D';
-                    up      = true;
-                    decided = true;
-                }
-                else
-                {
-                    go += 1;
-                    left -= g2;
-                    mode = 0;
-                }
+                done = true; // H of this cell is 0: the alignment begins after it
+                break;
             }
-            else if (mode == 2)
-            {
-                if (nib & 4u)
-                {
-                    gx += 1;
-                    left -= ge;
-                    op      = 'I';
-                    lft     = true;
-                    decided = true;
-                }
-                else
-                {
-                    go += 1;
-                    left -= g2;
-                    mode = 0;
-                }
-            }
-            if (!decided)
-            {
-                if (left <= 0)
-                {
-                    done = true; // H of this cell is 0: the alignment begins after it
-                    break;
-                }
-                uint32_t const code = nib & 3u;
-                if (code == 3)
-                {
-                    uint32_t const qi = q_sh + (uint32_t)j, si = s_sh + (uint32_t)i;
-                    if ((qi >> 4) != qg_at)
-                    {
-                        qg_at = qi >> 4;
-                        uint4 const v = *reinterpret_cast<uint4 const *>(q_al + ((uintptr_t)qg_at << 4));
-                        qw0 = v.x; qw1 = v.y; qw2 = v.z; qw3 = v.w;
-                    }
-                    if ((si >> 4) != sg_at)
-                    {
-                        sg_at = si >> 4;
-                        uint4 const v = *reinterpret_cast<uint4 const *>(s_al + ((uintptr_t)sg_at << 4));
-                        sw0 = v.x; sw1 = v.y; sw2 = v.z; sw3 = v.w;
-                    }
-                    uint32_t const qd = (qi & 8) ? ((qi & 4) ? qw3 : qw2) : ((qi & 4) ? qw1 : qw0);
-                    uint32_t const sd = (si & 8) ? ((si & 4) ? sw3 : sw2) : ((si & 4) ? sw1 : sw0);
-                    uint32_t const c0 = (qd >> (8 * (qi & 3))) & (kAlph - 1), c1 = (sd >> (8 * (si & 3))) & (kAlph - 1);
-                    int const      v       = ((int)smat4[c0 * kAlph + c1] - 3) >> 2;
-                    bool const     isMatch = p.bs_match_rule ? (smat4[c0 * kAlph + c1] == smat4[c0 * kAlph + c0]) : (c0 == c1);
-                    nm += isMatch;
-                    nx += !isMatch;
-                    np += (v > 0);
-                    left -= v;
-                    op  = 'M';
-                    up  = true;
-                    lft = true;
-                }
-                else
-                {
-                    left -= ge;
-                    bool const vert = code == 2;
-                    op   = vert ? 'D' : 'I';
-                    up   = vert;
-                    lft  = !vert;
-                    mode = vert ? 1 : 2;
-                }
-            }
-            emit(op);
-            i -= up ? 1 : 0;
-            j -= lft ? 1 : 0;
+            uint32_t const code = nib & 3u;
+            bool const     diag = !cont && code == 3, vert = cont ? in_v : code == 2;
+            // residues of this cell: column letter from the strip's dwords, row letter from the tile row's last word
+            uint32_t qsel = qd[0];
+#pragma unroll
+            for (int d = 1; d < (C + 3) / 4; ++d)
+                qsel = ((c >> 2) == d) ? qd[d] : qsel;
+            uint32_t const c0 = (qsel >> (8 * (c & 3))) & (kAlph - 1), c1 = last & (kAlph - 1);
+            int const      sm = (int)smat4[c0 * kAlph + c1];
+            int const      v  = (sm - 3) >> 2;
+            bool const     isMatch = p.bs_match_rule ? (sm == (int)smat4[c0 * kAlph + c0]) : (c0 == c1);
+            nm += (diag && isMatch) ? 1 : 0;
+            nx += (diag && !isMatch) ? 1 : 0;
+            np += (diag && v > 0) ? 1 : 0;
+            gx += cont ? 1 : 0;
+            left -= diag ? v : ge; // a gap character -- continued or first -- costs ge here, the opening surcharge when it ends
+            mode = diag ? 0 : (vert ? 1 : 2);
+            emit(diag ? (uint32_t)'M' : (vert ? (uint32_t)'D' : (uint32_t)'I'));
+            i -= (diag || vert) ? 1 : 0;
+            j -= (diag || !vert) ? 1 : 0;
         }
     }
     if (mode != 0)
