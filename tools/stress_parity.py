@@ -1,6 +1,6 @@
 """Randomised parity stress of the fused step on host buffers (lx_extend_batch) against the CPU oracle: random query
 lengths (all sweep geometries and the fall-backs), run lengths, schemes, gap costs, mutation rates, truncated / empty
-windows, cut-offs and pass-2 modes.  Development aid: `python tools/stress_parity.py SECONDS [SEED]` on a GPU box; the
+windows, cut-offs and pass-2 modes.  Development aid: `python tools/stress_parity.py SECONDS [SEED [MAX_QUERY_LENGTH]]` on a GPU box; the
 committed parity tests are tests/test_gpu_*.py."""
 import sys, time
 from pathlib import Path
@@ -11,6 +11,7 @@ from tests import oracle_lib
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_lq = int(sys.argv[3]) if len(sys.argv) > 3 else 215  # beyond 208 columns: multi-panel kernels, direction bits
 orc = oracle_lib.load()
 h = capi.Handle(0)
 t0 = time.time()
@@ -30,7 +31,7 @@ while time.time() - t0 < budget:
         sc_p, alpha = capi.builtin_scoring(62, gap_open=0, gap_extend=int(rng.integers(-6, -1))), synth.STD20[:int(rng.integers(2, 6))]
     osc = oracle_lib.scoring_from(sc_p)
     h.set_scoring(sc_p, 0)
-    lq = int(rng.integers(20, 215))
+    lq = int(rng.integers(20, max_lq))
     wpq = int(rng.choice([5, 8, 16, 24, 32, 40]))
     nq = int(rng.integers(4, 24))
     q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=int(rng.integers(1, 1 << 30)), alphabet=alpha,
