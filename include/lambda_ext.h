@@ -105,7 +105,8 @@ char const * lx_last_error(lx_handle const * h); /* h may be NULL: error of the 
  *                          that share one query slice (must be a multiple of 8; 0 = no promise).  Lets a wavefront
  *                          build one LDS profile instead of one per extension.  A violated promise is detected on
  *                          the device and reported as LX_ESTATE by lx_synchronize().
- *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB)
+ *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB; with
+ *                          LX_OPT_MAX_SLEN set it grows by itself to 8 bytes per subject row of the batch)
  *   (LX_OPT_BS_MATCH_RULE is the one option that is not a tuning knob: it selects which of the reference's two
  *   computeAlignmentStats overloads the pass-2 match counts follow.) */
 enum

@@ -328,8 +328,13 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     return LX_OK;
 }
 
-int prepare_workspace(lx_handle * h, hipStream_t stream)
+// pairs_hint: carry pairs (8 bytes each) the call can need at most -- one per subject row of every extension whose
+// query is wider than a panel; the workspace grows to that (the device cannot grow it, it can only report)
+int prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint = 0)
 {
+    uint64_t const want = std::min<uint64_t>(pairs_hint, 0xfffffff0ull) * 8 + 4096;
+    if (pairs_hint != 0 && want > h->opt_ws_bytes)
+        h->opt_ws_bytes = want;
     int rc = ensure(h, h->d_ws, h->opt_ws_bytes);
     if (rc)
         return rc;
@@ -653,12 +658,12 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     if (rc)
         return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
-    if ((rc = prepare_workspace(h, stream)))
-        return rc;
     // geometry from the caller's hints; any geometry is correct for any query length (multi-panel path)
     bool const want_shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
     int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu), want_shared) : 0;
     bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
+    if ((rc = prepare_workspace(h, stream, multi ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
+        return rc;
     bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
     if (!h->in_fused)
     {
@@ -1093,8 +1098,6 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     if (rc)
         return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
-    if ((rc = prepare_workspace(h, stream)))
-        return rc;
     uint64_t max_q = h->opt_max_qlen, max_s = h->opt_max_slen;
     if (max_q == 0 || max_s == 0)
     {
@@ -1107,6 +1110,8 @@ int lx_align_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
         max_q = std::max<uint64_t>(ml.max_q, 1);
         max_s = std::max<uint64_t>(ml.max_s, 1);
     }
+    if ((rc = prepare_workspace(h, stream, max_q > (uint64_t)lx::trace_cfg_panel(1) ? n * ((max_s + 3) & ~3ull) : 0)))
+        return rc;
     h->phase_ev.clear();
     h->ev_pool_used = 0;
     LX_HIP(h, hipEventRecord(h->ev0, stream));
@@ -1411,7 +1416,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     }
     else if (phases & 1)
     {
-        // pass 1 (src/search_algo.hpp:1246)
+        // pass 1 (src/search_algo.hpp:1246).  Pass 2 may need the carry workspace even where pass 1 does not (its panels
+        // are narrower): size it now, while nothing is in flight
+        if (h->opt_max_qlen > (uint64_t)lx::trace_cfg_panel(1) && (rc = prepare_workspace(h, stream, n * ((h->opt_max_slen + 3) & ~3ull))))
+            return rc;
         h->in_fused = true;
         rc          = lx_score_batch_dev(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, stream);
         h->in_fused = false;
