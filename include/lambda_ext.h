@@ -130,7 +130,8 @@ enum
                                    2 (default) = single sweep in lx_extend_batch_dev: one checkpointing kernel over ALL
                                        extensions is pass 1 and the forward half of pass 2 at once -- where mode 1
                                        applies, LX_OPT_QUERY_RUN is a multiple of 8 and the checkpoints of the whole
-                                       batch (13.5 KB per 150 x 176 extension) fit LX_OPT_TRACE_BYTES, else mode 1 */
+                                       batch (7.7 KB per 150 x 176 extension as compact codes of the packed-half kernel,
+                                       13.5 KB as int16 pairs) fit LX_OPT_TRACE_BYTES, else mode 1 */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 
