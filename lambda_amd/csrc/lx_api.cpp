@@ -242,6 +242,8 @@ constexpr size_t kSlack = 256;
 // per wavefront would not fit the LDS budget), so without sharing only the 16/32/64-lane geometries are used.
 int pick_cfg(uint32_t qlen, bool shared)
 {
+    if (char const * e = getenv("LX_FORCE_SCORE_CFG")) // development aid: measure a geometry on a shape it is not picked for
+        return atoi(e);
     if (shared)
     {
         if (qlen <= 64)
@@ -261,9 +263,28 @@ int pick_cfg(uint32_t qlen, bool shared)
         return 7;
     if (qlen <= 256)
         return 8;
-    if (qlen <= 320)
-        return 2;
-    return 3;
+    // Longer queries: several panels of a 16-lane geometry beat one wide panel of the 32- / 64-lane ones (400 aa x 442:
+    // (16,13) x 2 panels 4.4 TCUPS, (16,16) x 2 3.8, (16,10) x 3 3.8, (32,10) x 2 2.6, (64,10) 2.3 -- the wide groups pay
+    // for their long skew and cross-row shifts).  Pick the geometry with the least padded work, weighted by the time
+    // each took per padded column in that measurement.
+    struct Cand
+    {
+        int    cfg, panel;
+        double cost;
+    };
+    static constexpr Cand cands[] = {{8, 256, 0.0581}, {7, 208, 0.0619}, {0, 160, 0.0621}};
+    int    best      = 8;
+    double best_cost = 1e30;
+    for (Cand const & c : cands)
+    {
+        double const cost = (double)((qlen + c.panel - 1) / c.panel * c.panel) * c.cost;
+        if (cost < best_cost)
+        {
+            best_cost = cost;
+            best      = c.cfg;
+        }
+    }
+    return best;
 }
 
 int check_async_error(lx_handle * h)
@@ -979,8 +1000,11 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
     // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
     // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
+    // Beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile as well).
+    auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
     int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
                     : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
+                    : (share_slots >= 4 && padded(2) < padded(0))                      ? 2
                                                                                       : 0;
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
