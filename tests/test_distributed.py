@@ -45,8 +45,10 @@ def _worker(rank, world, port, nq, wpq, out_dir):
         scores = orc.score_batch(q, s, mine, sc)
         keep = scores >= 40
         rec = np.stack([np.arange(lo * wpq, hi * wpq)[keep], scores[keep]], axis=1).astype(np.int64)
-        allrec = shard.gather_hits(torch.from_numpy(rec))
-        np.save(os.path.join(out_dir, f"rank{rank}.npy"), allrec.numpy())
+        root = shard.gather_hits(torch.from_numpy(rec))              # to rank 0, the writer
+        everyone = shard.gather_hits(torch.from_numpy(rec), dst=None)  # all_gather variant
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), everyone.numpy())
+        np.save(os.path.join(out_dir, f"root{rank}.npy"), root.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -65,3 +67,5 @@ def test_two_rank_gather_equals_unsharded(tmp_path, oracle):
     for r in range(world):
         got = np.load(tmp_path / f"rank{r}.npy")
         assert got.shape == want.shape and (got == want).all()
+        root = np.load(tmp_path / f"root{r}.npy")
+        assert (root.shape == want.shape and (root == want).all()) if r == 0 else root.shape == (0, 2)
