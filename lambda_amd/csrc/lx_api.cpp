@@ -240,6 +240,17 @@ constexpr size_t kSlack = 256;
 
 // Smallest panel that holds the query; 8-lane geometries need one shared profile per wavefront (8 profile slots
 // per wavefront would not fit the LDS budget), so without sharing only the 16/32/64-lane geometries are used.
+// LDS a wavefront of the packed-half kernel may spend on two query profiles (one per half wavefront: query runs of 8)
+size_t pair_lds_limit()
+{
+    static size_t const v = []() -> size_t
+    {
+        char const * e = getenv("LX_PAIR_LDS_LIMIT"); // development aid
+        return e ? (size_t)atoll(e) : (size_t)24 * 1024; // protein profiles too: 12.8 vs 14.0 ms (pass 1), 16.6 vs 19.1 ms (sweep) for runs of 8
+    }();
+    return v;
+}
+
 int pick_cfg(uint32_t qlen, bool shared)
 {
     if (char const * e = getenv("LX_FORCE_SCORE_CFG")) // development aid: measure a geometry on a shape it is not picked for
@@ -705,7 +716,7 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
             int const      nrows    = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
             if (h->opt_query_run % per_wave == 0)
                 pair_cfg = pc;
-            else if (groups >= 2 && h->opt_query_run % (per_wave / 2) == 0 && 2 * lx::score_pair_profile_bytes(pc, nrows) <= 13 * 1024)
+            else if (groups >= 2 && h->opt_query_run % (per_wave / 2) == 0 && 2 * lx::score_pair_profile_bytes(pc, nrows) <= pair_lds_limit())
             {
                 pair_cfg   = pc;
                 pair_share = groups / 2;
@@ -1349,7 +1360,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
                          ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
             if (h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
                 sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
-                2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= 13 * 1024)
+                2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
             {
                 half_sweep  = true;
                 sweep_share = 4;
