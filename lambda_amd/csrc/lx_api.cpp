@@ -1646,30 +1646,29 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
                                     idx[o++] = (uint32_t)i;
                         });
     }
-    constexpr uint64_t kRun = 16;
     auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
-    // groups: first list position and first slot of every run (+ a sentinel)
+    // groups: first list position and first slot of every run (+ a sentinel).  A list whose query offsets never step
+    // back is grouped (lambda's lists are sorted by query); anything else is sorted first.
     std::vector<uint64_t> & grp = h->xb_grp;
     auto find_groups = [&]()
     {
         grp.clear();
-        uint64_t total = 0;
+        bool monotone = true;
         for (size_t k = 0; k < idx.size();)
         {
             size_t k1 = k + 1;
             while (k1 < idx.size() && same_slice(idx[k1], idx[k]))
                 ++k1;
+            monotone = monotone && (k == 0 || ext[idx[k]].q_off >= ext[idx[k - 1]].q_off);
             grp.push_back(k);
-            grp.push_back(total);
-            total += (k1 - k + kRun - 1) / kRun * kRun;
+            grp.push_back(0);
             k = k1;
         }
         grp.push_back(idx.size());
-        grp.push_back(total);
-        return total;
+        grp.push_back(0);
+        return monotone;
     };
-    uint64_t slots = find_groups();
-    if (slots > idx.size() + idx.size() / 2 + 4 * kRun)
+    if (!find_groups())
     {
         std::sort(idx.begin(), idx.end(),
                   [&](uint32_t a, uint32_t b)
@@ -1677,7 +1676,25 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
                       lx_extension const &x = ext[a], &y = ext[b];
                       return x.q_off != y.q_off ? x.q_off < y.q_off : x.q_len != y.q_len ? x.q_len < y.q_len : a < b;
                   });
-        slots = find_groups();
+        (void)find_groups();
+    }
+    uint64_t const ngroups = grp.size() / 2 - 1;
+    // Runs are padded to 16 slots (one query per wavefront of the 8-lane packed geometry) or, when the queries have few
+    // windows each, to 8 (one query per half wavefront: ~1.4 x the time per slot, measured) -- whichever is less work.
+    uint64_t slots16 = 0, slots8 = 0;
+    for (uint64_t g = 0; g < ngroups; ++g)
+    {
+        uint64_t const len = grp[2 * g + 2] - grp[2 * g];
+        slots16 += (len + 15) / 16 * 16;
+        slots8 += (len + 7) / 8 * 8;
+    }
+    uint64_t const kRun = (slots8 * 7 < slots16 * 5) ? 8 : 16;
+    uint64_t       slots = 0;
+    for (uint64_t g = 0; g <= ngroups; ++g)
+    {
+        grp[2 * g + 1] = slots;
+        if (g < ngroups)
+            slots += (grp[2 * g + 2] - grp[2 * g] + kRun - 1) / kRun * kRun;
     }
     std::vector<lx_extension> & slot_ext = h->xb_ext;
     std::vector<uint32_t> &     slot_src = h->xb_src;
@@ -1685,7 +1702,6 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
     slot_ext.resize(slots);
     slot_src.resize(slots);
     slot_min.resize(slots);
-    uint64_t const ngroups = grp.size() / 2 - 1;
     parallel_ranges(ngroups, nthreads,
                     [&](unsigned, uint64_t glo, uint64_t ghi)
                     {
