@@ -28,6 +28,9 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 #ifndef LX_F16_UNROLL
 #define LX_F16_UNROLL 2 // steps unrolled in the main loop: 2 removes the register-rotation moves at 168 VGPRs
 #endif
+#ifndef LX_F16_CKPT_WAVES
+#define LX_F16_CKPT_WAVES 3 // wavefronts per SIMD the checkpointing instantiations are compiled for (headline sweep: 2 -> 12.1 ms, 3 -> 11.9 ms; steps unrolled 1 / 2 / 4 -> 12.7 / 11.9 / 12.0 ms)
+#endif
 #define LX_PRAGMA(x) _Pragma(#x)
 #define LX_UNROLL(n) LX_PRAGMA(unroll n)
 
@@ -80,7 +83,7 @@ struct PairGeo
 // lx_ckpt.hip: strip boundaries per step, row checkpoints every 16 steps, here as the compact codes of Ckpt16Layout) and
 // keeps, per strip and extension, the best value, the first row that reached it and whether a later row tied.
 template <int G, int C, bool CKPT>
-__global__ __launch_bounds__(64, (CKPT ? 3 : 1)) void score_pair_kernel(ScoreParams p)
+__global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair_kernel(ScoreParams p)
 {
     static_assert(C <= 24, "profile rows hold 24 halves per lane");
     using Geo = PairGeo<G, C>;
