@@ -773,3 +773,35 @@ def test_sweep_unusual_gap_costs(handle, oracle, gap_open, gap_extend):
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, name)
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops, i
+
+
+def test_published_durbin_local_alignment(handle):
+    """The worked local-alignment example of Durbin et al. (figure 2.6: HEAGAWGHEE vs PAWHEAE, BLOSUM50, linear gap cost 8,
+    best local alignment AWGHE / AW-HE with score 28) through every entry point: pass 1, pass 2 and the fused step."""
+    import ctypes as C
+
+    from tests.test_oracle import DURBIN_LETTERS, durbin_example
+
+    m6, q, s = durbin_example()
+    sc = capi.Scoring()
+    sc.alphabet_size, sc.gap_open, sc.gap_extend = len(DURBIN_LETTERS), -8, -8
+    m = np.zeros((capi.LX_ALPH, capi.LX_ALPH), dtype=np.int8)
+    m[:6, :6] = m6
+    C.memmove(sc.matrix, m.ctypes.data, m.nbytes)
+    handle.set_scoring(sc, 0)
+    try:
+        res = np.concatenate([q, s])
+        ext = np.zeros(32, dtype=capi.EXT_DTYPE)
+        ext["q_off"], ext["q_len"], ext["s_off"], ext["s_len"] = 0, len(q), len(q), len(s)
+        assert (handle.score_batch(res, res, ext) == 28).all()
+        hsp, ops = handle.align_batch(res, res, ext)
+        fscore, fhsp, foff, fops = handle.extend_batch(res, res, ext, 20)
+        assert (fscore == 28).all() and "single sweep" in handle.last_trace_kernel_name()
+        for k in range(32):
+            assert tuple(int(hsp[k][f]) for f in ("score", "q_begin", "q_end", "s_begin", "s_end")) == (28, 4, 9, 1, 5)
+            assert ops[k] == b"MMIMM"
+            assert tuple(int(fhsp[k][f]) for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops")) == (28, 4, 9, 1, 5, 5)
+            st = int(foff[k]) + int(fhsp[k]["ops_shift"])
+            assert bytes(fops[st: st + 5]) == b"MMIMM"
+    finally:
+        handle.set_scoring(SCHEMES["blosum62"], 0)

@@ -273,3 +273,32 @@ def test_published_known_answers(oracle):
     for raw, bits in ((63, 28.9), (71, 32.0), (112, 47.8)):
         assert round(oracle.bitscore(raw, ka), 1) == bits
         assert round(lib.lx_bitscore(raw, C.byref(cka)), 1) == bits
+
+
+DURBIN_LETTERS = "AEGHPW"
+# BLOSUM50 entries for these letters (Durbin, Eddy, Krogh, Mitchison: Biological Sequence Analysis, 1998, figure 2.2)
+DURBIN_B50 = {("A", "A"): 5, ("A", "E"): -1, ("A", "G"): 0, ("A", "H"): -2, ("A", "P"): -1, ("A", "W"): -3,
+              ("E", "E"): 6, ("E", "G"): -3, ("E", "H"): 0, ("E", "P"): -1, ("E", "W"): -3,
+              ("G", "G"): 8, ("G", "H"): -2, ("G", "P"): -2, ("G", "W"): -3,
+              ("H", "H"): 10, ("H", "P"): -2, ("H", "W"): -3,
+              ("P", "P"): 10, ("P", "W"): -4, ("W", "W"): 15}
+
+
+def durbin_example():
+    """The worked local-alignment example of the same book (figure 2.6): HEAGAWGHEE vs PAWHEAE, BLOSUM50, linear gap
+    cost 8 -- best local alignment AWGHE / AW-HE with score 28."""
+    n = len(DURBIN_LETTERS)
+    m = np.zeros((n, n), dtype=np.int8)
+    for (a, b), v in DURBIN_B50.items():
+        m[DURBIN_LETTERS.index(a), DURBIN_LETTERS.index(b)] = m[DURBIN_LETTERS.index(b), DURBIN_LETTERS.index(a)] = v
+    enc = lambda t: np.array([DURBIN_LETTERS.index(c) for c in t], dtype=np.uint8)
+    return m, enc("HEAGAWGHEE"), enc("PAWHEAE")
+
+
+def test_published_durbin_local_alignment(oracle):
+    m, q, s = durbin_example()
+    sc = oracle_lib.make_scoring(len(DURBIN_LETTERS), m, -8, -8)
+    hsp, ops = oracle.align(q, s, sc)
+    assert hsp.score == 28 and ops == b"MMIMM"  # AWGHE / AW-HE: the gap is in the subject row
+    assert (hsp.q_begin, hsp.q_end, hsp.s_begin, hsp.s_end) == (4, 9, 1, 5)
+    assert int(brute.sw_general(q, s, m.astype(int), -8, -8).max()) == 28
