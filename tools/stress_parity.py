@@ -1,6 +1,6 @@
 """Randomised parity stress of the fused step on host buffers (lx_extend_batch) against the CPU oracle: random query
 lengths (all sweep geometries and the fall-backs), run lengths, schemes, gap costs, mutation rates, truncated / empty
-windows, cut-offs and pass-2 modes.  Development aid: `python tools/stress_parity.py SECONDS [SEED [MAX_QUERY_LENGTH]]` on a GPU box; the
+windows, cut-offs and pass-2 modes.  Development aid: `python tools/stress_parity.py SECONDS [SEED [MAX_QUERY_LENGTH [MIN_QUERY_LENGTH]]]` on a GPU box; the
 committed parity tests are tests/test_gpu_*.py."""
 import sys, time
 from pathlib import Path
@@ -12,6 +12,7 @@ from tests import oracle_lib
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 max_lq = int(sys.argv[3]) if len(sys.argv) > 3 else 215  # beyond 208 columns: multi-panel kernels, direction bits
+min_lq = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 orc = oracle_lib.load()
 h = capi.Handle(0)
 t0 = time.time()
@@ -31,7 +32,7 @@ while time.time() - t0 < budget:
         sc_p, alpha = capi.builtin_scoring(62, gap_open=0, gap_extend=int(rng.integers(-6, -1))), synth.STD20[:int(rng.integers(2, 6))]
     osc = oracle_lib.scoring_from(sc_p)
     h.set_scoring(sc_p, 0)
-    lq = int(rng.integers(20, max_lq))
+    lq = int(rng.integers(min_lq, max_lq))
     wpq = int(rng.choice([5, 8, 16, 24, 32, 40]))
     nq = int(rng.integers(4, 24))
     q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=int(rng.integers(1, 1 << 30)), alphabet=alpha,
@@ -41,6 +42,7 @@ while time.time() - t0 < budget:
     full = ext["s_len"].copy()
     ext["s_len"] = np.where(cut < 0.03, 0, np.where(cut < 0.1, rng.integers(1, 10, len(ext)),
                             np.where(cut < 0.4, (full * rng.uniform(0.3, 1.0, len(ext))).astype(np.uint32), full))).astype(np.uint32)
+    ext["s_len"] = np.minimum(ext["s_len"], full)
     if rng.random() < 0.3:
         ext = ext[rng.permutation(len(ext))]
     want = orc.score_batch(q, s, ext, osc, threads=8)
