@@ -1741,23 +1741,25 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
     uint64_t * const d_count = static_cast<uint64_t *>(h->d_keep.ptr);
     int32_t * const  d_min   = reinterpret_cast<int32_t *>(d_count + 2);
     LX_HIP(h, hipMemcpyAsync(d_min, slot_min.data(), slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    uint64_t const sv_qlen = h->opt_max_qlen, sv_slen = h->opt_max_slen, sv_run = h->opt_query_run;
+    // the promises of the device path hold for the padded list; the caller's option values come back on every exit
+    struct RestoreOptions
+    {
+        lx_handle * h;
+        uint64_t    qlen, slen, run;
+        ~RestoreOptions()
+        {
+            h->opt_max_qlen  = qlen;
+            h->opt_max_slen  = slen;
+            h->opt_query_run = run;
+        }
+    } const restore_options{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run};
     h->opt_max_qlen  = max_q;
     h->opt_max_slen  = max_s;
     h->opt_query_run = kRun;
-    auto restore = [&]()
-    {
-        h->opt_max_qlen  = sv_qlen;
-        h->opt_max_slen  = sv_slen;
-        h->opt_query_run = sv_run;
-    };
     rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, nullptr, nullptr, nullptr, d_count,
                     h->stream, 1, true);
     if (rc)
-    {
-        restore();
         return rc;
-    }
     hm.mark("phase1-issue");
     uint64_t             count[2] = {0, 0};
     std::vector<int32_t> & slot_score = h->xb_score;
@@ -1765,16 +1767,10 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
     if (hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipMemcpyAsync(slot_score.data(), h->d_out.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         (rc = check_async_error(h)))
-    {
-        restore();
         return rc ? rc : fail(h, LX_EHIP, "download after pass 1 failed");
-    }
     hm.mark("phase1-wait");
     if (count[0] > cap_sel)
-    {
-        restore();
         return fail(h, LX_ESTATE, "survivor list longer than its capacity");
-    }
     std::vector<uint32_t> & sel_src = h->xb_sel;
     sel_src.resize(count[0]);
     if (count[0])
@@ -1797,18 +1793,12 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
     {
         if ((rc = ensure(h, h->d_hsp, count[0] * sizeof(lx_hsp))) || (rc = ensure(h, h->d_ops, total + 16)) ||
             (rc = ensure(h, h->d_opsoff, count[0] * sizeof(uint64_t))))
-        {
-            restore();
             return rc;
-        }
         LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, pos_off.data(), count[0] * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
         rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, h->d_hsp.ptr, h->d_ops.ptr,
                         h->d_opsoff.ptr, d_count, h->stream, 2, true);
         if (rc)
-        {
-            restore();
             return rc;
-        }
         hm.mark("phase2-issue");
         LX_HIP(h, hipMemcpyAsync(h->ext_hsp.data(), h->d_hsp.ptr, count[0] * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
         if (total)
@@ -1816,7 +1806,6 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
         rc = check_async_error(h);
         hm.mark("phase2-wait");
     }
-    restore();
     if (rc)
         return rc;
 
