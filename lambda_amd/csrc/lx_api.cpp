@@ -1338,7 +1338,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
     uint64_t ovf_cap = 0;
     int      sweep_share = 0;
-    bool     half_sweep = false;
+    bool     half_sweep = false, may_decline = true;
     int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
     {
@@ -1373,8 +1373,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
                 sweep        = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
                 // (the packed kernel's exactness gate, lx_score_f16.hip: it cannot decline when even the worst query passes)
                 int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) +
-                                      (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) + smax_entry + 2;
-                if (sweep && worst > 2046)
+                                      (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) +
+                                      (smax_entry - h->sc_host[slot].gap_extend) + 2; // (ScoringDev::smax = largest entry - ge)
+                may_decline = worst > 2046;
+                if (sweep && may_decline)
                     ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
             }
             else
@@ -1436,16 +1438,18 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
             p.fixup = 1;
         }
-        LX_HIP(h, lx::launch_ckpt_forward(p, stream));
+        if (!half_sweep || may_decline) // (the packed kernel declines nothing when even the worst query passes its test)
+            LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
         char buf[128];
-        if (half_sweep)
+        int const nameG = lx::trace_cfg_group(sweep_cfg), nameC = lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg);
+        if (half_sweep && may_decline)
             snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
-                     lx::trace_cfg_group(sweep_cfg), lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg),
-                     lx::trace_cfg_group(sweep_cfg), lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
+                     nameG, nameC, nameG, nameC);
+        else if (half_sweep)
+            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep)", nameG, nameC);
         else
-            snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", lx::trace_cfg_group(sweep_cfg),
-                     lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg));
+            snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", nameG, nameC);
         h->last_kernel       = buf;
         h->last_trace_kernel = buf;
     }

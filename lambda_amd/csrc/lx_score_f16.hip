@@ -170,7 +170,14 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
     // (every group summed its own query; one block over the limit sends the whole wavefront to the fix-up launch)
     bool too_big = __ballot((lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046)) != 0;
     if constexpr (CKPT)
-        too_big = too_big || (uint32_t)steps > p.steps_cap; // LX_OPT_MAX_SLEN promise broken: the int32 launch reports it
+    {
+        // LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN promise broken: reported here (the int32 launch, which would report it too, is
+        // skipped when no query the promise admits can fail the exactness test)
+        bool const broken = (__ballot(lq > Geo::kPanel) != 0) || (uint32_t)steps > p.steps_cap;
+        if (broken && lane == 0)
+            atomicExch(p.err, 3);
+        too_big = too_big || broken;
+    }
 
     if (too_big)
     {

@@ -398,8 +398,10 @@ def test_full_size_fused_step_properties(handle, oracle, pass2_mode):
         handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
         handle.synchronize()
         name = handle.last_trace_kernel_name()
-        assert ("ckpt_forward_kernel" in name) == (pass2_mode >= 1) and ("single sweep" in name) == (pass2_mode == 2)
-        assert ("score_pair_kernel<8,19,true>" in name) == (pass2_mode == 2)  # packed-half sweep on the headline shape
+        assert ("ckpt_forward_kernel" in name) == (pass2_mode == 1) and ("single sweep" in name) == (pass2_mode == 2)
+        # packed-half sweep on the headline shape; no 150-column BLOSUM62 query can fail its exactness test, so the int32
+        # fix-up launch is not even issued
+        assert ("score_pair_kernel<8,19,true>" in name) == (pass2_mode == 2)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
