@@ -1473,7 +1473,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     uint64_t const nruns  = (n + run - 1) / run;
     uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
-        (rc = ensure(h, h->d_sel_runs, (nruns + 2 * lx::select_blocks(nruns) + 2) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
+        (rc = ensure(h, h->d_sel_runs, (nruns + 2 * lx::select_blocks(pad_to <= 1 ? n : nruns) + 2) * sizeof(uint64_t))) || (rc = ensure(h, h->d_sel_score, cap * sizeof(int32_t))))
         return rc;
     if (phases & 1)
     {
