@@ -749,13 +749,17 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
                 if (need_col && row >= i - 3 && row < (int)x.s_len)
                 {
+                    // lowest column of this row whose H equals the score (no H exceeds it: H - score <= 0, a multiple of 4
+                    // after the tags are masked), as a maximum of keys without compares: key = (H - score) * 32 + (C - c)
+                    int const tgt4 = 4 * ec.score;
+                    int       kmax = 0;
 #pragma unroll
-                    for (int c = C - 1; c >= 0; --c)
-                        if (Hp[c] == 4 * ec.score && c <= res_col && (c < res_col || row < res_row))
-                        {
-                            res_col = c;
-                            res_row = row;
-                        }
+                    for (int c = 0; c < C; ++c)
+                        kmax = max(kmax, ((Hp[c] - tgt4) << 5) + (C - c));
+                    int const  cmin  = C - kmax;                  // C (none) when no key is positive
+                    bool const lower = kmax > 0 && cmin < res_col; // rows ascend: an equal column keeps its earlier row
+                    res_col          = lower ? cmin : res_col;
+                    res_row          = lower ? row : res_row;
                 }
             }
             qprev = qcur;
