@@ -253,8 +253,13 @@ size_t pair_lds_limit()
 
 int pick_cfg(uint32_t qlen, bool shared)
 {
-    if (char const * e = getenv("LX_FORCE_SCORE_CFG")) // development aid: measure a geometry on a shape it is not picked for
-        return atoi(e);
+    static int const forced = []() // development aid: measure a geometry on a shape it is not picked for
+    {
+        char const * e = getenv("LX_FORCE_SCORE_CFG");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0)
+        return forced;
     if (shared)
     {
         if (qlen <= 64)
