@@ -303,6 +303,19 @@ int pick_cfg(uint32_t qlen, bool shared)
     return best;
 }
 
+// Checkpoint geometry (trace cfg 1 = (8,19), 2 = (16,13)) for a query of max_q columns: one panel if it fits, else the
+// panel count x width x measured time per padded column that is least (int32 kernels: 0.070 vs 0.062 per column).
+int ckpt_cfg_for(uint64_t max_q)
+{
+    uint64_t const p1 = (uint64_t)lx::trace_cfg_panel(1), p2 = (uint64_t)lx::trace_cfg_panel(2);
+    if (max_q <= p1)
+        return 1;
+    if (max_q <= p2)
+        return 2;
+    double const c1 = (double)((max_q + p1 - 1) / p1 * p1) * 0.070, c2 = (double)((max_q + p2 - 1) / p2 * p2) * 0.062;
+    return c1 < c2 ? 1 : 2;
+}
+
 int check_async_error(lx_handle * h)
 {
     uint32_t flags[2] = {0, 0};
@@ -1016,22 +1029,24 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
     // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
     // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
-    // Beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile as well).
+    int smax_entry = 0;
+    for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
+        for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
+            smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+    // checkpoint mode (lx_ckpt.hip): shared-profile geometries (8,19) / (16,13), scores that fit int16; queries wider
+    // than 208 columns take several (16,13) panels
+    bool const ckpt = h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
+    // Direction bits beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile).
     auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
     int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
                     : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
+                    : ckpt                                                             ? ckpt_cfg_for(max_q)
                     : (share_slots >= 4 && padded(2) < padded(0))                      ? 2
                                                                                       : 0;
     int const G = lx::trace_cfg_group(cfg), P = lx::trace_cfg_panel(cfg), W = lx::trace_cfg_words(cfg);
     uint32_t const panels_cap = (uint32_t)std::max<uint64_t>(1, (max_q + P - 1) / P);
     uint32_t const steps_cap  = (uint32_t)((max_s + G - 1 + 15) & ~15ull); // multiple of the trace layout block
-    // checkpoint mode (lx_ckpt.hip): single-panel shared-profile geometries, scores that fit int16
-    int smax_entry = 0;
-    for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
-        for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
-            smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-    bool const ckpt = h->opt_pass2 >= 1 && cfg != 0 && panels_cap == 1 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
-    uint64_t const stride     = ckpt ? lx::ckpt_slot_dwords(cfg, steps_cap) : (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
+    uint64_t const stride     = ckpt ? (uint64_t)panels_cap * lx::ckpt_slot_dwords(cfg, steps_cap) : (uint64_t)panels_cap * steps_cap * G * W; // uint32 entries
     uint64_t const per_ext    = stride * 4;
     // The forward kernel finds the end cell cheaply when it knows each extension's best score; the fused path hands
     // over pass 1's scores, a stand-alone traceback call computes them first (a fraction of the traceback's cost).
@@ -1338,7 +1353,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     // place.  Needs the checkpoints of the whole batch inside the trace budget and a shared-profile geometry.
     bool sweep = false;
     int  sweep_cfg = 0;
-    uint32_t sweep_steps = 0;
+    uint32_t sweep_steps = 0, sweep_panels = 1;
     uint64_t sweep_stride = 0;   // uint32 per slot of the batch
     uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
     uint64_t ovf_cap = 0;
@@ -1347,7 +1362,9 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
     {
-        sweep_cfg = h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(1) ? 1 : h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(2) ? 2 : 0;
+        // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
+        sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen);
+        sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
         int smax_entry = 0;
         for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
             for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
@@ -1356,15 +1373,16 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         {
             int const G    = lx::trace_cfg_group(sweep_cfg);
             sweep_steps    = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
-            sweep_stride32 = lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
             // Packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query per
             // wavefront, or runs of 8 with one query per half wavefront where two LDS profiles fit, i.e. for the small
             // alphabets; (16,13): 8 extensions) and a gap's first character costs at most 31 (the compact checkpoint codes
             // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
-            half_sweep = h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
+            half_sweep = h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
+                         h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
                          ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
-            if (h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
-                sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
+            if (h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
+                h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
                 2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
             {
                 half_sweep  = true;
@@ -1396,7 +1414,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         uint64_t const batch_dw = half_sweep ? (n + 1) * sweep_stride : n * sweep_stride;
         if ((rc = ensure(h, h->d_trace, (batch_dw + ovf_cap * sweep_stride32) * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
             return rc;
-        if ((rc = prepare_workspace(h, stream)))
+        if ((rc = prepare_workspace(h, stream, sweep_panels > 1 ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
             return rc;
         LX_HIP(h, hipMemsetAsync(h->d_ws_top + 4, 0, sizeof(uint32_t), stream));
         lx::TraceParams p{};
@@ -1408,7 +1426,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.trace          = static_cast<uint32_t *>(h->d_trace.ptr);
         p.slot_stride    = sweep_stride;
         p.steps_cap      = sweep_steps;
-        p.panels_cap     = 1;
+        p.panels_cap     = sweep_panels;
+        p.ws             = static_cast<int32_t *>(h->d_ws.ptr);
+        p.ws_top         = h->d_ws_top;
+        p.ws_cap         = (uint32_t)std::min<uint64_t>(h->d_ws.cap / 8, 0xffffffffu);
         p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
         p.score_out      = static_cast<int32_t *>(d_out_score);
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
@@ -1516,7 +1537,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.trace         = static_cast<uint32_t *>(h->d_trace.ptr);
         p.slot_stride   = sweep_stride;
         p.steps_cap     = sweep_steps;
-        p.panels_cap    = 1;
+        p.panels_cap    = sweep_panels;
         p.ends          = static_cast<lx::EndCell *>(h->d_ends.ptr);
         p.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
         p.out_ops       = static_cast<uint8_t *>(d_out_ops);

@@ -83,7 +83,10 @@ __device__ __forceinline__ uint32_t pack16(int lo, int hi)
 // that reaches it.  !KNOWN = single sweep over all extensions: the kernel also IS pass 1 -- every lane keeps the best
 // value of its strip, the first row that reached it and whether a later row reached it again; the group then reports
 // score, strip and row, and the backtrace resolves the column (and, if the strip tied, the row) from the checkpoints.
-template <int G, int C, bool KNOWN>
+// MULTI = queries wider than one panel: the panels of an extension are swept one after the other, each into its own
+// part of the slot ([panel][boundary quads + row checkpoints]); the last strip's (H, E) per row reaches the next
+// panel's first strip through the carry workspace of lx_score.hip / lx_trace.hip.
+template <int G, int C, bool KNOWN, bool MULTI>
 __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
     int const  grp      = lane / G;
     int const  g        = lane % G;
     bool const is_first = (g == 0);
+    bool const is_last  = (g == G - 1);
 
     uint64_t const e     = (uint64_t)blockIdx.x * Geo::kGroups + grp;
     uint64_t       limit = p.n;
@@ -156,20 +160,63 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
             atomicExch(p.err, 2);
     }
 
-    int ls_max = ls;
+    int       ls_max    = ls;
+    int       npanels   = (lq + Geo::kPanel - 1) / Geo::kPanel;
+    int const my_panels = npanels; // of this group's query (uniform over the group)
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
+    {
         ls_max = max(ls_max, __shfl_xor(ls_max, off));
+        if constexpr (MULTI)
+            npanels = max(npanels, __shfl_xor(npanels, off));
+    }
     ls_max = __builtin_amdgcn_readfirstlane(ls_max);
+    if constexpr (MULTI)
+        npanels = max(1, __builtin_amdgcn_readfirstlane(npanels));
+    else
+        npanels = 1; // the host sends wider queries to the MULTI instantiation
 
     bool bad = false;
-    if (active && (lq > Geo::kPanel || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
+    if (active && (lq > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
     {
         bad = true; // the host sized the slots too small for this extension: report, never write out of bounds
         atomicExch(p.err, 3);
     }
     if (bad)
         ls = 0;
+
+    // carry workspace for multi-panel queries: Ls pairs (Hs, Es) per extension (lx_score.hip)
+    int32_t * carry = nullptr;
+    if constexpr (MULTI)
+    {
+        if (npanels > 1)
+        {
+            uint32_t base = 0;
+            int      ok   = 1;
+            if (is_first && my_panels > 1 && active && !bad)
+            {
+                base = atomicAdd(p.ws_top, (uint32_t)ls);
+                if (base + (uint32_t)ls > p.ws_cap)
+                {
+                    ok = 0;
+                    atomicExch(p.err, 1);
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) // broadcast lane g == 0's values through the group
+            {
+                base = max(base, (uint32_t)__shfl_xor((int)base, off));
+                ok   = min(ok, __shfl_xor(ok, off));
+            }
+            if (my_panels > 1 && ok)
+                carry = p.ws + 2ull * base;
+            else if (my_panels > 1)
+            {
+                bad = true; // workspace exhausted: neutralised, reported through p.err
+                ls  = 0;
+            }
+        }
+    }
 
     int const      slot_dw     = (grp / share) * (nrows * Geo::kRowDw);
     uint32_t const row_base_dw = (uint32_t)(slot_dw + g);
@@ -198,18 +245,31 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
             slot    = p.ovf + (uint64_t)(bad ? 0 : idx) * p.ovf_stride;
         }
     }
-    uint4 * const rowck    = reinterpret_cast<uint4 *>(slot + Lay::bnd_dwords(p.steps_cap));
-    bool const    store_ok = active && !bad;
-
     // KNOWN: target score and the best (lowest) column / its first row seen so far in this lane
     int tgt = 0;
     if constexpr (KNOWN)
         tgt = active ? p.score_in[e] : 0;
     int kcol = 0x7fffffff, krow = 0;
+    // !KNOWN, over the panels swept so far: best strip value, its (global) strip, first row, "reached again later"
+    int run_best = 0, run_strip = 0, run_row = 0, run_tie = 0;
+    uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
+
+    for (int panel = 0; panel < npanels; ++panel)
+    {
+    bool const    in_panel = panel < my_panels; // (a wavefront may hold queries with fewer panels than its widest)
+    bool const    store_ok = active && !bad && in_panel;
+    uint32_t * const pslot = slot + (uint64_t)(MULTI ? panel : 0) * panel_dw;
+    uint4 * const rowck    = reinterpret_cast<uint4 *>(pslot + Lay::bnd_dwords(p.steps_cap));
     // !KNOWN: best value of this lane's strip, first row that reached it, "reached again later"
     int lbest = 0, lrow = 0, ltie = 0;
+    bool use_carry_in = false, do_carry_out = false;
+    if constexpr (MULTI)
+    {
+        use_carry_in = is_first && panel > 0 && in_panel && carry != nullptr;
+        do_carry_out = is_last && panel + 1 < my_panels && carry != nullptr;
+    }
 
-    int const col0 = g * C;
+    int const col0 = (MULTI ? panel * Geo::kPanel : 0) + g * C;
     build_profile<G, C>(lds, slot_dw, g, q, lq, col0, sc->mat_adj, nrows, grp % share == 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -232,7 +292,7 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
 
     // boundary words are staged in a lane-private 16-byte LDS slot and leave as one quad every four steps
     uint32_t * const stage = lds + ((Geo::kGroups + share - 1) / share) * (nrows * Geo::kRowDw) + lane * 4;
-    uint4 * const    bnd   = reinterpret_cast<uint4 *>(slot);
+    uint4 * const    bnd   = reinterpret_cast<uint4 *>(pslot);
 
     // one DP step; stores the boundary word of this lane's strip for row k - g
     auto step = [&](int k, uint32_t t)
@@ -244,8 +304,18 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
         for (int d = 0; d < Geo::kD; ++d)
             pw[d] = prow[d * G];
 
-        int const recvH = shift_from_left<G>(sendH, z, is_first);
-        int       Ecur  = shift_from_left<G>(sendE, kNegInf, is_first);
+        // left boundary of this strip for row i: H = 0 (skewed: z), E = -inf; or the previous panel's last column
+        int bndH = z, bndE = kNegInf;
+        if constexpr (MULTI)
+        {
+            if (use_carry_in && (unsigned)i < (unsigned)ls)
+            {
+                bndH = carry[2 * i];
+                bndE = carry[2 * i + 1];
+            }
+        }
+        int const recvH = shift_from_left<G>(sendH, bndH, is_first);
+        int       Ecur  = shift_from_left<G>(sendE, bndE, is_first);
         int       dg    = diag0;
         diag0           = recvH;
 
@@ -297,6 +367,14 @@ __global__ __launch_bounds__(64, (KNOWN ? LX_CKPT_FWD_WAVES : 3)) void ckpt_forw
         }
         sendH = h;
         sendE = Ecur;
+        if constexpr (MULTI)
+        {
+            if (do_carry_out && (unsigned)i < (unsigned)ls)
+            {
+                carry[2 * i]     = sendH;
+                carry[2 * i + 1] = sendE;
+            }
+        }
         // un-skewed boundary pair: H of the strip's last column, E as the next strip's first column will use it
         stage[k & 3] = pack16(h - z, max(Ecur - z, -32768));
         z            = zn;
@@ -357,9 +435,44 @@ LX_CKPT_UNROLL_PRAGMA
             checkpoint(k0 + 3);
     }
 
+    if constexpr (!KNOWN)
+    {
+        // best strip value over the group; among equal ones the lowest strip (its columns come first).  Over the panels:
+        // a later panel only wins with a strictly greater value (its columns come later).
+        int gbest = lbest, gstrip = g, grow = lrow, gtie = ltie;
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1)
+        {
+            int const  ob = __shfl_xor(gbest, off), os = __shfl_xor(gstrip, off), orow = __shfl_xor(grow, off), ot = __shfl_xor(gtie, off);
+            bool const take = ob > gbest || (ob == gbest && os < gstrip);
+            gbest  = take ? ob : gbest;
+            gstrip = take ? os : gstrip;
+            grow   = take ? orow : grow;
+            gtie   = take ? ot : gtie;
+        }
+        bool const take = gbest > run_best;
+        run_best  = take ? gbest : run_best;
+        run_strip = take ? (MULTI ? panel * G : 0) + gstrip : run_strip;
+        run_row   = take ? grow : run_row;
+        run_tie   = take ? gtie : run_tie;
+    }
+    if constexpr (MULTI)
+    {
+        if (npanels > 1)
+        {
+            // make this panel's carry stores visible to the next panel's loads (same wave, other lanes); the LDS profile
+            // is rebuilt next
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    } // panels
+
     if constexpr (KNOWN)
     {
-        // lowest column over the lanes of the group (every lane owns different columns), with its row
+        // lowest column over the lanes of the group (every lane owns different columns in every panel), with its row
 #pragma unroll
         for (int off = 1; off < G; off <<= 1)
         {
@@ -384,18 +497,7 @@ LX_CKPT_UNROLL_PRAGMA
     }
     else
     {
-        // best strip value over the group; among equal ones the lowest strip (its columns come first)
-        int gbest = lbest, gstrip = g, grow = lrow, gtie = ltie;
-#pragma unroll
-        for (int off = 1; off < G; off <<= 1)
-        {
-            int const  ob = __shfl_xor(gbest, off), os = __shfl_xor(gstrip, off), orow = __shfl_xor(grow, off), ot = __shfl_xor(gtie, off);
-            bool const take = ob > gbest || (ob == gbest && os < gstrip);
-            gbest  = take ? ob : gbest;
-            gstrip = take ? os : gstrip;
-            grow   = take ? orow : grow;
-            gtie   = take ? ot : gtie;
-        }
+        int const gbest = run_best, gstrip = run_strip, grow = run_row, gtie = run_tie;
         if (in_list && is_first)
         {
             EndCell ec{};
@@ -474,21 +576,27 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         uint32_t const H = code16 & 0x7ffu;
         return H | ((H - (code16 >> 11)) << 16);
     };
-    uint32_t const * slot  = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
-    uint4 const *    bnd   = reinterpret_cast<uint4 const *>(slot);
-    uint4 const *    rowck = reinterpret_cast<uint4 const *>(slot + (c16 ? L16::bnd_dwords(p.steps_cap) : Lay::bnd_dwords(p.steps_cap)));
+    uint32_t const * slot = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
+    // A query wider than one panel has one part per panel in its slot (int16 pairs only): global strip st = panel * G +
+    // lane; a strip's step for row r is r + lane.
+    uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
+    auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (c16 ? 0 : (uint64_t)pn * panel_dw)); };
+    auto rowck_of = [&](uint32_t pn)
+    {
+        return reinterpret_cast<uint4 const *>(slot + (c16 ? L16::bnd_dwords(p.steps_cap) : (uint64_t)pn * panel_dw + Lay::bnd_dwords(p.steps_cap)));
+    };
     // word (H, F) of column c of strip st's row checkpoint m; word (H, E) of strip st's boundary at step k
     auto rowck_word = [&](uint32_t m, uint32_t st, uint32_t c) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(rowck + L16::rowck_quad_index(m, st, 0))[c]);
-        return reinterpret_cast<uint32_t const *>(rowck + rowck_quad_index<G, Lay::kCkDw>(m, st, c / 4))[c % 4];
+            return expand(reinterpret_cast<uint16_t const *>(rowck_of(0) + L16::rowck_quad_index(m, st, 0))[c]);
+        return reinterpret_cast<uint32_t const *>(rowck_of(st / G) + rowck_quad_index<G, Lay::kCkDw>(m, st % G, c / 4))[c % 4];
     };
     auto bnd_word_of = [&](uint32_t st, uint32_t k) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(bnd + L16::bnd_oct_index(k / 8, st))[k & 7]);
-        return slot[bnd_quad_index<G>(k / 4, st) * 4 + (k & 3)];
+            return expand(reinterpret_cast<uint16_t const *>(bnd_of(0) + L16::bnd_oct_index(k / 8, st))[k & 7]);
+        return reinterpret_cast<uint32_t const *>(bnd_of(st / G) + bnd_quad_index<G>(k / 4, st % G))[k & 3];
     };
     uint8_t const *  q     = p.q_res + x.q_off;
     uint8_t const *  s     = p.s_res + x.s_off;
@@ -510,7 +618,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         if (ec.flags & kEndAmbiguous)
         {
             int const go1 = p.sc->go;
-            int const m0  = (i + st) / kCkptEvery;
+            int const gl  = st % G, gL = (st - 1 + G) % G; // lanes of this strip and of its left neighbour
+            int const m0  = (i + gl) / kCkptEvery;
             int       Hp[C], F[C];
             if (m0 == 0)
             {
@@ -536,15 +645,15 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             { return bnd_word_of((uint32_t)(st - 1), (uint32_t)k); };
             int const target = ec.score;
             int       kcol = C, krow = i;
-            for (int r = max(m0 * kCkptEvery - st, 0); r < (int)x.s_len; ++r)
+            for (int r = max(m0 * kCkptEvery - gl, 0); r < (int)x.s_len; ++r)
             {
                 int const tl = s[r] & (kAlph - 1);
                 int       E  = kFar, Hd = 0;
                 if (st > 0)
                 {
-                    E = dec(bnd_word(r + st - 1) >> 16);
+                    E = dec(bnd_word(r + gL) >> 16);
                     if (r > 0)
-                        Hd = dec(bnd_word(r + st - 2) & 0xffffu);
+                        Hd = dec(bnd_word(r + gL - 1) & 0xffffu);
                 }
 #pragma unroll
                 for (int c = 0; c < C; ++c)
@@ -605,9 +714,11 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     {
         // ---- the tile of the current cell: strip st, step block m (step k = row + strip)
         int const st = j / C, j0 = st * C;
-        int const m  = (i + st) / kCkptEvery;
+        int const pn = st / G, gl = st % G; // panel and lane of this strip (one panel: gl = st)
+        int const m  = (i + gl) / kCkptEvery;
         int const k_base = m * kCkptEvery;  // first step of the block
-        int const r_base = k_base - st;     // row of tile row 0 (may be negative in block 0: virtual rows)
+        int const r_base = k_base - gl;     // row of tile row 0 (may be negative in block 0: virtual rows)
+        uint4 const * const rowck = rowck_of((uint32_t)pn);
 
         // top edge: H(r_base - 1, c) and the folded F(r_base, c)
         int Hp[C], F[C];
@@ -628,7 +739,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xq = 0; xq < L16::kCkDw / 4; ++xq)
                 {
-                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
+                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)]; // (one panel)
                     uint32_t const d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -646,7 +757,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xq = 0; xq < Lay::kCkDw / 4; ++xq)
                 {
-                    uint4 const v = rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)];
+                    uint4 const v = rowck[rowck_quad_index<G, Lay::kCkDw>((uint32_t)(m - 1), (uint32_t)gl, (uint32_t)xq)];
                     w[4 * xq] = v.x; w[4 * xq + 1] = v.y; w[4 * xq + 2] = v.z; w[4 * xq + 3] = v.w;
                 }
             }
@@ -673,18 +784,24 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         }
         // left edge: the boundary words of strip st - 1 for the steps k_base - 2 ... (word of step k - 1 holds E for
         // this strip's row k - st, the word of step k - 2 the diagonal H); quads are indexed by step / 4
+        // The left neighbour is the previous lane of this panel -- its step for a row is this strip's step - 1 -- or, for
+        // the first strip of a later panel, the last lane of the previous panel: step + G - 1, i.e. G / 4 quads further on
+        // with the same word positions.
         bool const has_left = st > 0;
-        auto load_bq = [&](int qd) -> uint4 // quad of steps 4 qd .. 4 qd + 3 of strip st - 1
+        int const  gL       = gl > 0 ? gl - 1 : G - 1;
+        int const  qshift   = (gl == 0 && has_left) ? G / 4 : 0;
+        uint4 const * const bndL = bnd_of((uint32_t)(gl > 0 ? pn : max(pn - 1, 0)));
+        auto load_bq = [&](int qd) -> uint4 // quad of steps 4 qd .. 4 qd + 3 (this strip's count) of the left neighbour
         {
-            if (!has_left || qd < 0)
+            if (!has_left || qd + qshift < 0)
                 return make_uint4(0, 0, 0, 0);
             if (c16)
             {
                 // half of the 16-byte group of eight steps
-                uint2 const v = reinterpret_cast<uint2 const *>(bnd + L16::bnd_oct_index((uint32_t)qd / 2, (uint32_t)(st - 1)))[qd & 1];
+                uint2 const v = reinterpret_cast<uint2 const *>(bndL + L16::bnd_oct_index((uint32_t)qd / 2, (uint32_t)gL))[qd & 1];
                 return make_uint4(expand(v.x & 0xffffu), expand(v.x >> 16), expand(v.y & 0xffffu), expand(v.y >> 16));
             }
-            return bnd[bnd_quad_index<G>((uint32_t)qd, (uint32_t)(st - 1))];
+            return bndL[bnd_quad_index<G>((uint32_t)(qd + qshift), (uint32_t)gL)];
         };
         int const qd0   = k_base / 4; // quad that holds step k_base
         uint4     qprev = load_bq(qd0 - 1), qcur = load_bq(qd0);
@@ -878,10 +995,15 @@ static hipError_t launch_ckpt_forward_cfg(TraceParams const & p, hipStream_t str
     int const    share = p.shared_profile > 1 ? std::min(p.shared_profile, Geo::kGroups) : 1;
     int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + 64 * 4) * sizeof(uint32_t);
-    if (p.score_in)
-        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    bool const multi = p.panels_cap > 1;
+    if (p.score_in && multi)
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else if (p.score_in)
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, true, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else if (multi)
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, false, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
-        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        hipLaunchKernelGGL((ckpt_forward_kernel<G, C, false, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 
