@@ -236,16 +236,17 @@ def test_iterate_matches_driver(handle, oracle, filters):
 
 
 @pytest.mark.parametrize("pass2_mode", [1, 0, 2])
-@pytest.mark.parametrize("wpq,run,lq", [(32, 32, 150), (8, 8, 150), (7, 0, 150), (32, 32, 200), (16, 16, 100)])
+@pytest.mark.parametrize("wpq,run,lq", [(32, 32, 150), (8, 8, 150), (7, 0, 150), (32, 32, 200), (16, 16, 100), (16, 16, 300), (8, 8, 450)])
 def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
     """lx_extend_batch_dev: pass 1 -> integer cut-off -> compaction (runs padded to whole wavefronts) -> pass 2.
-    lq = 200 is the shape of BASELINE.json configs[3] (200 aa queries, 230 aa windows: the (16,13) geometries)."""
+    lq = 200 is the shape of BASELINE.json configs[3] (200 aa queries, 230 aa windows: the (16,13) geometries); 300 and 450
+    columns take two (8,19) / three (16,13) panels: checkpoints carried across panels in modes 1 and 2."""
     import torch
 
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
     osc = oracle_lib.scoring_from(sc_p)
-    q, s, ext = synth.make_batch_np(90, lq, wpq, seed=1234 + wpq + lq)
+    q, s, ext = synth.make_batch_np(90 if lq <= 208 else 24, lq, wpq, seed=1234 + wpq + lq)
     n = len(ext)
     dev = torch.device("cuda:0")
     pad = np.zeros(256, np.uint8)
