@@ -4,7 +4,7 @@
 
 Inputs (made on the GPU box):
     <dir>/stats/bench_kernel_stats.csv          rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...
-    <dir>/pmc_sq|pmc_fetch|pmc_write/pmc_counter_collection.csv   three separate --pmc passes
+    <dir>/pmc_sq|pmc_sq_wait|pmc_fetch|pmc_write/pmc_counter_collection.csv   separate --pmc passes
     <dir>/bench.log, bench_pass1.log, stats.log  the bench JSON lines of the plain / pass-1-only / profiled runs
 """
 import collections
@@ -27,7 +27,9 @@ with open(out / f"{tag}_bench_kernel_stats.csv", "w", newline="") as f:
 
 steps_profiled = 3  # --steps 2 --warmup 1
 kern = {}
-for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for name in ("pmc_sq", "pmc_sq_wait", "pmc_fetch", "pmc_write"):
+    if not (src / name / "pmc_counter_collection.csv").exists():
+        continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     meta, launches = {}, collections.defaultdict(set)
     for r in csv.DictReader(open(src / name / "pmc_counter_collection.csv")):
@@ -44,10 +46,11 @@ for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
             d["counters_per_launch_mean"][c] = x / len(launches[k])
 json.dump({
     "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-               "(three separate passes: SQ_*, FETCH_SIZE, WRITE_SIZE)",
+               "(separate passes: SQ_* instruction counts, SQ_* wave-cycle breakdown, FETCH_SIZE, WRITE_SIZE)",
     "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads 1/2 of the bytes of wide coalesced reads "
             "(MI355X_MICROARCH.md, HBM) -> doubled before use.  The score kernels are launched once per step, the trace "
-            "kernels once per chunk, so per-step means are the comparable figures.",
+            "kernels once per chunk, so per-step means are the comparable figures.  SQ_WAVE_CYCLES ~ SQ_WAIT_ANY (parked on "
+            "s_waitcnt) + SQ_WAIT_INST_ANY (issue stall) + SQ_ACTIVE_INST_ANY, in quad-cycles summed over wavefronts.",
     "kernels": kern}, open(out / f"{tag}_bench_pmc.json", "w"), indent=1)
 
 for log, dst in (("bench.log", f"{tag}_bench_line.json"), ("bench_pass1.log", f"{tag}_bench_line_pass1_only.json"),

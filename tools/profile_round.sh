@@ -4,6 +4,7 @@ D=gpurun_out/r1c; mkdir -p $D; R=$PWD
 cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $R/$D/stats.log 2>&1
 (timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/$D/pmc_sq -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq.log 2>&1
+(timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $R/$D/pmc_sq_wait -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq_wait.log 2>&1
 (timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$D/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_fetch.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_write.log 2>&1
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -30
