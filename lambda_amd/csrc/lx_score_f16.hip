@@ -262,8 +262,6 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
     // CKPT: first row that reached this strip's best value, "a later row reached it again" (bit 0 = A, bit 1 = B)
     int      rowA = 0, rowB = 0;
     uint32_t tie  = 0;
-    int      krow = -g; // row of the step being processed
-    int      krow_slot = 0; // step % 8
     h2 const C24 = as_h2(kHalfTwoPowMinus24x2), NC24 = -C24, GEc = GE * C24;
     h2       nZc = -(Z * C24); // -Z 2^-24, kept in step with Z
     h2       cmax = as_h2(kHalfNegInf2); // best un-skewed row maximum of the current chunk
@@ -274,7 +272,8 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
     // staging of the boundary codes: [step % 8][lane] -- lane-minor, free of bank conflicts
     uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane;
 
-    auto step = [&](uint32_t tA, uint32_t tB)
+    // (slot8 = step % 8: where the step's boundary codes are staged)
+    auto step = [&](uint32_t tA, uint32_t tB, int slot8)
     {
         uint4 const * ra = reinterpret_cast<uint4 const *>(reinterpret_cast<char const *>(lds) + row_base + tA * kRowBytes);
         uint4 const * rb = reinterpret_cast<uint4 const *>(reinterpret_cast<char const *>(lds) + row_base + tB * kRowBytes);
@@ -332,10 +331,8 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
             // Ckpt16Layout codes of both extensions, staged for one 16-byte store per extension every eight steps
             h2 const hc           = h * C24;
-            stage[krow_slot * 64] = c16_pack(hc + nZc, __builtin_elementwise_fma(Ecur, NC24, hc));
+            stage[slot8 * 64]     = c16_pack(hc + nZc, __builtin_elementwise_fma(Ecur, NC24, hc));
             nZc                   = nZc + GEc; // Z grows by -ge per step
-            krow_slot             = (krow_slot + 1) & 7;
-            ++krow;
         }
         else
             best = hmax(best, cand);
@@ -371,8 +368,9 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
                 uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
                 bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
                 bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
-                rowA = gtA ? krow - 1 : rowA; // krow - 1 = the chunk's last row
-                rowB = gtB ? krow - 1 : rowB;
+                int const last = k0 + 3 - g; // the chunk's last row in this lane
+                rowA = gtA ? last : rowA;
+                rowB = gtB ? last : rowB;
                 tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
                 tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
                 best = nb;
@@ -458,7 +456,7 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
             fetch_checked(k0 + 4, na, nb);
 #pragma unroll 1
             for (int u = 0; u < 4; ++u)
-                step(ca[u], cb[u]);
+                step(ca[u], cb[u], (k0 & 4) + u);
             chunk_done(k0);
             k0 += 4;
         }
@@ -476,7 +474,7 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
                 wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
 LX_UNROLL(LX_F16_UNROLL)
                 for (int u = 0; u < 4; ++u)
-                    step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1));
+                    step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), (k0 & 4) + u);
                 chunk_done(k0);
                 k0 += 4;
             }
