@@ -47,6 +47,7 @@ uint64_t   ckpt_slot_dwords(int cfg, uint32_t steps_cap);
 uint64_t   ckpt16_slot_dwords(int cfg, uint32_t steps_cap);
 hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
+hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
@@ -615,7 +616,8 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
             _Float16 const hv = (_Float16)(float)v; // integers of magnitude <= 128: exact
             uint16_t       bits;
             std::memcpy(&bits, &hv, 2);
-            d.mat_h[a * lx::kAlph + b] = bits;
+            d.mat_h[a * lx::kAlph + b]   = bits;
+            d.mat_i16[a * lx::kAlph + b] = (int16_t)v;
             if (!pad)
             {
                 rm     = std::max(rm, (int)sc->matrix[a * LX_ALPH + b]);
@@ -1464,16 +1466,48 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
             p.fixup = 1;
         }
-        if (!half_sweep || may_decline) // (the packed kernel declines nothing when even the worst query passes its test)
+        // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16
+        // kernel writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range
+        // test is left to the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
+        bool const i16_sweep = !half_sweep && h->opt_f16 && !getenv("LX_NO_I16_SWEEP") &&
+                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0;
+        if (i16_sweep)
+        {
+            lx::ScoreParams sp1{};
+            sp1.q_res       = p.q_res;
+            sp1.s_res       = p.s_res;
+            sp1.ext         = p.ext;
+            sp1.n           = n;
+            sp1.sc          = p.sc;
+            sp1.out_score   = static_cast<int32_t *>(d_out_score);
+            sp1.ws          = p.ws;
+            sp1.ws_top      = p.ws_top;
+            sp1.ws_cap      = p.ws_cap;
+            sp1.err         = p.err;
+            sp1.nrows       = p.nrows;
+            sp1.ckpt        = p.trace;
+            sp1.ckpt_stride = sweep_stride;
+            sp1.steps_cap   = sweep_steps;
+            sp1.ends        = p.ends;
+            sp1.panels_cap  = sweep_panels;
+            LX_HIP(h, lx::launch_sweep_pair16(sweep_cfg, sp1, stream));
+            if (sweep_panels > 1) // the fix-up launch starts with an empty carry workspace
+                LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
+            p.fixup = 1;
+        }
+        if (!half_sweep || may_decline) // (the packed-half kernel declines nothing when even the worst query passes its test)
             LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
-        char buf[128];
+        char buf[160];
         int const nameG = lx::trace_cfg_group(sweep_cfg), nameC = lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg);
         if (half_sweep && may_decline)
             snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
                      nameG, nameC, nameG, nameC);
         else if (half_sweep)
             snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep)", nameG, nameC);
+        else if (i16_sweep)
+            snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<%d,%d,%s> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
+                     nameG, nameC, sweep_panels > 1 ? "true" : "false", nameG, nameC);
         else
             snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", nameG, nameC);
         h->last_kernel       = buf;

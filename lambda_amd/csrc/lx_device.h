@@ -28,6 +28,7 @@ struct ScoringDev
     int32_t  reserved[2];
     int16_t  rowmax[kAlph];
     uint16_t mat_h[kAlph * kAlph];
+    int16_t  mat_i16[kAlph * kAlph]; // packed-int16 sweep (lx_score_i16.hip): matrix - ge, pad ranks = kNegPad
 };
 
 // Mirrors lx_extension in include/lambda_ext.h (static_assert'ed in lx_api.cpp).
@@ -74,6 +75,7 @@ struct ScoreParams
     uint64_t           ckpt_stride;
     uint32_t           steps_cap;
     struct EndCell *   ends;        // [n]
+    uint32_t           panels_cap;  // packed-int16 sweep: bound on ceil(Lq / panel); the slot holds that many parts
 };
 
 // best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel
