@@ -305,15 +305,26 @@ int pick_cfg(uint32_t qlen, bool shared)
 }
 
 // Checkpoint geometry (trace cfg 1 = (8,19), 2 = (16,13)) for a query of max_q columns: one panel if it fits, else the
-// panel count x width x measured time per padded column that is least (int32 kernels: 0.070 vs 0.062 per column).
-int ckpt_cfg_for(uint64_t max_q)
+// panel count x width x measured time per padded column that is least (int32 kernels: 0.070 vs 0.062 per column;
+// packed16 = the sweep of lx_score_i16.hip will run).
+int ckpt_cfg_for(uint64_t max_q, bool packed16 = false)
 {
     uint64_t const p1 = (uint64_t)lx::trace_cfg_panel(1), p2 = (uint64_t)lx::trace_cfg_panel(2);
     if (max_q <= p1)
         return 1;
     if (max_q <= p2)
         return 2;
-    double const c1 = (double)((max_q + p1 - 1) / p1 * p1) * 0.070, c2 = (double)((max_q + p2 - 1) / p2 * p2) * 0.062;
+    static int const forced = []() // development aid
+    {
+        char const * e = getenv("LX_FORCE_CKPT_CFG");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2)
+        return forced;
+    // (the packed 16-bit sweep is bound by its checkpoint bytes: the 19-column strips of (8,19) store fewer boundary
+    // columns -- 400 aa: 0.0134 ms per padded column against 0.0156 for (16,13))
+    double const f1 = packed16 ? 0.0134 : 0.070, f2 = packed16 ? 0.0156 : 0.062;
+    double const c1 = (double)((max_q + p1 - 1) / p1 * p1) * f1, c2 = (double)((max_q + p2 - 1) / p2 * p2) * f2;
     return c1 < c2 ? 1 : 2;
 }
 
@@ -1365,7 +1376,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
     {
         // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
-        sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen);
+        sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen, h->opt_f16 && h->opt_query_run % 16 == 0);
         sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
         int smax_entry = 0;
         for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
