@@ -810,3 +810,59 @@ def test_published_durbin_local_alignment(handle):
             assert bytes(fops[st: st + 5]) == b"MMIMM"
     finally:
         handle.set_scoring(SCHEMES["blosum62"], 0)
+
+
+def test_full_size_host_entry_point_equals_device_path(handle):
+    """BASELINE.json configs[1] at a quarter of its size through lx_extend_batch (host buffers, resident subjects) and
+    through lx_extend_batch_dev: scores, records and op strings of every survivor are identical; the host call's ops
+    buffer holds exactly the survivors' slots."""
+    import torch
+
+    dev = torch.device("cuda:0")
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    nq, lq, wpq, cutoff = 25_000, 150, 32, 91
+    q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=0x1A3BDA02)
+    n = len(ext)
+    pad = np.zeros(256, np.uint8)
+    d_q, d_s = torch.from_numpy(np.concatenate([q, pad])).to(dev), torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    handle.set_option(capi.LX_OPT_MAX_QLEN, lq)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, int(ext["s_len"].max()))
+    handle.set_option(capi.LX_OPT_QUERY_RUN, wpq)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    try:
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+    dev_score = d_score.cpu().numpy()
+    dev_hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+    dev_ops = d_ops.cpu().numpy()
+    handle.set_subjects(s)
+    try:
+        score, hsp, hoff, ops = handle.extend_batch(q, None, ext, cutoff, copy_ops=False)
+        assert (score == dev_score).all()
+        surv = np.nonzero(dev_score >= cutoff)[0]
+        assert len(surv) > n // 3 and int(d_count.cpu()[1]) == len(surv)
+        for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops", "num_matches", "num_mismatches", "num_positives",
+                  "num_gap_opens", "num_gap_extensions"):
+            assert (hsp[f] == dev_hsp[f]).all(), f
+        assert len(ops) == int(sizes[surv].sum())
+        rng = np.random.default_rng(5)
+        for i in rng.choice(surv, 20_000, replace=False):
+            a = int(hoff[i]) + int(hsp[i]["ops_shift"])
+            b = int(off[i]) + int(dev_hsp[i]["ops_shift"])
+            k = int(hsp[i]["n_ops"])
+            assert bytes(ops[a: a + k]) == bytes(dev_ops[b: b + k]), i
+    finally:
+        handle.set_subjects(None)
