@@ -48,6 +48,7 @@ uint64_t   ckpt16_slot_dwords(int cfg, uint32_t steps_cap);
 hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t stream);
+hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
@@ -349,6 +350,8 @@ int check_async_error(lx_handle * h)
 
 // One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
 // (or need the multi-panel path when wider).
+constexpr int kPair16 = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
+
 int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n,
                       void * d_out, int cfg, bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0)
 {
@@ -368,7 +371,18 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     p.fixup          = 0;
     p.pair_share     = pair_share;
     char buf[128];
-    if (pair_cfg >= 0)
+    if (pair_cfg == kPair16)
+    {
+        // queries wider than the packed-half geometries: packed 16-bit integers (lx_score_i16.hip), panel by panel; what
+        // fails its range test is left to the int32 kernel, which starts with an empty carry workspace
+        LX_HIP(h, lx::launch_score_pair16(p, stream));
+        LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
+        p.fixup = 1;
+        LX_HIP(h, lx::launch_score(cfg, p, multi, stream));
+        snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<8,19,true,false> (+ int32 fix-up lx::score_kernel<%d,%d,%s>)",
+                 64 / lx::score_cfg_groups(cfg), lx::score_cfg_panel(cfg) * lx::score_cfg_groups(cfg) / 64, multi ? "true" : "false");
+    }
+    else if (pair_cfg >= 0)
     {
         // packed-half kernel first (two extensions per lane group); wavefronts whose score bound does not fit half
         // precision leave the sentinel -1, which the int32 kernel then resolves in fix-up mode
@@ -725,7 +739,9 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     bool const want_shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
     int const  cfg    = h->opt_max_qlen ? pick_cfg((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu), want_shared) : 0;
     bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
-    if ((rc = prepare_workspace(h, stream, multi ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
+    // (the packed 16-bit kernel sweeps wide queries in (8,19) panels even where the int32 geometry is a single one)
+    bool const wide16 = h->opt_f16 && h->opt_query_run % 16 == 0 && h->opt_query_run != 0 && h->opt_max_qlen > (uint64_t)lx::trace_cfg_panel(2);
+    if ((rc = prepare_workspace(h, stream, (multi || wide16) ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
         return rc;
     bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
     if (!h->in_fused)
@@ -755,6 +771,8 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
             else if (h->opt_query_run % 8 == 0) // two profiles do not fit: a 16-lane geometry holds 8 extensions per wavefront
                 pair_cfg = lx::score_pair_cfg_for_runs_of_8((uint32_t)std::min<uint64_t>(h->opt_max_qlen, 0xffffffffu));
         }
+        else if (h->opt_query_run % 16 == 0 && h->opt_max_slen != 0) // wider than any packed-half geometry
+            pair_cfg = kPair16;
     }
     PhaseTimer pt(h, stream, 0);
     if ((rc = launch_score_list(h, slot, d_q_res, d_s_res, d_ext, n, d_out_score, cfg, multi, shared, stream, pair_cfg, pair_share)))

@@ -69,7 +69,8 @@ struct Pair16Geo
     }
 };
 
-template <int G, int C, bool MULTI>
+// CKPT = false: score only (pass 1 of queries wider than the packed-half geometries): no slots, no end cells.
+template <int G, int C, bool MULTI, bool CKPT = true>
 __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 {
     static_assert(C <= 24, "profile rows hold 24 entries per lane");
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1)
         bound += __shfl_xor(bound, off);
-    bool const broken  = (__ballot(lq > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) != 0) || (uint32_t)steps > p.steps_cap;
+    bool const broken  = CKPT && ((__ballot(lq > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) != 0) || (uint32_t)steps > p.steps_cap);
     // (upper end: no value reaches the non-finite patterns; lower end: pad scores and the skew of the first rows stay above 0)
     bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > kI16Limit) != 0 ||
                          (-ge) * (G + 2) + (-sc->g2) + 256 > kBias;
@@ -169,12 +170,14 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
             if (actA)
             {
                 p.out_score[eA] = -1;
-                p.ends[eA]      = none;
+                if constexpr (CKPT)
+                    p.ends[eA] = none;
             }
             if (actB)
             {
                 p.out_score[eB] = -1;
-                p.ends[eB]      = none;
+                if constexpr (CKPT)
+                    p.ends[eB] = none;
             }
         }
         return;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
     uint32_t const     row_base  = (uint32_t)(g * Geo::kLaneDw) * 4u;
-    uint64_t const     panel_dw  = Geo::slot_dwords(p.steps_cap);
+    uint64_t const     panel_dw  = CKPT ? Geo::slot_dwords(p.steps_cap) : 0;
     uint32_t * const   stage     = lds + nrows * Geo::kRowDw + lane; // [extension A / B][step % 4][lane]
 
     s2 const GE = ssplat(ge), G2 = ssplat(sc->g2), NGE = ssplat(-ge);
@@ -266,9 +269,9 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 
         bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
         bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
-        uint32_t * const slotA = p.ckpt + eA * p.ckpt_stride + (uint64_t)panel * panel_dw;
-        uint32_t * const slotB = p.ckpt + eB * p.ckpt_stride + (uint64_t)panel * panel_dw;
-        bool const       stA = actA && writable, stB = actB && writable;
+        uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride + (uint64_t)panel * panel_dw : nullptr;
+        uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride + (uint64_t)panel * panel_dw : nullptr;
+        bool const       stA = CKPT && actA && writable, stB = CKPT && actB && writable;
 
         s2 Z = ssplat(ge * g + kBias); // z_i of the first processed row i = -g, biased
         s2 Hrow[C], F0[C];
@@ -355,17 +358,24 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                     carry[2 * i + 1] = as_u32(sendE);
                 }
             }
-            cmax = smax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
-            // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
-            // re-paired per extension and staged for one 16-byte store per four steps
-            s2 const hb = h - Z, eb = Ecur - Z;
-            stage[u * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
-            stage[(4 + u) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+            if constexpr (CKPT)
+            {
+                cmax = smax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
+                // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
+                // re-paired per extension and staged for one 16-byte store per four steps
+                s2 const hb = h - Z, eb = Ecur - Z;
+                stage[u * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
+                stage[(4 + u) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+            }
+            else
+                best = smax(best, rowmax - Z);
             Z = ZN;
         };
         // after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
         auto chunk_done = [&](int k0)
         {
+            if constexpr (!CKPT)
+                return;
             // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
             // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and columns
             // beyond the query stay strictly below a positive best: no validity test.
@@ -504,8 +514,16 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
             rrow   = take ? grow : rrow;
             rtie   = take ? gtie : rtie;
         };
-        merge((int)best.x, rowA, (int)(tie & 1u), runA, stripA, rrowA, rtieA);
-        merge((int)best.y, rowB, (int)((tie >> 1) & 1u), runB, stripB, rrowB, rtieB);
+        if constexpr (CKPT)
+        {
+            merge((int)best.x, rowA, (int)(tie & 1u), runA, stripA, rrowA, rtieA);
+            merge((int)best.y, rowB, (int)((tie >> 1) & 1u), runB, stripB, rrowB, rtieB);
+        }
+        else
+        {
+            runA = max(runA, (int)best.x); // per lane; reduced over the group once all panels are through
+            runB = max(runB, (int)best.y);
+        }
 
         if constexpr (MULTI)
         {
@@ -538,8 +556,24 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
             p.out_score[e] = writable ? run : -1;
         }
     };
-    finish(runA, stripA, rrowA, rtieA, actA, eA);
-    finish(runB, stripB, rrowB, rtieB, actB, eB);
+    if constexpr (CKPT)
+    {
+        finish(runA, stripA, rrowA, rtieA, actA, eA);
+        finish(runB, stripB, rrowB, rtieB, actB, eB);
+    }
+    else
+    {
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1)
+        {
+            runA = max(runA, __shfl_xor(runA, off));
+            runB = max(runB, __shfl_xor(runB, off));
+        }
+        if (is_first && actA)
+            p.out_score[eA] = writable ? runA : -1;
+        if (is_first && actB)
+            p.out_score[eB] = writable ? runB : -1;
+    }
 }
 
 template <int G, int C>
@@ -555,6 +589,21 @@ static hipError_t launch_sweep16_cfg(ScoreParams const & p, hipStream_t stream)
         hipLaunchKernelGGL((sweep_pair16_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((sweep_pair16_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+// score only, any query width, (8,19) panels: 16 extensions of one query per wavefront
+hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    using Geo = Pair16Geo<8, 19>;
+    uint64_t const per_wave = 2ull * Geo::kGroups;
+    uint64_t const blocks   = (p.n + per_wave - 1) / per_wave;
+    if (blocks > 0x7fffffffull)
+        return hipErrorInvalidValue;
+    size_t const lds = ((size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+    hipLaunchKernelGGL((sweep_pair16_kernel<8, 19, true, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
 }
 

@@ -151,7 +151,7 @@ def test_linearity_property_full_size_rows(handle):
     assert (got == M[qq, qq].sum(axis=1)).all()
 
 
-def _dev_scores(handle, q, s, ext, max_qlen, run, packed):
+def _dev_scores(handle, q, s, ext, max_qlen, run, packed, max_slen=0):
     import torch
 
     dev = torch.device("cuda:0")
@@ -164,6 +164,7 @@ def _dev_scores(handle, q, s, ext, max_qlen, run, packed):
     handle.set_option(capi.LX_OPT_MAX_QLEN, max_qlen)
     handle.set_option(capi.LX_OPT_QUERY_RUN, run)
     handle.set_option(capi.LX_OPT_PACKED_HALF, packed)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, max_slen)
     try:
         handle.score_batch_dev(d_q, d_s, d_ext, len(ext), d_out)
         handle.synchronize()
@@ -172,6 +173,7 @@ def _dev_scores(handle, q, s, ext, max_qlen, run, packed):
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
         handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
         handle.set_option(capi.LX_OPT_PACKED_HALF, 1)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
     return d_out.cpu().numpy(), name
 
 
@@ -281,3 +283,28 @@ def test_full_size_batch_properties(handle):
     sc = outs[1].view(nq, wpq)
     assert bool((sc[:, 0] == selfscore).all())
     assert bool((sc >= 0).all()) and bool((sc <= selfscore[:, None]).all())
+
+
+@pytest.mark.parametrize("name,lq,wpq", [("blosum62", 230, 16), ("blosum62", 450, 16), ("blosum62", 777, 32), ("nucl", 600, 16)])
+def test_packed_16bit_integer_kernel_wide_queries(handle, oracle, name, lq, wpq):
+    """Queries wider than every packed-half geometry: the packed 16-bit integer kernel (integer adds, maxima through the
+    half-precision comparators on biased values) sweeps them in (8,19) panels; scores equal the oracle's and the int32
+    kernel's, ragged windows and empty ones included."""
+    alpha = synth.STD20 if name == "blosum62" else np.arange(4, dtype=np.uint8)
+    sc_p = SCHEMES[name]
+    handle.set_scoring(sc_p, 0)
+    try:
+        q, s, ext = synth.make_batch_np(9, lq, wpq, seed=lq + wpq, alphabet=alpha, sub_rate=0.2 if name == "blosum62" else 0.05, indel_rate=0.03)
+        ext = ext.copy()
+        rng = np.random.default_rng(lq)
+        cut = rng.random(len(ext))
+        ext["s_len"] = np.where(cut < 0.05, 0, np.where(cut < 0.4, (ext["s_len"] * rng.uniform(0.2, 1.0, len(ext))).astype(np.uint32),
+                                                         ext["s_len"])).astype(np.uint32)
+        want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+        got, kn = _dev_scores(handle, q, s, ext, lq, wpq, 1, max_slen=int(ext["s_len"].max()))
+        assert "sweep_pair16_kernel<8,19,true,false>" in kn, kn
+        assert (got == want).all()
+        got32, kn32 = _dev_scores(handle, q, s, ext, lq, wpq, 0, max_slen=int(ext["s_len"].max()))
+        assert "pair16" not in kn32 and (got32 == want).all()
+    finally:
+        handle.set_scoring(SCHEMES["blosum62"], 0)
