@@ -120,13 +120,14 @@ enum
                                    processed in chunks, in order, on the same stream                            */
     LX_OPT_BS_MATCH_RULE   = 6, /* 1: lx_hsp match counts use the bisulfite rule score(c0,c1)==score(c0,c0)
                                    (src/evaluate_bisulfite_alignment.hpp:97) instead of rank equality        */
-    LX_OPT_PACKED_HALF     = 7, /* 1 (default): pass 1 may use the packed-half kernel where a per-wavefront score bound
-                                   proves it exact (results are bit-identical either way); 0: int32 kernel only */
+    LX_OPT_PACKED_HALF     = 7, /* 1 (default): the packed kernels (two extensions per lane group: half precision, or
+                                   16-bit integers for wider queries) run where a per-wavefront score bound proves them
+                                   exact (results are bit-identical either way); 0: int32 kernels only */
     LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical in every mode):
                                    0 = 4 direction bits per cell of every survivor;
                                    1 = strip boundaries + row checkpoints of every survivor, tiles recomputed by the
-                                       backtrace -- where its limits hold (query within one panel of a shared-profile
-                                       geometry, scores below 32000), else mode 0;
+                                       backtrace -- where its limits hold (extensions in blocks of >= 4 per query,
+                                       scores below 32000; queries of any width, panel by panel), else mode 0;
                                    2 (default) = single sweep in lx_extend_batch_dev: one checkpointing kernel over ALL
                                        extensions is pass 1 and the forward half of pass 2 at once -- where mode 1
                                        applies, LX_OPT_QUERY_RUN is a multiple of 8 and the checkpoints of the whole
