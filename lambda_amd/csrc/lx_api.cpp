@@ -868,22 +868,71 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             return x.s_len < y.s_len;
         return a < b;
     };
-    std::vector<uint32_t> idx;
-    idx.reserve(n);
-    bool ordered = true; // lambda hands its matches over sorted by query: then the sort is skipped
-    for (uint64_t i = 0; i < n; ++i)
+    // (the loops over the list are spread over a few host threads, as in lx_extend_batch)
+    unsigned const nthreads = host_threads(n);
+    struct Part
     {
-        lx_extension const & x = ext[i];
-        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
-            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
-        if (x.q_len == 0 || x.s_len == 0)
+        uint64_t live = 0, bad = ~0ull;
+        uint32_t first_live = 0xffffffffu, last_live = 0xffffffffu;
+        bool     ordered = true;
+    };
+    std::vector<Part> parts(nthreads);
+    parallel_ranges(n, nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        Part & pt = parts[t];
+                        for (uint64_t i = lo; i < hi; ++i)
+                        {
+                            lx_extension const & x = ext[i];
+                            if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+                            {
+                                pt.bad = std::min(pt.bad, i);
+                                continue;
+                            }
+                            if (x.q_len == 0 || x.s_len == 0)
+                            {
+                                out_score[i] = 0;
+                                continue;
+                            }
+                            if (pt.last_live != 0xffffffffu && before((uint32_t)i, pt.last_live))
+                                pt.ordered = false;
+                            if (pt.first_live == 0xffffffffu)
+                                pt.first_live = (uint32_t)i;
+                            pt.last_live = (uint32_t)i;
+                            ++pt.live;
+                        }
+                    });
+    bool     ordered = true; // lambda hands its matches over sorted by query: then the sort is skipped
+    uint64_t live    = 0;
+    {
+        uint32_t prev = 0xffffffffu;
+        for (Part const & pt : parts)
         {
-            out_score[i] = 0;
-            continue;
+            if (pt.bad != ~0ull)
+                return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
+            ordered = ordered && pt.ordered;
+            if (pt.first_live != 0xffffffffu)
+            {
+                if (prev != 0xffffffffu && before(pt.first_live, prev))
+                    ordered = false;
+                prev = pt.last_live;
+            }
+            live += pt.live;
         }
-        if (ordered && !idx.empty() && before((uint32_t)i, idx.back()))
-            ordered = false;
-        idx.push_back((uint32_t)i);
+    }
+    std::vector<uint32_t> idx(live);
+    {
+        std::vector<uint64_t> first(nthreads + 1, 0);
+        for (unsigned t = 0; t < nthreads; ++t)
+            first[t + 1] = first[t] + parts[t].live;
+        parallel_ranges(n, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = first[t];
+                            for (uint64_t i = lo; i < hi; ++i)
+                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                                    idx[o++] = (uint32_t)i;
+                        });
     }
     if (!ordered)
         std::sort(idx.begin(), idx.end(), before);
@@ -899,6 +948,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     {
         uint64_t first, count, pad; // positions in idx, padded slot count
         uint32_t bin;
+        uint64_t out;               // first slot in the upload buffer (set once the bins are laid out)
     };
     std::vector<Run>      runs;
     std::vector<uint64_t> bin_slots(nbins, 0);
@@ -939,7 +989,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             }
         }
         uint32_t const bin = kind == 2 ? (uint32_t)(ncfg * 2 + cfg) : (uint32_t)(cfg * 2 + kind);
-        runs.push_back(Run{k, run, pad, bin});
+        runs.push_back(Run{k, run, pad, bin, 0});
         bin_slots[bin] += pad;
         bin_maxq[bin] = std::max(bin_maxq[bin], qlen);
         if (kind != 2 && (int)qlen > lx::score_cfg_panel(cfg))
@@ -975,26 +1025,37 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         total_slots += bin_slots[b];
     }
     // every slot is written exactly once: straight into the upload buffer, no per-bin copies
-    std::vector<lx_extension> sorted(total_slots);
-    std::vector<uint32_t>     perm(total_slots);
-    for (Run const & r : runs)
+    for (Run & r : runs)
     {
-        uint64_t o = bin_cursor[r.bin];
-        for (uint64_t j = 0; j < r.count; ++j, ++o)
-        {
-            uint32_t const src = idx[r.first + j];
-            sorted[o]          = ext[src];
-            perm[o]            = src;
-        }
-        lx_extension dummy = ext[idx[r.first]]; // dummy slots keep one query per wavefront
-        dummy.s_len        = 0;
-        for (uint64_t j = r.count; j < r.pad; ++j, ++o)
-        {
-            sorted[o] = dummy;
-            perm[o]   = 0xffffffffu;
-        }
-        bin_cursor[r.bin] = o;
+        r.out = bin_cursor[r.bin];
+        bin_cursor[r.bin] += r.pad;
     }
+    std::vector<lx_extension> & sorted = h->xb_ext; // (host staging that keeps its pages between calls)
+    std::vector<uint32_t> &     perm   = h->xb_src;
+    sorted.resize(total_slots);
+    perm.resize(total_slots);
+    parallel_ranges(runs.size(), nthreads,
+                    [&](unsigned, uint64_t rlo, uint64_t rhi)
+                    {
+                        for (uint64_t ri = rlo; ri < rhi; ++ri)
+                        {
+                            Run const & r = runs[ri];
+                            uint64_t    o = r.out;
+                            for (uint64_t j = 0; j < r.count; ++j, ++o)
+                            {
+                                uint32_t const src = idx[r.first + j];
+                                sorted[o]          = ext[src];
+                                perm[o]            = src;
+                            }
+                            lx_extension dummy = ext[idx[r.first]]; // dummy slots keep one query per wavefront
+                            dummy.s_len        = 0;
+                            for (uint64_t j = r.count; j < r.pad; ++j, ++o)
+                            {
+                                sorted[o] = dummy;
+                                perm[o]   = 0xffffffffu;
+                            }
+                        }
+                    });
     if (sorted.empty())
         return LX_OK;
 
@@ -1028,15 +1089,20 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     h->timed = true;
 
     // ---- download + unpermute
-    std::vector<int32_t> res(sorted.size());
+    std::vector<int32_t> & res = h->xb_score;
+    res.resize(sorted.size());
     LX_HIP(h, hipMemcpyAsync(res.data(), h->d_out.ptr, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     hm.mark("launch");
     if ((rc = check_async_error(h)))
         return rc;
     hm.mark("wait");
-    for (size_t k = 0; k < res.size(); ++k)
-        if (perm[k] != 0xffffffffu)
-            out_score[perm[k]] = res[k];
+    parallel_ranges(res.size(), nthreads,
+                    [&](unsigned, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t k = lo; k < hi; ++k)
+                            if (perm[k] != 0xffffffffu)
+                                out_score[perm[k]] = res[k];
+                    });
     hm.mark("unpermute");
     return LX_OK;
 }
