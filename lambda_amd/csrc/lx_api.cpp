@@ -1310,7 +1310,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         max_q     = std::max<uint64_t>(max_q, x.q_len);
         max_s     = std::max<uint64_t>(max_s, x.s_len);
         ops_bytes = std::max<uint64_t>(ops_bytes, ops_off[i] + x.q_len + x.s_len);
-        if ((int)x.q_len > lx::trace_cfg_panel(0))
+        if ((int)x.q_len > lx::trace_cfg_panel(1)) // (the narrowest panel pass 2 may pick)
             carry_pairs += x.s_len;
         if (i > 0 && (x.q_off != ext[i - 1].q_off || x.q_len != ext[i - 1].q_len))
         {
@@ -1320,7 +1320,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         ++run;
     }
     padded += (run + 3) / 4 * 4;
-    bool const share = max_q <= (uint64_t)lx::trace_cfg_panel(2) && (padded - n) * 4 <= padded && padded <= 0xfffffff0ull;
+    bool const share = (padded - n) * 4 <= padded && padded <= 0xfffffff0ull; // (any query width: checkpoints carry across panels)
     uint64_t const slots = share ? padded : n;
 
     if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
@@ -1336,39 +1336,61 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return rc;
     hm.mark("validate+alloc");
 
-    // ---- slot list: the extensions in input order, every run followed by its padding slots (empty window, src = none)
-    std::vector<lx_extension> slot_ext;
-    std::vector<uint32_t>     slot_src;
-    std::vector<int32_t>      slot_score;
+    // ---- slot list: the extensions in input order, every run followed by its padding slots (empty window, src = none);
+    // filled on a few host threads into staging that keeps its pages between calls
+    std::vector<lx_extension> & slot_ext   = h->xb_ext;
+    std::vector<uint32_t> &     slot_src   = h->xb_src;
+    std::vector<int32_t> &      slot_score = h->xb_min;
+    slot_ext.clear();
+    slot_src.clear();
+    slot_score.clear();
     if (share)
     {
-        slot_ext.reserve(slots);
-        slot_src.reserve(slots);
-        if (known_score)
-            slot_score.reserve(slots);
+        std::vector<uint64_t> & grp = h->xb_grp; // (first extension, first slot) of every run + a sentinel
+        grp.clear();
+        uint64_t o = 0;
         for (uint64_t i = 0; i < n;)
         {
             uint64_t i1 = i + 1;
             while (i1 < n && ext[i1].q_off == ext[i].q_off && ext[i1].q_len == ext[i].q_len)
                 ++i1;
-            for (uint64_t j = i; j < i1; ++j)
-            {
-                slot_ext.push_back(ext[j]);
-                slot_src.push_back((uint32_t)j);
-                if (known_score)
-                    slot_score.push_back(known_score[j]);
-            }
-            lx_extension dummy = ext[i];
-            dummy.s_len        = 0;
-            for (uint64_t j = i1 - i; j % 4 != 0; ++j)
-            {
-                slot_ext.push_back(dummy);
-                slot_src.push_back(0xffffffffu);
-                if (known_score)
-                    slot_score.push_back(0);
-            }
+            grp.push_back(i);
+            grp.push_back(o);
+            o += (i1 - i + 3) / 4 * 4;
             i = i1;
         }
+        grp.push_back(n);
+        grp.push_back(o);
+        slot_ext.resize(slots);
+        slot_src.resize(slots);
+        if (known_score)
+            slot_score.resize(slots);
+        uint64_t const ngroups = grp.size() / 2 - 1;
+        parallel_ranges(ngroups, host_threads(n),
+                        [&](unsigned, uint64_t glo, uint64_t ghi)
+                        {
+                            for (uint64_t g = glo; g < ghi; ++g)
+                            {
+                                uint64_t const i0 = grp[2 * g], i1 = grp[2 * g + 2], o1 = grp[2 * g + 3];
+                                uint64_t       oo = grp[2 * g + 1];
+                                for (uint64_t j = i0; j < i1; ++j, ++oo)
+                                {
+                                    slot_ext[oo] = ext[j];
+                                    slot_src[oo] = (uint32_t)j;
+                                    if (known_score)
+                                        slot_score[oo] = known_score[j];
+                                }
+                                lx_extension dummy = ext[i0];
+                                dummy.s_len        = 0;
+                                for (; oo < o1; ++oo)
+                                {
+                                    slot_ext[oo] = dummy;
+                                    slot_src[oo] = 0xffffffffu;
+                                    if (known_score)
+                                        slot_score[oo] = 0;
+                                }
+                            }
+                        });
     }
     hm.mark("slots");
 
