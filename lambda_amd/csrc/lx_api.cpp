@@ -350,7 +350,8 @@ int check_async_error(lx_handle * h)
 
 // One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
 // (or need the multi-panel path when wider).
-constexpr int kPair16 = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
+constexpr int kPair16    = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
+constexpr int kPair16Bin = 7;   // its bin among the packed geometries of lx_score_batch
 
 int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n,
                       void * d_out, int cfg, bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0)
@@ -972,6 +973,12 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             cfg  = pcfg;
             pad  = pad16;
         }
+        else if (pcfg < 0 && h->opt_f16 && (pad16 - run) * 4 <= pad16)
+        {
+            kind = 2; // wider than every packed-half geometry: the packed 16-bit integer kernel, panel by panel
+            cfg  = kPair16Bin;
+            pad  = pad16;
+        }
         else
         {
             cfg          = pick_cfg(qlen, true);
@@ -992,7 +999,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         runs.push_back(Run{k, run, pad, bin, 0});
         bin_slots[bin] += pad;
         bin_maxq[bin] = std::max(bin_maxq[bin], qlen);
-        if (kind != 2 && (int)qlen > lx::score_cfg_panel(cfg))
+        if ((kind != 2 && (int)qlen > lx::score_cfg_panel(cfg)) || (kind == 2 && cfg == kPair16Bin))
             for (size_t j = k; j < k1; ++j)
                 carry_pairs += ext[idx[j]].s_len;
         k = k1;
@@ -1021,7 +1028,11 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
             segs.push_back(Seg{cfg, total_slots, bin_slots[b], bin_maxq[b] > (uint32_t)lx::score_cfg_panel(cfg), (b & 1) == 1, -1});
         }
         else // the int32 fix-up launch over the same list uses the shared-profile geometry of the longest query
-            segs.push_back(Seg{pick_cfg(bin_maxq[b], true), total_slots, bin_slots[b], false, true, (int)(b - (size_t)ncfg * 2)});
+        {
+            int const pair = (int)(b - (size_t)ncfg * 2), fcfg = pick_cfg(bin_maxq[b], true);
+            segs.push_back(Seg{fcfg, total_slots, bin_slots[b], pair == kPair16Bin && bin_maxq[b] > (uint32_t)lx::score_cfg_panel(fcfg), true,
+                               pair == kPair16Bin ? kPair16 : pair});
+        }
         total_slots += bin_slots[b];
     }
     // every slot is written exactly once: straight into the upload buffer, no per-bin copies
