@@ -49,6 +49,7 @@ hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
 hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t stream);
 hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream);
+hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 } // namespace lx
 
@@ -1591,7 +1592,11 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
-            LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
+            static bool const int_sweep = getenv("LX_SWEEP_INT") != nullptr; // A/B: the compact sweep in the integer domain
+            if (int_sweep && sweep_share == 0)
+                LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
+            else
+                LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
             p.fixup = 1;
         }
         // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16

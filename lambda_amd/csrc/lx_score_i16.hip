@@ -70,10 +70,15 @@ struct Pair16Geo
 };
 
 // CKPT = false: score only (pass 1 of queries wider than the packed-half geometries): no slots, no end cells.
-template <int G, int C, bool MULTI, bool CKPT = true>
+// COMPACT = the slots hold the 16-bit codes of Ckpt16Layout instead of int16 pairs (one panel, H <= 2047, a gap's
+// first character <= 31: the conditions of the packed-half sweep, whose slots these are): in the integer domain a code
+// is two subtractions and a shift-or.
+template <int G, int C, bool MULTI, bool CKPT = true, bool COMPACT = false>
 __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 {
     static_assert(C <= 24, "profile rows hold 24 entries per lane");
+    static_assert(!COMPACT || (CKPT && !MULTI), "compact codes: single-panel sweep only");
+    using L16 = Ckpt16Layout<G, C>;
     using Geo = Pair16Geo<G, C>;
     extern __shared__ uint32_t lds[];
 
@@ -158,11 +163,14 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
         bound += __shfl_xor(bound, off);
     bool const broken  = CKPT && ((__ballot(lq > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) != 0) || (uint32_t)steps > p.steps_cap);
     // (upper end: no value reaches the non-finite patterns; lower end: pad scores and the skew of the first rows stay above 0)
-    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > kI16Limit) != 0 ||
+    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (COMPACT ? 2046 : kI16Limit)) != 0 ||
                          (-ge) * (G + 2) + (-sc->g2) + 256 > kBias;
     if (too_big)
     {
-        // left to the int32 launch (TraceParams::fixup): sentinel -1; a broken length promise is reported there
+        // left to the int32 launch (TraceParams::fixup): sentinel -1; a broken length promise is reported there (and
+        // here, because the compact sweep may run without that launch)
+        if (broken && lane == 0)
+            atomicExch(p.err, 3);
         if (is_first)
         {
             EndCell none{};
@@ -269,8 +277,9 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 
         bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
         bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
-        uint32_t * const slotA = CKPT ? p.ckpt + eA * p.ckpt_stride + (uint64_t)panel * panel_dw : nullptr;
-        uint32_t * const slotB = CKPT ? p.ckpt + eB * p.ckpt_stride + (uint64_t)panel * panel_dw : nullptr;
+        // (compact sweep: an idle half owns the spare slot p.n -- its stores are unconditional)
+        uint32_t * const slotA = !CKPT ? nullptr : COMPACT ? p.ckpt + (actA ? eA : p.n) * p.ckpt_stride : p.ckpt + eA * p.ckpt_stride + (uint64_t)panel * panel_dw;
+        uint32_t * const slotB = !CKPT ? nullptr : COMPACT ? p.ckpt + (actB ? eB : p.n) * p.ckpt_stride : p.ckpt + eB * p.ckpt_stride + (uint64_t)panel * panel_dw;
         bool const       stA = CKPT && actA && writable, stB = CKPT && actB && writable;
 
         s2 Z = ssplat(ge * g + kBias); // z_i of the first processed row i = -g, biased
@@ -363,13 +372,64 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                 cmax = smax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
                 // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
                 // re-paired per extension and staged for one 16-byte store per four steps
-                s2 const hb = h - Z, eb = Ecur - Z;
-                stage[u * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
-                stage[(4 + u) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+                if constexpr (COMPACT)
+                    stage[((k & 4) + u) * 64] = (as_u32(h - Ecur) << 11) | as_u32(h - Z); // codes of both extensions: H | (H - E) << 11
+                else
+                {
+                    s2 const hb = h - Z, eb = Ecur - Z;
+                    stage[u * 64]       = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x05040100u);
+                    stage[(4 + u) * 64] = __builtin_amdgcn_perm(as_u32(eb), as_u32(hb), 0x07060302u);
+                }
             }
             else
                 best = smax(best, rowmax - Z);
             Z = ZN;
+        };
+        // compact sweep: the staged codes of the eight steps up to k0 + 3 leave, re-paired per extension (whole 128-byte
+        // lines per lane group, no branch around the stores); the row checkpoint behind step k0 + 3 (k0 % 16 == 12)
+        auto flush_codes = [&](int k0)
+        {
+            if constexpr (COMPACT)
+            {
+                uint32_t cw[8];
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+                    cw[x] = stage[x * 64];
+                uint32_t const oi = L16::bnd_oct_index((uint32_t)k0 / 8, (uint32_t)g);
+                reinterpret_cast<uint4 *>(slotA)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x05040100u), __builtin_amdgcn_perm(cw[3], cw[2], 0x05040100u),
+                                                                  __builtin_amdgcn_perm(cw[5], cw[4], 0x05040100u), __builtin_amdgcn_perm(cw[7], cw[6], 0x05040100u));
+                reinterpret_cast<uint4 *>(slotB)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x07060302u), __builtin_amdgcn_perm(cw[3], cw[2], 0x07060302u),
+                                                                  __builtin_amdgcn_perm(cw[5], cw[4], 0x07060302u), __builtin_amdgcn_perm(cw[7], cw[6], 0x07060302u));
+            }
+        };
+        auto rowck_codes = [&](int k0)
+        {
+            if constexpr (COMPACT)
+            {
+                // Hrow is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next row's:
+                // H - F un-skewed = (Hrow - z_i) - (F0 - Z) = Hrow - F0 - ge
+                s2 const zi = Z + GE;
+                uint32_t code[2 * L16::kCkDw];
+#pragma unroll
+                for (int c = 0; c < 2 * L16::kCkDw; ++c)
+                    code[c] = c < C ? ((as_u32((Hrow[c < C ? c : 0] - F0[c < C ? c : 0]) - GE) << 11) | as_u32(Hrow[c < C ? c : 0] - zi)) : 0u;
+                uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4) + L16::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, 0);
+                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+#pragma unroll
+                for (int x = 0; x < L16::kCkDw / 4; ++x)
+                {
+                    uint32_t wa[4], wb[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                    {
+                        int const c = 2 * (4 * x + b); // columns c, c + 1 of extension A (low halves) / B (high halves)
+                        wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
+                        wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
+                    }
+                    dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                    dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                }
+            }
         };
         // after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
         auto chunk_done = [&](int k0)
@@ -391,6 +451,12 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                 tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
                 best = nb;
                 cmax = ssplat(0);
+            }
+            if constexpr (COMPACT)
+            {
+                if (k0 & 4)
+                    flush_codes(k0);
+                return; // (the row checkpoint follows at the top of the next chunk: rowck_codes)
             }
             uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g; // lx_ckpt.hip: bnd_quad_index
             if (stA)
@@ -464,6 +530,8 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
             bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
             if (!cur_steady)
             {
+                if (COMPACT && k0 != 0 && (k0 & 15) == 0)
+                    rowck_codes(k0 - 4);
                 uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
                 mask_checked(k0, ca, cb);
                 fetch_checked(k0 + 4, na, nb);
@@ -479,6 +547,8 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                 uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
                 while (k0 < steady_hi)
                 {
+                    if (COMPACT && (k0 & 15) == 0) // (k0 >= steady_lo > 0)
+                        rowck_codes(k0 - 4);
                     uint32_t const ca = wa, cb = wb;
                     int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                     wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
@@ -493,6 +563,13 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
             }
         }
 
+        if constexpr (COMPACT)
+        {
+            if (steps != 0 && (steps & 15) == 0)
+                rowck_codes(steps - 4);
+            if (steps & 4)
+                flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
+        }
         // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first).
         // Over the panels a later one only wins with a strictly greater value (its columns come later).
         auto merge = [&](int lbest, int lrow, int ltie, int & run, int & rstrip, int & rrow, int & rtie)
@@ -550,7 +627,7 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
                 ec.score = run;
                 ec.q_end = -(rstrip + 1); // the backtrace finds the column inside this strip
                 ec.s_end = rrow + 1;
-                ec.flags = rtie ? kEndAmbiguous : 0;
+                ec.flags = (rtie ? kEndAmbiguous : 0) | (COMPACT ? kEndCompact : 0);
             }
             p.ends[e]      = ec;
             p.out_score[e] = writable ? run : -1;
@@ -605,6 +682,26 @@ hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream)
     size_t const lds = ((size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
     hipLaunchKernelGGL((sweep_pair16_kernel<8, 19, true, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     return hipGetLastError();
+}
+
+// the compact-slot sweep in the integer domain (same slots and conditions as score_pair_kernel<G,C,CKPT=true>)
+template <int G, int C>
+static hipError_t launch_sweep16_compact_cfg(ScoreParams const & p, hipStream_t stream)
+{
+    using Geo = Pair16Geo<G, C>;
+    uint64_t const per_wave = 2ull * Geo::kGroups;
+    uint64_t const blocks   = (p.n + per_wave - 1) / per_wave;
+    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0)
+        return hipErrorInvalidValue;
+    size_t const lds = ((size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+    hipLaunchKernelGGL((sweep_pair16_kernel<G, C, false, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    return trace_cfg == 1 ? launch_sweep16_compact_cfg<8, 19>(p, stream) : trace_cfg == 2 ? launch_sweep16_compact_cfg<16, 13>(p, stream) : hipErrorInvalidValue;
 }
 
 // trace cfg 1 = (8,19): 16 extensions of one query per wavefront; 2 = (16,13): 8
