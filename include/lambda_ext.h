@@ -94,6 +94,9 @@ typedef struct lx_handle lx_handle;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 int          lx_abi_version(void);
+/* Hash of the sources this library was compiled from (lambda_amd/build.py source_id()): lets a test or a deployment assert
+ * that the binary matches the tree. */
+char const * lx_build_id(void);
 int          lx_device_count(void);
 int          lx_create(int device_id, lx_handle ** out);
 void         lx_destroy(lx_handle * h);
@@ -135,6 +138,8 @@ enum
                                        13.5 KB as int16 pairs) fit LX_OPT_TRACE_BYTES, else mode 1 */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
+/* current value of an option (what the caller set or the default; never the library's internal growth of a workspace) */
+int lx_get_option(lx_handle const * h, int option, uint64_t * value);
 
 /* slot 0 = forward scheme, slot 1 = bisulfite reverse scheme (scoringSchemeAlignBSRev,
  * src/search_algo.hpp:1097-1098).  Must be called before any batch call using that slot. */
@@ -257,7 +262,9 @@ typedef struct lx_search_params
     int32_t   sbj_num_frames;
     int32_t   bisulfite;        /* 1: iterateMatches' bisulfite branch (src/search_algo.hpp:1367-1379): matches on even subject
                                    frames are extended with slot 0 (forward scheme), odd ones with slot 1 (reverse scheme);
-                                   the `slot` argument is ignored                                                          */
+                                   the `slot` argument is ignored; match counts / identity follow the bisulfite overload of
+                                   computeAlignmentStats (score(c0,c1)==score(c0,c0), src/evaluate_bisulfite_alignment.hpp:97)
+                                   for this call whatever LX_OPT_BS_MATCH_RULE says                                         */
     int32_t   q_frame_mode;     /* LX_FRAMES_*: how _setFrames derives qFrameShift from the frame-expanded qryId            */
     int32_t   s_frame_mode;     /* same for sFrameShift / subjId                                                            */
     lx_karlin karlin;

@@ -30,6 +30,38 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
+def _product_deps():
+    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
+    return srcs, list(srcs) + sorted(CSRC.glob("*.h")) + sorted((CSRC / "host").glob("*.hpp")) + [ROOT / "include" / "lambda_ext.h"]
+
+
+def source_id() -> str:
+    """SHA-256 (first 16 hex digits) over every source the product library is built from, names included.  Compiled
+    into the library (lx_build_id()); tests and build() compare it with the tree so that a stale .so cannot pass."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(_product_deps()[1], key=lambda f: str(f.relative_to(ROOT))):
+        h.update(str(f.relative_to(ROOT)).encode() + b"\0")
+        h.update(f.read_bytes())
+        h.update(b"\0")
+    h.update(os.environ.get("LX_EXTRA_DEFINES", "").encode())
+    return h.hexdigest()[:16]
+
+
+_ID_MARK = b"LXBUILDID:"
+
+
+def library_id(lib: Path = None) -> str | None:
+    """The source id compiled into a built library (read from the file, no dlopen), None if absent."""
+    lib = lib or LIB
+    if not lib.exists():
+        return None
+    data = lib.read_bytes()
+    at = data.find(_ID_MARK)
+    return data[at + len(_ID_MARK): at + len(_ID_MARK) + 16].decode("ascii", "replace") if at >= 0 else None
+
+
 def _newer(target: Path, deps) -> bool:
     if not target.exists():
         return False
@@ -38,10 +70,10 @@ def _newer(target: Path, deps) -> bool:
 
 
 def build_product(force: bool = False, verbose: bool = False) -> Path:
-    srcs = [CSRC / s for s in HIP_SOURCES if (CSRC / s).exists()]
-    deps = list(srcs) + list(CSRC.glob("*.h")) + list((CSRC / "host").glob("*.hpp")) + [ROOT / "include" / "lambda_ext.h"]
-    if not force and _newer(LIB, deps):
-        return LIB
+    srcs, deps = _product_deps()
+    sid = source_id()
+    if not force and library_id() == sid:
+        return LIB  # the library says it was built from exactly this tree (mtimes are not trusted)
     objs = []
     hipcc = _hipcc()
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}",
@@ -50,9 +82,10 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
     for s in srcs:
         o = s.with_suffix(".o")
         objs.append(o)
-        if not force and _newer(o, [s] + [d for d in deps if d.suffix in (".h", ".hpp")]):
+        is_api = s.name == "lx_api.cpp"  # carries the build id: recompiled whenever anything changed
+        if not force and not is_api and _newer(o, [s] + [d for d in deps if d.suffix in (".h", ".hpp")]):
             continue
-        cmd = [hipcc, *common, "-c", str(s), "-o", str(o)]
+        cmd = [hipcc, *common, *([f'-DLX_BUILD_ID="{sid}"'] if is_api else []), "-c", str(s), "-o", str(o)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

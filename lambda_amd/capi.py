@@ -22,7 +22,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 
 # every symbol include/lambda_ext.h declares (tests/test_abi.py checks that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lx_abi_version", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option",
+    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
     "lx_iterate_matches",
@@ -119,6 +119,7 @@ def load():
     lib = C.CDLL(str(LIB_PATH))
     vp, i32, u64 = C.c_void_p, C.c_int, C.c_uint64
     lib.lx_abi_version.restype = i32
+    lib.lx_build_id.restype = C.c_char_p
     lib.lx_device_count.restype = i32
     lib.lx_create.argtypes = [i32, C.POINTER(vp)]
     lib.lx_destroy.argtypes = [vp]
@@ -126,6 +127,7 @@ def load():
     lib.lx_last_error.argtypes = [vp]
     lib.lx_last_error.restype = C.c_char_p
     lib.lx_set_option.argtypes = [vp, i32, u64]
+    lib.lx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
     lib.lx_set_scoring.argtypes = [vp, i32, C.POINTER(Scoring)]
     lib.lx_builtin_scoring.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Scoring)]
     lib.lx_score_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp]
@@ -307,6 +309,11 @@ class Handle:
 
     def set_option(self, opt: int, value: int):
         self._check(self.lib.lx_set_option(self.h, opt, value))
+
+    def get_option(self, opt: int) -> int:
+        v = C.c_uint64()
+        self._check(self.lib.lx_get_option(self.h, opt, C.byref(v)))
+        return int(v.value)
 
     def set_scoring(self, sc: Scoring, slot: int = 0):
         self._check(self.lib.lx_set_scoring(self.h, slot, C.byref(sc)))

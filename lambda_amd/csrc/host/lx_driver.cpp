@@ -334,6 +334,18 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     int  rc;
     if (params->bisulfite)
     {
+        // The bisulfite scheme type selects the computeAlignmentStats overload whose match test is
+        // score(c0,c1) == score(c0,c0) (src/evaluate_bisulfite_alignment.hpp:97, called at src/search_algo.hpp:1308):
+        // in force for this call whatever the handle's LX_OPT_BS_MATCH_RULE says, restored afterwards.
+        uint64_t ruleBefore = 0;
+        (void)lx_get_option(h, LX_OPT_BS_MATCH_RULE, &ruleBefore);
+        (void)lx_set_option(h, LX_OPT_BS_MATCH_RULE, 1);
+        struct Restore
+        {
+            lx_handle * h;
+            uint64_t    v;
+            ~Restore() { (void)lx_set_option(h, LX_OPT_BS_MATCH_RULE, v); }
+        } restore{h, ruleBefore};
         // sort by (subjId % 2, Match); even subject frames use the forward scheme (slot 0), odd ones the reverse scheme
         // (slot 1); finally the HSPs are stably re-sorted by query (:1367-1379)
         std::sort(matches, matches + n_matches,

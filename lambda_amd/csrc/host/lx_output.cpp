@@ -92,7 +92,7 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
         if (rightFrameClip > 0)
             el.emplace_back('H', rightFrameClip);
     }
-    if (qTrans && m.q_frame < 0)
+    if (m.q_frame < 0) // every program, BLASTN's reverse-complement query frame included (src/search_output.hpp:192-193)
         std::reverse(el.begin(), el.end());
     std::string c;
     for (auto const & e : el)

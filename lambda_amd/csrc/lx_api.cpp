@@ -111,7 +111,8 @@ struct lx_handle
     // options
     uint64_t opt_max_qlen  = 0;
     uint64_t opt_query_run = 0;
-    uint64_t opt_ws_bytes  = 64ull << 20;
+    uint64_t opt_ws_bytes  = 64ull << 20; // the caller's LX_OPT_WORKSPACE_BYTES
+    uint64_t ws_grown      = 0;           // what the calls grew the workspace to by themselves (never shown to the caller)
     uint64_t opt_max_slen  = 0;
     uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
@@ -340,7 +341,7 @@ int check_async_error(lx_handle * h)
     if (flags[1] == 2)
         return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
     if (flags[1] == 3)
-        return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or s_len > 65535)");
+        return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or a subject window beyond the pass-2 limit)");
     if (flags[1] == 4)
         return fail(h, LX_EOVERFLOW, "single sweep: no checkpoint slot left for an extension the packed-half kernel declined "
                                      "(raise LX_OPT_TRACE_BYTES, or set LX_OPT_PASS2_MODE to 1)");
@@ -411,9 +412,9 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
 int prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint = 0)
 {
     uint64_t const want = std::min<uint64_t>(pairs_hint, 0xfffffff0ull) * 8 + 4096;
-    if (pairs_hint != 0 && want > h->opt_ws_bytes)
-        h->opt_ws_bytes = want;
-    int rc = ensure(h, h->d_ws, h->opt_ws_bytes);
+    if (pairs_hint != 0 && want > h->ws_grown)
+        h->ws_grown = want;
+    int rc = ensure(h, h->d_ws, std::max(h->opt_ws_bytes, h->ws_grown));
     if (rc)
         return rc;
     LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, 2 * sizeof(uint32_t), stream));
@@ -421,6 +422,12 @@ int prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint = 0
 }
 
 } // namespace
+
+// [off, off + len) inside a buffer of `bytes`, written so that offsets near 2^64 cannot wrap past the test
+static inline bool lx_slice_ok(uint64_t off, uint64_t len, uint64_t bytes)
+{
+    return len <= bytes && off <= bytes - len;
+}
 
 // a few host threads for the per-extension loops of the host-buffer entry point (none below a quarter million items)
 static unsigned host_threads(uint64_t n)
@@ -463,6 +470,16 @@ extern "C" {
 int lx_abi_version(void)
 {
     return LX_ABI_VERSION;
+}
+
+#ifndef LX_BUILD_ID
+#define LX_BUILD_ID "unknown-build-id"
+#endif
+// "LXBUILDID:" + id: lambda_amd/build.py finds the marker in the file without loading it
+static char const g_build_id[] = "LXBUILDID:" LX_BUILD_ID;
+char const * lx_build_id(void)
+{
+    return g_build_id + 10;
 }
 
 int lx_device_count(void)
@@ -583,6 +600,24 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
     }
 }
 
+int lx_get_option(lx_handle const * h, int option, uint64_t * value)
+{
+    if (!h || !value)
+        return LX_EINVAL;
+    switch (option)
+    {
+        case LX_OPT_MAX_QLEN: *value = h->opt_max_qlen; return LX_OK;
+        case LX_OPT_QUERY_RUN: *value = h->opt_query_run; return LX_OK;
+        case LX_OPT_WORKSPACE_BYTES: *value = h->opt_ws_bytes; return LX_OK;
+        case LX_OPT_MAX_SLEN: *value = h->opt_max_slen; return LX_OK;
+        case LX_OPT_TRACE_BYTES: *value = h->opt_trace_bytes; return LX_OK;
+        case LX_OPT_BS_MATCH_RULE: *value = h->opt_bs_rule; return LX_OK;
+        case LX_OPT_PACKED_HALF: *value = h->opt_f16; return LX_OK;
+        case LX_OPT_PASS2_MODE: *value = h->opt_pass2; return LX_OK;
+        default: return LX_EINVAL;
+    }
+}
+
 int lx_builtin_scoring(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend,
                        lx_scoring * sc)
 {
@@ -656,7 +691,8 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
     int rc = bind(h);
     if (rc)
         return rc;
-    LX_HIP(h, hipStreamSynchronize(h->stream));
+    // *_dev calls may still be in flight on a caller-supplied (non-blocking) stream and read this table
+    LX_HIP(h, hipDeviceSynchronize());
     LX_HIP(h, hipMemcpy(h->sc_dev[slot], &d, sizeof(d), hipMemcpyHostToDevice));
     h->sc_host[slot] = *sc;
     h->have_sc[slot] = true;
@@ -886,7 +922,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
                         for (uint64_t i = lo; i < hi; ++i)
                         {
                             lx_extension const & x = ext[i];
-                            if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
                             {
                                 pt.bad = std::min(pt.bad, i);
                                 continue;
@@ -1005,8 +1041,8 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
                 carry_pairs += ext[idx[j]].s_len;
         k = k1;
     }
-    if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
-        h->opt_ws_bytes = carry_pairs * 8 + 4096;
+    if (carry_pairs * 8 + 4096 > h->ws_grown)
+        h->ws_grown = carry_pairs * 8 + 4096;
 
     struct Seg
     {
@@ -1134,8 +1170,8 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
     if ((reinterpret_cast<uintptr_t>(d_q) | reinterpret_cast<uintptr_t>(d_s)) & 15)
         return fail(h, LX_EINVAL, "pass 2 reads residues in aligned 16-byte groups: the residue buffers must be 16-byte aligned");
-    if (max_s > 65535)
-        return fail(h, LX_EINVAL, "pass 2 supports subject windows up to 65535 residues (got %llu)", (unsigned long long)max_s);
+    if (max_s > (uint64_t)lx::kMaxTraceRows)
+        return fail(h, LX_EINVAL, "pass 2 supports subject windows up to %d residues (got %llu)", lx::kMaxTraceRows, (unsigned long long)max_s);
     // share_slots = every aligned block of that many slots holds one query (0: no such guarantee).  The 8-lane
     // geometry puts 8 extensions in a wavefront and needs blocks of >= 4 (two LDS profiles per wavefront).
     int smax_entry = 0;
@@ -1144,7 +1180,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
             smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
     // checkpoint mode (lx_ckpt.hip): shared-profile geometries (8,19) / (16,13), scores that fit int16; queries wider
     // than 208 columns take several (16,13) panels
-    bool const ckpt = h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000;
+    bool const ckpt = h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
     // Direction bits beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile).
     auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
     int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
@@ -1317,7 +1353,7 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     for (uint64_t i = 0; i < n; ++i)
     {
         lx_extension const & x = ext[i];
-        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
             return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
         max_q     = std::max<uint64_t>(max_q, x.q_len);
         max_s     = std::max<uint64_t>(max_s, x.s_len);
@@ -1335,8 +1371,8 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     bool const share = (padded - n) * 4 <= padded && padded <= 0xfffffff0ull; // (any query width: checkpoints carry across panels)
     uint64_t const slots = share ? padded : n;
 
-    if (carry_pairs * 8 + 4096 > h->opt_ws_bytes)
-        h->opt_ws_bytes = carry_pairs * 8 + 4096;
+    if (carry_pairs * 8 + 4096 > h->ws_grown)
+        h->ws_grown = carry_pairs * 8 + 4096;
     if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) ||
         (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
         (rc = ensure(h, h->d_ops, ops_bytes + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
@@ -1800,7 +1836,7 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
                         for (uint64_t i = lo; i < hi; ++i)
                         {
                             lx_extension const & x = ext[i];
-                            if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes)
+                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
                             {
                                 pt.bad = std::min(pt.bad, i);
                                 continue;
@@ -2076,7 +2112,7 @@ int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     for (uint64_t i = 0; i < n; ++i)
     {
         lx_seed const & x = seeds[i];
-        if (x.q_off + x.q_len > q_bytes || x.s_off + x.s_len > s_bytes || x.qry_end < x.qry_start || x.qry_end > x.q_len ||
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes) || x.qry_end < x.qry_start || x.qry_end > x.q_len ||
             (uint64_t)x.subj_start + (x.qry_end - x.qry_start) > x.s_len)
             return fail(h, LX_EINVAL, "seed %llu out of range", (unsigned long long)i);
     }

@@ -7,6 +7,9 @@ namespace lx
 
 constexpr int kAlph    = 32;          // matrix stride (include/lambda_ext.h LX_ALPH)
 constexpr int kNegPad  = -100;        // substitution score of any pad rank: can never start/extend/end a best local alignment
+// longest subject window pass 2 takes (direction-bit mode; merged windows of _widenAndPreprocessMatches have no bound
+// in the reference, src/search_algo.hpp:1153-1157): row indices are 32-bit, the skewed values x 4 stay far from overflow
+constexpr int kMaxTraceRows = 1 << 22;
 constexpr int kNegInf  = -(1 << 28);  // "minus infinity" for gap states; far from int32 overflow after any number of additions
 
 // Device copy of one scoring scheme, preprocessed for the row-skewed recurrence (see lx_score.hip).

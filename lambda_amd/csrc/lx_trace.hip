@@ -23,7 +23,8 @@
 // buffer as whole 16-byte quads, G lanes covering G consecutive quads (layout below).  The end cell under the
 // reference's tie rule (first strict maximum in column-major order) is the first cell in that order whose H equals
 // the extension's best score, which pass 1 already delivered (p.score_in): one max3 per two cells keeps the row
-// maximum, a rare slow path records the column.  Limits (checked by the host): Ls < 65536, |s - ge| <= 31.
+// maximum, a rare slow path records the column.  Limits (checked by the host): Ls <= kMaxTraceRows (lx_device.h),
+// |s - ge| <= 31.
 //
 // Kernel B (backtrace_kernel): one lane per extension walks from the end cell to the first cell with H = 0, emits
 // one op byte per alignment column ('M','D','I') and the counts of lx_hsp.
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(Tr
     npanels = MULTI ? __builtin_amdgcn_readfirstlane(npanels) : 1;
 
     bool bad = false;
-    if (active && ((uint32_t)my_panels > p.panels_cap || (!MULTI && my_panels > 1) || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > 65535))
+    if (active && ((uint32_t)my_panels > p.panels_cap || (!MULTI && my_panels > 1) || (uint32_t)((ls + G - 1 + 3) & ~3) > p.steps_cap || ls > kMaxTraceRows))
     {
         bad = true; // the host sized the trace slots too small for this extension: report, never write out of bounds
         atomicExch(p.err, 3);

@@ -23,9 +23,12 @@ def oracle():
 def lx_lib():
     from lambda_amd import build, capi
 
-    if not capi.LIB_PATH.exists():
-        build.build_product()
-    return capi.load()
+    # the library must have been compiled from exactly this tree: rebuilt here when it was not (hipcc is in the image on
+    # the GPU box as well), and its own report is checked after loading
+    build.build_product()
+    lib = capi.load()
+    assert lib.lx_build_id().decode() == build.source_id(), "liblambda_ext.so does not match the source tree"
+    return lib
 
 
 @pytest.fixture(scope="session")

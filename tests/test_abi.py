@@ -29,6 +29,13 @@ def test_library_exports_every_declared_symbol(lx_lib):
     assert lx_lib.lx_abi_version() == 1
 
 
+def test_library_matches_the_source_tree(lx_lib):
+    """The binary reports the hash of the sources it was compiled from; a stale .so (edited tree, old build) cannot pass."""
+    from lambda_amd import build
+
+    assert lx_lib.lx_build_id().decode() == build.source_id() == build.library_id()
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(capi.Scoring) == 16 + 1024
     assert capi.EXT_DTYPE.itemsize == 24 and capi.HSP_DTYPE.itemsize == 48

@@ -306,7 +306,9 @@ def test_iterate_matches_bisulfite(handle, oracle):
     fwd, rev = SCHEMES["bs_fwd"], SCHEMES["bs_rev"]
     handle.set_scoring(fwd, 0)
     handle.set_scoring(rev, 1)
-    handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 1)
+    # NOT set by hand: params.bisulfite = 1 must select the bisulfite computeAlignmentStats overload by itself
+    # (src/evaluate_bisulfite_alignment.hpp:97 via src/search_algo.hpp:1308) and leave the handle's option as it was
+    handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 0)
     ka = capi.karlin_params(0, 2, -3, -5, -2)
     oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
     rng = np.random.default_rng(77)
@@ -336,7 +338,9 @@ def test_iterate_matches_bisulfite(handle, oracle):
     try:
         bms, ops, stats = handle.iterate_matches(q, qoff, qlen, np.full(nq // 4, 100, np.uint64), s, soff, slen, m, params)
     finally:
+        rule_after = handle.get_option(capi.LX_OPT_BS_MATCH_RULE)
         handle.set_option(capi.LX_OPT_BS_MATCH_RULE, 0)
+    assert rule_after == 0  # the call's temporary rule did not leak into the handle
     mo = m.astype(oracle_lib.MATCH_DTYPE)
     want = []
     for parity, scheme in ((0, fwd), (1, rev)):
@@ -866,3 +870,35 @@ def test_full_size_host_entry_point_equals_device_path(handle):
             assert bytes(ops[a: a + k]) == bytes(dev_ops[b: b + k]), i
     finally:
         handle.set_subjects(None)
+
+
+def test_extend_batch_with_a_window_beyond_65535_residues(handle, oracle):
+    """_widenAndPreprocessMatches merges chains of overlapping windows without a bound (src/search_algo.hpp:1153-1157): one
+    long merged window (here 70 000 residues, beyond what the checkpoint slots address) must not fail the batch -- it is
+    traced through the direction-bit path with the rest of the list, bit-exact as ever."""
+    rng = np.random.default_rng(9)
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_batch_np(12, 120, 16, seed=77, sub_rate=0.2, indel_rate=0.03)
+    long_len = 70_000
+    long_s = rng.integers(0, 20, long_len).astype(np.uint8)
+    long_s[61_234: 61_234 + 120] = q[:120]                      # the first query, planted deep inside the long window
+    long_s[61_234 + 40: 61_234 + 44] = rng.integers(0, 20, 4)   # with a few substitutions
+    s2 = np.concatenate([s, long_s])
+    ext2 = np.concatenate([ext, ext[:1]])
+    ext2[-1]["s_off"], ext2[-1]["s_len"] = len(s), long_len
+    want_score = oracle.score_batch(q, s2, ext2, osc, threads=8)
+    cut = int(np.percentile(want_score, 40))
+    surv = np.nonzero(want_score >= cut)[0]
+    assert len(ext2) - 1 in surv
+    want = oracle.align_batch(q, s2, ext2[surv], osc)
+    score, hsp, off, ops = handle.extend_batch(q, s2, ext2, cut)
+    assert (score == want_score).all()
+    for i, (oh, oops) in zip(surv, want):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, i
+    assert hsp[len(ext2) - 1]["s_begin"] >= 61_000

@@ -119,3 +119,22 @@ def test_sam_writer_translated_query_cigar_clips_and_sequence(tmp_path):
                        program="tblastn")
     g = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")][0]
     assert g[5] == "*" and g[9] == "*" and g[3] == str(5 * 3 + 1 + 1)
+
+
+def test_sam_writer_blastn_minus_strand_cigar_is_reversed(tmp_path):
+    """blastMatchOneCigar reverses the element list whenever qFrameShift < 0 (src/search_output.hpp:192-193) -- BLASTN hits
+    of the reverse-complemented query frame included, not only translated queries.  Asymmetric alignment so that the
+    reversal shows: 2 leading unaligned, 6 M, 1 I, 9 M, 3 D, 4 M, 7 trailing unaligned."""
+    ops = b"M" * 6 + b"I" + b"M" * 9 + b"D" * 3 + b"M" * 4
+    qlen = 2 + 6 + 1 + 9 + 4 + 7
+    fwd = rec(0, 0, 2, 22, 40, 62, 41.0, alen=len(ops), nm=18, n_ops=len(ops), frame=1)
+    rev = rec(0, 1, 2, 22, 40, 62, 40.0, alen=len(ops), nm=18, n_ops=len(ops), frame=-1)
+    m = np.array([fwd, rev], dtype=capi.BLAST_MATCH_DTYPE)
+    read = b"ACGGTCATTGCAAGCTTAGGCATCGATAC"[:qlen]
+    p = tmp_path / "rc.sam"
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["r"], [qlen], ["c1", "c2"], [500, 500], program="blastn",
+                       q_ascii=read, q_ascii_off=[0])
+    f0, f1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
+    assert f0[1] == "0" and f0[5] == "2S6M1I9M3D4M7S"
+    assert f1[1] == str(256 | 16) and f1[5] == "7S4M3D9M1I6M2S"  # the same elements, back to front
+    assert "qf:i:-1" in f1
