@@ -1,27 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the seed-extension hot path on MI355X.
+"""bench.py -- benchmark of the seed-extension hot path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md section 8d "config 2 headline"): searchp, BLOSUM62 11/1,
-100 000 synthetic 150-aa queries x 32 candidate windows of Lq + 2b = 176 residues = 3.2 M extensions =
-84.48 Gcells of full-rectangle (parity mode) DP per GPU.  A *step* is one pass of the hot path over that batch:
-pass 1 (score every window) [+ e-value filter + pass 2 traceback of the survivors once --with-trace is on].
-Inputs are resident in HBM before the timed region starts.
+    python bench.py --gpus N --steps K --warmup W [--config {1,2,3,4}]
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+Default workload = BASELINE.json configs[1] (SURVEY.md section 8d "config 2 headline"): searchp, BLOSUM62 11/1, 100 000
+synthetic 150-aa queries x 32 candidate windows of Lq + 2b = 176 residues = 3.2 M extensions = 84.48 Gcells of
+full-rectangle (parity mode) DP per GPU.  `--config k` selects BASELINE.json configs[k] (lambda_amd/workloads.py):
+2 = searchn (1 M x 150 bp, 8 windows, +2/-3, 5/2, 1 % N), 3 = searchp scale-out (1 M x 200 aa x 32 windows split by query
+over the ranks), 4 = bisulfite (500 k x 150 bp, both matrices / two scoring slots).
 
-Multi-GPU: the path shards by query with no data-path collective -> weak scaling, every
-rank owns its own 100 k queries; the only collective is the final gather of per-rank result counts/top hits,
-which is outside the hot loop but inside the timed region's last step.
+A *step* is one pass of the hot path over the rank's share of the job: pass 1 (score every window) -> e-value filter ->
+pass 2 (traceback of the survivors), all on the GPU, inputs resident in HBM before the timed region starts.  A share
+that does not fit one device call (checkpoint slots of configs[3] at N = 1) is processed in several calls per step.
 
-Rank 0 prints ONE JSON line.  `value` = GCUPS = (sum over ranks of Lq*Ls cells of pass 1) * K / max-over-ranks
-seconds / 1e9.  The oracle is used ONLY for the cpu_baseline leg (rank 0, N = 1), never for `value`.
+Multi-GPU: one process per GPU.  Launched by the driver as `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...`; started plainly with --gpus N > 1 it re-executes itself under torch.distributed.run (and fails
+loudly when the node has fewer than N devices).  The path shards by query with no data-path collective (SURVEY.md section
+8e); the only collective is the final gather of the per-query top hits, inside the timed region after the last step.
+Weak scaling (every rank owns a full per-GPU share; default of configs 1, 2) or strong scaling (the job's queries split over
+the ranks: default of configs 3, 4; `--total-queries T` forces it, `--queries Q` forces weak with Q per rank).
+
+Rank 0 prints ONE JSON line.  `value` = GCUPS = (pass-1 cells of all ranks, sum Lq*Ls) * K / max-over-ranks seconds / 1e9.
+The oracle is used ONLY for the cpu_baseline leg (rank 0, N = 1), never for `value`.
+`--dry-run` walks through launch, rendezvous (gloo) and sharding without touching a GPU (CPU tests of the launch path).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -38,24 +47,72 @@ ALGO_OPS_PER_CELL = 10
 PEAK_INT32_TOPS = 256 * 128 * 2.4e9 / 1e12
 # kernels that compute two cells per lane-op (packed 16-bit): SURVEY.md section 8d quotes 157 Tops/s for them
 PEAK_PACKED16_TOPS = 2 * PEAK_INT32_TOPS
-ALGO_BYTES_PER_EXT_EXTRA = 16 + 4  # extension record read + score written
+ALGO_BYTES_PER_EXT_EXTRA = 24 + 4  # extension record read + score written
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--queries", type=int, default=100_000, help="queries per GPU")
-    ap.add_argument("--lq", type=int, default=150)
-    ap.add_argument("--windows", type=int, default=32)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 2, 3, 4], help="BASELINE.json configs[k]")
+    ap.add_argument("--queries", type=int, default=None, help="weak scaling: queries per GPU (default: the config's per-GPU share)")
+    ap.add_argument("--total-queries", type=int, default=None, help="strong scaling: queries of the whole job, split over the ranks")
+    ap.add_argument("--batch-queries", type=int, default=None, help="queries per device call (default: the config's)")
+    ap.add_argument("--lq", type=int, default=None, help="override the config's query length")
+    ap.add_argument("--windows", type=int, default=None, help="override the config's windows per query")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-queries", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-queries", type=int, default=None)
     ap.add_argument("--pass1-only", action="store_true", help="time the score kernel alone (no filter, no traceback)")
-    ap.add_argument("--db-length", type=int, default=205_000_000, help="dbTotalLength for the e-value (Swiss-Prot sized)")
-    ap.add_argument("--max-evalue", type=float, default=1e-2)
+    ap.add_argument("--db-length", type=int, default=None, help="dbTotalLength for the e-value (default: the config's)")
+    ap.add_argument("--max-evalue", type=float, default=None)
     ap.add_argument("--max-matches", type=int, default=25, help="HSPs kept per query for the final gather (maxMatches)")
-    return ap.parse_args()
+    ap.add_argument("--trace-bytes", type=int, default=160 << 30, help="LX_OPT_TRACE_BYTES: HBM the checkpoint slots may take")
+    ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
+    return ap.parse_args(argv)
+
+
+def workload_of(args):
+    import dataclasses
+
+    from lambda_amd import workloads
+
+    w = workloads.WORKLOADS[args.config]
+    over = {}
+    if args.lq is not None:
+        over["lq"] = args.lq
+    if args.windows is not None:
+        over["windows"] = args.windows
+    if args.db_length is not None:
+        over["db_length"] = args.db_length
+    if args.max_evalue is not None:
+        over["max_evalue"] = args.max_evalue
+    return dataclasses.replace(w, **over) if over else w
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_self_spawn(args) -> None:
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    if not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to run fewer ranks than asked for")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def usable_cpus() -> tuple[int, str]:
@@ -75,16 +132,19 @@ def usable_cpus() -> tuple[int, str]:
     return n, note
 
 
-def cpu_baseline(args, cores: int, note: str = ""):
+def cpu_baseline(w, sample_queries: int, cores: int, note: str = ""):
     """Times the oracle's inter-sequence int16 SIMD batch scorer (the shape of the reference's CPU path,
     oracle/lx_oracle_simd.cpp) on a bounded sample of the same workload, on this box's host cores."""
-    from lambda_amd import capi, synth
+    from lambda_amd import capi, synth, workloads
     from tests import oracle_lib
 
     orc = oracle_lib.load()
-    nq = min(args.cpu_sample_queries, args.queries)
-    q, s, ext = synth.make_batch_np(nq, args.lq, args.windows, seed=0x1A3BDA02)
-    sc = oracle_lib.scoring_from(capi.builtin_scoring(62, gap_open=-11, gap_extend=-1))
+    d = w.directions[0]
+    q, s, ext = synth.make_batch_np(sample_queries, w.lq, w.windows, seed=w.seed, alphabet=workloads.alphabet_array(w),
+                                    sub_rate=w.sub_rate, indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank,
+                                    convert=d.convert, convert_rate=w.convert_rate)
+    m, ma, mi, go, ge = d.scoring
+    sc = oracle_lib.scoring_from(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge))
     cells = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
     best = float("inf")
     for _ in range(3):
@@ -96,17 +156,18 @@ def cpu_baseline(args, cores: int, note: str = ""):
         "unit": "GCUPS",
         "cores": cores,
         "kind": "port",
-        "sample": f"{nq} queries x {args.windows} windows ({len(ext)} extensions, {cells / 1e9:.2f} Gcells), "
+        "sample": f"{sample_queries} queries x {w.windows} windows ({len(ext)} extensions, {cells / 1e9:.2f} Gcells) of this workload"
+                  f"{' (forward direction)' if len(w.directions) > 1 else ''}, "
                   f"oracle inter-sequence int16 SIMD restatement (NOT SeqAn), OpenMP with {cores} threads ({note}), "
                   f"best of 3, {best:.3f} s",
     }
 
 
 def pmc_traffic(kernel_name: str):
-    """HBM bytes per step of a kernel (kernel_name = substring of its rocprofv3 name) from the committed rocprofv3 PMC passes (profiles/*_pmc.json):
-    (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md.
-    PMC counters cannot be read from inside a timed run, so this is the figure of the profiled run of the same
-    command; None if no profile of this kernel instantiation is committed."""
+    """HBM bytes per launch of a kernel (kernel_name = substring of its rocprofv3 name) from the committed rocprofv3 PMC
+    passes (profiles/*_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 correction in
+    MI355X_MICROARCH.md.  PMC counters cannot be read from inside a timed run, so this is the figure of the profiled run of
+    the headline command; None if no profile of this kernel instantiation is committed."""
     try:
         files = sorted((ROOT / "profiles").glob("*_pmc.json"))
         for f in reversed(files):
@@ -114,24 +175,93 @@ def pmc_traffic(kernel_name: str):
                 c = d.get("counters_per_step_mean", d.get("counters_per_launch_mean", {}))
                 if kernel_name in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                     return ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-                            f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per step of {name}")
+                            f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {name} on the headline batch")
     except Exception:
         pass
     return None, "no committed PMC profile for this kernel instantiation"
 
 
-def main():
-    args = parse()
-    import torch
+def dry_run(args, w, world, rank):
+    """No GPU: rendezvous over gloo, plan the sharding, gather the plans, print the line the real run would print (value
+    null).  What the CPU tests and `python bench.py --gpus 2 --config 3 --dry-run` exercise."""
     import torch.distributed as dist
 
-    from lambda_amd import capi, shard, synth
+    from lambda_amd import workloads
 
+    pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
+    mine = {"rank": rank, "q_lo": pl.q_lo, "q_hi": pl.q_hi, "calls": [[b.direction.slot, b.n_queries] for b in pl.batches]}
+    plans = [mine]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        plans = [None] * world
+        dist.all_gather_object(plans, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "GCUPS (gapped extension, full-rectangle parity mode)", "value": None, "unit": "GCUPS", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "scaling": pl.scaling, "dry_run": True,
+            "config": {"workload": workloads.describe(w), "job_queries": pl.job_queries,
+                       "job_gcells": round(workloads.cells_of(w, pl.job_queries) / 1e9, 3)},
+            "ranks": plans}), flush=True)
+
+
+class DevBatch:
+    """One device call's inputs and outputs, resident in HBM."""
+
+    def __init__(self, w, b, dev, min_score):
+        import torch
+
+        from lambda_amd import synth, workloads
+
+        self.slot = b.direction.slot
+        self.n_queries = b.n_queries
+        self.q_first = b.q_lo
+        d_q, d_s, self.d_ext, ext = synth.make_batch_torch(
+            b.n_queries, w.lq, w.windows, b.seed, dev, alphabet=workloads.alphabet_array(w), sub_rate=w.sub_rate,
+            indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank, convert=b.direction.convert, convert_rate=w.convert_rate)
+        pad = torch.zeros(256, dtype=torch.uint8, device=dev)
+        self.d_q = torch.cat([d_q, pad])
+        self.d_s = torch.cat([d_s, pad])
+        self.n = n = len(ext)
+        self.max_slen = int(ext["s_len"].max())
+        self.cells = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
+        self.q_bytes, self.s_bytes = float(ext["q_len"].sum()) / w.windows, float(ext["s_len"].sum())
+        self.d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+        # pass-2 outputs (worst case sizes: every extension may survive)
+        sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+        off = np.zeros(n, dtype=np.uint64)
+        off[1:] = np.cumsum(sizes)[:-1]
+        self.d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+        self.d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+        self.d_hsp = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
+        self.d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.min_score = min_score
+
+
+def main():
+    args = parse()
+    maybe_self_spawn(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != max(1, args.gpus) and world > 1:
+    if world != max(1, args.gpus):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    w = workload_of(args)
+    if args.dry_run:
+        return dry_run(args, w, world, rank)
+
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from lambda_amd import capi, shard, synth, workloads
+
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: no device {local_rank} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("LX_BENCH_FORCE_DIST") == "1"  # the env switch lets one GPU exercise the RCCL path
@@ -140,46 +270,43 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    # ---- workload, generated directly in HBM; every rank owns different queries (shard by query) ----
+    pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
+
+    # ---- scoring schemes and the e-value filter of iterateMatchesFullSimd as an integer score cut-off
     h = capi.Handle(local_rank)
-    h.set_scoring(capi.builtin_scoring(62, gap_open=-11, gap_extend=-1), 0)
-    h.set_option(capi.LX_OPT_MAX_QLEN, args.lq)
-    h.set_option(capi.LX_OPT_QUERY_RUN, args.windows if args.windows % 8 == 0 else 0)
-    d_q, d_s, d_ext, ext = synth.make_batch_torch(args.queries, args.lq, args.windows, 0x1A3BDA02 + rank, dev)
-    pad = torch.zeros(256, dtype=torch.uint8, device=dev)
-    d_q = torch.cat([d_q, pad])
-    d_s = torch.cat([d_s, pad])
-    n = len(ext)
-    cells_rank = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
-    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
-    # pass-2 outputs (worst case sizes: every extension may survive)
-    h.set_option(capi.LX_OPT_MAX_SLEN, int(ext["s_len"].max()))
-    sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
-    off = np.zeros(n, dtype=np.uint64)
-    off[1:] = np.cumsum(sizes)[:-1]
-    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
-    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
-    d_hsp = torch.zeros(n * 48, dtype=torch.uint8, device=dev)
-    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
-    # e-value filter of iterateMatchesFullSimd (maxEValue 1e-2, src/search_options.hpp:96) as an integer score cut-off
-    ka = capi.karlin_params(62, gap_open=-11, gap_extend=-1)
+    for d in w.directions:
+        m, ma, mi, go, ge = d.scoring
+        h.set_scoring(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
+    h.set_option(capi.LX_OPT_BS_MATCH_RULE, 1 if len(w.directions) > 1 else 0)
+    h.set_option(capi.LX_OPT_MAX_QLEN, w.lq)
+    h.set_option(capi.LX_OPT_QUERY_RUN, w.windows if w.windows % 8 == 0 else 0)
+    h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+    ka = capi.karlin_params(*w.karlin)
     lib = capi.load()
-    import ctypes as C
-    adj = lib.lx_length_adjustment(args.db_length, args.lq, C.byref(ka))
+    adj = lib.lx_length_adjustment(w.db_length, w.lq, C.byref(ka))
     min_score = 1
-    while lib.lx_evalue(min_score, args.lq - adj, args.db_length - adj, C.byref(ka)) > args.max_evalue:
+    while lib.lx_evalue(min_score, w.lq - adj, w.db_length - adj, C.byref(ka)) > w.max_evalue:
         min_score += 1
+
+    # ---- workload, generated directly in HBM; every rank owns different queries (shard by query)
+    batches = [DevBatch(w, b, dev, min_score) for b in pl.batches]
+    if not batches:
+        raise SystemExit(f"rank {rank}: no queries to process (job of {pl.job_queries} queries over {world} ranks)")
+    h.set_option(capi.LX_OPT_MAX_SLEN, max(b.max_slen for b in batches))
+    cells_rank = sum(b.cells for b in batches)
+    n_rank = sum(b.n for b in batches)
     # a non-default torch stream: its handle is non-NULL, so the kernels really run on the stream the timing events
     # are recorded on (NULL would select the lx handle's private stream)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
 
     def step():
-        if args.pass1_only:
-            h.score_batch_dev(d_q, d_s, d_ext, n, d_score, stream=stream.cuda_stream)
-        else:
-            h.extend_batch_dev(d_q, d_s, d_ext, n, min_score, d_score, d_hsp, d_ops, d_off, d_count,
-                               stream=stream.cuda_stream)
+        for b in batches:
+            if args.pass1_only:
+                h.score_batch_dev(b.d_q, b.d_s, b.d_ext, b.n, b.d_score, slot=b.slot, stream=stream.cuda_stream)
+            else:
+                h.extend_batch_dev(b.d_q, b.d_s, b.d_ext, b.n, b.min_score, b.d_score, b.d_hsp, b.d_ops, b.d_off, b.d_count,
+                                   slot=b.slot, stream=stream.cuda_stream)
 
     def fence():
         if use_dist:
@@ -191,18 +318,22 @@ def main():
         # HSPs (src/search_options.hpp:99) among the survivors of the e-value filter, then one gather of fixed-size
         # records [global extension id, lx_hsp (48 B)] = 56 B each -- RCCL over xGMI.  Query ranges are disjoint, so
         # rank order is the final order.
-        if args.pass1_only or args.windows <= 0:
-            hit = torch.nonzero(d_score >= min_score).flatten()
-            return shard.gather_hits(torch.stack([hit + rank * n, d_score[hit].to(torch.int64)], dim=1), dst=None)
-        sc2 = d_score.view(args.queries, args.windows)
-        k = min(args.max_matches, args.windows)
-        top, idx = torch.topk(sc2, k, dim=1)
-        keep = top >= min_score
-        ext_id = (idx + torch.arange(args.queries, device=dev).unsqueeze(1) * args.windows)[keep]
-        hsp64 = d_hsp.view(torch.int64).view(n, 6)[ext_id]
-        rec = torch.cat([(ext_id + rank * n).unsqueeze(1), hsp64], dim=1)
+        recs = []
+        for b in batches:
+            base = b.q_first * w.windows  # global extension numbering of this direction's queries
+            if args.pass1_only or w.windows <= 0:
+                hit = torch.nonzero(b.d_score >= b.min_score).flatten()
+                recs.append(torch.stack([hit + base, b.d_score[hit].to(torch.int64)], dim=1))
+                continue
+            sc2 = b.d_score.view(b.n_queries, w.windows)
+            k = min(args.max_matches, w.windows)
+            top, idx = torch.topk(sc2, k, dim=1)
+            keep = top >= b.min_score
+            ext_id = (idx + torch.arange(b.n_queries, device=dev).unsqueeze(1) * w.windows)[keep]
+            hsp64 = b.d_hsp.view(torch.int64).view(b.n, 6)[ext_id]
+            recs.append(torch.cat([(ext_id + base).unsqueeze(1), hsp64], dim=1))
         # all_gather (dst=None): ~2 ms for 8 x 90 MB over xGMI, once per run; a gather to the writing rank costs the same
-        return shard.gather_hits(rec, dst=None)
+        return shard.gather_hits(torch.cat(recs, dim=0), dst=None)
 
     for _ in range(args.warmup):
         step()
@@ -228,72 +359,84 @@ def main():
     dt = time.perf_counter() - t0
     h.synchronize()
     kernel_name = h.last_kernel_name()
-    survivors = int(d_count.cpu()[1]) if not args.pass1_only else 0
+    survivors = sum(int(b.d_count.cpu()[1]) for b in batches) if not args.pass1_only else 0
+    last = batches[-1]  # the library's phase events are those of the most recent call: the last batch of the last step
+    survivors_last = int(last.d_count.cpu()[1]) if not args.pass1_only else 0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # whole-job figures need every rank's share (strong scaling: ranks own different numbers of queries)
+    tot = torch.tensor([dt, cells_rank, float(n_rank), float(survivors)], dtype=torch.float64, device=dev)
     if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[0].item())
+    total_cells, total_ext, total_surv = float(tot[1].item()), float(tot[2].item()), float(tot[3].item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    # device time per phase of the LAST timed step (HIP events recorded by the library on the launch stream, around
-    # each kernel launch): 0 = pass-1 score kernel, 1 = selection, 2 = pass-2 forward kernel, 3 = pass-2 backtrace
+    # device time per phase of the LAST call of the last timed step (HIP events recorded by the library on the launch
+    # stream, around each kernel launch): 0 = pass-1 score kernel, 1 = selection, 2 = pass-2 forward kernel, 3 = backtrace
     phase_ms = {ph: h.last_phase_ms(ph) for ph in (0, 1, 2, 3)}
     trace_kernel_name = h.last_trace_kernel_name()
 
     if rank == 0:
-        total_cells = cells_rank * world
         gcups = total_cells * args.steps / dt / 1e9
-        lq, ls = args.lq, synth.window_len(args.lq)
+        lq, ls = w.lq, synth.window_len(w.lq)
 
-        def roofline(kernel, ms, launches, cells, pmc_key, algo_bytes):
+        def roofline(kernel, ms, launches, cells, pmc_key, algo_bytes, stored_bytes):
             """The DP kernels are bound by integer VALU issue (not HBM, not MFMA), so `bound` is
-            "valu" and achieved/peak count lane-ops; the HBM side of the same kernel -- algorithmic bytes per step over
-            its duration against 8 TB/s -- is reported next to it as evidence that memory is not the limit."""
+            "valu" and achieved/peak count lane-ops of ONE launch (cells of the last device call / its duration); the HBM
+            side of the same launch -- algorithmic bytes (windows, queries, records, scores), the
+            checkpoint bytes the kernel additionally writes for pass 2, and the PMC traffic -- is reported next to it."""
             gc = cells / (ms * 1e-3) / 1e9
             tops = gc * ALGO_OPS_PER_CELL / 1e3
             traffic, note = pmc_traffic(pmc_key)
-            packed = "pair_kernel" in kernel
+            packed = "pair" in kernel
             peak = PEAK_PACKED16_TOPS if packed else PEAK_INT32_TOPS
-            hbm = algo_bytes / (ms * 1e-3) / 1e9
+            hbm = (algo_bytes + stored_bytes) / (ms * 1e-3) / 1e9
             return {
                 "bound": "valu", "kernel": kernel, "achieved": round(tops, 3), "peak": round(peak, 2),
                 "unit": "Tops/s (%s lane-ops; 10 algorithmic ops per cell)" % ("packed 16-bit" if packed else "int32"),
                 "frac": round(tops / peak, 4),
-                "kernel_ms_per_step": round(ms, 4), "launches_per_step": launches, "kernel_gcups": round(gc, 1),
-                "cells_per_step": cells,
+                "kernel_ms_per_launch": round(ms, 4), "launches": launches, "kernel_gcups": round(gc, 1),
+                "cells_per_launch": cells,
                 "hbm": {"bound": "hbm", "achieved": round(hbm, 2), "peak": 8000, "unit": "GB/s", "frac": round(hbm / 8000, 4),
-                        "algorithmic_bytes_per_step": algo_bytes},
-                "traffic": traffic, "traffic_note": note,
+                        "algorithmic_bytes_per_launch": algo_bytes, "checkpoint_bytes_written_per_launch": stored_bytes,
+                        "write_amplification": round((algo_bytes + stored_bytes) / algo_bytes, 2)},
+                "traffic": traffic if (args.config == 1 and args.lq is None and args.windows is None) else None,
+                "traffic_note": note if (args.config == 1 and args.lq is None and args.windows is None)
+                                else "PMC passes are committed for the headline batch only",
             }
 
-        # algorithmic bytes: pass 1 reads every window once, every query once per run, one 24-byte record per extension and
-        # writes one int32 score; pass 2 forward reads the same per survivor (+ its score) and writes 4 direction bits per cell
-        algo_bytes = float(ext["q_len"].sum()) / args.windows + float(ext["s_len"].sum()) + n * ALGO_BYTES_PER_EXT_EXTRA
+        # algorithmic bytes of pass 1 (SURVEY.md section 8d): every window once, every query once per run, one 24-byte
+        # record per extension, one int32 score written
+        algo_bytes = last.q_bytes + last.s_bytes + last.n * ALGO_BYTES_PER_EXT_EXTRA
+        stored = 0.0
         if "single sweep" in kernel_name:
             # the sweep also writes the checkpoints of every extension: one boundary pair per strip and row, one pair per
-            # column every 16 rows -- 2-byte codes from the packed-half kernel, int16 pairs from the int32 kernel -- and a
-            # 16-byte end record
-            pair_bytes = 2 if "pair_kernel" in kernel_name else 4
-            algo_bytes += n * (ls * (-(-lq // 19)) * pair_bytes + (ls / 16.0) * lq * pair_bytes + 16)
-        r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], cells_rank,
-                           "score_pair_kernel" if "pair_kernel" in kernel_name else "score_kernel", algo_bytes)
+            # column every 16 rows -- 2-byte codes from the packed-half kernel, int16 pairs otherwise -- and a 16-byte end
+            # record.  NOT algorithmic: the price of fusing pass 2's forward half into pass 1.
+            pair_bytes = 2 if "score_pair_kernel" in kernel_name else 4
+            strip = 13 if "<16,13" in kernel_name else 19
+            stored = last.n * (ls * (-(-lq // strip)) * pair_bytes + (ls / 16.0) * lq * pair_bytes + 16)
+        r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], last.cells,
+                           "score_pair_kernel" if "score_pair_kernel" in kernel_name else "score_kernel", algo_bytes, stored)
         rooflines = [r_score]
         if not args.pass1_only and phase_ms[2][0] > 0:
-            cells2 = float(survivors) * lq * ls
+            cells2 = float(survivors_last) * lq * ls
             if "ckpt" in trace_kernel_name:
-                # checkpoint mode: one 4-byte boundary pair per strip and row + one 4-byte pair per column every 16 rows
                 strips = -(-lq // 19)
-                stored = ls * strips * 4 + (ls / 16.0) * lq * 4
+                stored2 = survivors_last * (ls * strips * 4 + (ls / 16.0) * lq * 4)
                 pmc_key = "ckpt_forward_kernel"
             else:
-                stored = lq * ls / 2.0  # 4 direction bits per cell
+                stored2 = survivors_last * lq * ls / 2.0  # 4 direction bits per cell
                 pmc_key = "trace_forward_kernel"
-            algo2 = survivors * (stored + ls + lq / 4.0 + ALGO_BYTES_PER_EXT_EXTRA + 4)
-            rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], cells2, pmc_key, algo2))
-        rooflines.sort(key=lambda r: -r["kernel_ms_per_step"])
+            algo2 = survivors_last * (ls + lq / 4.0 + ALGO_BYTES_PER_EXT_EXTRA + 4)
+            rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], cells2, pmc_key, algo2, stored2))
+        rooflines.sort(key=lambda r: -r["kernel_ms_per_launch"])
+        packed_name = "score_pair_kernel" in kernel_name
         out = {
-            "metric": "GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) searchp BLOSUM62",
+            "metric": "GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) "
+                      + ("searchp BLOSUM62" if w.program == "blastp" else w.name),
             "value": round(gcups, 2),
             "unit": "GCUPS",
             "n_gpus": world,
@@ -301,30 +444,33 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": pl.scaling,
             "vs_baseline": None,
-            "dtype": "f16x2 (exact small integers) + int32" if "pair_kernel" in kernel_name else "int32",
+            "dtype": ("f16x2 (exact small integers) + int32" if packed_name else
+                      "i16x2 (packed 16-bit integers) + int32" if "pair16" in kernel_name else "int32"),
             "data": "synthetic",
             "config": {
-                "workload": f"searchp BLOSUM62 gap 11/1, {args.queries} x {args.lq} aa queries x {args.windows} "
-                            f"windows of {synth.window_len(args.lq)} aa per GPU (BASELINE.json configs[1]), "
-                            f"cells = sum Lq*Ls (full rectangle, band off as in the reference)",
-                "extensions_per_gpu": n,
-                "gcells_per_gpu": round(cells_rank / 1e9, 3),
-                "parallelism": f"query-sharded x{world}, no data-path collective; one gather of the per-query top-"
-                               f"{args.max_matches} HSP records (56 B) after the last step"
+                "workload": workloads.describe(w),
+                "baseline_config": args.config,
+                "job_queries": pl.job_queries,
+                "queries_rank0": pl.n_queries,
+                "device_calls_per_step_rank0": len(batches),
+                "extensions_job": int(total_ext),
+                "gcells_job": round(total_cells / 1e9, 3),
+                "parallelism": f"query-sharded x{world} ({pl.scaling} scaling), no data-path collective; one gather of the per-query "
+                               f"top-{args.max_matches} HSP records (56 B) after the last step"
                                + (f" ({n_hits_total} records)" if n_hits_total is not None else ""),
-                "step": ("pass 1 score kernel over the whole batch" if args.pass1_only else
+                "step": ("pass 1 score kernel over the whole share" if args.pass1_only else
                          ("single sweep: " if "single sweep" in kernel_name else "") +
-                         f"pass 1 (score all) -> e-value filter (E<={args.max_evalue:g} at db {args.db_length}, i.e. score>={min_score}) "
-                         f"-> pass 2 (traceback of the {survivors} survivors), all on the GPU; GCUPS counts pass-1 cells only"),
-                "survivors_per_gpu": survivors,
-                "pass2_gcells_per_gpu": round(survivors * args.lq * synth.window_len(args.lq) / 1e9, 3),
+                         f"pass 1 (score all) -> e-value filter (E<={w.max_evalue:g} at db {w.db_length}, i.e. score>={min_score}) "
+                         f"-> pass 2 (traceback of the {int(total_surv)} survivors of the job), all on the GPU; GCUPS counts pass-1 cells only"),
+                "survivors_job": int(total_surv),
+                "pass2_gcells_job": round(total_surv * lq * ls / 1e9, 3),
             },
-            "alignments_per_s": round(n * world * args.steps / dt, 1),
-            "traced_per_s": round(survivors * world * args.steps / dt, 1),
-            "total_gcups_both_passes": round((cells_rank + float(survivors) * lq * ls) * world * args.steps / dt / 1e9, 2),
-            "phase_ms_last_step": {"score": round(phase_ms[0][0], 3), "select": round(phase_ms[1][0], 3),
+            "alignments_per_s": round(total_ext * args.steps / dt, 1),
+            "traced_per_s": round(total_surv * args.steps / dt, 1),
+            "total_gcups_both_passes": round((total_cells + total_surv * lq * ls) * args.steps / dt / 1e9, 2),
+            "phase_ms_last_call": {"score": round(phase_ms[0][0], 3), "select": round(phase_ms[1][0], 3),
                                    "trace_forward": round(phase_ms[2][0], 3), "backtrace": round(phase_ms[3][0], 3),
                                    "events_step_ms": round(kern_ms, 3)},
             "roofline": rooflines[0],           # the kernel that takes most of the step
@@ -332,7 +478,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             cores, note = usable_cpus()
-            out["cpu_baseline"] = cpu_baseline(args, cores, note)
+            # ~84 Gcells of CPU work per repetition at most (a second or so on the box's 16 granted CPUs), three repetitions
+            default_sample = max(1, min(pl.n_queries, int(84.5e9 / (w.windows * lq * ls))))
+            out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_sample_queries or default_sample, pl.n_queries), cores, note)
         print(json.dumps(out), flush=True)
     h.close()
     if use_dist:

@@ -20,6 +20,10 @@ from .capi import EXT_DTYPE
 STD20 = np.array([0, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12, 13, 15, 16, 17, 18, 19, 21, 22, 23], dtype=np.uint8)
 
 
+# bisulfite conversions in SeqAn Dna5 ranks (A, C, G, T, N): read letter that replaces the genome's
+CONVERSIONS = {"CT": (1, 3), "GA": (2, 0)}
+
+
 def band_size(lq: int) -> int:
     return int(math.sqrt(lq)) + 1
 
@@ -30,11 +34,14 @@ def window_len(lq: int) -> int:
 
 def make_batch_np(n_queries: int, lq: int, windows_per_query: int, seed: int, alphabet: np.ndarray = STD20,
                   homolog_frac: float = 0.5, sub_rate: float = 0.25, indel_rate: float = 0.02, n_rate: float = 0.0,
-                  n_rank: int = 4, bisulfite: str | None = None):
+                  n_rank: int = 4, convert: str | None = None, convert_rate: float = 0.99):
     """Returns (q_res, s_res, ext): uint8 residue buffers and the EXT_DTYPE extension list.
 
     Extensions are ordered query-major (all windows of query 0, then query 1, ...), i.e. runs of
     `windows_per_query` consecutive entries share one query slice.
+
+    convert = "CT" / "GA": bisulfite reads (SeqAn Dna5 ranks A, C, G, T = 0..3) -- after the windows have been copied
+    from the unconverted read, `convert_rate` of the read's C become T (forward strand) / of its G become A (reverse).
     """
     rng = np.random.default_rng(seed)
     b = band_size(lq)
@@ -55,8 +62,6 @@ def make_batch_np(n_queries: int, lq: int, windows_per_query: int, seed: int, al
         src = np.arange(ls)[None, :] - b + shift
         inside = (src >= 0) & (src < lq) & ~ins
         copied = q_idx[hq[:, None], np.clip(src, 0, lq - 1)]
-        if bisulfite == "fwd":    # C->T conversion of the read relative to the genome: genome keeps C where the read has T
-            pass
         sub = rng.random((nh, ls)) < sub_rate
         keep = inside & ~sub
         rows = w_idx[homolog]
@@ -65,6 +70,9 @@ def make_batch_np(n_queries: int, lq: int, windows_per_query: int, seed: int, al
 
     q_res = alphabet[q_idx].astype(np.uint8)
     s_res = alphabet[w_idx].astype(np.uint8)
+    if convert:
+        frm, to = CONVERSIONS[convert]
+        q_res[(q_res == frm) & (rng.random(q_res.shape) < convert_rate)] = to
     if n_rate > 0:
         q_res[rng.random(q_res.shape) < n_rate] = n_rank
         s_res[rng.random(s_res.shape) < n_rate] = n_rank
@@ -110,7 +118,8 @@ def make_ragged_np(n_ext: int, seed: int, alphabet: np.ndarray = STD20, lq_range
 
 def make_batch_torch(n_queries: int, lq: int, windows_per_query: int, seed: int, device, alphabet: np.ndarray = STD20,
                      homolog_frac: float = 0.5, sub_rate: float = 0.25, indel_rate: float = 0.02,
-                     n_rate: float = 0.0, n_rank: int = 4, chunk_queries: int = 8192):
+                     n_rate: float = 0.0, n_rank: int = 4, chunk_queries: int = 8192, convert: str | None = None,
+                     convert_rate: float = 0.99):
     """Same workload as make_batch_np, generated directly on `device` (torch).  Returns torch tensors
     (q_res u8 [n_queries*lq], s_res u8 [n_ext*ls], ext u8 view of EXT_DTYPE records [n_ext*24])."""
     import torch
@@ -145,6 +154,9 @@ def make_batch_torch(n_queries: int, lq: int, windows_per_query: int, seed: int,
         w_idx = torch.where(keep, copied, w_idx)
         qr = alpha[q_idx].to(torch.uint8)
         sr = alpha[w_idx].to(torch.uint8)
+        if convert:
+            frm, to = CONVERSIONS[convert]
+            qr[(qr == frm) & (torch.rand(qr.shape, generator=gen, device=device) < convert_rate)] = to
         if n_rate > 0:
             qr[torch.rand(qr.shape, generator=gen, device=device) < n_rate] = n_rank
             sr[torch.rand(sr.shape, generator=gen, device=device) < n_rate] = n_rank
