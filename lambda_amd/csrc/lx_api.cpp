@@ -107,7 +107,7 @@ struct lx_handle
     DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_db;
     // multi-panel carry workspace
     DevBuf     d_ws;
-    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag, [2..3] = MaxLens, [4] = overflow checkpoint slots handed out
+    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag, [2..3] = MaxLens, [4] = overflow checkpoint slots handed out, [5] = backtrace work queue
     // options
     uint64_t opt_max_qlen  = 0;
     uint64_t opt_query_run = 0;
@@ -1253,6 +1253,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
         p.bs_match_rule  = (int32_t)h->opt_bs_rule;
+        p.work_counter   = h->d_ws_top + 5;
         p.shared_profile = share_slots;
         p.cfg            = cfg;
         if (nchunks >= 2) // buffer b is free once the backtrace of chunk k-2 has finished
@@ -1751,6 +1752,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.err           = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows         = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
         p.bs_match_rule = (int32_t)h->opt_bs_rule;
+        p.work_counter  = h->d_ws_top + 5;
         p.cfg           = sweep_cfg;
         p.slot_by_src   = 1;
         p.out_by_pos    = by_pos ? 1 : 0;

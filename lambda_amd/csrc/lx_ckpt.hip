@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "lx_dp_common.h"
 
@@ -517,69 +518,86 @@ LX_CKPT_UNROLL_PRAGMA
     }
 }
 
-// One lane per extension: recompute the tile around the current cell, walk it, repeat.
-// The tile DP uses the tagged arithmetic of lx_trace.hip (values x 4, the two low bits resolve the traceback ties) in
-// its plain, un-skewed form:  tt = 4 H(i-1,j-1) + (4 s + 3);  m = max3(tt, E|1, F|2);  H = m & ~3;  A = H + 4 go;
-// Fr = max3(F + 4 ge, A, 0), F' = Fr | 2;  Er = max(E + 4 ge, A), E' = Er | 1;  nibble = tag(m) | (Fr|Er)&3 << 2.
+// Backtrace: one lane per extension AT A TIME, lanes are persistent -- a lane that has finished its extension takes the
+// next one from a device-side queue (p.work_counter), so the lockstep of a wavefront costs the average walk, not the
+// slowest of 64.  Two ways forward from the current cell (i, j), both reproducing the forward pass's decisions exactly:
+//
+//   (1) Diagonal shortcut (no DP).  The slot holds H on every tile border: H(row, last column of a strip) for every row
+//       (boundary array) and H(last row of a step block, column) for every column (row checkpoints).  In state "H", walk
+//       the diagonal from (i, j) to the border cell (i - k, j - k) of the tile, summing the substitution scores.  The
+//       recurrence gives H(a) >= H(b) + S(b -> a) for every diagonal piece and H >= 0, hence with L_t = H(i, j) - (sum of
+//       the first t scores) >= H(i - t, j - t):
+//         * L_k == H(border cell)  =>  every inequality on the piece is an equality, i.e. at every cell of it the diagonal
+//           candidate equals H; the traceback prefers the diagonal on ties (GapsLeft: diagonal > vertical > horizontal,
+//           /root/reference/src/search_algo.hpp:1083), so the walk IS this diagonal: k columns 'M', no tile needed;
+//         * L_t == 0 for some t  =>  H(i - t, j - t) = 0 exactly (it is >= 0 and <= L_t): the alignment begins after that
+//           cell, the t cells before it are the walk.
+//       Anything else (a gap or another path inside this tile) leaves the lane "blocked" for
+//   (2) the tile recomputation of the first version of this kernel: the 16 x C tile of (strip, step block) from the
+//       checkpoint above it and the boundary array of the strip to its left, tagged arithmetic of lx_trace.hip (values
+//       x 4, the two low bits resolve the traceback ties) in its plain, un-skewed form:
+//           tt = 4 H(i-1,j-1) + (4 s + 3);  m = max3(tt, E|1, F|2);  H = m & ~3;  A = H + 4 go;
+//           Fr = max3(F + 4 ge, A, 0), F' = Fr | 2;  Er = max(E + 4 ge, A), E' = Er | 1;  nibble = tag(m) | (Fr|Er)&3 << 2
+//       nibbles in LDS, walked until the walk leaves the tile.  Needed for the first tile of a single-sweep extension
+//       (its end column is still open), for tiles with gaps, and while the walk is inside a gap.
+// Per outer iteration: shortcut phase (lanes run diagonals until blocked or finished) -> finished lanes are retired and
+// refilled -> one tile phase for every lane that needs it (new extensions start with one).  On the headline batch an
+// alignment crosses ~17 tiles and has ~3 gaps: ~5 tile phases per extension instead of 17-18.
 template <int G, int C>
 __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 {
     using Lay               = CkptLayout<G, C>;
+    using L16               = Ckpt16Layout<G, C>;
     constexpr int kNibDw    = (C + 7) / 8; // dwords of direction nibbles per tile row
     constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions (multiple of 4)
+    static_assert(kCkptEvery == 16, "the diagonal shortcut reads at most 16 residues per sequence");
     __shared__ int8_t   smat4[kAlph * kAlph]; // 4 s + 3: diagonal step of the tile DP with its tag (the walk divides it back)
+    __shared__ int8_t   smat1[kAlph * kAlph]; // s itself, for the diagonal shortcut
     __shared__ uint32_t tiles[kCkptEvery * kNibDw * 64]; // [tile row][word][lane]: lane-minor, conflict-free
     for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x)
     {
         int const v = p.sc->mat[x];
         smat4[x]    = (int8_t)((v < -32 || v > 31) ? -125 : 4 * v + 3); // pad ranks (and entries pass 2 does not admit) far down
+        smat1[x]    = (int8_t)v;
     }
     __syncthreads();
     uint32_t const lane  = threadIdx.x;
-    uint64_t const e     = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t       limit = p.n;
     if (p.count_ptr)
     {
         uint64_t const total = *p.count_ptr;
         limit = total > p.chunk_start ? min(p.n, total - p.chunk_start) : 0;
     }
-    if (e >= limit)
-        return;
-    uint64_t oi = e;
-    if (p.src)
-    {
-        uint32_t const sidx = p.src[e];
-        if (sidx == 0xffffffffu)
-            return; // padding slot
-        oi = sidx;
-    }
-    uint64_t const po = p.out_by_pos ? e : oi; // where this extension's record and ops slot are
-    uint64_t const  se = p.slot_by_src ? oi : e; // single-sweep mode: checkpoints and end cells sit at the original index
-    EndCell         ec = p.ends[se];
-    Extension const x  = p.ext[e];
-    Hsp             out{};
-    if (ec.score <= 0)
-    {
-        out.score = ec.score < 0 ? -1 : 0;
-        p.out_hsp[po] = out;
-        return;
-    }
+    int const ge = p.sc->ge, g2 = p.sc->g2;                 // a gap of k characters costs g2 + k ge
+    int const ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go;       // tile DP: values x 4 (go = first gap character)
+    uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
+
+    // ---- state of the extension this lane is working on
+    bool             have = false, blocked = false, done = false, need_col = false, c16 = false;
+    uint64_t         po = 0;          // where the extension's record and ops slot are
+    EndCell          ec{};
+    uint32_t const * slot = nullptr;
+    uint8_t const *  q = nullptr, * s = nullptr;
+    uint8_t *        ops_al = nullptr;
+    uint32_t         cap = 0, a0 = 0, apos = 0, acc = 0, n = 0;
+    int              lq = 0, ls = 0;
+    int              i = 0, j = 0, end_i = 0, end_j = 0;
+    int              res_col = C, res_row = 0x7fffffff; // resolution of the end cell inside the first tile
+    int              mode = 0;                          // 0 = H, 1 = F (vertical), 2 = E (horizontal)
+    int              left = 0;
+    int32_t          nm = 0, nx = 0, np = 0, go = 0, gx = 0;
+
     // Checkpoint words are int16 pairs (value, gap state).  Slots written by the packed-half sweep hold the compact
     // codes of Ckpt16Layout instead: the loaders below expand them to the same pairs.  An extension that sweep declined
     // has an int16-pair slot of its own in the overflow area.
-    using L16            = Ckpt16Layout<G, C>;
-    bool const     c16   = (ec.flags & kEndCompact) != 0;
-    uint32_t const ovf   = (uint32_t)ec.flags >> kEndOverflowShift;
     auto dec = [](uint32_t bits16) -> int { return (int)(int16_t)bits16; };
     auto expand = [](uint32_t code16) -> uint32_t
     {
         uint32_t const H = code16 & 0x7ffu;
         return H | ((H - (code16 >> 11)) << 16);
     };
-    uint32_t const * slot = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
     // A query wider than one panel has one part per panel in its slot (int16 pairs only): global strip st = panel * G +
     // lane; a strip's step for row r is r + lane.
-    uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
     auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (c16 ? 0 : (uint64_t)pn * panel_dw)); };
     auto rowck_of = [&](uint32_t pn)
     {
@@ -598,101 +616,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             return expand(reinterpret_cast<uint16_t const *>(bnd_of(0) + L16::bnd_oct_index(k / 8, st))[k & 7]);
         return reinterpret_cast<uint32_t const *>(bnd_of(st / G) + bnd_quad_index<G>(k / 4, st % G))[k & 3];
     };
-    uint8_t const *  q     = p.q_res + x.q_off;
-    uint8_t const *  s     = p.s_res + x.s_off;
-    uint8_t *        ops   = p.out_ops + p.ops_off[po];
-    uint32_t const   cap   = x.q_len + x.s_len;
-    int const        lq    = (int)x.q_len;
-    int const        ge = p.sc->ge, g2 = p.sc->g2;    // a gap of k characters costs g2 + k ge
-    int              ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go; // tile DP: values x 4 (go = first gap character)
-
-    int      i = ec.s_end - 1, j = ec.q_end - 1;
-    // single-sweep mode: only the strip of the end cell is known (ec.q_end = -(strip + 1)).  The column is read off the
-    // first tile (its last computed row is the end row); if the strip reached the best score in several rows, a plain
-    // re-run of the strip from the checkpoint above the first such row finds the cell the tie rule wants first.
-    bool need_col = ec.q_end < 0;
-    if (need_col)
-    {
-        int const st = -ec.q_end - 1;
-        j            = st * C + (C - 1); // provisional: the whole strip is computed
-        if (ec.flags & kEndAmbiguous)
-        {
-            int const go1 = p.sc->go;
-            int const gl  = st % G, gL = (st - 1 + G) % G; // lanes of this strip and of its left neighbour
-            int const m0  = (i + gl) / kCkptEvery;
-            int       Hp[C], F[C];
-            if (m0 == 0)
-            {
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    Hp[c] = F[c] = 0;
-            }
-            else
-            {
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                {
-                    uint32_t const w = rowck_word((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)c);
-                    Hp[c]            = dec(w & 0xffffu);
-                    F[c]             = dec(w >> 16);
-                }
-            }
-            int qr[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-                qr[c] = (st * C + c < lq) ? (int)(q[st * C + c] & (kAlph - 1)) * kAlph : (kAlph - 1) * kAlph;
-            auto bnd_word = [&](int k) -> uint32_t // boundary word of strip st - 1 at step k
-            { return bnd_word_of((uint32_t)(st - 1), (uint32_t)k); };
-            int const target = ec.score;
-            int       kcol = C, krow = i;
-            for (int r = max(m0 * kCkptEvery - gl, 0); r < (int)x.s_len; ++r)
-            {
-                int const tl = s[r] & (kAlph - 1);
-                int       E  = kFar, Hd = 0;
-                if (st > 0)
-                {
-                    E = dec(bnd_word(r + gL) >> 16);
-                    if (r > 0)
-                        Hd = dec(bnd_word(r + gL - 1) & 0xffffu);
-                }
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                {
-                    int const v  = ((int)smat4[qr[c] + tl] - 3) >> 2;
-                    int const tt = Hd + v;
-                    Hd           = Hp[c];
-                    int const H  = max3i(tt, E, F[c]);
-                    int const A  = H + go1;
-                    F[c]         = max3i(F[c] + ge, A, 0);
-                    E            = max(E + ge, A);
-                    Hp[c]        = H;
-                    if (H == target && c < kcol) // lowest column wins; rows ascend, so its first hit is its lowest row
-                    {
-                        kcol = c;
-                        krow = r;
-                    }
-                }
-            }
-            if (kcol < C)
-            {
-                i        = krow;
-                j        = st * C + kcol;
-                need_col = false;
-            }
-            // (kcol == C cannot happen: the forward pass saw the score in this strip; the tile path below then flags it)
-        }
-    }
-    int end_i = i, end_j = j; // final once need_col is false
-    int res_col = C, res_row = 0x7fffffff; // resolution of the end cell inside the first tile
-    int      mode = 0; // 0 = H, 1 = F (vertical), 2 = E (horizontal)
-    int      left = ec.score;
-    uint32_t n    = 0;
-    int32_t  nm = 0, nx = 0, np = 0, go = 0, gx = 0;
-
-    uint32_t const  a0     = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
-    uint8_t * const ops_al = ops - a0;
-    uint32_t        apos   = a0 + cap - 1;
-    uint32_t        acc    = 0;
+    // ops are produced end -> begin into the slot [0, cap): apos = misalignment of the slot start + offset of the next byte
     auto emit = [&](uint32_t op)
     {
         acc |= op << (8 * (apos & 3));
@@ -709,9 +633,305 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         ++n;
     };
 
-    bool done = false;
-    while (!done && i >= 0 && j >= 0 && n < cap)
+    // ---- a lane takes list position e: end cell, slot, sequences, ops slot; single-sweep extensions whose strip tied
+    // get their end cell resolved right here
+    auto begin_extension = [&](uint64_t e)
     {
+        uint64_t oi = e;
+        if (p.src)
+        {
+            uint32_t const sidx = p.src[e];
+            if (sidx == 0xffffffffu)
+                return; // padding slot
+            oi = sidx;
+        }
+        po                 = p.out_by_pos ? e : oi;
+        uint64_t const  se = p.slot_by_src ? oi : e; // single-sweep mode: checkpoints and end cells sit at the original index
+        ec                 = p.ends[se];
+        Extension const x  = p.ext[e];
+        if (ec.score <= 0)
+        {
+            Hsp out{};
+            out.score     = ec.score < 0 ? -1 : 0;
+            p.out_hsp[po] = out;
+            return;
+        }
+        c16                = (ec.flags & kEndCompact) != 0;
+        uint32_t const ovf = (uint32_t)ec.flags >> kEndOverflowShift;
+        slot               = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
+        q                  = p.q_res + x.q_off;
+        s                  = p.s_res + x.s_off;
+        uint8_t * const ops = p.out_ops + p.ops_off[po];
+        cap                = x.q_len + x.s_len;
+        lq                 = (int)x.q_len;
+        ls                 = (int)x.s_len;
+        i                  = ec.s_end - 1;
+        j                  = ec.q_end - 1;
+        // single-sweep mode: only the strip of the end cell is known (ec.q_end = -(strip + 1)).  The column is read off the
+        // first tile (its last computed row is the end row); if the strip reached the best score in several rows, a plain
+        // re-run of the strip from the checkpoint above the first such row finds the cell the tie rule wants first.
+        need_col = ec.q_end < 0;
+        if (need_col)
+        {
+            int const st = -ec.q_end - 1;
+            j            = st * C + (C - 1); // provisional: the whole strip is computed
+            if (ec.flags & kEndAmbiguous)
+            {
+                int const go1 = p.sc->go;
+                int const gl  = st % G, gL = (st - 1 + G) % G; // lanes of this strip and of its left neighbour
+                int const m0  = (i + gl) / kCkptEvery;
+                int       Hp[C], F[C];
+                if (m0 == 0)
+                {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        Hp[c] = F[c] = 0;
+                }
+                else
+                {
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                    {
+                        uint32_t const w = rowck_word((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)c);
+                        Hp[c]            = dec(w & 0xffffu);
+                        F[c]             = dec(w >> 16);
+                    }
+                }
+                int qr[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    qr[c] = (st * C + c < lq) ? (int)(q[st * C + c] & (kAlph - 1)) * kAlph : (kAlph - 1) * kAlph;
+                int const target = ec.score;
+                int       kcol = C, krow = i;
+                for (int r = max(m0 * kCkptEvery - gl, 0); r < ls; ++r)
+                {
+                    int const tl = s[r] & (kAlph - 1);
+                    int       E  = kFar, Hd = 0;
+                    if (st > 0)
+                    {
+                        E = dec(bnd_word_of((uint32_t)(st - 1), (uint32_t)(r + gL)) >> 16);
+                        if (r > 0)
+                            Hd = dec(bnd_word_of((uint32_t)(st - 1), (uint32_t)(r + gL - 1)) & 0xffffu);
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                    {
+                        int const v  = ((int)smat4[qr[c] + tl] - 3) >> 2;
+                        int const tt = Hd + v;
+                        Hd           = Hp[c];
+                        int const H  = max3i(tt, E, F[c]);
+                        int const A  = H + go1;
+                        F[c]         = max3i(F[c] + ge, A, 0);
+                        E            = max(E + ge, A);
+                        Hp[c]        = H;
+                        if (H == target && c < kcol) // lowest column wins; rows ascend, so its first hit is its lowest row
+                        {
+                            kcol = c;
+                            krow = r;
+                        }
+                    }
+                }
+                if (kcol < C)
+                {
+                    i        = krow;
+                    j        = st * C + kcol;
+                    need_col = false;
+                }
+                // (kcol == C cannot happen: the forward pass saw the score in this strip; the tile path below then flags it)
+            }
+        }
+        end_i = i; // final once need_col is false
+        end_j = j;
+        res_col = C;
+        res_row = 0x7fffffff;
+        mode = 0;
+        left = ec.score;
+        n    = 0;
+        nm = nx = np = go = gx = 0;
+        a0     = (uint32_t)(reinterpret_cast<uintptr_t>(ops) & 3);
+        ops_al = ops - a0;
+        apos   = a0 + cap - 1;
+        acc    = 0;
+        have    = true;
+        done    = false;
+        blocked = false;
+    };
+
+    // ---- the record of a finished extension
+    auto finish_extension = [&]()
+    {
+        if (mode != 0)
+            go += 1; // ran into the border right after a gap character: it can only have been an opening
+        if ((apos & 3) != 3)
+            for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
+                ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
+        Hsp out{};
+        if (ec.score < 0)
+            out.score = -1;
+        else
+        {
+            out.score              = ec.score;
+            out.q_begin            = j + 1;
+            out.q_end              = end_j + 1;
+            out.s_begin            = i + 1;
+            out.s_end              = end_i + 1;
+            out.n_ops              = (int32_t)n;
+            out.num_matches        = nm;
+            out.num_mismatches     = nx;
+            out.num_positives      = np;
+            out.num_gap_opens      = go;
+            out.num_gap_extensions = gx;
+            out.ops_shift          = (int32_t)(cap - n);
+        }
+        p.out_hsp[po] = out;
+        have          = false;
+    };
+
+    bool queue_empty = false; // wave-uniform
+    for (;;)
+    {
+        // ================= (1) diagonal shortcuts, until every lane is blocked, finished or idle
+        for (;;)
+        {
+            bool const can = have && !done && !blocked && !need_col && mode == 0 && i >= 0 && j >= 0 && n < cap;
+            if (__ballot(can) == 0)
+                break;
+            if (can)
+            {
+                int const st = j / C, j0 = st * C, c = j - j0;
+                int const gl = st % G;
+                int const m  = (i + gl) / kCkptEvery;
+                int const r_base = m * kCkptEvery - gl;       // row of tile row 0
+                int const kt = i - r_base + 1, kl = c + 1;    // diagonal steps to the row above the tile / the column left of it
+                int const k  = min(min(kt, kl), i + 1);       // 1 .. 16; never above the matrix (block 0 has virtual rows)
+                int const bi = i - k, bj = j - k;             // the border cell
+                int       Hb = 0;                             // (beyond the matrix: H = 0)
+                if (bi >= 0 && bj >= 0)
+                {
+                    uint32_t const w = (kl <= kt) ? bnd_word_of((uint32_t)(st - 1), (uint32_t)(bi + (st - 1) % G))
+                                                  : rowck_word((uint32_t)(m - 1), (uint32_t)st, (uint32_t)(bj - j0));
+                    Hb               = dec(w & 0xffffu);
+                }
+                // the residues of the diagonal piece: q[j - k + 1 .. j], s[i - k + 1 .. i] (256 bytes of slack behind the buffers)
+                uint32_t qw[4], sw[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                {
+                    qw[d] = *reinterpret_cast<unaligned_u32 const *>(q + (j - k + 1) + 4 * d);
+                    sw[d] = *reinterpret_cast<unaligned_u32 const *>(s + (i - k + 1) + 4 * d);
+                }
+                // One pass over the (at most 16) cells, entry cell first: L = H the diagonal piece implies for the cell
+                // at hand.  `stopped` = some cell before this one had L == 0 (the alignment begins after that cell).
+                // Everything per cell is a compare feeding a carry or a select: no branches, few VALU slots.
+                int      L = left, cnt = 0;
+                int32_t  tp = 0, tmb = 0;
+                bool     stopped = false;
+                bool const bs = p.bs_match_rule != 0; // (uniform)
+#pragma unroll
+                for (int u = kCkptEvery - 1; u >= 0; --u) // cell (i - t, j - t) is byte u = k - 1 - t of the pieces
+                {
+                    uint32_t const c0 = (qw[u >> 2] >> (8 * (u & 3))) & (kAlph - 1), c1 = (sw[u >> 2] >> (8 * (u & 3))) & (kAlph - 1);
+                    int const      v  = (int)smat1[c0 * kAlph + c1];
+                    bool const     in = u < k;
+                    stopped           = stopped || (in && L <= 0); // H of this cell is 0
+                    bool const take   = in && !stopped;
+                    L -= take ? v : 0;
+                    cnt += take ? 1 : 0;
+                    tp += (take && v > 0) ? 1 : 0;
+                    if (bs) // the bisulfite overload of computeAlignmentStats: a match scores what the letter scores with itself
+                        tmb += (take && v == (int)smat1[c0 * kAlph + c0]) ? 1 : 0;
+                }
+                // L < 0 cannot happen (L_t >= H >= 0); were it to, the piece is left to the tile DP, never guessed
+                bool const ok = stopped ? (L == 0) : (L == Hb);
+                if (ok)
+                {
+                    // identical letters among the cnt cells taken = bytes [k - cnt, k) of the two pieces (ranks < 32 by
+                    // contract; masked like everywhere else): zero bytes of the XOR, counted four at a time
+                    int32_t tm = tmb;
+                    if (!bs)
+                    {
+                        int const lo = k - cnt;
+#pragma unroll
+                        for (int d = 0; d < 4; ++d)
+                        {
+                            uint32_t const x   = (qw[d] ^ sw[d]) & 0x1f1f1f1fu;
+                            uint32_t const nz  = (x + 0x7f7f7f7fu) & 0x80808080u;  // bit 7 of every non-zero byte (bytes < 0x80)
+                            int const      b0  = max(lo - 4 * d, 0), b1 = min(k - 4 * d, 4); // bytes [b0, b1) of this dword count
+                            uint32_t const msk = b1 > b0 ? ((b1 >= 4 ? 0xffffffffu : ((1u << (8 * b1)) - 1u)) & ~((1u << (8 * b0)) - 1u)) : 0u;
+                            tm += __popc(~nz & 0x80808080u & msk);
+                        }
+                    }
+                    left = L;
+                    nm += tm;
+                    nx += cnt - tm;
+                    np += tp;
+                    // cnt bytes 'M' below apos, whole dwords at a time
+                    {
+                        uint32_t const hi = apos, lo = apos + 1 - (uint32_t)cnt; // byte positions [lo, hi] (cnt >= 1 here or skipped)
+                        if (cnt > 0)
+                        {
+                            for (uint32_t D = hi & ~3u;; D -= 4)
+                            {
+                                uint32_t const b0  = lo > D ? lo - D : 0, b1 = min(hi - D, 3u);   // bytes b0 .. b1 of dword D
+                                uint32_t const msk = (b1 >= 3 ? 0xffffffffu : ((1u << (8 * (b1 + 1))) - 1u)) & ~((1u << (8 * b0)) - 1u);
+                                acc |= 0x4d4d4d4du & msk;
+                                if (b0 == 0 && lo <= D) // byte 0 of the dword written: the dword is complete
+                                {
+                                    if (D + 3 <= a0 + cap - 1)
+                                        *reinterpret_cast<uint32_t *>(ops_al + D) = acc;
+                                    else
+                                        for (uint32_t b = 0; b < 4 && D + b <= a0 + cap - 1; ++b)
+                                            ops_al[D + b] = (uint8_t)(acc >> (8 * b));
+                                    acc = 0;
+                                }
+                                if (D <= lo || D < 4)
+                                    break;
+                            }
+                            apos -= (uint32_t)cnt;
+                            n += (uint32_t)cnt;
+                        }
+                    }
+                    i -= cnt;
+                    j -= cnt;
+                    done = stopped;
+                }
+                else
+                    blocked = true;
+            }
+        }
+
+        // ================= retire and refill
+        if (have && (done || i < 0 || j < 0 || n >= cap))
+            finish_extension();
+        if (!queue_empty)
+        {
+            uint64_t const want = __ballot(!have);
+            if (want != 0)
+            {
+                uint32_t  base   = 0;
+                int const leader = __ffsll((unsigned long long)want) - 1;
+                if ((int)lane == leader)
+                    base = atomicAdd(p.work_counter, (uint32_t)__popcll(want));
+                base = (uint32_t)__shfl((int)base, leader);
+                if ((uint64_t)base + (uint32_t)__popcll(want) >= limit)
+                    queue_empty = true;
+                if (!have)
+                {
+                    uint64_t const e = (uint64_t)base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                    if (e < limit)
+                        begin_extension(e);
+                }
+            }
+        }
+        if (__ballot(have) == 0)
+            break;
+
+        // ================= (2) one tile for every lane that cannot go on without it
+        bool const tile_now = have && !done && i >= 0 && j >= 0 && n < cap && (blocked || need_col || mode != 0);
+        if (__ballot(tile_now) == 0)
+            continue;
+        if (tile_now)
+        {
         // ---- the tile of the current cell: strip st, step block m (step k = row + strip)
         int const st = j / C, j0 = st * C;
         int const pn = st / G, gl = st % G; // panel and lane of this strip (one panel: gl = st)
@@ -864,7 +1084,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
-                if (need_col && row >= i - 3 && row < (int)x.s_len)
+                if (need_col && row >= i - 3 && row < ls)
                 {
                     // lowest column of this row whose H equals the score (no H exceeds it: H - score <= 0, a multiple of 4
                     // after the tags are masked), as a maximum of keys without compares: key = (H - score) * 32 + (C - c)
@@ -883,6 +1103,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             qcur  = qnext;
         }
 
+        bool walk_ok = true;
         if (need_col)
         {
             // the end row is one of the last four computed rows (the packed-half sweep reports the chunk, the int32 sweep
@@ -893,18 +1114,21 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 done     = true; // the forward pass saw this score in these rows of the strip: never guess
                 left     = -1;
                 ec.score = -1;
-                break;
+                walk_ok  = false;
             }
-            i     = res_row;
-            j     = j0 + res_col;
-            end_i = i;
-            end_j = j;
+            else
+            {
+                i     = res_row;
+                j     = j0 + res_col;
+                end_i = i;
+                end_j = j;
+            }
         }
         // ---- walk inside the tile.  Written with selects instead of nested branches: one data-dependent exit (the
         // alignment's first cell), everything else is arithmetic on the nibble -- bit 3 / bit 2 = the vertical /
         // horizontal gap state extends, low two bits = where H came from (3 diagonal, 2 vertical, 1 horizontal).
         static_assert(32 - 4 * (C - 8 * (kNibDw - 1)) >= 5, "the last nibble word needs 5 spare bits for the subject letter");
-        while (i >= 0 && j >= j0 && i >= r_base && n < cap)
+        while (walk_ok && i >= 0 && j >= j0 && i >= r_base && n < cap)
         {
             int const      kk   = i - r_base, c = j - j0;
             int const      xw   = c >> 3;
@@ -943,33 +1167,9 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             i -= (diag || vert) ? 1 : 0;
             j -= (diag || !vert) ? 1 : 0;
         }
+        blocked = false;
+        } // tile_now
     }
-    if (mode != 0)
-        go += 1; // ran into the border right after a gap character: it can only have been an opening
-    if ((apos & 3) != 3)
-        for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
-            ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
-
-    if (ec.score < 0)
-    {
-        Hsp failed{};
-        failed.score  = -1;
-        p.out_hsp[po] = failed;
-        return;
-    }
-    out.score              = ec.score;
-    out.q_begin            = j + 1;
-    out.q_end              = end_j + 1;
-    out.s_begin            = i + 1;
-    out.s_end              = end_i + 1;
-    out.n_ops              = (int32_t)n;
-    out.num_matches        = nm;
-    out.num_mismatches     = nx;
-    out.num_positives      = np;
-    out.num_gap_opens      = go;
-    out.num_gap_extensions = gx;
-    out.ops_shift          = (int32_t)(cap - n);
-    p.out_hsp[po]          = out;
 }
 
 // ---- host-visible launchers: checkpoint geometries follow the trace geometries (cfg 1 = (8,19), cfg 2 = (16,13)) --------
@@ -1014,11 +1214,31 @@ hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream)
     return p.cfg == 2 ? launch_ckpt_forward_cfg<16, 13>(p, stream) : launch_ckpt_forward_cfg<8, 19>(p, stream);
 }
 
+static int backtrace_resident_waves()
+{
+    static int const v = []()
+    {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        char const * e = getenv("LX_BT_WAVES_PER_CU"); // development aid
+        return std::max(1, cus) * (e ? std::max(1, atoi(e)) : 12);
+    }();
+    return v;
+}
+
 hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    uint64_t const b2 = (p.n + 63) / 64;
+    if (!p.work_counter)
+        return hipErrorInvalidValue;
+    // persistent lanes: as many wavefronts as the chip holds at this kernel's occupancy (3 per SIMD), each taking
+    // extensions from the queue until it is empty
+    uint64_t const b2 = std::min<uint64_t>((p.n + 63) / 64, (uint64_t)backtrace_resident_waves());
+    hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
     if (p.cfg == 2)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<16, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else

@@ -154,6 +154,7 @@ struct TraceParams
     uint64_t           ovf_stride;
     uint32_t           ovf_cap;
     uint32_t *         ovf_count;     // device counter of handed-out overflow slots
+    uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,
