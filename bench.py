@@ -68,6 +68,8 @@ def parse(argv=None):
     ap.add_argument("--max-evalue", type=float, default=None)
     ap.add_argument("--max-matches", type=int, default=25, help="HSPs kept per query for the final gather (maxMatches)")
     ap.add_argument("--trace-bytes", type=int, default=160 << 30, help="LX_OPT_TRACE_BYTES: HBM the checkpoint slots may take")
+    ap.add_argument("--band", type=int, default=0, help="band mode (LX_OPT_BAND, not the reference's configuration): half width in "
+                    "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
     return ap.parse_args(argv)
 
@@ -211,7 +213,7 @@ def dry_run(args, w, world, rank):
 class DevBatch:
     """One device call's inputs and outputs, resident in HBM."""
 
-    def __init__(self, w, b, dev, min_score):
+    def __init__(self, w, b, dev, min_score, band=0):
         import torch
 
         from lambda_amd import synth, workloads
@@ -227,7 +229,7 @@ class DevBatch:
         self.d_s = torch.cat([d_s, pad])
         self.n = n = len(ext)
         self.max_slen = int(ext["s_len"].max())
-        self.cells = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
+        self.cells = float((ext["q_len"].astype(np.float64) * (np.minimum(ext["s_len"], 2 * band + 1) if band > 0 else ext["s_len"])).sum())
         self.q_bytes, self.s_bytes = float(ext["q_len"].sum()) / w.windows, float(ext["s_len"].sum())
         self.d_score = torch.zeros(n, dtype=torch.int32, device=dev)
         # pass-2 outputs (worst case sizes: every extension may survive)
@@ -281,6 +283,8 @@ def main():
     h.set_option(capi.LX_OPT_MAX_QLEN, w.lq)
     h.set_option(capi.LX_OPT_QUERY_RUN, w.windows if w.windows % 8 == 0 else 0)
     h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+    if args.band > 0:
+        h.set_band(args.band)  # default centres: min(_bandSize(Lq), Ls - Lq), the seed diagonal of the synthetic windows
     ka = capi.karlin_params(*w.karlin)
     lib = capi.load()
     adj = lib.lx_length_adjustment(w.db_length, w.lq, C.byref(ka))
@@ -289,7 +293,7 @@ def main():
         min_score += 1
 
     # ---- workload, generated directly in HBM; every rank owns different queries (shard by query)
-    batches = [DevBatch(w, b, dev, min_score) for b in pl.batches]
+    batches = [DevBatch(w, b, dev, min_score, args.band) for b in pl.batches]
     if not batches:
         raise SystemExit(f"rank {rank}: no queries to process (job of {pl.job_queries} queries over {world} ranks)")
     h.set_option(capi.LX_OPT_MAX_SLEN, max(b.max_slen for b in batches))
@@ -435,7 +439,9 @@ def main():
         rooflines.sort(key=lambda r: -r["kernel_ms_per_launch"])
         packed_name = "score_pair_kernel" in kernel_name
         out = {
-            "metric": "GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) "
+            "metric": ("GCUPS (gapped extension, full-rectangle parity mode; pass-1 cells per second of whole step) " if args.band <= 0 else
+                       f"GCUPS (gapped extension, BAND MODE band={args.band}: cells = sum Lq*min(Ls, 2*band+1); not the reference's "
+                       f"configuration, never to be mixed with the parity line) ")
                       + ("searchp BLOSUM62" if w.program == "blastp" else w.name),
             "value": round(gcups, 2),
             "unit": "GCUPS",
@@ -450,8 +456,11 @@ def main():
                       "i16x2 (packed 16-bit integers) + int32" if "pair16" in kernel_name else "int32"),
             "data": "synthetic",
             "config": {
-                "workload": workloads.describe(w),
+                "workload": workloads.describe(w) if args.band <= 0 else
+                            workloads.describe(w).replace("cells = sum Lq*Ls (full rectangle, band off as in the reference)",
+                                                          f"band={args.band} around the seed diagonal: cells = sum Lq*min(Ls, {2 * args.band + 1})"),
                 "baseline_config": args.config,
+                "band": args.band,
                 "job_queries": pl.job_queries,
                 "queries_rank0": pl.n_queries,
                 "device_calls_per_step_rank0": len(batches),

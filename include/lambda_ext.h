@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LX_ABI_VERSION 1
+#define LX_ABI_VERSION 2
 #define LX_ALPH 32 /* matrix stride; alphabet_size <= 31, rank 31 is reserved as padding */
 
 enum
@@ -126,7 +126,7 @@ enum
     LX_OPT_PACKED_HALF     = 7, /* 1 (default): the packed kernels (two extensions per lane group: half precision, or
                                    16-bit integers for wider queries) run where a per-wavefront score bound proves them
                                    exact (results are bit-identical either way); 0: int32 kernels only */
-    LX_OPT_PASS2_MODE      = 8  /* how pass 2 keeps what the traceback needs (results are bit-identical in every mode):
+    LX_OPT_PASS2_MODE      = 8, /* how pass 2 keeps what the traceback needs (results are bit-identical in every mode):
                                    0 = 4 direction bits per cell of every survivor;
                                    1 = strip boundaries + row checkpoints of every survivor, tiles recomputed by the
                                        backtrace -- where its limits hold (extensions in blocks of >= 4 per query,
@@ -136,10 +136,27 @@ enum
                                        applies, LX_OPT_QUERY_RUN is a multiple of 8 and the checkpoints of the whole
                                        batch (7.7 KB per 150 x 176 extension as compact codes of the packed-half kernel,
                                        13.5 KB as int16 pairs) fit LX_OPT_TRACE_BYTES, else mode 1 */
+    LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
+                                   says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
+                                   parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of
+                                   the subject slice, column j of the query slice, 0-based) lies within b of the extension's
+                                   centre diagonal exist, as in a banded SeqAn alignment: cells off the band are never
+                                   computed, no gap runs through them.  Centres: lx_set_band_centres[_dev]; without them
+                                   min(_bandSize(q_len), s_len - q_len), the seed diagonal of a window built by _widenMatch
+                                   that was not clipped at the subject's start.  Applies to every score / align / extend entry
+                                   point; runs int32 kernels and direction bits (results are those of the oracle's
+                                   lxo_score_banded / lxo_align_banded), slower per cell than the full rectangle: at
+                                   150 x 176 with b = 64 the band removes 27 % of the cells and no step of the strip mapping */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 /* current value of an option (what the caller set or the default; never the library's internal growth of a workspace) */
 int lx_get_option(lx_handle const * h, int option, uint64_t * value);
+
+/* Band mode (LX_OPT_BAND > 0): centre diagonal of every extension of the NEXT host-buffer call, diag[i] for ext[i] (n must
+ * equal that call's n; diag = NULL, n = 0 returns to the default centres).  The *_dev calls read a device array of int32,
+ * one per extension, that must stay valid while they run (NULL = default centres). */
+int lx_set_band_centres(lx_handle * h, int32_t const * diag, uint64_t n);
+int lx_set_band_centres_dev(lx_handle * h, void const * d_diag);
 
 /* slot 0 = forward scheme, slot 1 = bisulfite reverse scheme (scoringSchemeAlignBSRev,
  * src/search_algo.hpp:1097-1098).  Must be called before any batch call using that slot. */
@@ -268,6 +285,9 @@ typedef struct lx_search_params
     int32_t   q_frame_mode;     /* LX_FRAMES_*: how _setFrames derives qFrameShift from the frame-expanded qryId            */
     int32_t   s_frame_mode;     /* same for sFrameShift / subjId                                                            */
     lx_karlin karlin;
+    int32_t   band;             /* 0: full rectangle, what the reference computes; b > 0: band mode (LX_OPT_BAND) with the default
+                                   centres for the duration of the call -- not a parity mode                               */
+    int32_t   reserved;
 } lx_search_params;
 
 /* ---- frame bookkeeping (_setFrames, _untrueQryId, _untrueSubjId; src/search_algo.hpp:768-814, :940-996) ------------

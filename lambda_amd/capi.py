@@ -22,7 +22,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 
 # every symbol include/lambda_ext.h declares (tests/test_abi.py checks that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option",
+    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_set_band_centres", "lx_set_band_centres_dev",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
     "lx_iterate_matches",
@@ -37,6 +37,7 @@ LX_OPT_TRACE_BYTES = 5
 LX_OPT_BS_MATCH_RULE = 6
 LX_OPT_PACKED_HALF = 7
 LX_OPT_PASS2_MODE = 8
+LX_OPT_BAND = 9
 
 
 class Karlin(C.Structure):
@@ -48,7 +49,7 @@ class SearchParams(C.Structure):
     _fields_ = [("max_evalue", C.c_double), ("min_bitscore", C.c_int32), ("id_cutoff", C.c_int32),
                 ("db_total_length", C.c_uint64), ("query_translated", C.c_int32), ("qry_num_frames", C.c_int32),
                 ("sbj_num_frames", C.c_int32), ("bisulfite", C.c_int32), ("q_frame_mode", C.c_int32),
-                ("s_frame_mode", C.c_int32), ("karlin", Karlin)]
+                ("s_frame_mode", C.c_int32), ("karlin", Karlin), ("band", C.c_int32), ("reserved", C.c_int32)]
 
 
 class IterateStats(C.Structure):
@@ -128,6 +129,8 @@ def load():
     lib.lx_last_error.restype = C.c_char_p
     lib.lx_set_option.argtypes = [vp, i32, u64]
     lib.lx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
+    lib.lx_set_band_centres.argtypes = [vp, vp, u64]
+    lib.lx_set_band_centres_dev.argtypes = [vp, vp]
     lib.lx_set_scoring.argtypes = [vp, i32, C.POINTER(Scoring)]
     lib.lx_builtin_scoring.argtypes = [i32, i32, i32, i32, i32, C.POINTER(Scoring)]
     lib.lx_score_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp]
@@ -309,6 +312,18 @@ class Handle:
 
     def set_option(self, opt: int, value: int):
         self._check(self.lib.lx_set_option(self.h, opt, value))
+
+    def set_band(self, band: int, centres=None, d_centres=None):
+        """Band mode (LX_OPT_BAND): half width in diagonals (0 = off), optional per-extension centre diagonals for the next
+        host-buffer call (numpy int32) / for the *_dev calls (torch int32 tensor on the device)."""
+        self.set_option(LX_OPT_BAND, band)
+        if centres is None:
+            self._check(self.lib.lx_set_band_centres(self.h, None, 0))
+        else:
+            c = np.ascontiguousarray(centres, dtype=np.int32)
+            self._check(self.lib.lx_set_band_centres(self.h, _ptr(c), len(c)))
+        self._band_dev = d_centres  # keeps the tensor alive
+        self._check(self.lib.lx_set_band_centres_dev(self.h, d_centres.data_ptr() if d_centres is not None else None))
 
     def get_option(self, opt: int) -> int:
         v = C.c_uint64()

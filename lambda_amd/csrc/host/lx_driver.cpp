@@ -332,6 +332,20 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
             return LX_EINVAL;
     auto res = new lx_iterate_result();
     int  rc;
+    // band mode for the duration of the call (default centres: the windows are built here, by _widenMatch's rule)
+    uint64_t bandBefore = 0;
+    (void)lx_get_option(h, LX_OPT_BAND, &bandBefore);
+    struct RestoreBand
+    {
+        lx_handle * h;
+        uint64_t    v;
+        ~RestoreBand() { (void)lx_set_option(h, LX_OPT_BAND, v); }
+    } restoreBand{h, bandBefore};
+    if (params->band > 0 && (rc = lx_set_option(h, LX_OPT_BAND, (uint64_t)params->band)) != LX_OK)
+    {
+        delete res;
+        return rc;
+    }
     if (params->bisulfite)
     {
         // The bisulfite scheme type selects the computeAlignmentStats overload whose match test is

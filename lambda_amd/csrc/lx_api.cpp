@@ -117,6 +117,10 @@ struct lx_handle
     uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
+    uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
+    int32_t const * band_dev = nullptr;  // lx_set_band_centres_dev: the caller's device array for the *_dev calls
+    std::vector<int32_t> band_host;      // lx_set_band_centres: centres of the next host-buffer call's extensions
+    DevBuf   d_band;                     // ... uploaded
     uint64_t opt_pass2     = 2; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip), 2 = single sweep; each where applicable
     uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
@@ -374,6 +378,17 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
     p.fixup          = 0;
     p.pair_share     = pair_share;
     char buf[128];
+    if (h->opt_band)
+    {
+        // band mode: the int32 kernel of the generic geometry, any query width (the packed kernels carry no band code)
+        p.band           = (int32_t)h->opt_band;
+        p.band_diag      = h->band_dev;
+        p.shared_profile = 0;
+        LX_HIP(h, lx::launch_score(0, p, true, stream));
+        snprintf(buf, sizeof(buf), "lx::score_kernel<16,10,true,band> (band mode, +-%d diagonals)", p.band);
+        h->last_kernel = buf;
+        return LX_OK;
+    }
     if (pair_cfg == kPair16)
     {
         // queries wider than the packed-half geometries: packed 16-bit integers (lx_score_i16.hip), panel by panel; what
@@ -465,6 +480,11 @@ static void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
         th.join();
 }
 
+static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                       lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
+                       int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
+                       uint64_t const * caller_ops_off, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
+
 extern "C" {
 
 int lx_abi_version(void)
@@ -550,7 +570,7 @@ void lx_destroy(lx_handle * h)
     if (h->stream)
         (void)hipStreamSynchronize(h->stream);
     for (DevBuf * b : {&h->d_q, &h->d_s, &h->d_ext, &h->d_out, &h->d_ops, &h->d_opsoff, &h->d_keep, &h->d_trace, &h->d_ends,
-                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_sel_score, &h->d_trace_score, &h->d_db, &h->d_ws})
+                       &h->d_hsp, &h->d_seeds, &h->d_sel_ext, &h->d_sel_src, &h->d_sel_runs, &h->d_sel_score, &h->d_trace_score, &h->d_db, &h->d_ws, &h->d_band})
         if (b->ptr)
             (void)hipFree(b->ptr);
     for (int s = 0; s < 2; ++s)
@@ -596,6 +616,11 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
         case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
+        case LX_OPT_BAND:
+            if (value > (1u << 20))
+                return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
+            h->opt_band = value;
+            return LX_OK;
         default: return fail(h, LX_EINVAL, "unknown option %d", option);
     }
 }
@@ -614,8 +639,25 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_BS_MATCH_RULE: *value = h->opt_bs_rule; return LX_OK;
         case LX_OPT_PACKED_HALF: *value = h->opt_f16; return LX_OK;
         case LX_OPT_PASS2_MODE: *value = h->opt_pass2; return LX_OK;
+        case LX_OPT_BAND: *value = h->opt_band; return LX_OK;
         default: return LX_EINVAL;
     }
+}
+
+int lx_set_band_centres(lx_handle * h, int32_t const * diag, uint64_t n)
+{
+    if (!h || (!diag && n))
+        return LX_EINVAL;
+    h->band_host.assign(diag, diag + n);
+    return LX_OK;
+}
+
+int lx_set_band_centres_dev(lx_handle * h, void const * d_diag)
+{
+    if (!h)
+        return LX_EINVAL;
+    h->band_dev = static_cast<int32_t const *>(d_diag);
+    return LX_OK;
 }
 
 int lx_builtin_scoring(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend,
@@ -779,7 +821,7 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
     bool const multi  = h->opt_max_qlen == 0 || h->opt_max_qlen > (uint64_t)lx::score_cfg_panel(cfg);
     // (the packed 16-bit kernel sweeps wide queries in (8,19) panels even where the int32 geometry is a single one)
     bool const wide16 = h->opt_f16 && h->opt_query_run % 16 == 0 && h->opt_query_run != 0 && h->opt_max_qlen > (uint64_t)lx::trace_cfg_panel(2);
-    if ((rc = prepare_workspace(h, stream, (multi || wide16) ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
+    if ((rc = prepare_workspace(h, stream, (multi || wide16 || (h->opt_band && (h->opt_max_qlen == 0 || h->opt_max_qlen > 160))) ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
         return rc;
     bool const shared = h->opt_query_run != 0 && (h->opt_query_run % (uint64_t)lx::score_cfg_groups(cfg)) == 0;
     if (!h->in_fused)
@@ -881,6 +923,9 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return LX_OK;
     if (!ext || !out_score || (!q_res && q_bytes))
         return fail(h, LX_EINVAL, "NULL argument");
+    if (h->opt_band)
+        return host_banded(h, slot, 0, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, nullptr, 0, out_score, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
     int rc = bind(h);
     if (rc)
         return rc;
@@ -1180,10 +1225,11 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
             smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
     // checkpoint mode (lx_ckpt.hip): shared-profile geometries (8,19) / (16,13), scores that fit int16; queries wider
     // than 208 columns take several (16,13) panels
-    bool const ckpt = h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
+    bool const ckpt = !h->opt_band && h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
     // Direction bits beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile).
     auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
-    int const cfg = (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))   ? 1
+    int const cfg = h->opt_band                                                         ? 0 // (band mode: generic geometry)
+                    : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1
                     : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
                     : ckpt                                                             ? ckpt_cfg_for(max_q)
                     : (share_slots >= 4 && padded(2) < padded(0))                      ? 2
@@ -1254,7 +1300,9 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.nrows          = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
         p.bs_match_rule  = (int32_t)h->opt_bs_rule;
         p.work_counter   = h->d_ws_top + 5;
-        p.shared_profile = share_slots;
+        p.band           = (int32_t)h->opt_band;
+        p.band_diag      = h->band_dev ? (d_src ? h->band_dev : h->band_dev + c0) : nullptr; // indexed like the caller's list
+        p.shared_profile = h->opt_band ? 0 : share_slots;
         p.cfg            = cfg;
         if (nchunks >= 2) // buffer b is free once the backtrace of chunk k-2 has finished
             LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
@@ -1340,6 +1388,9 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return fail(h, LX_EINVAL, "NULL argument");
     if (n > 0xfffffff0ull)
         return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    if (h->opt_band)
+        return host_banded(h, slot, 1, q_res, q_bytes, s_res, s_bytes, ext, n, known_score, nullptr, 0, nullptr, out_hsp, out_ops, ops_off,
+                           nullptr, nullptr, nullptr);
     int rc = bind(h);
     if (rc)
         return rc;
@@ -1528,7 +1579,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     int      sweep_share = 0;
     bool     half_sweep = false, may_decline = true;
     int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
-    if (h->opt_pass2 == 2 && shared && h->trace_ok[slot])
+    if (h->opt_pass2 == 2 && shared && h->trace_ok[slot] && !h->opt_band)
     {
         // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
         sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen, h->opt_f16 && h->opt_query_run % 16 == 0);
@@ -1782,6 +1833,143 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     return LX_OK;
 }
 
+
+// ---- band mode on host buffers ---------------------------------------------------------------------------------------
+// Band mode (LX_OPT_BAND) is a semantic option, not a fast path: it runs one int32 kernel geometry and direction bits for
+// pass 2, so the host-buffer entry points skip the binning / grouping of their full-rectangle versions -- the list goes to
+// the device as it is, the centres (lx_set_band_centres) with it.
+//   what = 0: lx_score_batch, 1: lx_align_batch (caller's ops slots), 2: lx_extend_batch (ops slots of the handle)
+static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                       lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
+                       int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
+                       uint64_t const * caller_ops_off, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    uint64_t max_q = 1, max_s = 1, total = 0;
+    std::vector<uint64_t> & off = h->xb_off;
+    off.resize(n + 1);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_extension const & x = ext[i];
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
+        max_q  = std::max<uint64_t>(max_q, x.q_len);
+        max_s  = std::max<uint64_t>(max_s, x.s_len);
+        off[i] = total;
+        total += (uint64_t)x.q_len + x.s_len;
+    }
+    off[n] = total;
+    if (!h->band_host.empty() && h->band_host.size() != n)
+        return fail(h, LX_EINVAL, "lx_set_band_centres gave %llu centres, the call has %llu extensions",
+                    (unsigned long long)h->band_host.size(), (unsigned long long)n);
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, n * sizeof(lx_extension))) ||
+        (rc = ensure(h, h->d_out, n * sizeof(int32_t))) || (rc = ensure(h, h->d_keep, n * sizeof(int32_t) + 64)) ||
+        (!h->band_host.empty() && (rc = ensure(h, h->d_band, n * sizeof(int32_t)))))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, ext, n * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    if (!h->band_host.empty())
+        LX_HIP(h, hipMemcpyAsync(h->d_band.ptr, h->band_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    struct Restore
+    {
+        lx_handle *     h;
+        uint64_t        qlen, slen, run;
+        int32_t const * band_dev;
+        ~Restore()
+        {
+            h->opt_max_qlen  = qlen;
+            h->opt_max_slen  = slen;
+            h->opt_query_run = run;
+            h->band_dev      = band_dev;
+        }
+    } const restore{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run, h->band_dev};
+    h->opt_max_qlen  = max_q;
+    h->opt_max_slen  = max_s;
+    h->opt_query_run = 0;
+    h->band_dev      = h->band_host.empty() ? nullptr : static_cast<int32_t const *>(h->d_band.ptr);
+    if (what == 0)
+    {
+        if ((rc = lx_score_batch_dev(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, n, h->d_out.ptr, h->stream)))
+            return rc;
+        LX_HIP(h, hipMemcpyAsync(out_score, h->d_out.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        return check_async_error(h);
+    }
+    if ((rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) || (rc = ensure(h, h->d_ops, total + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
+        return rc;
+    LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    if (what == 1)
+    {
+        if ((rc = prepare_workspace(h, h->stream, max_q > 160 ? n * ((max_s + 3) & ~3ull) : 0)))
+            return rc;
+        int32_t const * d_known = nullptr;
+        if (known_score)
+        {
+            if ((rc = ensure(h, h->d_trace_score, n * sizeof(int32_t))))
+                return rc;
+            LX_HIP(h, hipMemcpyAsync(h->d_trace_score.ptr, known_score, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            d_known = static_cast<int32_t const *>(h->d_trace_score.ptr);
+        }
+        h->phase_ev.clear();
+        h->ev_pool_used = 0;
+        if ((rc = align_dev_impl(h, slot, h->d_q.ptr, sref.dev, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
+                                 static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
+                                 static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, 0, nullptr, nullptr, d_known)))
+            return rc;
+    }
+    else
+    {
+        uint64_t * const d_count = static_cast<uint64_t *>(h->d_keep.ptr);
+        int32_t *        d_min   = nullptr;
+        if (min_score)
+        {
+            if ((rc = ensure(h, h->d_keep, 16 + n * sizeof(int32_t))))
+                return rc;
+            d_min = reinterpret_cast<int32_t *>(static_cast<uint64_t *>(h->d_keep.ptr) + 2);
+            LX_HIP(h, hipMemcpyAsync(d_min, min_score, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        }
+        if ((rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, n, d_min, min_score_all, h->d_out.ptr, h->d_hsp.ptr, h->d_ops.ptr,
+                             h->d_opsoff.ptr, static_cast<uint64_t *>(h->d_keep.ptr), h->stream, 3, false)))
+            return rc;
+        (void)d_count;
+        LX_HIP(h, hipMemcpyAsync(out_score, h->d_out.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    LX_HIP(h, hipMemcpyAsync(out_hsp, h->d_hsp.ptr, n * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
+    h->ext_ops.resize(total + 16);
+    if (total)
+        LX_HIP(h, hipMemcpyAsync(h->ext_ops.data(), h->d_ops.ptr, total, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = check_async_error(h)))
+        return rc;
+    for (uint64_t i = 0; i < n; ++i)
+        if (out_hsp[i].score < 0)
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)i);
+    if (what == 1)
+    {
+        for (uint64_t i = 0; i < n; ++i) // into the caller's slots, same position inside the slot
+            if (out_hsp[i].n_ops > 0)
+                std::memcpy(caller_ops + caller_ops_off[i] + out_hsp[i].ops_shift, h->ext_ops.data() + off[i] + out_hsp[i].ops_shift,
+                            (size_t)out_hsp[i].n_ops);
+    }
+    else
+    {
+        for (uint64_t i = 0; i < n; ++i)
+            out_ops_off[i] = off[i];
+        *out_ops       = h->ext_ops.data();
+        *out_ops_bytes = total;
+    }
+    return LX_OK;
+}
+
 int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext,
                         uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
                         void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream_)
@@ -1812,6 +2000,9 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
         return fail(h, LX_EINVAL, "NULL argument");
     if (n > 0xfffffff0ull / 2)
         return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    if (h->opt_band)
+        return host_banded(h, slot, 2, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, min_score, min_score_all, out_score, out_hsp, nullptr,
+                           nullptr, out_ops_off, out_ops, out_ops_bytes);
     int rc = bind(h);
     if (rc)
         return rc;

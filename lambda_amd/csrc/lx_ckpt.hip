@@ -41,6 +41,12 @@ constexpr int kCkptEvery = LX_CKPT_EVERY;
 #define LX_CKPT_PRAGMA(x) _Pragma(#x)
 #define LX_CKPT_UNROLL_N(n) LX_CKPT_PRAGMA(unroll n)
 #define LX_CKPT_UNROLL_PRAGMA LX_CKPT_UNROLL_N(LX_CKPT_UNROLL)
+#ifndef LX_BT_TILE_AT
+#define LX_BT_TILE_AT 48   // backtrace: lanes waiting for a tile that trigger a tile phase
+#endif
+#ifndef LX_BT_REFILL_AT
+#define LX_BT_REFILL_AT 12 // backtrace: finished / empty lanes that trigger a refill outside a tile phase
+#endif
 #ifndef LX_CKPT_FWD_WAVES
 #define LX_CKPT_FWD_WAVES 4
 #endif
@@ -787,15 +793,62 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         have          = false;
     };
 
+    // Scheduling of the wavefront: a shortcut pass costs ~1/15 of a tile phase, so shortcuts run while enough lanes can use
+    // them; a tile phase runs when LX_BT_TILE_AT lanes wait for one (or nobody can do anything else), right after the
+    // finished lanes have been retired and refilled (a new extension starts with a tile).
     bool queue_empty = false; // wave-uniform
+    int const tile_at = p.bt_tile_at > 0 ? p.bt_tile_at : LX_BT_TILE_AT, refill_at = p.bt_refill_at > 0 ? p.bt_refill_at : LX_BT_REFILL_AT;
     for (;;)
     {
-        // ================= (1) diagonal shortcuts, until every lane is blocked, finished or idle
-        for (;;)
+        bool fin       = have && (done || i < 0 || j < 0 || n >= cap);
+        bool can       = have && !fin && !blocked && !need_col && mode == 0;
+        bool tile_need = have && !fin && !can;
+        int  n_can = __popcll(__ballot(can)), n_tile = __popcll(__ballot(tile_need));
+        int const n_idle = 64 - n_can - n_tile; // finished or empty lanes
+        bool run_tile = n_can == 0 || n_tile >= tile_at;
+        if (n_idle > 0 && (run_tile || n_idle >= refill_at))
         {
-            bool const can = have && !done && !blocked && !need_col && mode == 0 && i >= 0 && j >= 0 && n < cap;
-            if (__ballot(can) == 0)
-                break;
+            // ================= retire and refill
+            if (fin)
+                finish_extension();
+            if (!queue_empty)
+            {
+                uint64_t const want = __ballot(!have);
+                if (want != 0)
+                {
+                    uint32_t  base   = 0;
+                    int const leader = __ffsll((unsigned long long)want) - 1;
+                    if ((int)lane == leader)
+                        base = atomicAdd(p.work_counter, (uint32_t)__popcll(want));
+                    base = (uint32_t)__shfl((int)base, leader);
+                    if ((uint64_t)base + (uint32_t)__popcll(want) >= limit)
+                        queue_empty = true;
+                    if (!have)
+                    {
+                        uint64_t const e = (uint64_t)base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
+                        if (e < limit)
+                            begin_extension(e);
+                    }
+                }
+            }
+            fin       = have && (done || i < 0 || j < 0 || n >= cap); // (an extension without a positive score never gets here)
+            can       = have && !fin && !blocked && !need_col && mode == 0;
+            tile_need = have && !fin && !can;
+            n_can     = __popcll(__ballot(can));
+            n_tile    = __popcll(__ballot(tile_need));
+            if (n_can == 0 && n_tile == 0)
+            {
+                if (__ballot(have) == 0 && queue_empty)
+                    break;
+                if (__ballot(have) == 0)
+                    continue; // (only padding slots or score-less extensions came out of the queue: take more)
+            }
+            run_tile = n_can == 0 || n_tile >= tile_at;
+        }
+
+        if (!run_tile)
+        {
+            // ================= (1) one diagonal shortcut for every lane that can take one
             if (can)
             {
                 int const st = j / C, j0 = st * C, c = j - j0;
@@ -898,39 +951,11 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 else
                     blocked = true;
             }
+            continue;
         }
-
-        // ================= retire and refill
-        if (have && (done || i < 0 || j < 0 || n >= cap))
-            finish_extension();
-        if (!queue_empty)
-        {
-            uint64_t const want = __ballot(!have);
-            if (want != 0)
-            {
-                uint32_t  base   = 0;
-                int const leader = __ffsll((unsigned long long)want) - 1;
-                if ((int)lane == leader)
-                    base = atomicAdd(p.work_counter, (uint32_t)__popcll(want));
-                base = (uint32_t)__shfl((int)base, leader);
-                if ((uint64_t)base + (uint32_t)__popcll(want) >= limit)
-                    queue_empty = true;
-                if (!have)
-                {
-                    uint64_t const e = (uint64_t)base + (uint32_t)__popcll(want & ((1ull << lane) - 1ull));
-                    if (e < limit)
-                        begin_extension(e);
-                }
-            }
-        }
-        if (__ballot(have) == 0)
-            break;
 
         // ================= (2) one tile for every lane that cannot go on without it
-        bool const tile_now = have && !done && i >= 0 && j >= 0 && n < cap && (blocked || need_col || mode != 0);
-        if (__ballot(tile_now) == 0)
-            continue;
-        if (tile_now)
+        if (tile_need)
         {
         // ---- the tile of the current cell: strip st, step block m (step k = row + strip)
         int const st = j / C, j0 = st * C;
@@ -1168,7 +1193,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             j -= (diag || !vert) ? 1 : 0;
         }
         blocked = false;
-        } // tile_now
+        } // tile_need
     }
 }
 
@@ -1227,12 +1252,18 @@ static int backtrace_resident_waves()
     return v;
 }
 
-hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream)
+hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
 {
-    if (p.n == 0)
+    if (p_in.n == 0)
         return hipSuccess;
-    if (!p.work_counter)
+    if (!p_in.work_counter)
         return hipErrorInvalidValue;
+    TraceParams p = p_in;
+    {
+        static int const ta = getenv("LX_BT_TILE_AT") ? atoi(getenv("LX_BT_TILE_AT")) : 0, ra = getenv("LX_BT_REFILL_AT") ? atoi(getenv("LX_BT_REFILL_AT")) : 0; // development aid
+        p.bt_tile_at   = ta;
+        p.bt_refill_at = ra;
+    }
     // persistent lanes: as many wavefronts as the chip holds at this kernel's occupancy (3 per SIMD), each taking
     // extensions from the queue until it is empty
     uint64_t const b2 = std::min<uint64_t>((p.n + 63) / 64, (uint64_t)backtrace_resident_waves());

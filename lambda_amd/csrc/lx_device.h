@@ -79,6 +79,9 @@ struct ScoreParams
     uint32_t           steps_cap;
     struct EndCell *   ends;        // [n]
     uint32_t           panels_cap;  // packed-int16 sweep: bound on ceil(Lq / panel); the slot holds that many parts
+    // band mode (LX_OPT_BAND; not the reference's configuration): only cells with |(i - j) - diag| <= band exist
+    int32_t            band;        // half width in diagonals, 0 = off (full rectangle)
+    int32_t const *    band_diag;   // optional [n]: centre diagonal per extension; nullptr = band_default_diag()
 };
 
 // best cell of one extension, written by the forward-trace kernel, consumed by the backtrace kernel
@@ -154,6 +157,9 @@ struct TraceParams
     uint64_t           ovf_stride;
     uint32_t           ovf_cap;
     uint32_t *         ovf_count;     // device counter of handed-out overflow slots
+    int32_t            band;          // band mode, as in ScoreParams (direction-bit kernels only)
+    int32_t const *    band_diag;
+    int32_t            bt_tile_at, bt_refill_at; // checkpoint backtrace scheduling thresholds (0 = the compiled defaults)
     uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
 };
 

@@ -95,4 +95,22 @@ __device__ __forceinline__ void build_profile(uint32_t * lds, int slot_dw, int g
 
 typedef uint32_t __attribute__((aligned(1))) unaligned_u32;
 
+// _bandSize, /root/reference/src/search_misc.hpp:46-50: int64(sqrt(double(len))) + 1, here with an exact integer root
+__device__ __forceinline__ int band_size_dev(int len)
+{
+    int r = (int)sqrtf((float)len);
+    while (r * r > len)
+        --r;
+    while ((r + 1) * (r + 1) <= len)
+        ++r;
+    return r + 1;
+}
+// Band mode without per-extension centres: the seed diagonal of a window built by _widenMatch (src/search_algo.hpp:919-938)
+// crosses the window's first column b = _bandSize(Lq) rows down -- unless the window was clipped at the subject's start,
+// which only the caller can know (then it passes the centres).
+__device__ __forceinline__ int band_default_diag(int lq, int ls)
+{
+    return max(0, min(band_size_dev(lq), ls - lq));
+}
+
 } // namespace lx

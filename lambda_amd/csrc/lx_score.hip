@@ -39,7 +39,11 @@ namespace lx
 
 
 // MULTI = the launch may contain queries wider than one panel (carry workspace code compiled in)
-template <int G, int C, bool MULTI>
+// BAND = band mode (ScoreParams::band > 0; NOT what the reference runs, src/search_algo.hpp:1081 is BandOff): cells off the
+// band behave as if they did not exist -- H = 0, no gap state leaves them (oracle/lx_oracle.c lxo_score_banded).  The
+// strip mapping cannot skip them (at every step some lane of the group is inside the band), so they are computed and
+// overwritten: five more instructions per cell; rows below the band's last row are clipped.
+template <int G, int C, bool MULTI, bool BAND = false>
 __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -80,6 +84,17 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
         q += x.q_off;
         if (ls != 0)
             s += x.s_off;
+    }
+    int blo = 0, bw = 0; // in-band diagonals: blo <= i - j <= blo + bw
+    if constexpr (BAND)
+    {
+        if (active)
+        {
+            int const d0 = p.band_diag ? p.band_diag[e] : band_default_diag(lq, ls);
+            blo          = d0 - p.band;
+            bw           = 2 * p.band;
+            ls           = min(ls, max(lq + blo + bw, 0)); // from row Lq + hi on no cell is inside the band
+        }
     }
     // An empty query or window needs no special case: no real row/column exists, every cell stays at the floor.
 
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
             int const zn     = z - ge; // z_{i+1}
             int       rowmax = kNegInf;
             int       h      = 0;
+            int const cl     = (k - g) - (blo + bw) - col0; // BAND: first column of this strip inside the band in this row
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
@@ -225,10 +241,22 @@ __global__ __launch_bounds__(64) void score_kernel(ScoreParams p)
                 dg            = Hrow[c];
                 h             = max3i(tt, Ecur, F0[c]);
                 LX_OPAQUE(h); // keeps rowmax a chain over h instead of a wider tree over (tt, E, F0)
-                int const A   = h + g2;
-                F0[c]         = max3i(F0[c], A, zn);
-                LX_OPAQUE(F0[c]);
-                Ecur          = max(Ecur, A) + ge;
+                if constexpr (BAND)
+                {
+                    bool const inb = (unsigned)(c - cl) <= (unsigned)bw;
+                    h              = inb ? h : z; // H = 0
+                    int const A    = h + g2;
+                    int const Fn   = max3i(F0[c], A, zn);
+                    F0[c]          = inb ? Fn : zn;                       // the cell below sees the floor only
+                    Ecur           = inb ? max(Ecur, A) + ge : kNegInf;   // no horizontal gap leaves the cell
+                }
+                else
+                {
+                    int const A = h + g2;
+                    F0[c]       = max3i(F0[c], A, zn);
+                    LX_OPAQUE(F0[c]);
+                    Ecur        = max(Ecur, A) + ge;
+                }
                 Hrow[c]       = h;
                 rowmax        = max(rowmax, h);
             }
@@ -339,7 +367,15 @@ static hipError_t launch_score_cfg(ScoreParams const & p, bool multi, hipStream_
         return hipErrorInvalidValue;
     int const    slots = p.shared_profile ? 1 : Geo::kGroups;
     size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
-    if (multi)
+    if (p.band > 0)
+    {
+        // band mode: the any-width instantiation of the generic geometry only (launch_score sends nothing else here)
+        if constexpr (G == 16 && C == 10)
+            hipLaunchKernelGGL((score_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        else
+            return hipErrorInvalidValue;
+    }
+    else if (multi)
         hipLaunchKernelGGL((score_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((score_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);

@@ -74,7 +74,8 @@ struct TraceWords
 };
 
 // MULTI = queries may be wider than one panel of G*C columns (boundary columns are carried through p.ws)
-template <int G, int C, bool MULTI>
+// BAND: band mode, exactly as in lx_score.hip's score_kernel (cells off the band: H = 0, no gap state leaves them).
+template <int G, int C, bool MULTI, bool BAND = false>
 __global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(TraceParams p)
 {
     using Geo = ScoreGeo<G, C>;
@@ -128,6 +129,18 @@ __global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(Tr
             ls = (int)x.s_len;
             if (ls != 0)
                 s += x.s_off;
+        }
+    }
+    int blo = 0, bw = 0; // in-band diagonals: blo <= i - j <= blo + bw
+    if constexpr (BAND)
+    {
+        if (active)
+        {
+            uint64_t const oi = p.src ? p.src[e] : e; // centres are indexed like the caller's extension list
+            int const      d0 = p.band_diag ? p.band_diag[oi] : band_default_diag(lq, ls);
+            blo               = d0 - p.band;
+            bw                = 2 * p.band;
+            ls                = min(ls, max(lq + blo + bw, 0));
         }
     }
     // p.shared_profile = number of consecutive groups that share one LDS profile (0/1: none).  The compaction
@@ -269,6 +282,7 @@ __global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(Tr
             for (int x = 0; x < TW::kWords; ++x)
                 w[x] = 0;
             int hc = 0;
+            int const cl = i - (blo + bw) - col0; // BAND: first column of this strip inside the band in this row
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
@@ -278,12 +292,18 @@ __global__ __launch_bounds__(64, (C <= 13 ? 4 : 3)) void trace_forward_kernel(Tr
                 int m         = max3i(tt, Ecur, F1[c]);          // E tag 1 < F tag 2 < diagonal tag 3
                 LX_OPAQUE(m);
                 hc            = m & ~3;
+                bool inb      = true;
+                if constexpr (BAND)
+                {
+                    inb = (unsigned)(c - cl) <= (unsigned)bw;
+                    hc  = inb ? hc : Z;                          // H = 0 off the band (no walk ever gets there)
+                }
                 int const A0  = hc + g20v;                       // gap-open candidate, tag 0
                 // F of the next row: tag 2 = extended (wins ties), 0 = opened or the next row's zero floor.  A floor
                 // that wins makes that cell's H = 0, where every walk has already stopped: its flag is never read.
-                int const Fr  = max3i(F1[c], A0, ZN);
+                int const Fr  = inb ? max3i(F1[c], A0, ZN) : ZN;
                 F1[c]         = Fr | 2;
-                int const Er  = max(Ecur, A0);                   // tag 1 = extended (wins ties), 0 = opened
+                int const Er  = inb ? max(Ecur, A0) : 4 * kNegInf; // tag 1 = extended (wins ties), 0 = opened
                 Ecur          = (Er & ~3) + ge41v;
                 uint32_t wc   = w[c >> 3];
                 wc            = __builtin_amdgcn_alignbit((uint32_t)m, wc, 2);
@@ -694,7 +714,14 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
                        sizeof(uint32_t);
     if (!p.score_in)
         return hipErrorInvalidValue; // the end cell is located through the known best score
-    if (p.panels_cap > 1)
+    if (p.band > 0)
+    {
+        if constexpr (G == 16 && C == 10) // band mode: the generic geometry only
+            hipLaunchKernelGGL((trace_forward_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        else
+            return hipErrorInvalidValue;
+    }
+    else if (p.panels_cap > 1)
         hipLaunchKernelGGL((trace_forward_kernel<G, C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((trace_forward_kernel<G, C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);

@@ -155,8 +155,8 @@ int lxo_score_banded(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t l
  * traceback pass: src/search_algo.hpp:1296 -> :1116-1127 (CompleteTrace, GapsLeft)
  * Full matrices are kept; the walk reads scores, not stored direction bits.
  * -------------------------------------------------------------------------- */
-int lxo_align(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
-              lxo_hsp * out, uint8_t * ops)
+static int align_impl(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
+                      int32_t diag_lo, int32_t diag_hi, lxo_hsp * out, uint8_t * ops)
 {
     memset(out, 0, sizeof(*out));
     if (lq <= 0 || ls <= 0)
@@ -186,10 +186,19 @@ int lxo_align(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_
     for (int32_t j = 1; j <= lq; ++j)
         for (int32_t i = 1; i <= ls; ++i)
         {
-            int32_t const e = imax(E[i * W + j - 1] + ge, H[i * W + j - 1] + go);
-            int32_t const f = imax(F[(i - 1) * W + j] + ge, H[(i - 1) * W + j] + go);
-            int32_t       h = H[(i - 1) * W + j - 1] + sub_score(sc, q[j - 1], s[i - 1]);
-            h               = imax(h, imax(e, f));
+            /* band mode (not the reference's configuration): cells off the band are never computed -- H = 0, no gap
+             * state -- and a neighbour off the band feeds no gap (same rules as lxo_score_banded) */
+            int32_t const d = (i - 1) - (j - 1);
+            if (d < diag_lo || d > diag_hi)
+                continue;
+            int32_t e = imax(E[i * W + j - 1] + ge, H[i * W + j - 1] + go);
+            int32_t f = imax(F[(i - 1) * W + j] + ge, H[(i - 1) * W + j] + go);
+            if (d + 1 > diag_hi)
+                e = NEG_INF;
+            if (d - 1 < diag_lo)
+                f = NEG_INF;
+            int32_t h = H[(i - 1) * W + j - 1] + sub_score(sc, q[j - 1], s[i - 1]);
+            h         = imax(h, imax(e, f));
             if (h <= 0)
                 h = 0;
             H[i * W + j] = h;
@@ -265,6 +274,19 @@ int lxo_align(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_
     free(E);
     free(F);
     return 0;
+}
+
+int lxo_align(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
+              lxo_hsp * out, uint8_t * ops)
+{
+    return align_impl(q, lq, s, ls, sc, INT32_MIN / 2, INT32_MAX / 2, out, ops); /* BandOff, src/search_algo.hpp:1081 */
+}
+
+/* The same with the band of lxo_score_banded: diag_lo <= (i - j) <= diag_hi.  NOT a parity mode. */
+int lxo_align_banded(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
+                     int32_t diag_lo, int32_t diag_hi, lxo_hsp * out, uint8_t * ops)
+{
+    return align_impl(q, lq, s, ls, sc, diag_lo, diag_hi, out, ops);
 }
 
 int lxo_score_batch(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,

@@ -77,6 +77,9 @@ int lxo_score_banded(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t l
  * ops must hold lq+ls bytes. */
 int lxo_align(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
               lxo_hsp * out, uint8_t * ops);
+/* with the band of lxo_score_banded (diag_lo <= i - j <= diag_hi, 0-based i over subject, j over query); not a parity mode */
+int lxo_align_banded(uint8_t const * q, int32_t lq, uint8_t const * s, int32_t ls, lxo_scoring const * sc,
+                     int32_t diag_lo, int32_t diag_hi, lxo_hsp * out, uint8_t * ops);
 
 int lxo_score_batch(uint8_t const * qres, uint8_t const * sres, uint64_t const * q_off, uint32_t const * q_len,
                     uint64_t const * s_off, uint32_t const * s_len, uint64_t n, lxo_scoring const * sc,

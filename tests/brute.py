@@ -6,16 +6,27 @@ form), which shares no recurrence with the Gotoh E/F formulation used by the ora
 import numpy as np
 
 
-def sw_general(q, s, matrix, go, ge):
-    """Returns the full H matrix, (ls+1) x (lq+1), rows = subject, columns = query."""
+def sw_general(q, s, matrix, go, ge, band=None):
+    """Returns the full H matrix, (ls+1) x (lq+1), rows = subject, columns = query.
+
+    band = (lo, hi): only cells with lo <= (i - 1) - (j - 1) <= hi exist; a gap runs through cells of the band only
+    (every cell it crosses and the cell it opens from lie inside)."""
     lq, ls = len(q), len(s)
     H = np.zeros((ls + 1, lq + 1), dtype=np.int64)
+    lo, hi = band if band is not None else (-10 ** 9, 10 ** 9)
     for i in range(1, ls + 1):
         for j in range(1, lq + 1):
+            d = i - j
+            if d < lo or d > hi:
+                continue
             best = H[i - 1, j - 1] + int(matrix[q[j - 1], s[i - 1]])
             for k in range(1, i + 1):
+                if d - k < lo:
+                    break  # the vertical gap would start off the band
                 best = max(best, H[i - k, j] + go + (k - 1) * ge)
             for k in range(1, j + 1):
+                if d + k > hi:
+                    break
                 best = max(best, H[i, j - k] + go + (k - 1) * ge)
             H[i, j] = max(0, best)
     return H

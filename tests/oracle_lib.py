@@ -62,6 +62,7 @@ class Oracle:
         lib.lxo_score.argtypes = [vp, i32, vp, i32, C.POINTER(Scoring), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         lib.lxo_score_banded.argtypes = [vp, i32, vp, i32, C.POINTER(Scoring), i32, i32, C.POINTER(i32)]
         lib.lxo_align.argtypes = [vp, i32, vp, i32, C.POINTER(Scoring), C.POINTER(Hsp), vp]
+        lib.lxo_align_banded.argtypes = [vp, i32, vp, i32, C.POINTER(Scoring), i32, i32, C.POINTER(Hsp), vp]
         for f in (lib.lxo_score_batch, lib.lxo_score_batch_simd):
             f.argtypes = [vp, vp, vp, vp, vp, vp, u64, C.POINTER(Scoring), vp, vp, vp, i32]
         lib.lxo_band_size.argtypes = [u64]
@@ -108,6 +109,15 @@ class Oracle:
         hsp = Hsp()
         ops = np.zeros(len(q) + len(s) + 1, dtype=np.uint8)
         rc = self.lib.lxo_align(self._p(q), len(q), self._p(s), len(s), C.byref(sc), C.byref(hsp), self._p(ops))
+        assert rc == 0
+        return hsp, bytes(ops[: hsp.n_ops])
+
+    def align_banded(self, q: np.ndarray, s: np.ndarray, sc: Scoring, lo: int, hi: int):
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        s = np.ascontiguousarray(s, dtype=np.uint8)
+        hsp = Hsp()
+        ops = np.zeros(len(q) + len(s) + 1, dtype=np.uint8)
+        rc = self.lib.lxo_align_banded(self._p(q), len(q), self._p(s), len(s), C.byref(sc), lo, hi, C.byref(hsp), self._p(ops))
         assert rc == 0
         return hsp, bytes(ops[: hsp.n_ops])
 

@@ -170,6 +170,43 @@ def test_banded_equals_full_when_band_covers_rectangle(oracle):
         assert oracle.score_banded(qq, ss, sc, -3, 3) <= oracle.score(qq, ss, sc)[0]
 
 
+@pytest.mark.parametrize("name", ["blosum62", "nucl"])
+def test_banded_oracle_equals_banded_brute_force(oracle, name):
+    """Band mode (not the reference's configuration) pinned like the full rectangle: the Gotoh restatement with a band against
+    the general-gap Smith-Waterman restricted to the band, on small random pairs, bands that cut through the alignment
+    included; the banded traceback re-scores to the banded score, stays inside the band and equals the full one when the
+    band covers the rectangle."""
+    sc_p = SCHEMES[name]
+    sc = oracle_lib.scoring_from(sc_p)
+    M = sc_p.matrix_np()
+    rng = np.random.default_rng(8)
+    q, s, ext = synth.make_ragged_np(60, seed=12, alphabet=alphabet_of(name), lq_range=(3, 28), ls_extra=(0, 12))
+    for x in ext:
+        qq = q[int(x["q_off"]): int(x["q_off"]) + int(x["q_len"])]
+        ss = s[int(x["s_off"]): int(x["s_off"]) + int(x["s_len"])]
+        d0, b = int(rng.integers(-3, 8)), int(rng.integers(0, 7))
+        lo, hi = d0 - b, d0 + b
+        H = brute.sw_general(qq, ss, M, sc_p.gap_open, sc_p.gap_extend, band=(lo, hi))
+        want = int(H.max())
+        assert oracle.score_banded(qq, ss, sc, lo, hi) == want
+        hsp, ops = oracle.align_banded(qq, ss, sc, lo, hi)
+        assert hsp.score == want
+        if want > 0:
+            best, bq, bs = brute.best_cell_column_major(H)
+            assert (hsp.q_end, hsp.s_end) == (bq, bs)
+            got, qi, si = brute.score_of_ops(qq, ss, hsp.q_begin, hsp.s_begin, ops, M, sc_p.gap_open, sc_p.gap_extend)
+            assert (got, qi, si) == (want, hsp.q_end, hsp.s_end)
+            i, j = hsp.s_begin, hsp.q_begin  # every cell the alignment passes lies inside the band
+            for op in ops:
+                i += op in (ord("M"), ord("D"))
+                j += op in (ord("M"), ord("I"))
+                assert lo <= (i - 1) - (j - 1) <= hi
+        full_h, full_ops = oracle.align(qq, ss, sc)
+        wide_h, wide_ops = oracle.align_banded(qq, ss, sc, -1000, 1000)
+        assert (wide_h.score, wide_h.q_begin, wide_h.q_end, wide_h.s_begin, wide_h.s_end, wide_ops) == \
+               (full_h.score, full_h.q_begin, full_h.q_end, full_h.s_begin, full_h.s_end, full_ops)
+
+
 def test_band_size(oracle):
     # src/search_misc.hpp:46-50
     for n, b in ((0, 1), (1, 2), (99, 10), (100, 11), (150, 13), (200, 15), (10 ** 6, 1001)):
