@@ -40,7 +40,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.Scoring) == 16 + 1024
     assert capi.EXT_DTYPE.itemsize == 24 and capi.HSP_DTYPE.itemsize == 48
     assert capi.MATCH_DTYPE.itemsize == 48 and capi.SEED_DTYPE.itemsize == 40
-    assert C.sizeof(capi.SearchParams) == 88 and capi.BLAST_MATCH_DTYPE.itemsize == 128
+    assert C.sizeof(capi.SearchParams) == 96 and capi.BLAST_MATCH_DTYPE.itemsize == 128
 
 
 def test_no_device_means_loud_failure(lx_lib):
