@@ -383,9 +383,11 @@ int launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_
         // band mode: the int32 kernel of the generic geometry, any query width (the packed kernels carry no band code)
         p.band           = (int32_t)h->opt_band;
         p.band_diag      = h->band_dev;
-        p.shared_profile = 0;
-        LX_HIP(h, lx::launch_score(0, p, true, stream));
-        snprintf(buf, sizeof(buf), "lx::score_kernel<16,10,true,band> (band mode, +-%d diagonals)", p.band);
+        // query runs of a multiple of 8 whose queries fit 152 columns: (8,19), one LDS profile per wavefront
+        bool const narrow = shared && cfg == 6 && !multi;
+        p.shared_profile  = narrow ? 1 : 0;
+        LX_HIP(h, lx::launch_score(narrow ? 6 : 0, p, true, stream));
+        snprintf(buf, sizeof(buf), "lx::score_kernel<%s,band> (band mode, +-%d diagonals)", narrow ? "8,19,false" : "16,10,true", p.band);
         h->last_kernel = buf;
         return LX_OK;
     }
@@ -1228,7 +1230,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
     bool const ckpt = !h->opt_band && h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
     // Direction bits beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile).
     auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
-    int const cfg = h->opt_band                                                         ? 0 // (band mode: generic geometry)
+    int const cfg = (h->opt_band && !(share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))) ? 0 // (band mode: (8,19) or generic)
                     : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1
                     : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
                     : ckpt                                                             ? ckpt_cfg_for(max_q)
@@ -1302,7 +1304,7 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.work_counter   = h->d_ws_top + 5;
         p.band           = (int32_t)h->opt_band;
         p.band_diag      = h->band_dev ? (d_src ? h->band_dev : h->band_dev + c0) : nullptr; // indexed like the caller's list
-        p.shared_profile = h->opt_band ? 0 : share_slots;
+        p.shared_profile = (h->opt_band && cfg == 0) ? 0 : share_slots;
         p.cfg            = cfg;
         if (nchunks >= 2) // buffer b is free once the backtrace of chunk k-2 has finished
             LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));

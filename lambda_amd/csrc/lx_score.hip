@@ -369,9 +369,12 @@ static hipError_t launch_score_cfg(ScoreParams const & p, bool multi, hipStream_
     size_t const lds   = (size_t)slots * (size_t)p.nrows * Geo::kRowDw * sizeof(uint32_t);
     if (p.band > 0)
     {
-        // band mode: the any-width instantiation of the generic geometry only (launch_score sends nothing else here)
+        // band mode: the any-width instantiation of the generic geometry, or (8,19) with one LDS profile per wavefront
+        // for query runs (launch_score_list sends nothing else here)
         if constexpr (G == 16 && C == 10)
             hipLaunchKernelGGL((score_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        else if constexpr (G == 8 && C == 19)
+            hipLaunchKernelGGL((score_kernel<G, C, false, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
         else
             return hipErrorInvalidValue;
     }

@@ -716,8 +716,10 @@ static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t st
         return hipErrorInvalidValue; // the end cell is located through the known best score
     if (p.band > 0)
     {
-        if constexpr (G == 16 && C == 10) // band mode: the generic geometry only
+        if constexpr (G == 16 && C == 10) // band mode: the generic geometry, or (8,19) with shared profiles
             hipLaunchKernelGGL((trace_forward_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        else if constexpr (G == 8 && C == 19)
+            hipLaunchKernelGGL((trace_forward_kernel<G, C, false, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
         else
             return hipErrorInvalidValue;
     }
