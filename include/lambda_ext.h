@@ -216,12 +216,23 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
 
 /* The same on host buffers (what lx_iterate_matches uses).  Extension order is free; extensions of one query slice are
  * best adjacent (lambda's lists are).  out_score[n] as in pass 1; out_hsp[n]: filtered-out rows carry the score and
- * n_ops = 0; the ops of a survivor i are *out_ops + out_ops_off[i] + out_hsp[i].ops_shift (the callee lays the slots out
- * compactly; the buffer belongs to the handle and stays valid until its next lx_extend_batch call).  One
- * synchronisation between the passes: only the survivors' records and ops cross PCIe. */
+ * n_ops = 0; the ops of a survivor i are *out_ops + out_ops_off[i] + out_hsp[i].ops_shift (the callee lays them out
+ * compactly; the buffer belongs to the handle and stays valid until its next lx_extend_batch[_rle] call).  The list is
+ * processed as a pipeline of chunks (uploads, kernels, downloads and the host's share overlap); only scores, the
+ * survivors' records and their run-length coded ops cross PCIe. */
 int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                     lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                     lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
+
+/* The same with the ops in the form they cross PCIe in: run-length codes instead of one byte per column -- one byte per run,
+ * (op << 6) | (length - 1) with op 0 = 'M', 1 = 'D', 2 = 'I', runs longer than 64 columns split, begin -> end order.  The codes
+ * of a survivor i start at *out_ops + out_ops_off[i] and end where their lengths add up to out_hsp[i].n_ops (the number of
+ * alignment columns, as ever); out_hsp[i].ops_shift is 0.  This is what a binding that fills SeqAn's gapped rows wants (ArrayGaps
+ * stores run lengths) and what lx_iterate_matches uses; lx_expand_ops turns one survivor's codes into column bytes. */
+int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                        lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                        lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
+int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out /* n_ops bytes */);
 
 /* ---- pre-extension filter (seedLooksPromising, src/search_algo.hpp:426-481) ------------------ */
 /* One diagonal per item; out_keep[i] = 1 if the ungapped max-segment score reaches the threshold. */

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_extend_batch", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -158,6 +158,8 @@ def load():
     lib.lx_convert_ranks.argtypes = [i32, vp, u64, vp]
     lib.lx_set_subjects.argtypes = [vp, vp, u64]
     lib.lx_extend_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
+    lib.lx_extend_batch_rle.argtypes = lib.lx_extend_batch.argtypes
+    lib.lx_expand_ops.argtypes = [vp, i32, vp]
     lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lx_set_frames.restype = None
     lib.lx_untrue_qry_id.argtypes = [i32, u64, i32]
@@ -374,7 +376,20 @@ class Handle:
                                                 _ptr(seeds), len(seeds), seed_length, pre_scoring, thresh, _ptr(keep)))
         return keep
 
-    def extend_batch(self, q_res, s_res, ext, min_score, slot: int = 0, copy_ops: bool = True):
+    def extend_batch_rle(self, q_res, s_res, ext, min_score, slot: int = 0):
+        """lx_extend_batch_rle: as extend_batch, the ops as run-length codes ((op << 6) | (len - 1), op 0/1/2 = M/D/I)."""
+        return self.extend_batch(q_res, s_res, ext, min_score, slot=slot, rle=True)
+
+    @staticmethod
+    def expand_ops(codes: np.ndarray, n_ops: int) -> bytes:
+        out = np.zeros(max(n_ops, 1), dtype=np.uint8)
+        c = np.ascontiguousarray(codes, dtype=np.uint8)
+        rc = load().lx_expand_ops(_ptr(c), n_ops, _ptr(out))
+        if rc != LX_OK:
+            raise LambdaExtError(rc, "lx_expand_ops")
+        return bytes(out[:n_ops])
+
+    def extend_batch(self, q_res, s_res, ext, min_score, slot: int = 0, copy_ops: bool = True, rle: bool = False, out=None):
         """lx_extend_batch: both passes on host buffers.  min_score = int cut-off for all, or an int32 array per
         extension.  Returns (scores, hsp, ops_off, ops) -- ops is a copy of the handle-owned buffer (copy_ops=False: a
         view that the next call invalidates)."""
@@ -383,11 +398,11 @@ class Handle:
         ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
         n = len(ext)
         per = None if np.isscalar(min_score) else np.ascontiguousarray(min_score, dtype=np.int32)
-        score = np.zeros(n, dtype=np.int32)
-        hsp = np.zeros(n, dtype=HSP_DTYPE)
-        off = np.zeros(n, dtype=np.uint64)
+        # out = (score, hsp, off) arrays of an earlier call to write into (a caller that keeps its buffers pays no page faults)
+        score, hsp, off = out if out is not None else (np.zeros(n, dtype=np.int32), np.zeros(n, dtype=HSP_DTYPE), np.zeros(n, dtype=np.uint64))
         p, nb = C.c_void_p(), C.c_uint64()
-        self._check(self.lib.lx_extend_batch(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext), n,
+        fn = self.lib.lx_extend_batch_rle if rle else self.lib.lx_extend_batch
+        self._check(fn(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext), n,
                                              None if per is None else _ptr(per), 0 if per is not None else int(min_score),
                                              _ptr(score), _ptr(hsp), _ptr(off), C.byref(p), C.byref(nb)))
         if not nb.value:

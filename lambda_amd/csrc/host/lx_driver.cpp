@@ -241,8 +241,13 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     std::vector<uint64_t> opsOffAll(n);
     uint8_t const *       ops      = nullptr;
     uint64_t              opsBytes = 0;
-    int rc = lx_extend_batch(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), hspAll.data(),
-                             opsOffAll.data(), &ops, &opsBytes);
+    // (the ops arrive as run-length codes -- the form they cross PCIe in -- and only the HSPs that pass the identity cut-off
+    // are expanded into column bytes below; band mode returns column bytes)
+    uint64_t bandNow = 0;
+    (void)lx_get_option(h, LX_OPT_BAND, &bandNow);
+    bool const rle = bandNow == 0;
+    int rc = (rle ? lx_extend_batch_rle : lx_extend_batch)(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0,
+                                                            scores.data(), hspAll.data(), opsOffAll.data(), &ops, &opsBytes);
     if (rc != LX_OK)
         return rc;
 
@@ -309,7 +314,13 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         bm.ops_off   = res->ops.size();
         bm.n_ops     = (uint32_t)a.n_ops;
         uint8_t const * const first = ops + opsOffAll[k] + a.ops_shift;
-        res->ops.insert(res->ops.end(), first, first + a.n_ops);
+        if (rle)
+        {
+            res->ops.resize(res->ops.size() + (size_t)a.n_ops);
+            (void)lx_expand_ops(first, a.n_ops, res->ops.data() + bm.ops_off);
+        }
+        else
+            res->ops.insert(res->ops.end(), first, first + a.n_ops);
         res->matches.push_back(bm);
     }
     return LX_OK;

@@ -14,6 +14,9 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -51,6 +54,7 @@ hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t
 hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream);
 hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hipStream_t stream);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
+hipError_t launch_rle_pack(PackParams const & p, hipStream_t stream);
 } // namespace lx
 
 static_assert(sizeof(lx_extension) == sizeof(lx::Extension), "ABI mismatch");
@@ -80,12 +84,42 @@ struct lx_handle
     bool        timed = false;
     std::string error;
     // lx_extend_batch: host staging that keeps its pages between calls
-    std::vector<uint32_t>     xb_idx, xb_src, xb_sel;
+    std::vector<uint32_t>     xb_idx, xb_src, xb_sel, xb_pos;
+    std::vector<uint8_t>      xb_newrun;
     std::vector<uint64_t>     xb_grp, xb_off;
     std::vector<lx_extension> xb_ext;
     std::vector<int32_t>      xb_min, xb_score;
-    std::vector<lx_hsp>  ext_hsp; // lx_extend_batch: the survivors' records and ops of the last call (handed out by pointer)
-    std::vector<uint8_t> ext_ops;
+    std::vector<uint8_t> ext_ops; // band mode: the ops of the last lx_extend_batch call (handed out by pointer)
+    // lx_extend_batch: the ops of the last call, grown without touching what is already there
+    struct Bytes
+    {
+        uint8_t * p   = nullptr;
+        size_t    cap = 0;
+        uint8_t * data() { return p; }
+        void      clear() {}
+        void      grow(size_t bytes)
+        {
+            if (bytes <= cap)
+                return;
+            size_t const want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+            p                 = static_cast<uint8_t *>(std::realloc(p, want));
+            cap               = p ? want : 0;
+        }
+        ~Bytes() { std::free(p); }
+    } ext_bytes;
+    // lx_extend_batch's two chunks in flight: pinned staging, device buffers, events
+    struct Pinned
+    {
+        void * ptr = nullptr;
+        size_t cap = 0;
+    };
+    struct XbLane
+    {
+        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle;
+        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt;
+        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
+    } xb[2];
+    hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
     std::string last_trace_kernel;
     // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
@@ -350,7 +384,7 @@ int check_async_error(lx_handle * h)
         return fail(h, LX_EOVERFLOW, "single sweep: no checkpoint slot left for an extension the packed-half kernel declined "
                                      "(raise LX_OPT_TRACE_BYTES, or set LX_OPT_PASS2_MODE to 1)");
     if (flags[1] != 0)
-        return fail(h, LX_EHIP, "device reported error flag %u", flags[1]);
+        return fail(h, flags[1] == 5 ? LX_EOVERFLOW : LX_EHIP, "device reported error flag %u", flags[1]);
     return LX_OK;
 }
 
@@ -463,6 +497,83 @@ static unsigned host_threads(uint64_t n)
     return avail;
 }
 
+// A few persistent host threads (started on first use): the per-extension loops of the host-buffer entry points are spread
+// over them; spawning threads per loop would cost more than the loops of a pipeline chunk.
+namespace
+{
+class HostPool
+{
+    std::vector<std::thread>       workers_;
+    std::mutex                     m_;
+    std::condition_variable        cv_, done_;
+    std::function<void(unsigned)>  job_;
+    unsigned                       want_ = 0, gen_ = 0, running_ = 0;
+    bool                           stop_ = false;
+
+    void loop(unsigned id)
+    {
+        unsigned seen = 0;
+        for (;;)
+        {
+            std::function<void(unsigned)> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && id < want_); });
+                if (stop_)
+                    return;
+                seen = gen_;
+                job  = job_;
+            }
+            job(id);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--running_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+
+public:
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread & t : workers_)
+            t.join();
+    }
+    // runs f(1) .. f(nthreads - 1) on the workers and f(0) on the caller; returns when all are done
+    void run(unsigned nthreads, std::function<void(unsigned)> f)
+    {
+        static std::mutex           callers; // one parallel loop at a time (handles on several host threads share the pool)
+        std::lock_guard<std::mutex> one(callers);
+        while (workers_.size() + 1 < nthreads)
+        {
+            unsigned const id = (unsigned)workers_.size() + 1;
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_     = f;
+            want_    = nthreads;
+            running_ = nthreads - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return running_ == 0; });
+    }
+};
+HostPool & host_pool()
+{
+    static HostPool p;
+    return p;
+}
+} // namespace
+
 template <typename F>
 static void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
 {
@@ -472,14 +583,8 @@ static void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
             body(t, t == 0 ? 0 : n, n);
         return;
     }
-    std::vector<std::thread> pool;
-    pool.reserve(nthreads - 1);
     uint64_t const step = (n + nthreads - 1) / nthreads;
-    for (unsigned t = 1; t < nthreads; ++t)
-        pool.emplace_back([&body, t, step, n]() { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
-    body(0, 0, std::min(n, step));
-    for (std::thread & th : pool)
-        th.join();
+    host_pool().run(nthreads, [&body, step, n](unsigned t) { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
 }
 
 static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
@@ -547,8 +652,13 @@ int lx_create(int device_id, lx_handle ** out)
         return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess)
         return bail("hipEventCreate", e);
-    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess)
+    if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
+    for (auto & ln : h->xb)
+        for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt})
+            if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
+                return bail("hipEventCreate", e);
     for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
         if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
             return bail("hipEventCreate", e);
@@ -580,10 +690,23 @@ void lx_destroy(lx_handle * h)
             (void)hipFree(h->sc_dev[s]);
     if (h->d_ws_top)
         (void)hipFree(h->d_ws_top);
-    if (h->stream2)
+    for (hipStream_t st : {h->stream2, h->stream3})
+        if (st)
+        {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (auto & ln : h->xb)
     {
-        (void)hipStreamSynchronize(h->stream2);
-        (void)hipStreamDestroy(h->stream2);
+        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt})
+            if (b->ptr)
+                (void)hipFree(b->ptr);
+        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle})
+            if (b->ptr)
+                (void)hipHostFree(b->ptr);
+        for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt})
+            if (ev)
+                (void)hipEventDestroy(ev);
     }
     for (hipEvent_t ev : {h->evF[0], h->evF[1], h->evB[0], h->evB[1], h->evS})
         if (ev)
@@ -1211,7 +1334,8 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext,
                           uint64_t n, lx::Hsp * d_hsp, uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream,
                           uint64_t max_q, uint64_t max_s, int share_slots, uint32_t const * d_src = nullptr,
-                          uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr, bool by_pos = false)
+                          uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr, bool by_pos = false,
+                          uint64_t ops_stride = 0)
 {
     if (!h->trace_ok[slot])
         return fail(h, LX_EINVAL, "pass 2 needs every (matrix entry - gap_extend) in [-31, 31]");
@@ -1289,7 +1413,10 @@ static int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const 
         p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr) + (uint64_t)b * chunk;
         p.out_hsp        = (d_src && !by_pos) ? d_hsp : d_hsp + c0;
         p.out_ops        = d_ops;
-        p.ops_off        = (d_src && !by_pos) ? d_ops_off : d_ops_off + c0;
+        p.ops_off        = !d_ops_off ? nullptr : (d_src && !by_pos) ? d_ops_off : d_ops_off + c0;
+        p.ops_stride     = ops_stride;
+        if (!d_ops_off && ((d_src && !by_pos) ? false : c0 != 0)) // uniform slots are addressed by the index inside the chunk
+            p.out_ops = d_ops + c0 * ops_stride;
         p.out_by_pos     = by_pos ? 1 : 0;
         p.src            = d_src ? d_src + c0 : nullptr;
         p.score_in       = d_score_in + c0;
@@ -1540,9 +1667,49 @@ int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
 // phases: 1 = pass 1 (or the sweep) + selection, 2 = pass 2 (or the sweep's backtrace), 3 = both.  by_pos: records and
 // ops offsets are indexed by the position in the survivor list instead of by extension (the host entry point assigns
 // compact ops offsets between the two phases and downloads only the survivors' records).
+// lx_extend_batch's additions to the fused step: ops slots of one size instead of an offset per extension, the survivors'
+// ops run-length packed into a dense stream (lx_pack.hip), a copy of the survivor list's original indices
+struct FusedExtra
+{
+    uint64_t             ops_stride = 0;
+    uint8_t *            d_rle      = nullptr;
+    unsigned long long * d_rle_top  = nullptr;
+    uint64_t             rle_cap    = 0;
+    uint32_t *           d_src_out  = nullptr; // [survivor list capacity]
+};
+
+// after the backtrace (records and slots by list position): the survivors' ops as run-length codes, the list's original
+// indices next to them
+static int fused_pack(lx_handle * h, FusedExtra const * fx, uint64_t cap, void * d_out_hsp, void * d_out_ops, void const * d_ops_off,
+                      void * d_out_count, hipStream_t stream, bool packed_already = false)
+{
+    if (!fx || !fx->d_rle)
+        return LX_OK;
+    if (fx->d_src_out)
+        LX_HIP(h, hipMemcpyAsync(fx->d_src_out, h->d_sel_src.ptr, cap * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+    if (packed_already) // (the checkpoint backtrace emits the codes itself)
+        return LX_OK;
+    lx::PackParams pp{};
+    pp.hsp        = static_cast<lx::Hsp *>(d_out_hsp);
+    pp.ops        = static_cast<uint8_t const *>(d_out_ops);
+    pp.ops_off    = static_cast<uint64_t const *>(d_ops_off);
+    pp.ops_stride = fx->ops_stride;
+    pp.src        = static_cast<uint32_t const *>(h->d_sel_src.ptr);
+    pp.count_ptr  = static_cast<uint64_t const *>(d_out_count);
+    pp.n          = cap;
+    pp.rle        = fx->d_rle;
+    pp.rle_top    = fx->d_rle_top;
+    pp.rle_cap    = fx->rle_cap;
+    pp.err        = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
+    LX_HIP(h, hipMemsetAsync(fx->d_rle_top, 0, sizeof(unsigned long long), stream));
+    LX_HIP(h, lx::launch_rle_pack(pp, stream));
+    return LX_OK;
+}
+
 static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext, uint64_t n,
                       void const * d_min_score, int32_t min_score_all, void * d_out_score, void * d_out_hsp, void * d_out_ops,
-                      void const * d_ops_off, void * d_out_count, void * stream_, int phases, bool by_pos)
+                      void const * d_ops_off, void * d_out_count, void * stream_, int phases, bool by_pos,
+                      FusedExtra const * fx = nullptr)
 {
     if (!h)
         return LX_EINVAL;
@@ -1550,7 +1717,8 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (n == 0)
         return LX_OK;
-    if (!d_q_res || !d_s_res || !d_ext || !d_out_score || !d_out_count || ((phases & 2) && (!d_out_hsp || !d_out_ops || !d_ops_off)))
+    if (!d_q_res || !d_s_res || !d_ext || !d_out_score || !d_out_count ||
+        ((phases & 2) && (!d_out_hsp || !d_out_ops || (!d_ops_off && !(fx && fx->ops_stride)))))
         return fail(h, LX_EINVAL, "NULL device pointer");
     if (h->opt_max_qlen == 0 || h->opt_max_slen == 0)
         return fail(h, LX_ESTATE, "lx_extend_batch_dev needs LX_OPT_MAX_QLEN and LX_OPT_MAX_SLEN (it never synchronises)");
@@ -1799,6 +1967,14 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         p.out_hsp       = static_cast<lx::Hsp *>(d_out_hsp);
         p.out_ops       = static_cast<uint8_t *>(d_out_ops);
         p.ops_off       = static_cast<uint64_t const *>(d_ops_off);
+        p.ops_stride    = fx ? fx->ops_stride : 0;
+        if (fx && fx->d_rle) // the backtrace writes run-length codes itself
+        {
+            p.rle     = fx->d_rle;
+            p.rle_top = fx->d_rle_top;
+            p.rle_cap = fx->rle_cap;
+            LX_HIP(h, hipMemsetAsync(fx->d_rle_top, 0, sizeof(unsigned long long), stream));
+        }
         p.src           = static_cast<uint32_t const *>(h->d_sel_src.ptr);
         p.count_ptr     = static_cast<uint64_t const *>(d_out_count);
         p.chunk_start   = 0;
@@ -1817,6 +1993,8 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         PhaseTimer ptb(h, stream, 3);
         LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));
         ptb.close();
+        if ((rc = fused_pack(h, fx, cap, d_out_hsp, d_out_ops, d_ops_off, d_out_count, stream, true)))
+            return rc;
         LX_HIP(h, hipEventRecord(h->ev1, stream));
         h->timed = true;
         return LX_OK;
@@ -1827,8 +2005,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
                         static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? 4 : 0,
                         static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count),
-                        static_cast<int32_t const *>(h->d_sel_score.ptr), by_pos);
+                        static_cast<int32_t const *>(h->d_sel_score.ptr), by_pos, fx ? fx->ops_stride : 0);
     if (rc)
+        return rc;
+    if ((rc = fused_pack(h, fx, cap, d_out_hsp, d_out_ops, d_ops_off, d_out_count, stream)))
         return rc;
     LX_HIP(h, hipEventRecord(h->ev1, stream));
     h->timed = true;
@@ -1980,10 +2160,465 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
                       d_out_count, stream_, 3, false);
 }
 
-// Both passes on host buffers.  The extensions are grouped by query slice (sorted if the caller's list is not grouped),
-// every run is padded to 16 slots so that the device path may promise LX_OPT_QUERY_RUN = 16, and the two phases of the
-// fused step are split by one synchronisation: after pass 1 + selection the host knows the survivors and hands out compact
-// ops offsets, so that only the survivors' records and ops cross PCIe.
+// Both passes on host buffers, as a pipeline of chunks.  The list is cut at query-run boundaries into chunks of a few
+// hundred thousand extensions; per chunk the host groups the extensions by query slice and pads every run to 16 (or 8)
+// slots -- the promise LX_OPT_QUERY_RUN makes to the device path -- into pinned staging, the GPU runs the whole fused step
+// (sweep -> selection -> backtrace -> run-length packing of the ops, nothing in between comes back to the host), and the
+// results return as scores + the survivors' records + their run-length codes.  Two chunks are in flight: uploads and
+// downloads of one run on copy streams while the other's kernels run, and the host prepares chunk k + 1 / unpacks
+// chunk k - 1 meanwhile.  What crosses PCIe per extension: 28 B up, 4 B + (survivors) 52 B + ~8 B of codes down.
+namespace
+{
+
+struct XbPrep // what the host keeps about a chunk until its results are back
+{
+    uint64_t              k0 = 0, k1 = 0; // positions in the ordered list
+    uint64_t              slots = 0, cap_sel = 0;
+    std::vector<uint32_t> slot_src;       // original index of every slot (0xffffffff = padding)
+};
+
+inline void rle_expand(uint8_t const * codes, int32_t n_ops, uint8_t * out)
+{
+    static char const kOp[4] = {'M', 'D', 'I', 'M'};
+    int32_t done = 0;
+    while (done < n_ops)
+    {
+        uint8_t const c   = *codes++;
+        int32_t const len = (c & 63) + 1;
+        std::memset(out + done, kOp[c >> 6], (size_t)len);
+        done += len;
+    }
+}
+
+inline uint64_t rle_length(uint8_t const * codes, int32_t n_ops)
+{
+    uint64_t k = 0;
+    for (int32_t done = 0; done < n_ops; ++k)
+        done += (codes[k] & 63) + 1;
+    return k;
+}
+
+int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return LX_OK;
+    if (b.ptr)
+    {
+        LX_HIP(h, hipHostFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+    }
+    size_t const want = bytes + bytes / 4 + 4096;
+    LX_HIP(h, hipHostMalloc(&b.ptr, want, hipHostMallocDefault));
+    b.cap = want;
+    return LX_OK;
+}
+
+} // namespace
+
+static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                           lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, bool want_rle)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    HostMarks hm(want_rle ? "lx_extend_batch_rle" : "lx_extend_batch");
+
+    // ---- validate; is the list grouped by query (lambda's lists are sorted by query)?  The loops over the list are spread
+    // over a few host threads: at millions of extensions per call they would otherwise cost more than the kernels.
+    unsigned const nthreads = host_threads(n);
+    struct Part
+    {
+        uint64_t live = 0, bad = ~0ull;
+        bool     monotone = true;
+    };
+    std::vector<Part> parts(nthreads);
+    parallel_ranges(n, nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        Part &   pt   = parts[t];
+                        uint64_t prev = ~0ull; // last live extension before i (of the whole list)
+                        for (uint64_t i = lo; i-- > 0;)
+                            if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                            {
+                                prev = i;
+                                break;
+                            }
+                        for (uint64_t i = lo; i < hi; ++i)
+                        {
+                            lx_extension const & x = ext[i];
+                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+                            {
+                                pt.bad = std::min(pt.bad, i);
+                                continue;
+                            }
+                            if (x.q_len == 0 || x.s_len == 0)
+                            {
+                                out_score[i]   = 0;
+                                out_hsp[i]     = lx_hsp{};
+                                out_ops_off[i] = 0;
+                                continue;
+                            }
+                            if (prev != ~0ull && x.q_off < ext[prev].q_off)
+                                pt.monotone = false;
+                            prev = i;
+                            ++pt.live;
+                        }
+                    });
+    uint64_t live = 0;
+    bool     monotone = true;
+    for (Part const & pt : parts)
+    {
+        if (pt.bad != ~0ull)
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
+        live += pt.live;
+        monotone = monotone && pt.monotone;
+    }
+    if (live == 0)
+        return LX_OK;
+    std::vector<uint32_t> & idx = h->xb_idx;
+    idx.resize(live);
+    {
+        std::vector<uint64_t> first(nthreads + 1, 0);
+        for (unsigned t = 0; t < nthreads; ++t)
+            first[t + 1] = first[t] + parts[t].live;
+        parallel_ranges(n, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = first[t];
+                            for (uint64_t i = lo; i < hi; ++i)
+                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                                    idx[o++] = (uint32_t)i;
+                        });
+    }
+    if (!monotone) // anything else is sorted first: equal slices become adjacent
+        std::sort(idx.begin(), idx.end(),
+                  [&](uint32_t a, uint32_t b)
+                  {
+                      lx_extension const &x = ext[a], &y = ext[b];
+                      return x.q_off != y.q_off ? x.q_off < y.q_off : x.q_len != y.q_len ? x.q_len < y.q_len : a < b;
+                  });
+    auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
+    // where the runs of one query slice begin in the ordered list
+    std::vector<uint8_t> & newrun = h->xb_newrun;
+    newrun.resize(live + 1);
+    parallel_ranges(live, nthreads,
+                    [&](unsigned, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t k = lo; k < hi; ++k)
+                            newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
+                    });
+    newrun[live] = 1;
+    hm.mark("validate");
+
+    // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
+    struct Guard
+    {
+        lx_handle * h;
+        uint64_t    qlen, slen, run;
+        ~Guard()
+        {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->stream2);
+            (void)hipStreamSynchronize(h->stream3);
+            h->opt_max_qlen  = qlen;
+            h->opt_max_slen  = slen;
+            h->opt_query_run = run;
+        }
+    } const guard{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run};
+
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+
+    static uint64_t const chunk_target = []() -> uint64_t
+    {
+        char const * e = getenv("LX_EXTEND_CHUNK"); // development aid
+        return e ? (uint64_t)std::max(1024ll, atoll(e)) : 640ull << 10;
+    }();
+    h->ext_bytes.clear();
+    uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
+    double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0; // LX_HOST_TIMING: where the host's time goes
+    auto     now    = []() { return std::chrono::steady_clock::now(); };
+    auto     ms     = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b)
+    { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    XbPrep   prep[2];
+    bool     in_flight[2] = {false, false};
+
+    // ---- chunk k0 .. k1 of the ordered list -> padded slots in lane L's pinned staging -> uploads and kernels queued
+    auto enqueue = [&](int L, uint64_t k0, uint64_t k1) -> int
+    {
+        auto const          t0 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        pr.k0 = k0;
+        pr.k1 = k1;
+        // runs of one query slice; padded to 16 slots (one query per wavefront of the 8-lane packed geometry) or, when the
+        // queries have few windows each, to 8 (one query per half wavefront: ~1.4 x the time per slot) -- whichever is less work
+        std::vector<uint64_t> & grp = h->xb_grp; // (first position, first slot) of every run + a sentinel
+        grp.clear();
+        uint64_t slots16 = 0, slots8 = 0, max_q = 1, max_s = 1;
+        for (uint64_t k = k0; k < k1;)
+        {
+            uint64_t kk = k + 1;
+            while (kk < k1 && !newrun[kk])
+                ++kk;
+            grp.push_back(k);
+            grp.push_back(0);
+            slots16 += (kk - k + 15) / 16 * 16;
+            slots8 += (kk - k + 7) / 8 * 8;
+            max_q = std::max<uint64_t>(max_q, ext[idx[k]].q_len);
+            k     = kk;
+        }
+        grp.push_back(k1);
+        grp.push_back(0);
+        uint64_t const ngroups = grp.size() / 2 - 1;
+        uint64_t const kRun    = (slots8 * 7 < slots16 * 5) ? 8 : 16;
+        uint64_t       slots   = 0;
+        for (uint64_t g = 0; g <= ngroups; ++g)
+        {
+            grp[2 * g + 1] = slots;
+            if (g < ngroups)
+                slots += (grp[2 * g + 2] - grp[2 * g] + kRun - 1) / kRun * kRun;
+        }
+        pr.slots   = slots;
+        pr.cap_sel = (slots + slots / kRun * 3 + 7) / 8 * 8 + 8;
+        pr.slot_src.resize(slots);
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_ext, slots * sizeof(lx_extension))) || (rc2 = ensure_pinned(h, ln.p_min, slots * sizeof(int32_t))))
+            return rc2;
+        lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
+        int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
+        uint32_t * const     slot_src = pr.slot_src.data();
+        std::vector<uint64_t> tmax(nthreads, 1);
+        parallel_ranges(ngroups, nthreads,
+                        [&](unsigned t, uint64_t glo, uint64_t ghi)
+                        {
+                            uint64_t ms = 1;
+                            for (uint64_t g = glo; g < ghi; ++g)
+                            {
+                                uint64_t const a = grp[2 * g], b = grp[2 * g + 2], o1 = grp[2 * g + 3];
+                                uint64_t       o = grp[2 * g + 1];
+                                for (uint64_t j = a; j < b; ++j, ++o)
+                                {
+                                    slot_ext[o] = ext[idx[j]];
+                                    slot_src[o] = idx[j];
+                                    slot_min[o] = min_score ? min_score[idx[j]] : min_score_all;
+                                    ms          = std::max<uint64_t>(ms, ext[idx[j]].s_len);
+                                }
+                                lx_extension dummy = ext[idx[a]];
+                                dummy.s_len        = 0;
+                                for (; o < o1; ++o)
+                                {
+                                    slot_ext[o] = dummy;
+                                    slot_src[o] = 0xffffffffu;
+                                    slot_min[o] = 0x7fffffff; // never survives
+                                }
+                            }
+                            tmax[t] = std::max(tmax[t], ms);
+                        });
+        for (uint64_t v : tmax)
+            max_s = std::max(max_s, v);
+        auto const t1 = now();
+        t_prep += ms(t0, t1);
+        // device side of the lane
+        uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
+        if ((rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
+            (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) ||
+            (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) ||
+            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_score, slots * sizeof(int32_t))) || (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+            return rc2;
+        LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipMemcpyAsync(ln.d_min.ptr, slot_min, slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+        h->opt_max_qlen  = max_q;
+        h->opt_max_slen  = max_s;
+        h->opt_query_run = kRun;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                              nullptr, d_cnt, h->stream, 3, true, &fx)))
+            return rc2;
+        LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
+        // what has a size the host knows goes back at once; records and codes follow when the counts have arrived
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipMemcpyAsync(ln.p_score.ptr, ln.d_score.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
+        in_flight[L] = true;
+        t_issue += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- results of the chunk in lane L -> the caller's arrays
+    auto collect = [&](int L) -> int
+    {
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        in_flight[L]           = false;
+        auto const t0          = now();
+        LX_HIP(h, hipEventSynchronize(ln.ev_cnt));
+        uint64_t const * const cnt = static_cast<uint64_t const *>(ln.p_cnt.ptr);
+        uint64_t const count = cnt[0], nrle = cnt[2];
+        if (count > pr.cap_sel)
+            return fail(h, LX_ESTATE, "survivor list longer than its capacity");
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
+            (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
+            return rc2;
+        // (on the upload stream: stream2 already holds the next chunk's first-stage copies, which wait for its kernels)
+        if (count)
+        {
+            LX_HIP(h, hipMemcpyAsync(ln.p_hsp.ptr, ln.d_hsp.ptr, count * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_src.ptr, ln.d_src.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            if (nrle)
+                LX_HIP(h, hipMemcpyAsync(ln.p_rle.ptr, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
+        }
+        LX_HIP(h, hipStreamSynchronize(h->stream3));
+        auto const t1 = now();
+        t_wait += ms(t0, t1);
+        int32_t const * const  sc      = static_cast<int32_t const *>(ln.p_score.ptr);
+        lx_hsp const * const   hs      = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
+        uint32_t const * const sel_src = static_cast<uint32_t const *>(ln.p_src.ptr);
+        uint8_t const * const  codes   = static_cast<uint8_t const *>(ln.p_rle.ptr);
+        uint32_t const * const slot_src = pr.slot_src.data();
+        // (1) per survivor: how many bytes its ops take in the handle's buffer (column bytes, or the codes themselves),
+        //     and which list position a slot has
+        std::vector<uint64_t> & pos_off  = h->xb_off;
+        std::vector<uint32_t> & slot_pos = h->xb_pos;
+        pos_off.resize(count + 1);
+        slot_pos.resize(pr.slots);
+        parallel_ranges(pr.slots, nthreads,
+                        [&](unsigned, uint64_t lo, uint64_t hi) { std::fill(slot_pos.begin() + lo, slot_pos.begin() + hi, 0xffffffffu); });
+        std::vector<uint64_t> part(nthreads + 1, 0);
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t sum = 0;
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t len = 0;
+                                if (sel_src[e] != 0xffffffffu)
+                                {
+                                    slot_pos[sel_src[e]] = (uint32_t)e;
+                                    if (hs[e].score > 0)
+                                        len = want_rle ? rle_length(codes + (uint32_t)hs[e].ops_shift, hs[e].n_ops) : (uint64_t)hs[e].n_ops;
+                                }
+                                pos_off[e] = len;
+                                sum += len;
+                            }
+                            part[t + 1] = sum;
+                        });
+        // (2) offsets: prefix over the threads' shares, then inside each share
+        part[0] = ops_total;
+        for (unsigned t = 0; t < nthreads; ++t)
+            part[t + 1] += part[t];
+        uint64_t const total = part[nthreads];
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t at = part[t];
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t const len = pos_off[e];
+                                pos_off[e]         = at;
+                                at += len;
+                            }
+                        });
+        pos_off[count] = total;
+        h->ext_bytes.grow(total + 16);
+        uint8_t * const dst = h->ext_bytes.data();
+        // (3) one pass over the chunk's slots: score and record of every extension, the survivors' ops
+        std::vector<uint64_t> untraced(nthreads, ~0ull);
+        parallel_ranges(pr.slots, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            for (uint64_t o = lo; o < hi; ++o)
+                            {
+                                uint32_t const orig = slot_src[o];
+                                if (orig == 0xffffffffu)
+                                    continue;
+                                out_score[orig]  = sc[o];
+                                uint32_t const e = slot_pos[o];
+                                if (e == 0xffffffffu)
+                                {
+                                    lx_hsp r{};
+                                    r.score           = sc[o];
+                                    out_hsp[orig]     = r;
+                                    out_ops_off[orig] = 0;
+                                    continue;
+                                }
+                                lx_hsp r = hs[e];
+                                if (r.score < 0)
+                                {
+                                    untraced[t] = std::min<uint64_t>(untraced[t], orig);
+                                    continue;
+                                }
+                                uint8_t const * const c = codes + (uint32_t)r.ops_shift;
+                                if (r.score > 0 && want_rle)
+                                    std::memcpy(dst + pos_off[e], c, (size_t)(pos_off[e + 1] - pos_off[e]));
+                                else if (r.score > 0)
+                                    rle_expand(c, r.n_ops, dst + pos_off[e]);
+                                r.ops_shift       = 0;
+                                out_hsp[orig]     = r;
+                                out_ops_off[orig] = pos_off[e];
+                            }
+                        });
+        for (uint64_t u : untraced)
+            if (u != ~0ull)
+                return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
+        ops_total = total;
+        t_unpack += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- the pipeline: prepare + queue chunk c, then unpack chunk c - 1 while c runs
+    uint64_t k0 = 0;
+    int      c  = 0;
+    while (k0 < live)
+    {
+        uint64_t k1 = std::min<uint64_t>(live, k0 + chunk_target);
+        while (k1 < live && !newrun[k1]) // never cut a query's run
+            ++k1;
+        int const L = c & 1;
+        if (in_flight[L] && (rc = collect(L)))
+            return rc;
+        if ((rc = enqueue(L, k0, k1)))
+            return rc;
+        if (in_flight[L ^ 1] && (rc = collect(L ^ 1)))
+            return rc;
+        k0 = k1;
+        ++c;
+    }
+    for (int L : {c & 1, (c & 1) ^ 1})
+        if (in_flight[L] && (rc = collect(L)))
+            return rc;
+    if ((rc = check_async_error(h)))
+        return rc;
+    hm.mark("pipeline");
+    if (hm.on)
+        fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f\n", c, t_prep, t_issue,
+                t_wait, t_unpack);
+    *out_ops       = h->ext_bytes.data();
+    *out_ops_bytes = ops_total;
+    return LX_OK;
+}
+
 int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                     lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                     lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
@@ -2005,277 +2640,39 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
     if (h->opt_band)
         return host_banded(h, slot, 2, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, min_score, min_score_all, out_score, out_hsp, nullptr,
                            nullptr, out_ops_off, out_ops, out_ops_bytes);
-    int rc = bind(h);
-    if (rc)
-        return rc;
-    SubjectRef sref;
-    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
-        return rc;
-    s_bytes = sref.bytes;
-    HostMarks hm("lx_extend_batch");
+    return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
+                           out_ops_bytes, false);
+}
 
-    // ---- validate, group by query slice.  Every maximal run of adjacent extensions of one slice is a group; only a
-    // list that is badly grouped (the padding would cost more than half of the work) is sorted first.  The loops over
-    // the list are spread over a few host threads: at millions of extensions per call they would otherwise cost more
-    // than the kernels.
-    unsigned const nthreads = host_threads(n);
-    struct Part
-    {
-        uint64_t max_q = 1, max_s = 1, live = 0, bad = ~0ull;
-    };
-    std::vector<Part> parts(nthreads);
-    parallel_ranges(n, nthreads,
-                    [&](unsigned t, uint64_t lo, uint64_t hi)
-                    {
-                        Part & pt = parts[t];
-                        for (uint64_t i = lo; i < hi; ++i)
-                        {
-                            lx_extension const & x = ext[i];
-                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
-                            {
-                                pt.bad = std::min(pt.bad, i);
-                                continue;
-                            }
-                            if (x.q_len == 0 || x.s_len == 0)
-                            {
-                                out_score[i]   = 0;
-                                out_hsp[i]     = lx_hsp{};
-                                out_ops_off[i] = 0;
-                                continue;
-                            }
-                            pt.max_q = std::max<uint64_t>(pt.max_q, x.q_len);
-                            pt.max_s = std::max<uint64_t>(pt.max_s, x.s_len);
-                            ++pt.live;
-                        }
-                    });
-    uint64_t max_q = 1, max_s = 1, live = 0;
-    for (Part const & pt : parts)
-    {
-        if (pt.bad != ~0ull)
-            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
-        max_q = std::max(max_q, pt.max_q);
-        max_s = std::max(max_s, pt.max_s);
-        live += pt.live;
-    }
-    if (live == 0)
+int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                        lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                        lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (out_ops)
+        *out_ops = nullptr;
+    if (out_ops_bytes)
+        *out_ops_bytes = 0;
+    if (n == 0)
         return LX_OK;
-    std::vector<uint32_t> & idx = h->xb_idx;
-    idx.resize(live);
-    {
-        std::vector<uint64_t> first(nthreads + 1, 0);
-        for (unsigned t = 0; t < nthreads; ++t)
-            first[t + 1] = first[t] + parts[t].live;
-        parallel_ranges(n, nthreads,
-                        [&](unsigned t, uint64_t lo, uint64_t hi)
-                        {
-                            uint64_t o = first[t];
-                            for (uint64_t i = lo; i < hi; ++i)
-                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
-                                    idx[o++] = (uint32_t)i;
-                        });
-    }
-    auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
-    // groups: first list position and first slot of every run (+ a sentinel).  A list whose query offsets never step
-    // back is grouped (lambda's lists are sorted by query); anything else is sorted first.
-    std::vector<uint64_t> & grp = h->xb_grp;
-    auto find_groups = [&]()
-    {
-        grp.clear();
-        bool monotone = true;
-        for (size_t k = 0; k < idx.size();)
-        {
-            size_t k1 = k + 1;
-            while (k1 < idx.size() && same_slice(idx[k1], idx[k]))
-                ++k1;
-            monotone = monotone && (k == 0 || ext[idx[k]].q_off >= ext[idx[k - 1]].q_off);
-            grp.push_back(k);
-            grp.push_back(0);
-            k = k1;
-        }
-        grp.push_back(idx.size());
-        grp.push_back(0);
-        return monotone;
-    };
-    if (!find_groups())
-    {
-        std::sort(idx.begin(), idx.end(),
-                  [&](uint32_t a, uint32_t b)
-                  {
-                      lx_extension const &x = ext[a], &y = ext[b];
-                      return x.q_off != y.q_off ? x.q_off < y.q_off : x.q_len != y.q_len ? x.q_len < y.q_len : a < b;
-                  });
-        (void)find_groups();
-    }
-    uint64_t const ngroups = grp.size() / 2 - 1;
-    // Runs are padded to 16 slots (one query per wavefront of the 8-lane packed geometry) or, when the queries have few
-    // windows each, to 8 (one query per half wavefront: ~1.4 x the time per slot, measured) -- whichever is less work.
-    uint64_t slots16 = 0, slots8 = 0;
-    for (uint64_t g = 0; g < ngroups; ++g)
-    {
-        uint64_t const len = grp[2 * g + 2] - grp[2 * g];
-        slots16 += (len + 15) / 16 * 16;
-        slots8 += (len + 7) / 8 * 8;
-    }
-    uint64_t const kRun = (slots8 * 7 < slots16 * 5) ? 8 : 16;
-    uint64_t       slots = 0;
-    for (uint64_t g = 0; g <= ngroups; ++g)
-    {
-        grp[2 * g + 1] = slots;
-        if (g < ngroups)
-            slots += (grp[2 * g + 2] - grp[2 * g] + kRun - 1) / kRun * kRun;
-    }
-    std::vector<lx_extension> & slot_ext = h->xb_ext;
-    std::vector<uint32_t> &     slot_src = h->xb_src;
-    std::vector<int32_t> &      slot_min = h->xb_min;
-    slot_ext.resize(slots);
-    slot_src.resize(slots);
-    slot_min.resize(slots);
-    parallel_ranges(ngroups, nthreads,
-                    [&](unsigned, uint64_t glo, uint64_t ghi)
-                    {
-                        for (uint64_t g = glo; g < ghi; ++g)
-                        {
-                            uint64_t const k0 = grp[2 * g], k1 = grp[2 * g + 2], o1 = grp[2 * g + 3];
-                            uint64_t       o = grp[2 * g + 1];
-                            for (uint64_t j = k0; j < k1; ++j, ++o)
-                            {
-                                slot_ext[o] = ext[idx[j]];
-                                slot_src[o] = idx[j];
-                                slot_min[o] = min_score ? min_score[idx[j]] : min_score_all;
-                            }
-                            lx_extension dummy = ext[idx[k0]];
-                            dummy.s_len        = 0;
-                            for (; o < o1; ++o)
-                            {
-                                slot_ext[o] = dummy;
-                                slot_src[o] = 0xffffffffu;
-                                slot_min[o] = 0x7fffffff; // never survives
-                            }
-                        }
-                    });
-    hm.mark("group");
+    if (!ext || !out_score || !out_hsp || !out_ops_off || !out_ops || !out_ops_bytes || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    if (h->opt_band)
+        return fail(h, LX_EINVAL, "lx_extend_batch_rle: band mode returns column bytes only (lx_extend_batch)");
+    return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
+                           out_ops_bytes, true);
+}
 
-    // ---- upload, phase 1
-    uint64_t const cap_sel = (slots + slots / kRun * 3 + 7) / 8 * 8 + 8;
-    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) ||
-        (rc = ensure(h, h->d_out, slots * sizeof(int32_t))) || (rc = ensure(h, h->d_keep, slots * sizeof(int32_t) + 64)))
-        return rc;
-    if (q_bytes)
-        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
-    if (sref.upload)
-        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
-    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, slot_ext.data(), slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
-    // d_keep: [2 x uint64 count][int32 min score per slot]
-    uint64_t * const d_count = static_cast<uint64_t *>(h->d_keep.ptr);
-    int32_t * const  d_min   = reinterpret_cast<int32_t *>(d_count + 2);
-    LX_HIP(h, hipMemcpyAsync(d_min, slot_min.data(), slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-    // the promises of the device path hold for the padded list; the caller's option values come back on every exit
-    struct RestoreOptions
-    {
-        lx_handle * h;
-        uint64_t    qlen, slen, run;
-        ~RestoreOptions()
-        {
-            h->opt_max_qlen  = qlen;
-            h->opt_max_slen  = slen;
-            h->opt_query_run = run;
-        }
-    } const restore_options{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run};
-    h->opt_max_qlen  = max_q;
-    h->opt_max_slen  = max_s;
-    h->opt_query_run = kRun;
-    rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, nullptr, nullptr, nullptr, d_count,
-                    h->stream, 1, true);
-    if (rc)
-        return rc;
-    hm.mark("phase1-issue");
-    uint64_t             count[2] = {0, 0};
-    std::vector<int32_t> & slot_score = h->xb_score;
-    slot_score.resize(slots);
-    if (hipMemcpyAsync(count, d_count, sizeof(count), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        hipMemcpyAsync(slot_score.data(), h->d_out.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-        (rc = check_async_error(h)))
-        return rc ? rc : fail(h, LX_EHIP, "download after pass 1 failed");
-    hm.mark("phase1-wait");
-    if (count[0] > cap_sel)
-        return fail(h, LX_ESTATE, "survivor list longer than its capacity");
-    std::vector<uint32_t> & sel_src = h->xb_sel;
-    sel_src.resize(count[0]);
-    if (count[0])
-        LX_HIP(h, hipMemcpyAsync(sel_src.data(), h->d_sel_src.ptr, count[0] * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
-    LX_HIP(h, hipStreamSynchronize(h->stream));
-
-    // ---- compact ops offsets by survivor position, phase 2
-    std::vector<uint64_t> & pos_off = h->xb_off;
-    pos_off.resize(count[0] + 1);
-    uint64_t total = 0;
-    for (uint64_t e = 0; e < count[0]; ++e)
-    {
-        pos_off[e] = total;
-        if (sel_src[e] != 0xffffffffu)
-            total += (uint64_t)slot_ext[sel_src[e]].q_len + slot_ext[sel_src[e]].s_len;
-    }
-    h->ext_hsp.resize(count[0]);
-    h->ext_ops.resize(total + 16);
-    if (count[0])
-    {
-        if ((rc = ensure(h, h->d_hsp, count[0] * sizeof(lx_hsp))) || (rc = ensure(h, h->d_ops, total + 16)) ||
-            (rc = ensure(h, h->d_opsoff, count[0] * sizeof(uint64_t))))
-            return rc;
-        LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, pos_off.data(), count[0] * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
-        rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, slots, d_min, 0, h->d_out.ptr, h->d_hsp.ptr, h->d_ops.ptr,
-                        h->d_opsoff.ptr, d_count, h->stream, 2, true);
-        if (rc)
-            return rc;
-        hm.mark("phase2-issue");
-        LX_HIP(h, hipMemcpyAsync(h->ext_hsp.data(), h->d_hsp.ptr, count[0] * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
-        if (total)
-            LX_HIP(h, hipMemcpyAsync(h->ext_ops.data(), h->d_ops.ptr, total, hipMemcpyDeviceToHost, h->stream));
-        rc = check_async_error(h);
-        hm.mark("phase2-wait");
-    }
-    if (rc)
-        return rc;
-
-    // ---- results back to the caller's order
-    parallel_ranges(slots, nthreads,
-                    [&](unsigned, uint64_t lo, uint64_t hi)
-                    {
-                        for (uint64_t o = lo; o < hi; ++o)
-                            if (slot_src[o] != 0xffffffffu)
-                            {
-                                lx_hsp r{};
-                                r.score                  = slot_score[o];
-                                out_score[slot_src[o]]   = slot_score[o];
-                                out_hsp[slot_src[o]]     = r;
-                                out_ops_off[slot_src[o]] = 0;
-                            }
-                    });
-    std::vector<uint64_t> untraced(nthreads, ~0ull);
-    parallel_ranges(count[0], nthreads,
-                    [&](unsigned t, uint64_t lo, uint64_t hi)
-                    {
-                        for (uint64_t e = lo; e < hi; ++e)
-                        {
-                            if (sel_src[e] == 0xffffffffu)
-                                continue;
-                            uint32_t const orig = slot_src[sel_src[e]];
-                            lx_hsp const & r    = h->ext_hsp[e];
-                            if (r.score < 0)
-                            {
-                                untraced[t] = std::min<uint64_t>(untraced[t], orig);
-                                continue;
-                            }
-                            out_hsp[orig]     = r;
-                            out_ops_off[orig] = pos_off[e];
-                        }
-                    });
-    for (uint64_t u : untraced)
-        if (u != ~0ull)
-            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
-    *out_ops       = h->ext_ops.data();
-    *out_ops_bytes = total;
-    hm.mark("scatter");
+int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out)
+{
+    if (!codes || !out || n_ops < 0)
+        return LX_EINVAL;
+    rle_expand(codes, n_ops, out);
     return LX_OK;
 }
 

@@ -592,6 +592,9 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     int              mode = 0;                          // 0 = H, 1 = F (vertical), 2 = E (horizontal)
     int              left = 0;
     int32_t          nm = 0, nx = 0, np = 0, go = 0, gx = 0;
+    // run-length mode (p.rle): the run being collected (op 0 = 'M', 1 = 'D', 2 = 'I'; 3 = none yet) and the codes written so far
+    bool const       rle_mode = p.rle != nullptr;
+    uint32_t         run_op = 3, run_len = 0, ncodes = 0;
 
     // Checkpoint words are int16 pairs (value, gap state).  Slots written by the packed-half sweep hold the compact
     // codes of Ckpt16Layout instead: the loaders below expand them to the same pairs.  An extension that sweep declined
@@ -623,9 +626,9 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         return reinterpret_cast<uint32_t const *>(bnd_of(st / G) + bnd_quad_index<G>(k / 4, st % G))[k & 3];
     };
     // ops are produced end -> begin into the slot [0, cap): apos = misalignment of the slot start + offset of the next byte
-    auto emit = [&](uint32_t op)
+    auto put_byte = [&](uint32_t byte)
     {
-        acc |= op << (8 * (apos & 3));
+        acc |= byte << (8 * (apos & 3));
         if ((apos & 3) == 0)
         {
             if (apos + 3 <= a0 + cap - 1)
@@ -636,6 +639,27 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             acc = 0;
         }
         --apos;
+    };
+    // one alignment column: its op byte, or -- run-length mode -- one more column of the current run
+    auto emit = [&](uint32_t op)
+    {
+        if (rle_mode)
+        {
+            uint32_t const oc = op == (uint32_t)'M' ? 0u : (op == (uint32_t)'D' ? 1u : 2u);
+            if (oc != run_op || run_len == 64)
+            {
+                if (run_op != 3)
+                {
+                    put_byte((run_op << 6) | (run_len - 1));
+                    ++ncodes;
+                }
+                run_op  = oc;
+                run_len = 0;
+            }
+            ++run_len;
+        }
+        else
+            put_byte(op);
         ++n;
     };
 
@@ -667,7 +691,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         slot               = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
         q                  = p.q_res + x.q_off;
         s                  = p.s_res + x.s_off;
-        uint8_t * const ops = p.out_ops + p.ops_off[po];
+        uint8_t * const ops = p.out_ops + (p.ops_off ? p.ops_off[po] : po * p.ops_stride);
         cap                = x.q_len + x.s_len;
         lq                 = (int)x.q_len;
         ls                 = (int)x.s_len;
@@ -758,19 +782,47 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         ops_al = ops - a0;
         apos   = a0 + cap - 1;
         acc    = 0;
+        run_op  = 3;
+        run_len = 0;
+        ncodes  = 0;
         have    = true;
         done    = false;
         blocked = false;
     };
 
     // ---- the record of a finished extension
-    auto finish_extension = [&]()
+    // ---- the last code / the bytes collected in the lowest, partial dword leave
+    auto close_ops = [&]()
     {
         if (mode != 0)
             go += 1; // ran into the border right after a gap character: it can only have been an opening
+        if (rle_mode && run_op != 3)
+        {
+            put_byte((run_op << 6) | (run_len - 1));
+            ++ncodes;
+        }
         if ((apos & 3) != 3)
             for (uint32_t b = (apos & 3) + 1; b < 4 && (apos & ~3u) + b <= a0 + cap - 1; ++b)
                 ops_al[(apos & ~3u) + b] = (uint8_t)(acc >> (8 * b));
+    };
+    // ---- the record of a finished extension; run-length mode: its codes move from the slot to `at` in the dense stream
+    auto finish_extension = [&](uint64_t at)
+    {
+        if (rle_mode && ec.score >= 0)
+        {
+            if (at + ncodes > p.rle_cap)
+            {
+                atomicExch(p.err, 5);
+                ec.score = -1;
+            }
+            else
+            {
+                uint8_t const * const src = ops_al + apos + 1;
+                uint8_t * const       dst = p.rle + at;
+                for (uint32_t k = 0; k < ncodes; ++k)
+                    dst[k] = src[k];
+            }
+        }
         Hsp out{};
         if (ec.score < 0)
             out.score = -1;
@@ -787,7 +839,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             out.num_positives      = np;
             out.num_gap_opens      = go;
             out.num_gap_extensions = gx;
-            out.ops_shift          = (int32_t)(cap - n);
+            out.ops_shift          = rle_mode ? (int32_t)(uint32_t)at : (int32_t)(cap - n);
         }
         p.out_hsp[po] = out;
         have          = false;
@@ -810,7 +862,29 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         {
             // ================= retire and refill
             if (fin)
-                finish_extension();
+                close_ops();
+            uint64_t at = 0;
+            if (rle_mode)
+            {
+                // room in the dense code stream for every lane that finishes now: one atomic per wavefront
+                uint32_t const mine = fin ? ncodes : 0u;
+                uint32_t       incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1)
+                {
+                    uint32_t const up = (uint32_t)__shfl_up((int)incl, off);
+                    if ((int)lane >= off)
+                        incl += up;
+                }
+                uint32_t const     total = (uint32_t)__shfl((int)incl, 63);
+                unsigned long long base  = 0;
+                if (lane == 63 && total != 0)
+                    base = atomicAdd(p.rle_top, (unsigned long long)total);
+                base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 63);
+                at   = base + incl - mine;
+            }
+            if (fin)
+                finish_extension(at);
             if (!queue_empty)
             {
                 uint64_t const want = __ballot(!have);
@@ -918,7 +992,29 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                     nm += tm;
                     nx += cnt - tm;
                     np += tp;
-                    // cnt bytes 'M' below apos, whole dwords at a time
+                    // cnt columns 'M': run-length mode extends the current run (codes of at most 64 columns)
+                    if (rle_mode)
+                    {
+                        int left_m = cnt;
+                        while (left_m > 0)
+                        {
+                            if (run_op != 0 || run_len == 64)
+                            {
+                                if (run_op != 3)
+                                {
+                                    put_byte((run_op << 6) | (run_len - 1));
+                                    ++ncodes;
+                                }
+                                run_op  = 0;
+                                run_len = 0;
+                            }
+                            int const take = min(left_m, 64 - (int)run_len);
+                            run_len += (uint32_t)take;
+                            left_m -= take;
+                        }
+                        n += (uint32_t)cnt;
+                    }
+                    else // cnt bytes 'M' below apos, whole dwords at a time
                     {
                         uint32_t const hi = apos, lo = apos + 1 - (uint32_t)cnt; // byte positions [lo, hi] (cnt >= 1 here or skipped)
                         if (cnt > 0)

@@ -132,7 +132,9 @@ struct TraceParams
     EndCell *          ends;        // [n]
     Hsp *              out_hsp;     // indexed by src[e] when src != nullptr, else by e
     uint8_t *          out_ops;
-    uint64_t const *   ops_off;     // byte offset of each extension's ops slot (slot size q_len + s_len), same indexing
+    uint64_t const *   ops_off;     // byte offset of each extension's ops slot (slot size q_len + s_len), same indexing;
+                                    // nullptr: slots of ops_stride bytes, slot = index * ops_stride
+    uint64_t           ops_stride;
     int32_t const *    score_in;    // optional: best score of each slot (pass 1) -> cheaper end-cell search
     uint32_t const *   src;         // optional: original index of each slot, 0xffffffff = padding slot (skipped)
     uint64_t const *   count_ptr;   // optional: device-side number of valid slots of the whole list
@@ -159,6 +161,11 @@ struct TraceParams
     uint32_t *         ovf_count;     // device counter of handed-out overflow slots
     int32_t            band;          // band mode, as in ScoreParams (direction-bit kernels only)
     int32_t const *    band_diag;
+    // checkpoint backtrace, lx_extend_batch: the ops leave as run-length codes (lx_pack.hip's format) in a dense stream --
+    // rle != nullptr selects it; the slots of out_ops then only stage the codes, Hsp::ops_shift is the offset in the stream
+    uint8_t *            rle;
+    unsigned long long * rle_top;
+    uint64_t             rle_cap;
     int32_t            bt_tile_at, bt_refill_at; // checkpoint backtrace scheduling thresholds (0 = the compiled defaults)
     uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
 };
@@ -181,6 +188,22 @@ struct SelectParams
     uint32_t *        out_src;   // [capacity]
     uint64_t *        out_count; // [0] = total slots, [1] = true survivors
     Hsp *             out_hsp;   // optional [n]: rows of non-survivors are filled here (score, no alignment)
+};
+
+// run-length packing of the survivors' op bytes (lx_pack.hip); records and ops slots are addressed by list position
+struct PackParams
+{
+    Hsp *                hsp;       // [n] records by position; ops_shift is rewritten to the offset in the code stream
+    uint8_t const *      ops;       // op bytes as the backtrace left them
+    uint64_t const *     ops_off;   // slot of position e, or nullptr: e * ops_stride
+    uint64_t             ops_stride;
+    uint32_t const *     src;       // optional: 0xffffffff marks a padding slot of the list
+    uint64_t const *     count_ptr; // optional device-side list length
+    uint64_t             n;         // capacity of the list
+    uint8_t *            rle;       // dense code stream
+    unsigned long long * rle_top;   // bytes handed out (zeroed by the host before the launch)
+    uint64_t             rle_cap;
+    int32_t *            err;
 };
 
 struct MaxLens

@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void backtrace_kernel(TraceParams p)
         return;
     }
     uint32_t const * tr  = p.trace + e * p.slot_stride;
-    uint8_t *        ops = p.out_ops + p.ops_off[po];
+    uint8_t *        ops = p.out_ops + (p.ops_off ? p.ops_off[po] : po * p.ops_stride);
     uint32_t const   cap = x.q_len + x.s_len;
 
     // The walk is serial per extension and every lane of the wavefront is at a different point of its own walk, so

@@ -697,8 +697,8 @@ def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, handle.last_trace_kernel_name())
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops, i
-        total += int(ext["q_len"][i]) + int(ext["s_len"][i])
-    assert len(ops) == max(total, 1)  # compact: exactly the survivors' slots
+        total += oh.n_ops
+    assert len(ops) == max(total, 1)  # compact: exactly the survivors' alignment columns
     surv2 = np.nonzero((want_score >= int(np.percentile(want_score, 50))) & (ext["s_len"] > 0))[0]
     assert (np.nonzero(hsp2["n_ops"])[0] == surv2[want_score[surv2] > 0]).all()
 
@@ -861,7 +861,7 @@ def test_full_size_host_entry_point_equals_device_path(handle):
         for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops", "num_matches", "num_mismatches", "num_positives",
                   "num_gap_opens", "num_gap_extensions"):
             assert (hsp[f] == dev_hsp[f]).all(), f
-        assert len(ops) == int(sizes[surv].sum())
+        assert len(ops) == int(hsp["n_ops"][surv].sum())  # compact: exactly the survivors' alignment columns
         rng = np.random.default_rng(5)
         for i in rng.choice(surv, 20_000, replace=False):
             a = int(hoff[i]) + int(hsp[i]["ops_shift"])
@@ -870,6 +870,38 @@ def test_full_size_host_entry_point_equals_device_path(handle):
             assert bytes(ops[a: a + k]) == bytes(dev_ops[b: b + k]), i
     finally:
         handle.set_subjects(None)
+
+
+def test_extend_batch_rle_codes_expand_to_the_column_bytes(handle, oracle):
+    """lx_extend_batch_rle: the ops in the form they cross PCIe in -- one byte per run, (op << 6) | (length - 1), runs beyond
+    64 columns split -- must expand (lx_expand_ops) to exactly the column bytes lx_extend_batch returns, for several chunks
+    of the pipeline (LX_EXTEND_CHUNK is not set: the batch is made larger than one chunk instead)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_batch_np(30_000, 150, 16, seed=91, sub_rate=0.2, indel_rate=0.03)  # 480 k extensions: two chunks
+    cut = 80
+    score, hsp, off, ops = handle.extend_batch(q, s, ext, cut, copy_ops=True)
+    score2, hsp2, off2, codes = handle.extend_batch_rle(q, s, ext, cut)
+    assert (score == score2).all()
+    for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops", "num_matches", "num_gap_opens"):
+        assert (hsp[f] == hsp2[f]).all(), f
+    surv = np.nonzero(hsp["n_ops"])[0]
+    assert len(surv) > 100_000 and len(codes) < len(ops) // 8
+    rng = np.random.default_rng(1)
+    long_runs = 0
+    for i in rng.choice(surv, 3000, replace=False):
+        k = int(hsp["n_ops"][i])
+        a = int(off[i]) + int(hsp["ops_shift"][i])
+        c = codes[int(off2[i]): int(off2[i]) + k]  # (never more codes than columns)
+        assert capi.Handle.expand_ops(c, k) == bytes(ops[a: a + k]), i
+        long_runs += int((c[:4] & 63).max() == 63)
+    assert long_runs > 100  # runs of more than 64 columns occur and are split
+    # the oracle on a few of them
+    osc = oracle_lib.scoring_from(sc_p)
+    some = rng.choice(surv, 200, replace=False)
+    for i, (oh, oops) in zip(some, oracle.align_batch(q, s, ext[some], osc)):
+        a = int(off[i])
+        assert bytes(ops[a: a + oh.n_ops]) == oops and hsp["n_ops"][i] == oh.n_ops
 
 
 def test_extend_batch_with_a_window_beyond_65535_residues(handle, oracle):
