@@ -70,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--trace-bytes", type=int, default=160 << 30, help="LX_OPT_TRACE_BYTES: HBM the checkpoint slots may take")
     ap.add_argument("--band", type=int, default=0, help="band mode (LX_OPT_BAND, not the reference's configuration): half width in "
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
+    ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
+                    "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
     return ap.parse_args(argv)
 
@@ -210,6 +212,94 @@ def dry_run(args, w, world, rank):
             "ranks": plans}), flush=True)
 
 
+def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
+    """The step through the host-buffer entry point: every call takes the extension list from host memory, returns scores,
+    records and ops to host memory; the database (here: the synthetic windows) stays on the device between calls, as
+    lx_set_subjects is meant to be used.  Wall-clock around K calls."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+
+    from lambda_amd import capi, synth, workloads
+
+    h = capi.Handle(local_rank)
+    for d in w.directions:
+        m, ma, mi, go, ge = d.scoring
+        h.set_scoring(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
+    h.set_option(capi.LX_OPT_BS_MATCH_RULE, 1 if len(w.directions) > 1 else 0)
+    h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+    ka = capi.karlin_params(*w.karlin)
+    lib = capi.load()
+    adj = lib.lx_length_adjustment(w.db_length, w.lq, C.byref(ka))
+    min_score = 1
+    while lib.lx_evalue(min_score, w.lq - adj, w.db_length - adj, C.byref(ka)) > w.max_evalue:
+        min_score += 1
+    # host copies of the synthetic batches; all windows of the rank form its resident "database"
+    parts, s_all, s_at = [], [], 0
+    for b in pl.batches:
+        d_q, d_s, _, ext = synth.make_batch_torch(b.n_queries, w.lq, w.windows, b.seed, dev, alphabet=workloads.alphabet_array(w),
+                                                  sub_rate=w.sub_rate, indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank,
+                                                  convert=b.direction.convert, convert_rate=w.convert_rate)
+        ext = ext.copy()
+        ext["s_off"] += s_at
+        s_np = d_s.cpu().numpy()
+        s_at += len(s_np)
+        s_all.append(s_np)
+        parts.append((b.direction.slot, d_q.cpu().numpy(), ext))
+        del d_q, d_s
+    h.set_subjects(np.concatenate(s_all))
+    cells_rank = sum(float((e["q_len"].astype(np.float64) * e["s_len"]).sum()) for _, _, e in parts)
+    keep = [None] * len(parts)
+
+    def step():
+        surv = 0
+        for i, (slot, q, ext) in enumerate(parts):
+            r = h.extend_batch(q, None, ext, min_score, slot=slot, copy_ops=False, out=keep[i])
+            keep[i] = r[:3]  # the caller keeps its result arrays between calls, like lambda's per-thread holders
+            surv += int((r[1]["n_ops"] > 0).sum()) if args.steps <= 1 else 0
+        return surv
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dt = time.perf_counter() - t0
+    survivors = sum(int((k[1]["n_ops"] > 0).sum()) for k in keep)
+    tot = torch.tensor([dt, cells_rank, float(sum(len(e) for _, _, e in parts)), float(survivors)], dtype=torch.float64, device=dev)
+    if use_dist:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt = float(mx[0].item())
+    if rank == 0:
+        total_cells, total_ext, total_surv = float(tot[1].item()), float(tot[2].item()), float(tot[3].item())
+        up = total_ext / world * 28 + sum(len(q) for _, q, _ in parts)
+        print(json.dumps({
+            "metric": "GCUPS (gapped extension through the HOST-buffer entry point lx_extend_batch: PCIe and host work included; "
+                      "full-rectangle parity mode, pass-1 cells per second of whole step) " + ("searchp BLOSUM62" if w.program == "blastp" else w.name),
+            "value": round(total_cells * args.steps / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": pl.scaling,
+            "vs_baseline": None, "dtype": "f16x2 (exact small integers) + int32", "data": "synthetic",
+            "config": {"workload": workloads.describe(w), "baseline_config": args.config, "host_path": True,
+                       "entry_point": "lx_extend_batch(host buffers; subjects resident via lx_set_subjects; result arrays kept by the caller)",
+                       "extensions_job": int(total_ext), "gcells_job": round(total_cells / 1e9, 3), "survivors_job": int(total_surv),
+                       "bytes_up_per_step_rank0": int(up),
+                       "bytes_down_per_step_rank0_approx": int(total_ext / world * 4 + total_surv / world * 60),
+                       "step": f"lx_extend_batch per device call: host grouping + padding -> chunk pipeline (upload, single sweep, selection, "
+                               f"backtrace, run-length ops) -> scores, records and ops back in the caller's arrays; cut-off score>={min_score}"},
+            "alignments_per_s": round(total_ext * args.steps / dt, 1), "traced_per_s": round(total_surv * args.steps / dt, 1),
+            "roofline": None, "cpu_baseline": None,
+            "note": "secondary line: the kernels are those of the headline line (see its roofline); this one prices the boundary a binding crosses",
+        }), flush=True)
+    h.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
 class DevBatch:
     """One device call's inputs and outputs, resident in HBM."""
 
@@ -273,6 +363,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
+    if args.host_path:
+        return host_path(args, w, pl, world, rank, local_rank, dev, use_dist)
 
     # ---- scoring schemes and the e-value filter of iterateMatchesFullSimd as an integer score cut-off
     h = capi.Handle(local_rank)
