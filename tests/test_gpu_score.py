@@ -191,6 +191,33 @@ def test_packed_half_kernel_is_exact(handle, oracle, lq, wpq):
     assert "score_pair_kernel" not in name32 and (got32 == want).all()
 
 
+@pytest.mark.parametrize("method,gaps", [(45, (-15, -2)), (80, (-10, -1)), (45, (-19, -1)), (80, (-9, -2))])
+def test_packed_half_kernel_is_exact_with_blosum45_and_blosum80(handle, oracle, method, gaps):
+    """The other two matrices prepareScoring() offers (src/search_algo.hpp:198-219) through the same kernels, with gap costs
+    NCBI has Karlin-Altschul values for: packed-half and int32 scores equal the oracle's, the fused step's alignments too
+    (BLOSUM45 has entries up to 15: the exactness gate sees larger bounds than with BLOSUM62)."""
+    sc_p = capi.builtin_scoring(method, gap_open=gaps[0], gap_extend=gaps[1])
+    assert capi.karlin_params(method, gap_open=gaps[0], gap_extend=gaps[1]).lambda_ > 0
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    lq, wpq = 150, 32
+    q, s, ext = synth.make_batch_np(64, lq, wpq, seed=4500 + method, sub_rate=0.3, indel_rate=0.03)
+    want = oracle.score_batch(q, s, ext, osc, threads=8)
+    got, name = _dev_scores(handle, q, s, ext, lq, wpq, 1)
+    assert "score_pair_kernel" in name and (got == want).all()
+    got32, _ = _dev_scores(handle, q, s, ext, lq, wpq, 0)
+    assert (got32 == want).all()
+    cut = int(np.percentile(want, 60))
+    score, hsp, off, ops = handle.extend_batch(q, s, ext, cut)
+    assert (score == want).all()
+    surv = np.nonzero(want >= cut)[0][:300]
+    for i, (oh, oops) in zip(surv, oracle.align_batch(q, s, ext[surv], osc)):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+        assert bytes(ops[int(off[i]): int(off[i]) + oh.n_ops]) == oops
+
+
 def test_packed_half_declines_when_bound_too_large(handle, oracle):
     """Tryptophan-rich queries (W/W = 11): the per-wavefront bound exceeds what half precision holds exactly, the
     packed kernel must leave them to the int32 fix-up launch; mixed with ordinary queries in one batch."""
