@@ -72,6 +72,9 @@ def parse(argv=None):
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
                     "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
+    ap.add_argument("--ragged", action="store_true", help="--host-path on a ragged seed list as lambda really produces them (query lengths "
+                    "50-400, windows per query geometric with mean 12, 10 %% merged windows of up to 3 Lq): GCUPS and the padded share")
+    ap.add_argument("--ragged-queries", type=int, default=50_000)
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
     return ap.parse_args(argv)
 
@@ -237,7 +240,12 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
         min_score += 1
     # host copies of the synthetic batches; all windows of the rank form its resident "database"
     parts, s_all, s_at = [], [], 0
-    for b in pl.batches:
+    if args.ragged:
+        q_np, s_np, ext = synth.make_ragged_lists_np(args.ragged_queries, seed=0x1A3BDA07 + rank, alphabet=workloads.alphabet_array(w),
+                                                      sub_rate=w.sub_rate, indel_rate=w.indel_rate)
+        s_all.append(s_np)
+        parts.append((0, q_np, ext))
+    for b in ([] if args.ragged else pl.batches):
         d_q, d_s, _, ext = synth.make_batch_torch(b.n_queries, w.lq, w.windows, b.seed, dev, alphabet=workloads.alphabet_array(w),
                                                   sub_rate=w.sub_rate, indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank,
                                                   convert=b.direction.convert, convert_rate=w.convert_rate)
@@ -284,7 +292,12 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
             "value": round(total_cells * args.steps / dt / 1e9, 2), "unit": "GCUPS", "n_gpus": world, "steps": args.steps,
             "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": pl.scaling,
             "vs_baseline": None, "dtype": "f16x2 (exact small integers) + int32", "data": "synthetic",
-            "config": {"workload": workloads.describe(w), "baseline_config": args.config, "host_path": True,
+            "config": {"workload": workloads.describe(w) if not args.ragged else
+                       f"RAGGED seed list, {w.program} scheme of configs[{w.key}]: {args.ragged_queries} queries of 50-400 residues, windows per query "
+                       f"geometric (mean 12), 10 % merged windows of up to 3 Lq, half homologous; cells = sum Lq*Ls",
+                       "baseline_config": args.config, "host_path": True, "ragged": bool(args.ragged),
+                       "padding": (lambda st: {"extensions": st[0], "slots": st[1], "cells": st[2], "executed_cells": st[3],
+                                               "padded_share_of_executed_cells": round(1 - st[2] / max(st[3], 1), 4)})(h.last_extend_stats()),
                        "entry_point": "lx_extend_batch(host buffers; subjects resident via lx_set_subjects; result arrays kept by the caller)",
                        "extensions_job": int(total_ext), "gcells_job": round(total_cells / 1e9, 3), "survivors_job": int(total_surv),
                        "bytes_up_per_step_rank0": int(up),
@@ -363,7 +376,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
-    if args.host_path:
+    if args.host_path or args.ragged:
         return host_path(args, w, pl, world, rank, local_rank, dev, use_dist)
 
     # ---- scoring schemes and the e-value filter of iterateMatchesFullSimd as an integer score cut-off

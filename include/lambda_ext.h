@@ -233,6 +233,9 @@ int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t
                         lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                         lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
 int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out /* n_ops bytes */);
+/* Padding of the last lx_extend_batch[_rle] call: out4 = {extensions with residues, slots after padding every query's run
+ * to 8 / 16, cells (sum q_len * s_len), cells the wavefronts execute (whole panels x the longest window of each block)}. */
+int lx_last_extend_stats(lx_handle const * h, uint64_t * out4);
 
 /* ---- pre-extension filter (seedLooksPromising, src/search_algo.hpp:426-481) ------------------ */
 /* One diagonal per item; out_keep[i] = 1 if the ungapped max-segment score reaches the threshold. */

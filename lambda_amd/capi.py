@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -160,6 +160,7 @@ def load():
     lib.lx_extend_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
     lib.lx_extend_batch_rle.argtypes = lib.lx_extend_batch.argtypes
     lib.lx_expand_ops.argtypes = [vp, i32, vp]
+    lib.lx_last_extend_stats.argtypes = [vp, vp]
     lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.lx_set_frames.restype = None
     lib.lx_untrue_qry_id.argtypes = [i32, u64, i32]
@@ -409,6 +410,12 @@ class Handle:
             return score, hsp, off, np.zeros(1, np.uint8)
         ops = np.ctypeslib.as_array((C.c_uint8 * int(nb.value)).from_address(p.value))
         return score, hsp, off, ops.copy() if copy_ops else ops
+
+    def last_extend_stats(self):
+        """(extensions, slots, cells, executed cells) of the last extend_batch call."""
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self.lib.lx_last_extend_stats(self.h, _ptr(out)))
+        return tuple(int(x) for x in out)
 
     def set_subjects(self, s_res):
         """lx_set_subjects: keep the subject residues on the device; later host-buffer calls may pass s_res=None."""

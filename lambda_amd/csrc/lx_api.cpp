@@ -86,6 +86,7 @@ struct lx_handle
     // lx_extend_batch: host staging that keeps its pages between calls
     std::vector<uint32_t>     xb_idx, xb_src, xb_sel, xb_pos;
     std::vector<uint8_t>      xb_newrun;
+    uint64_t                  xb_stats[4] = {0, 0, 0, 0}; // lx_extend_batch: extensions, slots, cells, cells executed (padding included)
     std::vector<uint64_t>     xb_grp, xb_off;
     std::vector<lx_extension> xb_ext;
     std::vector<int32_t>      xb_min, xb_score;
@@ -2314,6 +2315,75 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                     });
     newrun[live] = 1;
+    // Mixed query lengths (a real seed list; the synthetic batches have one): a chunk runs the kernel geometry of its longest
+    // query, so runs are dealt to geometry classes first -- one panel of 152 columns, one of 208, two / three / ... panels of
+    // 152 -- and every class goes through the pipeline by itself.  Inside a run the windows are ordered by length (merged
+    // windows are up to 3 x longer: src/search_algo.hpp:1153-1157), so that a wavefront's 16 windows take about as many steps
+    // each -- the reason the reference sorts its SIMD batches (:1229-1235).  Results are scattered by original index anyway.
+    {
+        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 152 ? 0u : lq <= 208 ? 1u : 1u + (lq + 151) / 152; };
+        uint32_t cmin = ~0u, cmax = 0;
+        bool     ragged_s = false;
+        for (uint64_t k = 0; k < live; ++k)
+        {
+            if (newrun[k])
+            {
+                uint32_t const c = qclass(ext[idx[k]].q_len);
+                cmin = std::min(cmin, c);
+                cmax = std::max(cmax, c);
+            }
+            else if (ext[idx[k]].s_len != ext[idx[k - 1]].s_len)
+                ragged_s = true;
+        }
+        static bool const no_classes = getenv("LX_EXTEND_NO_CLASSES") != nullptr, no_sort = getenv("LX_EXTEND_NO_SORT") != nullptr; // A/B aids
+        if (cmin != cmax && !no_classes)
+        {
+            std::vector<uint64_t> at(cmax + 2, 0);
+            for (uint64_t k = 0; k < live;)
+            {
+                uint64_t kk = k + 1;
+                while (!newrun[kk])
+                    ++kk;
+                at[qclass(ext[idx[k]].q_len) + 1] += kk - k;
+                k = kk;
+            }
+            for (uint32_t c = 0; c <= cmax; ++c)
+                at[c + 1] += at[c];
+            std::vector<uint32_t> & idx2 = h->xb_src;
+            idx2.resize(live);
+            for (uint64_t k = 0; k < live;)
+            {
+                uint64_t kk = k + 1;
+                while (!newrun[kk])
+                    ++kk;
+                uint64_t & o = at[qclass(ext[idx[k]].q_len)];
+                std::copy(idx.begin() + k, idx.begin() + kk, idx2.begin() + o);
+                o += kk - k;
+                k = kk;
+            }
+            idx.swap(idx2);
+            parallel_ranges(live, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t k = lo; k < hi; ++k)
+                                    newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
+                            });
+        }
+        if (ragged_s && !no_sort)
+        {
+            std::vector<uint64_t> starts;
+            for (uint64_t k = 0; k <= live; ++k)
+                if (newrun[k])
+                    starts.push_back(k);
+            parallel_ranges(starts.size() - 1, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t r = lo; r < hi; ++r)
+                                    std::sort(idx.begin() + starts[r], idx.begin() + starts[r + 1],
+                                              [&](uint32_t a, uint32_t b) { return ext[a].s_len != ext[b].s_len ? ext[a].s_len < ext[b].s_len : a < b; });
+                            });
+        }
+    }
     hm.mark("validate");
 
     // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
@@ -2347,6 +2417,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     h->ext_bytes.clear();
     uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
     double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0; // LX_HOST_TIMING: where the host's time goes
+    h->xb_stats[0] = live;
+    h->xb_stats[1] = h->xb_stats[2] = h->xb_stats[3] = 0; // slots, cells, cells the wavefronts execute
     auto     now    = []() { return std::chrono::steady_clock::now(); };
     auto     ms     = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b)
     { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -2398,7 +2470,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
         int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
         uint32_t * const     slot_src = pr.slot_src.data();
-        std::vector<uint64_t> tmax(nthreads, 1);
+        std::vector<uint64_t> tmax(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
+        // (what the wavefronts will execute: every block of kRun slots runs all columns of its panels for as many steps as
+        // its longest window has rows)
+        uint64_t const panel = max_q <= 152 ? 152 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
         parallel_ranges(ngroups, nthreads,
                         [&](unsigned t, uint64_t glo, uint64_t ghi)
                         {
@@ -2407,6 +2482,17 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             {
                                 uint64_t const a = grp[2 * g], b = grp[2 * g + 2], o1 = grp[2 * g + 3];
                                 uint64_t       o = grp[2 * g + 1];
+                                uint64_t const cols = (ext[idx[a]].q_len + panel - 1) / panel * panel;
+                                for (uint64_t j0 = a; j0 < b; j0 += kRun)
+                                {
+                                    uint64_t bmax = 0;
+                                    for (uint64_t j = j0; j < std::min(b, j0 + kRun); ++j)
+                                    {
+                                        bmax = std::max<uint64_t>(bmax, ext[idx[j]].s_len);
+                                        tcells[t] += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
+                                    }
+                                    tpad[t] += kRun * cols * (bmax + lanes - 1);
+                                }
                                 for (uint64_t j = a; j < b; ++j, ++o)
                                 {
                                     slot_ext[o] = ext[idx[j]];
@@ -2427,6 +2513,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                         });
         for (uint64_t v : tmax)
             max_s = std::max(max_s, v);
+        h->xb_stats[1] += slots;
+        for (unsigned t = 0; t < nthreads; ++t)
+        {
+            h->xb_stats[2] += tcells[t];
+            h->xb_stats[3] += tpad[t];
+        }
         auto const t1 = now();
         t_prep += ms(t0, t1);
         // device side of the lane
@@ -2595,6 +2687,23 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint64_t k1 = std::min<uint64_t>(live, k0 + chunk_target);
         while (k1 < live && !newrun[k1]) // never cut a query's run
             ++k1;
+        {
+            // ... and never mix geometry classes (the list is class-major): cut where the class changes
+            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 152 ? 0u : lq <= 208 ? 1u : 1u + (lq + 151) / 152; };
+            uint32_t const c0 = qclass(ext[idx[k0]].q_len);
+            if (!getenv("LX_EXTEND_NO_CLASSES") && qclass(ext[idx[k1 - 1]].q_len) != c0)
+            {
+                uint64_t lo = k0, hi = k1 - 1; // first position of another class: the classes ascend
+                while (hi - lo > 1)
+                {
+                    uint64_t const mid = lo + (hi - lo) / 2;
+                    (qclass(ext[idx[mid]].q_len) == c0 ? lo : hi) = mid;
+                }
+                k1 = hi;
+                while (k1 > k0 + 1 && !newrun[k1])
+                    --k1;
+            }
+        }
         int const L = c & 1;
         if (in_flight[L] && (rc = collect(L)))
             return rc;
@@ -2666,6 +2775,14 @@ int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t
         return fail(h, LX_EINVAL, "lx_extend_batch_rle: band mode returns column bytes only (lx_extend_batch)");
     return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
                            out_ops_bytes, true);
+}
+
+int lx_last_extend_stats(lx_handle const * h, uint64_t * out4)
+{
+    if (!h || !out4)
+        return LX_EINVAL;
+    std::memcpy(out4, h->xb_stats, sizeof(h->xb_stats));
+    return LX_OK;
 }
 
 int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out)

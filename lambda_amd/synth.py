@@ -169,3 +169,48 @@ def make_batch_torch(n_queries: int, lq: int, windows_per_query: int, seed: int,
     ext["s_len"] = ls
     d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(device)
     return q_res.reshape(-1), s_res.reshape(-1), d_ext, ext
+
+
+def make_ragged_lists_np(n_queries: int, seed: int, alphabet: np.ndarray = STD20, lq_range=(50, 400), mean_windows: float = 12.0,
+                         merged_frac: float = 0.10, homolog_frac: float = 0.5, sub_rate: float = 0.25, indel_rate: float = 0.02):
+    """A seed list as lambda really hands it over (after _widenAndPreprocessMatches, src/search_algo.hpp:1136-1175): queries
+    of mixed lengths, a geometric number of windows per query (mean `mean_windows`), most windows Lq + 2b long, a tenth of
+    them merged ones of up to 3 Lq; grouped by query.  Returns (q_res, s_res, ext)."""
+    rng = np.random.default_rng(seed)
+    na = len(alphabet)
+    lqs = rng.integers(lq_range[0], lq_range[1] + 1, n_queries)
+    nwin = rng.geometric(1.0 / mean_windows, n_queries)
+    q_off = np.concatenate([[0], np.cumsum(lqs)[:-1]])
+    q_idx = rng.integers(0, na, int(lqs.sum()), dtype=np.uint8)
+    n_ext = int(nwin.sum())
+    ext = np.zeros(n_ext, dtype=EXT_DTYPE)
+    qid = np.repeat(np.arange(n_queries), nwin)
+    lq_e = lqs[qid]
+    b_e = (np.sqrt(lq_e).astype(np.int64) + 1)
+    ls_e = lq_e + 2 * b_e
+    merged = rng.random(n_ext) < merged_frac
+    ls_e = np.where(merged, rng.integers(ls_e, 3 * lq_e + 1), ls_e)
+    s_off = np.concatenate([[0], np.cumsum(ls_e)[:-1]])
+    s_idx = rng.integers(0, na, int(ls_e.sum()), dtype=np.uint8)
+    homolog = np.nonzero(rng.random(n_ext) < homolog_frac)[0]
+    if len(homolog):
+        # vectorised: the (substituted) query copied into the window at offset a -- b for a plain window, anywhere for a merged
+        # one -- with up to two residues of the query skipped (a gap in the alignment each)
+        lq_h, ls_h, b_h = lq_e[homolog], ls_e[homolog], b_e[homolog]
+        a_h = np.where(merged[homolog], (rng.random(len(homolog)) * np.maximum(1, ls_h - lq_h - b_h + 1)).astype(np.int64), b_h)
+        ndel = rng.binomial(2, min(1.0, indel_rate * float(lqs.mean()) / 2.0), len(homolog))
+        p1 = (rng.random(len(homolog)) * lq_h).astype(np.int64)
+        p2 = (rng.random(len(homolog)) * lq_h).astype(np.int64)
+        len_h = np.minimum(lq_h - ndel, ls_h - a_h)
+        tot = int(len_h.sum())
+        first = np.concatenate([[0], np.cumsum(len_h)[:-1]])
+        k = np.arange(tot) - np.repeat(first, len_h)                    # position inside the copied piece
+        rep = lambda x: np.repeat(x, len_h)
+        skip = (rep(ndel) >= 1) * (k >= rep(p1)) + (rep(ndel) >= 2) * (k >= rep(p2))
+        src = rep(q_off[qid[homolog]]) + np.minimum(k + skip, rep(lq_h) - 1)
+        val = q_idx[src]
+        mut = rng.random(tot) < sub_rate
+        val[mut] = rng.integers(0, na, int(mut.sum()), dtype=np.uint8)
+        s_idx[rep(s_off[homolog] + a_h) + k] = val
+    ext["q_off"], ext["q_len"], ext["s_off"], ext["s_len"] = q_off[qid], lq_e, s_off, ls_e
+    return alphabet[q_idx].astype(np.uint8), alphabet[s_idx].astype(np.uint8), ext
