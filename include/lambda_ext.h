@@ -329,8 +329,9 @@ uint64_t lx_untrue_subj_id(int s_mode, uint64_t n_sid, int32_t s_frame);
  * src/shared_definitions.hpp:246-281): `dna5` holds n BioC++ dna5 ranks (A, C, G, N, T).  Writes the frames
  * +1, +2, +3, -1, -2, -3 back to back into `out` (SeqAn AminoAcid ranks; 2n bytes are always enough) and their
  * offsets/lengths into frame_off/frame_len.  A codon with N becomes the amino acid all its completions agree on,
- * else X.  genetic_code: 1 (the canonical code; the reference's default, src/search_options.hpp:170).
- * Returns LX_EINVAL for other codes, bad ranks or a too small `out`. */
+ * else X.  genetic_code: an NCBI translation table id as bio::alphabet::genetic_code numbers them (1 = canonical, the
+ * reference's default, src/search_options.hpp:170; 2-6, 9-16, 21-25).  Returns LX_EINVAL for other ids, bad ranks or a
+ * too small `out`. */
 int lx_translate_six_frames(uint8_t const * dna5, uint64_t n, int genetic_code, uint8_t * out, uint64_t out_capacity,
                             uint64_t * frame_off, uint64_t * frame_len);
 

@@ -1,0 +1,335 @@
+// lx_seeding.hpp -- the seeding stage of the minimal lambda3 front end, host-only C++.
+//
+// What the reference does per query batch (search(), /root/reference/src/search_algo.hpp:611-762): every seedOffset letters
+// a seed of seedLength letters of the REDUCED query (Li-10 for proteins, src/mkindex_options.hpp:182-185) is searched in an
+// FM-index over the reduced database -- exactly, or "half exact" (first half exact, the second half with up to maxSeedDist
+// substitutions, searchHalfExactImpl :537-604) -- the hit set of every cursor is thinned by ADAPTIVE ELONGATION (:679-727: the
+// seed grows to the right while that does not push the number of occurrences under what the query still needs to reach
+// maxMatches), over-abundant cursors are dropped (:729), and every located hit passes seedLooksPromising (:426-481) before it
+// becomes a Match.  Queries without any result after extension are searched again with the second parameter set
+// (iterativeSearch, :1391-1457; defaults src/search_options.hpp:309-337).
+//
+// What is different here: there is no FM-index (fmindex-collection is absent and out of scope).  The same questions -- how
+// often does this reduced word occur, where -- are answered by a sorted table of packed words: every database position
+// carries the key of its next kKeyLen reduced letters (base alphabet + 1, the extra digit pads sequence ends), a cursor is a
+// range of that table, extendRight narrows it by binary search.  Hit sets are identical to the FM-index's for words of up to
+// kKeyLen letters (18 for Li-10, 27 for nucleotides); elongation stops there.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "../../../include/lambda_ext.h"
+
+namespace lambda_amd
+{
+
+// bio::alphabet::aa10li over SeqAn AminoAcid ranks "ABCDEFGHIJKLMNOPQRSTUVWYZX*": Li et al. 2003, {AST} {BDEQZ} {CU} {FWY} {G}
+// {HN} {IV} {JLM} {KOR} {P}; X joins the first group, '*' the aromatic one as in BioC++'s table [UPSTREAM-RECALL]
+inline constexpr uint8_t kLi10[27] = {/*A*/ 0, /*B*/ 1, /*C*/ 2, /*D*/ 1, /*E*/ 1, /*F*/ 3, /*G*/ 4, /*H*/ 5, /*I*/ 6, /*J*/ 7,
+                                      /*K*/ 8, /*L*/ 7, /*M*/ 7, /*N*/ 5, /*O*/ 8, /*P*/ 9, /*Q*/ 1, /*R*/ 8, /*S*/ 0, /*T*/ 0,
+                                      /*U*/ 2, /*V*/ 6, /*W*/ 3, /*Y*/ 3, /*Z*/ 1, /*X*/ 0, /***/ 3};
+// bio::alphabet::aa10murphy (Murphy et al. 2000): {ILMVJ} {CU} {AX*} {G} {ST} {P} {FYW} {EDNQBZ} {KRO} {H}
+inline constexpr uint8_t kMurphy10[27] = {/*A*/ 2, /*B*/ 7, /*C*/ 1, /*D*/ 7, /*E*/ 7, /*F*/ 6, /*G*/ 3, /*H*/ 9, /*I*/ 0, /*J*/ 0,
+                                          /*K*/ 8, /*L*/ 0, /*M*/ 0, /*N*/ 7, /*O*/ 8, /*P*/ 5, /*Q*/ 7, /*R*/ 8, /*S*/ 4, /*T*/ 4,
+                                          /*U*/ 1, /*V*/ 0, /*W*/ 6, /*Y*/ 6, /*Z*/ 7, /*X*/ 2, /***/ 2};
+// BioC++ dna5 ranks (A, C, G, N, T) -> dna4 (A, C, G, T); N converts to A like every non-dna4 letter does
+inline constexpr uint8_t kDna4[5] = {0, 1, 2, 0, 3};
+
+struct SeedParams // SearchOptions' seeding part, src/search_options.hpp:309-337
+{
+    int seedLength = 10, seedOffset = 5, maxSeedDist = 0;
+};
+
+class ReducedIndex
+{
+public:
+    struct Cursor
+    {
+        uint64_t lo = 0, hi = 0; // range of the sorted table
+        int      len = 0;        // letters matched
+        uint64_t prefix = 0;     // the word so far, base (alph + 1)
+        uint64_t count() const { return hi - lo; }
+        bool     empty() const { return hi <= lo; }
+    };
+
+    // red = reduced residues of all (frame-expanded) subject sequences, off/len per sequence; alph = reduced alphabet size
+    void build(std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
+    {
+        alph_   = alph;
+        base_   = (uint64_t)alph + 1;
+        keyLen_ = 0;
+        for (uint64_t lim = ~0ull / 2, p = 1; p <= lim / base_; p *= base_)
+            ++keyLen_;
+        pow_.assign(keyLen_ + 1, 1);
+        for (int i = 1; i <= keyLen_; ++i)
+            pow_[i] = pow_[i - 1] * base_;
+        uint64_t total = 0;
+        for (uint64_t l : len)
+            total += l;
+        entries_.clear();
+        entries_.reserve(total);
+        for (size_t s = 0; s < off.size(); ++s)
+        {
+            // rolling key of the next keyLen_ letters, pad digit `alph` beyond the sequence end
+            uint64_t const L = len[s];
+            if (L == 0)
+                continue;
+            uint64_t key = 0;
+            for (int i = 0; i < keyLen_; ++i)
+                key = key * base_ + ((uint64_t)i < L ? red[off[s] + i] : (uint64_t)alph);
+            for (uint64_t p = 0; p < L; ++p)
+            {
+                entries_.push_back(Entry{key, (uint32_t)s, (uint32_t)p});
+                uint64_t const next = p + keyLen_ < L ? red[off[s] + p + keyLen_] : (uint64_t)alph;
+                key                 = (key % pow_[keyLen_ - 1]) * base_ + next;
+            }
+        }
+        std::sort(entries_.begin(), entries_.end(), [](Entry const & a, Entry const & b) { return a.key < b.key; });
+    }
+
+    int    keyLen() const { return keyLen_; }
+    Cursor root() const { return Cursor{0, entries_.size(), 0, 0}; }
+
+    // the cursor of word + c; empty when the word does not occur (or the table's word length is exhausted)
+    Cursor extendRight(Cursor const & cu, uint8_t c) const
+    {
+        Cursor n = cu;
+        if (cu.len >= keyLen_)
+        {
+            n.hi = n.lo;
+            return n;
+        }
+        n.prefix = cu.prefix * base_ + c;
+        n.len    = cu.len + 1;
+        uint64_t const scale = pow_[keyLen_ - n.len], first = n.prefix * scale, last = first + (scale - 1);
+        auto const     b = entries_.begin() + (std::ptrdiff_t)cu.lo, e = entries_.begin() + (std::ptrdiff_t)cu.hi;
+        n.lo = (uint64_t)(std::lower_bound(b, e, first, [](Entry const & x, uint64_t k) { return x.key < k; }) - entries_.begin());
+        n.hi = (uint64_t)(std::upper_bound(b, e, last, [](uint64_t k, Entry const & x) { return k < x.key; }) - entries_.begin());
+        return n;
+    }
+
+    template <typename F>
+    void locate(Cursor const & cu, F && f) const // f(subject sequence, offset)
+    {
+        for (uint64_t i = cu.lo; i < cu.hi; ++i)
+            f(entries_[i].seq, entries_[i].pos);
+    }
+
+private:
+    struct Entry
+    {
+        uint64_t key;
+        uint32_t seq, pos;
+    };
+    std::vector<Entry>    entries_;
+    std::vector<uint64_t> pow_;
+    uint64_t              base_ = 11;
+    int                   alph_ = 10, keyLen_ = 18;
+};
+
+// search_impl with maxSeedDist = 0 (:505-535): the exact word
+inline void searchExact(ReducedIndex const & ix, uint8_t const * seed, int seedLength, std::vector<ReducedIndex::Cursor> & out)
+{
+    ReducedIndex::Cursor c = ix.root();
+    for (int i = 0; i < seedLength; ++i)
+    {
+        c = ix.extendRight(c, seed[i]);
+        if (c.empty())
+            return;
+    }
+    out.push_back(c);
+}
+
+// searchHalfExactImpl (:537-604): first half exact, then letter by letter every cursor below the error budget branches into all
+// letters of the alphabet (a different letter costs one error), the others continue with the seed's letter
+inline void searchHalfExact(ReducedIndex const & ix, uint8_t const * seed, int seedLength, int maxSeedDist, int alph,
+                            std::vector<ReducedIndex::Cursor> & out)
+{
+    int const firstHalf = seedLength / 2, secondHalf = seedLength - firstHalf;
+    std::vector<std::pair<ReducedIndex::Cursor, int>> cur, nxt;
+    ReducedIndex::Cursor                              c = ix.root();
+    for (int i = 0; i < firstHalf; ++i)
+    {
+        c = ix.extendRight(c, seed[i]);
+        if (c.empty())
+            return;
+    }
+    cur.emplace_back(c, 0);
+    for (int i = 0; i < secondHalf; ++i)
+    {
+        uint8_t const want = seed[firstHalf + i];
+        nxt.clear();
+        for (auto const & [cursor, errors] : cur)
+        {
+            if (errors < maxSeedDist)
+            {
+                for (int r = 0; r < alph; ++r)
+                {
+                    ReducedIndex::Cursor n = ix.extendRight(cursor, (uint8_t)r);
+                    if (!n.empty())
+                        nxt.emplace_back(n, errors + ((uint8_t)r != want));
+                }
+            }
+            else
+            {
+                ReducedIndex::Cursor n = ix.extendRight(cursor, want);
+                if (!n.empty())
+                    nxt.emplace_back(n, errors);
+            }
+        }
+        cur.swap(nxt);
+    }
+    for (auto const & [cursor, errors] : cur)
+        out.push_back(cursor);
+}
+
+// seedLooksPromising (:426-481) on the host, with the reference's integer types and order of operations: the seeding loop asks
+// it per located hit (hitsThisSeq feeds the elongation of the NEXT seeds), so it cannot wait for a batched GPU pass here.
+// q / s = the whole (frame) sequences in alignment ranks; matrix[q_rank * 32 + s_rank].
+inline bool seedLooksPromising(uint8_t const * q, uint64_t qLen, uint8_t const * s, uint64_t sLen, lx_match const & m, int seedLength,
+                               int preScoring, double preScoringThresh, int8_t const * matrix)
+{
+    int64_t  effectiveQBegin = (int64_t)m.qryStart, effectiveSBegin = (int64_t)m.subjStart;
+    uint64_t actualLength    = m.qryEnd - m.qryStart;
+    uint64_t effectiveLength = std::max<uint64_t>((uint64_t)(seedLength * preScoring), actualLength);
+    if (effectiveLength > actualLength)
+    {
+        effectiveQBegin -= (int64_t)((effectiveLength - actualLength) / 2);
+        effectiveSBegin -= (int64_t)((effectiveLength - actualLength) / 2);
+        int64_t const mn = std::min(effectiveQBegin, effectiveSBegin);
+        if (mn < 0)
+        {
+            effectiveQBegin -= mn;
+            effectiveSBegin -= mn;
+            effectiveLength += (uint64_t)mn; // (unsigned wrap-around of a negative addend, as in the reference)
+        }
+        effectiveLength = std::min({(uint64_t)(qLen - (uint64_t)effectiveQBegin), (uint64_t)(sLen - (uint64_t)effectiveSBegin), effectiveLength});
+    }
+    int       sc = 0, maxScore = 0;
+    int const thresh = (int)(preScoringThresh * (double)effectiveLength);
+    for (uint64_t i = 0; i < effectiveLength; ++i)
+    {
+        sc += matrix[(q[(uint64_t)effectiveQBegin + i] & 31) * LX_ALPH + (s[(uint64_t)effectiveSBegin + i] & 31)];
+        if (sc < 0)
+            sc = 0;
+        else if (sc > maxScore)
+            maxScore = sc;
+        if (maxScore >= thresh)
+            return true;
+    }
+    return false;
+}
+
+struct SeedingStats
+{
+    uint64_t hitsAfterSeeding = 0, hitsFailedPreExtendTest = 0;
+};
+
+struct SeedingInput
+{
+    // queries: alignment ranks and reduced letters of every (frame-expanded) sequence, frames of one read adjacent
+    uint8_t const *  qRes;
+    uint8_t const *  qRed;
+    uint64_t const * qOff;
+    uint64_t const * qLen;
+    uint64_t         nQSeq;
+    int              qNumFrames;
+    uint8_t          unknownRank; // 'X' (proteins) / 'N' (nucleotides) in alignment ranks: seeds do not start there (:655-660)
+    uint8_t const *  sRes;        // subjects in alignment ranks
+    uint64_t const * sOff;
+    uint64_t const * sLen;
+    int              alph;        // reduced alphabet size
+    int8_t const *   matrix;
+    uint64_t         maxMatches;
+    bool             halfExact, adaptive;
+    int              preScoring;
+    double           preScoringThresh;
+};
+
+// search(lH), :611-762, for the (frame-expanded) query sequences listed in `which` (all frames of a read, in order)
+inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedParams const & so, std::vector<uint64_t> const & which,
+                        std::vector<lx_match> & matches, SeedingStats & stats)
+{
+    size_t           hitsThisSeq = 0, needlesSum = 0, needlesPos = 0;
+    constexpr size_t heuristicFactor = 10; // :629
+    std::vector<ReducedIndex::Cursor> cursors;
+    for (size_t w = 0; w < which.size(); ++w)
+    {
+        uint64_t const i = which[w];
+        if (in.qLen[i] < (uint64_t)so.seedLength) // :640-641 (before the reset and without the bookkeeping below, as there)
+            continue;
+        if (i % (uint64_t)in.qNumFrames == 0) // reset on every "real" new read (:643-650)
+        {
+            hitsThisSeq = needlesSum = needlesPos = 0;
+            for (int j = 0; j < in.qNumFrames && i + (uint64_t)j < in.nQSeq; ++j)
+                needlesSum += in.qLen[i + (uint64_t)j];
+        }
+        uint64_t const        L   = in.qLen[i];
+        uint8_t const * const red = in.qRed + in.qOff[i];
+        uint8_t const * const res = in.qRes + in.qOff[i];
+        {
+            for (uint64_t seedBegin = 0;; seedBegin += (uint64_t)so.seedOffset)
+            {
+                // skip the unknown letter, skip a letter whose successor is the same (:655-660)
+                while (seedBegin < L - (uint64_t)so.seedLength && (res[seedBegin] == in.unknownRank || res[seedBegin] == res[seedBegin + 1]))
+                    ++seedBegin;
+                if (seedBegin > L - (uint64_t)so.seedLength) // :663
+                    break;
+                cursors.clear();
+                if (in.halfExact && so.maxSeedDist != 0)
+                    searchHalfExact(ix, red + seedBegin, so.seedLength, so.maxSeedDist, in.alph, cursors);
+                else
+                    searchExact(ix, red + seedBegin, so.seedLength, cursors);
+                for (ReducedIndex::Cursor cursor : cursors)
+                {
+                    uint64_t seedLength = (uint64_t)so.seedLength;
+                    if (in.adaptive) // :683-727, the deterministic branch
+                    {
+                        size_t desiredOccs = hitsThisSeq >= in.maxMatches
+                                               ? 1
+                                               : (in.maxMatches - hitsThisSeq) * heuristicFactor /
+                                                   std::max<size_t>((needlesSum - needlesPos - seedBegin) / (size_t)so.seedOffset, 1ul);
+                        if (desiredOccs == 0)
+                            desiredOccs = 1;
+                        ReducedIndex::Cursor old_cursor = cursor;
+                        size_t               old_count  = cursor.count();
+                        while (seedBegin + seedLength < L && (int)seedLength < ix.keyLen())
+                        {
+                            cursor                 = ix.extendRight(cursor, red[seedBegin + seedLength]);
+                            size_t const new_count = cursor.count();
+                            if (new_count < desiredOccs && new_count < old_count) // we always extend if we don't lose anything
+                            {
+                                cursor = old_cursor;
+                                break;
+                            }
+                            ++seedLength;
+                            old_count  = new_count;
+                            old_cursor = cursor;
+                        }
+                    }
+                    if (cursor.count() > heuristicFactor * in.maxMatches) // over-abundant (:729)
+                        continue;
+                    ix.locate(cursor,
+                              [&](uint32_t subjNo, uint32_t subjOffset)
+                              {
+                                  lx_match const m{i, subjNo, seedBegin, seedBegin + seedLength, subjOffset, subjOffset + seedLength};
+                                  ++stats.hitsAfterSeeding;
+                                  if (!seedLooksPromising(res, L, in.sRes + in.sOff[subjNo], in.sLen[subjNo], m, so.seedLength, in.preScoring,
+                                                          in.preScoringThresh, in.matrix))
+                                      ++stats.hitsFailedPreExtendTest;
+                                  else
+                                  {
+                                      matches.push_back(m);
+                                      ++hitsThisSeq;
+                                  }
+                              });
+                }
+            }
+        }
+        needlesPos += L; // :759
+    }
+}
+
+} // namespace lambda_amd

@@ -5,7 +5,7 @@
 //   _untrueQryId / _untrueSubjId       src/search_algo.hpp:940-996
 //   qryTransView / sbjTransView        src/shared_definitions.hpp:246-281   (which expansion a program uses)
 // The translation itself is BioC++'s (bio::views::translate_join, library absent here): frames in the order
-// +1 +2 +3 -1 -2 -3, canonical genetic code.  [UPSTREAM-RECALL] a codon containing an ambiguous nucleotide is
+// +1 +2 +3 -1 -2 -3, any of NCBI's genetic codes (table below).  [UPSTREAM-RECALL] a codon containing an ambiguous nucleotide is
 // translated to the amino acid all of its completions share, otherwise to X.
 #include <cstdint>
 #include <cstdlib>
@@ -16,8 +16,36 @@
 namespace
 {
 
-// NCBI translation table 1, codon index = 16 b1 + 4 b2 + b3 with T = 0, C = 1, A = 2, G = 3
-constexpr char kCanonical[65] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG";
+// NCBI translation tables (gc.prt; the ids are bio::alphabet::genetic_code's, the enum the reference casts its
+// --genetic-code option to: /root/reference/src/search_options.hpp:170, :628, src/mkindex_options.hpp:240), codon index
+// = 16 b1 + 4 b2 + b3 with T = 0, C = 1, A = 2, G = 3.  Table 11 differs from 1 in its start codons only.
+struct GeneticCode
+{
+    int          id;
+    char const * aa;
+};
+constexpr GeneticCode kGeneticCodes[] = {
+    {1, "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},  // canonical
+    {2, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSS**VVVVAAAADDEEGGGG"},  // vertebrate mitochondrial
+    {3, "FFLLSSSSYY**CCWWTTTTPPPPHHQQRRRRIIMMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},  // yeast mitochondrial
+    {4, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},  // mold / protozoan / coelenterate mitochondrial, Mycoplasma
+    {5, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSSSVVVVAAAADDEEGGGG"},  // invertebrate mitochondrial
+    {6, "FFLLSSSSYYQQCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"},  // ciliate
+    {9, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG"},  // echinoderm / flatworm mitochondrial
+    {10, "FFLLSSSSYY**CCCWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // euplotid
+    {11, "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // bacterial, archaeal, plant plastid
+    {12, "FFLLSSSSYY**CC*WLLLSPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // alternative yeast
+    {13, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNKKSSGGVVVVAAAADDEEGGGG"}, // ascidian mitochondrial
+    {14, "FFLLSSSSYYY*CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNNKSSSSVVVVAAAADDEEGGGG"}, // alternative flatworm mitochondrial
+    {15, "FFLLSSSSYY*QCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // Blepharisma
+    {16, "FFLLSSSSYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // chlorophycean mitochondrial
+    {21, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIMMTTTTNNNKSSSSVVVVAAAADDEEGGGG"}, // trematode mitochondrial
+    {22, "FFLLSS*SYY*LCC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // Scenedesmus obliquus mitochondrial
+    {23, "FF*LSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // Thraustochytrium mitochondrial
+    {24, "FFLLSSSSYY**CCWWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSSKVVVVAAAADDEEGGGG"}, // Pterobranchia mitochondrial
+    {25, "FFLLSSSSYY**CCGWLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"}, // candidate division SR1, Gracilibacteria
+};
+constexpr int kNumGeneticCodes = sizeof(kGeneticCodes) / sizeof(GeneticCode);
 // SeqAn AminoAcid rank order (the order of the scoring tables, src/seqan2_to_biocpp.hpp:352-366)
 constexpr char kSeqanAa[28] = "ABCDEFGHIJKLMNOPQRSTUVWYZX*";
 constexpr uint8_t kRankX = 25;
@@ -30,7 +58,7 @@ constexpr uint8_t kComplement[5] = {4, 2, 1, 3, 0};
 struct CodonTable
 {
     uint8_t aa[125]; // [b1][b2][b3] in dna5 ranks -> SeqAn aa rank
-    CodonTable()
+    explicit CodonTable(char const * kCanonical)
     {
         auto rankOf = [](char c) -> uint8_t { return (uint8_t)(std::strchr(kSeqanAa, c) - kSeqanAa); };
         for (int b1 = 0; b1 < 5; ++b1)
@@ -56,10 +84,20 @@ struct CodonTable
     }
 };
 
-CodonTable const & codonTable()
+// the table of a genetic code, nullptr for an id NCBI / BioC++ do not define
+CodonTable const * codonTable(int genetic_code)
 {
-    static CodonTable const t;
-    return t;
+    static CodonTable const tabs[kNumGeneticCodes] = {
+        CodonTable(kGeneticCodes[0].aa),  CodonTable(kGeneticCodes[1].aa),  CodonTable(kGeneticCodes[2].aa),  CodonTable(kGeneticCodes[3].aa),
+        CodonTable(kGeneticCodes[4].aa),  CodonTable(kGeneticCodes[5].aa),  CodonTable(kGeneticCodes[6].aa),  CodonTable(kGeneticCodes[7].aa),
+        CodonTable(kGeneticCodes[8].aa),  CodonTable(kGeneticCodes[9].aa),  CodonTable(kGeneticCodes[10].aa), CodonTable(kGeneticCodes[11].aa),
+        CodonTable(kGeneticCodes[12].aa), CodonTable(kGeneticCodes[13].aa), CodonTable(kGeneticCodes[14].aa), CodonTable(kGeneticCodes[15].aa),
+        CodonTable(kGeneticCodes[16].aa), CodonTable(kGeneticCodes[17].aa), CodonTable(kGeneticCodes[18].aa)};
+    static_assert(kNumGeneticCodes == 19, "one table per genetic code");
+    for (int i = 0; i < kNumGeneticCodes; ++i)
+        if (kGeneticCodes[i].id == genetic_code)
+            return &tabs[i];
+    return nullptr;
 }
 
 int32_t frameOf(int mode, uint64_t id, bool subject)
@@ -120,7 +158,8 @@ uint64_t lx_untrue_subj_id(int s_mode, uint64_t n_sid, int32_t s_frame)
 int lx_translate_six_frames(uint8_t const * dna5, uint64_t n, int genetic_code, uint8_t * out, uint64_t out_capacity,
                             uint64_t * frame_off, uint64_t * frame_len)
 {
-    if (genetic_code != 1 || !frame_off || !frame_len || (!dna5 && n) || (!out && n >= 3))
+    CodonTable const * const tabp = codonTable(genetic_code);
+    if (!tabp || !frame_off || !frame_len || (!dna5 && n) || (!out && n >= 3))
         return LX_EINVAL;
     uint64_t total = 0;
     for (int f = 0; f < 6; ++f)
@@ -135,7 +174,7 @@ int lx_translate_six_frames(uint8_t const * dna5, uint64_t n, int genetic_code, 
     for (uint64_t i = 0; i < n; ++i)
         if (dna5[i] > 4)
             return LX_EINVAL;
-    CodonTable const & tab = codonTable();
+    CodonTable const & tab = *tabp;
     for (int f = 0; f < 3; ++f)
     {
         uint8_t * fwd = out + frame_off[f];

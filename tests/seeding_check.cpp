@@ -1,0 +1,139 @@
+// Host-only check of lambda_amd/csrc/host/lx_seeding.hpp (compiled and run by tests/test_seeding.py with g++):
+// the sorted word table against brute force over random reduced sequences -- exact words, half-exact words (first half
+// exact, at most one substitution in the second half: searchHalfExactImpl, /root/reference/src/search_algo.hpp:537-604),
+// cursor counts under extendRight, and the reduction tables' group structure.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <set>
+#include <tuple>
+
+#include "../lambda_amd/csrc/host/lx_seeding.hpp"
+
+using namespace lambda_amd;
+
+static int fails = 0;
+#define CHECK(c)                                                         \
+    do                                                                   \
+    {                                                                    \
+        if (!(c))                                                        \
+        {                                                                \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #c);   \
+            ++fails;                                                     \
+        }                                                                \
+    } while (0)
+
+int main()
+{
+    // Li-10: ten groups, the published ones (Li et al. 2003)
+    char const * order = "ABCDEFGHIJKLMNOPQRSTUVWYZX*";
+    auto g = [&](char c) { return kLi10[std::strchr(order, c) - order]; };
+    std::set<int> groups;
+    for (int i = 0; i < 27; ++i)
+        groups.insert(kLi10[i]);
+    CHECK(groups.size() == 10);
+    CHECK(g('A') == g('S') && g('S') == g('T'));
+    CHECK(g('F') == g('W') && g('W') == g('Y'));
+    CHECK(g('L') == g('M') && g('I') == g('V') && g('I') != g('L'));
+    CHECK(g('N') == g('H') && g('Q') == g('E') && g('E') == g('D') && g('R') == g('K'));
+    CHECK(g('C') != g('A') && g('G') != g('A') && g('P') != g('A') && g('G') != g('P'));
+
+    std::mt19937_64 rng(7);
+    for (int alph : {10, 4})
+    {
+        std::vector<uint8_t>  red;
+        std::vector<uint64_t> off, len;
+        for (int s = 0; s < 40; ++s)
+        {
+            off.push_back(red.size());
+            uint64_t const L = 5 + rng() % 300;
+            len.push_back(L);
+            for (uint64_t i = 0; i < L; ++i)
+                red.push_back((uint8_t)(rng() % (alph == 4 ? 4 : 3 + rng() % 8))); // skewed: repeats occur
+        }
+        ReducedIndex ix;
+        ix.build(red, off, len, alph);
+        CHECK(ix.keyLen() == (alph == 10 ? 18 : 27));
+        for (int trial = 0; trial < 300; ++trial)
+        {
+            int const K = alph == 10 ? 6 + (int)(rng() % 6) : 8 + (int)(rng() % 8);
+            // the seed: a word of the database (mutated now and then) or random letters
+            std::vector<uint8_t> seed(K);
+            size_t const         s0 = rng() % off.size();
+            if (len[s0] >= (uint64_t)K && rng() % 4)
+            {
+                uint64_t const p = rng() % (len[s0] - K + 1);
+                for (int i = 0; i < K; ++i)
+                    seed[i] = red[off[s0] + p + i];
+                if (rng() % 2)
+                    seed[K / 2 + rng() % (K - K / 2)] = (uint8_t)(rng() % alph);
+            }
+            else
+                for (auto & c : seed)
+                    c = (uint8_t)(rng() % alph);
+            auto brute = [&](int maxDist)
+            {
+                std::set<std::pair<uint32_t, uint32_t>> hits;
+                for (size_t s = 0; s < off.size(); ++s)
+                    for (uint64_t p = 0; p + K <= len[s]; ++p)
+                    {
+                        int  d  = 0;
+                        bool ok = true;
+                        for (int i = 0; i < K && ok; ++i)
+                            if (red[off[s] + p + i] != seed[i])
+                            {
+                                if (i < K / 2)
+                                    ok = false; // the first half is exact
+                                else
+                                    ok = ++d <= maxDist;
+                            }
+                        if (ok)
+                            hits.emplace((uint32_t)s, (uint32_t)p);
+                    }
+                return hits;
+            };
+            std::vector<ReducedIndex::Cursor> cur;
+            searchExact(ix, seed.data(), K, cur);
+            std::set<std::pair<uint32_t, uint32_t>> got;
+            uint64_t                                cnt = 0;
+            for (auto const & c : cur)
+            {
+                cnt += c.count();
+                ix.locate(c, [&](uint32_t s, uint32_t p) { got.emplace(s, p); });
+            }
+            CHECK(got == brute(0) && cnt == got.size());
+            cur.clear();
+            got.clear();
+            cnt = 0;
+            searchHalfExact(ix, seed.data(), K, 1, alph, cur);
+            for (auto const & c : cur)
+            {
+                cnt += c.count();
+                ix.locate(c, [&](uint32_t s, uint32_t p) { got.emplace(s, p); });
+            }
+            CHECK(got == brute(1) && cnt == got.size()); // (every hit under exactly one cursor)
+        }
+    }
+    // seedLooksPromising: the planted diagonal passes, a random one does not
+    {
+        int8_t m[LX_ALPH * LX_ALPH];
+        for (int a = 0; a < 32; ++a)
+            for (int b = 0; b < 32; ++b)
+                m[a * LX_ALPH + b] = a == b ? 5 : -4;
+        std::vector<uint8_t> q(60), s(200);
+        for (auto & c : q)
+            c = (uint8_t)(rng() % 20);
+        for (auto & c : s)
+            c = (uint8_t)(rng() % 20);
+        for (int i = 0; i < 40; ++i)
+            s[100 + i] = q[10 + i];
+        lx_match const good{0, 0, 20, 30, 110, 120}, bad{0, 0, 20, 30, 15, 25};
+        CHECK(seedLooksPromising(q.data(), q.size(), s.data(), s.size(), good, 10, 2, 2.0, m));
+        CHECK(!seedLooksPromising(q.data(), q.size(), s.data(), s.size(), bad, 10, 2, 2.0, m));
+        lx_match const edge{0, 0, 0, 10, 0, 10}; // clipped at both sequence starts: no out-of-range read
+        (void)seedLooksPromising(q.data(), q.size(), s.data(), s.size(), edge, 10, 2, 2.0, m);
+    }
+    std::printf(fails ? "seeding check: %d failure(s)\n" : "seeding check: ok\n", fails);
+    return fails ? 1 : 0;
+}

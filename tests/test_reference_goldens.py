@@ -50,8 +50,7 @@ def test_replay_harness_on_own_output(handle, tmp_path):
 
     _make_config1(tmp_path, nq=150, ndb=500)
     db, qry, out = tmp_path / "db.fasta", tmp_path / "q.fasta", tmp_path / "own.m8"
-    r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out), "--seed-offset", "2"],
-                       capture_output=True, text=True)
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     rows = rr.read_m8(out)
     assert len(rows) >= 15

@@ -62,7 +62,44 @@ def test_translation_matches_oracle(oracle):
     with pytest.raises(capi.LambdaExtError):
         capi.translate_six_frames(np.array([0, 1, 5], dtype=np.uint8))
     with pytest.raises(capi.LambdaExtError):
-        capi.translate_six_frames(dna("ATGGCC"), genetic_code=11)
+        capi.translate_six_frames(dna("ATGGCC"), genetic_code=7)  # NCBI / bio::alphabet::genetic_code define no table 7
+
+
+def test_other_genetic_codes():
+    """--genetic-code of the reference is a bio::alphabet::genetic_code id = an NCBI translation table
+    (src/search_options.hpp:170, :628).  The tables are pinned by their published differences from table 1 (gc.prt)."""
+    diffs = {
+        2: {"AGA": "*", "AGG": "*", "ATA": "M", "TGA": "W"},                                  # vertebrate mitochondrial
+        3: {"ATA": "M", "CTT": "T", "CTC": "T", "CTA": "T", "CTG": "T", "TGA": "W"},          # yeast mitochondrial
+        4: {"TGA": "W"},                                                                      # mold mitochondrial / Mycoplasma
+        5: {"AGA": "S", "AGG": "S", "ATA": "M", "TGA": "W"},                                  # invertebrate mitochondrial
+        6: {"TAA": "Q", "TAG": "Q"},                                                          # ciliate
+        9: {"AAA": "N", "AGA": "S", "AGG": "S", "TGA": "W"},                                  # echinoderm mitochondrial
+        10: {"TGA": "C"},                                                                     # euplotid
+        11: {},                                                                               # bacterial: as table 1
+        12: {"CTG": "S"},                                                                     # alternative yeast
+        13: {"AGA": "G", "AGG": "G", "ATA": "M", "TGA": "W"},                                 # ascidian mitochondrial
+        14: {"AAA": "N", "AGA": "S", "AGG": "S", "TAA": "Y", "TGA": "W"},                     # alternative flatworm mitochondrial
+        15: {"TAG": "Q"},                                                                     # Blepharisma
+        16: {"TAG": "L"},                                                                     # chlorophycean mitochondrial
+        21: {"TGA": "W", "ATA": "M", "AGA": "S", "AGG": "S", "AAA": "N"},                     # trematode mitochondrial
+        22: {"TCA": "*", "TAG": "L"},                                                         # Scenedesmus mitochondrial
+        23: {"TTA": "*"},                                                                     # Thraustochytrium mitochondrial
+        24: {"AGA": "S", "AGG": "K", "TGA": "W"},                                             # Pterobranchia mitochondrial
+        25: {"TGA": "G"},                                                                     # Gracilibacteria
+    }
+    bases = "TCAG"
+    codons = [a + b + c for a in bases for b in bases for c in bases]
+    std = {c: prot(capi.translate_six_frames(dna(c))[0]) for c in codons}
+    for code, d in diffs.items():
+        for c in codons:
+            assert prot(capi.translate_six_frames(dna(c), genetic_code=code)[0]) == d.get(c, std[c]), (code, c)
+    # the reverse frames use the same table: TCA is the reverse complement of TGA
+    f = capi.translate_six_frames(dna("TCA"), genetic_code=4)
+    assert prot(f[0]) == "S" and prot(f[3]) == "W"
+    # ambiguity under another table: TGN is C/C/W/W in table 4 -> X, ATN is I/I/I/M in both -> X, AGN: S/S/R/R vs S/S/S/S in table 5
+    assert prot(capi.translate_six_frames(dna("AGN"), genetic_code=5)[0]) == "S"
+    assert prot(capi.translate_six_frames(dna("AGN"), genetic_code=1)[0]) == "X"
 
 
 def test_frames_match_oracle_and_roundtrip(oracle):
