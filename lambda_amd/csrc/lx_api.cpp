@@ -1754,6 +1754,13 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
     {
         // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
         sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen, h->opt_f16 && h->opt_query_run % 16 == 0);
+        // short queries (<= 104 columns, e.g. 100-residue reads): the (8,13) geometry where the packed-half sweep applies --
+        // a third fewer padded columns than (8,19)
+        bool const half_ok = h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
+        static bool const no_narrow = getenv("LX_NO_NARROW_SWEEP") != nullptr; // A/B aid
+        if (sweep_cfg == 1 && half_ok && !no_narrow && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(3) &&
+            (h->opt_query_run % 16 == 0 || 2 * lx::score_pair_profile_bytes(1, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit()))
+            sweep_cfg = 3;
         sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
         int smax_entry = 0;
         for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
@@ -1770,10 +1777,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
             half_sweep = h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
                          h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
-                         ((sweep_cfg == 1 && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
+                         (((sweep_cfg == 1 || sweep_cfg == 3) && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
             if (h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
-                h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && sweep_cfg == 1 && !half_sweep && h->opt_query_run % 8 == 0 &&
-                2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
+                h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && h->opt_query_run % 8 == 0 &&
+                2 * lx::score_pair_profile_bytes(sweep_cfg == 3 ? 1 : 0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
             {
                 half_sweep  = true;
                 sweep_share = 4;
@@ -1833,7 +1840,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             p.ovf_cap    = (uint32_t)ovf_cap;
             p.ovf_count  = h->d_ws_top + 4;
         }
-        int const sweep_pair = sweep_cfg == 1 ? 0 : 5; // pair geometry with the same (G, C): (8,19) / (16,13)
+        int const sweep_pair = sweep_cfg == 1 ? 0 : sweep_cfg == 3 ? 1 : 5; // pair geometry with the same (G, C): (8,19) / (8,13) / (16,13)
         PhaseTimer pt0(h, stream, 0);
         if (half_sweep)
         {
@@ -1862,7 +1869,7 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
         // kernel writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range
         // test is left to the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
         bool const i16_sweep = !half_sweep && h->opt_f16 && !getenv("LX_NO_I16_SWEEP") &&
-                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0;
+                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0 && sweep_cfg != 3;
         if (i16_sweep)
         {
             lx::ScoreParams sp1{};
@@ -2321,7 +2328,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // windows are up to 3 x longer: src/search_algo.hpp:1153-1157), so that a wavefront's 16 windows take about as many steps
     // each -- the reason the reference sorts its SIMD batches (:1229-1235).  Results are scattered by original index anyway.
     {
-        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 152 ? 0u : lq <= 208 ? 1u : 1u + (lq + 151) / 152; };
+        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
         uint32_t cmin = ~0u, cmax = 0;
         bool     ragged_s = false;
         for (uint64_t k = 0; k < live; ++k)
@@ -2473,7 +2480,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         std::vector<uint64_t> tmax(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
         // (what the wavefronts will execute: every block of kRun slots runs all columns of its panels for as many steps as
         // its longest window has rows)
-        uint64_t const panel = max_q <= 152 ? 152 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
+        uint64_t const panel = max_q <= 104 ? 104 : max_q <= 152 ? 152 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
         parallel_ranges(ngroups, nthreads,
                         [&](unsigned t, uint64_t glo, uint64_t ghi)
                         {
@@ -2689,7 +2696,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             ++k1;
         {
             // ... and never mix geometry classes (the list is class-major): cut where the class changes
-            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 152 ? 0u : lq <= 208 ? 1u : 1u + (lq + 151) / 152; };
+            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
             uint32_t const c0 = qclass(ext[idx[k0]].q_len);
             if (!getenv("LX_EXTEND_NO_CLASSES") && qclass(ext[idx[k1 - 1]].q_len) != c0)
             {

@@ -1297,13 +1297,13 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 
 uint64_t ckpt_slot_dwords(int cfg, uint32_t steps_cap)
 {
-    return cfg == 2 ? CkptLayout<16, 13>::slot_dwords(steps_cap) : CkptLayout<8, 19>::slot_dwords(steps_cap);
+    return cfg == 2 ? CkptLayout<16, 13>::slot_dwords(steps_cap) : cfg == 3 ? CkptLayout<8, 13>::slot_dwords(steps_cap) : CkptLayout<8, 19>::slot_dwords(steps_cap);
 }
 
 // compact slots of the packed-half sweep
 uint64_t ckpt16_slot_dwords(int cfg, uint32_t steps_cap)
 {
-    return cfg == 2 ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap) : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
+    return cfg == 2 ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap) : cfg == 3 ? Ckpt16Layout<8, 13>::slot_dwords(steps_cap) : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
 }
 
 template <int G, int C>
@@ -1332,7 +1332,7 @@ hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return p.cfg == 2 ? launch_ckpt_forward_cfg<16, 13>(p, stream) : launch_ckpt_forward_cfg<8, 19>(p, stream);
+    return p.cfg == 2 ? launch_ckpt_forward_cfg<16, 13>(p, stream) : p.cfg == 3 ? launch_ckpt_forward_cfg<8, 13>(p, stream) : launch_ckpt_forward_cfg<8, 19>(p, stream);
 }
 
 static int backtrace_resident_waves()
@@ -1368,6 +1368,8 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
         return e;
     if (p.cfg == 2)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<16, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    else if (p.cfg == 3)
+        hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 19>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     return hipGetLastError();

@@ -561,7 +561,10 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
     {
         if (!p.ends || p.steps_cap % 16 != 0)
             return hipErrorInvalidValue;
-        return cfg == 0 ? launch_pair_cfg<8, 19, true>(p, stream) : cfg == 5 ? launch_pair_cfg<16, 13, true>(p, stream) : hipErrorInvalidValue;
+        return cfg == 0   ? launch_pair_cfg<8, 19, true>(p, stream)
+               : cfg == 5 ? launch_pair_cfg<16, 13, true>(p, stream)
+               : cfg == 1 ? launch_pair_cfg<8, 13, true>(p, stream) // short queries: 104 columns
+                          : hipErrorInvalidValue;
     }
     switch (cfg)
     {
