@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     auto rowck_word = [&](uint32_t m, uint32_t st, uint32_t c) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(rowck_of(0) + L16::rowck_quad_index(m, st, 0))[c]);
+            return expand(reinterpret_cast<uint16_t const *>(rowck_of(0) + L16::rowck_quad_index(m, st, c / 8))[c % 8]);
         return reinterpret_cast<uint32_t const *>(rowck_of(st / G) + rowck_quad_index<G, Lay::kCkDw>(m, st % G, c / 4))[c % 4];
     };
     auto bnd_word_of = [&](uint32_t st, uint32_t k) -> uint32_t

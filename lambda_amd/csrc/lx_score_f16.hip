@@ -395,8 +395,8 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
                 code[c] = c < C ? c16_pack(__builtin_elementwise_fma(Hrow[c < C ? c : 0], C24, nzic),
                                            __builtin_elementwise_fma(Hrow[c < C ? c : 0] - F0[c < C ? c : 0], C24, nGEc))
                                 : 0u;
-            uint32_t const base = (uint32_t)(Lay::bnd_dwords(p.steps_cap) / 4) + Lay::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, 0);
-            uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+            uint32_t const base0 = (uint32_t)(Lay::bnd_dwords(p.steps_cap) / 4);
+            uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base0, * const dB = reinterpret_cast<uint4 *>(slotB) + base0;
 #pragma unroll
             for (int x = 0; x < Lay::kCkDw / 4; ++x)
             {
@@ -408,8 +408,9 @@ __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair
                     wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
                     wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
                 }
-                dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
-                dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                uint32_t const qi = Lay::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, (uint32_t)x);
+                dA[qi] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                dB[qi] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
             }
         }
     };

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 #pragma unroll
                 for (int c = 0; c < 2 * L16::kCkDw; ++c)
                     code[c] = c < C ? ((as_u32((Hrow[c < C ? c : 0] - F0[c < C ? c : 0]) - GE) << 11) | as_u32(Hrow[c < C ? c : 0] - zi)) : 0u;
-                uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4) + L16::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, 0);
+                uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4);
                 uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
                 for (int x = 0; x < L16::kCkDw / 4; ++x)
@@ -426,8 +426,9 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                         wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
                         wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
                     }
-                    dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
-                    dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                    uint32_t const qi = L16::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, (uint32_t)x);
+                    dA[qi] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                    dB[qi] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
                 }
             }
         };
