@@ -116,8 +116,8 @@ struct lx_handle
     };
     struct XbLane
     {
-        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle;
-        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt;
+        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len;
+        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len;
         hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
     } xb[2];
     hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
@@ -699,10 +699,10 @@ void lx_destroy(lx_handle * h)
         }
     for (auto & ln : h->xb)
     {
-        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt})
+        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt, &ln.d_len})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle})
+        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt})
@@ -1677,6 +1677,7 @@ struct FusedExtra
     unsigned long long * d_rle_top  = nullptr;
     uint64_t             rle_cap    = 0;
     uint32_t *           d_src_out  = nullptr; // [survivor list capacity]
+    uint32_t *           d_rle_len  = nullptr; // [survivor list capacity]: code bytes per position
 };
 
 // after the backtrace (records and slots by list position): the survivors' ops as run-length codes, the list's original
@@ -1701,6 +1702,7 @@ static int fused_pack(lx_handle * h, FusedExtra const * fx, uint64_t cap, void *
     pp.rle        = fx->d_rle;
     pp.rle_top    = fx->d_rle_top;
     pp.rle_cap    = fx->rle_cap;
+    pp.rle_len    = fx->d_rle_len;
     pp.err        = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
     LX_HIP(h, hipMemsetAsync(fx->d_rle_top, 0, sizeof(unsigned long long), stream));
     LX_HIP(h, lx::launch_rle_pack(pp, stream));
@@ -1981,7 +1983,10 @@ static int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const 
             p.rle     = fx->d_rle;
             p.rle_top = fx->d_rle_top;
             p.rle_cap = fx->rle_cap;
+            p.rle_len = fx->d_rle_len;
             LX_HIP(h, hipMemsetAsync(fx->d_rle_top, 0, sizeof(unsigned long long), stream));
+            if (fx->d_rle_len) // (positions the backtrace never visits -- padding, score-less -- read 0)
+                LX_HIP(h, hipMemsetAsync(fx->d_rle_len, 0, cap * sizeof(uint32_t), stream));
         }
         p.src           = static_cast<uint32_t const *>(h->d_sel_src.ptr);
         p.count_ptr     = static_cast<uint64_t const *>(d_out_count);
@@ -2193,7 +2198,15 @@ inline void rle_expand(uint8_t const * codes, int32_t n_ops, uint8_t * out)
     {
         uint8_t const c   = *codes++;
         int32_t const len = (c & 63) + 1;
-        std::memset(out + done, kOp[c >> 6], (size_t)len);
+        if (done + ((len + 15) & ~15) <= n_ops)
+        {
+            // whole 16-byte stores while they stay inside this alignment's columns (the surplus is overwritten by the runs that
+            // follow; a call to memset per run of a few columns costs more than the stores)
+            for (int32_t k = 0; k < len; k += 16)
+                std::memset(out + done + k, kOp[c >> 6], 16);
+        }
+        else
+            std::memset(out + done, kOp[c >> 6], (size_t)len);
         done += len;
     }
 }
@@ -2423,7 +2436,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     }();
     h->ext_bytes.clear();
     uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
-    double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0; // LX_HOST_TIMING: where the host's time goes
+    double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0, t_u1 = 0, t_u2 = 0; // LX_HOST_TIMING: where the host's time goes
     h->xb_stats[0] = live;
     h->xb_stats[1] = h->xb_stats[2] = h->xb_stats[3] = 0; // slots, cells, cells the wavefronts execute
     auto     now    = []() { return std::chrono::steady_clock::now(); };
@@ -2484,7 +2497,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         parallel_ranges(ngroups, nthreads,
                         [&](unsigned t, uint64_t glo, uint64_t ghi)
                         {
-                            uint64_t ms = 1;
+                            uint64_t ms = 1, cells = 0, padded = 0; // (locals: the per-thread slots share cache lines)
                             for (uint64_t g = glo; g < ghi; ++g)
                             {
                                 uint64_t const a = grp[2 * g], b = grp[2 * g + 2], o1 = grp[2 * g + 3];
@@ -2496,9 +2509,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     for (uint64_t j = j0; j < std::min(b, j0 + kRun); ++j)
                                     {
                                         bmax = std::max<uint64_t>(bmax, ext[idx[j]].s_len);
-                                        tcells[t] += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
+                                        cells += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
                                     }
-                                    tpad[t] += kRun * cols * (bmax + lanes - 1);
+                                    padded += kRun * cols * (bmax + lanes - 1);
                                 }
                                 for (uint64_t j = a; j < b; ++j, ++o)
                                 {
@@ -2516,7 +2529,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     slot_min[o] = 0x7fffffff; // never survives
                                 }
                             }
-                            tmax[t] = std::max(tmax[t], ms);
+                            tmax[t]   = std::max(tmax[t], ms);
+                            tcells[t] = cells;
+                            tpad[t]   = padded;
                         });
         for (uint64_t v : tmax)
             max_s = std::max(max_s, v);
@@ -2533,7 +2548,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         if ((rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
             (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) ||
             (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) ||
-            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
+            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) ||
+            (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
             (rc2 = ensure_pinned(h, ln.p_score, slots * sizeof(int32_t))) || (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
             return rc2;
         LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
@@ -2550,6 +2566,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
         fx.rle_cap    = pr.cap_sel * stride;
         fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
         if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
                               nullptr, d_cnt, h->stream, 3, true, &fx)))
             return rc2;
@@ -2578,6 +2595,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             return fail(h, LX_ESTATE, "survivor list longer than its capacity");
         int rc2;
         if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
+            (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) ||
             (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
             return rc2;
         // (on the upload stream: stream2 already holds the next chunk's first-stage copies, which wait for its kernels)
@@ -2585,6 +2603,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             LX_HIP(h, hipMemcpyAsync(ln.p_hsp.ptr, ln.d_hsp.ptr, count * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream3));
             LX_HIP(h, hipMemcpyAsync(ln.p_src.ptr, ln.d_src.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_len.ptr, ln.d_len.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
             if (nrle)
                 LX_HIP(h, hipMemcpyAsync(ln.p_rle.ptr, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
         }
@@ -2595,6 +2614,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         lx_hsp const * const   hs      = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
         uint32_t const * const sel_src = static_cast<uint32_t const *>(ln.p_src.ptr);
         uint8_t const * const  codes   = static_cast<uint8_t const *>(ln.p_rle.ptr);
+        uint32_t const * const code_len = static_cast<uint32_t const *>(ln.p_len.ptr);
         uint32_t const * const slot_src = pr.slot_src.data();
         // (1) per survivor: how many bytes its ops take in the handle's buffer (column bytes, or the codes themselves),
         //     and which list position a slot has
@@ -2616,13 +2636,15 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 {
                                     slot_pos[sel_src[e]] = (uint32_t)e;
                                     if (hs[e].score > 0)
-                                        len = want_rle ? rle_length(codes + (uint32_t)hs[e].ops_shift, hs[e].n_ops) : (uint64_t)hs[e].n_ops;
+                                        len = want_rle ? (uint64_t)code_len[e] : (uint64_t)hs[e].n_ops;
                                 }
                                 pos_off[e] = len;
                                 sum += len;
                             }
                             part[t + 1] = sum;
                         });
+        auto const tu1 = now();
+        t_u1 += ms(t1, tu1);
         // (2) offsets: prefix over the threads' shares, then inside each share
         part[0] = ops_total;
         for (unsigned t = 0; t < nthreads; ++t)
@@ -2642,6 +2664,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         pos_off[count] = total;
         h->ext_bytes.grow(total + 16);
         uint8_t * const dst = h->ext_bytes.data();
+        t_u2 += ms(tu1, now());
         // (3) one pass over the chunk's slots: score and record of every extension, the survivors' ops
         std::vector<uint64_t> untraced(nthreads, ~0ull);
         parallel_ranges(pr.slots, nthreads,
@@ -2728,8 +2751,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         return rc;
     hm.mark("pipeline");
     if (hm.on)
-        fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f\n", c, t_prep, t_issue,
-                t_wait, t_unpack);
+        fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f (lengths %.1f, offsets %.1f)\n", c, t_prep, t_issue,
+                t_wait, t_unpack, t_u1, t_u2);
     *out_ops       = h->ext_bytes.data();
     *out_ops_bytes = ops_total;
     return LX_OK;

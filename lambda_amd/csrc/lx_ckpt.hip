@@ -581,6 +581,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     // ---- state of the extension this lane is working on
     bool             have = false, blocked = false, done = false, need_col = false, c16 = false;
     uint64_t         po = 0;          // where the extension's record and ops slot are
+    uint64_t         pos = 0;         // its position in the list
     EndCell          ec{};
     uint32_t const * slot = nullptr;
     uint8_t const *  q = nullptr, * s = nullptr;
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 return; // padding slot
             oi = sidx;
         }
+        pos                = e;
         po                 = p.out_by_pos ? e : oi;
         uint64_t const  se = p.slot_by_src ? oi : e; // single-sweep mode: checkpoints and end cells sit at the original index
         ec                 = p.ends[se];
@@ -842,6 +844,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             out.ops_shift          = rle_mode ? (int32_t)(uint32_t)at : (int32_t)(cap - n);
         }
         p.out_hsp[po] = out;
+        if (rle_mode && p.rle_len)
+            p.rle_len[pos] = ec.score > 0 ? ncodes : 0u;
         have          = false;
     };
 

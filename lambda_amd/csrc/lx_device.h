@@ -172,6 +172,7 @@ struct TraceParams
     uint8_t *            rle;
     unsigned long long * rle_top;
     uint64_t             rle_cap;
+    uint32_t *           rle_len;     // [list capacity]: code bytes of every position (0 for padding slots / no alignment)
     int32_t            bt_tile_at, bt_refill_at; // checkpoint backtrace scheduling thresholds (0 = the compiled defaults)
     uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
 };
@@ -207,6 +208,7 @@ struct PackParams
     uint64_t const *     count_ptr; // optional device-side list length
     uint64_t             n;         // capacity of the list
     uint8_t *            rle;       // dense code stream
+    uint32_t *           rle_len;   // [n]: code bytes of every position
     unsigned long long * rle_top;   // bytes handed out (zeroed by the host before the launch)
     uint64_t             rle_cap;
     int32_t *            err;

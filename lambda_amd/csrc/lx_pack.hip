@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void rle_pack_kernel(PackParams p)
     if (lane == 63 && total != 0)
         base = atomicAdd(p.rle_top, (unsigned long long)total);
     base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 63) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 63);
+    if (e < p.n && p.rle_len)
+        p.rle_len[e] = mine ? ncodes : 0u;
     if (!mine)
         return;
     uint64_t const at = base + incl - ncodes;
