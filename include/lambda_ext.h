@@ -136,6 +136,8 @@ enum
                                        applies, LX_OPT_QUERY_RUN is a multiple of 8 and the checkpoints of the whole
                                        batch (7.7 KB per 150 x 176 extension as compact codes of the packed-half kernel,
                                        13.5 KB as int16 pairs) fit LX_OPT_TRACE_BYTES, else mode 1 */
+    LX_OPT_EXTEND_CHUNK    = 10, /* extensions per chunk of lx_extend_batch's pipeline (0 = default, ~640 k; at least 1024):
+                                   smaller chunks start returning results earlier, larger ones amortise the per-chunk launches */
     LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
                                    says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
                                    parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of

@@ -38,6 +38,7 @@ LX_OPT_BS_MATCH_RULE = 6
 LX_OPT_PACKED_HALF = 7
 LX_OPT_PASS2_MODE = 8
 LX_OPT_BAND = 9
+LX_OPT_EXTEND_CHUNK = 10
 
 
 class Karlin(C.Structure):

@@ -152,6 +152,7 @@ struct lx_handle
     uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
+    uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
     uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
     int32_t const * band_dev = nullptr;  // lx_set_band_centres_dev: the caller's device array for the *_dev calls
     std::vector<int32_t> band_host;      // lx_set_band_centres: centres of the next host-buffer call's extensions
@@ -742,6 +743,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_BS_MATCH_RULE: h->opt_bs_rule = value ? 1 : 0; return LX_OK;
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
         case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
+        case LX_OPT_EXTEND_CHUNK: h->opt_extend_chunk = value; return LX_OK;
         case LX_OPT_BAND:
             if (value > (1u << 20))
                 return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
@@ -766,6 +768,7 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_PACKED_HALF: *value = h->opt_f16; return LX_OK;
         case LX_OPT_PASS2_MODE: *value = h->opt_pass2; return LX_OK;
         case LX_OPT_BAND: *value = h->opt_band; return LX_OK;
+        case LX_OPT_EXTEND_CHUNK: *value = h->opt_extend_chunk; return LX_OK;
         default: return LX_EINVAL;
     }
 }
@@ -2429,10 +2432,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     if (sref.upload)
         LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
 
-    static uint64_t const chunk_target = []() -> uint64_t
+    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : []() -> uint64_t
     {
-        char const * e = getenv("LX_EXTEND_CHUNK"); // development aid
-        return e ? (uint64_t)std::max(1024ll, atoll(e)) : 640ull << 10;
+        static uint64_t const v = []() -> uint64_t
+        {
+            char const * e = getenv("LX_EXTEND_CHUNK"); // development aid
+            return e ? (uint64_t)std::max(1024ll, atoll(e)) : 640ull << 10;
+        }();
+        return v;
     }();
     h->ext_bytes.clear();
     uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far

@@ -876,13 +876,19 @@ def test_full_size_host_entry_point_equals_device_path(handle):
 def test_extend_batch_rle_codes_expand_to_the_column_bytes(handle, oracle):
     """lx_extend_batch_rle: the ops in the form they cross PCIe in -- one byte per run, (op << 6) | (length - 1), runs beyond
     64 columns split -- must expand (lx_expand_ops) to exactly the column bytes lx_extend_batch returns, for several chunks
-    of the pipeline (LX_EXTEND_CHUNK is not set: the batch is made larger than one chunk instead)."""
+    of the pipeline (LX_OPT_EXTEND_CHUNK) and for a single one."""
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
-    q, s, ext = synth.make_batch_np(30_000, 150, 16, seed=91, sub_rate=0.2, indel_rate=0.03)  # 480 k extensions: two chunks
+    q, s, ext = synth.make_batch_np(30_000, 150, 16, seed=91, sub_rate=0.2, indel_rate=0.03)  # 480 k extensions
     cut = 80
-    score, hsp, off, ops = handle.extend_batch(q, s, ext, cut, copy_ops=True)
-    score2, hsp2, off2, codes = handle.extend_batch_rle(q, s, ext, cut)
+    handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 60_000)  # eight chunks: the two lanes of the pipeline are reused four times
+    try:
+        score, hsp, off, ops = handle.extend_batch(q, s, ext, cut, copy_ops=True)
+        score2, hsp2, off2, codes = handle.extend_batch_rle(q, s, ext, cut)
+    finally:
+        handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
+    score1, hsp1, off1, ops1 = handle.extend_batch(q, s, ext, cut, copy_ops=True)  # one chunk: same results, same layout
+    assert (score1 == score).all() and (hsp1["n_ops"] == hsp["n_ops"]).all() and (off1 == off).all() and (ops1 == ops).all()
     assert (score == score2).all()
     for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops", "num_matches", "num_gap_opens"):
         assert (hsp[f] == hsp2[f]).all(), f
