@@ -1,0 +1,1336 @@
+// lx_host.cpp -- the host-buffer entry points of the C ABI (compiled with hipcc): what a binding of the reference calls with
+// the sequences and lists it has in host memory.  lx_score_batch / lx_align_batch bin the list by kernel geometry,
+// lx_extend_batch runs the fused step as a pipeline of chunks (pinned staging, two chunks in flight, run-length coded ops on
+// the wire), band mode takes a plain path.  The device entry points they drive live in lx_api.cpp; no DP arithmetic here.
+#include "lx_internal.h"
+using namespace lxi;
+
+// a few host threads for the per-extension loops of the host-buffer entry point (none below a quarter million items)
+unsigned lxi::host_threads(uint64_t n)
+{
+    if (n < 250000)
+        return 1;
+    static unsigned const avail = []()
+    {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
+        if (char const * e = getenv("LX_HOST_THREADS"))
+            c = (unsigned)std::max(1, atoi(e));
+        return std::max(1u, std::min(c, 8u));
+    }();
+    return avail;
+}
+
+lxi::HostPool & lxi::host_pool()
+{
+    static HostPool p;
+    return p;
+}
+
+static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                       lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
+                       int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
+                       uint64_t const * caller_ops_off, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
+
+extern "C" {
+
+int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t * out_score)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (h->opt_band)
+        return host_banded(h, slot, 0, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, nullptr, 0, out_score, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr);
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+
+    HostMarks hm("lx_score_batch");
+    // ---- validate; order by (q_len, q_off, s_len): extensions of one query become adjacent (one LDS profile per
+    // wavefront), similar lengths become adjacent (lanes of a wavefront run in lockstep; the reference sorts its
+    // SIMD batches for the same reason, src/search_algo.hpp:1229-1235)
+    if (n > 0xfffffff0ull)
+        return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    auto before = [&](uint32_t a, uint32_t b)
+    {
+        lx_extension const &x = ext[a], &y = ext[b];
+        if (x.q_len != y.q_len)
+            return x.q_len < y.q_len;
+        if (x.q_off != y.q_off)
+            return x.q_off < y.q_off;
+        if (x.s_len != y.s_len)
+            return x.s_len < y.s_len;
+        return a < b;
+    };
+    // (the loops over the list are spread over a few host threads, as in lx_extend_batch)
+    unsigned const nthreads = host_threads(n);
+    struct Part
+    {
+        uint64_t live = 0, bad = ~0ull;
+        uint32_t first_live = 0xffffffffu, last_live = 0xffffffffu;
+        bool     ordered = true;
+    };
+    std::vector<Part> parts(nthreads);
+    parallel_ranges(n, nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        Part & pt = parts[t];
+                        for (uint64_t i = lo; i < hi; ++i)
+                        {
+                            lx_extension const & x = ext[i];
+                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+                            {
+                                pt.bad = std::min(pt.bad, i);
+                                continue;
+                            }
+                            if (x.q_len == 0 || x.s_len == 0)
+                            {
+                                out_score[i] = 0;
+                                continue;
+                            }
+                            if (pt.last_live != 0xffffffffu && before((uint32_t)i, pt.last_live))
+                                pt.ordered = false;
+                            if (pt.first_live == 0xffffffffu)
+                                pt.first_live = (uint32_t)i;
+                            pt.last_live = (uint32_t)i;
+                            ++pt.live;
+                        }
+                    });
+    bool     ordered = true; // lambda hands its matches over sorted by query: then the sort is skipped
+    uint64_t live    = 0;
+    {
+        uint32_t prev = 0xffffffffu;
+        for (Part const & pt : parts)
+        {
+            if (pt.bad != ~0ull)
+                return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
+            ordered = ordered && pt.ordered;
+            if (pt.first_live != 0xffffffffu)
+            {
+                if (prev != 0xffffffffu && before(pt.first_live, prev))
+                    ordered = false;
+                prev = pt.last_live;
+            }
+            live += pt.live;
+        }
+    }
+    std::vector<uint32_t> idx(live);
+    {
+        std::vector<uint64_t> first(nthreads + 1, 0);
+        for (unsigned t = 0; t < nthreads; ++t)
+            first[t + 1] = first[t] + parts[t].live;
+        parallel_ranges(n, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = first[t];
+                            for (uint64_t i = lo; i < hi; ++i)
+                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                                    idx[o++] = (uint32_t)i;
+                        });
+    }
+    if (!ordered)
+        std::sort(idx.begin(), idx.end(), before);
+    hm.mark("validate+sort");
+
+    // ---- bin query runs by kernel geometry.  A run whose padding to a whole number of wavefront slots wastes
+    // <= 25 % goes to a "shared profile" launch (8-lane geometries allowed), the rest to per-extension profiles.
+    // bin index: kind 0 = per-extension profiles, 1 = one profile per wavefront (int32): cfg * 2 + kind;
+    // kind 2 = packed half (16 extensions of one query per wavefront): ncfg * 2 + pair geometry
+    int const    ncfg  = lx::score_cfg_count();
+    size_t const nbins = (size_t)ncfg * 2 + 8;
+    struct Run
+    {
+        uint64_t first, count, pad; // positions in idx, padded slot count
+        uint32_t bin;
+        uint64_t out;               // first slot in the upload buffer (set once the bins are laid out)
+    };
+    std::vector<Run>      runs;
+    std::vector<uint64_t> bin_slots(nbins, 0);
+    std::vector<uint32_t> bin_maxq(nbins, 0);
+    uint64_t              carry_pairs = 0;
+    runs.reserve(idx.size() / 8 + 16);
+    for (size_t k = 0; k < idx.size();)
+    {
+        size_t k1 = k + 1;
+        while (k1 < idx.size() && ext[idx[k1]].q_off == ext[idx[k]].q_off && ext[idx[k1]].q_len == ext[idx[k]].q_len)
+            ++k1;
+        uint64_t const run  = k1 - k;
+        uint32_t const qlen = ext[idx[k]].q_len;
+        int            kind = 0, cfg = 0;
+        uint64_t       pad  = run;
+        int const      pcfg = h->opt_f16 ? lx::score_pair_cfg_for(qlen) : -1;
+        uint64_t const pad16 = (run + 15) / 16 * 16;
+        if (pcfg >= 0 && (pad16 - run) * 4 <= pad16)
+        {
+            kind = 2;
+            cfg  = pcfg;
+            pad  = pad16;
+        }
+        else if (pcfg < 0 && h->opt_f16 && (pad16 - run) * 4 <= pad16)
+        {
+            kind = 2; // wider than every packed-half geometry: the packed 16-bit integer kernel, panel by panel
+            cfg  = kPair16Bin;
+            pad  = pad16;
+        }
+        else
+        {
+            cfg          = pick_cfg(qlen, true);
+            uint64_t grp = (uint64_t)lx::score_cfg_groups(cfg);
+            pad          = (run + grp - 1) / grp * grp;
+            kind         = (grp > 1 && (pad - run) * 4 <= pad) ? 1 : 0;
+            if (kind == 0)
+            {
+                cfg  = pick_cfg(qlen, false);
+                grp  = (uint64_t)lx::score_cfg_groups(cfg);
+                pad  = (run + grp - 1) / grp * grp;
+                kind = (grp > 1 && (pad - run) * 4 <= pad) ? 1 : 0;
+                if (kind == 0)
+                    pad = run;
+            }
+        }
+        uint32_t const bin = kind == 2 ? (uint32_t)(ncfg * 2 + cfg) : (uint32_t)(cfg * 2 + kind);
+        runs.push_back(Run{k, run, pad, bin, 0});
+        bin_slots[bin] += pad;
+        bin_maxq[bin] = std::max(bin_maxq[bin], qlen);
+        if ((kind != 2 && (int)qlen > lx::score_cfg_panel(cfg)) || (kind == 2 && cfg == kPair16Bin))
+            for (size_t j = k; j < k1; ++j)
+                carry_pairs += ext[idx[j]].s_len;
+        k = k1;
+    }
+    if (carry_pairs * 8 + 4096 > h->ws_grown)
+        h->ws_grown = carry_pairs * 8 + 4096;
+
+    struct Seg
+    {
+        int      cfg;
+        uint64_t first, count;
+        bool     multi, shared;
+        int      pair_cfg;
+    };
+    std::vector<Seg>      segs;
+    std::vector<uint64_t> bin_cursor(nbins, 0);
+    uint64_t              total_slots = 0;
+    for (size_t b = 0; b < nbins; ++b)
+    {
+        if (!bin_slots[b])
+            continue;
+        bin_cursor[b] = total_slots;
+        if (b < (size_t)ncfg * 2)
+        {
+            int const cfg = (int)(b / 2);
+            segs.push_back(Seg{cfg, total_slots, bin_slots[b], bin_maxq[b] > (uint32_t)lx::score_cfg_panel(cfg), (b & 1) == 1, -1});
+        }
+        else // the int32 fix-up launch over the same list uses the shared-profile geometry of the longest query
+        {
+            int const pair = (int)(b - (size_t)ncfg * 2), fcfg = pick_cfg(bin_maxq[b], true);
+            segs.push_back(Seg{fcfg, total_slots, bin_slots[b], pair == kPair16Bin && bin_maxq[b] > (uint32_t)lx::score_cfg_panel(fcfg), true,
+                               pair == kPair16Bin ? kPair16 : pair});
+        }
+        total_slots += bin_slots[b];
+    }
+    // every slot is written exactly once: straight into the upload buffer, no per-bin copies
+    for (Run & r : runs)
+    {
+        r.out = bin_cursor[r.bin];
+        bin_cursor[r.bin] += r.pad;
+    }
+    std::vector<lx_extension> & sorted = h->xb_ext; // (host staging that keeps its pages between calls)
+    std::vector<uint32_t> &     perm   = h->xb_src;
+    sorted.resize(total_slots);
+    perm.resize(total_slots);
+    parallel_ranges(runs.size(), nthreads,
+                    [&](unsigned, uint64_t rlo, uint64_t rhi)
+                    {
+                        for (uint64_t ri = rlo; ri < rhi; ++ri)
+                        {
+                            Run const & r = runs[ri];
+                            uint64_t    o = r.out;
+                            for (uint64_t j = 0; j < r.count; ++j, ++o)
+                            {
+                                uint32_t const src = idx[r.first + j];
+                                sorted[o]          = ext[src];
+                                perm[o]            = src;
+                            }
+                            lx_extension dummy = ext[idx[r.first]]; // dummy slots keep one query per wavefront
+                            dummy.s_len        = 0;
+                            for (uint64_t j = r.count; j < r.pad; ++j, ++o)
+                            {
+                                sorted[o] = dummy;
+                                perm[o]   = 0xffffffffu;
+                            }
+                        }
+                    });
+    if (sorted.empty())
+        return LX_OK;
+
+    hm.mark("bin");
+    // ---- upload
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, sorted.size() * sizeof(lx_extension))) ||
+        (rc = ensure(h, h->d_out, sorted.size() * sizeof(int32_t))))
+        return rc;
+    if ((rc = prepare_workspace(h, h->stream)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, sorted.data(), sorted.size() * sizeof(lx_extension), hipMemcpyHostToDevice,
+                             h->stream));
+
+    hm.mark("upload-issue");
+    // ---- launch
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    for (Seg const & seg : segs)
+    {
+        rc = launch_score_list(h, slot, h->d_q.ptr, sref.dev,
+                               static_cast<lx_extension const *>(h->d_ext.ptr) + seg.first, seg.count,
+                               static_cast<int32_t *>(h->d_out.ptr) + seg.first, seg.cfg, seg.multi, seg.shared,
+                               h->stream, seg.pair_cfg);
+        if (rc)
+            return rc;
+    }
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+
+    // ---- download + unpermute
+    std::vector<int32_t> & res = h->xb_score;
+    res.resize(sorted.size());
+    LX_HIP(h, hipMemcpyAsync(res.data(), h->d_out.ptr, res.size() * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    hm.mark("launch");
+    if ((rc = check_async_error(h)))
+        return rc;
+    hm.mark("wait");
+    parallel_ranges(res.size(), nthreads,
+                    [&](unsigned, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t k = lo; k < hi; ++k)
+                            if (perm[k] != 0xffffffffu)
+                                out_score[perm[k]] = res[k];
+                    });
+    hm.mark("unpermute");
+    return LX_OK;
+}
+
+
+int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                   uint64_t s_bytes, lx_extension const * ext, uint64_t n, int32_t const * known_score, lx_hsp * out_hsp,
+                   uint8_t * out_ops, uint64_t const * ops_off)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_hsp || !out_ops || !ops_off || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull)
+        return fail(h, LX_EINVAL, "at most 2^32-16 extensions per call");
+    if (h->opt_band)
+        return host_banded(h, slot, 1, q_res, q_bytes, s_res, s_bytes, ext, n, known_score, nullptr, 0, nullptr, out_hsp, out_ops, ops_off,
+                           nullptr, nullptr, nullptr);
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    HostMarks hm("lx_align_batch");
+    // ---- validate; find the runs of consecutive extensions that share their query slice (lambda's lists are grouped by
+    // query).  If padding every run to a multiple of 4 slots costs <= 25 %, pass 2 runs the shared-profile geometries.
+    uint64_t max_q = 1, max_s = 1, ops_bytes = 0, carry_pairs = 0, padded = 0, run = 0;
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_extension const & x = ext[i];
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
+        max_q     = std::max<uint64_t>(max_q, x.q_len);
+        max_s     = std::max<uint64_t>(max_s, x.s_len);
+        ops_bytes = std::max<uint64_t>(ops_bytes, ops_off[i] + x.q_len + x.s_len);
+        if ((int)x.q_len > lx::trace_cfg_panel(1)) // (the narrowest panel pass 2 may pick)
+            carry_pairs += x.s_len;
+        if (i > 0 && (x.q_off != ext[i - 1].q_off || x.q_len != ext[i - 1].q_len))
+        {
+            padded += (run + 3) / 4 * 4;
+            run = 0;
+        }
+        ++run;
+    }
+    padded += (run + 3) / 4 * 4;
+    bool const share = (padded - n) * 4 <= padded && padded <= 0xfffffff0ull; // (any query width: checkpoints carry across panels)
+    uint64_t const slots = share ? padded : n;
+
+    if (carry_pairs * 8 + 4096 > h->ws_grown)
+        h->ws_grown = carry_pairs * 8 + 4096;
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) ||
+        (rc = ensure(h, h->d_ext, slots * sizeof(lx_extension))) || (rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) ||
+        (rc = ensure(h, h->d_ops, ops_bytes + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
+        return rc;
+    if ((share && (rc = ensure(h, h->d_sel_src, slots * sizeof(uint32_t)))) ||
+        (known_score && (rc = ensure(h, h->d_sel_score, slots * sizeof(int32_t)))))
+        return rc;
+    if ((rc = prepare_workspace(h, h->stream)))
+        return rc;
+    hm.mark("validate+alloc");
+
+    // ---- slot list: the extensions in input order, every run followed by its padding slots (empty window, src = none);
+    // filled on a few host threads into staging that keeps its pages between calls
+    std::vector<lx_extension> & slot_ext   = h->xb_ext;
+    std::vector<uint32_t> &     slot_src   = h->xb_src;
+    std::vector<int32_t> &      slot_score = h->xb_min;
+    slot_ext.clear();
+    slot_src.clear();
+    slot_score.clear();
+    if (share)
+    {
+        std::vector<uint64_t> & grp = h->xb_grp; // (first extension, first slot) of every run + a sentinel
+        grp.clear();
+        uint64_t o = 0;
+        for (uint64_t i = 0; i < n;)
+        {
+            uint64_t i1 = i + 1;
+            while (i1 < n && ext[i1].q_off == ext[i].q_off && ext[i1].q_len == ext[i].q_len)
+                ++i1;
+            grp.push_back(i);
+            grp.push_back(o);
+            o += (i1 - i + 3) / 4 * 4;
+            i = i1;
+        }
+        grp.push_back(n);
+        grp.push_back(o);
+        slot_ext.resize(slots);
+        slot_src.resize(slots);
+        if (known_score)
+            slot_score.resize(slots);
+        uint64_t const ngroups = grp.size() / 2 - 1;
+        parallel_ranges(ngroups, host_threads(n),
+                        [&](unsigned, uint64_t glo, uint64_t ghi)
+                        {
+                            for (uint64_t g = glo; g < ghi; ++g)
+                            {
+                                uint64_t const i0 = grp[2 * g], i1 = grp[2 * g + 2], o1 = grp[2 * g + 3];
+                                uint64_t       oo = grp[2 * g + 1];
+                                for (uint64_t j = i0; j < i1; ++j, ++oo)
+                                {
+                                    slot_ext[oo] = ext[j];
+                                    slot_src[oo] = (uint32_t)j;
+                                    if (known_score)
+                                        slot_score[oo] = known_score[j];
+                                }
+                                lx_extension dummy = ext[i0];
+                                dummy.s_len        = 0;
+                                for (; oo < o1; ++oo)
+                                {
+                                    slot_ext[oo] = dummy;
+                                    slot_src[oo] = 0xffffffffu;
+                                    if (known_score)
+                                        slot_score[oo] = 0;
+                                }
+                            }
+                        });
+    }
+    hm.mark("slots");
+
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, share ? slot_ext.data() : ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, ops_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    if (share)
+        LX_HIP(h, hipMemcpyAsync(h->d_sel_src.ptr, slot_src.data(), slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    if (known_score)
+        LX_HIP(h, hipMemcpyAsync(h->d_sel_score.ptr, share ? slot_score.data() : known_score, slots * sizeof(int32_t),
+                                 hipMemcpyHostToDevice, h->stream));
+    hm.mark("upload-issue");
+    h->phase_ev.clear();
+    h->ev_pool_used = 0;
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    rc = align_dev_impl(h, slot, h->d_q.ptr, sref.dev, static_cast<lx::Extension const *>(h->d_ext.ptr), slots,
+                        static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
+                        static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, share ? 4 : 0,
+                        share ? static_cast<uint32_t const *>(h->d_sel_src.ptr) : nullptr, nullptr,
+                        known_score ? static_cast<int32_t const *>(h->d_sel_score.ptr) : nullptr);
+    if (rc)
+        return rc;
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    hm.mark("launch");
+    LX_HIP(h, hipMemcpyAsync(out_hsp, h->d_hsp.ptr, n * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_ops, h->d_ops.ptr, ops_bytes, hipMemcpyDeviceToHost, h->stream));
+    hm.mark("download-issue");
+    if ((rc = check_async_error(h)))
+        return rc;
+    hm.mark("wait");
+    for (uint64_t i = 0; i < n; ++i)
+        if (out_hsp[i].score < 0)
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced (workspace exhausted, or known_score is not its score)",
+                        (unsigned long long)i);
+    return LX_OK;
+}
+
+
+// ---- band mode on host buffers ---------------------------------------------------------------------------------------
+// Band mode (LX_OPT_BAND) is a semantic option, not a fast path: it runs one int32 kernel geometry and direction bits for
+// pass 2, so the host-buffer entry points skip the binning / grouping of their full-rectangle versions -- the list goes to
+// the device as it is, the centres (lx_set_band_centres) with it.
+//   what = 0: lx_score_batch, 1: lx_align_batch (caller's ops slots), 2: lx_extend_batch (ops slots of the handle)
+static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                       lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
+                       int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
+                       uint64_t const * caller_ops_off, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    uint64_t max_q = 1, max_s = 1, total = 0;
+    std::vector<uint64_t> & off = h->xb_off;
+    off.resize(n + 1);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_extension const & x = ext[i];
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)i);
+        max_q  = std::max<uint64_t>(max_q, x.q_len);
+        max_s  = std::max<uint64_t>(max_s, x.s_len);
+        off[i] = total;
+        total += (uint64_t)x.q_len + x.s_len;
+    }
+    off[n] = total;
+    if (!h->band_host.empty() && h->band_host.size() != n)
+        return fail(h, LX_EINVAL, "lx_set_band_centres gave %llu centres, the call has %llu extensions",
+                    (unsigned long long)h->band_host.size(), (unsigned long long)n);
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_ext, n * sizeof(lx_extension))) ||
+        (rc = ensure(h, h->d_out, n * sizeof(int32_t))) || (rc = ensure(h, h->d_keep, n * sizeof(int32_t) + 64)) ||
+        (!h->band_host.empty() && (rc = ensure(h, h->d_band, n * sizeof(int32_t)))))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_ext.ptr, ext, n * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream));
+    if (!h->band_host.empty())
+        LX_HIP(h, hipMemcpyAsync(h->d_band.ptr, h->band_host.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    struct Restore
+    {
+        lx_handle *     h;
+        uint64_t        qlen, slen, run;
+        int32_t const * band_dev;
+        ~Restore()
+        {
+            h->opt_max_qlen  = qlen;
+            h->opt_max_slen  = slen;
+            h->opt_query_run = run;
+            h->band_dev      = band_dev;
+        }
+    } const restore{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run, h->band_dev};
+    h->opt_max_qlen  = max_q;
+    h->opt_max_slen  = max_s;
+    h->opt_query_run = 0;
+    h->band_dev      = h->band_host.empty() ? nullptr : static_cast<int32_t const *>(h->d_band.ptr);
+    if (what == 0)
+    {
+        if ((rc = lx_score_batch_dev(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, n, h->d_out.ptr, h->stream)))
+            return rc;
+        LX_HIP(h, hipMemcpyAsync(out_score, h->d_out.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+        return check_async_error(h);
+    }
+    if ((rc = ensure(h, h->d_hsp, n * sizeof(lx_hsp))) || (rc = ensure(h, h->d_ops, total + 16)) || (rc = ensure(h, h->d_opsoff, n * sizeof(uint64_t))))
+        return rc;
+    LX_HIP(h, hipMemcpyAsync(h->d_opsoff.ptr, off.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+    if (what == 1)
+    {
+        if ((rc = prepare_workspace(h, h->stream, max_q > 160 ? n * ((max_s + 3) & ~3ull) : 0)))
+            return rc;
+        int32_t const * d_known = nullptr;
+        if (known_score)
+        {
+            if ((rc = ensure(h, h->d_trace_score, n * sizeof(int32_t))))
+                return rc;
+            LX_HIP(h, hipMemcpyAsync(h->d_trace_score.ptr, known_score, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+            d_known = static_cast<int32_t const *>(h->d_trace_score.ptr);
+        }
+        h->phase_ev.clear();
+        h->ev_pool_used = 0;
+        if ((rc = align_dev_impl(h, slot, h->d_q.ptr, sref.dev, static_cast<lx::Extension const *>(h->d_ext.ptr), n,
+                                 static_cast<lx::Hsp *>(h->d_hsp.ptr), static_cast<uint8_t *>(h->d_ops.ptr),
+                                 static_cast<uint64_t const *>(h->d_opsoff.ptr), h->stream, max_q, max_s, 0, nullptr, nullptr, d_known)))
+            return rc;
+    }
+    else
+    {
+        uint64_t * const d_count = static_cast<uint64_t *>(h->d_keep.ptr);
+        int32_t *        d_min   = nullptr;
+        if (min_score)
+        {
+            if ((rc = ensure(h, h->d_keep, 16 + n * sizeof(int32_t))))
+                return rc;
+            d_min = reinterpret_cast<int32_t *>(static_cast<uint64_t *>(h->d_keep.ptr) + 2);
+            LX_HIP(h, hipMemcpyAsync(d_min, min_score, n * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        }
+        if ((rc = fused_impl(h, slot, h->d_q.ptr, sref.dev, h->d_ext.ptr, n, d_min, min_score_all, h->d_out.ptr, h->d_hsp.ptr, h->d_ops.ptr,
+                             h->d_opsoff.ptr, static_cast<uint64_t *>(h->d_keep.ptr), h->stream, 3, false)))
+            return rc;
+        (void)d_count;
+        LX_HIP(h, hipMemcpyAsync(out_score, h->d_out.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    }
+    LX_HIP(h, hipMemcpyAsync(out_hsp, h->d_hsp.ptr, n * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream));
+    h->ext_ops.resize(total + 16);
+    if (total)
+        LX_HIP(h, hipMemcpyAsync(h->ext_ops.data(), h->d_ops.ptr, total, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = check_async_error(h)))
+        return rc;
+    for (uint64_t i = 0; i < n; ++i)
+        if (out_hsp[i].score < 0)
+            return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)i);
+    if (what == 1)
+    {
+        for (uint64_t i = 0; i < n; ++i) // into the caller's slots, same position inside the slot
+            if (out_hsp[i].n_ops > 0)
+                std::memcpy(caller_ops + caller_ops_off[i] + out_hsp[i].ops_shift, h->ext_ops.data() + off[i] + out_hsp[i].ops_shift,
+                            (size_t)out_hsp[i].n_ops);
+    }
+    else
+    {
+        for (uint64_t i = 0; i < n; ++i)
+            out_ops_off[i] = off[i];
+        *out_ops       = h->ext_ops.data();
+        *out_ops_bytes = total;
+    }
+    return LX_OK;
+}
+
+// Both passes on host buffers, as a pipeline of chunks.  The list is cut at query-run boundaries into chunks of a few
+// hundred thousand extensions; per chunk the host groups the extensions by query slice and pads every run to 16 (or 8)
+// slots -- the promise LX_OPT_QUERY_RUN makes to the device path -- into pinned staging, the GPU runs the whole fused step
+// (sweep -> selection -> backtrace -> run-length packing of the ops, nothing in between comes back to the host), and the
+// results return as scores + the survivors' records + their run-length codes.  Two chunks are in flight: uploads and
+// downloads of one run on copy streams while the other's kernels run, and the host prepares chunk k + 1 / unpacks
+// chunk k - 1 meanwhile.  What crosses PCIe per extension: 28 B up, 4 B + (survivors) 52 B + ~8 B of codes down.
+namespace
+{
+
+struct XbPrep // what the host keeps about a chunk until its results are back
+{
+    uint64_t              k0 = 0, k1 = 0; // positions in the ordered list
+    uint64_t              slots = 0, cap_sel = 0;
+    std::vector<uint32_t> slot_src;       // original index of every slot (0xffffffff = padding)
+};
+
+inline void rle_expand(uint8_t const * codes, int32_t n_ops, uint8_t * out)
+{
+    static char const kOp[4] = {'M', 'D', 'I', 'M'};
+    int32_t done = 0;
+    while (done < n_ops)
+    {
+        uint8_t const c   = *codes++;
+        int32_t const len = (c & 63) + 1;
+        if (done + ((len + 15) & ~15) <= n_ops)
+        {
+            // whole 16-byte stores while they stay inside this alignment's columns (the surplus is overwritten by the runs that
+            // follow; a call to memset per run of a few columns costs more than the stores)
+            for (int32_t k = 0; k < len; k += 16)
+                std::memset(out + done + k, kOp[c >> 6], 16);
+        }
+        else
+            std::memset(out + done, kOp[c >> 6], (size_t)len);
+        done += len;
+    }
+}
+
+inline uint64_t rle_length(uint8_t const * codes, int32_t n_ops)
+{
+    uint64_t k = 0;
+    for (int32_t done = 0; done < n_ops; ++k)
+        done += (codes[k] & 63) + 1;
+    return k;
+}
+
+int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
+{
+    if (bytes <= b.cap)
+        return LX_OK;
+    if (b.ptr)
+    {
+        LX_HIP(h, hipHostFree(b.ptr));
+        b.ptr = nullptr;
+        b.cap = 0;
+    }
+    size_t const want = bytes + bytes / 4 + 4096;
+    LX_HIP(h, hipHostMalloc(&b.ptr, want, hipHostMallocDefault));
+    b.cap = want;
+    return LX_OK;
+}
+
+} // namespace
+
+static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                           lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, bool want_rle)
+{
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    SubjectRef sref;
+    if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
+        return rc;
+    s_bytes = sref.bytes;
+    HostMarks hm(want_rle ? "lx_extend_batch_rle" : "lx_extend_batch");
+
+    // ---- validate; is the list grouped by query (lambda's lists are sorted by query)?  The loops over the list are spread
+    // over a few host threads: at millions of extensions per call they would otherwise cost more than the kernels.
+    unsigned const nthreads = host_threads(n);
+    struct Part
+    {
+        uint64_t live = 0, bad = ~0ull;
+        bool     monotone = true;
+    };
+    std::vector<Part> parts(nthreads);
+    parallel_ranges(n, nthreads,
+                    [&](unsigned t, uint64_t lo, uint64_t hi)
+                    {
+                        Part &   pt   = parts[t];
+                        uint64_t prev = ~0ull; // last live extension before i (of the whole list)
+                        for (uint64_t i = lo; i-- > 0;)
+                            if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                            {
+                                prev = i;
+                                break;
+                            }
+                        for (uint64_t i = lo; i < hi; ++i)
+                        {
+                            lx_extension const & x = ext[i];
+                            if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes))
+                            {
+                                pt.bad = std::min(pt.bad, i);
+                                continue;
+                            }
+                            if (x.q_len == 0 || x.s_len == 0)
+                            {
+                                out_score[i]   = 0;
+                                out_hsp[i]     = lx_hsp{};
+                                out_ops_off[i] = 0;
+                                continue;
+                            }
+                            if (prev != ~0ull && x.q_off < ext[prev].q_off)
+                                pt.monotone = false;
+                            prev = i;
+                            ++pt.live;
+                        }
+                    });
+    uint64_t live = 0;
+    bool     monotone = true;
+    for (Part const & pt : parts)
+    {
+        if (pt.bad != ~0ull)
+            return fail(h, LX_EINVAL, "extension %llu exceeds the residue buffers", (unsigned long long)pt.bad);
+        live += pt.live;
+        monotone = monotone && pt.monotone;
+    }
+    if (live == 0)
+        return LX_OK;
+    std::vector<uint32_t> & idx = h->xb_idx;
+    idx.resize(live);
+    {
+        std::vector<uint64_t> first(nthreads + 1, 0);
+        for (unsigned t = 0; t < nthreads; ++t)
+            first[t + 1] = first[t] + parts[t].live;
+        parallel_ranges(n, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = first[t];
+                            for (uint64_t i = lo; i < hi; ++i)
+                                if (ext[i].q_len != 0 && ext[i].s_len != 0)
+                                    idx[o++] = (uint32_t)i;
+                        });
+    }
+    if (!monotone) // anything else is sorted first: equal slices become adjacent
+        std::sort(idx.begin(), idx.end(),
+                  [&](uint32_t a, uint32_t b)
+                  {
+                      lx_extension const &x = ext[a], &y = ext[b];
+                      return x.q_off != y.q_off ? x.q_off < y.q_off : x.q_len != y.q_len ? x.q_len < y.q_len : a < b;
+                  });
+    auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
+    // where the runs of one query slice begin in the ordered list
+    std::vector<uint8_t> & newrun = h->xb_newrun;
+    newrun.resize(live + 1);
+    parallel_ranges(live, nthreads,
+                    [&](unsigned, uint64_t lo, uint64_t hi)
+                    {
+                        for (uint64_t k = lo; k < hi; ++k)
+                            newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
+                    });
+    newrun[live] = 1;
+    // Mixed query lengths (a real seed list; the synthetic batches have one): a chunk runs the kernel geometry of its longest
+    // query, so runs are dealt to geometry classes first -- one panel of 152 columns, one of 208, two / three / ... panels of
+    // 152 -- and every class goes through the pipeline by itself.  Inside a run the windows are ordered by length (merged
+    // windows are up to 3 x longer: src/search_algo.hpp:1153-1157), so that a wavefront's 16 windows take about as many steps
+    // each -- the reason the reference sorts its SIMD batches (:1229-1235).  Results are scattered by original index anyway.
+    {
+        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
+        uint32_t cmin = ~0u, cmax = 0;
+        bool     ragged_s = false;
+        for (uint64_t k = 0; k < live; ++k)
+        {
+            if (newrun[k])
+            {
+                uint32_t const c = qclass(ext[idx[k]].q_len);
+                cmin = std::min(cmin, c);
+                cmax = std::max(cmax, c);
+            }
+            else if (ext[idx[k]].s_len != ext[idx[k - 1]].s_len)
+                ragged_s = true;
+        }
+        static bool const no_classes = getenv("LX_EXTEND_NO_CLASSES") != nullptr, no_sort = getenv("LX_EXTEND_NO_SORT") != nullptr; // A/B aids
+        if (cmin != cmax && !no_classes)
+        {
+            std::vector<uint64_t> at(cmax + 2, 0);
+            for (uint64_t k = 0; k < live;)
+            {
+                uint64_t kk = k + 1;
+                while (!newrun[kk])
+                    ++kk;
+                at[qclass(ext[idx[k]].q_len) + 1] += kk - k;
+                k = kk;
+            }
+            for (uint32_t c = 0; c <= cmax; ++c)
+                at[c + 1] += at[c];
+            std::vector<uint32_t> & idx2 = h->xb_src;
+            idx2.resize(live);
+            for (uint64_t k = 0; k < live;)
+            {
+                uint64_t kk = k + 1;
+                while (!newrun[kk])
+                    ++kk;
+                uint64_t & o = at[qclass(ext[idx[k]].q_len)];
+                std::copy(idx.begin() + k, idx.begin() + kk, idx2.begin() + o);
+                o += kk - k;
+                k = kk;
+            }
+            idx.swap(idx2);
+            parallel_ranges(live, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t k = lo; k < hi; ++k)
+                                    newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
+                            });
+        }
+        if (ragged_s && !no_sort)
+        {
+            std::vector<uint64_t> starts;
+            for (uint64_t k = 0; k <= live; ++k)
+                if (newrun[k])
+                    starts.push_back(k);
+            parallel_ranges(starts.size() - 1, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t r = lo; r < hi; ++r)
+                                    std::sort(idx.begin() + starts[r], idx.begin() + starts[r + 1],
+                                              [&](uint32_t a, uint32_t b) { return ext[a].s_len != ext[b].s_len ? ext[a].s_len < ext[b].s_len : a < b; });
+                            });
+        }
+    }
+    hm.mark("validate");
+
+    // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
+    struct Guard
+    {
+        lx_handle * h;
+        uint64_t    qlen, slen, run;
+        ~Guard()
+        {
+            (void)hipStreamSynchronize(h->stream);
+            (void)hipStreamSynchronize(h->stream2);
+            (void)hipStreamSynchronize(h->stream3);
+            h->opt_max_qlen  = qlen;
+            h->opt_max_slen  = slen;
+            h->opt_query_run = run;
+        }
+    } const guard{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run};
+
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)))
+        return rc;
+    if (q_bytes)
+        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+
+    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : []() -> uint64_t
+    {
+        static uint64_t const v = []() -> uint64_t
+        {
+            char const * e = getenv("LX_EXTEND_CHUNK"); // development aid
+            return e ? (uint64_t)std::max(1024ll, atoll(e)) : 640ull << 10;
+        }();
+        return v;
+    }();
+    h->ext_bytes.clear();
+    uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
+    double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0, t_u1 = 0, t_u2 = 0; // LX_HOST_TIMING: where the host's time goes
+    h->xb_stats[0] = live;
+    h->xb_stats[1] = h->xb_stats[2] = h->xb_stats[3] = 0; // slots, cells, cells the wavefronts execute
+    auto     now    = []() { return std::chrono::steady_clock::now(); };
+    auto     ms     = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b)
+    { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    XbPrep   prep[2];
+    bool     in_flight[2] = {false, false};
+
+    // ---- chunk k0 .. k1 of the ordered list -> padded slots in lane L's pinned staging -> uploads and kernels queued
+    auto enqueue = [&](int L, uint64_t k0, uint64_t k1) -> int
+    {
+        auto const          t0 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        pr.k0 = k0;
+        pr.k1 = k1;
+        // runs of one query slice; padded to 16 slots (one query per wavefront of the 8-lane packed geometry) or, when the
+        // queries have few windows each, to 8 (one query per half wavefront: ~1.4 x the time per slot) -- whichever is less work
+        std::vector<uint64_t> & grp = h->xb_grp; // (first position, first slot) of every run + a sentinel
+        grp.clear();
+        uint64_t slots16 = 0, slots8 = 0, max_q = 1, max_s = 1;
+        for (uint64_t k = k0; k < k1;)
+        {
+            uint64_t kk = k + 1;
+            while (kk < k1 && !newrun[kk])
+                ++kk;
+            grp.push_back(k);
+            grp.push_back(0);
+            slots16 += (kk - k + 15) / 16 * 16;
+            slots8 += (kk - k + 7) / 8 * 8;
+            max_q = std::max<uint64_t>(max_q, ext[idx[k]].q_len);
+            k     = kk;
+        }
+        grp.push_back(k1);
+        grp.push_back(0);
+        uint64_t const ngroups = grp.size() / 2 - 1;
+        uint64_t const kRun    = (slots8 * 7 < slots16 * 5) ? 8 : 16;
+        uint64_t       slots   = 0;
+        for (uint64_t g = 0; g <= ngroups; ++g)
+        {
+            grp[2 * g + 1] = slots;
+            if (g < ngroups)
+                slots += (grp[2 * g + 2] - grp[2 * g] + kRun - 1) / kRun * kRun;
+        }
+        pr.slots   = slots;
+        pr.cap_sel = (slots + slots / kRun * 3 + 7) / 8 * 8 + 8;
+        pr.slot_src.resize(slots);
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_ext, slots * sizeof(lx_extension))) || (rc2 = ensure_pinned(h, ln.p_min, slots * sizeof(int32_t))))
+            return rc2;
+        lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
+        int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
+        uint32_t * const     slot_src = pr.slot_src.data();
+        std::vector<uint64_t> tmax(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
+        // (what the wavefronts will execute: every block of kRun slots runs all columns of its panels for as many steps as
+        // its longest window has rows)
+        uint64_t const panel = max_q <= 104 ? 104 : max_q <= 152 ? 152 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
+        parallel_ranges(ngroups, nthreads,
+                        [&](unsigned t, uint64_t glo, uint64_t ghi)
+                        {
+                            uint64_t ms = 1, cells = 0, padded = 0; // (locals: the per-thread slots share cache lines)
+                            for (uint64_t g = glo; g < ghi; ++g)
+                            {
+                                uint64_t const a = grp[2 * g], b = grp[2 * g + 2], o1 = grp[2 * g + 3];
+                                uint64_t       o = grp[2 * g + 1];
+                                uint64_t const cols = (ext[idx[a]].q_len + panel - 1) / panel * panel;
+                                for (uint64_t j0 = a; j0 < b; j0 += kRun)
+                                {
+                                    uint64_t bmax = 0;
+                                    for (uint64_t j = j0; j < std::min(b, j0 + kRun); ++j)
+                                    {
+                                        bmax = std::max<uint64_t>(bmax, ext[idx[j]].s_len);
+                                        cells += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
+                                    }
+                                    padded += kRun * cols * (bmax + lanes - 1);
+                                }
+                                for (uint64_t j = a; j < b; ++j, ++o)
+                                {
+                                    slot_ext[o] = ext[idx[j]];
+                                    slot_src[o] = idx[j];
+                                    slot_min[o] = min_score ? min_score[idx[j]] : min_score_all;
+                                    ms          = std::max<uint64_t>(ms, ext[idx[j]].s_len);
+                                }
+                                lx_extension dummy = ext[idx[a]];
+                                dummy.s_len        = 0;
+                                for (; o < o1; ++o)
+                                {
+                                    slot_ext[o] = dummy;
+                                    slot_src[o] = 0xffffffffu;
+                                    slot_min[o] = 0x7fffffff; // never survives
+                                }
+                            }
+                            tmax[t]   = std::max(tmax[t], ms);
+                            tcells[t] = cells;
+                            tpad[t]   = padded;
+                        });
+        for (uint64_t v : tmax)
+            max_s = std::max(max_s, v);
+        h->xb_stats[1] += slots;
+        for (unsigned t = 0; t < nthreads; ++t)
+        {
+            h->xb_stats[2] += tcells[t];
+            h->xb_stats[3] += tpad[t];
+        }
+        auto const t1 = now();
+        t_prep += ms(t0, t1);
+        // device side of the lane
+        uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
+        if ((rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
+            (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) ||
+            (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) ||
+            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) ||
+            (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_score, slots * sizeof(int32_t))) || (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+            return rc2;
+        LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipMemcpyAsync(ln.d_min.ptr, slot_min, slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+        h->opt_max_qlen  = max_q;
+        h->opt_max_slen  = max_s;
+        h->opt_query_run = kRun;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
+        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                              nullptr, d_cnt, h->stream, 3, true, &fx)))
+            return rc2;
+        LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
+        // what has a size the host knows goes back at once; records and codes follow when the counts have arrived
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipMemcpyAsync(ln.p_score.ptr, ln.d_score.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
+        in_flight[L] = true;
+        t_issue += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- results of the chunk in lane L -> the caller's arrays
+    auto collect = [&](int L) -> int
+    {
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        in_flight[L]           = false;
+        auto const t0          = now();
+        LX_HIP(h, hipEventSynchronize(ln.ev_cnt));
+        uint64_t const * const cnt = static_cast<uint64_t const *>(ln.p_cnt.ptr);
+        uint64_t const count = cnt[0], nrle = cnt[2];
+        if (count > pr.cap_sel)
+            return fail(h, LX_ESTATE, "survivor list longer than its capacity");
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
+            (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) ||
+            (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
+            return rc2;
+        // (on the upload stream: stream2 already holds the next chunk's first-stage copies, which wait for its kernels)
+        if (count)
+        {
+            LX_HIP(h, hipMemcpyAsync(ln.p_hsp.ptr, ln.d_hsp.ptr, count * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_src.ptr, ln.d_src.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_len.ptr, ln.d_len.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            if (nrle)
+                LX_HIP(h, hipMemcpyAsync(ln.p_rle.ptr, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
+        }
+        LX_HIP(h, hipStreamSynchronize(h->stream3));
+        auto const t1 = now();
+        t_wait += ms(t0, t1);
+        int32_t const * const  sc      = static_cast<int32_t const *>(ln.p_score.ptr);
+        lx_hsp const * const   hs      = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
+        uint32_t const * const sel_src = static_cast<uint32_t const *>(ln.p_src.ptr);
+        uint8_t const * const  codes   = static_cast<uint8_t const *>(ln.p_rle.ptr);
+        uint32_t const * const code_len = static_cast<uint32_t const *>(ln.p_len.ptr);
+        uint32_t const * const slot_src = pr.slot_src.data();
+        // (1) per survivor: how many bytes its ops take in the handle's buffer (column bytes, or the codes themselves),
+        //     and which list position a slot has
+        std::vector<uint64_t> & pos_off  = h->xb_off;
+        std::vector<uint32_t> & slot_pos = h->xb_pos;
+        pos_off.resize(count + 1);
+        slot_pos.resize(pr.slots);
+        parallel_ranges(pr.slots, nthreads,
+                        [&](unsigned, uint64_t lo, uint64_t hi) { std::fill(slot_pos.begin() + lo, slot_pos.begin() + hi, 0xffffffffu); });
+        std::vector<uint64_t> part(nthreads + 1, 0);
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t sum = 0;
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t len = 0;
+                                if (sel_src[e] != 0xffffffffu)
+                                {
+                                    slot_pos[sel_src[e]] = (uint32_t)e;
+                                    if (hs[e].score > 0)
+                                        len = want_rle ? (uint64_t)code_len[e] : (uint64_t)hs[e].n_ops;
+                                }
+                                pos_off[e] = len;
+                                sum += len;
+                            }
+                            part[t + 1] = sum;
+                        });
+        auto const tu1 = now();
+        t_u1 += ms(t1, tu1);
+        // (2) offsets: prefix over the threads' shares, then inside each share
+        part[0] = ops_total;
+        for (unsigned t = 0; t < nthreads; ++t)
+            part[t + 1] += part[t];
+        uint64_t const total = part[nthreads];
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t at = part[t];
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t const len = pos_off[e];
+                                pos_off[e]         = at;
+                                at += len;
+                            }
+                        });
+        pos_off[count] = total;
+        h->ext_bytes.grow(total + 16);
+        uint8_t * const dst = h->ext_bytes.data();
+        t_u2 += ms(tu1, now());
+        // (3) one pass over the chunk's slots: score and record of every extension, the survivors' ops
+        std::vector<uint64_t> untraced(nthreads, ~0ull);
+        parallel_ranges(pr.slots, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            for (uint64_t o = lo; o < hi; ++o)
+                            {
+                                uint32_t const orig = slot_src[o];
+                                if (orig == 0xffffffffu)
+                                    continue;
+                                out_score[orig]  = sc[o];
+                                uint32_t const e = slot_pos[o];
+                                if (e == 0xffffffffu)
+                                {
+                                    lx_hsp r{};
+                                    r.score           = sc[o];
+                                    out_hsp[orig]     = r;
+                                    out_ops_off[orig] = 0;
+                                    continue;
+                                }
+                                lx_hsp r = hs[e];
+                                if (r.score < 0)
+                                {
+                                    untraced[t] = std::min<uint64_t>(untraced[t], orig);
+                                    continue;
+                                }
+                                uint8_t const * const c = codes + (uint32_t)r.ops_shift;
+                                if (r.score > 0 && want_rle)
+                                    std::memcpy(dst + pos_off[e], c, (size_t)(pos_off[e + 1] - pos_off[e]));
+                                else if (r.score > 0)
+                                    rle_expand(c, r.n_ops, dst + pos_off[e]);
+                                r.ops_shift       = 0;
+                                out_hsp[orig]     = r;
+                                out_ops_off[orig] = pos_off[e];
+                            }
+                        });
+        for (uint64_t u : untraced)
+            if (u != ~0ull)
+                return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
+        ops_total = total;
+        t_unpack += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- the pipeline: prepare + queue chunk c, then unpack chunk c - 1 while c runs
+    uint64_t k0 = 0;
+    int      c  = 0;
+    while (k0 < live)
+    {
+        uint64_t k1 = std::min<uint64_t>(live, k0 + chunk_target);
+        while (k1 < live && !newrun[k1]) // never cut a query's run
+            ++k1;
+        {
+            // ... and never mix geometry classes (the list is class-major): cut where the class changes
+            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
+            uint32_t const c0 = qclass(ext[idx[k0]].q_len);
+            if (!getenv("LX_EXTEND_NO_CLASSES") && qclass(ext[idx[k1 - 1]].q_len) != c0)
+            {
+                uint64_t lo = k0, hi = k1 - 1; // first position of another class: the classes ascend
+                while (hi - lo > 1)
+                {
+                    uint64_t const mid = lo + (hi - lo) / 2;
+                    (qclass(ext[idx[mid]].q_len) == c0 ? lo : hi) = mid;
+                }
+                k1 = hi;
+                while (k1 > k0 + 1 && !newrun[k1])
+                    --k1;
+            }
+        }
+        int const L = c & 1;
+        if (in_flight[L] && (rc = collect(L)))
+            return rc;
+        if ((rc = enqueue(L, k0, k1)))
+            return rc;
+        if (in_flight[L ^ 1] && (rc = collect(L ^ 1)))
+            return rc;
+        k0 = k1;
+        ++c;
+    }
+    for (int L : {c & 1, (c & 1) ^ 1})
+        if (in_flight[L] && (rc = collect(L)))
+            return rc;
+    if ((rc = check_async_error(h)))
+        return rc;
+    hm.mark("pipeline");
+    if (hm.on)
+        fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f (lengths %.1f, offsets %.1f)\n", c, t_prep, t_issue,
+                t_wait, t_unpack, t_u1, t_u2);
+    *out_ops       = h->ext_bytes.data();
+    *out_ops_bytes = ops_total;
+    return LX_OK;
+}
+
+int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                    lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                    lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (out_ops)
+        *out_ops = nullptr;
+    if (out_ops_bytes)
+        *out_ops_bytes = 0;
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || !out_hsp || !out_ops_off || !out_ops || !out_ops_bytes || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    if (h->opt_band)
+        return host_banded(h, slot, 2, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, min_score, min_score_all, out_score, out_hsp, nullptr,
+                           nullptr, out_ops_off, out_ops, out_ops_bytes);
+    return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
+                           out_ops_bytes, false);
+}
+
+int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                        lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                        lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (out_ops)
+        *out_ops = nullptr;
+    if (out_ops_bytes)
+        *out_ops_bytes = 0;
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || !out_hsp || !out_ops_off || !out_ops || !out_ops_bytes || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    if (h->opt_band)
+        return fail(h, LX_EINVAL, "lx_extend_batch_rle: band mode returns column bytes only (lx_extend_batch)");
+    return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
+                           out_ops_bytes, true);
+}
+
+int lx_last_extend_stats(lx_handle const * h, uint64_t * out4)
+{
+    if (!h || !out4)
+        return LX_EINVAL;
+    std::memcpy(out4, h->xb_stats, sizeof(h->xb_stats));
+    return LX_OK;
+}
+
+int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out)
+{
+    if (!codes || !out || n_ops < 0)
+        return LX_EINVAL;
+    rle_expand(codes, n_ops, out);
+    return LX_OK;
+}
+
+// ---- pre-extension filter --------------------------------------------------------------------------------
+
+int lx_prefilter_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,
+                       uint64_t s_bytes, lx_seed const * seeds, uint64_t n, uint32_t seed_length, int32_t pre_scoring,
+                       double pre_scoring_thresh, uint8_t * out_keep)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n == 0)
+        return LX_OK;
+    if (!seeds || !out_keep || !q_res)
+        return fail(h, LX_EINVAL, "NULL argument");
+    SubjectRef sref;
+    {
+        int const rc0 = bind(h);
+        if (rc0)
+            return rc0;
+        int const rc1 = resolve_subjects(h, s_res, s_bytes, sref);
+        if (rc1)
+            return rc1;
+        s_bytes = sref.bytes;
+    }
+    static_assert(sizeof(lx_seed) == sizeof(lx::PrefilterSeed), "ABI mismatch");
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        lx_seed const & x = seeds[i];
+        if (!lx_slice_ok(x.q_off, x.q_len, q_bytes) || !lx_slice_ok(x.s_off, x.s_len, s_bytes) || x.qry_end < x.qry_start || x.qry_end > x.q_len ||
+            (uint64_t)x.subj_start + (x.qry_end - x.qry_start) > x.s_len)
+            return fail(h, LX_EINVAL, "seed %llu out of range", (unsigned long long)i);
+    }
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)) || (rc = ensure(h, h->d_seeds, n * sizeof(lx_seed))) || (rc = ensure(h, h->d_keep, n)))
+        return rc;
+    LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (sref.upload)
+        LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(h->d_seeds.ptr, seeds, n * sizeof(lx_seed), hipMemcpyHostToDevice, h->stream));
+    lx::PrefilterParams p{};
+    p.q_res              = static_cast<uint8_t const *>(h->d_q.ptr);
+    p.s_res              = static_cast<uint8_t const *>(sref.dev);
+    p.seeds              = static_cast<lx::PrefilterSeed const *>(h->d_seeds.ptr);
+    p.n                  = n;
+    p.sc                 = h->sc_dev[slot];
+    p.seed_length        = seed_length;
+    p.pre_scoring        = pre_scoring;
+    p.pre_scoring_thresh = pre_scoring_thresh;
+    p.out_keep           = static_cast<uint8_t *>(h->d_keep.ptr);
+    LX_HIP(h, hipEventRecord(h->ev0, h->stream));
+    LX_HIP(h, lx::launch_prefilter(p, h->stream));
+    LX_HIP(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    LX_HIP(h, hipMemcpyAsync(out_keep, h->d_keep.ptr, n, hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+    return LX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,369 @@
+// lx_internal.h -- what lx_api.cpp (handle, options, device entry points, the fused step) and lx_host.cpp (the host-buffer
+// entry points and their pipelines) share: the handle, the launchers of the kernel files, small host helpers.  Not part of
+// the ABI; include/lambda_ext.h is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include <sched.h>
+
+#include "../../include/lambda_ext.h"
+#include "host/scoring_tables.hpp"
+#include "lx_device.h"
+
+
+namespace lx
+{
+hipError_t launch_score(int cfg, ScoreParams const & p, bool multi, hipStream_t stream);
+int        score_cfg_panel(int cfg);
+int        score_cfg_groups(int cfg);
+int        score_cfg_count();
+hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream);
+int        score_pair_cfg_for(uint32_t max_qlen);
+uint64_t   select_blocks(uint64_t nruns);
+int        score_pair_cfg_cols(int cfg);
+int        score_pair_cfg_for_runs_of_8(uint32_t max_qlen);
+int        score_pair_cfg_group(int cfg);
+size_t     score_pair_profile_bytes(int cfg, int nrows);
+hipError_t launch_trace_forward(TraceParams const & p, hipStream_t stream);
+hipError_t launch_backtrace(TraceParams const & p, hipStream_t stream);
+hipError_t launch_max_lens(Extension const * ext, uint64_t n, MaxLens * out, hipStream_t stream);
+int        trace_cfg_panel(int cfg);
+int        trace_cfg_group(int cfg);
+int        trace_cfg_words(int cfg);
+hipError_t launch_select(SelectParams const & p, hipStream_t stream);
+uint64_t   ckpt_slot_dwords(int cfg, uint32_t steps_cap);
+uint64_t   ckpt16_slot_dwords(int cfg, uint32_t steps_cap);
+hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
+hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
+hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t stream);
+hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream);
+hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hipStream_t stream);
+hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
+hipError_t launch_rle_pack(PackParams const & p, hipStream_t stream);
+} // namespace lx
+
+namespace lxi
+{
+
+struct DevBuf
+{
+    void * ptr = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace lxi
+using lxi::DevBuf;
+
+struct lx_handle
+{
+    int         device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev0 = nullptr, ev1 = nullptr;
+    hipStream_t stream2 = nullptr;                       // backtrace of chunk k overlaps the forward kernel of chunk k+1
+    hipEvent_t  evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evS = nullptr;
+    bool        timed = false;
+    std::string error;
+    // lx_extend_batch: host staging that keeps its pages between calls
+    std::vector<uint32_t>     xb_idx, xb_src, xb_sel, xb_pos;
+    std::vector<uint8_t>      xb_newrun;
+    uint64_t                  xb_stats[4] = {0, 0, 0, 0}; // lx_extend_batch: extensions, slots, cells, cells executed (padding included)
+    std::vector<uint64_t>     xb_grp, xb_off;
+    std::vector<lx_extension> xb_ext;
+    std::vector<int32_t>      xb_min, xb_score;
+    std::vector<uint8_t> ext_ops; // band mode: the ops of the last lx_extend_batch call (handed out by pointer)
+    // lx_extend_batch: the ops of the last call, grown without touching what is already there
+    struct Bytes
+    {
+        uint8_t * p   = nullptr;
+        size_t    cap = 0;
+        uint8_t * data() { return p; }
+        void      clear() {}
+        void      grow(size_t bytes)
+        {
+            if (bytes <= cap)
+                return;
+            size_t const want = std::max(bytes + bytes / 2, (size_t)1 << 20);
+            p                 = static_cast<uint8_t *>(std::realloc(p, want));
+            cap               = p ? want : 0;
+        }
+        ~Bytes() { std::free(p); }
+    } ext_bytes;
+    // lx_extend_batch's two chunks in flight: pinned staging, device buffers, events
+    struct Pinned
+    {
+        void * ptr = nullptr;
+        size_t cap = 0;
+    };
+    struct XbLane
+    {
+        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len;
+        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len;
+        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
+    } xb[2];
+    hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
+    std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
+    std::string last_trace_kernel;
+    // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
+    struct PhaseEv
+    {
+        int        phase;
+        hipEvent_t a, b;
+    };
+    std::vector<PhaseEv>    phase_ev;      // events recorded by the last call
+    std::vector<hipEvent_t> ev_pool;       // reusable timing events
+    size_t                  ev_pool_used = 0;
+
+    bool             have_sc[2] = {false, false};
+    bool             trace_ok[2] = {false, false};
+    lx_scoring       sc_host[2];
+    lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
+
+    // staging for the host-buffer entry points
+    DevBuf d_q, d_s, d_ext, d_out, d_ops, d_opsoff, d_keep, d_trace, d_ends, d_hsp, d_seeds, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_db;
+    // multi-panel carry workspace
+    DevBuf     d_ws;
+    uint32_t * d_ws_top = nullptr; // [0] = bump pointer, [1] = error flag, [2..3] = MaxLens, [4] = overflow checkpoint slots handed out, [5] = backtrace work queue
+    // options
+    uint64_t opt_max_qlen  = 0;
+    uint64_t opt_query_run = 0;
+    uint64_t opt_ws_bytes  = 64ull << 20; // the caller's LX_OPT_WORKSPACE_BYTES
+    uint64_t ws_grown      = 0;           // what the calls grew the workspace to by themselves (never shown to the caller)
+    uint64_t opt_max_slen  = 0;
+    uint64_t opt_trace_bytes = 64ull << 30;
+    uint64_t opt_bs_rule   = 0;
+    uint64_t opt_f16       = 1;
+    uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
+    uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
+    int32_t const * band_dev = nullptr;  // lx_set_band_centres_dev: the caller's device array for the *_dev calls
+    std::vector<int32_t> band_host;      // lx_set_band_centres: centres of the next host-buffer call's extensions
+    DevBuf   d_band;                     // ... uploaded
+    uint64_t opt_pass2     = 2; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip), 2 = single sweep; each where applicable
+    uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
+    bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
+};
+
+namespace lxi
+{
+
+int        fail(lx_handle * h, int code, char const * fmt, ...);
+hipEvent_t pool_event(lx_handle * h);
+
+// Wall-clock marks of the host-buffer entry points, printed when LX_HOST_TIMING is set (development aid).
+struct HostMarks
+{
+    bool                                                               on;
+    char const *                                                       what;
+    std::chrono::steady_clock::time_point                              t0, last;
+    std::string                                                        line;
+    explicit HostMarks(char const * w) : on(std::getenv("LX_HOST_TIMING") != nullptr), what(w)
+    {
+        t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(char const * name)
+    {
+        if (!on)
+            return;
+        auto const now = std::chrono::steady_clock::now();
+        char       buf[96];
+        snprintf(buf, sizeof(buf), " %s %.1f", name, std::chrono::duration<double, std::milli>(now - last).count());
+        line += buf;
+        last = now;
+    }
+    ~HostMarks()
+    {
+        if (on)
+            fprintf(stderr, "[lx host ms] %s:%s | total %.1f\n", what, line.c_str(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+// RAII-less phase bracket: records a start event now, the end event on close()
+struct PhaseTimer
+{
+    lx_handle * h;
+    hipStream_t s;
+    int         phase;
+    hipEvent_t  a = nullptr, b = nullptr;
+    PhaseTimer(lx_handle * h_, hipStream_t s_, int phase_) : h(h_), s(s_), phase(phase_)
+    {
+        if (h->phase_ev.size() < 64)
+        {
+            a = pool_event(h);
+            b = pool_event(h);
+            if (a && b)
+                (void)hipEventRecord(a, s);
+        }
+    }
+    void close()
+    {
+        if (a && b)
+        {
+            (void)hipEventRecord(b, s);
+            h->phase_ev.push_back({phase, a, b});
+        }
+    }
+};
+
+#define LX_HIP(h, call)                                                                                         \
+    do                                                                                                          \
+    {                                                                                                           \
+        hipError_t _e = (call);                                                                                 \
+        if (_e != hipSuccess)                                                                                   \
+            return fail((h), _e == hipErrorOutOfMemory ? LX_ENOMEM : LX_EHIP, "%s failed: %s", #call,           \
+                        hipGetErrorString(_e));                                                                 \
+    } while (0)
+
+int    ensure(lx_handle * h, DevBuf & b, size_t bytes);
+int    bind(lx_handle * h);
+size_t pair_lds_limit();
+int    pick_cfg(uint32_t qlen, bool shared);
+int    ckpt_cfg_for(uint64_t max_q, bool packed16 = false);
+int    check_async_error(lx_handle * h);
+int    launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n, void * d_out, int cfg,
+                         bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0);
+int    prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint = 0);
+
+// padding of q/s staging buffers so that clamped / prefetching loads never leave the allocation
+constexpr size_t kSlack = 256;
+constexpr int kPair16    = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
+constexpr int kPair16Bin = 7;   // its bin among the packed geometries of lx_score_batch
+
+// Subject side of a host-buffer call: either the caller's buffer, uploaded into d_s, or -- s_res == NULL, s_bytes == 0
+// after lx_set_subjects -- the resident copy.
+struct SubjectRef
+{
+    void *   dev   = nullptr;
+    uint64_t bytes = 0;
+    bool     upload = false;
+};
+
+int resolve_subjects(lx_handle * h, uint8_t const * s_res, uint64_t s_bytes, SubjectRef & out);
+
+// lx_extend_batch's additions to the fused step: ops slots of one size instead of an offset per extension, the survivors'
+// ops run-length packed into a dense stream (lx_pack.hip), a copy of the survivor list's original indices
+struct FusedExtra
+{
+    uint64_t             ops_stride = 0;
+    uint8_t *            d_rle      = nullptr;
+    unsigned long long * d_rle_top  = nullptr;
+    uint64_t             rle_cap    = 0;
+    uint32_t *           d_src_out  = nullptr; // [survivor list capacity]
+    uint32_t *           d_rle_len  = nullptr; // [survivor list capacity]: code bytes per position
+};
+
+int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, lx::Extension const * d_ext, uint64_t n, lx::Hsp * d_hsp,
+                   uint8_t * d_ops, uint64_t const * d_ops_off, hipStream_t stream, uint64_t max_q, uint64_t max_s, int share_slots,
+                   uint32_t const * d_src = nullptr, uint64_t const * d_count = nullptr, int32_t const * d_score_in = nullptr,
+                   bool by_pos = false, uint64_t ops_stride = 0);
+int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext, uint64_t n, void const * d_min_score,
+               int32_t min_score_all, void * d_out_score, void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count,
+               void * stream_, int phases, bool by_pos, FusedExtra const * fx = nullptr);
+
+unsigned host_threads(uint64_t n);
+
+// [off, off + len) inside a buffer of `bytes`, written so that offsets near 2^64 cannot wrap past the test
+inline bool lx_slice_ok(uint64_t off, uint64_t len, uint64_t bytes)
+{
+    return len <= bytes && off <= bytes - len;
+}
+
+
+// A few persistent host threads (started on first use): the per-extension loops of the host-buffer entry points are spread
+// over them; spawning threads per loop would cost more than the loops of a pipeline chunk.
+class HostPool
+{
+    std::vector<std::thread>       workers_;
+    std::mutex                     m_;
+    std::condition_variable        cv_, done_;
+    std::function<void(unsigned)>  job_;
+    unsigned                       want_ = 0, gen_ = 0, running_ = 0;
+    bool                           stop_ = false;
+
+    void loop(unsigned id)
+    {
+        unsigned seen = 0;
+        for (;;)
+        {
+            std::function<void(unsigned)> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && id < want_); });
+                if (stop_)
+                    return;
+                seen = gen_;
+                job  = job_;
+            }
+            job(id);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--running_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+
+public:
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread & t : workers_)
+            t.join();
+    }
+    // runs f(1) .. f(nthreads - 1) on the workers and f(0) on the caller; returns when all are done
+    void run(unsigned nthreads, std::function<void(unsigned)> f)
+    {
+        static std::mutex           callers; // one parallel loop at a time (handles on several host threads share the pool)
+        std::lock_guard<std::mutex> one(callers);
+        while (workers_.size() + 1 < nthreads)
+        {
+            unsigned const id = (unsigned)workers_.size() + 1;
+            workers_.emplace_back([this, id] { loop(id); });
+        }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_     = f;
+            want_    = nthreads;
+            running_ = nthreads - 1;
+            ++gen_;
+        }
+        cv_.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return running_ == 0; });
+    }
+};
+HostPool & host_pool();
+
+template <typename F>
+inline void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
+{
+    if (nthreads <= 1 || n < 2 * (uint64_t)nthreads)
+    {
+        for (unsigned t = 0; t < nthreads; ++t) // keep the per-thread slots of the callers meaningful
+            body(t, t == 0 ? 0 : n, n);
+        return;
+    }
+    uint64_t const step = (n + nthreads - 1) / nthreads;
+    host_pool().run(nthreads, [&body, step, n](unsigned t) { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
+}
+
+
+} // namespace lxi
