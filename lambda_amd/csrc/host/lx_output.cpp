@@ -129,14 +129,15 @@ uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_mat
             ++hi;
         ++st.qrys_with_hit; // :826
         std::vector<lx_blast_match> rec(m + lo, m + hi);
-        // sort matches, using an inverted bitScore to have the highest score first (:832-853)
+        // order by subject, coordinates and frames; among equal keys the better bit score comes first (b and a swapped in the
+        // last tie component), so that std::unique below keeps it (:832-853)
         std::stable_sort(rec.begin(), rec.end(),
                          [](lx_blast_match const & a, lx_blast_match const & b)
                          {
                              return std::tie(a.n_sid, a.q_start, a.q_end, a.s_start, a.s_end, a.q_frame, a.s_frame, b.bit_score) <
                                     std::tie(b.n_sid, b.q_start, b.q_end, b.s_start, b.s_end, b.q_frame, b.s_frame, a.bit_score);
                          });
-        // removes duplicates and keeping the ones with the greatest score (:856-862)
+        // one record per (subject, coordinates, frames): the first of each group survives (:856-862)
         auto const before = rec.size();
         rec.erase(std::unique(rec.begin(), rec.end(),
                               [](lx_blast_match const & a, lx_blast_match const & b)
@@ -146,10 +147,10 @@ uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_mat
                               }),
                   rec.end());
         st.hits_duplicate2 += before - rec.size();
-        // sort by evalue before writing (:865) -- std::list::sort is stable
+        // output order: best bit score (= smallest e-value) first; stable like the reference's list sort (:865)
         std::stable_sort(rec.begin(), rec.end(),
                          [](lx_blast_match const & a, lx_blast_match const & b) { return a.bit_score > b.bit_score; });
-        // cutoff abundant (:867-872)
+        // at most max_matches records per query, the rest is counted (:867-872)
         if (rec.size() > max_matches)
         {
             st.hits_abundant += rec.size() - max_matches;

@@ -1,0 +1,36 @@
+// lx_aids.h -- development aids: the environment switches of the library, read ONCE per process (first use) in one place
+// (lx::dev_aids() in lx_api.cpp).  None of them is part of the ABI and none changes results: they pick between bit-identical
+// kernels / schedules for A/B measurements (tools/), or print host timings.  Options a caller is meant to
+// set go through lx_set_option (include/lambda_ext.h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace lx
+{
+
+struct DevAids
+{
+    // variable                 meaning                                                                      default
+    size_t   pair_lds_limit;    // LX_PAIR_LDS_LIMIT     LDS a wavefront of the packed-half kernel may spend on profiles   24 KiB
+    int      force_score_cfg;   // LX_FORCE_SCORE_CFG    pass-1 geometry for every list (-1 = pick by query width)         -1
+    int      force_ckpt_cfg;    // LX_FORCE_CKPT_CFG     checkpoint geometry 1 = (8,19), 2 = (16,13) (0 = pick)            0
+    bool     trace_overlap;     // LX_TRACE_OVERLAP=1    mode-0 pass 2: forward of chunk k+1 beside the backtrace of k     off
+    uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1
+    bool     no_narrow_sweep;   // LX_NO_NARROW_SWEEP    keep (8,19) for queries <= 104 columns instead of (8,13)          off
+    bool     sweep_int;         // LX_SWEEP_INT          compact sweep in the integer domain instead of packed half        off
+    bool     no_i16_sweep;      // LX_NO_I16_SWEEP       wide queries: int32 sweep instead of the packed 16-bit one        off
+    int      pass2_mode;        // LX_PASS2_MODE         initial value of LX_OPT_PASS2_MODE (-1 = the library's default)   -1
+    unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 8)           0
+    bool     extend_no_classes; // LX_EXTEND_NO_CLASSES  lx_extend_batch: no geometry-class binning of ragged lists        off
+    bool     extend_no_sort;    // LX_EXTEND_NO_SORT     lx_extend_batch: no in-run sort by window length                  off
+    uint64_t extend_chunk;      // LX_EXTEND_CHUNK       default of LX_OPT_EXTEND_CHUNK (extensions per pipeline chunk)    640 Ki
+    int      bt_waves_per_cu;   // LX_BT_WAVES_PER_CU    persistent wavefronts of the backtrace per CU                     12
+    int      bt_tile_at;        // LX_BT_TILE_AT         lanes waiting for a tile that start the tile phase (0 = default)  0
+    int      bt_refill_at;      // LX_BT_REFILL_AT       retired lanes that trigger a queue refill (0 = default)           0
+    bool     host_timing;       // LX_HOST_TIMING        print where the host-buffer entry points spend their time         off
+};
+
+DevAids const & dev_aids();
+
+} // namespace lx

@@ -17,6 +17,40 @@ namespace
 thread_local std::string g_create_error;
 }
 
+// every environment switch of the library (lx_aids.h has the table)
+lx::DevAids const & lx::dev_aids()
+{
+    static DevAids const aids = []()
+    {
+        auto num = [](char const * name, long long dflt) -> long long
+        {
+            char const * e = getenv(name);
+            return e && *e ? atoll(e) : dflt;
+        };
+        auto set = [](char const * name) { return getenv(name) != nullptr; };
+        DevAids a{};
+        a.pair_lds_limit    = (size_t)num("LX_PAIR_LDS_LIMIT", 24 * 1024);
+        a.force_score_cfg   = (int)num("LX_FORCE_SCORE_CFG", -1);
+        a.force_ckpt_cfg    = (int)num("LX_FORCE_CKPT_CFG", 0);
+        a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
+        a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
+        a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
+        a.sweep_int         = set("LX_SWEEP_INT");
+        a.no_i16_sweep      = set("LX_NO_I16_SWEEP");
+        a.pass2_mode        = set("LX_PASS2_MODE") ? (int)std::min(std::max(num("LX_PASS2_MODE", 2), 0ll), 2ll) : -1;
+        a.host_threads      = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
+        a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
+        a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
+        a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
+        a.bt_waves_per_cu   = (int)std::max(1ll, num("LX_BT_WAVES_PER_CU", 12));
+        a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);
+        a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
+        a.host_timing       = set("LX_HOST_TIMING");
+        return a;
+    }();
+    return aids;
+}
+
 namespace lxi
 {
 
@@ -76,23 +110,15 @@ int bind(lx_handle * h)
 // Smallest panel that holds the query; 8-lane geometries need one shared profile per wavefront (8 profile slots
 // per wavefront would not fit the LDS budget), so without sharing only the 16/32/64-lane geometries are used.
 // LDS a wavefront of the packed-half kernel may spend on two query profiles (one per half wavefront: query runs of 8)
+// (24 KiB; protein profiles too: 12.8 vs 14.0 ms (pass 1), 16.6 vs 19.1 ms (sweep) for runs of 8)
 size_t pair_lds_limit()
 {
-    static size_t const v = []() -> size_t
-    {
-        char const * e = getenv("LX_PAIR_LDS_LIMIT"); // development aid
-        return e ? (size_t)atoll(e) : (size_t)24 * 1024; // protein profiles too: 12.8 vs 14.0 ms (pass 1), 16.6 vs 19.1 ms (sweep) for runs of 8
-    }();
-    return v;
+    return lx::dev_aids().pair_lds_limit;
 }
 
 int pick_cfg(uint32_t qlen, bool shared)
 {
-    static int const forced = []() // development aid: measure a geometry on a shape it is not picked for
-    {
-        char const * e = getenv("LX_FORCE_SCORE_CFG");
-        return e ? atoi(e) : -1;
-    }();
+    int const forced = lx::dev_aids().force_score_cfg; // development aid: measure a geometry on a shape it is not picked for
     if (forced >= 0)
         return forced;
     if (shared)
@@ -148,11 +174,7 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
         return 1;
     if (max_q <= p2)
         return 2;
-    static int const forced = []() // development aid
-    {
-        char const * e = getenv("LX_FORCE_CKPT_CFG");
-        return e ? atoi(e) : 0;
-    }();
+    int const forced = lx::dev_aids().force_ckpt_cfg; // development aid
     if (forced == 1 || forced == 2)
         return forced;
     // (the packed 16-bit sweep is bound by its checkpoint bytes: the 19-column strips of (8,19) store fewer boundary
@@ -344,10 +366,10 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
     // Without the overlap one buffer is enough, so a chunk may use the whole budget: as few launches (and kernel
     // tails) as the budget allows.  In the fused path `n` is the capacity of the survivor list; launches beyond the
     // device-side count exit at once.
-    bool const     overlap     = getenv("LX_TRACE_OVERLAP") && atoi(getenv("LX_TRACE_OVERLAP")) != 0;
+    bool const     overlap     = lx::dev_aids().trace_overlap;
     uint64_t const nbuf        = overlap ? 2 : 1;
     uint64_t       chunk       = std::max<uint64_t>(1, h->opt_trace_bytes / nbuf / std::max<uint64_t>(per_ext, 1));
-    uint64_t const want_chunks = getenv("LX_TRACE_CHUNKS") ? (uint64_t)atoi(getenv("LX_TRACE_CHUNKS")) : 1;
+    uint64_t const want_chunks = lx::dev_aids().trace_chunks;
     chunk                      = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
     hipStream_t const bstream  = overlap ? h->stream2 : stream;
     chunk                      = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
@@ -507,7 +529,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         // short queries (<= 104 columns, e.g. 100-residue reads): the (8,13) geometry where the packed-half sweep applies --
         // a third fewer padded columns than (8,19)
         bool const half_ok = h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
-        static bool const no_narrow = getenv("LX_NO_NARROW_SWEEP") != nullptr; // A/B aid
+        bool const no_narrow = lx::dev_aids().no_narrow_sweep; // A/B aid
         if (sweep_cfg == 1 && half_ok && !no_narrow && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(3) &&
             (h->opt_query_run % 16 == 0 || 2 * lx::score_pair_profile_bytes(1, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit()))
             sweep_cfg = 3;
@@ -608,7 +630,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
-            static bool const int_sweep = getenv("LX_SWEEP_INT") != nullptr; // A/B: the compact sweep in the integer domain
+            bool const int_sweep = lx::dev_aids().sweep_int; // A/B: the compact sweep in the integer domain
             if (int_sweep && sweep_share == 0)
                 LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
             else
@@ -618,7 +640,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16
         // kernel writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range
         // test is left to the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
-        bool const i16_sweep = !half_sweep && h->opt_f16 && !getenv("LX_NO_I16_SWEEP") &&
+        bool const i16_sweep = !half_sweep && h->opt_f16 && !lx::dev_aids().no_i16_sweep &&
                                h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0 && sweep_cfg != 3;
         if (i16_sweep)
         {
@@ -823,8 +845,8 @@ int lx_create(int device_id, lx_handle ** out)
                     prop.gcnArchName);
 
     lx_handle * h = new lx_handle();
-    if (char const * m = getenv("LX_PASS2_MODE")) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
-        h->opt_pass2 = (uint64_t)std::min(std::max(atoi(m), 0), 2);
+    if (lx::dev_aids().pass2_mode >= 0) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
+        h->opt_pass2 = (uint64_t)lx::dev_aids().pass2_mode;
     h->device     = device_id;
     auto bail     = [&](char const * what, hipError_t err)
     {

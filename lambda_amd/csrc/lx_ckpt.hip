@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include "lx_aids.h"
 #include "lx_dp_common.h"
 
 namespace lx
@@ -1346,8 +1347,7 @@ static int backtrace_resident_waves()
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        char const * e = getenv("LX_BT_WAVES_PER_CU"); // development aid
-        return std::max(1, cus) * (e ? std::max(1, atoi(e)) : 12);
+        return std::max(1, cus) * dev_aids().bt_waves_per_cu;
     }();
     return v;
 }
@@ -1360,9 +1360,8 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
         return hipErrorInvalidValue;
     TraceParams p = p_in;
     {
-        static int const ta = getenv("LX_BT_TILE_AT") ? atoi(getenv("LX_BT_TILE_AT")) : 0, ra = getenv("LX_BT_REFILL_AT") ? atoi(getenv("LX_BT_REFILL_AT")) : 0; // development aid
-        p.bt_tile_at   = ta;
-        p.bt_refill_at = ra;
+        p.bt_tile_at   = dev_aids().bt_tile_at; // development aids
+        p.bt_refill_at = dev_aids().bt_refill_at;
     }
     // persistent lanes: as many wavefronts as the chip holds at this kernel's occupancy (3 per SIMD), each taking
     // extensions from the queue until it is empty

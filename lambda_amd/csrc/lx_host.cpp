@@ -15,8 +15,8 @@ unsigned lxi::host_threads(uint64_t n)
         cpu_set_t set;
         CPU_ZERO(&set);
         unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
-        if (char const * e = getenv("LX_HOST_THREADS"))
-            c = (unsigned)std::max(1, atoi(e));
+        if (lx::dev_aids().host_threads)
+            c = lx::dev_aids().host_threads;
         return std::max(1u, std::min(c, 8u));
     }();
     return avail;
@@ -801,7 +801,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             else if (ext[idx[k]].s_len != ext[idx[k - 1]].s_len)
                 ragged_s = true;
         }
-        static bool const no_classes = getenv("LX_EXTEND_NO_CLASSES") != nullptr, no_sort = getenv("LX_EXTEND_NO_SORT") != nullptr; // A/B aids
+        bool const no_classes = lx::dev_aids().extend_no_classes, no_sort = lx::dev_aids().extend_no_sort; // A/B aids
         if (cmin != cmax && !no_classes)
         {
             std::vector<uint64_t> at(cmax + 2, 0);
@@ -875,15 +875,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     if (sref.upload)
         LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
 
-    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : []() -> uint64_t
-    {
-        static uint64_t const v = []() -> uint64_t
-        {
-            char const * e = getenv("LX_EXTEND_CHUNK"); // development aid
-            return e ? (uint64_t)std::max(1024ll, atoll(e)) : 640ull << 10;
-        }();
-        return v;
-    }();
+    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
     h->ext_bytes.clear();
     uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
     double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0, t_u1 = 0, t_u2 = 0; // LX_HOST_TIMING: where the host's time goes
@@ -1171,7 +1163,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // ... and never mix geometry classes (the list is class-major): cut where the class changes
             auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
             uint32_t const c0 = qclass(ext[idx[k0]].q_len);
-            if (!getenv("LX_EXTEND_NO_CLASSES") && qclass(ext[idx[k1 - 1]].q_len) != c0)
+            if (!lx::dev_aids().extend_no_classes && qclass(ext[idx[k1 - 1]].q_len) != c0)
             {
                 uint64_t lo = k0, hi = k1 - 1; // first position of another class: the classes ascend
                 while (hi - lo > 1)

@@ -22,6 +22,7 @@
 
 #include "../../include/lambda_ext.h"
 #include "host/scoring_tables.hpp"
+#include "lx_aids.h"
 #include "lx_device.h"
 
 
@@ -169,7 +170,7 @@ struct HostMarks
     char const *                                                       what;
     std::chrono::steady_clock::time_point                              t0, last;
     std::string                                                        line;
-    explicit HostMarks(char const * w) : on(std::getenv("LX_HOST_TIMING") != nullptr), what(w)
+    explicit HostMarks(char const * w) : on(lx::dev_aids().host_timing), what(w)
     {
         t0 = last = std::chrono::steady_clock::now();
     }
