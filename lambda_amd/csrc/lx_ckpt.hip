@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
 
     // ---- state of the extension this lane is working on
-    bool             have = false, blocked = false, done = false, need_col = false, c16 = false;
+    bool             have = false, blocked = false, done = false, need_col = false, scan = false, c16 = false;
     uint64_t         po = 0;          // where the extension's record and ops slot are
     uint64_t         pos = 0;         // its position in the list
     EndCell          ec{};
@@ -701,76 +701,20 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         i                  = ec.s_end - 1;
         j                  = ec.q_end - 1;
         // single-sweep mode: only the strip of the end cell is known (ec.q_end = -(strip + 1)).  The column is read off the
-        // first tile (its last computed row is the end row); if the strip reached the best score in several rows, a plain
-        // re-run of the strip from the checkpoint above the first such row finds the cell the tie rule wants first.
+        // first tile (its last computed rows hold the end row), unless the strip reached the best score in ...
         need_col = ec.q_end < 0;
         if (need_col)
         {
             int const st = -ec.q_end - 1;
             j            = st * C + (C - 1); // provisional: the whole strip is computed
-            if (ec.flags & kEndAmbiguous)
+            // ... several rows: the tile phases scan the strip from the step block of the first such row to its end
+            // (scan mode: one block per phase, in step with the tiles of the other lanes), keeping the lowest column
+            // and, for it, the lowest row
+            scan = (ec.flags & kEndAmbiguous) != 0;
+            if (scan)
             {
-                int const go1 = p.sc->go;
-                int const gl  = st % G, gL = (st - 1 + G) % G; // lanes of this strip and of its left neighbour
-                int const m0  = (i + gl) / kCkptEvery;
-                int       Hp[C], F[C];
-                if (m0 == 0)
-                {
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                        Hp[c] = F[c] = 0;
-                }
-                else
-                {
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                    {
-                        uint32_t const w = rowck_word((uint32_t)(m0 - 1), (uint32_t)st, (uint32_t)c);
-                        Hp[c]            = dec(w & 0xffffu);
-                        F[c]             = dec(w >> 16);
-                    }
-                }
-                int qr[C];
-#pragma unroll
-                for (int c = 0; c < C; ++c)
-                    qr[c] = (st * C + c < lq) ? (int)(q[st * C + c] & (kAlph - 1)) * kAlph : (kAlph - 1) * kAlph;
-                int const target = ec.score;
-                int       kcol = C, krow = i;
-                for (int r = max(m0 * kCkptEvery - gl, 0); r < ls; ++r)
-                {
-                    int const tl = s[r] & (kAlph - 1);
-                    int       E  = kFar, Hd = 0;
-                    if (st > 0)
-                    {
-                        E = dec(bnd_word_of((uint32_t)(st - 1), (uint32_t)(r + gL)) >> 16);
-                        if (r > 0)
-                            Hd = dec(bnd_word_of((uint32_t)(st - 1), (uint32_t)(r + gL - 1)) & 0xffffu);
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c)
-                    {
-                        int const v  = ((int)smat4[qr[c] + tl] - 3) >> 2;
-                        int const tt = Hd + v;
-                        Hd           = Hp[c];
-                        int const H  = max3i(tt, E, F[c]);
-                        int const A  = H + go1;
-                        F[c]         = max3i(F[c] + ge, A, 0);
-                        E            = max(E + ge, A);
-                        Hp[c]        = H;
-                        if (H == target && c < kcol) // lowest column wins; rows ascend, so its first hit is its lowest row
-                        {
-                            kcol = c;
-                            krow = r;
-                        }
-                    }
-                }
-                if (kcol < C)
-                {
-                    i        = krow;
-                    j        = st * C + kcol;
-                    need_col = false;
-                }
-                // (kcol == C cannot happen: the forward pass saw the score in this strip; the tile path below then flags it)
+                int const gl = st % G;
+                i            = min(((i + gl) / kCkptEvery) * kCkptEvery - gl + kCkptEvery - 1, ls - 1);
             }
         }
         end_i = i; // final once need_col is false
@@ -1210,7 +1154,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
-                if (need_col && row >= i - 3 && row < ls)
+                if (need_col && (scan || row >= i - 3) && row < ls)
                 {
                     // lowest column of this row whose H equals the score (no H exceeds it: H - score <= 0, a multiple of 4
                     // after the tags are masked), as a maximum of keys without compares: key = (H - score) * 32 + (C - c)
@@ -1230,17 +1174,25 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         }
 
         bool walk_ok = true;
-        if (need_col)
+        if (scan && r_base + kCkptEvery < ls)
+        {
+            // scan mode, rows left below this block: the next phase takes the next block
+            i       = min(r_base + 2 * kCkptEvery - 1, ls - 1);
+            walk_ok = false;
+        }
+        else if (need_col)
         {
             // the end row is one of the last four computed rows (the packed-half sweep reports the chunk, the int32 sweep
-            // the exact row -- earlier rows of the strip then do not carry the score): lowest column, then lowest row
+            // the exact row -- earlier rows of the strip then do not carry the score), or one of those scanned: lowest
+            // column, then lowest row.  From the end cell the walk starts like anywhere else: with a diagonal shortcut.
             need_col = false;
+            scan     = false;
+            walk_ok  = false;
             if (res_col >= C)
             {
                 done     = true; // the forward pass saw this score in these rows of the strip: never guess
                 left     = -1;
                 ec.score = -1;
-                walk_ok  = false;
             }
             else
             {
@@ -1254,7 +1206,11 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         // alignment's first cell), everything else is arithmetic on the nibble -- bit 3 / bit 2 = the vertical /
         // horizontal gap state extends, low two bits = where H came from (3 diagonal, 2 vertical, 1 horizontal).
         static_assert(32 - 4 * (C - 8 * (kNibDw - 1)) >= 5, "the last nibble word needs 5 spare bits for the subject letter");
-        while (walk_ok && i >= 0 && j >= j0 && i >= r_base && n < cap)
+        // The walk takes the lane through what the shortcut cannot: up to and through the next gap.  Back in state H
+        // with a gap behind it, the rest of the tile is the shortcut's again (1/4 of the instructions per column, and the
+        // lockstep of the wavefront pays the longest walk of its lanes).
+        bool passed = false;
+        while (walk_ok && i >= 0 && j >= j0 && i >= r_base && n < cap && !(passed && mode == 0))
         {
             int const      kk   = i - r_base, c = j - j0;
             int const      xw   = c >> 3;
@@ -1289,6 +1245,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             gx += cont ? 1 : 0;
             left -= diag ? v : ge; // a gap character -- continued or first -- costs ge here, the opening surcharge when it ends
             mode = diag ? 0 : (vert ? 1 : 2);
+            passed = passed || !diag;
             emit(diag ? (uint32_t)'M' : (vert ? (uint32_t)'D' : (uint32_t)'I'));
             i -= (diag || vert) ? 1 : 0;
             j -= (diag || !vert) ? 1 : 0;
