@@ -42,7 +42,7 @@ lx::DevAids const & lx::dev_aids()
         a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
-        a.bt_waves_per_cu   = (int)std::max(1ll, num("LX_BT_WAVES_PER_CU", 12));
+        a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
         a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);
         a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
         a.host_timing       = set("LX_HOST_TIMING");

@@ -43,7 +43,13 @@ constexpr int kCkptEvery = LX_CKPT_EVERY;
 #define LX_CKPT_UNROLL_N(n) LX_CKPT_PRAGMA(unroll n)
 #define LX_CKPT_UNROLL_PRAGMA LX_CKPT_UNROLL_N(LX_CKPT_UNROLL)
 #ifndef LX_BT_TILE_AT
-#define LX_BT_TILE_AT 48   // backtrace: lanes waiting for a tile that trigger a tile phase
+#define LX_BT_TILE_AT 40   // backtrace: lanes waiting for a tile that trigger a tile phase
+#endif
+#ifndef LX_BT_WAVES
+#define LX_BT_WAVES 2      // backtrace: wavefronts per SIMD the register budget is set for (2: 256 VGPRs, no spills)
+#endif
+#ifndef LX_BT_HOPS
+#define LX_BT_HOPS 2       // backtrace: tile borders a diagonal shortcut pass may cross
 #endif
 #ifndef LX_BT_REFILL_AT
 #define LX_BT_REFILL_AT 12 // backtrace: finished / empty lanes that trigger a refill outside a tile phase
@@ -545,13 +551,19 @@ LX_CKPT_UNROLL_PRAGMA
 //       x 4, the two low bits resolve the traceback ties) in its plain, un-skewed form:
 //           tt = 4 H(i-1,j-1) + (4 s + 3);  m = max3(tt, E|1, F|2);  H = m & ~3;  A = H + 4 go;
 //           Fr = max3(F + 4 ge, A, 0), F' = Fr | 2;  Er = max(E + 4 ge, A), E' = Er | 1;  nibble = tag(m) | (Fr|Er)&3 << 2
-//       nibbles in LDS, walked until the walk leaves the tile.  Needed for the first tile of a single-sweep extension
-//       (its end column is still open), for tiles with gaps, and while the walk is inside a gap.
-// Per outer iteration: shortcut phase (lanes run diagonals until blocked or finished) -> finished lanes are retired and
-// refilled -> one tile phase for every lane that needs it (new extensions start with one).  On the headline batch an
-// alignment crosses ~17 tiles and has ~3 gaps: ~5 tile phases per extension instead of 17-18.
+//       nibbles in LDS.  Needed for the first tile of a single-sweep extension (its end column is still open: the tile
+//       yields the end cell, the walk then starts like anywhere else), for tiles with gaps, and while the walk is inside a
+//       gap.  In such a tile the walk takes the leading diagonal steps in one go (the nibbles say how many; same routine
+//       as the shortcut, without the border test), then single steps through the gap, and hands back to (1) as soon as
+//       it is in state H again.
+// Per outer iteration: shortcut pass (every lane that can crosses up to LX_BT_HOPS tile borders; the border words and
+// residues of all hops are requested together, one round trip to memory) -> finished lanes are retired and refilled -> one
+// tile phase for every lane that needs it (new extensions start with one).  On the headline batch an alignment crosses ~17
+// tiles and has ~3 gaps: 3.7 tile phases per extension instead of 17-18.
+// What bounds the kernel (r02 profile): ~2/3 VALU issue, the rest memory latency of the scattered border-word reads that
+// only more resident wavefronts hide -- 8 per CU (256 VGPRs, no spills) beat 11 with the ~10 spilled dwords 168 VGPRs cost.
 template <int G, int C>
-__global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
+__global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TraceParams p)
 {
     using Lay               = CkptLayout<G, C>;
     using L16               = Ckpt16Layout<G, C>;
@@ -559,13 +571,13 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
     constexpr int kFar      = -(1 << 28);  // "minus infinity" that survives a few additions (multiple of 4)
     static_assert(kCkptEvery == 16, "the diagonal shortcut reads at most 16 residues per sequence");
     __shared__ int8_t   smat4[kAlph * kAlph]; // 4 s + 3: diagonal step of the tile DP with its tag (the walk divides it back)
-    __shared__ int8_t   smat1[kAlph * kAlph]; // s itself, for the diagonal shortcut
+    __shared__ int8_t   smat1n[kAlph * kAlph]; // -s for the diagonal runs; the pair (31, 31) -- rank 31 is the reserved pad rank -- scores 0 there
     __shared__ uint32_t tiles[kCkptEvery * kNibDw * 64]; // [tile row][word][lane]: lane-minor, conflict-free
     for (int x = threadIdx.x; x < kAlph * kAlph; x += blockDim.x)
     {
         int const v = p.sc->mat[x];
         smat4[x]    = (int8_t)((v < -32 || v > 31) ? -125 : 4 * v + 3); // pad ranks (and entries pass 2 does not admit) far down
-        smat1[x]    = (int8_t)v;
+        smat1n[x]   = (int8_t)(x == kAlph * kAlph - 1 ? 0 : min(-v, 127));
     }
     __syncthreads();
     uint32_t const lane  = threadIdx.x;
@@ -794,7 +806,137 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         have          = false;
     };
 
-    // Scheduling of the wavefront: a shortcut pass costs ~1/15 of a tile phase, so shortcuts run while enough lanes can use
+
+    // ---- k cells up the diagonal from (i, j) in state H, 1 <= k <= 16: the walk takes them if the piece is the traceback's
+    // path -- verify: L after k cells equals Hb, the stored H of the cell beyond (see above); !verify: the caller knows
+    // (direction nibbles of a tile) -- or up to the cell whose H is 0 (L == 0: the alignment begins after it).  Returns
+    // false, and changes nothing, if the piece is not the path.
+    // residues of the k cells up the diagonal from (ci, cj): q[cj - k + 1 .. cj], s[ci - k + 1 .. ci] = bytes 0 .. k - 1 of
+    // the dwords (256 bytes of slack behind the buffers)
+    auto load_diagonal = [&](int ci, int cj, int k, uint32_t (&qw)[4], uint32_t (&sw)[4])
+    {
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            qw[d] = *reinterpret_cast<unaligned_u32 const *>(q + (cj - k + 1) + 4 * d);
+            sw[d] = *reinterpret_cast<unaligned_u32 const *>(s + (ci - k + 1) + 4 * d);
+        }
+    };
+    auto take_diagonal = [&](int k, int Hb, bool verify, uint32_t (&qw)[4], uint32_t (&sw)[4]) -> bool
+    {
+        // bytes >= k of the pieces become the pair (31, 31), which scores 0 in smat1n
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+        {
+            int const      nb  = k - 4 * d; // bytes of this dword inside the piece
+            uint32_t const pad = nb >= 4 ? 0u : (nb <= 0 ? 0x1f1f1f1fu : (0x1f1f1f1fu << (8 * nb)));
+            qw[d]              = (qw[d] & 0x1f1f1f1fu) | pad;
+            sw[d]              = (sw[d] & 0x1f1f1f1fu) | pad;
+        }
+        // One pass over the 16 byte positions, the cells beyond the piece first (they score 0 and change nothing but the
+        // count), then the entry cell, then up the diagonal: P = sum of the scores taken so far, frozen once the cell at
+        // hand has H = 0 (L = left - P <= 0).  Per cell: index, LDS read, compare, carry, select, subtract, shift.
+        int      P = 0, cnt = 0;
+        uint32_t posbits = 0;
+        int32_t  tmb = 0;
+        bool const bs = p.bs_match_rule != 0; // (uniform)
+#pragma unroll
+        for (int u = kCkptEvery - 1; u >= 0; --u) // cell (i - t, j - t) is byte u = k - 1 - t
+        {
+            int const      d   = u >> 2, b = u & 3;
+            uint32_t const idx = (((qw[d] >> (8 * b)) & 0x1fu) << 5) | ((sw[d] >> (8 * b)) & 0x1fu);
+            int const      nv  = (int)smat1n[idx];
+            bool const     take = P < left;
+            int const      nve = take ? nv : 0;
+            cnt += take ? 1 : 0;
+            P -= nve;
+            posbits = __builtin_amdgcn_alignbit(posbits, (uint32_t)nve, 31); // bit = the score taken is positive
+            if (bs) // the bisulfite overload of computeAlignmentStats: a match scores what the letter scores with itself
+                tmb += (take && nv == (int)smat1n[(idx >> 5) * (kAlph + 1)]) ? 1 : 0;
+        }
+        int const beyond = left > 0 ? kCkptEvery - k : 0; // cells beyond the piece that were counted
+        cnt -= beyond;
+        tmb -= bs ? beyond : 0;
+        int const  L       = left - P;
+        bool const stopped = cnt < k;
+        // L < 0 cannot happen (L_t >= H >= 0); were it to, the piece is left to the tile DP, never guessed
+        if (!(stopped ? (L == 0) : (!verify || L == Hb)))
+            return false;
+        // identical letters among the cnt cells taken = bytes [k - cnt, k) of the two pieces: zero bytes of the XOR,
+        // counted four at a time
+        int32_t tm = tmb;
+        if (!bs)
+        {
+            int const lo = k - cnt;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+            {
+                uint32_t const x   = qw[d] ^ sw[d];
+                uint32_t const nz  = (x + 0x7f7f7f7fu) & 0x80808080u;  // bit 7 of every non-zero byte (bytes < 0x80)
+                int const      b0  = max(lo - 4 * d, 0), b1 = min(k - 4 * d, 4); // bytes [b0, b1) of this dword count
+                uint32_t const msk = b1 > b0 ? ((b1 >= 4 ? 0xffffffffu : ((1u << (8 * b1)) - 1u)) & ~((1u << (8 * b0)) - 1u)) : 0u;
+                tm += __popc(~nz & 0x80808080u & msk);
+            }
+        }
+        left = L;
+        nm += tm;
+        nx += cnt - tm;
+        np += __popc(posbits);
+        if (rle_mode) // cnt columns 'M' extend the current run (codes of at most 64 columns)
+        {
+            int left_m = cnt;
+            while (left_m > 0)
+            {
+                if (run_op != 0 || run_len == 64)
+                {
+                    if (run_op != 3)
+                    {
+                        put_byte((run_op << 6) | (run_len - 1));
+                        ++ncodes;
+                    }
+                    run_op  = 0;
+                    run_len = 0;
+                }
+                int const take = min(left_m, 64 - (int)run_len);
+                run_len += (uint32_t)take;
+                left_m -= take;
+            }
+        }
+        else if (cnt > 0) // cnt bytes 'M' below apos: at most five dwords, the lowest one may stay open in acc
+        {
+            uint32_t const hi = apos, lo = apos + 1 - (uint32_t)cnt, Dtop = hi & ~3u, Dlow = lo & ~3u;
+#pragma unroll
+            for (int sl = 0; sl < 5; ++sl)
+            {
+                uint32_t const D = Dtop - 4u * sl;
+                if (Dtop >= 4u * sl && D >= Dlow)
+                {
+                    uint32_t const b0  = lo > D ? lo - D : 0, b1 = sl == 0 ? hi - D : 3u; // bytes b0 .. b1 of dword D
+                    uint32_t const msk = (b1 >= 3 ? 0xffffffffu : ((1u << (8 * (b1 + 1))) - 1u)) & ~((1u << (8 * b0)) - 1u);
+                    uint32_t const val = (sl == 0 ? acc : 0u) | (0x4d4d4d4du & msk);
+                    if (lo <= D) // byte 0 of the dword written: the dword is complete
+                    {
+                        if (sl != 0 || D + 3 <= a0 + cap - 1)
+                            *reinterpret_cast<uint32_t *>(ops_al + D) = val;
+                        else
+                            for (uint32_t bb = 0; bb < 4 && D + bb <= a0 + cap - 1; ++bb)
+                                ops_al[D + bb] = (uint8_t)(val >> (8 * bb));
+                        acc = 0;
+                    }
+                    else
+                        acc = val;
+                }
+            }
+            apos -= (uint32_t)cnt;
+        }
+        n += (uint32_t)cnt;
+        i -= cnt;
+        j -= cnt;
+        done = stopped;
+        return true;
+    };
+
+    // Scheduling of the wavefront: a shortcut pass costs ~1/8 of a tile phase, so shortcuts run while enough lanes can use
     // them; a tile phase runs when LX_BT_TILE_AT lanes wait for one (or nobody can do anything else), right after the
     // finished lanes have been retired and refilled (a new extension starts with a tile).
     bool queue_empty = false; // wave-uniform
@@ -871,130 +1013,41 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 
         if (!run_tile)
         {
-            // ================= (1) one diagonal shortcut for every lane that can take one
+            // ================= (1) diagonal shortcuts for every lane that can take them: up to LX_BT_HOPS tile borders in
+            // one pass.  Where the hops end is geometry alone (the diagonal through (i, j)), so the border words and the
+            // residues of all of them are requested at once -- one round trip to memory for the lot; hop h + 1 counts only if
+            // hop h reached its border.
             if (can)
             {
-                int const st = j / C, j0 = st * C, c = j - j0;
-                int const gl = st % G;
-                int const m  = (i + gl) / kCkptEvery;
-                int const r_base = m * kCkptEvery - gl;       // row of tile row 0
-                int const kt = i - r_base + 1, kl = c + 1;    // diagonal steps to the row above the tile / the column left of it
-                int const k  = min(min(kt, kl), i + 1);       // 1 .. 16; never above the matrix (block 0 has virtual rows)
-                int const bi = i - k, bj = j - k;             // the border cell
-                int       Hb = 0;                             // (beyond the matrix: H = 0)
-                if (bi >= 0 && bj >= 0)
-                {
-                    uint32_t const w = (kl <= kt) ? bnd_word_of((uint32_t)(st - 1), (uint32_t)(bi + (st - 1) % G))
-                                                  : rowck_word((uint32_t)(m - 1), (uint32_t)st, (uint32_t)(bj - j0));
-                    Hb               = dec(w & 0xffffu);
-                }
-                // the residues of the diagonal piece: q[j - k + 1 .. j], s[i - k + 1 .. i] (256 bytes of slack behind the buffers)
-                uint32_t qw[4], sw[4];
+                int      hk[LX_BT_HOPS];
+                uint32_t hw[LX_BT_HOPS], hqw[LX_BT_HOPS][4], hsw[LX_BT_HOPS][4];
+                int      ci = i, cj = j;
 #pragma unroll
-                for (int d = 0; d < 4; ++d)
+                for (int h = 0; h < LX_BT_HOPS; ++h)
                 {
-                    qw[d] = *reinterpret_cast<unaligned_u32 const *>(q + (j - k + 1) + 4 * d);
-                    sw[d] = *reinterpret_cast<unaligned_u32 const *>(s + (i - k + 1) + 4 * d);
+                    bool const on = ci >= 0 && cj >= 0;
+                    int const ai = max(ci, 0), aj = max(cj, 0);
+                    int const st = aj / C, j0 = st * C, c = aj - j0;
+                    int const gl = st % G;
+                    int const m  = (ai + gl) / kCkptEvery;
+                    int const r_base = m * kCkptEvery - gl;       // row of tile row 0
+                    int const kt = ai - r_base + 1, kl = c + 1;   // diagonal steps to the row above the tile / the column left of it
+                    int const k  = min(min(kt, kl), ai + 1);      // 1 .. 16; never above the matrix (block 0 has virtual rows)
+                    int const bi = ai - k, bj = aj - k;           // the border cell
+                    hk[h] = on ? k : 0;
+                    hw[h] = 0;                                    // (beyond the matrix: H = 0)
+                    if (on && bi >= 0 && bj >= 0)
+                        hw[h] = (kl <= kt) ? bnd_word_of((uint32_t)(st - 1), (uint32_t)(bi + (st - 1) % G))
+                                           : rowck_word((uint32_t)(m - 1), (uint32_t)st, (uint32_t)(bj - j0));
+                    load_diagonal(ai, aj, k, hqw[h], hsw[h]);
+                    ci -= k;
+                    cj -= k;
                 }
-                // One pass over the (at most 16) cells, entry cell first: L = H the diagonal piece implies for the cell
-                // at hand.  `stopped` = some cell before this one had L == 0 (the alignment begins after that cell).
-                // Everything per cell is a compare feeding a carry or a select: no branches, few VALU slots.
-                int      L = left, cnt = 0;
-                int32_t  tp = 0, tmb = 0;
-                bool     stopped = false;
-                bool const bs = p.bs_match_rule != 0; // (uniform)
 #pragma unroll
-                for (int u = kCkptEvery - 1; u >= 0; --u) // cell (i - t, j - t) is byte u = k - 1 - t of the pieces
-                {
-                    uint32_t const c0 = (qw[u >> 2] >> (8 * (u & 3))) & (kAlph - 1), c1 = (sw[u >> 2] >> (8 * (u & 3))) & (kAlph - 1);
-                    int const      v  = (int)smat1[c0 * kAlph + c1];
-                    bool const     in = u < k;
-                    stopped           = stopped || (in && L <= 0); // H of this cell is 0
-                    bool const take   = in && !stopped;
-                    L -= take ? v : 0;
-                    cnt += take ? 1 : 0;
-                    tp += (take && v > 0) ? 1 : 0;
-                    if (bs) // the bisulfite overload of computeAlignmentStats: a match scores what the letter scores with itself
-                        tmb += (take && v == (int)smat1[c0 * kAlph + c0]) ? 1 : 0;
-                }
-                // L < 0 cannot happen (L_t >= H >= 0); were it to, the piece is left to the tile DP, never guessed
-                bool const ok = stopped ? (L == 0) : (L == Hb);
-                if (ok)
-                {
-                    // identical letters among the cnt cells taken = bytes [k - cnt, k) of the two pieces (ranks < 32 by
-                    // contract; masked like everywhere else): zero bytes of the XOR, counted four at a time
-                    int32_t tm = tmb;
-                    if (!bs)
-                    {
-                        int const lo = k - cnt;
-#pragma unroll
-                        for (int d = 0; d < 4; ++d)
-                        {
-                            uint32_t const x   = (qw[d] ^ sw[d]) & 0x1f1f1f1fu;
-                            uint32_t const nz  = (x + 0x7f7f7f7fu) & 0x80808080u;  // bit 7 of every non-zero byte (bytes < 0x80)
-                            int const      b0  = max(lo - 4 * d, 0), b1 = min(k - 4 * d, 4); // bytes [b0, b1) of this dword count
-                            uint32_t const msk = b1 > b0 ? ((b1 >= 4 ? 0xffffffffu : ((1u << (8 * b1)) - 1u)) & ~((1u << (8 * b0)) - 1u)) : 0u;
-                            tm += __popc(~nz & 0x80808080u & msk);
-                        }
-                    }
-                    left = L;
-                    nm += tm;
-                    nx += cnt - tm;
-                    np += tp;
-                    // cnt columns 'M': run-length mode extends the current run (codes of at most 64 columns)
-                    if (rle_mode)
-                    {
-                        int left_m = cnt;
-                        while (left_m > 0)
-                        {
-                            if (run_op != 0 || run_len == 64)
-                            {
-                                if (run_op != 3)
-                                {
-                                    put_byte((run_op << 6) | (run_len - 1));
-                                    ++ncodes;
-                                }
-                                run_op  = 0;
-                                run_len = 0;
-                            }
-                            int const take = min(left_m, 64 - (int)run_len);
-                            run_len += (uint32_t)take;
-                            left_m -= take;
-                        }
-                        n += (uint32_t)cnt;
-                    }
-                    else // cnt bytes 'M' below apos, whole dwords at a time
-                    {
-                        uint32_t const hi = apos, lo = apos + 1 - (uint32_t)cnt; // byte positions [lo, hi] (cnt >= 1 here or skipped)
-                        if (cnt > 0)
-                        {
-                            for (uint32_t D = hi & ~3u;; D -= 4)
-                            {
-                                uint32_t const b0  = lo > D ? lo - D : 0, b1 = min(hi - D, 3u);   // bytes b0 .. b1 of dword D
-                                uint32_t const msk = (b1 >= 3 ? 0xffffffffu : ((1u << (8 * (b1 + 1))) - 1u)) & ~((1u << (8 * b0)) - 1u);
-                                acc |= 0x4d4d4d4du & msk;
-                                if (b0 == 0 && lo <= D) // byte 0 of the dword written: the dword is complete
-                                {
-                                    if (D + 3 <= a0 + cap - 1)
-                                        *reinterpret_cast<uint32_t *>(ops_al + D) = acc;
-                                    else
-                                        for (uint32_t b = 0; b < 4 && D + b <= a0 + cap - 1; ++b)
-                                            ops_al[D + b] = (uint8_t)(acc >> (8 * b));
-                                    acc = 0;
-                                }
-                                if (D <= lo || D < 4)
-                                    break;
-                            }
-                            apos -= (uint32_t)cnt;
-                            n += (uint32_t)cnt;
-                        }
-                    }
-                    i -= cnt;
-                    j -= cnt;
-                    done = stopped;
-                }
-                else
-                    blocked = true;
+                for (int h = 0; h < LX_BT_HOPS; ++h)
+                    if (hk[h] > 0 && !blocked && !done)
+                        if (!take_diagonal(hk[h], dec(hw[h] & 0xffffu), true, hqw[h], hsw[h]))
+                            blocked = true;
             }
             continue;
         }
@@ -1059,8 +1112,8 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             }
         }
         // LDS offsets of the matrix rows of this strip's query residues (columns beyond the query use the pad rank)
-        uint32_t qoff[C];
-        uint32_t qd[(C + 3) / 4]; // the strip's query residues: the walk picks its column's letter from these
+        uint32_t qoff2[(C + 1) / 2]; // two columns per register (the offsets are < 1024): the DP is the register peak of the kernel
+        uint32_t qd[(C + 3) / 4];    // the strip's query residues: the walk picks its column's letter from these
         {
 #pragma unroll
             for (int d = 0; d < (C + 3) / 4; ++d)
@@ -1069,7 +1122,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
             for (int c = 0; c < C; ++c)
             {
                 uint32_t const r = (j0 + c < lq) ? ((qd[c >> 2] >> (8 * (c & 3))) & (kAlph - 1)) : (uint32_t)(kAlph - 1);
-                qoff[c]          = r * kAlph;
+                qoff2[c >> 1]    = (c & 1) ? (qoff2[c >> 1] | ((r * kAlph) << 16)) : r * kAlph;
             }
         }
         // left edge: the boundary words of strip st - 1 for the steps k_base - 2 ... (word of step k - 1 holds E for
@@ -1096,32 +1149,32 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         int const qd0   = k_base / 4; // quad that holds step k_base
         uint4     qprev = load_bq(qd0 - 1), qcur = load_bq(qd0);
 
-        bool rows_left = true;
+        // The rows are computed without a branch per lane: rows below the lane's cell (row > i) yield values nobody reads
+        // (the walk starts at i, the end-cell search below stops there), virtual rows of block 0 (row < 0) see the pad
+        // letter and no left neighbour, which leaves H = 0 and F at its floor.  The loop ends when no lane has rows left.
+        uint32_t snext = *reinterpret_cast<unaligned_u32 const *>(s + max(r_base, 0));
 #pragma unroll 1
-        for (int t = 0; t < kCkptEvery / 4 && rows_left; ++t)
+        for (int t = 0; t < kCkptEvery / 4; ++t)
         {
+            if (__ballot(r_base + 4 * t <= i) == 0)
+                break;
             uint4 const qnext = load_bq(qd0 + t + 1); // needed by the next iteration
-            // subject letters of the 4 rows r_base + 4t ... (rows < 0 are virtual and skipped)
+            // subject letters of the 4 rows r_base + 4t ... (rows < 0 are virtual and skipped), loaded one iteration ahead
+            // (reads run into the slack behind the residues at most)
             int const      row0 = r_base + 4 * t;
             int const      lb   = max(row0, 0);
-            uint32_t const sdw  = *reinterpret_cast<unaligned_u32 const *>(s + lb);
+            uint32_t const sdw  = snext;
+            snext               = *reinterpret_cast<unaligned_u32 const *>(s + max(row0 + 4, 0));
             // boundary words by tile row u: (left word = step k-1, diagonal word = step k-2)
             uint32_t const lw[4] = {qprev.w, qcur.x, qcur.y, qcur.z};
             uint32_t const dw[4] = {qprev.z, qprev.w, qcur.x, qcur.y};
 #pragma unroll
             for (int u = 0; u < 4; ++u)
             {
-                int const row = row0 + u;
-                if (row > i)
-                {
-                    rows_left = false;
-                    break;
-                }
-                if (row < 0)
-                    continue; // virtual row of block 0: H = 0, F = floor stay as they are
-                uint32_t const tl = (sdw >> (8 * (row - lb))) & (kAlph - 1);
-                int            E  = has_left ? ((4 * dec(lw[u] >> 16)) | 1) : (kFar | 1);
-                int            Hd = (has_left && row > 0) ? 4 * dec(dw[u] & 0xffffu) : 0;
+                int const      row = row0 + u;
+                uint32_t const tl  = row >= 0 ? (sdw >> (8 * (row - lb))) & (kAlph - 1) : (uint32_t)(kAlph - 1);
+                int            E   = (has_left && row >= 0) ? ((4 * dec(lw[u] >> 16)) | 1) : (kFar | 1);
+                int            Hd  = (has_left && row > 0) ? 4 * dec(dw[u] & 0xffffu) : 0;
                 uint32_t       w[kNibDw];
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
@@ -1130,7 +1183,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
                 int sub4[C];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
-                    sub4[c] = (int)smat4[qoff[c] + tl];
+                    sub4[c] = (int)smat4[((qoff2[c >> 1] >> (16 * (c & 1))) & 0xffffu) + tl];
 #pragma unroll
                 for (int c = 0; c < C; ++c)
                 {
@@ -1154,7 +1207,7 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
-                if (need_col && (scan || row >= i - 3) && row < ls)
+                if (need_col && (scan || row >= i - 3) && row <= i && row >= 0 && row < ls) // (a chunk may end behind the last row)
                 {
                     // lowest column of this row whose H equals the score (no H exceeds it: H - score <= 0, a multiple of 4
                     // after the tags are masked), as a maximum of keys without compares: key = (H - score) * 32 + (C - c)
@@ -1210,7 +1263,31 @@ __global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
         // with a gap behind it, the rest of the tile is the shortcut's again (1/4 of the instructions per column, and the
         // lockstep of the wavefront pays the longest walk of its lanes).
         bool passed = false;
-        while (walk_ok && i >= 0 && j >= j0 && i >= r_base && n < cap && !(passed && mode == 0))
+        if (walk_ok && mode == 0 && i >= 0 && j >= j0 && i >= r_base)
+        {
+            // the leading diagonal steps all at once: cell (i - t, j - t) continues the run if its H came from the diagonal
+            int const kk = i - r_base, c = j - j0;
+            int const kmax = min(min(kk, c), i) + 1; // cells of the diagonal inside the tile (and the matrix)
+            uint32_t  nd = 0;                        // bit t: not a diagonal step (or beyond)
+#pragma unroll
+            for (int t = 0; t < kCkptEvery; ++t)
+            {
+                int const      rr   = max(kk - t, 0), cc = max(c - t, 0);
+                int const      xw   = cc >> 3;
+                uint32_t const word = tiles[(rr * kNibDw + xw) * 64 + lane];
+                int const      sh   = (xw == kNibDw - 1 ? 32 - 4 * (C - 8 * (kNibDw - 1)) : 0) + 4 * (cc & 7);
+                nd |= (((word >> sh) & 3u) != 3u) ? (1u << t) : 0u;
+            }
+            nd |= ~0u << kmax;
+            int const d = __ffs((int)nd) - 1;
+            if (d > 0)
+            {
+                uint32_t qw[4], sw[4];
+                load_diagonal(i, j, d, qw, sw);
+                (void)take_diagonal(d, 0, false, qw, sw);
+            }
+        }
+        while (walk_ok && !done && i >= 0 && j >= j0 && i >= r_base && n < cap && !(passed && mode == 0))
         {
             int const      kk   = i - r_base, c = j - j0;
             int const      xw   = c >> 3;
@@ -1304,7 +1381,8 @@ static int backtrace_resident_waves()
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        return std::max(1, cus) * dev_aids().bt_waves_per_cu;
+        int const per_cu = dev_aids().bt_waves_per_cu > 0 ? dev_aids().bt_waves_per_cu : 4 * LX_BT_WAVES; // 4 SIMDs per CU
+        return std::max(1, cus) * per_cu;
     }();
     return v;
 }
@@ -1320,7 +1398,7 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
         p.bt_tile_at   = dev_aids().bt_tile_at; // development aids
         p.bt_refill_at = dev_aids().bt_refill_at;
     }
-    // persistent lanes: as many wavefronts as the chip holds at this kernel's occupancy (3 per SIMD), each taking
+    // persistent lanes: as many wavefronts as the chip holds at this kernel's occupancy (LX_BT_WAVES per SIMD), each taking
     // extensions from the queue until it is empty
     uint64_t const b2 = std::min<uint64_t>((p.n + 63) / 64, (uint64_t)backtrace_resident_waves());
     hipError_t e = hipMemsetAsync(p.work_counter, 0, sizeof(uint32_t), stream);

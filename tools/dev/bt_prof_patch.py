@@ -15,11 +15,11 @@ def rep(a, b, must=True):
 
 
 rep('''template <int G, int C>
-__global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
+__global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TraceParams p)
 {''', '''__device__ unsigned long long bt_prof[16];
 #define PROF_T() ((unsigned long long)__builtin_readcyclecounter())
 template <int G, int C>
-__global__ __launch_bounds__(64, 3) void ckpt_backtrace_kernel(TraceParams p)
+__global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TraceParams p)
 {
     unsigned long long pf_short = 0, pf_refill = 0, pf_dp = 0, pf_walk = 0, pf_nshort = 0, pf_can = 0, pf_ntile = 0, pf_tneed = 0, pf_nrefill = 0, pf_t0 = PROF_T(), pf_setup = 0, pf_steps = 0;''')
 rep('''        if (n_idle > 0 && (run_tile || n_idle >= refill_at))
@@ -37,23 +37,23 @@ rep('''            run_tile = n_can == 0 || n_tile >= tile_at;
         if (!run_tile)
         {
             unsigned long long const pt = PROF_T(); ++pf_nshort; pf_can += n_can;''')
-rep('''                else
-                    blocked = true;
+rep('''                        if (!take_diagonal(hk[h], dec(hw[h] & 0xffffu), true, hqw[h], hsw[h]))
+                            blocked = true;
             }
             continue;
         }
-''', '''                else
-                    blocked = true;
+''', '''                        if (!take_diagonal(hk[h], dec(hw[h] & 0xffffu), true, hqw[h], hsw[h]))
+                            blocked = true;
             }
             pf_short += PROF_T() - pt;
             continue;
         }
         unsigned long long const ptile0 = PROF_T(); ++pf_ntile; pf_tneed += n_tile;
 ''')
-rep('''        bool rows_left = true;
-#pragma unroll 1''', '''        unsigned long long const ptile1 = PROF_T(); pf_setup += ptile1 - ptile0;
-        bool rows_left = true;
-#pragma unroll 1''')
+rep('''        bool     rows_left = true;
+''', '''        unsigned long long const ptile1 = PROF_T(); pf_setup += ptile1 - ptile0;
+        bool     rows_left = true;
+''')
 rep('''        bool walk_ok = true;
 ''', '''        unsigned long long const ptile2 = PROF_T(); pf_dp += ptile2 - ptile1;
         bool walk_ok = true;
