@@ -18,6 +18,7 @@ struct DevAids
     bool     trace_overlap;     // LX_TRACE_OVERLAP=1    mode-0 pass 2: forward of chunk k+1 beside the backtrace of k     off
     uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1
     bool     no_narrow_sweep;   // LX_NO_NARROW_SWEEP    keep (8,19) for queries <= 104 columns instead of (8,13)          off
+    bool     no_wide_strips;    // LX_NO_WIDE_STRIPS     153-200 column queries: (16,13) strips instead of (8,25)                off
     bool     sweep_int;         // LX_SWEEP_INT          compact sweep in the integer domain instead of packed half        off
     bool     no_i16_sweep;      // LX_NO_I16_SWEEP       wide queries: int32 sweep instead of the packed 16-bit one        off
     int      pass2_mode;        // LX_PASS2_MODE         initial value of LX_OPT_PASS2_MODE (-1 = the library's default)   -1

@@ -35,6 +35,7 @@ lx::DevAids const & lx::dev_aids()
         a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
         a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
         a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
+        a.no_wide_strips    = set("LX_NO_WIDE_STRIPS");
         a.sweep_int         = set("LX_SWEEP_INT");
         a.no_i16_sweep      = set("LX_NO_I16_SWEEP");
         a.pass2_mode        = set("LX_PASS2_MODE") ? (int)std::min(std::max(num("LX_PASS2_MODE", 2), 0ll), 2ll) : -1;
@@ -533,6 +534,11 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         if (sweep_cfg == 1 && half_ok && !no_narrow && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(3) &&
             (h->opt_query_run % 16 == 0 || 2 * lx::score_pair_profile_bytes(1, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit()))
             sweep_cfg = 3;
+        // 153 - 200 columns: 25-column strips of 8-lane groups (16 extensions of one query per wavefront, 7 steps of skew
+        // instead of 15, no padded column at 200) where the packed-half sweep applies
+        if (sweep_cfg == 2 && half_ok && !lx::dev_aids().no_wide_strips && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(4) &&
+            h->opt_query_run % 16 == 0)
+            sweep_cfg = 4;
         sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
         int smax_entry = 0;
         for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
@@ -549,7 +555,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
             half_sweep = h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
                          h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
-                         (((sweep_cfg == 1 || sweep_cfg == 3) && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
+                         (((sweep_cfg == 1 || sweep_cfg == 3 || sweep_cfg == 4) && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
             if (h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
                 h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && h->opt_query_run % 8 == 0 &&
                 2 * lx::score_pair_profile_bytes(sweep_cfg == 3 ? 1 : 0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
@@ -612,7 +618,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             p.ovf_cap    = (uint32_t)ovf_cap;
             p.ovf_count  = h->d_ws_top + 4;
         }
-        int const sweep_pair = sweep_cfg == 1 ? 0 : sweep_cfg == 3 ? 1 : 5; // pair geometry with the same (G, C): (8,19) / (8,13) / (16,13)
+        int const sweep_pair = sweep_cfg == 1 ? 0 : sweep_cfg == 3 ? 1 : sweep_cfg == 4 ? 7 : 5; // pair geometry with the same (G, C): (8,19) / (8,13) / (8,25) / (16,13)
         PhaseTimer pt0(h, stream, 0);
         if (half_sweep)
         {
@@ -641,7 +647,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         // kernel writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range
         // test is left to the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
         bool const i16_sweep = !half_sweep && h->opt_f16 && !lx::dev_aids().no_i16_sweep &&
-                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0 && sweep_cfg != 3;
+                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0 && sweep_cfg != 3 && sweep_cfg != 4;
         if (i16_sweep)
         {
             lx::ScoreParams sp1{};

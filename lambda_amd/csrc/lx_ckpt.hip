@@ -1332,17 +1332,24 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     }
 }
 
-// ---- host-visible launchers: checkpoint geometries follow the trace geometries (cfg 1 = (8,19), cfg 2 = (16,13)) --------
+// ---- host-visible launchers: checkpoint geometries follow the trace geometries (cfg 1 = (8,19), cfg 2 = (16,13)), plus
+// cfg 3 = (8,13) for queries of up to 104 columns and cfg 4 = (8,25) for 153-200 columns --------
 
 uint64_t ckpt_slot_dwords(int cfg, uint32_t steps_cap)
 {
-    return cfg == 2 ? CkptLayout<16, 13>::slot_dwords(steps_cap) : cfg == 3 ? CkptLayout<8, 13>::slot_dwords(steps_cap) : CkptLayout<8, 19>::slot_dwords(steps_cap);
+    return cfg == 2   ? CkptLayout<16, 13>::slot_dwords(steps_cap)
+           : cfg == 3 ? CkptLayout<8, 13>::slot_dwords(steps_cap)
+           : cfg == 4 ? CkptLayout<8, 25>::slot_dwords(steps_cap)
+                      : CkptLayout<8, 19>::slot_dwords(steps_cap);
 }
 
 // compact slots of the packed-half sweep
 uint64_t ckpt16_slot_dwords(int cfg, uint32_t steps_cap)
 {
-    return cfg == 2 ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap) : cfg == 3 ? Ckpt16Layout<8, 13>::slot_dwords(steps_cap) : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
+    return cfg == 2   ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap)
+           : cfg == 3 ? Ckpt16Layout<8, 13>::slot_dwords(steps_cap)
+           : cfg == 4 ? Ckpt16Layout<8, 25>::slot_dwords(steps_cap)
+                      : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
 }
 
 template <int G, int C>
@@ -1371,7 +1378,10 @@ hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return p.cfg == 2 ? launch_ckpt_forward_cfg<16, 13>(p, stream) : p.cfg == 3 ? launch_ckpt_forward_cfg<8, 13>(p, stream) : launch_ckpt_forward_cfg<8, 19>(p, stream);
+    return p.cfg == 2   ? launch_ckpt_forward_cfg<16, 13>(p, stream)
+           : p.cfg == 3 ? launch_ckpt_forward_cfg<8, 13>(p, stream)
+           : p.cfg == 4 ? launch_ckpt_forward_cfg<8, 25>(p, stream)
+                        : launch_ckpt_forward_cfg<8, 19>(p, stream);
 }
 
 static int backtrace_resident_waves()
@@ -1408,6 +1418,8 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<16, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else if (p.cfg == 3)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    else if (p.cfg == 4)
+        hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 25>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 19>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     return hipGetLastError();

@@ -149,7 +149,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
     // bin index: kind 0 = per-extension profiles, 1 = one profile per wavefront (int32): cfg * 2 + kind;
     // kind 2 = packed half (16 extensions of one query per wavefront): ncfg * 2 + pair geometry
     int const    ncfg  = lx::score_cfg_count();
-    size_t const nbins = (size_t)ncfg * 2 + 8;
+    size_t const nbins = (size_t)ncfg * 2 + 9;
     struct Run
     {
         uint64_t first, count, pad; // positions in idx, padded slot count
@@ -787,7 +787,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // windows are up to 3 x longer: src/search_algo.hpp:1153-1157), so that a wavefront's 16 windows take about as many steps
     // each -- the reason the reference sorts its SIMD batches (:1229-1235).  Results are scattered by original index anyway.
     {
-        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
+        auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 200 ? 2u : lq <= 208 ? 3u : 3u + (lq + 151) / 152; };
         uint32_t cmin = ~0u, cmax = 0;
         bool     ragged_s = false;
         for (uint64_t k = 0; k < live; ++k)
@@ -935,7 +935,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         std::vector<uint64_t> tmax(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
         // (what the wavefronts will execute: every block of kRun slots runs all columns of its panels for as many steps as
         // its longest window has rows)
-        uint64_t const panel = max_q <= 104 ? 104 : max_q <= 152 ? 152 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
+        uint64_t const panel = max_q <= 104 ? 104 : max_q <= 152 ? 152 : max_q <= 200 ? 200 : max_q <= 208 ? 208 : 152, lanes = panel == 208 ? 16 : 8;
         parallel_ranges(ngroups, nthreads,
                         [&](unsigned t, uint64_t glo, uint64_t ghi)
                         {
@@ -1161,7 +1161,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             ++k1;
         {
             // ... and never mix geometry classes (the list is class-major): cut where the class changes
-            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 208 ? 2u : 2u + (lq + 151) / 152; };
+            auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 200 ? 2u : lq <= 208 ? 3u : 3u + (lq + 151) / 152; };
             uint32_t const c0 = qclass(ext[idx[k0]].q_len);
             if (!lx::dev_aids().extend_no_classes && qclass(ext[idx[k1 - 1]].q_len) != c0)
             {

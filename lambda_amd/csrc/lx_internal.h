@@ -241,7 +241,7 @@ int    prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint 
 // padding of q/s staging buffers so that clamped / prefetching loads never leave the allocation
 constexpr size_t kSlack = 256;
 constexpr int kPair16    = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
-constexpr int kPair16Bin = 7;   // its bin among the packed geometries of lx_score_batch
+constexpr int kPair16Bin = 8;   // its bin among the packed geometries of lx_score_batch
 
 // Subject side of a host-buffer call: either the caller's buffer, uploaded into d_s, or -- s_res == NULL, s_bytes == 0
 // after lx_set_subjects -- the resident copy.

@@ -18,6 +18,7 @@
 // (LX_OPT_QUERY_RUN multiple of 16, or host-side padding).
 #include <hip/hip_runtime.h>
 
+#include "lx_aids.h"
 #include "lx_dp_common.h"
 
 namespace lx
@@ -85,7 +86,7 @@ struct PairGeo
 template <int G, int C, bool CKPT>
 __global__ __launch_bounds__(64, (CKPT ? LX_F16_CKPT_WAVES : 1)) void score_pair_kernel(ScoreParams p)
 {
-    static_assert(C <= 24, "profile rows hold 24 halves per lane");
+    static_assert(C <= 32, "profile rows hold 32 halves per lane");
     using Geo = PairGeo<G, C>;
     extern __shared__ uint32_t lds[];
 
@@ -553,7 +554,8 @@ static hipError_t launch_pair_cfg(ScoreParams const & p, hipStream_t stream)
 }
 
 // pair geometries: 0 = (8,19) 152 columns, 1 = (8,13) 104, 2 = (8,16) 128, 3 = (8,8) 64, 4 = (8,24) 192, 5 = (16,13) 208,
-// 6 = (16,10) 160 [8 extensions per wavefront: for query runs that are a multiple of 8 but not of 16]
+// 6 = (16,10) 160 [8 extensions per wavefront: for query runs that are a multiple of 8 but not of 16], 7 = (8,25) 200
+// [200-residue queries without a padded column: 7.7 against 6.7 TCUPS for (16,13) in pass 1]
 hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
@@ -565,6 +567,7 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
         return cfg == 0   ? launch_pair_cfg<8, 19, true>(p, stream)
                : cfg == 5 ? launch_pair_cfg<16, 13, true>(p, stream)
                : cfg == 1 ? launch_pair_cfg<8, 13, true>(p, stream) // short queries: 104 columns
+               : cfg == 7 ? launch_pair_cfg<8, 25, true>(p, stream) // 153 - 200 columns
                           : hipErrorInvalidValue;
     }
     switch (cfg)
@@ -576,6 +579,7 @@ hipError_t launch_score_pair(int cfg, ScoreParams const & p, hipStream_t stream)
         case 4: return launch_pair_cfg<8, 24>(p, stream);
         case 5: return launch_pair_cfg<16, 13>(p, stream);
         case 6: return launch_pair_cfg<16, 10>(p, stream);
+        case 7: return launch_pair_cfg<8, 25>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -592,6 +596,8 @@ int score_pair_cfg_for(uint32_t max_qlen)
         return 0;
     if (max_qlen <= 192)
         return 4;
+    if (max_qlen <= 200 && !dev_aids().no_wide_strips)
+        return 7;
     if (max_qlen <= 208)
         return 5;
     return -1;
@@ -609,8 +615,8 @@ int score_pair_cfg_for_runs_of_8(uint32_t max_qlen)
 
 int score_pair_cfg_cols(int cfg)
 {
-    static int const c[7] = {19, 13, 16, 8, 24, 13, 10};
-    return (cfg >= 0 && cfg < 7) ? c[cfg] : 0;
+    static int const c[8] = {19, 13, 16, 8, 24, 13, 10, 25};
+    return (cfg >= 0 && cfg < 8) ? c[cfg] : 0;
 }
 
 int score_pair_cfg_group(int cfg) { return (cfg == 5 || cfg == 6) ? 16 : 8; }

@@ -704,15 +704,17 @@ def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
     assert (np.nonzero(hsp2["n_ops"])[0] == surv2[want_score[surv2] > 0]).all()
 
 
-def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle):
+@pytest.mark.parametrize("lq,G,C", [(200, 8, 25), (206, 16, 13)])
+def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle, lq, G, C):
     """Single sweep with compact slots: wavefronts whose query fails the packed-half exactness gate (tryptophan-rich 200 aa
     queries: the bound on the intermediates exceeds 2046, real scores beyond 2047 occur) go to the int32 kernel and get
-    int16-pair slots in the overflow area; their neighbours keep the compact ones.  Both must reproduce the oracle."""
+    int16-pair slots in the overflow area; their neighbours keep the compact ones.  Both must reproduce the oracle.
+    200 columns take the (8,25) strips, 201-208 the (16,13) ones."""
     rng = np.random.default_rng(99)
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
     osc = oracle_lib.scoring_from(sc_p)
-    lq, wpq, nq = 200, 16, 10
+    wpq, nq = 16, 10
     q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=4711, sub_rate=0.1, indel_rate=0.02)
     q, s = q.copy(), s.copy()
     W = 22
@@ -733,7 +735,7 @@ def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle):
     want = oracle.align_batch(q, s, ext[surv], osc)
     handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
     score, hsp, off, ops = handle.extend_batch(q, s, ext, cutoff)
-    assert "single sweep" in handle.last_trace_kernel_name() and "score_pair_kernel<16,13,true>" in handle.last_trace_kernel_name()
+    assert "single sweep" in handle.last_trace_kernel_name() and f"score_pair_kernel<{G},{C},true>" in handle.last_trace_kernel_name()
     assert (score == want_score).all()
     heavy_surv = 0
     for i, (oh, oops) in zip(surv, want):
@@ -745,8 +747,9 @@ def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle):
         heavy_surv += (i // wpq) in heavy
     assert heavy_surv >= 8 and len(surv) - heavy_surv >= 8  # both kinds of slots were walked
     # a trace budget that leaves too small an overflow area: the call must fail loudly, not return wrong alignments
-    steps = (int(ext["s_len"].max()) + 16 - 1 + 15) & ~15
-    compact, pairs = steps * 16 // 2 + steps // 16 * 16 * 8, steps * 16 + steps // 16 * 16 * 16  # uint32 per slot, (16,13)
+    steps = (int(ext["s_len"].max()) + G - 1 + 15) & ~15
+    ck16, ck32 = ((C + 1) // 2 + 3) // 4 * 4, (C + 3) // 4 * 4  # dwords per lane per row checkpoint: codes / int16 pairs
+    compact, pairs = steps * G // 2 + steps // 16 * G * ck16, steps * G + steps // 16 * G * ck32  # uint32 per slot
     handle.set_option(capi.LX_OPT_TRACE_BYTES, ((len(ext) + 1) * compact + 10 * pairs) * 4)
     try:
         with pytest.raises(capi.LambdaExtError, match="checkpoint slot"):
