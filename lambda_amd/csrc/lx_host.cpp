@@ -705,10 +705,16 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         bool     monotone = true;
     };
     std::vector<Part> parts(nthreads);
+    // (the same pass writes what the common case needs -- every extension live, the list grouped by query already: the order
+    // is the identity and the runs begin where the slice changes)
+    std::vector<uint32_t> & idx    = h->xb_idx;
+    std::vector<uint8_t> &  newrun = h->xb_newrun;
+    idx.resize(n);
+    newrun.resize(n + 1);
     parallel_ranges(n, nthreads,
                     [&](unsigned t, uint64_t lo, uint64_t hi)
                     {
-                        Part &   pt   = parts[t];
+                        Part     pt;           // (a local: the per-thread slots share cache lines)
                         uint64_t prev = ~0ull; // last live extension before i (of the whole list)
                         for (uint64_t i = lo; i-- > 0;)
                             if (ext[i].q_len != 0 && ext[i].s_len != 0)
@@ -733,9 +739,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             }
                             if (prev != ~0ull && x.q_off < ext[prev].q_off)
                                 pt.monotone = false;
-                            prev = i;
+                            idx[i]    = (uint32_t)i;
+                            newrun[i] = (i == 0 || x.q_off != ext[i - 1].q_off || x.q_len != ext[i - 1].q_len) ? 1 : 0;
+                            prev      = i;
                             ++pt.live;
                         }
+                        parts[t] = pt;
                     });
     uint64_t live = 0;
     bool     monotone = true;
@@ -748,8 +757,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     }
     if (live == 0)
         return LX_OK;
-    std::vector<uint32_t> & idx = h->xb_idx;
+    bool const as_given = live == n && monotone;
     idx.resize(live);
+    if (!as_given)
     {
         std::vector<uint64_t> first(nthreads + 1, 0);
         for (unsigned t = 0; t < nthreads; ++t)
@@ -772,14 +782,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                   });
     auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
     // where the runs of one query slice begin in the ordered list
-    std::vector<uint8_t> & newrun = h->xb_newrun;
     newrun.resize(live + 1);
-    parallel_ranges(live, nthreads,
-                    [&](unsigned, uint64_t lo, uint64_t hi)
-                    {
-                        for (uint64_t k = lo; k < hi; ++k)
-                            newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
-                    });
+    if (!as_given)
+        parallel_ranges(live, nthreads,
+                        [&](unsigned, uint64_t lo, uint64_t hi)
+                        {
+                            for (uint64_t k = lo; k < hi; ++k)
+                                newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
+                        });
     newrun[live] = 1;
     // Mixed query lengths (a real seed list; the synthetic batches have one): a chunk runs the kernel geometry of its longest
     // query, so runs are dealt to geometry classes first -- one panel of 152 columns, one of 208, two / three / ... panels of
@@ -790,16 +800,36 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 200 ? 2u : lq <= 208 ? 3u : 3u + (lq + 151) / 152; };
         uint32_t cmin = ~0u, cmax = 0;
         bool     ragged_s = false;
-        for (uint64_t k = 0; k < live; ++k)
         {
-            if (newrun[k])
+            struct Scan
             {
-                uint32_t const c = qclass(ext[idx[k]].q_len);
-                cmin = std::min(cmin, c);
-                cmax = std::max(cmax, c);
+                uint32_t cmin = ~0u, cmax = 0;
+                bool     ragged = false;
+            };
+            std::vector<Scan> scans(nthreads);
+            parallel_ranges(live, nthreads,
+                            [&](unsigned t, uint64_t lo, uint64_t hi)
+                            {
+                                Scan sc; // (a local: the per-thread slots share cache lines)
+                                for (uint64_t k = lo; k < hi; ++k)
+                                {
+                                    if (newrun[k])
+                                    {
+                                        uint32_t const c = qclass(ext[idx[k]].q_len);
+                                        sc.cmin = std::min(sc.cmin, c);
+                                        sc.cmax = std::max(sc.cmax, c);
+                                    }
+                                    else if (ext[idx[k]].s_len != ext[idx[k - 1]].s_len)
+                                        sc.ragged = true;
+                                }
+                                scans[t] = sc;
+                            });
+            for (Scan const & sc : scans)
+            {
+                cmin     = std::min(cmin, sc.cmin);
+                cmax     = std::max(cmax, sc.cmax);
+                ragged_s = ragged_s || sc.ragged;
             }
-            else if (ext[idx[k]].s_len != ext[idx[k - 1]].s_len)
-                ragged_s = true;
         }
         bool const no_classes = lx::dev_aids().extend_no_classes, no_sort = lx::dev_aids().extend_no_sort; // A/B aids
         if (cmin != cmax && !no_classes)
