@@ -390,6 +390,27 @@ typedef struct lx_record_stats
 } lx_record_stats;
 uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_matches, lx_record_stats * stats);
 
+/* The taxonomy the reference keeps in its index (indexFile.taxonParentIDs / taxonHeights / sTaxIds): parents[t] and heights[t]
+ * for taxon t < n_taxa (parent 0 = unassigned or the root), and per true subject id the taxa it is assigned to in CSR form:
+ * s_tax_ids[s_tax_off[s] .. s_tax_off[s + 1]). */
+typedef struct lx_tax_tree
+{
+    uint32_t const * parents;
+    uint32_t const * heights;
+    uint64_t         n_taxa;
+    uint64_t const * s_tax_off; /* n_s + 1 entries */
+    uint32_t const * s_tax_ids;
+    uint64_t         n_s;
+} lx_tax_tree;
+/* The LCA step of _writeRecord (src/search_algo.hpp:884-907, computeLCA: src/search_misc.hpp:86-112) over a result list
+ * grouped by n_qid (what lx_postprocess_records returns): per query the lowest common ancestor of the taxa of its subjects --
+ * starting from the first match whose subject has a first taxon with a parent, folding in every assigned taxon of every match.
+ * Writes one (n_qid, lcaTaxId) pair per query in list order (lcaTaxId 0 = no assigned subject) and their number; out arrays
+ * need one entry per query with hits (at most n).  LX_EINVAL for ids outside the tree or a path that does not lead to the root
+ * (the reference throws "LCA-computation error"). */
+int lx_compute_lca(lx_blast_match const * m, uint64_t n, lx_tax_tree const * tree, uint64_t * out_qid, uint32_t * out_lca,
+                   uint64_t * out_n);
+
 /* What the writers need to know about the sequences (the reference reads these from lH.qryIds / indexFile.ids). */
 typedef struct lx_seq_names
 {

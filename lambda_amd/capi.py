@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_matches",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
-    "lx_widen_and_preprocess", "lx_postprocess_records", "lx_write_records", "lx_convert_ranks",
+    "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
     "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
 ]
 
@@ -68,6 +68,11 @@ BLAST_MATCH_DTYPE = np.dtype([
 
 class RecordStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("qrys_with_hit", "hits_duplicate2", "hits_abundant", "hits_final", "pairs")]
+
+
+class TaxTree(C.Structure):
+    _fields_ = [("parents", C.c_void_p), ("heights", C.c_void_p), ("n_taxa", C.c_uint64), ("s_tax_off", C.c_void_p),
+                ("s_tax_ids", C.c_void_p), ("n_s", C.c_uint64)]
 
 
 class SeqNames(C.Structure):
@@ -186,8 +191,26 @@ def load():
     lib.lx_postprocess_records.argtypes = [vp, u64, u64, C.POINTER(RecordStats)]
     lib.lx_postprocess_records.restype = u64
     lib.lx_write_records.argtypes = [C.c_char_p, i32, i32, C.c_char_p, vp, u64, vp, C.POINTER(SeqNames), vp, vp]
+    lib.lx_compute_lca.argtypes = [vp, u64, C.POINTER(TaxTree), vp, vp, C.POINTER(u64)]
     _lib = lib
     return lib
+
+
+def compute_lca(bms: np.ndarray, parents, heights, s_tax_off, s_tax_ids):
+    """The LCA step of _writeRecord (src/search_algo.hpp:884-907) over a result list grouped by query: (n_qid, lcaTaxId) arrays."""
+    m = np.ascontiguousarray(bms, dtype=BLAST_MATCH_DTYPE)
+    par = np.ascontiguousarray(parents, dtype=np.uint32)
+    hgt = np.ascontiguousarray(heights, dtype=np.uint32)
+    off = np.ascontiguousarray(s_tax_off, dtype=np.uint64)
+    ids = np.ascontiguousarray(s_tax_ids, dtype=np.uint32)
+    tree = TaxTree(par.ctypes.data, hgt.ctypes.data, len(par), off.ctypes.data, ids.ctypes.data if len(ids) else None, len(off) - 1)
+    qid = np.zeros(max(len(m), 1), dtype=np.uint64)
+    lca = np.zeros(max(len(m), 1), dtype=np.uint32)
+    cnt = C.c_uint64(0)
+    rc = load().lx_compute_lca(_ptr(m) if len(m) else None, len(m), C.byref(tree), _ptr(qid), _ptr(lca), C.byref(cnt))
+    if rc != 0:
+        raise LambdaExtError(rc, "lx_compute_lca: ids outside the taxonomy, or a path that does not lead to the root")
+    return qid[: cnt.value].copy(), lca[: cnt.value].copy()
 
 
 def postprocess_records(bms: np.ndarray, max_matches: int = 25):

@@ -170,6 +170,92 @@ uint64_t lx_postprocess_records(lx_blast_match * m, uint64_t n, uint64_t max_mat
     return w;
 }
 
+// computeLCA (src/search_misc.hpp:86-112): level the two nodes, then climb together; 0 = the paths never met
+static bool lca_of(lx_tax_tree const & t, uint32_t n1, uint32_t n2, uint32_t & out)
+{
+    if (n1 == n2)
+    {
+        out = n1;
+        return true;
+    }
+    if (n1 >= t.n_taxa || n2 >= t.n_taxa)
+        return false;
+    for (uint32_t i = t.heights[n1]; i > t.heights[n2]; --i)
+    {
+        n1 = t.parents[n1];
+        if (n1 >= t.n_taxa)
+            return false;
+    }
+    for (uint32_t i = t.heights[n2]; i > t.heights[n1]; --i)
+    {
+        n2 = t.parents[n2];
+        if (n2 >= t.n_taxa)
+            return false;
+    }
+    while (n1 != 0 && n2 != 0)
+    {
+        if (n1 == n2)
+        {
+            out = n1;
+            return true;
+        }
+        n1 = t.parents[n1];
+        n2 = t.parents[n2];
+        if (n1 >= t.n_taxa || n2 >= t.n_taxa)
+            return false;
+    }
+    return false; // "LCA-computation error: One of the paths didn't lead to root."
+}
+
+int lx_compute_lca(lx_blast_match const * m, uint64_t n, lx_tax_tree const * tree, uint64_t * out_qid, uint32_t * out_lca,
+                   uint64_t * out_n)
+{
+    if ((!m && n) || !tree || !out_qid || !out_lca || !out_n || !tree->parents || !tree->heights || !tree->s_tax_off ||
+        (!tree->s_tax_ids && tree->n_s && tree->s_tax_off[tree->n_s]))
+        return LX_EINVAL;
+    lx_tax_tree const & t = *tree;
+    uint64_t            w = 0;
+    for (uint64_t lo = 0; lo < n;)
+    {
+        uint64_t hi = lo + 1;
+        while (hi < n && m[hi].n_qid == m[lo].n_qid)
+            ++hi;
+        for (uint64_t k = lo; k < hi; ++k)
+            if (m[k].n_sid >= t.n_s)
+                return LX_EINVAL;
+        // the first match whose subject's first taxon is assigned (has a parent) starts the fold (:887-896)
+        uint32_t lca = 0;
+        for (uint64_t k = lo; k < hi && lca == 0; ++k)
+        {
+            uint64_t const a = t.s_tax_off[m[k].n_sid], b = t.s_tax_off[m[k].n_sid + 1];
+            if (b > a)
+            {
+                uint32_t const first = t.s_tax_ids[a];
+                if (first >= t.n_taxa)
+                    return LX_EINVAL;
+                if (t.parents[first] != 0)
+                    lca = first;
+            }
+        }
+        if (lca != 0) // every assigned taxon of every match (:898-906); unassigned ones are ignored
+            for (uint64_t k = lo; k < hi; ++k)
+                for (uint64_t x = t.s_tax_off[m[k].n_sid]; x < t.s_tax_off[m[k].n_sid + 1]; ++x)
+                {
+                    uint32_t const tax = t.s_tax_ids[x];
+                    if (tax >= t.n_taxa)
+                        return LX_EINVAL;
+                    if (t.parents[tax] != 0 && !lca_of(t, tax, lca, lca))
+                        return LX_EINVAL;
+                }
+        out_qid[w] = m[lo].n_qid;
+        out_lca[w] = lca;
+        ++w;
+        lo = hi;
+    }
+    *out_n = w;
+    return LX_OK;
+}
+
 int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
                      uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                      uint64_t const * q_ascii_off)

@@ -1,6 +1,7 @@
 """CPU tests of row N2: _writeRecord semantics (src/search_algo.hpp:820-913) and the BLAST-tabular / SAM writers
 (src/search_output.hpp:463-733).  No GPU needed: the inputs are finished HSP records."""
 import numpy as np
+import pytest
 
 from lambda_amd import capi
 
@@ -138,3 +139,82 @@ def test_sam_writer_blastn_minus_strand_cigar_is_reversed(tmp_path):
     assert f0[1] == "0" and f0[5] == "2S6M1I9M3D4M7S"
     assert f1[1] == str(256 | 16) and f1[5] == "7S4M3D9M1I6M2S"  # the same elements, back to front
     assert "qf:i:-1" in f1
+
+
+def _lca_reference(parents, heights, n1, n2):
+    """computeLCA as the reference writes it (/root/reference/src/search_misc.hpp:86-112), restated for the test."""
+    if n1 == n2:
+        return n1
+    i = heights[n1]
+    while i > heights[n2]:
+        n1 = parents[n1]
+        i -= 1
+    i = heights[n2]
+    while i > heights[n1]:
+        n2 = parents[n2]
+        i -= 1
+    while n1 != 0 and n2 != 0:
+        if n1 == n2:
+            return n1
+        n1, n2 = parents[n1], parents[n2]
+    raise RuntimeError("LCA-computation error")
+
+
+def test_lca_of_a_query_follows_write_record():
+    """The LCA step of _writeRecord (/root/reference/src/search_algo.hpp:884-907) on a random taxonomy: start from the first match
+    whose subject's first taxon is assigned, fold in every assigned taxon of every match; unassigned taxa (parent 0) are ignored,
+    a query without an assigned subject reports 0."""
+    rng = np.random.default_rng(5)
+    n_taxa = 400
+    parents = np.zeros(n_taxa, dtype=np.uint32)
+    heights = np.zeros(n_taxa, dtype=np.uint32)
+    parents[1] = 1  # the root is its own parent in NCBI's dump; height 0
+    for t in range(2, n_taxa):
+        if rng.random() < 0.05:
+            continue  # unassigned: parent 0
+        par = int(rng.integers(1, t))
+        while par != 1 and parents[par] == 0:
+            par = int(rng.integers(1, t))
+        parents[t] = par
+        heights[t] = heights[par] + 1
+    n_s = 300
+    ntax = rng.choice([0, 1, 1, 1, 2, 3], n_s)
+    s_tax_off = np.concatenate([[0], np.cumsum(ntax)]).astype(np.uint64)
+    s_tax_ids = rng.integers(2, n_taxa, int(ntax.sum())).astype(np.uint32)
+    bms = np.zeros(0, dtype=capi.BLAST_MATCH_DTYPE)
+    groups = []
+    for qid in range(60):
+        k = int(rng.integers(1, 12))
+        g = np.zeros(k, dtype=capi.BLAST_MATCH_DTYPE)
+        g["n_qid"] = qid * 3
+        g["n_sid"] = rng.integers(0, 20 if qid % 7 == 0 else n_s, k)
+        groups.append(g)
+    bms = np.concatenate(groups)
+    qids, lcas = capi.compute_lca(bms, parents, heights, s_tax_off, s_tax_ids)
+    assert list(qids) == [g["n_qid"][0] for g in groups]
+    nonzero = 0
+    for g, got in zip(groups, lcas):
+        want = 0
+        for sid in g["n_sid"]:
+            taxa = s_tax_ids[int(s_tax_off[sid]): int(s_tax_off[sid + 1])]
+            if len(taxa) and parents[taxa[0]] != 0:
+                want = int(taxa[0])
+                break
+        if want:
+            for sid in g["n_sid"]:
+                for tax in s_tax_ids[int(s_tax_off[sid]): int(s_tax_off[sid + 1])]:
+                    if parents[tax] != 0:
+                        want = _lca_reference(parents, heights, int(tax), want)
+        assert int(got) == want
+        nonzero += want != 0
+    assert nonzero > 40
+    # two trees that never meet: the reference throws, the library reports the error
+    parents2, heights2 = parents.copy(), heights.copy()
+    parents2[1] = 0  # cut the root's self-loop: the climb now runs into 0 before the paths meet ...
+    a, b = 2, 3
+    parents2[a], parents2[b], heights2[a], heights2[b] = 4, 5, 1, 1
+    parents2[4], parents2[5], heights2[4], heights2[5] = 0, 0, 0, 0  # ... for these two: roots of their own
+    one = np.zeros(2, dtype=capi.BLAST_MATCH_DTYPE)
+    one["n_sid"] = [0, 1]
+    with pytest.raises(capi.LambdaExtError):
+        capi.compute_lca(one, parents2, heights2, np.array([0, 1, 2], dtype=np.uint64), np.array([a, b], dtype=np.uint32))
