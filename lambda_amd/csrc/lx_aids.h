@@ -19,6 +19,7 @@ struct DevAids
     uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1
     bool     no_narrow_sweep;   // LX_NO_NARROW_SWEEP    keep (8,19) for queries <= 104 columns instead of (8,13)          off
     bool     no_wide_strips;    // LX_NO_WIDE_STRIPS     153-200 column queries: (16,13) strips instead of (8,25)                off
+    bool     no_wide_compact;   // LX_NO_WIDE_COMPACT    queries wider than a panel: int16-pair slots instead of compact codes    off
     bool     sweep_int;         // LX_SWEEP_INT          compact sweep in the integer domain instead of packed half        off
     bool     no_i16_sweep;      // LX_NO_I16_SWEEP       wide queries: int32 sweep instead of the packed 16-bit one        off
     int      pass2_mode;        // LX_PASS2_MODE         initial value of LX_OPT_PASS2_MODE (-1 = the library's default)   -1

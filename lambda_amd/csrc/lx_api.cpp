@@ -36,6 +36,7 @@ lx::DevAids const & lx::dev_aids()
         a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
         a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
         a.no_wide_strips    = set("LX_NO_WIDE_STRIPS");
+        a.no_wide_compact   = set("LX_NO_WIDE_COMPACT");
         a.sweep_int         = set("LX_SWEEP_INT");
         a.no_i16_sweep      = set("LX_NO_I16_SWEEP");
         a.pass2_mode        = set("LX_PASS2_MODE") ? (int)std::min(std::max(num("LX_PASS2_MODE", 2), 0ll), 2ll) : -1;
@@ -179,8 +180,9 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
     if (forced == 1 || forced == 2)
         return forced;
     // (the packed 16-bit sweep is bound by its checkpoint bytes: the 19-column strips of (8,19) store fewer boundary
-    // columns -- 400 aa: 0.0134 ms per padded column against 0.0156 for (16,13))
-    double const f1 = packed16 ? 0.0134 : 0.070, f2 = packed16 ? 0.0156 : 0.062;
+    // columns -- 400 aa: 0.0134 ms per padded column against 0.0156 for (16,13) with int16-pair slots; with compact codes,
+    // which only the (8,19) panels have, 0.0108)
+    double const f1 = packed16 ? 0.0108 : 0.070, f2 = packed16 ? 0.0156 : 0.062;
     double const c1 = (double)((max_q + p1 - 1) / p1 * p1) * f1, c2 = (double)((max_q + p2 - 1) / p2 * p2) * f2;
     return c1 < c2 ? 1 : 2;
 }
@@ -521,7 +523,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
     uint64_t ovf_cap = 0;
     int      sweep_share = 0;
-    bool     half_sweep = false, may_decline = true;
+    bool     half_sweep = false, may_decline = true, wide_compact = false;
     int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     if (h->opt_pass2 == 2 && shared && h->trace_ok[slot] && !h->opt_band)
     {
@@ -556,6 +558,12 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             half_sweep = h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
                          h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
                          (((sweep_cfg == 1 || sweep_cfg == 3 || sweep_cfg == 4) && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
+            // Queries wider than a panel: compact codes as well, one part per (8,19) panel, written by the packed int16 kernel
+            // (the half-precision one has no carry between panels); what scores beyond the codes' 2046 goes to the int32 launch
+            wide_compact = h->opt_f16 && sweep_panels > 1 && sweep_cfg == 1 && h->opt_query_run % 16 == 0 &&
+                           -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
+                           !lx::dev_aids().no_wide_compact && !lx::dev_aids().no_i16_sweep;
+            half_sweep = half_sweep || wide_compact;
             if (h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
                 h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && h->opt_query_run % 8 == 0 &&
                 2 * lx::score_pair_profile_bytes(sweep_cfg == 3 ? 1 : 0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
@@ -567,13 +575,13 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             {
                 // compact slots for the batch (+ the spare slot idle halves write to), int16-pair slots for what the
                 // packed kernel declines in whatever the budget leaves
-                sweep_stride = lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+                sweep_stride = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
                 sweep        = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
                 // (the packed kernel's exactness gate, lx_score_f16.hip: it cannot decline when even the worst query passes)
                 int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) +
                                       (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) +
                                       (smax_entry - h->sc_host[slot].gap_extend) + 2; // (ScoringDev::smax = largest entry - ge)
-                may_decline = worst > 2046;
+                may_decline = worst > 2046 || wide_compact;
                 if (sweep && may_decline)
                     ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
             }
@@ -637,7 +645,16 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
             bool const int_sweep = lx::dev_aids().sweep_int; // A/B: the compact sweep in the integer domain
-            if (int_sweep && sweep_share == 0)
+            if (wide_compact)
+            {
+                sp1.ws         = p.ws;
+                sp1.ws_top     = p.ws_top;
+                sp1.ws_cap     = p.ws_cap;
+                sp1.panels_cap = sweep_panels;
+                LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
+                LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream)); // the fix-up launch starts with an empty carry workspace
+            }
+            else if (int_sweep && sweep_share == 0)
                 LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
             else
                 LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
@@ -675,9 +692,12 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         if (!half_sweep || may_decline) // (the packed-half kernel declines nothing when even the worst query passes its test)
             LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
-        char buf[160];
+        char buf[200];
         int const nameG = lx::trace_cfg_group(sweep_cfg), nameC = lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg);
-        if (half_sweep && may_decline)
+        if (wide_compact)
+            snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<%d,%d,true,true,true> (single sweep, compact codes; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
+                     nameG, nameC, nameG, nameC);
+        else if (half_sweep && may_decline)
             snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
                      nameG, nameC, nameG, nameC);
         else if (half_sweep)

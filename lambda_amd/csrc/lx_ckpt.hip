@@ -619,24 +619,26 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         uint32_t const H = code16 & 0x7ffu;
         return H | ((H - (code16 >> 11)) << 16);
     };
-    // A query wider than one panel has one part per panel in its slot (int16 pairs only): global strip st = panel * G +
+    // A query wider than one panel has one part per panel in its slot (int16 pairs or compact codes): global strip st = panel * G +
     // lane; a strip's step for row r is r + lane.
-    auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (c16 ? 0 : (uint64_t)pn * panel_dw)); };
+    uint64_t const panel16_dw = L16::slot_dwords(p.steps_cap); // (compact codes: one part per panel as well)
+    auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (uint64_t)pn * (c16 ? panel16_dw : panel_dw)); };
     auto rowck_of = [&](uint32_t pn)
     {
-        return reinterpret_cast<uint4 const *>(slot + (c16 ? L16::bnd_dwords(p.steps_cap) : (uint64_t)pn * panel_dw + Lay::bnd_dwords(p.steps_cap)));
+        return reinterpret_cast<uint4 const *>(slot + (c16 ? (uint64_t)pn * panel16_dw + L16::bnd_dwords(p.steps_cap)
+                                                           : (uint64_t)pn * panel_dw + Lay::bnd_dwords(p.steps_cap)));
     };
     // word (H, F) of column c of strip st's row checkpoint m; word (H, E) of strip st's boundary at step k
     auto rowck_word = [&](uint32_t m, uint32_t st, uint32_t c) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(rowck_of(0) + L16::rowck_quad_index(m, st, c / 8))[c % 8]);
+            return expand(reinterpret_cast<uint16_t const *>(rowck_of(st / G) + L16::rowck_quad_index(m, st % G, c / 8))[c % 8]);
         return reinterpret_cast<uint32_t const *>(rowck_of(st / G) + rowck_quad_index<G, Lay::kCkDw>(m, st % G, c / 4))[c % 4];
     };
     auto bnd_word_of = [&](uint32_t st, uint32_t k) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(bnd_of(0) + L16::bnd_oct_index(k / 8, st))[k & 7]);
+            return expand(reinterpret_cast<uint16_t const *>(bnd_of(st / G) + L16::bnd_oct_index(k / 8, st % G))[k & 7]);
         return reinterpret_cast<uint32_t const *>(bnd_of(st / G) + bnd_quad_index<G>(k / 4, st % G))[k & 3];
     };
     // ops are produced end -> begin into the slot [0, cap): apos = misalignment of the slot start + offset of the next byte
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
 #pragma unroll
                 for (int xq = 0; xq < L16::kCkDw / 4; ++xq)
                 {
-                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)st, (uint32_t)xq)]; // (one panel)
+                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)gl, (uint32_t)xq)];
                     uint32_t const d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -1141,7 +1143,8 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
             if (c16)
             {
                 // half of the 16-byte group of eight steps
-                uint2 const v = reinterpret_cast<uint2 const *>(bndL + L16::bnd_oct_index((uint32_t)qd / 2, (uint32_t)gL))[qd & 1];
+                int const   qs = qd + qshift;
+                uint2 const v  = reinterpret_cast<uint2 const *>(bndL + L16::bnd_oct_index((uint32_t)qs / 2, (uint32_t)gL))[qs & 1];
                 return make_uint4(expand(v.x & 0xffffu), expand(v.x >> 16), expand(v.y & 0xffffu), expand(v.y >> 16));
             }
             return bndL[bnd_quad_index<G>((uint32_t)(qd + qshift), (uint32_t)gL)];

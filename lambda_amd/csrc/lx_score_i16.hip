@@ -70,14 +70,17 @@ struct Pair16Geo
 };
 
 // CKPT = false: score only (pass 1 of queries wider than the packed-half geometries): no slots, no end cells.
-// COMPACT = the slots hold the 16-bit codes of Ckpt16Layout instead of int16 pairs (one panel, H <= 2047, a gap's
-// first character <= 31: the conditions of the packed-half sweep, whose slots these are): in the integer domain a code
-// is two subtractions and a shift-or.
+// COMPACT = the slots hold the 16-bit codes of Ckpt16Layout instead of int16 pairs (H <= 2047, a gap's first character
+// <= 31: the conditions of the packed-half sweep, whose slots these are): in the integer domain a code is two subtractions
+// and a shift-or.  One panel: the bound on the intermediates is tested up front, like the packed-half kernel does.  MULTI
+// (queries wider than a panel: one part of compact codes per panel): no bound a real protein query passes would admit
+// them, so the int16 range is tested up front and the code range afterwards -- an extension whose best score is beyond
+// 2046 leaves the sentinel and is redone by the int32 launch into an overflow slot, like one the other test declines.
 template <int G, int C, bool MULTI, bool CKPT = true, bool COMPACT = false>
 __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 {
     static_assert(C <= 24, "profile rows hold 24 entries per lane");
-    static_assert(!COMPACT || (CKPT && !MULTI), "compact codes: single-panel sweep only");
+    static_assert(!COMPACT || CKPT, "compact codes belong to the checkpointing sweep");
     using L16 = Ckpt16Layout<G, C>;
     using Geo = Pair16Geo<G, C>;
     extern __shared__ uint32_t lds[];
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
         bound += __shfl_xor(bound, off);
     bool const broken  = CKPT && ((__ballot(lq > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) != 0) || (uint32_t)steps > p.steps_cap);
     // (upper end: no value reaches the non-finite patterns; lower end: pad scores and the skew of the first rows stay above 0)
-    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (COMPACT ? 2046 : kI16Limit)) != 0 ||
+    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > ((COMPACT && !MULTI) ? 2046 : kI16Limit)) != 0 ||
                          (-ge) * (G + 2) + (-sc->g2) + 256 > kBias;
     if (too_big)
     {
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
 
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
     uint32_t const     row_base  = (uint32_t)(g * Geo::kLaneDw) * 4u;
-    uint64_t const     panel_dw  = CKPT ? Geo::slot_dwords(p.steps_cap) : 0;
+    uint64_t const     panel_dw  = !CKPT ? 0 : COMPACT ? L16::slot_dwords(p.steps_cap) : Geo::slot_dwords(p.steps_cap);
     uint32_t * const   stage     = lds + nrows * Geo::kRowDw + lane; // [extension A / B][step % 4][lane]
 
     s2 const GE = ssplat(ge), G2 = ssplat(sc->g2), NGE = ssplat(-ge);
@@ -278,8 +281,8 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
         bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
         bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
         // (compact sweep: an idle half owns the spare slot p.n -- its stores are unconditional)
-        uint32_t * const slotA = !CKPT ? nullptr : COMPACT ? p.ckpt + (actA ? eA : p.n) * p.ckpt_stride : p.ckpt + eA * p.ckpt_stride + (uint64_t)panel * panel_dw;
-        uint32_t * const slotB = !CKPT ? nullptr : COMPACT ? p.ckpt + (actB ? eB : p.n) * p.ckpt_stride : p.ckpt + eB * p.ckpt_stride + (uint64_t)panel * panel_dw;
+        uint32_t * const slotA = !CKPT ? nullptr : p.ckpt + ((COMPACT && !actA) ? p.n : eA) * p.ckpt_stride + (uint64_t)panel * panel_dw;
+        uint32_t * const slotB = !CKPT ? nullptr : p.ckpt + ((COMPACT && !actB) ? p.n : eB) * p.ckpt_stride + (uint64_t)panel * panel_dw;
         bool const       stA = CKPT && actA && writable, stB = CKPT && actB && writable;
 
         s2 Z = ssplat(ge * g + kBias); // z_i of the first processed row i = -g, biased
@@ -621,7 +624,8 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
         if (is_first && act)
         {
             EndCell ec{};
-            if (!writable)
+            bool const declined = COMPACT && MULTI && run > 2046; // beyond what the codes hold: the int32 launch redoes it
+            if (!writable || declined)
                 ec.score = -1;
             else if (run > 0)
             {
@@ -631,7 +635,7 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
                 ec.flags = (rtie ? kEndAmbiguous : 0) | (COMPACT ? kEndCompact : 0);
             }
             p.ends[e]      = ec;
-            p.out_score[e] = writable ? run : -1;
+            p.out_score[e] = (writable && !declined) ? run : -1;
         }
     };
     if constexpr (CKPT)
@@ -702,6 +706,16 @@ hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hip
 {
     if (p.n == 0)
         return hipSuccess;
+    if (p.panels_cap > 1) // queries wider than a panel: (8,19) panels, one part of compact codes each
+    {
+        using Geo = Pair16Geo<8, 19>;
+        uint64_t const blocks = (p.n + 2ull * Geo::kGroups - 1) / (2ull * Geo::kGroups);
+        if (trace_cfg != 1 || blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0)
+            return hipErrorInvalidValue;
+        size_t const lds = ((size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+        hipLaunchKernelGGL((sweep_pair16_kernel<8, 19, true, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        return hipGetLastError();
+    }
     return trace_cfg == 1 ? launch_sweep16_compact_cfg<8, 19>(p, stream) : trace_cfg == 2 ? launch_sweep16_compact_cfg<16, 13>(p, stream) : hipErrorInvalidValue;
 }
 

@@ -704,12 +704,13 @@ def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
     assert (np.nonzero(hsp2["n_ops"])[0] == surv2[want_score[surv2] > 0]).all()
 
 
-@pytest.mark.parametrize("lq,G,C", [(200, 8, 25), (206, 16, 13)])
+@pytest.mark.parametrize("lq,G,C", [(200, 8, 25), (206, 16, 13), (330, 8, 19)])
 def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle, lq, G, C):
     """Single sweep with compact slots: wavefronts whose query fails the packed-half exactness gate (tryptophan-rich 200 aa
     queries: the bound on the intermediates exceeds 2046, real scores beyond 2047 occur) go to the int32 kernel and get
     int16-pair slots in the overflow area; their neighbours keep the compact ones.  Both must reproduce the oracle.
-    200 columns take the (8,25) strips, 201-208 the (16,13) ones."""
+    200 columns take the (8,25) strips, 201-208 the (16,13) ones; 330 columns are three (8,19) panels of compact codes written
+    by the packed int16 kernel, which declines by extension, after the fact (best score beyond 2046)."""
     rng = np.random.default_rng(99)
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
@@ -735,7 +736,9 @@ def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle, lq, G, C):
     want = oracle.align_batch(q, s, ext[surv], osc)
     handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
     score, hsp, off, ops = handle.extend_batch(q, s, ext, cutoff)
-    assert "single sweep" in handle.last_trace_kernel_name() and f"score_pair_kernel<{G},{C},true>" in handle.last_trace_kernel_name()
+    panels = (lq + G * C - 1) // (G * C)
+    kernel = f"score_pair_kernel<{G},{C},true>" if panels == 1 else f"sweep_pair16_kernel<{G},{C},true,true,true>"
+    assert "single sweep" in handle.last_trace_kernel_name() and kernel in handle.last_trace_kernel_name()
     assert (score == want_score).all()
     heavy_surv = 0
     for i, (oh, oops) in zip(surv, want):
@@ -749,7 +752,7 @@ def test_sweep_overflow_slots_for_declined_wavefronts(handle, oracle, lq, G, C):
     # a trace budget that leaves too small an overflow area: the call must fail loudly, not return wrong alignments
     steps = (int(ext["s_len"].max()) + G - 1 + 15) & ~15
     ck16, ck32 = ((C + 1) // 2 + 3) // 4 * 4, (C + 3) // 4 * 4  # dwords per lane per row checkpoint: codes / int16 pairs
-    compact, pairs = steps * G // 2 + steps // 16 * G * ck16, steps * G + steps // 16 * G * ck32  # uint32 per slot
+    compact, pairs = panels * (steps * G // 2 + steps // 16 * G * ck16), panels * (steps * G + steps // 16 * G * ck32)  # uint32 per slot
     handle.set_option(capi.LX_OPT_TRACE_BYTES, ((len(ext) + 1) * compact + 10 * pairs) * 4)
     try:
         with pytest.raises(capi.LambdaExtError, match="checkpoint slot"):
