@@ -659,7 +659,8 @@ def test_extend_batch_host_buffers(handle, oracle, order, pass2_mode):
     osc = oracle_lib.scoring_from(sc_p)
     qs, ss, exts = [], [], []
     qo = so = 0
-    for k, (lq, wpq) in enumerate([(150, 37), (97, 16), (150, 5), (33, 50), (200, 21)]):
+    # (200 columns: the (8,25) strips; 330 and 440: three panels -- compact codes over panels in the single sweep)
+    for k, (lq, wpq) in enumerate([(150, 37), (97, 16), (150, 5), (33, 50), (200, 21), (330, 19), (440, 32)]):
         q, s, ext = synth.make_batch_np(6, lq, wpq, seed=500 + k, sub_rate=0.2, indel_rate=0.03)
         ext = ext.copy()
         ext["q_off"] += qo
