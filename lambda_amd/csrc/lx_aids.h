@@ -26,6 +26,7 @@ struct DevAids
     unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 8)           0
     bool     extend_no_classes; // LX_EXTEND_NO_CLASSES  lx_extend_batch: no geometry-class binning of ragged lists        off
     bool     extend_no_sort;    // LX_EXTEND_NO_SORT     lx_extend_batch: no in-run sort by window length                  off
+    uint64_t extend_run;        // LX_EXTEND_RUN         lx_extend_batch: pad query runs to 8 or 16 slots (0 = by estimated work)  0
     uint64_t extend_chunk;      // LX_EXTEND_CHUNK       default of LX_OPT_EXTEND_CHUNK (extensions per pipeline chunk)    640 Ki
     int      bt_waves_per_cu;   // LX_BT_WAVES_PER_CU    persistent wavefronts of the backtrace per CU (0 = what fits)     0
     int      bt_tile_at;        // LX_BT_TILE_AT         lanes waiting for a tile that start the tile phase (0 = default)  0

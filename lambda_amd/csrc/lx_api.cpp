@@ -43,6 +43,7 @@ lx::DevAids const & lx::dev_aids()
         a.host_threads      = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
         a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
+        a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
         a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);

@@ -926,7 +926,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         pr.k0 = k0;
         pr.k1 = k1;
         // runs of one query slice; padded to 16 slots (one query per wavefront of the 8-lane packed geometry) or, when the
-        // queries have few windows each, to 8 (one query per half wavefront: ~1.4 x the time per slot) -- whichever is less work
+        // queries have few windows each, to 8 (one query per half wavefront, or the 16-lane geometries) -- whichever is less work
         std::vector<uint64_t> & grp = h->xb_grp; // (first position, first slot) of every run + a sentinel
         grp.clear();
         uint64_t slots16 = 0, slots8 = 0, max_q = 1, max_s = 1;
@@ -945,7 +945,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         grp.push_back(k1);
         grp.push_back(0);
         uint64_t const ngroups = grp.size() / 2 - 1;
-        uint64_t const kRun    = (slots8 * 7 < slots16 * 5) ? 8 : 16;
+        uint64_t const kRun    = lx::dev_aids().extend_run ? lx::dev_aids().extend_run : (slots8 * 9 < slots16 * 8) ? 8 : 16; // (a slot of a run of 8 costs ~1.1 x one of a run of 16 on the ragged list of bench.py)
         uint64_t       slots   = 0;
         for (uint64_t g = 0; g <= ngroups; ++g)
         {
