@@ -945,7 +945,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         grp.push_back(k1);
         grp.push_back(0);
         uint64_t const ngroups = grp.size() / 2 - 1;
-        uint64_t const kRun    = lx::dev_aids().extend_run ? lx::dev_aids().extend_run : (slots8 * 9 < slots16 * 8) ? 8 : 16; // (a slot of a run of 8 costs ~1.1 x one of a run of 16 on the ragged list of bench.py)
+        // (measured on the ragged list of bench.py: a slot of a run of 8 costs ~1.1 x one of a run of 16 while the query fits a
+        // panel; wider queries run (8,19) panels with compact codes at 16 and (16,13) panels with int16 pairs at 8 -- the
+        // padded columns and 0.0108 against 0.0156 ms per column, ckpt_cfg_for in lx_api.cpp, decide)
+        double const cost16 = max_q > 208 ? (double)slots16 * (double)((max_q + 151) / 152 * 152) * 1.08 : (double)slots16 * 8.0;
+        double const cost8  = max_q > 208 ? (double)slots8 * (double)((max_q + 207) / 208 * 208) * 1.56 : (double)slots8 * 9.0;
+        uint64_t const kRun = lx::dev_aids().extend_run ? lx::dev_aids().extend_run : cost8 < cost16 ? 8 : 16;
         uint64_t       slots   = 0;
         for (uint64_t g = 0; g <= ngroups; ++g)
         {
