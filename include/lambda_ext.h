@@ -105,7 +105,7 @@ char const * lx_last_error(lx_handle const * h); /* h may be NULL: error of the 
 /* Tuning knobs.  They never change results, only which kernel geometry is launched:
  *   LX_OPT_MAX_QLEN        longest query slice the *_dev calls will see (0 = unknown -> generic geometry)
  *   LX_OPT_QUERY_RUN       promise for the *_dev calls: extensions come in runs of this many consecutive entries
- *                          that share one query slice (must be a multiple of 8; 0 = no promise).  Lets a wavefront
+ *                          that share one query slice (a multiple of 8, or 4 for the multi-query sweep; 0 = no promise).  Lets a wavefront
  *                          build one LDS profile instead of one per extension.  A violated promise is detected on
  *                          the device and reported as LX_ESTATE by lx_synchronize().
  *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB; with
@@ -138,6 +138,12 @@ enum
                                        13.5 KB as int16 pairs) fit LX_OPT_TRACE_BYTES, else mode 1 */
     LX_OPT_EXTEND_CHUNK    = 10, /* extensions per chunk of lx_extend_batch's pipeline (0 = default, ~640 k; at least 1024):
                                    smaller chunks start returning results earlier, larger ones amortise the per-chunk launches */
+    LX_OPT_MQ_SWEEP        = 11, /* multi-query single sweep (ragged seed lists: up to four queries per wavefront, byte profiles
+                                   in LDS): 1 (default) = where LX_OPT_QUERY_RUN is 4 or 8 -- which is what lx_extend_batch
+                                   makes of a list whose queries have few windows each; 2 = for every run that is a multiple
+                                   of 4; 0 = never (runs of 8 / 16 on the one-query-per-wavefront kernels).  Needs what the
+                                   single sweep needs and a scheme in which no substitution costs more than a gap's first
+                                   character (every scheme of the reference with its default gap costs) */
     LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
                                    says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
                                    parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of

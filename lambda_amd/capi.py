@@ -39,6 +39,7 @@ LX_OPT_PACKED_HALF = 7
 LX_OPT_PASS2_MODE = 8
 LX_OPT_BAND = 9
 LX_OPT_EXTEND_CHUNK = 10
+LX_OPT_MQ_SWEEP = 11
 
 
 class Karlin(C.Structure):

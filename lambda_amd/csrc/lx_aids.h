@@ -14,6 +14,7 @@ struct DevAids
     // variable                 meaning                                                                      default
     size_t   pair_lds_limit;    // LX_PAIR_LDS_LIMIT     LDS a wavefront of the packed-half kernel may spend on profiles   24 KiB
     int      force_score_cfg;   // LX_FORCE_SCORE_CFG    pass-1 geometry for every list (-1 = pick by query width)         -1
+    int      force_mq_cfg;      // LX_FORCE_MQ_CFG       multi-query sweep geometry 1 = (8,19), 3 = (8,13), 4 = (8,25) (0 = pick)  0
     int      force_ckpt_cfg;    // LX_FORCE_CKPT_CFG     checkpoint geometry 1 = (8,19), 2 = (16,13) (0 = pick)            0
     bool     trace_overlap;     // LX_TRACE_OVERLAP=1    mode-0 pass 2: forward of chunk k+1 beside the backtrace of k     off
     uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1

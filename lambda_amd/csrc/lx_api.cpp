@@ -32,6 +32,7 @@ lx::DevAids const & lx::dev_aids()
         a.pair_lds_limit    = (size_t)num("LX_PAIR_LDS_LIMIT", 24 * 1024);
         a.force_score_cfg   = (int)num("LX_FORCE_SCORE_CFG", -1);
         a.force_ckpt_cfg    = (int)num("LX_FORCE_CKPT_CFG", 0);
+        a.force_mq_cfg      = (int)num("LX_FORCE_MQ_CFG", 0);
         a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
         a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
         a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
@@ -186,6 +187,37 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
     double const f1 = packed16 ? 0.0108 : 0.070, f2 = packed16 ? 0.0156 : 0.062;
     double const c1 = (double)((max_q + p1 - 1) / p1 * p1) * f1, c2 = (double)((max_q + p2 - 1) / p2 * p2) * f2;
     return c1 < c2 ? 1 : 2;
+}
+
+// Multi-query sweep (lx_sweep_mq.hip): checkpoint geometry for queries of up to max_q columns -- trace cfg 3 = (8,13),
+// 1 = (8,19), 4 = (8,25) -- one panel where one holds the query, else the panel width with the least padded work (columns
+// swept x instructions per column: 3.75 per cell of the recurrence + ~12 per step and lane spread over the strip's columns).
+// lx_host.cpp deals ragged lists to classes with the same function, so a chunk's geometry is the one its class was formed for.
+int mq_cfg_for(uint64_t max_q)
+{
+    int const forced = lx::dev_aids().force_mq_cfg; // development aid
+    if (forced == 1 || forced == 3 || forced == 4)
+        return forced;
+    if (max_q <= 104)
+        return 3;
+    if (max_q <= 152)
+        return 1;
+    if (max_q <= 200)
+        return 4;
+    int    best = 1;
+    double best_cost = 1e30;
+    for (int cfg : {1, 4, 3})
+    {
+        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cfg);
+        double const   C     = (double)panel / 8.0;
+        double const   cost  = (double)((max_q + panel - 1) / panel * panel) * (3.75 * C + 12.0) / C;
+        if (cost < best_cost - 1e-9)
+        {
+            best_cost = cost;
+            best      = cfg;
+        }
+    }
+    return best;
 }
 
 int check_async_error(lx_handle * h)
@@ -526,7 +558,45 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     int      sweep_share = 0;
     bool     half_sweep = false, may_decline = true, wide_compact = false;
     int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
-    if (h->opt_pass2 == 2 && shared && h->trace_ok[slot] && !h->opt_band)
+    // Multi-query sweep (lx_sweep_mq.hip): query runs of 4 or 8 (2 / 4 lane groups per LDS profile) -- what lx_extend_batch
+    // makes of a ragged list --, or any multiple of 4 when LX_OPT_MQ_SWEEP = 2 asks for it.  Needs byte profiles (no
+    // substitution dearer than a gap's first character) and compact codes (that character costs at most 31).
+    bool mq = false;
+    {
+        bool const gaps_ok = -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
+        uint64_t const run = h->opt_query_run;
+        bool const wanted  = h->opt_mq == 2 ? (run != 0 && run % 4 == 0) : h->opt_mq == 1 ? (run == 4 || run == 8) : false;
+        mq = wanted && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && gaps_ok && !h->opt_band;
+    }
+    if (mq)
+    {
+        int smax_entry = 0;
+        for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
+            for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
+                smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+        sweep_cfg    = mq_cfg_for(h->opt_max_qlen);
+        sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
+        mq           = (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535;
+        if (mq)
+        {
+            int const G    = 8;
+            sweep_steps    = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
+            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            sweep_stride   = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+            half_sweep     = true;
+            sweep_share    = (int)std::min<uint64_t>(h->opt_query_run, 16) / 2; // lane groups per query
+            sweep          = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
+            int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) + (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) +
+                                  (smax_entry - h->sc_host[slot].gap_extend) + 2;
+            may_decline = worst > 2046 || sweep_panels > 1;
+            if (sweep && may_decline)
+                ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
+            mq = sweep; // (a batch beyond the slot budget: the per-survivor paths below)
+            if (!sweep)
+                half_sweep = false;
+        }
+    }
+    if (!mq && h->opt_pass2 == 2 && shared && h->trace_ok[slot] && !h->opt_band)
     {
         // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
         sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen, h->opt_f16 && h->opt_query_run % 16 == 0);
@@ -618,7 +688,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         p.score_out      = static_cast<int32_t *>(d_out_score);
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows          = nrows_sc;
-        p.shared_profile = 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query
+        p.shared_profile = mq ? (int)std::min<uint64_t>(h->opt_query_run, 8) : 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query (mq: every run)
         p.cfg            = sweep_cfg;
         if (half_sweep)
         {
@@ -646,7 +716,17 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
             bool const int_sweep = lx::dev_aids().sweep_int; // A/B: the compact sweep in the integer domain
-            if (wide_compact)
+            if (mq)
+            {
+                sp1.ws         = p.ws;
+                sp1.ws_top     = p.ws_top;
+                sp1.ws_cap     = p.ws_cap;
+                sp1.panels_cap = sweep_panels;
+                LX_HIP(h, lx::launch_sweep_mq(sweep_cfg, sp1, stream));
+                if (sweep_panels > 1) // the fix-up launch starts with an empty carry workspace
+                    LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
+            }
+            else if (wide_compact)
             {
                 sp1.ws         = p.ws;
                 sp1.ws_top     = p.ws_top;
@@ -695,7 +775,10 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         pt0.close();
         char buf[200];
         int const nameG = lx::trace_cfg_group(sweep_cfg), nameC = lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg);
-        if (wide_compact)
+        if (mq)
+            snprintf(buf, sizeof(buf), "lx::sweep_mq_kernel<%d,%s> (single sweep, %d queries per wavefront%s)", nameC, sweep_panels > 1 ? "true" : "false",
+                     8 / sweep_share, may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
+        else if (wide_compact)
             snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<%d,%d,true,true,true> (single sweep, compact codes; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
                      nameG, nameC, nameG, nameC);
         else if (half_sweep && may_decline)
@@ -977,6 +1060,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
         case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
         case LX_OPT_EXTEND_CHUNK: h->opt_extend_chunk = value; return LX_OK;
+        case LX_OPT_MQ_SWEEP: h->opt_mq = value > 2 ? 1 : value; return LX_OK;
         case LX_OPT_BAND:
             if (value > (1u << 20))
                 return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
@@ -1002,6 +1086,7 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_PASS2_MODE: *value = h->opt_pass2; return LX_OK;
         case LX_OPT_BAND: *value = h->opt_band; return LX_OK;
         case LX_OPT_EXTEND_CHUNK: *value = h->opt_extend_chunk; return LX_OK;
+        case LX_OPT_MQ_SWEEP: *value = h->opt_mq; return LX_OK;
         default: return LX_EINVAL;
     }
 }
@@ -1072,6 +1157,16 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
         }
     d.trace_ok = trace_ok;
     d.smax     = 0;
+    d.b8_ok    = 1;
+    for (int a = 0; a < lx::kAlph; ++a)
+        for (int b = 0; b < lx::kAlph; ++b)
+        {
+            bool const pad = a >= sc->alphabet_size || b >= sc->alphabet_size;
+            int const  v   = pad ? 0 : sc->matrix[a * LX_ALPH + b] - sc->gap_open;
+            if (v < 0 || v > 255)
+                d.b8_ok = 0;
+            d.mat_b8[a * lx::kAlph + b] = (uint8_t)std::min(std::max(v, 0), 255);
+        }
     for (int a = 0; a < lx::kAlph; ++a)
     {
         int rm = 0;
@@ -1101,6 +1196,7 @@ int lx_set_scoring(lx_handle * h, int slot, lx_scoring const * sc)
     h->sc_host[slot] = *sc;
     h->have_sc[slot] = true;
     h->trace_ok[slot] = trace_ok != 0;
+    h->b8_ok[slot]    = d.b8_ok != 0;
     return LX_OK;
 }
 

@@ -28,10 +28,14 @@ struct ScoringDev
     // packed-half pass 1 (lx_score_f16.hip): (matrix - ge) as IEEE half bits, pad ranks = -100; per query rank the
     // largest positive score of its row (upper bound of what one query column can contribute); largest entry
     int32_t  smax;
-    int32_t  reserved[2];
+    int32_t  b8_ok;       // mat_b8 is valid: every real entry satisfies 0 <= matrix - go <= 255
+    int32_t  reserved;
     int16_t  rowmax[kAlph];
     uint16_t mat_h[kAlph * kAlph];
     int16_t  mat_i16[kAlph * kAlph]; // packed-int16 sweep (lx_score_i16.hip): matrix - ge, pad ranks = kNegPad
+    // multi-query sweep (lx_sweep_mq.hip): matrix[q*32+s] - go as an unsigned byte (go = cost of a gap's first character),
+    // pad ranks = 0 -- a pad cell scores like opening a gap
+    uint8_t  mat_b8[kAlph * kAlph];
 };
 
 // Mirrors lx_extension in include/lambda_ext.h (static_assert'ed in lx_api.cpp).

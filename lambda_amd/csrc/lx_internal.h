@@ -53,6 +53,8 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p, hipStream_t stream);
 hipError_t launch_sweep_pair16(int trace_cfg, ScoreParams const & p, hipStream_t stream);
 hipError_t launch_score_pair16(ScoreParams const & p, hipStream_t stream);
 hipError_t launch_sweep_pair16_compact(int trace_cfg, ScoreParams const & p, hipStream_t stream);
+hipError_t launch_sweep_mq(int trace_cfg, ScoreParams const & p, hipStream_t stream);
+size_t     sweep_mq_lds_bytes(int trace_cfg, int nrows, int share);
 hipError_t launch_prefilter(PrefilterParams const & p, hipStream_t stream);
 hipError_t launch_rle_pack(PackParams const & p, hipStream_t stream);
 } // namespace lx
@@ -130,6 +132,7 @@ struct lx_handle
 
     bool             have_sc[2] = {false, false};
     bool             trace_ok[2] = {false, false};
+    bool             b8_ok[2]    = {false, false}; // byte profiles of lx_sweep_mq.hip apply (no substitution dearer than a gap's first character)
     lx_scoring       sc_host[2];
     lx::ScoringDev * sc_dev[2] = {nullptr, nullptr};
 
@@ -147,6 +150,7 @@ struct lx_handle
     uint64_t opt_trace_bytes = 64ull << 30;
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
+    uint64_t opt_mq        = 1; // LX_OPT_MQ_SWEEP
     uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
     uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
     int32_t const * band_dev = nullptr;  // lx_set_band_centres_dev: the caller's device array for the *_dev calls

@@ -1,0 +1,617 @@
+// lx_sweep_mq.hip -- the single sweep for RAGGED seed lists: up to four queries per wavefront, byte profiles (gfx950 only).
+//
+// Same reference seam as lx_score_f16.hip / lx_score_i16.hip (_performAlignment, /root/reference/src/search_algo.hpp:1070-1134:
+// pass 1 at :1246 and the forward half of pass 2 at :1296 as one sweep), same strip-systolic mapping, same row-skewed
+// recurrence on packed 16-bit integers whose maxima run through the half-precision comparators (lx_score_i16.hip's header).
+// What is new is the unit a wavefront serves.  The list lambda hands over after _widenAndPreprocessMatches (:1136-1175) has
+// a dozen windows per query on average, a tenth of them merged ones of up to three times the length: a wavefront that must
+// hold 16 windows of ONE query (the LDS profile is the query's) runs half empty and as long as its longest window.  Here a
+// wavefront's eight lane groups are dealt to `share` = 1, 2, 4 or 8 sub-blocks of 16 / 8 / 4 / 2 windows, each with its own
+// query and its own profile slot, so that the host can sort sub-blocks by length across queries (lx_host.cpp).
+//
+// That needs profiles a quarter the size -- four of them must fit next to each other at full occupancy:
+//   * a profile entry is ONE BYTE, the non-negative integer  s(q, t) - ge - (go - ge) = s(q, t) - go  (go = cost of a gap's
+//     first character: applicable when no substitution costs more than opening a gap, which every BLOSUM / nucleotide /
+//     bisulfite scheme of the reference satisfies with its default gap costs); 152 columns x 28 letters = 4.4 KB instead of
+//     10.5 KB.  One v_perm_b32 per column -- the instruction that interleaved the two extensions' halves before -- now picks
+//     byte k of the two letters' rows and zero-extends both;
+//   * the extra (go - ge) is not subtracted again: the diagonal operand of the next row is the gap-open candidate
+//     A = H + (go - ge), which the recurrence computes anyway, so the lanes keep A[row - 1][c] instead of H[row - 1][c] and
+//     hand A of their last column to the right.  7.5 packed instructions per two cells, as before;
+//   * pad letters (rows beyond the window, columns beyond the query) have entry 0, i.e. score like a gap's first character:
+//     such a cell is never above its neighbours, so it can neither start, nor extend, nor end a best local alignment.
+// Slots are the compact 16-bit codes of Ckpt16Layout (one part per panel); an extension whose best score is beyond 2046
+// leaves the sentinel and is redone by the int32 launch into an overflow slot, like a wavefront the range test declines.
+#include <hip/hip_runtime.h>
+
+#include "lx_dp_common.h"
+
+namespace lx
+{
+namespace
+{
+
+typedef unsigned short q2 __attribute__((ext_vector_type(2)));
+typedef _Float16       qf2 __attribute__((ext_vector_type(2)));
+
+// integer maxima of patterns in 0 .. 0x7BFF through the half-precision comparators (lx_score_i16.hip)
+__device__ __forceinline__ q2 qmax(q2 a, q2 b)
+{
+    return __builtin_bit_cast(q2, __builtin_elementwise_maximum(__builtin_bit_cast(qf2, a), __builtin_bit_cast(qf2, b)));
+}
+__device__ __forceinline__ q2 qmax3(q2 a, q2 b, q2 c)
+{
+    return __builtin_bit_cast(q2, __builtin_elementwise_maximum(__builtin_elementwise_maximum(__builtin_bit_cast(qf2, a), __builtin_bit_cast(qf2, b)),
+                                                                __builtin_bit_cast(qf2, c))); // v_pk_maximum3_f16
+}
+__device__ __forceinline__ q2 qsplat(int x) { return q2{(unsigned short)x, (unsigned short)x}; }
+__device__ __forceinline__ q2 as_q2(uint32_t x) { return __builtin_bit_cast(q2, x); }
+__device__ __forceinline__ uint32_t qbits(q2 x) { return __builtin_bit_cast(uint32_t, x); }
+
+constexpr int kMqBias  = 2048;             // keeps every finite skewed value positive
+constexpr int kMqLimit = 0x7BFF - kMqBias; // every finite intermediate stays below this
+
+template <int C>
+struct MqGeo
+{
+    static constexpr int G       = 8;
+    static constexpr int kGroups = 8;           // lane groups per wavefront, two extensions each
+    static constexpr int kPanel  = G * C;
+    static constexpr int kD      = (C + 3) / 4; // profile dwords (4 byte entries each) per lane and letter
+    static constexpr int kRowDw  = kD * G;
+    // a lane's dwords of a row: one 16-byte piece, one 8-byte piece, one 4-byte piece (whichever kD needs), each piece
+    // lane-contiguous so that it is read with one aligned ds_read_b128 / b64 / b32
+    static constexpr int kN4 = kD / 4, kN2 = (kD % 4) / 2, kN1 = kD % 2;
+    static constexpr int kBase2 = 4 * G * kN4, kBase1 = kBase2 + 2 * G * kN2;
+    static_assert(kD <= 7, "at most 28 columns per strip");
+    __host__ __device__ static constexpr int dw_index(int d, int g)
+    {
+        return d < 4 * kN4 ? g * 4 + d : d < 4 * kN4 + 2 * kN2 ? kBase2 + g * 2 + (d - 4 * kN4) : kBase1 + g;
+    }
+};
+
+} // namespace
+
+// MULTI: queries wider than one panel -- the panels are swept one after the other, the (A, E) pair of the last strip per
+// subject row goes through lx_score.hip's carry workspace, every panel writes its own part of the extension's slot.
+template <int C, bool MULTI>
+__global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
+{
+    using Geo = MqGeo<C>;
+    using L16 = Ckpt16Layout<8, C>;
+    constexpr int G = 8;
+    extern __shared__ uint32_t lds[];
+
+    int const  lane     = threadIdx.x;
+    int const  grp      = lane / G;
+    int const  g        = lane % G;
+    bool const is_first = (g == 0);
+    bool const is_last  = (g == G - 1);
+
+    uint64_t const pair = (uint64_t)blockIdx.x * Geo::kGroups + grp;
+    uint64_t const eA   = 2 * pair, eB = 2 * pair + 1;
+    bool const     actA = eA < p.n, actB = eB < p.n;
+
+    ScoringDev const * __restrict__ sc = p.sc;
+    int const      ge    = sc->ge;
+    int const      nrows = p.nrows;
+    uint32_t const padt  = (uint32_t)(nrows - 1);
+
+    int             lq = 0, lsA = 0, lsB = 0;
+    uint8_t const * q  = p.q_res;
+    uint8_t const * sA = p.s_res;
+    uint8_t const * sB = p.s_res;
+    uint64_t        q_off = 0;
+    if (actA)
+    {
+        Extension const x = p.ext[eA];
+        lq    = (int)x.q_len;
+        q_off = x.q_off;
+        q += x.q_off;
+        lsA = (int)x.s_len;
+        if (lsA != 0)
+            sA += x.s_off;
+    }
+    uint64_t q_offB = q_off;
+    int      lqB    = lq;
+    if (actB)
+    {
+        Extension const x = p.ext[eB];
+        lqB    = (int)x.q_len;
+        q_offB = x.q_off;
+        lsB    = (int)x.s_len;
+        if (lsB != 0)
+            sB += x.s_off;
+    }
+    // p.pair_share lane groups (0 = all eight) use one LDS profile: the extensions of such a sub-block share the query
+    int const share_g = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
+    int const blk     = grp / share_g;
+    {
+        // the caller promised one query per sub-block: verify against the sub-block's first lane, fail loudly otherwise
+        int const      leader  = blk * share_g * G;
+        uint64_t const q0      = ((uint64_t)(uint32_t)__shfl((int)(q_off >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)q_off, leader);
+        int const      l0      = __shfl(lq, leader);
+        bool const     lead_in = __shfl(actA ? 1 : 0, leader) != 0;
+        if (lead_in && ((actA && (q_off != q0 || lq != l0)) || (actB && (q_offB != q0 || lqB != l0))))
+            atomicExch(p.err, 2);
+    }
+
+    int ls_max = max(lsA, lsB);
+    int ls_min = min(actA ? lsA : 0x7fffffff, actB ? lsB : 0x7fffffff);
+    int lq_max = lq;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1)
+    {
+        ls_max = max(ls_max, __shfl_xor(ls_max, off));
+        ls_min = min(ls_min, __shfl_xor(ls_min, off));
+        lq_max = max(lq_max, __shfl_xor(lq_max, off));
+    }
+    ls_max = __builtin_amdgcn_readfirstlane(ls_max);
+    ls_min = __builtin_amdgcn_readfirstlane(ls_min);
+    lq_max = __builtin_amdgcn_readfirstlane(lq_max);
+    int const steps   = (ls_max + G - 1 + 3) & ~3;
+    // the sub-blocks of a wavefront may differ in width (the host deals them by geometry class, so they rarely do): all of
+    // them sweep as many panels as the widest needs, the narrower ones over pad columns
+    int const npanels = MULTI ? max(1, (lq_max + Geo::kPanel - 1) / Geo::kPanel) : 1;
+
+    // ---- range test (wave-uniform): an upper bound of every finite intermediate must stay below the limit -- the codes'
+    // 2046 for one panel (tested up front), the 16-bit patterns' for wider queries (their codes are tested afterwards)
+    int bound = 0;
+    for (int pn = 0; pn < npanels; ++pn)
+    {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+            int const j = pn * Geo::kPanel + g * C + c;
+            if (j < lq)
+                bound += sc->rowmax[q[j] & (kAlph - 1)];
+        }
+    }
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1)
+        bound += __shfl_xor(bound, off);
+    bool const broken  = (lq_max > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > p.steps_cap;
+    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (MULTI ? kMqLimit : 2046)) != 0 ||
+                         (-ge) * (G + 2) + (-sc->g2) * 2 + 256 > kMqBias;
+    if (too_big)
+    {
+        // left to the int32 launch (TraceParams::fixup): sentinel -1; a broken length promise is reported here as well,
+        // because that launch is skipped when no query the promise admits can fail the test
+        if (broken && lane == 0)
+            atomicExch(p.err, 3);
+        if (is_first)
+        {
+            EndCell none{};
+            none.score = -1;
+            if (actA)
+            {
+                p.out_score[eA] = -1;
+                p.ends[eA]      = none;
+            }
+            if (actB)
+            {
+                p.out_score[eB] = -1;
+                p.ends[eB]      = none;
+            }
+        }
+        return;
+    }
+
+    // carry workspace for multi-panel queries: one (packed A, packed E) pair per subject row and lane group
+    uint32_t * carry   = nullptr;
+    int const  ls_pair = max(lsA, lsB);
+    if constexpr (MULTI)
+    {
+        if (npanels > 1)
+        {
+            uint32_t base = 0;
+            int      ok   = 1;
+            if (is_first && actA)
+            {
+                base = atomicAdd(p.ws_top, (uint32_t)ls_pair);
+                if (base + (uint32_t)ls_pair > p.ws_cap)
+                {
+                    ok = 0;
+                    atomicExch(p.err, 1);
+                }
+            }
+#pragma unroll
+            for (int off = G / 2; off >= 1; off >>= 1) // broadcast lane g == 0's values through the group
+            {
+                base = max(base, (uint32_t)__shfl_xor((int)base, off));
+                ok   = min(ok, __shfl_xor(ok, off));
+            }
+            if (ok)
+                carry = reinterpret_cast<uint32_t *>(p.ws) + 2ull * base;
+        }
+    }
+    bool const writable = !MULTI || npanels == 1 || carry != nullptr; // (workspace exhausted: reported, nothing kept)
+
+    constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
+    int const          nslots    = Geo::kGroups / share_g;
+    uint32_t const     slot_dw   = (uint32_t)blk * (uint32_t)(nrows * Geo::kRowDw);
+    uint32_t const     slot_byte = slot_dw * 4u;
+    uint64_t const     panel_dw  = L16::slot_dwords(p.steps_cap);
+    uint32_t * const   stage     = lds + nslots * (nrows * Geo::kRowDw) + lane; // [step % 8][lane]: lane-minor, conflict-free
+
+    q2 const GE = qsplat(ge), G2 = qsplat(sc->g2), NGE = qsplat(-ge);
+    // over the panels swept so far, per extension: best strip value, its (global) strip, first row, "met again later"
+    int runA = 0, stripA = 0, rrowA = 0, rtieA = 0, runB = 0, stripB = 0, rrowB = 0, rtieB = 0;
+
+    for (int panel = 0; panel < npanels; ++panel)
+    {
+        int const col0 = panel * Geo::kPanel + g * C;
+        // ---- profile: prof[slot][t][piece][g] = bytes (s(q_col, t) - go) of the lane's columns, four per dword.  The lane
+        // groups of a sub-block share the work: group r writes the letters 4w .. 4w+3 with w % share == r.
+        {
+            int const r = grp % share_g;
+#pragma unroll 1
+            for (int d = 0; d < Geo::kD; ++d)
+            {
+                uint32_t rows[4][8];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+                {
+                    int const c  = 4 * d + cc;
+                    int const j  = col0 + c;
+                    uint32_t  ql = kAlph - 1; // pad rank: a row of zeros
+                    if (c < C && j < lq)
+                        ql = q[j] & (kAlph - 1);
+                    uint4 const * mrow = reinterpret_cast<uint4 const *>(sc->mat_b8 + ql * kAlph);
+                    uint4 const   lo = mrow[0], hi = mrow[1];
+                    rows[cc][0] = lo.x; rows[cc][1] = lo.y; rows[cc][2] = lo.z; rows[cc][3] = lo.w;
+                    rows[cc][4] = hi.x; rows[cc][5] = hi.y; rows[cc][6] = hi.z; rows[cc][7] = hi.w;
+                }
+                uint32_t * dst = lds + slot_dw + Geo::dw_index(d, g);
+#pragma unroll
+                for (int w = 0; w < 8; ++w)
+                {
+                    if (4 * w < nrows && (w % share_g) == r)
+                    {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                        {
+                            // byte b of the matrix rows of columns 0..3 -> one dword [c0,c1,c2,c3] for subject letter 4w+b
+                            uint32_t const sel = (uint32_t)b | ((uint32_t)(4 + b) << 8) | 0x0c0c0000u;
+                            uint32_t const x01 = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
+                            uint32_t const x23 = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
+                            dst[(4 * w + b) * Geo::kRowDw] = x01 | (x23 << 16);
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
+        bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
+        // (an idle half owns the spare slot p.n -- the stores are unconditional)
+        uint32_t * const slotA = p.ckpt + (actA ? eA : p.n) * p.ckpt_stride + (uint64_t)panel * panel_dw;
+        uint32_t * const slotB = p.ckpt + (actB ? eB : p.n) * p.ckpt_stride + (uint64_t)panel * panel_dw;
+
+        q2 Z = qsplat(ge * g + kMqBias); // z_i of the first processed row i = -g, biased
+        q2 Arow[C], F0[C];               // A = H + (go - ge) of the previous row (its frame), folded F of this row
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+        {
+            Arow[c] = Z + GE + G2;
+            F0[c]   = Z;
+        }
+        q2 diag0 = Z + GE + G2;
+        q2 sendA = Z + GE + G2;
+        q2 sendE = as_q2(0u);
+        q2 best  = qsplat(0);
+        // first row that reached this strip's best value, "a later row reached it again" (bit 0 = A, bit 1 = B)
+        int      rowA = 0, rowB = 0;
+        uint32_t tie  = 0;
+        q2       cmax = qsplat(0); // best un-skewed (and unbiased: >= 0) row maximum of the current chunk
+
+        // one DP step at step index k = k0 + u (row k - g of this lane's strip)
+        auto step = [&](uint32_t tA, uint32_t tB, int k, int u)
+        {
+            char const * const ra = reinterpret_cast<char const *>(lds) + slot_byte + tA * kRowBytes;
+            char const * const rb = reinterpret_cast<char const *>(lds) + slot_byte + tB * kRowBytes;
+            uint32_t           pa[Geo::kD], pb[Geo::kD];
+            if constexpr (Geo::kN4 != 0)
+            {
+                uint4 const va = *reinterpret_cast<uint4 const *>(ra + g * 16), vb = *reinterpret_cast<uint4 const *>(rb + g * 16);
+                pa[0] = va.x; pa[1] = va.y; pa[2] = va.z; pa[3] = va.w;
+                pb[0] = vb.x; pb[1] = vb.y; pb[2] = vb.z; pb[3] = vb.w;
+            }
+            if constexpr (Geo::kN2 != 0)
+            {
+                uint2 const va = *reinterpret_cast<uint2 const *>(ra + Geo::kBase2 * 4 + g * 8), vb = *reinterpret_cast<uint2 const *>(rb + Geo::kBase2 * 4 + g * 8);
+                pa[4 * Geo::kN4] = va.x; pa[4 * Geo::kN4 + 1] = va.y;
+                pb[4 * Geo::kN4] = vb.x; pb[4 * Geo::kN4 + 1] = vb.y;
+            }
+            if constexpr (Geo::kN1 != 0)
+            {
+                pa[Geo::kD - 1] = *reinterpret_cast<uint32_t const *>(ra + Geo::kBase1 * 4 + g * 4);
+                pb[Geo::kD - 1] = *reinterpret_cast<uint32_t const *>(rb + Geo::kBase1 * 4 + g * 4);
+            }
+
+            // left boundary: H[i][-1] = 0 (skewed: z; as A: z + (go - ge)), E = -inf; or the previous panel's last column
+            uint32_t bndA = qbits(Z + G2), bndE = 0u;
+            if constexpr (MULTI)
+            {
+                int const i = k - g;
+                if (use_carry_in && (unsigned)i < (unsigned)ls_pair)
+                {
+                    bndA = carry[2 * i];
+                    bndE = carry[2 * i + 1];
+                }
+            }
+            q2 const recvA = as_q2((uint32_t)shift_from_left<G>((int)qbits(sendA), (int)bndA, is_first));
+            q2       Ecur  = as_q2((uint32_t)shift_from_left<G>((int)qbits(sendE), (int)bndE, is_first));
+            q2       dg    = diag0;
+            diag0          = recvA;
+
+            q2 const ZN     = Z + NGE;
+            q2       rowmax = as_q2(0u);
+            q2       h      = Z, hprev = Z, A = Z;
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+            {
+                // (entry of column c vs letter tA | entry of column c vs letter tB), zero-extended bytes
+                uint32_t const sel = 0x0c000c00u | (uint32_t)(c & 3) | ((uint32_t)(4 + (c & 3)) << 16);
+                q2 const       sub = as_q2(__builtin_amdgcn_perm(pb[c >> 2], pa[c >> 2], sel));
+                q2 const       tt  = dg + sub;
+                dg                 = Arow[c];
+                hprev              = h;
+                h                  = qmax3(tt, Ecur, F0[c]);
+                A                  = h + G2;
+                F0[c]              = qmax3(F0[c], A, ZN);
+                Ecur               = qmax(Ecur, A) + GE;
+                Arow[c]            = A;
+                if (c & 1)
+                    rowmax = qmax3(rowmax, hprev, h);
+            }
+            if (C & 1)
+                rowmax = qmax(rowmax, h);
+            sendA = A;
+            sendE = Ecur;
+            if constexpr (MULTI)
+            {
+                int const i = k - g;
+                if (do_carry_out && (unsigned)i < (unsigned)ls_pair)
+                {
+                    carry[2 * i]     = qbits(sendA);
+                    carry[2 * i + 1] = qbits(sendE);
+                }
+            }
+            cmax = qmax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
+            // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
+            // Ckpt16Layout codes of both extensions: H | (H - E) << 11
+            stage[((k & 4) + u) * 64] = (qbits(h - Ecur) << 11) | qbits(h - Z);
+            Z = ZN;
+        };
+        // the staged codes of the eight steps up to k0 + 3 leave, re-paired per extension (whole 128-byte lines per lane
+        // group, no branch around the stores)
+        auto flush_codes = [&](int k0)
+        {
+            uint32_t cw[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x)
+                cw[x] = stage[x * 64];
+            uint32_t const oi = L16::bnd_oct_index((uint32_t)k0 / 8, (uint32_t)g);
+            reinterpret_cast<uint4 *>(slotA)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x05040100u), __builtin_amdgcn_perm(cw[3], cw[2], 0x05040100u),
+                                                              __builtin_amdgcn_perm(cw[5], cw[4], 0x05040100u), __builtin_amdgcn_perm(cw[7], cw[6], 0x05040100u));
+            reinterpret_cast<uint4 *>(slotB)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x07060302u), __builtin_amdgcn_perm(cw[3], cw[2], 0x07060302u),
+                                                              __builtin_amdgcn_perm(cw[5], cw[4], 0x07060302u), __builtin_amdgcn_perm(cw[7], cw[6], 0x07060302u));
+        };
+        // the row checkpoint behind step k0 + 3 (k0 % 16 == 12), issued at the top of the next chunk
+        auto rowck_codes = [&](int k0)
+        {
+            // Arow - (go - ge) = H is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next
+            // row's:  H - F un-skewed = (H - z_i) - (F0 - Z) = H - F0 - ge
+            q2 const ziA = Z + GE + G2, geA = GE + G2;
+            uint32_t code[2 * L16::kCkDw];
+#pragma unroll
+            for (int c = 0; c < 2 * L16::kCkDw; ++c)
+                code[c] = c < C ? ((qbits((Arow[c < C ? c : 0] - F0[c < C ? c : 0]) - geA) << 11) | qbits(Arow[c < C ? c : 0] - ziA)) : 0u;
+            uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4);
+            uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+#pragma unroll
+            for (int x = 0; x < L16::kCkDw / 4; ++x)
+            {
+                uint32_t wa[4], wb[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                {
+                    int const c = 2 * (4 * x + b); // columns c, c + 1 of extension A (low halves) / B (high halves)
+                    wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
+                    wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
+                }
+                uint32_t const qi = L16::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, (uint32_t)x);
+                dA[qi] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                dB[qi] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            }
+        };
+        auto chunk_done = [&](int k0)
+        {
+            // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
+            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and columns
+            // beyond the query stay strictly below a positive best: no validity test.
+            q2 const       nb   = qmax(best, cmax);
+            uint32_t const rose = qbits(nb) ^ qbits(best), met = qbits(cmax) ^ qbits(best);
+            bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
+            bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
+            int const      last = k0 + 3 - g; // the chunk's last row in this lane
+            rowA = gtA ? last : rowA;
+            rowB = gtB ? last : rowB;
+            tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
+            tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+            best = nb;
+            cmax = qsplat(0);
+            if (k0 & 4)
+                flush_codes(k0);
+        };
+
+        uint32_t const lscA = (uint32_t)max(lsA, 1) - 1u, lscB = (uint32_t)max(lsB, 1) - 1u;
+        auto fetch_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
+        {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                uint32_t const i = (uint32_t)(k0 + u - g);
+                ta[u]            = sA[min(i, lscA)];
+                tb[u]            = sB[min(i, lscB)];
+            }
+        };
+        auto mask_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
+        {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+            {
+                uint32_t const i = (uint32_t)(k0 + u - g);
+                ta[u]            = (i < (uint32_t)lsA) ? (ta[u] & (kAlph - 1)) : padt;
+                tb[u]            = (i < (uint32_t)lsB) ? (tb[u] & (kAlph - 1)) : padt;
+            }
+        };
+
+        int const steady_lo = (G - 1 + 3) & ~3;
+        int const steady_hi = ls_min - 3;
+        uint8_t const * spA = sA - g;
+        uint8_t const * spB = sB - g;
+
+        int      k0 = 0;
+        uint32_t na[4], nb[4];
+        fetch_checked(0, na, nb);
+        while (k0 < steps)
+        {
+            bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
+            if (!cur_steady)
+            {
+                if (k0 != 0 && (k0 & 15) == 0)
+                    rowck_codes(k0 - 4);
+                uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
+                mask_checked(k0, ca, cb);
+                fetch_checked(k0 + 4, na, nb);
+#pragma unroll 2
+                for (int u = 0; u < 4; ++u)
+                    step(ca[u], cb[u], k0 + u, u);
+                chunk_done(k0);
+                k0 += 4;
+            }
+            else
+            {
+                uint32_t wa = *reinterpret_cast<unaligned_u32 const *>(spA + k0);
+                uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
+                while (k0 < steady_hi)
+                {
+                    if ((k0 & 15) == 0) // (k0 >= steady_lo > 0)
+                        rowck_codes(k0 - 4);
+                    uint32_t const ca = wa, cb = wb;
+                    int const      kn = max(min(k0 + 4, ls_min - 4), 0);
+                    wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
+                    wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
+#pragma unroll 2
+                    for (int u = 0; u < 4; ++u)
+                        step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), k0 + u, u);
+                    chunk_done(k0);
+                    k0 += 4;
+                }
+                fetch_checked(k0, na, nb);
+            }
+        }
+        if (steps != 0 && (steps & 15) == 0)
+            rowck_codes(steps - 4);
+        if (steps & 4)
+            flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
+
+        // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first).
+        // Over the panels a later one only wins with a strictly greater value (its columns come later).
+        auto merge = [&](int lbest, int lrow, int ltie, int & run, int & rstrip, int & rrow, int & rtie)
+        {
+            int gbest = lbest, gstrip = g, grow = lrow, gtie = ltie;
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1)
+            {
+                int const  ob = __shfl_xor(gbest, off), os = __shfl_xor(gstrip, off), orow = __shfl_xor(grow, off), ot = __shfl_xor(gtie, off);
+                bool const take = ob > gbest || (ob == gbest && os < gstrip);
+                gbest  = take ? ob : gbest;
+                gstrip = take ? os : gstrip;
+                grow   = take ? orow : grow;
+                gtie   = take ? ot : gtie;
+            }
+            bool const take = gbest > run;
+            run    = take ? gbest : run;
+            rstrip = take ? panel * G + gstrip : rstrip;
+            rrow   = take ? grow : rrow;
+            rtie   = take ? gtie : rtie;
+        };
+        merge((int)best.x, rowA, (int)(tie & 1u), runA, stripA, rrowA, rtieA);
+        merge((int)best.y, rowB, (int)((tie >> 1) & 1u), runB, stripB, rrowB, rtieB);
+
+        if constexpr (MULTI)
+        {
+            if (npanels > 1)
+            {
+                // make this panel's carry stores visible to the next panel's loads (same wave, other lanes)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } // panels
+
+    auto finish = [&](int run, int rstrip, int rrow, int rtie, bool act, uint64_t e)
+    {
+        if (is_first && act)
+        {
+            EndCell ec{};
+            bool const declined = MULTI && run > 2046; // beyond what the codes hold: the int32 launch redoes it
+            if (!writable || declined)
+                ec.score = -1;
+            else if (run > 0)
+            {
+                ec.score = run;
+                ec.q_end = -(rstrip + 1); // the backtrace finds the column inside this strip
+                ec.s_end = rrow + 1;
+                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact;
+            }
+            p.ends[e]      = ec;
+            p.out_score[e] = (writable && !declined) ? run : -1;
+        }
+    };
+    finish(runA, stripA, rrowA, rtieA, actA, eA);
+    finish(runB, stripB, rrowB, rtieB, actB, eB);
+}
+
+template <int C>
+static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
+{
+    using Geo = MqGeo<C>;
+    uint64_t const blocks = (p.n + 2ull * Geo::kGroups - 1) / (2ull * Geo::kGroups);
+    int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
+    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0)
+        return hipErrorInvalidValue;
+    size_t const lds = ((size_t)(Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+    if (p.panels_cap > 1)
+        hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    else
+        hipLaunchKernelGGL((sweep_mq_kernel<C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+// trace cfg 1 = (8,19), 3 = (8,13), 4 = (8,25): the geometries lx_ckpt.hip's compact layout is instantiated for with
+// 8-lane groups.  p.pair_share = lane groups per query (1, 2, 4; 0 or 8 = one query per wavefront); the slots are the
+// compact codes of Ckpt16Layout<8, C>, p.panels_cap parts each.
+hipError_t launch_sweep_mq(int trace_cfg, ScoreParams const & p, hipStream_t stream)
+{
+    if (p.n == 0)
+        return hipSuccess;
+    return trace_cfg == 1 ? launch_sweep_mq_cfg<19>(p, stream) : trace_cfg == 3 ? launch_sweep_mq_cfg<13>(p, stream) : trace_cfg == 4 ? launch_sweep_mq_cfg<25>(p, stream) : hipErrorInvalidValue;
+}
+
+// LDS bytes of one wavefront (profiles + staging)
+size_t sweep_mq_lds_bytes(int trace_cfg, int nrows, int share)
+{
+    int const C = trace_cfg == 1 ? 19 : trace_cfg == 3 ? 13 : 25;
+    int const s = (share > 0 && share < 8) ? share : 8;
+    return ((size_t)(8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
+}
+
+} // namespace lx

@@ -1,0 +1,159 @@
+"""GPU parity of the multi-query single sweep (lambda_amd/csrc/lx_sweep_mq.hip) through lx_extend_batch_dev: query runs of
+4 / 8 / 16 slots (four / two / one query per wavefront), byte profiles, every strip geometry, one and several panels, ragged
+window lengths -- scores, end / begin cells and ops bit-exact against the oracle.  The seam is _performAlignment,
+/root/reference/src/search_algo.hpp:1070-1134 (called at :1246 and :1296)."""
+import numpy as np
+import pytest
+
+from lambda_amd import capi, synth
+from tests import oracle_lib
+from tests.test_gpu_score import SCHEMES
+
+pytestmark = pytest.mark.gpu
+
+
+def pack_runs(ext, run, rng=None):
+    """Slots for LX_OPT_QUERY_RUN = run: every query's windows sorted by length and cut into sub-blocks of `run`, the last one
+    filled with copies of its last window (what lx_extend_batch does, and what the reference does with its SIMD batches,
+    src/search_algo.hpp:1063-1067); sub-blocks ordered by (query length class, longest window).  Returns (slots, src) with
+    src[k] = index into ext, -1 for a filler."""
+    order = np.lexsort((ext["s_len"], ext["q_len"], ext["q_off"]))
+    blocks = []
+    k = 0
+    while k < len(order):
+        kk = k
+        while kk < len(order) and ext["q_off"][order[kk]] == ext["q_off"][order[k]] and ext["q_len"][order[kk]] == ext["q_len"][order[k]]:
+            kk += 1
+        for j in range(k, kk, run):
+            idx = list(order[j:min(kk, j + run)])
+            src = idx + [-1] * (run - len(idx))
+            idx = idx + [idx[-1]] * (run - len(idx))
+            blocks.append((int(ext["s_len"][idx].max()), idx, src))
+        k = kk
+    blocks.sort(key=lambda b: b[0])
+    slots = np.concatenate([ext[b[1]] for b in blocks])
+    src = np.concatenate([np.array(b[2]) for b in blocks])
+    return slots, src
+
+
+def run_fused(handle, q, s, slots, run, cutoff, mq=2):
+    import torch
+
+    n = len(slots)
+    dev = torch.device("cuda:0")
+    pad = np.zeros(256, np.uint8)
+    d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+    d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+    d_ext = torch.from_numpy(slots.view(np.uint8).copy()).to(dev)
+    sizes = slots["q_len"].astype(np.uint64) + slots["s_len"].astype(np.uint64)
+    off = np.zeros(n, dtype=np.uint64)
+    off[1:] = np.cumsum(sizes)[:-1]
+    d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+    d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+    d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+    d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+    handle.set_option(capi.LX_OPT_MAX_QLEN, int(slots["q_len"].max()))
+    handle.set_option(capi.LX_OPT_MAX_SLEN, int(slots["s_len"].max()))
+    handle.set_option(capi.LX_OPT_QUERY_RUN, run)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    handle.set_option(capi.LX_OPT_MQ_SWEEP, mq)
+    torch.cuda.synchronize()
+    try:
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, cutoff, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+        name = handle.last_trace_kernel_name()
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_option(capi.LX_OPT_MQ_SWEEP, 1)
+    hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+    return d_score.cpu().numpy(), hsp, d_ops.cpu().numpy(), off, d_count.cpu().numpy(), name
+
+
+def check_against_oracle(oracle, osc, q, s, slots, cutoff, got_score, hsp, ops, off, cnt):
+    want_score = oracle.score_batch(q, s, slots, osc, threads=8)
+    bad = np.nonzero(got_score != want_score)[0]
+    assert len(bad) == 0, (bad[:10], got_score[bad[:10]], want_score[bad[:10]], slots[bad[:10]])
+    surv = np.nonzero(want_score >= cutoff)[0]
+    assert cnt[1] == len(surv) and len(surv) > 5
+    rejected = np.setdiff1d(np.arange(len(slots)), surv)
+    assert (hsp["score"][rejected] == want_score[rejected]).all() and (hsp["n_ops"][rejected] == 0).all()
+    for i, (oh, oops) in zip(surv, oracle.align_batch(q, s, slots[surv], osc)):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, slots[i])
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, (i, slots[i])
+
+
+@pytest.mark.parametrize("run", [4, 8, 16])
+@pytest.mark.parametrize("lq_range,expect", [((30, 104), "sweep_mq_kernel<13,false>"), ((105, 152), "sweep_mq_kernel<19,false>"),
+                                             ((153, 200), "sweep_mq_kernel<25,false>"), ((209, 304), "sweep_mq_kernel<19,true>"),
+                                             ((330, 400), "sweep_mq_kernel<25,true>"), ((401, 440), "sweep_mq_kernel<19,true>")])
+def test_mq_sweep_ragged_lists(handle, oracle, run, lq_range, expect):
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(40 if lq_range[1] <= 208 else 16, seed=77 + run + lq_range[0], lq_range=lq_range, mean_windows=5.0,
+                                           merged_frac=0.15)
+    slots, src = pack_runs(ext, run)
+    cutoff = 60
+    got = run_fused(handle, q, s, slots, run, cutoff)
+    assert expect in got[5], got[5]
+    assert f"{16 // run} queries per wavefront" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
+
+
+@pytest.mark.parametrize("scheme", ["nucl", "bs_fwd", "bs_rev", "blosum45", "blosum80"])
+def test_mq_sweep_other_schemes(handle, oracle, scheme):
+    sc_p = SCHEMES[scheme] if scheme in SCHEMES else capi.builtin_scoring(int(scheme[6:]), gap_open=-11, gap_extend=-1)
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    nuc = scheme in ("nucl", "bs_fwd", "bs_rev")
+    alphabet = np.arange(4, dtype=np.uint8) if nuc else synth.STD20
+    q, s, ext = synth.make_ragged_lists_np(40, seed=5 + len(scheme), alphabet=alphabet, lq_range=(60, 260), mean_windows=5.0, merged_frac=0.15,
+                                           sub_rate=0.1 if nuc else 0.25)
+    slots, src = pack_runs(ext, 4)
+    cutoff = 40
+    got = run_fused(handle, q, s, slots, 4, cutoff)
+    assert "sweep_mq_kernel" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
+
+
+def test_mq_sweep_declined_extensions_go_to_the_int32_launch(handle, oracle):
+    """Tryptophan-rich wide queries: best scores beyond the compact codes' 2046 -- the sweep leaves the sentinel for exactly
+    those extensions (or declines the whole wavefront when the bound fails up front) and the int32 launch redoes them into
+    overflow slots; the neighbours in the same wavefront keep their compact slots."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    rng = np.random.default_rng(3)
+    q, s, ext = synth.make_ragged_lists_np(12, seed=11, lq_range=(230, 300), mean_windows=5.0, merged_frac=0.1)
+    # every third query becomes W-only, its homologous windows too (score 11 per column: 2 500 - 3 300)
+    starts = np.unique(ext["q_off"])
+    for k, qo in enumerate(starts):
+        if k % 3 == 0:
+            sel = np.nonzero(ext["q_off"] == qo)[0]
+            L = int(ext["q_len"][sel[0]])
+            q[qo:qo + L] = 22
+            for i in sel[::2]:
+                s[ext["s_off"][i]: ext["s_off"][i] + ext["s_len"][i]] = 22
+    slots, src = pack_runs(ext, 4)
+    got = run_fused(handle, q, s, slots, 4, 60)
+    assert "int32 fix-up" in got[5], got[5]
+    assert got[0].max() > 2046
+    check_against_oracle(oracle, osc, q, s, slots, 60, *got[:5])
+
+
+def test_mq_sweep_rejects_mixed_queries_in_a_sub_block(handle):
+    import torch
+
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    q, s, ext = synth.make_batch_np(8, 120, 4, seed=2)
+    ext = ext.copy()
+    ext["q_off"][2] = ext["q_off"][5]  # second half of the first sub-block names another query
+    with pytest.raises(capi.LambdaExtError):
+        run_fused(handle, q, s, ext, 4, 50)

@@ -5,7 +5,8 @@
 
 URLs and SHA-256 sums are the ones the reference's test suite declares (/root/reference/test/data/datasources.cmake: base URL
 :7; db_prot :17-19, db_nucl :9-11, db_nucl_bs :13-15; queries_prot :65-67, queries_nucl :57-59, queries_nucl_bs :61-63;
-output_blastp_fm.m8 :179-181, output_blastn_fm.m8 :140-142, output_blastn_bs_fm.m8 :101-103).  They are DATA (sequences and
+output_blastp_fm.m8 :179-181, output_blastn_fm.m8 :140-142, output_blastn_bs_fm.m8 :101-103, the three .sam files
+:185-187, :146-148, :107-109).  They are DATA (sequences and
 BLAST-tabular result tables), the only reference outputs that exist for this path; with them in place
 `pytest tests/test_reference_goldens.py -m gpu` replays every row through lx_iterate_matches and the tabular writer and
 requires identical coordinates, counts, bit score and e-value -- the step that turns "parity unpinned" into a pin.
@@ -28,12 +29,18 @@ FILES = {
     "output_files/output_blastp_fm.m8": "99f520bb55f5c1b371ae5ba41b881c21360a84e7fcb8ff097e01036beb801d4c",
     "output_files/output_blastn_fm.m8": "18b7a0feb4b5e76a44be7ec4ae26ceb1be05fa257df0725a6d231f841de01d54",
     "output_files/output_blastn_bs_fm.m8": "732b439bded780e0b4b68478e6e89368934cab43d261c2f41e48d90ab505a01e",
+    # the SAM goldens carry CIGAR / NM / AS / POS: the only reference data that discriminates the traceback tie rule
+    # (datasources.cmake:185-187, :146-148, :107-109)
+    "output_files/output_blastp_fm.sam": "d7267490e2c6c1ebf838fb7f08a5f370bf0f2b23024ca76db6bfed440851fc91",
+    "output_files/output_blastn_fm.sam": "ca8202a68e22d59e731d023c021244e27e664077d8aa68662041346ac828c110",
+    "output_files/output_blastn_bs_fm.sam": "2247d450da5ad0fa76f630e373bbf70d0fde79a736637d19f8f25d985178fcfa",
 }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dest", default=str(Path(__file__).resolve().parent.parent / "tests" / "golden" / "reference"))
+    ap.add_argument("--timeout", default="60")
     args = ap.parse_args()
     dest = Path(args.dest)
     dest.mkdir(parents=True, exist_ok=True)
@@ -44,7 +51,7 @@ def main():
             continue
         url = f"{BASEURL}/{rel}"
         try:
-            data = urllib.request.urlopen(url, timeout=60).read()
+            data = urllib.request.urlopen(url, timeout=float(args.timeout)).read()
         except Exception as e:  # no network here: say so, change nothing
             print(f"FAILED  {url}: {e}", file=sys.stderr)
             return 1
