@@ -72,6 +72,10 @@ def parse(argv=None):
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
                     "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
+    ap.add_argument("--query-run", type=int, default=0, help="development aid: LX_OPT_QUERY_RUN promise for the device-resident step (default: the "
+                    "workload's windows per query)")
+    ap.add_argument("--mq-sweep", type=int, default=None, help="development aid: LX_OPT_MQ_SWEEP (2 = the multi-query sweep for every run that is a "
+                    "multiple of 4)")
     ap.add_argument("--ragged", action="store_true", help="--host-path on a ragged seed list as lambda really produces them (query lengths "
                     "50-400, windows per query geometric with mean 12, 10 %% merged windows of up to 3 Lq): GCUPS and the padded share")
     ap.add_argument("--ragged-queries", type=int, default=50_000)
@@ -386,7 +390,9 @@ def main():
         h.set_scoring(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
     h.set_option(capi.LX_OPT_BS_MATCH_RULE, 1 if len(w.directions) > 1 else 0)
     h.set_option(capi.LX_OPT_MAX_QLEN, w.lq)
-    h.set_option(capi.LX_OPT_QUERY_RUN, w.windows if w.windows % 8 == 0 else 0)
+    h.set_option(capi.LX_OPT_QUERY_RUN, args.query_run if args.query_run else (w.windows if w.windows % 8 == 0 else 0))
+    if args.mq_sweep is not None:
+        h.set_option(capi.LX_OPT_MQ_SWEEP, args.mq_sweep)
     h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
     if args.band > 0:
         h.set_band(args.band)  # default centres: min(_bandSize(Lq), Ls - Lq), the seed diagonal of the synthetic windows

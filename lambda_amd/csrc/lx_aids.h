@@ -14,7 +14,8 @@ struct DevAids
     // variable                 meaning                                                                      default
     size_t   pair_lds_limit;    // LX_PAIR_LDS_LIMIT     LDS a wavefront of the packed-half kernel may spend on profiles   24 KiB
     int      force_score_cfg;   // LX_FORCE_SCORE_CFG    pass-1 geometry for every list (-1 = pick by query width)         -1
-    int      force_mq_cfg;      // LX_FORCE_MQ_CFG       multi-query sweep geometry 1 = (8,19), 3 = (8,13), 4 = (8,25) (0 = pick)  0
+    int      force_mq_cfg;      // LX_FORCE_MQ_CFG       multi-query sweep geometry 1 = (8,19), 3 = (8,13), 5 = (8,11) (0 = pick)  0
+    int      mq_set;            // LX_MQ_SET             strip widths lx_extend_batch's multi-query plan picks from: 1 = 19, 2 = 13, 4 = 11 columns (sum)  7
     int      force_ckpt_cfg;    // LX_FORCE_CKPT_CFG     checkpoint geometry 1 = (8,19), 2 = (16,13) (0 = pick)            0
     bool     trace_overlap;     // LX_TRACE_OVERLAP=1    mode-0 pass 2: forward of chunk k+1 beside the backtrace of k     off
     uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1
@@ -27,6 +28,9 @@ struct DevAids
     unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 8)           0
     bool     extend_no_classes; // LX_EXTEND_NO_CLASSES  lx_extend_batch: no geometry-class binning of ragged lists        off
     bool     extend_no_sort;    // LX_EXTEND_NO_SORT     lx_extend_batch: no in-run sort by window length                  off
+    bool     extend_no_mq;      // LX_EXTEND_NO_MQ       lx_extend_batch: ragged lists on the one-query-per-wavefront kernels      off
+    bool     extend_two_streams;// LX_EXTEND_TWO_STREAMS lx_extend_batch: odd chunks' kernels on a second stream + working set (measured: slower)  off
+    bool     extend_bt_overlap; // LX_EXTEND_BT_OVERLAP=1 lx_extend_batch: a chunk's backtrace on a second stream beside the next chunk's sweep (measured: slower)  off
     uint64_t extend_run;        // LX_EXTEND_RUN         lx_extend_batch: pad query runs to 8 or 16 slots (0 = by estimated work)  0
     uint64_t extend_chunk;      // LX_EXTEND_CHUNK       default of LX_OPT_EXTEND_CHUNK (extensions per pipeline chunk)    640 Ki
     int      bt_waves_per_cu;   // LX_BT_WAVES_PER_CU    persistent wavefronts of the backtrace per CU (0 = what fits)     0

@@ -33,6 +33,9 @@ lx::DevAids const & lx::dev_aids()
         a.force_score_cfg   = (int)num("LX_FORCE_SCORE_CFG", -1);
         a.force_ckpt_cfg    = (int)num("LX_FORCE_CKPT_CFG", 0);
         a.force_mq_cfg      = (int)num("LX_FORCE_MQ_CFG", 0);
+        a.mq_set            = (int)num("LX_MQ_SET", 7) & 7;
+        if (a.mq_set == 0)
+            a.mq_set = 7;
         a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
         a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
         a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
@@ -44,6 +47,9 @@ lx::DevAids const & lx::dev_aids()
         a.host_threads      = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
         a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
+        a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
+        a.extend_two_streams = set("LX_EXTEND_TWO_STREAMS");
+        a.extend_bt_overlap  = num("LX_EXTEND_BT_OVERLAP", 0) != 0;
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
@@ -93,7 +99,7 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
         return LX_OK;
     if (b.ptr)
     {
-        LX_HIP(h, hipStreamSynchronize(h->stream));
+        LX_HIP(h, hipDeviceSynchronize()); // (kernels of either chunk stream may still read the old block)
         LX_HIP(h, hipFree(b.ptr));
         b.ptr = nullptr;
         b.cap = 0;
@@ -102,6 +108,24 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
     LX_HIP(h, hipMalloc(&b.ptr, want));
     b.cap = want;
     return LX_OK;
+}
+
+void use_ctx(lx_handle * h, int which)
+{
+    if (h->ctx_active == which)
+        return;
+    lx_handle::FusedCtx & a = h->alt;
+    std::swap(h->d_trace, a.d_trace);
+    std::swap(h->d_ends, a.d_ends);
+    std::swap(h->d_sel_ext, a.d_sel_ext);
+    std::swap(h->d_sel_src, a.d_sel_src);
+    std::swap(h->d_sel_runs, a.d_sel_runs);
+    std::swap(h->d_sel_score, a.d_sel_score);
+    std::swap(h->d_trace_score, a.d_trace_score);
+    std::swap(h->d_ws, a.d_ws);
+    std::swap(h->d_ws_top, a.d_ws_top);
+    std::swap(h->ws_grown, a.ws_grown);
+    h->ctx_active = which;
 }
 
 int bind(lx_handle * h)
@@ -190,27 +214,24 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
 }
 
 // Multi-query sweep (lx_sweep_mq.hip): checkpoint geometry for queries of up to max_q columns -- trace cfg 3 = (8,13),
-// 1 = (8,19), 4 = (8,25) -- one panel where one holds the query, else the panel width with the least padded work (columns
-// swept x instructions per column: 3.75 per cell of the recurrence + ~12 per step and lane spread over the strip's columns).
-// lx_host.cpp deals ragged lists to classes with the same function, so a chunk's geometry is the one its class was formed for.
+// 5 = (8,11), 1 = (8,19), as many panels as the query needs: the one with the least padded work (columns swept x instructions
+// per column: 3.75 per cell of the recurrence + ~12 per step and lane spread over the strip's columns).  lx_host.cpp deals
+// ragged lists to classes with the same function, so a chunk's geometry is the one its class was formed for.
 int mq_cfg_for(uint64_t max_q)
 {
     int const forced = lx::dev_aids().force_mq_cfg; // development aid
-    if (forced == 1 || forced == 3 || forced == 4)
+    if (forced == 1 || forced == 3 || forced == 5)
         return forced;
-    if (max_q <= 104)
-        return 3;
-    if (max_q <= 152)
-        return 1;
-    if (max_q <= 200)
-        return 4;
     int    best = 1;
     double best_cost = 1e30;
-    for (int cfg : {1, 4, 3})
+    int const set = lx::dev_aids().mq_set; // development aid: bit 0 = (8,19), 1 = (8,13), 2 = (8,11)
+    for (int cfg : {1, 5, 3})
     {
+        if (!(set & (cfg == 1 ? 1 : cfg == 3 ? 2 : 4)))
+            continue;
         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cfg);
         double const   C     = (double)panel / 8.0;
-        double const   cost  = (double)((max_q + panel - 1) / panel * panel) * (3.75 * C + 12.0) / C;
+        double const   cost  =(double)((std::max<uint64_t>(max_q, 1) + panel - 1) / panel * panel) * (3.75 * C + 12.0) / C;
         if (cost < best_cost - 1e-9)
         {
             best_cost = cost;
@@ -220,23 +241,29 @@ int mq_cfg_for(uint64_t max_q)
     return best;
 }
 
+// the device's error word (d_ws_top[1]) as a return code
+int error_for_flag(lx_handle * h, uint32_t flag)
+{
+    if (flag == 1)
+        return fail(h, LX_EOVERFLOW, "multi-panel carry workspace exhausted (raise LX_OPT_WORKSPACE_BYTES)");
+    if (flag == 2)
+        return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
+    if (flag == 3)
+        return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or a subject window beyond the pass-2 limit)");
+    if (flag == 4)
+        return fail(h, LX_EOVERFLOW, "single sweep: no checkpoint slot left for an extension the packed-half kernel declined "
+                                     "(raise LX_OPT_TRACE_BYTES, or set LX_OPT_PASS2_MODE to 1)");
+    if (flag != 0)
+        return fail(h, flag == 5 ? LX_EOVERFLOW : LX_EHIP, "device reported error flag %u", flag);
+    return LX_OK;
+}
+
 int check_async_error(lx_handle * h)
 {
     uint32_t flags[2] = {0, 0};
     LX_HIP(h, hipMemcpyAsync(flags, h->d_ws_top, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
     LX_HIP(h, hipStreamSynchronize(h->stream));
-    if (flags[1] == 1)
-        return fail(h, LX_EOVERFLOW, "multi-panel carry workspace exhausted (raise LX_OPT_WORKSPACE_BYTES)");
-    if (flags[1] == 2)
-        return fail(h, LX_ESTATE, "LX_OPT_QUERY_RUN promise violated: extensions of one wavefront use different queries");
-    if (flags[1] == 3)
-        return fail(h, LX_EOVERFLOW, "an extension exceeds the trace slot bounds (LX_OPT_MAX_QLEN / LX_OPT_MAX_SLEN too small, or a subject window beyond the pass-2 limit)");
-    if (flags[1] == 4)
-        return fail(h, LX_EOVERFLOW, "single sweep: no checkpoint slot left for an extension the packed-half kernel declined "
-                                     "(raise LX_OPT_TRACE_BYTES, or set LX_OPT_PASS2_MODE to 1)");
-    if (flags[1] != 0)
-        return fail(h, flags[1] == 5 ? LX_EOVERFLOW : LX_EHIP, "device reported error flag %u", flags[1]);
-    return LX_OK;
+    return error_for_flag(h, flags[1]);
 }
 
 // One kernel sequence for a device-resident extension list whose queries all fit geometry `cfg`
@@ -574,7 +601,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
             for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
                 smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-        sweep_cfg    = mq_cfg_for(h->opt_max_qlen);
+        sweep_cfg    = h->mq_cfg_call ? h->mq_cfg_call : mq_cfg_for(h->opt_max_qlen);
         sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
         mq           = (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535;
         if (mq)
@@ -971,10 +998,11 @@ int lx_create(int device_id, lx_handle ** out)
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess)
         return bail("hipEventCreate", e);
     if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking)) != hipSuccess)
+        (e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     for (auto & ln : h->xb)
-        for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt})
+        for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt, &ln.ev_mid})
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
     for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
@@ -983,6 +1011,10 @@ int lx_create(int device_id, lx_handle ** out)
     if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc", e);
     if ((e = hipMemset(h->d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipMemset", e);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&h->alt.d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
+        return bail("hipMalloc", e);
+    if ((e = hipMemset(h->alt.d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMemset", e);
     for (int s = 0; s < 2; ++s)
         if ((e = hipMalloc(reinterpret_cast<void **>(&h->sc_dev[s]), sizeof(lx::ScoringDev))) != hipSuccess)
@@ -1008,7 +1040,13 @@ void lx_destroy(lx_handle * h)
             (void)hipFree(h->sc_dev[s]);
     if (h->d_ws_top)
         (void)hipFree(h->d_ws_top);
-    for (hipStream_t st : {h->stream2, h->stream3})
+    if (h->alt.d_ws_top)
+        (void)hipFree(h->alt.d_ws_top);
+    for (DevBuf * b : {&h->alt.d_trace, &h->alt.d_ends, &h->alt.d_sel_ext, &h->alt.d_sel_src, &h->alt.d_sel_runs, &h->alt.d_sel_score,
+                       &h->alt.d_trace_score, &h->alt.d_ws})
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    for (hipStream_t st : {h->stream2, h->stream3, h->stream4})
         if (st)
         {
             (void)hipStreamSynchronize(st);
@@ -1022,7 +1060,7 @@ void lx_destroy(lx_handle * h)
         for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
-        for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt})
+        for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt, ln.ev_mid})
             if (ev)
                 (void)hipEventDestroy(ev);
     }

@@ -1343,6 +1343,7 @@ uint64_t ckpt_slot_dwords(int cfg, uint32_t steps_cap)
     return cfg == 2   ? CkptLayout<16, 13>::slot_dwords(steps_cap)
            : cfg == 3 ? CkptLayout<8, 13>::slot_dwords(steps_cap)
            : cfg == 4 ? CkptLayout<8, 25>::slot_dwords(steps_cap)
+           : cfg == 5 ? CkptLayout<8, 11>::slot_dwords(steps_cap)
                       : CkptLayout<8, 19>::slot_dwords(steps_cap);
 }
 
@@ -1352,6 +1353,7 @@ uint64_t ckpt16_slot_dwords(int cfg, uint32_t steps_cap)
     return cfg == 2   ? Ckpt16Layout<16, 13>::slot_dwords(steps_cap)
            : cfg == 3 ? Ckpt16Layout<8, 13>::slot_dwords(steps_cap)
            : cfg == 4 ? Ckpt16Layout<8, 25>::slot_dwords(steps_cap)
+           : cfg == 5 ? Ckpt16Layout<8, 11>::slot_dwords(steps_cap)
                       : Ckpt16Layout<8, 19>::slot_dwords(steps_cap);
 }
 
@@ -1384,6 +1386,7 @@ hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream)
     return p.cfg == 2   ? launch_ckpt_forward_cfg<16, 13>(p, stream)
            : p.cfg == 3 ? launch_ckpt_forward_cfg<8, 13>(p, stream)
            : p.cfg == 4 ? launch_ckpt_forward_cfg<8, 25>(p, stream)
+           : p.cfg == 5 ? launch_ckpt_forward_cfg<8, 11>(p, stream)
                         : launch_ckpt_forward_cfg<8, 19>(p, stream);
 }
 
@@ -1423,6 +1426,8 @@ hipError_t launch_ckpt_backtrace(TraceParams const & p_in, hipStream_t stream)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 13>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else if (p.cfg == 4)
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 25>), dim3((unsigned)b2), dim3(64), 0, stream, p);
+    else if (p.cfg == 5)
+        hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 11>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     else
         hipLaunchKernelGGL((ckpt_backtrace_kernel<8, 19>), dim3((unsigned)b2), dim3(64), 0, stream, p);
     return hipGetLastError();

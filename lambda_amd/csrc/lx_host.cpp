@@ -791,6 +791,42 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                         });
     newrun[live] = 1;
+    // positions where the runs of one query slice begin, + the sentinel `live` (two parallel passes over newrun)
+    std::vector<uint64_t> & starts = h->xb_starts;
+    starts.clear();
+    auto run_starts = [&](std::vector<uint64_t> & out)
+    {
+        std::vector<uint64_t> cnt(nthreads + 1, 0);
+        parallel_ranges(live + 1, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t c = 0;
+                            for (uint64_t k = lo; k < hi; ++k)
+                                c += newrun[k];
+                            cnt[t + 1] = c;
+                        });
+        for (unsigned t = 0; t < nthreads; ++t)
+            cnt[t + 1] += cnt[t];
+        out.resize(cnt[nthreads]);
+        parallel_ranges(live + 1, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t o = cnt[t];
+                            for (uint64_t k = lo; k < hi; ++k)
+                                if (newrun[k])
+                                    out[o++] = k;
+                        });
+    };
+    // Multi-query sweep (lx_sweep_mq.hip) for lists that are not uniform: sub-blocks of 4 windows of one query, ordered by
+    // (geometry class, longest window) ACROSS queries, four sub-blocks per wavefront -- see the plan below.  Needs what
+    // fused_impl's mq branch needs; uniform lists (one query length, one window length, runs that fill whole wavefronts) stay
+    // on the one-query-per-wavefront kernels.
+    bool use_mq = false;
+    {
+        lx_scoring const & sh = h->sc_host[slot];
+        use_mq = h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap &&
+                 sh.gap_open <= sh.gap_extend && !lx::dev_aids().extend_no_mq;
+    }
     // Mixed query lengths (a real seed list; the synthetic batches have one): a chunk runs the kernel geometry of its longest
     // query, so runs are dealt to geometry classes first -- one panel of 152 columns, one of 208, two / three / ... panels of
     // 152 -- and every class goes through the pipeline by itself.  Inside a run the windows are ordered by length (merged
@@ -832,7 +868,17 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             }
         }
         bool const no_classes = lx::dev_aids().extend_no_classes, no_sort = lx::dev_aids().extend_no_sort; // A/B aids
-        if (cmin != cmax && !no_classes)
+        if (use_mq && cmin == cmax && !ragged_s && h->opt_mq < 2)
+        {
+            // one geometry, one window length: uniform if every run fills whole wavefronts
+            run_starts(starts);
+            bool all16 = true;
+            for (size_t r = 0; r + 1 < starts.size() && all16; ++r)
+                all16 = (starts[r + 1] - starts[r]) % 16 == 0;
+            if (all16)
+                use_mq = false;
+        }
+        if (cmin != cmax && !no_classes && !use_mq)
         {
             std::vector<uint64_t> at(cmax + 2, 0);
             for (uint64_t k = 0; k < live;)
@@ -867,10 +913,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         if (ragged_s && !no_sort)
         {
-            std::vector<uint64_t> starts;
-            for (uint64_t k = 0; k <= live; ++k)
-                if (newrun[k])
-                    starts.push_back(k);
+            run_starts(starts);
             parallel_ranges(starts.size() - 1, nthreads,
                             [&](unsigned, uint64_t lo, uint64_t hi)
                             {
@@ -878,6 +921,123 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     std::sort(idx.begin() + starts[r], idx.begin() + starts[r + 1],
                                               [&](uint32_t a, uint32_t b) { return ext[a].s_len != ext[b].s_len ? ext[a].s_len < ext[b].s_len : a < b; });
                             });
+        }
+    }
+    // ---- multi-query plan: every run is cut into sub-blocks of 4 windows (the shortest first -- the runs are sorted by window
+    // length), a sub-block's key is (geometry class of its query, its longest window), the sub-blocks of the WHOLE list are
+    // sorted by key (stable LSD radix sort) and dealt four to a wavefront: the windows that share a wavefront take about the
+    // same number of steps whatever their queries, a merged window (up to 3 x longer, src/search_algo.hpp:1153-1157) stretches
+    // only wavefronts of its like, and a query with five windows fills two sub-blocks, not a wavefront.  An incomplete
+    // sub-block is filled with copies of its last window (as the reference pads its SIMD batches, :1063-1067): they cost
+    // what the window costs and never survive (cut-off INT_MAX).
+    constexpr uint64_t kSub = 4;
+    std::vector<uint32_t> & sb_first = h->xb_sbfirst, & sb_key = h->xb_sbkey, & sb_order = h->xb_sborder, & sb_tmp = h->xb_sbtmp;
+    uint64_t nsb = 0;
+    // ONE strip geometry per call, the one that sweeps the fewest padded columns over the whole list (weighted by the
+    // instructions a column costs at that width): every further geometry is a further pair of launches, and the backtrace of a
+    // chunk with a few ten thousand survivors is bound by the latency of its longest walks (~1 ms), not by its work -- measured
+    // on the ragged list of bench.py: (8,11) + (8,13) + (8,19) chosen per query 28.5 % padded cells but 27-31 ms, one geometry
+    // 34.5 % / 39.9 % padded and 22.7-24.2 ms.  Class of a query = its panel count.  Sort key: most panels first, longest windows
+    // first -- the wavefronts with the most work start first, the chunks with the most survivors are unpacked beside the later
+    // chunks' kernels, and the call ends with a small chunk.
+    int mq_cfg = 1;
+    auto mq_class = [&](uint32_t lq) -> uint32_t
+    {
+        return (uint32_t)std::min<uint64_t>(1023, ((uint64_t)lq + lx::trace_cfg_panel(mq_cfg) - 1) / lx::trace_cfg_panel(mq_cfg));
+    };
+    auto mq_key_class = [](uint32_t cls) -> uint32_t { return 0xfffu - cls; };
+    if (use_mq)
+    {
+        if (starts.empty())
+            run_starts(starts);
+        uint64_t const        nruns = starts.size() - 1;
+        {
+            int const cand[3] = {1, 3, 5};
+            std::vector<double> tc(3 * (size_t)nthreads, 0.0);
+            parallel_ranges(nruns, nthreads,
+                            [&](unsigned t, uint64_t rlo, uint64_t rhi)
+                            {
+                                double c[3] = {0, 0, 0};
+                                for (uint64_t r = rlo; r < rhi; ++r)
+                                {
+                                    uint64_t const lq = ext[idx[starts[r]]].q_len, nw = (starts[r + 1] - starts[r] + kSub - 1) / kSub * kSub;
+                                    for (int k = 0; k < 3; ++k)
+                                    {
+                                        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]);
+                                        c[k] += (double)nw * (double)((lq + panel - 1) / panel * panel);
+                                    }
+                                }
+                                for (int k = 0; k < 3; ++k)
+                                    tc[3 * t + k] = c[k];
+                            });
+            double best = 1e300;
+            int const set = lx::dev_aids().mq_set, forced = lx::dev_aids().force_mq_cfg;
+            for (int k = 0; k < 3; ++k)
+            {
+                double c = 0;
+                for (unsigned t = 0; t < nthreads; ++t)
+                    c += tc[3 * t + k];
+                double const C = (double)lx::trace_cfg_panel(cand[k]) / 8.0;
+                c *= (3.75 * C + 12.0) / C * (cand[k] == 1 ? 1.0 : 1.04); // (narrower strips: more tiles per walk in the backtrace)
+                if (!(set & (1 << k)) && forced != cand[k])
+                    continue;
+                if (forced == cand[k])
+                    c = 0;
+                if (c < best)
+                {
+                    best   = c;
+                    mq_cfg = cand[k];
+                }
+            }
+        }
+        h->mq_cfg_call = mq_cfg;
+        std::vector<uint64_t> sb_off(nruns + 1, 0);
+        for (uint64_t r = 0; r < nruns; ++r)
+            sb_off[r + 1] = sb_off[r] + (starts[r + 1] - starts[r] + kSub - 1) / kSub;
+        nsb = sb_off[nruns];
+        sb_first.resize(nsb);
+        sb_key.resize(nsb);
+        sb_order.resize(nsb);
+        sb_tmp.resize(nsb);
+        parallel_ranges(nruns, nthreads,
+                        [&](unsigned, uint64_t rlo, uint64_t rhi)
+                        {
+                            for (uint64_t r = rlo; r < rhi; ++r)
+                            {
+                                uint32_t const cls = mq_key_class(mq_class(ext[idx[starts[r]]].q_len));
+                                uint64_t       o   = sb_off[r];
+                                for (uint64_t k = starts[r]; k < starts[r + 1]; k += kSub, ++o)
+                                {
+                                    uint32_t mx = 0;
+                                    for (uint64_t j = k; j < std::min(starts[r + 1], k + kSub); ++j)
+                                        mx = std::max(mx, ext[idx[j]].s_len);
+                                    sb_first[o] = (uint32_t)k;
+                                    // (longest first inside a class: the wavefronts that run longest start first, the tail of
+                                    // the launch is made of short ones)
+                                    sb_key[o]   = (cls << 16) | (0xffffu - std::min<uint32_t>(mx, 0xffffu));
+                                }
+                            }
+                        });
+        // LSD radix sort of the sub-block numbers by key: three passes of 10 bits (keys have 28)
+        for (uint64_t o = 0; o < nsb; ++o)
+            sb_order[o] = (uint32_t)o;
+        for (int pass = 0; pass < 3; ++pass)
+        {
+            int const shift = 10 * pass;
+            uint32_t  hist[1025] = {0};
+            for (uint64_t o = 0; o < nsb; ++o)
+                ++hist[((sb_key[sb_order[o]] >> shift) & 1023u) + 1];
+            bool one_bucket = false;
+            for (int b = 0; b < 1024; ++b)
+            {
+                one_bucket = one_bucket || hist[b + 1] == nsb;
+                hist[b + 1] += hist[b];
+            }
+            if (one_bucket)
+                continue;
+            for (uint64_t o = 0; o < nsb; ++o)
+                sb_tmp[hist[(sb_key[sb_order[o]] >> shift) & 1023u]++] = sb_order[o];
+            sb_order.swap(sb_tmp);
         }
     }
     hm.mark("validate");
@@ -892,6 +1052,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamSynchronize(h->stream2);
             (void)hipStreamSynchronize(h->stream3);
+            (void)hipStreamSynchronize(h->stream4);
+            use_ctx(h, 0);
+            h->mq_cfg_call   = 0;
             h->opt_max_qlen  = qlen;
             h->opt_max_slen  = slen;
             h->opt_query_run = run;
@@ -904,6 +1067,13 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
     if (sref.upload)
         LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
+    // (the odd chunks' kernels run on stream4: they wait for the residues too)
+    LX_HIP(h, hipEventRecord(h->evS, h->stream));
+    LX_HIP(h, hipStreamWaitEvent(h->stream4, h->evS, 0));
+    // (measured: two chunks side by side on the GPU LOSE -- ragged list 28.5 against 24.4 ms, headline batch 40.0 against 31.3 ms:
+    // the persistent-lane backtrace of one chunk gets its wavefronts late while the other chunk's sweep holds the CUs, and the
+    // results the host waits for arrive later; kept behind LX_EXTEND_TWO_STREAMS for re-measurement)
+    bool const two_streams = lx::dev_aids().extend_two_streams;
 
     uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
     h->ext_bytes.clear();
@@ -916,6 +1086,78 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     { return std::chrono::duration<double, std::milli>(b - a).count(); };
     XbPrep   prep[2];
     bool     in_flight[2] = {false, false};
+
+    // ---- device side of a chunk whose padded slots stand in lane L's pinned staging: uploads and kernels queued
+    auto launch_chunk = [&](int L, uint64_t slots, uint64_t max_q, uint64_t max_s, uint64_t kRun) -> int
+    {
+        auto const          t1 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
+        int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
+        int rc2;
+        // device side of the lane
+        uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
+        if ((rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
+            (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) ||
+            (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) ||
+            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) ||
+            (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_score, slots * sizeof(int32_t))) || (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+            return rc2;
+        LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipMemcpyAsync(ln.d_min.ptr, slot_min, slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+        // two chunks on the GPU at once: lane 1's kernels on their own stream with the handle's second working set -- the
+        // tail of one chunk's sweep and its latency-bound backtrace run beside the other chunk's sweep
+        hipStream_t const ks = (two_streams && L == 1) ? h->stream4 : h->stream;
+        // LX_EXTEND_BT_OVERLAP=1: every chunk's sweep and selection on `stream`, in order; its backtrace -- one lane per survivor,
+        // bound by the latency of its walks when a chunk has few survivors -- on stream4, beside the NEXT chunk's sweep, the two
+        // chunks on the handle's two working sets.  Measured: no gain on the ragged list (27-29 ms either way), a loss on the
+        // headline batch (34.9 against 29.0 ms) -- kernels side by side cost more than their tails and latencies save.  Off.
+        bool const bt_beside = !two_streams && lx::dev_aids().extend_bt_overlap;
+        use_ctx(h, ((two_streams || bt_beside) && L == 1) ? 1 : 0);
+        LX_HIP(h, hipStreamWaitEvent(ks, ln.ev_up, 0));
+        h->opt_max_qlen  = max_q;
+        h->opt_max_slen  = max_s;
+        h->opt_query_run = kRun;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
+        hipStream_t ke = ks; // the stream the chunk's last kernel runs on
+        if (bt_beside)
+        {
+            if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                                  nullptr, d_cnt, ks, 1, true, &fx)))
+                return rc2;
+            LX_HIP(h, hipEventRecord(ln.ev_mid, ks));
+            LX_HIP(h, hipStreamWaitEvent(h->stream4, ln.ev_mid, 0));
+            ke = h->stream4;
+            if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                                  nullptr, d_cnt, ke, 2, true, &fx)))
+                return rc2;
+        }
+        else if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                                   nullptr, d_cnt, ks, 3, true, &fx)))
+            return rc2;
+        // the device's error word of THIS chunk, saved in stream order (the next chunk's prepare_workspace clears it): it comes
+        // back with the counts and is checked in collect()
+        LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, ke));
+        LX_HIP(h, hipEventRecord(ln.ev_k, ke));
+        // what has a size the host knows goes back at once; records and codes follow when the counts have arrived
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipMemcpyAsync(ln.p_score.ptr, ln.d_score.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
+        in_flight[L] = true;
+        t_issue += ms(t1, now());
+        return LX_OK;
+    };
 
     // ---- chunk k0 .. k1 of the ordered list -> padded slots in lane L's pinned staging -> uploads and kernels queued
     auto enqueue = [&](int L, uint64_t k0, uint64_t k1) -> int
@@ -1018,44 +1260,81 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             h->xb_stats[2] += tcells[t];
             h->xb_stats[3] += tpad[t];
         }
-        auto const t1 = now();
-        t_prep += ms(t0, t1);
-        // device side of the lane
-        uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
-        if ((rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
-            (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) ||
-            (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) ||
-            (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) ||
-            (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
-            (rc2 = ensure_pinned(h, ln.p_score, slots * sizeof(int32_t))) || (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+        t_prep += ms(t0, now());
+        return launch_chunk(L, slots, max_q, max_s, kRun);
+    };
+
+    // ---- sub-blocks o0 .. o1 of the sorted plan -> slots in lane L's pinned staging -> uploads and kernels queued
+    auto enqueue_mq = [&](int L, uint64_t o0, uint64_t o1) -> int
+    {
+        auto const          t0 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        pr.k0 = o0;
+        pr.k1 = o1;
+        uint64_t const slots = (o1 - o0) * kSub;
+        pr.slots   = slots;
+        pr.cap_sel = (slots + 7) / 8 * 8 + 8;
+        pr.slot_src.resize(slots);
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_ext, slots * sizeof(lx_extension))) || (rc2 = ensure_pinned(h, ln.p_min, slots * sizeof(int32_t))))
             return rc2;
-        LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
-        LX_HIP(h, hipMemcpyAsync(ln.d_min.ptr, slot_min, slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream3));
-        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
-        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
-        h->opt_max_qlen  = max_q;
-        h->opt_max_slen  = max_s;
-        h->opt_query_run = kRun;
-        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
-        FusedExtra       fx;
-        fx.ops_stride = stride;
-        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
-        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
-        fx.rle_cap    = pr.cap_sel * stride;
-        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
-        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
-        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
-                              nullptr, d_cnt, h->stream, 3, true, &fx)))
-            return rc2;
-        LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
-        // what has a size the host knows goes back at once; records and codes follow when the counts have arrived
-        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
-        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
-        LX_HIP(h, hipMemcpyAsync(ln.p_score.ptr, ln.d_score.ptr, slots * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream2));
-        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
-        in_flight[L] = true;
-        t_issue += ms(t1, now());
-        return LX_OK;
+        lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
+        int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
+        uint32_t * const     slot_src = pr.slot_src.data();
+        uint64_t const       panel    = (uint64_t)lx::trace_cfg_panel(mq_cfg);
+        std::vector<uint64_t> tq(nthreads, 1), ts(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
+        // whole wavefronts (four sub-blocks) per thread share, so that the executed-cells estimate sees each wavefront once
+        parallel_ranges((o1 - o0 + 3) / 4, nthreads,
+                        [&](unsigned t, uint64_t wlo, uint64_t whi)
+                        {
+                            uint64_t mq_ = 1, ms_ = 1, cells = 0, padded = 0; // (locals: the per-thread slots share cache lines)
+                            for (uint64_t w = wlo; w < whi; ++w)
+                            {
+                                uint64_t wmax = 0, wq = 1;
+                                for (uint64_t o = o0 + 4 * w; o < std::min(o1, o0 + 4 * w + 4); ++o)
+                                {
+                                    uint32_t const sb    = sb_order[o];
+                                    uint64_t const first = sb_first[sb];
+                                    uint64_t       cnt   = 1;
+                                    while (cnt < kSub && !newrun[first + cnt])
+                                        ++cnt;
+                                    uint64_t const so = (o - o0) * kSub;
+                                    for (uint64_t j = 0; j < kSub; ++j)
+                                    {
+                                        uint32_t const     orig = idx[first + std::min(j, cnt - 1)];
+                                        lx_extension const x    = ext[orig];
+                                        slot_ext[so + j]        = x;
+                                        slot_src[so + j]        = j < cnt ? orig : 0xffffffffu;
+                                        slot_min[so + j]        = j < cnt ? (min_score ? min_score[orig] : min_score_all) : 0x7fffffff;
+                                        if (j < cnt)
+                                            cells += (uint64_t)x.q_len * x.s_len;
+                                        wmax = std::max<uint64_t>(wmax, x.s_len);
+                                        wq   = std::max<uint64_t>(wq, x.q_len);
+                                    }
+                                }
+                                ms_ = std::max(ms_, wmax);
+                                mq_ = std::max(mq_, wq);
+                                // (a wavefront sweeps as many panels as its widest query needs, each for as many steps as its
+                                // longest window has rows)
+                                padded += 16 * ((wq + panel - 1) / panel * panel) * (wmax + 7);
+                            }
+                            tq[t]     = mq_;
+                            ts[t]     = ms_;
+                            tcells[t] = cells;
+                            tpad[t]   = padded;
+                        });
+        uint64_t max_q = 1, max_s = 1;
+        for (unsigned t = 0; t < nthreads; ++t)
+        {
+            max_q = std::max(max_q, tq[t]);
+            max_s = std::max(max_s, ts[t]);
+            h->xb_stats[2] += tcells[t];
+            h->xb_stats[3] += tpad[t];
+        }
+        h->xb_stats[1] += slots;
+        t_prep += ms(t0, now());
+        return launch_chunk(L, slots, max_q, max_s, kSub);
     };
 
     // ---- results of the chunk in lane L -> the caller's arrays
@@ -1068,6 +1347,13 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipEventSynchronize(ln.ev_cnt));
         uint64_t const * const cnt = static_cast<uint64_t const *>(ln.p_cnt.ptr);
         uint64_t const count = cnt[0], nrle = cnt[2];
+        {
+            uint32_t flags[2];
+            std::memcpy(flags, cnt + 3, sizeof(flags));
+            int const rcf = error_for_flag(h, flags[1]);
+            if (rcf)
+                return rcf;
+        }
         if (count > pr.cap_sel)
             return fail(h, LX_ESTATE, "survivor list longer than its capacity");
         int rc2;
@@ -1189,6 +1475,54 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // ---- the pipeline: prepare + queue chunk c, then unpack chunk c - 1 while c runs
     uint64_t k0 = 0;
     int      c  = 0;
+    if (use_mq)
+    {
+        // chunks = ranges of the sorted sub-blocks, about chunk_target slots, whole wavefronts; a change of the panel count
+        // starts a new chunk only when both sides fill the chip a few times (a chunk's slots are sized for its widest query;
+        // a launch of a few hundred wavefronts costs its latency)
+        uint64_t const per_chunk = std::max<uint64_t>(4, chunk_target / kSub / 4 * 4), min_chunk = std::min<uint64_t>(per_chunk, 16384);
+        uint64_t       o0        = 0;
+        while (o0 < nsb)
+        {
+            uint64_t       o1   = std::min(nsb, o0 + per_chunk);
+            auto first_not = [&](uint64_t lo, uint64_t hi, auto same) // first position in (lo, hi] whose class differs (same(lo) holds)
+            {
+                if (same(hi - 1))
+                    return hi;
+                --hi;
+                while (hi - lo > 1)
+                {
+                    uint64_t const mid = lo + (hi - lo) / 2;
+                    (same(mid) ? lo : hi) = mid;
+                }
+                return hi;
+            };
+            // panel-count boundaries inside [o0, o1): cut at the first one that leaves a chunk of at least min_chunk sub-blocks
+            for (uint64_t at = o0;;)
+            {
+                uint32_t const c_at = sb_key[sb_order[at]] >> 16;
+                uint64_t const nx   = first_not(at, o1, [&](uint64_t o) { return (sb_key[sb_order[o]] >> 16) == c_at; });
+                if (nx >= o1)
+                    break;
+                if (nx - o0 >= min_chunk && o1 - nx >= min_chunk) // (neither side becomes a launch of a few hundred wavefronts)
+                {
+                    o1 = nx;
+                    break;
+                }
+                at = nx;
+            }
+            int const L = c & 1;
+            if (in_flight[L] && (rc = collect(L)))
+                return rc;
+            if ((rc = enqueue_mq(L, o0, o1)))
+                return rc;
+            if (in_flight[L ^ 1] && (rc = collect(L ^ 1)))
+                return rc;
+            o0 = o1;
+            ++c;
+        }
+        k0 = live;
+    }
     while (k0 < live)
     {
         uint64_t k1 = std::min<uint64_t>(live, k0 + chunk_target);
@@ -1224,9 +1558,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     for (int L : {c & 1, (c & 1) ^ 1})
         if (in_flight[L] && (rc = collect(L)))
             return rc;
-    if ((rc = check_async_error(h)))
-        return rc;
-    hm.mark("pipeline");
+    hm.mark("pipeline"); // (every chunk's error word came back with its counts: collect())
     if (hm.on)
         fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f (lengths %.1f, offsets %.1f)\n", c, t_prep, t_issue,
                 t_wait, t_unpack, t_u1, t_u2);

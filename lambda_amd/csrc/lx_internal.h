@@ -84,7 +84,8 @@ struct lx_handle
     std::vector<uint32_t>     xb_idx, xb_src, xb_sel, xb_pos;
     std::vector<uint8_t>      xb_newrun;
     uint64_t                  xb_stats[4] = {0, 0, 0, 0}; // lx_extend_batch: extensions, slots, cells, cells executed (padding included)
-    std::vector<uint64_t>     xb_grp, xb_off;
+    std::vector<uint64_t>     xb_grp, xb_off, xb_starts;
+    std::vector<uint32_t>     xb_sbfirst, xb_sbkey, xb_sborder, xb_sbtmp; // multi-query plan: sub-blocks of 4 windows
     std::vector<lx_extension> xb_ext;
     std::vector<int32_t>      xb_min, xb_score;
     std::vector<uint8_t> ext_ops; // band mode: the ops of the last lx_extend_batch call (handed out by pointer)
@@ -115,9 +116,21 @@ struct lx_handle
     {
         Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len;
         DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len;
-        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
+        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr, ev_mid = nullptr;
     } xb[2];
     hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
+    hipStream_t stream4 = nullptr; // kernels of lx_extend_batch's odd chunks (the even ones run on `stream`)
+    // lx_extend_batch keeps two chunks on the GPU at once, each on its own stream with its own working set: the buffers the
+    // fused step owns (checkpoint slots, end cells, selection lists, carry workspace, counters).  The second set lives here
+    // and is swapped with the members of the same name around every odd chunk (lxi::use_ctx; the host side of a handle is
+    // single-threaded, the kernels keep the pointers they were launched with).
+    struct FusedCtx
+    {
+        DevBuf     d_trace, d_ends, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_ws;
+        uint32_t * d_ws_top = nullptr;
+        uint64_t   ws_grown = 0;
+    } alt;
+    int ctx_active = 0;
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
     std::string last_trace_kernel;
     // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
@@ -151,6 +164,7 @@ struct lx_handle
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
     uint64_t opt_mq        = 1; // LX_OPT_MQ_SWEEP
+    int      mq_cfg_call   = 0; // lx_extend_batch: the strip geometry (trace cfg) it chose for this call's chunks (0 = fused_impl picks per chunk)
     uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
     uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
     int32_t const * band_dev = nullptr;  // lx_set_band_centres_dev: the caller's device array for the *_dev calls
@@ -238,6 +252,9 @@ size_t pair_lds_limit();
 int    pick_cfg(uint32_t qlen, bool shared);
 int    ckpt_cfg_for(uint64_t max_q, bool packed16 = false);
 int    check_async_error(lx_handle * h);
+int    error_for_flag(lx_handle * h, uint32_t flag);
+void   use_ctx(lx_handle * h, int which); // 0 = the handle's own working set, 1 = lx_handle::alt
+int    mq_cfg_for(uint64_t max_q);
 int    launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n, void * d_out, int cfg,
                          bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0);
 int    prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint = 0);

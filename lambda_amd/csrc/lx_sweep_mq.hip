@@ -80,6 +80,9 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     using Geo = MqGeo<C>;
     using L16 = Ckpt16Layout<8, C>;
     constexpr int G = 8;
+    // (steps unrolled by 2 in the chunk loops: removes the register-rotation moves.  MULTI indexes its per-chunk carry registers
+    // by the step inside the chunk, which must be a constant -- a dynamic index sends the arrays to scratch memory --, so its
+    // four steps are written out, with a scheduling barrier in the middle that keeps two steps' loads in flight, not four)
     extern __shared__ uint32_t lds[];
 
     int const  lane     = threadIdx.x;
@@ -242,13 +245,30 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     {
         int const col0 = panel * Geo::kPanel + g * C;
         // ---- profile: prof[slot][t][piece][g] = bytes (s(q_col, t) - go) of the lane's columns, four per dword.  The lane
-        // groups of a sub-block share the work: group r writes the letters 4w .. 4w+3 with w % share == r.
+        // groups of a sub-block share the work: group r writes the letters 4w .. 4w+3 with w % share == r.  The 1 KB table is
+        // copied into the (still idle) staging area first, so that the per-column row reads are LDS reads -- two dependent
+        // global loads per four columns made a wavefront's profiles cost 5 % of a panel.
         {
+            __builtin_amdgcn_wave_barrier(); // (the previous panel's staged codes have left)
+            uint32_t * const tab = lds + nslots * (nrows * Geo::kRowDw);
+            reinterpret_cast<uint4 *>(tab)[lane] = reinterpret_cast<uint4 const *>(sc->mat_b8)[lane];
+            auto letters = [&](int d) -> uint32_t // the query letters of columns 4d .. 4d+3 of this lane's strip, one per byte
+            {
+                int const j0 = col0 + 4 * d;
+                uint32_t  w  = 0x1f1f1f1fu;
+                if (j0 < lq)
+                    w = *reinterpret_cast<unaligned_u32 const *>(q + j0); // (the residue buffers carry slack behind their end)
+                return w;
+            };
+            uint32_t wcur = letters(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             int const r = grp % share_g;
 #pragma unroll 1
             for (int d = 0; d < Geo::kD; ++d)
             {
-                uint32_t rows[4][8];
+                uint32_t const wnext = d + 1 < Geo::kD ? letters(d + 1) : 0u;
+                uint32_t       rows[4][8];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
                 {
@@ -256,12 +276,13 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     int const j  = col0 + c;
                     uint32_t  ql = kAlph - 1; // pad rank: a row of zeros
                     if (c < C && j < lq)
-                        ql = q[j] & (kAlph - 1);
-                    uint4 const * mrow = reinterpret_cast<uint4 const *>(sc->mat_b8 + ql * kAlph);
+                        ql = (wcur >> (8 * cc)) & (kAlph - 1);
+                    uint4 const * mrow = reinterpret_cast<uint4 const *>(reinterpret_cast<uint8_t const *>(tab) + ql * kAlph);
                     uint4 const   lo = mrow[0], hi = mrow[1];
                     rows[cc][0] = lo.x; rows[cc][1] = lo.y; rows[cc][2] = lo.z; rows[cc][3] = lo.w;
                     rows[cc][4] = hi.x; rows[cc][5] = hi.y; rows[cc][6] = hi.z; rows[cc][7] = hi.w;
                 }
+                wcur = wnext;
                 uint32_t * dst = lds + slot_dw + Geo::dw_index(d, g);
 #pragma unroll
                 for (int w = 0; w < 8; ++w)
@@ -307,6 +328,39 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         uint32_t tie  = 0;
         q2       cmax = qsplat(0); // best un-skewed (and unbiased: >= 0) row maximum of the current chunk
 
+        // MULTI: the left boundary (A, E) of this chunk's four rows -- the previous panel's last column where there is one, the
+        // rectangle's edge (z + (go - ge), -inf) elsewhere -- made one chunk ahead, so that a step takes it from registers
+        // without a branch (a load issued in the step that needs it leaves its whole latency exposed; a lane-dependent branch
+        // per step costs a fifth of the step)
+        uint32_t cinA[4] = {0, 0, 0, 0}, cinE[4] = {0, 0, 0, 0}, ninA[4] = {0, 0, 0, 0}, ninE[4] = {0, 0, 0, 0};
+        uint32_t outA[4] = {0, 0, 0, 0}, outE[4] = {0, 0, 0, 0}; // (A, E) this lane sent in the chunk's four steps
+        auto carry_fetch = [&](int k0, q2 zf, uint32_t (&a)[4], uint32_t (&e)[4]) // zf = Z of step k0
+        {
+            if constexpr (MULTI)
+            {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    a[u] = qbits(zf + G2);
+                    e[u] = 0u;
+                    zf   = zf + NGE;
+                }
+                if (use_carry_in)
+                {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        int const i = k0 + u - g;
+                        if ((unsigned)i < (unsigned)ls_pair)
+                        {
+                            uint2 const v = *reinterpret_cast<uint2 const *>(carry + 2 * i);
+                            a[u]          = v.x;
+                            e[u]          = v.y;
+                        }
+                    }
+                }
+            }
+        };
         // one DP step at step index k = k0 + u (row k - g of this lane's strip)
         auto step = [&](uint32_t tA, uint32_t tB, int k, int u)
         {
@@ -335,12 +389,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             uint32_t bndA = qbits(Z + G2), bndE = 0u;
             if constexpr (MULTI)
             {
-                int const i = k - g;
-                if (use_carry_in && (unsigned)i < (unsigned)ls_pair)
-                {
-                    bndA = carry[2 * i];
-                    bndE = carry[2 * i + 1];
-                }
+                bndA = cinA[u];
+                bndE = cinE[u];
             }
             q2 const recvA = as_q2((uint32_t)shift_from_left<G>((int)qbits(sendA), (int)bndA, is_first));
             q2       Ecur  = as_q2((uint32_t)shift_from_left<G>((int)qbits(sendE), (int)bndE, is_first));
@@ -373,12 +423,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             sendE = Ecur;
             if constexpr (MULTI)
             {
-                int const i = k - g;
-                if (do_carry_out && (unsigned)i < (unsigned)ls_pair)
-                {
-                    carry[2 * i]     = qbits(sendA);
-                    carry[2 * i + 1] = qbits(sendE);
-                }
+                outA[u] = qbits(sendA); // (stored by chunk_done: one branch per four steps)
+                outE[u] = qbits(sendE);
             }
             cmax = qmax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
@@ -446,6 +492,19 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             cmax = qsplat(0);
             if (k0 & 4)
                 flush_codes(k0);
+            if constexpr (MULTI)
+            {
+                if (do_carry_out)
+                {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                    {
+                        int const i = k0 + u - g;
+                        if ((unsigned)i < (unsigned)ls_pair)
+                            *reinterpret_cast<uint2 *>(carry + 2 * i) = make_uint2(outA[u], outE[u]);
+                    }
+                }
+            }
         };
 
         uint32_t const lscA = (uint32_t)max(lsA, 1) - 1u, lscB = (uint32_t)max(lsB, 1) - 1u;
@@ -475,9 +534,23 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         uint8_t const * spA = sA - g;
         uint8_t const * spB = sB - g;
 
+        auto carry_rotate = [&](int k0)
+        {
+            if constexpr (MULTI)
+            {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                {
+                    cinA[u] = ninA[u];
+                    cinE[u] = ninE[u];
+                }
+                carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE); // (Z is the chunk's first step's here)
+            }
+        };
         int      k0 = 0;
         uint32_t na[4], nb[4];
         fetch_checked(0, na, nb);
+        carry_fetch(0, Z, ninA, ninE);
         while (k0 < steps)
         {
             bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
@@ -488,9 +561,21 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
                 mask_checked(k0, ca, cb);
                 fetch_checked(k0 + 4, na, nb);
+                carry_rotate(k0);
+                if constexpr (MULTI)
+                {
+                    step(ca[0], cb[0], k0, 0);
+                    step(ca[1], cb[1], k0 + 1, 1);
+                    __builtin_amdgcn_sched_barrier(0); // (two steps at a time in flight, as in the loops unrolled by 2)
+                    step(ca[2], cb[2], k0 + 2, 2);
+                    step(ca[3], cb[3], k0 + 3, 3);
+                }
+                else
+                {
 #pragma unroll 2
-                for (int u = 0; u < 4; ++u)
-                    step(ca[u], cb[u], k0 + u, u);
+                    for (int u = 0; u < 4; ++u)
+                        step(ca[u], cb[u], k0 + u, u);
+                }
                 chunk_done(k0);
                 k0 += 4;
             }
@@ -506,9 +591,21 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                     wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
                     wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
+                    carry_rotate(k0);
+                    if constexpr (MULTI)
+                    {
+                        step(ca & (kAlph - 1), cb & (kAlph - 1), k0, 0);
+                        step((ca >> 8) & (kAlph - 1), (cb >> 8) & (kAlph - 1), k0 + 1, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        step((ca >> 16) & (kAlph - 1), (cb >> 16) & (kAlph - 1), k0 + 2, 2);
+                        step((ca >> 24) & (kAlph - 1), (cb >> 24) & (kAlph - 1), k0 + 3, 3);
+                    }
+                    else
+                    {
 #pragma unroll 2
-                    for (int u = 0; u < 4; ++u)
-                        step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), k0 + u, u);
+                        for (int u = 0; u < 4; ++u)
+                            step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), k0 + u, u);
+                    }
                     chunk_done(k0);
                     k0 += 4;
                 }
@@ -596,20 +693,21 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
     return hipGetLastError();
 }
 
-// trace cfg 1 = (8,19), 3 = (8,13), 4 = (8,25): the geometries lx_ckpt.hip's compact layout is instantiated for with
-// 8-lane groups.  p.pair_share = lane groups per query (1, 2, 4; 0 or 8 = one query per wavefront); the slots are the
-// compact codes of Ckpt16Layout<8, C>, p.panels_cap parts each.
+// trace cfg 5 = (8,11), 3 = (8,13), 1 = (8,19): strips whose byte profiles leave room for four queries per wavefront at two
+// wavefronts per SIMD (<= 20 bytes per lane and letter; 25-column strips were measured and lose a fifth to their occupancy).
+// p.pair_share = lane groups per query (1, 2, 4; 0 or 8 = one query per wavefront); the slots are the compact codes of
+// Ckpt16Layout<8, C>, p.panels_cap parts each.
 hipError_t launch_sweep_mq(int trace_cfg, ScoreParams const & p, hipStream_t stream)
 {
     if (p.n == 0)
         return hipSuccess;
-    return trace_cfg == 1 ? launch_sweep_mq_cfg<19>(p, stream) : trace_cfg == 3 ? launch_sweep_mq_cfg<13>(p, stream) : trace_cfg == 4 ? launch_sweep_mq_cfg<25>(p, stream) : hipErrorInvalidValue;
+    return trace_cfg == 1 ? launch_sweep_mq_cfg<19>(p, stream) : trace_cfg == 3 ? launch_sweep_mq_cfg<13>(p, stream) : trace_cfg == 5 ? launch_sweep_mq_cfg<11>(p, stream) : hipErrorInvalidValue;
 }
 
 // LDS bytes of one wavefront (profiles + staging)
 size_t sweep_mq_lds_bytes(int trace_cfg, int nrows, int share)
 {
-    int const C = trace_cfg == 1 ? 19 : trace_cfg == 3 ? 13 : 25;
+    int const C = trace_cfg == 1 ? 19 : trace_cfg == 3 ? 13 : 11;
     int const s = (share > 0 && share < 8) ? share : 8;
     return ((size_t)(8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
 }

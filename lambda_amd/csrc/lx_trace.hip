@@ -699,9 +699,10 @@ __global__ void max_lens_kernel(Extension const * ext, uint64_t n, MaxLens * out
 // (cfg 2 = (16,13) [<= 208 columns, shared profile])
 // (cfg 3 = (8,13) [<= 104 columns, shared profile]: checkpoint / single-sweep kernels only, for short queries)
 // (cfg 3 = (8,13) and cfg 4 = (8,25) exist for the checkpoint kernels of lx_ckpt.hip only)
-int trace_cfg_panel(int cfg) { return cfg == 1 ? 8 * 19 : cfg == 2 ? 16 * 13 : cfg == 3 ? 8 * 13 : cfg == 4 ? 8 * 25 : 16 * 10; }
-int trace_cfg_group(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 4) ? 8 : 16; }
-int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : (cfg == 2 || cfg == 3) ? TraceWords<13>::kWords : cfg == 4 ? TraceWords<25>::kWords : TraceWords<10>::kWords; }
+// trace cfg: 0 = (16,10), 1 = (8,19), 2 = (16,13), 3 = (8,13), 4 = (8,25), 5 = (8,11) [checkpoint kernels only: the multi-query sweep]
+int trace_cfg_panel(int cfg) { return cfg == 1 ? 8 * 19 : cfg == 2 ? 16 * 13 : cfg == 3 ? 8 * 13 : cfg == 4 ? 8 * 25 : cfg == 5 ? 8 * 11 : 16 * 10; }
+int trace_cfg_group(int cfg) { return (cfg == 1 || cfg == 3 || cfg == 4 || cfg == 5) ? 8 : 16; }
+int trace_cfg_words(int cfg) { return cfg == 1 ? TraceWords<19>::kWords : (cfg == 2 || cfg == 3) ? TraceWords<13>::kWords : cfg == 4 ? TraceWords<25>::kWords : cfg == 5 ? TraceWords<11>::kWords : TraceWords<10>::kWords; }
 
 template <int G, int C>
 static hipError_t launch_trace_forward_cfg(TraceParams const & p, hipStream_t stream)

@@ -90,9 +90,11 @@ def check_against_oracle(oracle, osc, q, s, slots, cutoff, got_score, hsp, ops, 
 
 
 @pytest.mark.parametrize("run", [4, 8, 16])
-@pytest.mark.parametrize("lq_range,expect", [((30, 104), "sweep_mq_kernel<13,false>"), ((105, 152), "sweep_mq_kernel<19,false>"),
-                                             ((153, 200), "sweep_mq_kernel<25,false>"), ((209, 304), "sweep_mq_kernel<19,true>"),
-                                             ((330, 400), "sweep_mq_kernel<25,true>"), ((401, 440), "sweep_mq_kernel<19,true>")])
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((89, 104), "sweep_mq_kernel<13,false>"),
+                                             ((105, 152), "sweep_mq_kernel<19,false>"), ((153, 176), "sweep_mq_kernel<11,true>"),
+                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((265, 304), "sweep_mq_kernel<19,true>"),
+                                             ((313, 352), "sweep_mq_kernel<11,true>"), ((417, 440), "sweep_mq_kernel<19,true>"),
+                                             ((60, 456), "sweep_mq_kernel<19,true>")])
 def test_mq_sweep_ragged_lists(handle, oracle, run, lq_range, expect):
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)

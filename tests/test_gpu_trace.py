@@ -274,8 +274,10 @@ def test_fused_extend_on_device(handle, oracle, wpq, run, lq, pass2_mode):
             name = handle.last_trace_kernel_name()
             if lq > 208 and pass2_mode == 2 and run % 16 == 0:  # wider than a panel: the packed 16-bit sweep, panel by panel
                 assert "sweep_pair16_kernel" in name and ",true>" in name, name
-            assert (("ckpt_forward_kernel" in name) or ("score_pair_kernel<8,19,true>" in name) or
-                    ("score_pair_kernel<8,13,true>" in name)) == (pass2_mode >= 1)  # (8,13): queries of <= 104 columns
+            # (8,13): queries of <= 104 columns; runs of 8: the multi-query sweep, two queries per wavefront
+            assert (("ckpt_forward_kernel" in name) or ("score_pair_kernel<8,19,true>" in name) or ("score_pair_kernel<8,13,true>" in name) or
+                    ("sweep_mq_kernel" in name)) == (pass2_mode >= 1)
+            assert ("sweep_mq_kernel" in name and "2 queries per wavefront" in name) == (pass2_mode == 2 and run == 8)
             assert ("single sweep" in name) == (pass2_mode == 2)
     finally:
         handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
