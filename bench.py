@@ -72,6 +72,10 @@ def parse(argv=None):
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
                     "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
+    ap.add_argument("--survivor-rate", type=float, default=None, help="share of homologous windows in the synthetic batch (default 0.5: "
+                    "half of the windows pass the e-value cut-off, far more than a real seed set); 0.02 / 0.1 show the adaptive pass-2 mode "
+                    "(LX_OPT_ADAPT_PERMILLE)")
+    ap.add_argument("--adapt-permille", type=int, default=None, help="LX_OPT_ADAPT_PERMILLE (0 = always the single sweep)")
     ap.add_argument("--query-run", type=int, default=0, help="development aid: LX_OPT_QUERY_RUN promise for the device-resident step (default: the "
                     "workload's windows per query)")
     ap.add_argument("--mq-sweep", type=int, default=None, help="development aid: LX_OPT_MQ_SWEEP (2 = the multi-query sweep for every run that is a "
@@ -320,7 +324,7 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
 class DevBatch:
     """One device call's inputs and outputs, resident in HBM."""
 
-    def __init__(self, w, b, dev, min_score, band=0):
+    def __init__(self, w, b, dev, min_score, band=0, homolog_frac=0.5):
         import torch
 
         from lambda_amd import synth, workloads
@@ -330,7 +334,8 @@ class DevBatch:
         self.q_first = b.q_lo
         d_q, d_s, self.d_ext, ext = synth.make_batch_torch(
             b.n_queries, w.lq, w.windows, b.seed, dev, alphabet=workloads.alphabet_array(w), sub_rate=w.sub_rate,
-            indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank, convert=b.direction.convert, convert_rate=w.convert_rate)
+            indel_rate=w.indel_rate, n_rate=w.n_rate, n_rank=w.n_rank, convert=b.direction.convert, convert_rate=w.convert_rate,
+            homolog_frac=homolog_frac)
         pad = torch.zeros(256, dtype=torch.uint8, device=dev)
         self.d_q = torch.cat([d_q, pad])
         self.d_s = torch.cat([d_s, pad])
@@ -393,6 +398,8 @@ def main():
     h.set_option(capi.LX_OPT_QUERY_RUN, args.query_run if args.query_run else (w.windows if w.windows % 8 == 0 else 0))
     if args.mq_sweep is not None:
         h.set_option(capi.LX_OPT_MQ_SWEEP, args.mq_sweep)
+    if args.adapt_permille is not None:
+        h.set_option(capi.LX_OPT_ADAPT_PERMILLE, args.adapt_permille)
     h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
     if args.band > 0:
         h.set_band(args.band)  # default centres: min(_bandSize(Lq), Ls - Lq), the seed diagonal of the synthetic windows
@@ -404,7 +411,7 @@ def main():
         min_score += 1
 
     # ---- workload, generated directly in HBM; every rank owns different queries (shard by query)
-    batches = [DevBatch(w, b, dev, min_score, args.band) for b in pl.batches]
+    batches = [DevBatch(w, b, dev, min_score, args.band, 0.5 if args.survivor_rate is None else args.survivor_rate) for b in pl.batches]
     if not batches:
         raise SystemExit(f"rank {rank}: no queries to process (job of {pl.job_queries} queries over {world} ranks)")
     h.set_option(capi.LX_OPT_MAX_SLEN, max(b.max_slen for b in batches))

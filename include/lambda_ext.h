@@ -144,6 +144,11 @@ enum
                                    of 4; 0 = never (runs of 8 / 16 on the one-query-per-wavefront kernels).  Needs what the
                                    single sweep needs and a scheme in which no substitution costs more than a gap's first
                                    character (every scheme of the reference with its default gap costs) */
+    LX_OPT_ADAPT_PERMILLE  = 12, /* adaptive pass 2 (with LX_OPT_PASS2_MODE = 2): when fewer than this many per mille of the previous
+                                   batch's extensions passed the cut-off, the step runs plain pass 1 and writes checkpoints for
+                                   the survivors only (mode 1) instead of checkpoints for every window -- the reference's own
+                                   order, src/search_algo.hpp:1246 / :1251-1283 / :1296; default 30, 0 = always the single sweep.
+                                   Results are identical either way */
     LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
                                    says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
                                    parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of

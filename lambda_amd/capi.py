@@ -40,6 +40,7 @@ LX_OPT_PASS2_MODE = 8
 LX_OPT_BAND = 9
 LX_OPT_EXTEND_CHUNK = 10
 LX_OPT_MQ_SWEEP = 11
+LX_OPT_ADAPT_PERMILLE = 12
 
 
 class Karlin(C.Structure):
@@ -481,7 +482,7 @@ class Handle:
                 return np.zeros(0, dtype=BLAST_MATCH_DTYPE), [], stats
             buf = (C.c_char * (n * BLAST_MATCH_DTYPE.itemsize)).from_address(self.lib.lx_iterate_result_matches(res))
             bms = np.frombuffer(buf, dtype=BLAST_MATCH_DTYPE).copy()
-            total = int(bms["ops_off"][-1]) + int(bms["n_ops"][-1])
+            total = int((bms["ops_off"].astype(np.uint64) + bms["n_ops"].astype(np.uint64)).max())  # (not the last record's: bisulfite runs two passes)
             obuf = (C.c_char * max(total, 1)).from_address(self.lib.lx_iterate_result_ops(res))
             allops = bytes(obuf)
             ops = [allops[int(b["ops_off"]):int(b["ops_off"]) + int(b["n_ops"])] for b in bms]

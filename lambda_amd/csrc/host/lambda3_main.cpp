@@ -1,11 +1,18 @@
-// lambda3_main.cpp -- minimal `lambda3 searchp|searchn` front end around liblambda_ext (SURVEY.md section 7 step 9,
+// lambda3_main.cpp -- minimal `lambda3 searchp|searchn|searchbs` front end around liblambda_ext (SURVEY.md section 7 step 9,
 // section 8f rows N2/N3): plumbing for BASELINE.json configs[0], not a port of the reference's driver.
 //
 //   lambda3 searchp -q queries.fasta -d db.fasta -o out.m8 [-e 1e-2] [-n 25] [--seed-length 10] [--seed-offset 5]
+//                   [--devices 0,1,...] [-t THREADS]
 //
 // What it mirrors from the reference, and what it does not:
 //   * subcommand split and the handful of options of the hot path (src/lambda.cpp:30-118; src/search_options.hpp:88-107,
-//     :290-337): -q, -o (format from the extension, :684-710), -e, -n, --seed-length, --seed-offset, -t (accepted, unused);
+//     :290-337): -q, -o (format from the extension, :684-710), -e, -n, --seed-length, --seed-offset;
+//   * the thread split of realMain (src/search.cpp:379-385): -t worker threads (default: one per device of --devices, default
+//     all visible devices), each with its own handle -- one LocalDataHolder per thread there, one lx_handle = device + stream
+//     here --, the queries dealt to them in contiguous ranges, the records concatenated in range order before _writeRecord;
+//   * searchbs (src/lambda.cpp:103; domain_t::bisulfite, src/search_options.hpp:127, :261-264, :328): four query frames
+//     (strand x bisulfite duplicate), two subject frames, the 6-letter reduction of src/view_reduce_to_bisulfite.hpp for
+//     seeding, both scoring schemes (src/bisulfite_scoring.hpp:67-93), iterateMatches' bisulfite branch (:1367-1379);
 //   * the per-batch flow of realMain (src/search.cpp:389-459): seeding -> seedLooksPromising -> iterateMatches ->
 //     writeRecords, with the three middle stages on the GPU through the C ABI;
 //   * NOT the FM-index: the reference searches an index built by `lambda3 mkindexp` (fmindex-collection, absent here,
@@ -23,6 +30,7 @@
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -62,8 +70,24 @@ uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets p
     }
 }
 
+uint8_t dnaRankSeqan(char c) // SeqAn Dna5 rank A,C,G,T,N: the bisulfite schemes are matrices over it (src/bisulfite_scoring.hpp:54-93)
+{
+    switch (std::toupper((unsigned char)c))
+    {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T':
+        case 'U': return 3;
+        default: return 4;
+    }
+}
+
 // translate = six protein frames per nucleotide sequence (BLASTX queries: qryNumFrames = 6, translate_join)
-void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet & out, bool translate = false, int geneticCode = 1)
+// bsFrames: 0 = none; 1 = bisulfite subjects (every sequence twice: views::duplicate, src/shared_definitions.hpp:249-250);
+// 2 = bisulfite queries (strand, strand, reverse complement, reverse complement: add_reverse_complement | duplicate, :260-261)
+void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet & out, bool translate = false, int geneticCode = 1,
+               int bsFrames = 0)
 {
     std::ifstream in(path);
     if (!in)
@@ -90,6 +114,30 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
                 out.off.push_back(out.res.size());
                 out.len.push_back(fl[f]);
                 out.res.insert(out.res.end(), aa.begin() + fo[f], aa.begin() + fo[f] + fl[f]);
+            }
+            cur.clear();
+            return;
+        }
+        if (bsFrames)
+        {
+            auto push = [&](bool rc)
+            {
+                out.off.push_back(out.res.size());
+                out.len.push_back(cur.size());
+                static uint8_t const comp[5] = {3, 2, 1, 0, 4};
+                if (!rc)
+                    for (char c : cur)
+                        out.res.push_back(dnaRankSeqan(c));
+                else
+                    for (size_t i = cur.size(); i-- > 0;)
+                        out.res.push_back(comp[dnaRankSeqan(cur[i])]);
+            };
+            push(false);
+            push(false);
+            if (bsFrames == 2)
+            {
+                push(true);
+                push(true);
             }
             cur.clear();
             return;
@@ -141,7 +189,8 @@ struct Options
     int         preScoring  = 2;    // :104
     double      preScoringThresh = 2.0;
     int         idCutOff    = 0;
-    int         device      = 0;
+    std::vector<int> devices;         // --devices (default: every visible device)
+    int         threads     = 0;    // -t (default: one per device)
     std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
     std::string dbAlphabet  = "auto"; // searchp: "dna5" = six-frame translated subjects (TBLASTN / TBLASTX)
 };
@@ -172,17 +221,20 @@ Options parse(int argc, char ** argv)
 {
     Options o;
     if (argc < 2)
-        throw std::runtime_error("usage: lambda3 searchp|searchn -q QUERY.fasta -d DB.fasta -o OUT.{m8,m9,sam} [-e EVALUE] [-n N]");
+        throw std::runtime_error("usage: lambda3 searchp|searchn|searchbs -q QUERY.fasta -d DB.fasta -o OUT.{m8,m9,sam} [-e EVALUE] [-n N] "
+                                 "[--devices 0,1,...] [-t THREADS]");
     o.cmd = argv[1];
-    if (o.cmd != "searchp" && o.cmd != "searchn")
-        throw std::runtime_error("unknown subcommand '" + o.cmd + "' (searchp and searchn are in scope)");
-    bool const prot = o.cmd == "searchp";
-    // per-domain defaults, src/search_options.hpp:309-337
-    o.seedLength0      = prot ? 10 : 14;
-    o.seedOffset0      = prot ? 5 : 9;
-    o.seedLength       = prot ? 11 : 14;
-    o.seedOffset       = prot ? 3 : 7;
-    o.preScoringThresh = prot ? 2.0 : 1.4;
+    if (o.cmd != "searchp" && o.cmd != "searchn" && o.cmd != "searchbs")
+        throw std::runtime_error("unknown subcommand '" + o.cmd + "' (searchp, searchn and searchbs are in scope)");
+    bool const prot = o.cmd == "searchp", bs = o.cmd == "searchbs";
+    // per-domain defaults, src/search_options.hpp:309-337 (bisulfite: :261-264, :328-336)
+    o.seedLength0      = prot ? 10 : bs ? 17 : 14;
+    o.seedOffset0      = prot ? 5 : bs ? 10 : 9;
+    o.seedLength       = prot ? 11 : bs ? 17 : 14;
+    o.seedOffset       = prot ? 3 : bs ? 10 : 7;
+    o.preScoringThresh = prot ? 2.0 : bs ? 1.5 : 1.4;
+    if (bs)
+        o.maxEValue = 1e-9;
     for (int i = 2; i < argc; ++i)
     {
         std::string a = argv[i];
@@ -228,8 +280,22 @@ Options parse(int argc, char ** argv)
             o.geneticCode = std::stoi(val());
         else if (a == "--percent-identity")
             o.idCutOff = std::stoi(val());
-        else if (a == "--device")
-            o.device = std::stoi(val());
+        else if (a == "--device" || a == "--devices")
+        {
+            o.devices.clear();
+            std::string const v = val();
+            for (size_t at = 0; at <= v.size();)
+            {
+                size_t const e = std::min(v.find(',', at), v.size());
+                if (e > at)
+                    o.devices.push_back(std::stoi(v.substr(at, e - at)));
+                at = e + 1;
+            }
+            if (o.devices.empty())
+                throw std::runtime_error("--devices takes a comma-separated list of device numbers");
+        }
+        else if (a == "-t" || a == "--threads")
+            o.threads = std::stoi(val());
         else if (a == "--db-alphabet")
         {
             o.dbAlphabet = val();
@@ -242,7 +308,7 @@ Options parse(int argc, char ** argv)
             if (o.qryAlphabet != "auto" && o.qryAlphabet != "dna5" && o.qryAlphabet != "aminoacid")
                 throw std::runtime_error("--query-alphabet takes auto, dna5 or aminoacid");
         }
-        else if (a == "-t" || a == "--threads" || a == "-v" || a == "--verbosity" || a == "--version-to-outputfile" || a == "-p" ||
+        else if (a == "-v" || a == "--verbosity" || a == "--version-to-outputfile" || a == "-p" ||
                  a == "--profile")
             (void)val(); // accepted for command-line compatibility, no effect here
         else
@@ -262,32 +328,41 @@ int main(int argc, char ** argv)
     try
     {
         Options const opt  = parse(argc, argv);
-        bool const    prot = opt.cmd == "searchp";
+        bool const    prot = opt.cmd == "searchp", bs = opt.cmd == "searchbs";
         // searchp with nucleotide queries is BLASTX: six translated frames per query against the protein database
         bool const    blastx = prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
         // searchp against a nucleotide database translates the subjects instead (TBLASTN), or both sides (TBLASTX)
         bool const    sTrans  = prot && (opt.dbAlphabet == "dna5" || (opt.dbAlphabet == "auto" && looksLikeDna(opt.db)));
-        int const     qFrames = blastx ? 6 : prot ? 1 : 2;
-        int const     sFrames = sTrans ? 6 : 1;
+        // frames per sequence, src/search_datastructures.hpp:380-385
+        int const     qFrames = bs ? 4 : blastx ? 6 : prot ? 1 : 2;
+        int const     sFrames = bs ? 2 : sTrans ? 6 : 1;
         char const *  program = blastx ? (sTrans ? "tblastx" : "blastx") : sTrans ? "tblastn" : prot ? "blastp" : "blastn";
 
         SeqSet qs, db;
-        readFasta(opt.query, prot, !prot, qs, blastx, opt.geneticCode);
-        readFasta(opt.db, prot, false, db, sTrans, opt.geneticCode);
+        readFasta(opt.query, prot, !prot, qs, blastx, opt.geneticCode, bs ? 2 : 0);
+        readFasta(opt.db, prot, false, db, sTrans, opt.geneticCode, bs ? 1 : 0);
         if (qs.ids.empty() || db.ids.empty())
             throw std::runtime_error("empty query or database file");
 
-        // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234)
-        lx_scoring sc;
+        // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234): bisulfite = two matrices over SeqAn Dna5
+        // (forward: slot 0, reverse: slot 1, :176-186), statistics from the match / mismatch scheme
+        lx_scoring sc, scRev;
         int const  gapOpen = prot ? -11 : -5, gapExtend = prot ? -1 : -2;
-        lambda_amd::builtinScoring(prot ? 62 : 0, 2, -3, gapOpen, gapExtend, sc);
+        lambda_amd::builtinScoring(prot ? 62 : bs ? -1 : 0, 2, -3, gapOpen, gapExtend, sc);
+        if (bs)
+            lambda_amd::builtinScoring(-2, 2, -3, gapOpen, gapExtend, scRev);
         lx_karlin ka;
         if (!lambda_amd::karlinParams(prot ? 62 : 0, 2, -3, gapOpen, gapExtend, ka))
             throw std::runtime_error("Could not compute Karlin-Altschul-Values for Scoring Scheme."); // :232-233
-        lambda_amd::Engine eng(opt.device);
-        eng.setScoring(sc, 0);
-        // the database stays on the GPU for the whole run (the reference keeps it in the index file it maps at start-up)
-        eng.check(lx_set_subjects(eng.raw(), db.res.data(), db.res.size()));
+
+        // ---- devices and worker threads (src/search.cpp:379-385: one LocalDataHolder per thread; here one handle per thread)
+        std::vector<int> devices = opt.devices;
+        if (devices.empty())
+            for (int d = 0; d < lx_device_count(); ++d)
+                devices.push_back(d);
+        if (devices.empty())
+            throw std::runtime_error("no HIP device available (this front end has no CPU path)");
+        size_t const nWorkers = std::max<size_t>(1, std::min<size_t>(opt.threads > 0 ? (size_t)opt.threads : devices.size(), qs.ids.size()));
 
         // ---- seeding (search(), src/search_algo.hpp:611-762) over a sorted table of reduced words instead of the FM-index
         uint8_t const * redTab = nullptr;
@@ -296,31 +371,43 @@ int main(int argc, char ** argv)
             redTab = lambda_amd::kLi10, alph = 10;
         else if (prot && opt.reduction == "murphy10")
             redTab = lambda_amd::kMurphy10, alph = 10;
+        else if (bs)
+            alph = 6;
         else if (!prot)
             redTab = lambda_amd::kDna4, alph = 4;
-        auto reduce = [&](std::vector<uint8_t> const & res)
+        // bisulfite: the reduction alternates with the frame (even: forward, odd: reverse; src/view_reduce_to_bisulfite.hpp:132-136)
+        auto reduce = [&](SeqSet const & set)
         {
-            std::vector<uint8_t> red(res.size());
-            for (size_t i = 0; i < res.size(); ++i)
-                red[i] = redTab ? redTab[res[i] < (prot ? 27 : 5) ? res[i] : 0] : res[i];
+            std::vector<uint8_t> red(set.res.size());
+            if (bs)
+            {
+                for (size_t f = 0; f < set.off.size(); ++f)
+                    for (uint64_t i = 0; i < set.len[f]; ++i)
+                        red[set.off[f] + i] = ((f & 1) ? lambda_amd::kBsRev : lambda_amd::kBsFwd)[std::min<uint8_t>(set.res[set.off[f] + i], 4)];
+                return red;
+            }
+            for (size_t i = 0; i < set.res.size(); ++i)
+                red[i] = redTab ? redTab[set.res[i] < (prot ? 27 : 5) ? set.res[i] : 0] : set.res[i];
             return red;
         };
-        std::vector<uint8_t> const qRed = reduce(qs.res), dbRed = reduce(db.res);
+        std::vector<uint8_t> const qRed = reduce(qs), dbRed = reduce(db);
         lambda_amd::ReducedIndex   ix;
         ix.build(dbRed, db.off, db.len, alph);
         lambda_amd::SeedingInput sin{};
         sin.qRes = qs.res.data(), sin.qRed = qRed.data(), sin.qOff = qs.off.data(), sin.qLen = qs.len.data(), sin.nQSeq = qs.off.size();
         sin.qNumFrames       = qFrames;
-        sin.unknownRank      = prot ? 25 : 3; // 'X' / 'N'
+        sin.unknownRank      = prot ? 25 : bs ? 4 : 3; // 'X' / 'N'
         sin.sRes = db.res.data(), sin.sOff = db.off.data(), sin.sLen = db.len.data();
         sin.alph             = alph;
         sin.matrix           = sc.matrix;
+        sin.matrixRev        = bs ? scRev.matrix : nullptr;
         sin.maxMatches       = opt.maxMatches;
         sin.halfExact        = opt.halfExact;
         sin.adaptive         = opt.adaptive;
         sin.preScoring       = opt.preScoring;
         sin.preScoringThresh = opt.preScoringThresh;
 
+        // dbTotalLength = sum of the (frame-expanded) subject lengths, src/search_algo.hpp:317-319
         uint64_t dbTotal = 0;
         for (auto l : db.len)
             dbTotal += l;
@@ -332,64 +419,130 @@ int main(int argc, char ** argv)
         sp.query_translated = blastx ? 1 : 0;
         sp.qry_num_frames   = qFrames;
         sp.sbj_num_frames   = sFrames;
-        sp.q_frame_mode     = blastx ? LX_FRAMES_TRANSLATED : prot ? LX_FRAMES_NONE : LX_FRAMES_REVCOMP; // _setFrames, :768-814
-        sp.s_frame_mode     = sTrans ? LX_FRAMES_TRANSLATED : LX_FRAMES_NONE;
+        sp.bisulfite        = bs ? 1 : 0;
+        sp.q_frame_mode     = bs ? LX_FRAMES_BISULFITE : blastx ? LX_FRAMES_TRANSLATED : prot ? LX_FRAMES_NONE : LX_FRAMES_REVCOMP; // _setFrames, :768-814
+        sp.s_frame_mode     = bs ? LX_FRAMES_BISULFITE : sTrans ? LX_FRAMES_TRANSLATED : LX_FRAMES_NONE;
         sp.karlin           = ka;
 
+        lambda_amd::SeedParams const so1{opt.seedLength, opt.seedOffset, opt.seedDelta}, so0{opt.seedLength0, opt.seedOffset0, 0};
+        // what a worker keeps for its range of reads
+        struct Part
+        {
+            std::vector<lx_blast_match> bms;
+            std::vector<uint8_t>        ops;
+            lx_iterate_stats            ist{};
+            lambda_amd::SeedingStats    sst{};
+            size_t                      nPromising = 0;
+            std::string                 error;
+        };
+        std::vector<Part> parts(nWorkers);
+        uint64_t const    nReads = qs.ids.size();
+        auto worker = [&](size_t w)
+        {
+            Part & pt = parts[w];
+            try
+            {
+                // contiguous range of reads, as `omp for schedule(dynamic)` over whole batches would hand a thread (:384-385)
+                uint64_t const rLo = nReads * w / nWorkers, rHi = nReads * (w + 1) / nWorkers;
+                if (rLo == rHi)
+                    return;
+                lambda_amd::Engine eng(devices[w % devices.size()]);
+                eng.setScoring(sc, 0);
+                if (bs)
+                    eng.setScoring(scRev, 1);
+                // the database stays on the GPU for the whole run (the reference keeps it in the index file it maps at start-up)
+                eng.check(lx_set_subjects(eng.raw(), db.res.data(), db.res.size()));
+                // one pass of the batch loop of realMain (src/search.cpp:426-459): seed, extend (GPU), collect
+                auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
+                {
+                    std::vector<lx_match> matches;
+                    if (std::getenv("LAMBDA3_TRACE"))
+                        std::fprintf(stderr, "[worker %zu] seeding %zu frame sequences (seed %d/%d, delta %d)\n", w, which.size(), so.seedLength, so.seedOffset, so.maxSeedDist);
+                    lambda_amd::seedQueries(ix, sin, so, which, matches, pt.sst);
+                    pt.nPromising += matches.size();
+                    if (std::getenv("LAMBDA3_TRACE"))
+                        std::fprintf(stderr, "[worker %zu] %zu promising seeds -> extension\n", w, matches.size());
+                    if (matches.empty())
+                        return;
+                    lx_iterate_result * res = nullptr;
+                    eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
+                                                 qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(), db.off.size(), matches.data(),
+                                                 matches.size(), &sp, &res));
+                    uint64_t const         n  = lx_iterate_result_count(res);
+                    lx_blast_match const * bm = lx_iterate_result_matches(res);
+                    uint64_t const         ob = pt.ops.size();
+                    uint64_t opsEnd = 0; // (the records are ordered by query, their ops as the passes produced them: bisulfite runs two)
+                    for (uint64_t k = 0; k < n; ++k)
+                        opsEnd = std::max<uint64_t>(opsEnd, bm[k].ops_off + bm[k].n_ops);
+                    if (opsEnd)
+                        pt.ops.insert(pt.ops.end(), lx_iterate_result_ops(res), lx_iterate_result_ops(res) + opsEnd);
+                    for (uint64_t k = 0; k < n; ++k)
+                    {
+                        pt.bms.push_back(bm[k]);
+                        pt.bms.back().ops_off += ob;
+                    }
+                    lx_iterate_stats const st = lx_iterate_result_stats(res);
+                    pt.ist.hits_duplicate += st.hits_duplicate, pt.ist.failed_bitscore += st.failed_bitscore, pt.ist.failed_evalue += st.failed_evalue;
+                    pt.ist.failed_identity += st.failed_identity, pt.ist.num_ext_score += st.num_ext_score, pt.ist.num_ext_ali += st.num_ext_ali;
+                    lx_iterate_result_free(res);
+                };
+                std::vector<uint64_t> all;
+                for (uint64_t i = rLo * (uint64_t)qFrames; i < rHi * (uint64_t)qFrames; ++i)
+                    all.push_back(i);
+                if (opt.search0) // iterativeSearch (:1391-1457): the exact pre-search first, the default parameters for reads without a result
+                {
+                    pass(so0, all);
+                    std::vector<uint8_t> successful(nReads, 0);
+                    for (auto const & bm : pt.bms)
+                        successful[bm.n_qid] = 1;
+                    std::vector<uint64_t> rest;
+                    for (uint64_t i : all)
+                        if (!successful[i / (uint64_t)qFrames])
+                            rest.push_back(i);
+                    if (!rest.empty())
+                        pass(so1, rest);
+                    // (the reference writes phase 1's records of a batch before phase 2's; here both lists are written together:
+                    // order by read, as one batch holding every read would give)
+                    std::stable_sort(pt.bms.begin(), pt.bms.end(), [](lx_blast_match const & a, lx_blast_match const & b) { return a.n_qid < b.n_qid; });
+                }
+                else
+                    pass(so1, all);
+            }
+            catch (std::exception const & e)
+            {
+                pt.error = e.what();
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (size_t w = 1; w < nWorkers; ++w)
+                pool.emplace_back(worker, w);
+            worker(0);
+            for (auto & t : pool)
+                t.join();
+        }
+        // the ranges are disjoint and ascending: concatenation in range order is the order one thread would have produced
         std::vector<lx_blast_match> bms;
         std::vector<uint8_t>        ops;
         lx_iterate_stats            ist{};
         lambda_amd::SeedingStats    sst{};
         size_t                      nPromising = 0;
-        // one pass of the batch loop of realMain (src/search.cpp:426-459): seed, extend (GPU), collect
-        auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
+        for (Part & pt : parts)
         {
-            std::vector<lx_match> matches;
-            lambda_amd::seedQueries(ix, sin, so, which, matches, sst);
-            nPromising += matches.size();
-            if (matches.empty())
-                return;
-            lx_iterate_result * res = nullptr;
-            eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
-                                         qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(), db.off.size(), matches.data(),
-                                         matches.size(), &sp, &res));
-            uint64_t const         n  = lx_iterate_result_count(res);
-            lx_blast_match const * bm = lx_iterate_result_matches(res);
-            uint64_t const         ob = ops.size();
-            if (n)
-                ops.insert(ops.end(), lx_iterate_result_ops(res), lx_iterate_result_ops(res) + bm[n - 1].ops_off + bm[n - 1].n_ops);
-            for (uint64_t k = 0; k < n; ++k)
+            if (!pt.error.empty())
+                throw std::runtime_error(pt.error);
+            uint64_t const ob = ops.size();
+            ops.insert(ops.end(), pt.ops.begin(), pt.ops.end());
+            for (lx_blast_match m : pt.bms)
             {
-                bms.push_back(bm[k]);
-                bms.back().ops_off += ob;
+                m.ops_off += ob;
+                bms.push_back(m);
             }
-            lx_iterate_stats const st = lx_iterate_result_stats(res);
-            ist.hits_duplicate += st.hits_duplicate, ist.failed_bitscore += st.failed_bitscore, ist.failed_evalue += st.failed_evalue;
-            ist.failed_identity += st.failed_identity, ist.num_ext_score += st.num_ext_score, ist.num_ext_ali += st.num_ext_ali;
-            lx_iterate_result_free(res);
-        };
-        std::vector<uint64_t> all(qs.off.size());
-        for (size_t i = 0; i < all.size(); ++i)
-            all[i] = i;
-        lambda_amd::SeedParams const so1{opt.seedLength, opt.seedOffset, opt.seedDelta}, so0{opt.seedLength0, opt.seedOffset0, 0};
-        if (opt.search0) // iterativeSearch (:1391-1457): the exact pre-search first, the default parameters for reads without a result
-        {
-            pass(so0, all);
-            std::vector<uint8_t> successful(qs.ids.size(), 0);
-            for (auto const & bm : bms)
-                successful[bm.n_qid] = 1;
-            std::vector<uint64_t> rest;
-            for (size_t i = 0; i < all.size(); ++i)
-                if (!successful[i / (size_t)qFrames])
-                    rest.push_back(i);
-            if (!rest.empty())
-                pass(so1, rest);
-            // (the reference writes phase 1's records of a batch before phase 2's; here both lists are written together: order
-            // by read, as one batch holding every read would give)
-            std::stable_sort(bms.begin(), bms.end(), [](lx_blast_match const & a, lx_blast_match const & b) { return a.n_qid < b.n_qid; });
+            ist.hits_duplicate += pt.ist.hits_duplicate, ist.failed_bitscore += pt.ist.failed_bitscore, ist.failed_evalue += pt.ist.failed_evalue;
+            ist.failed_identity += pt.ist.failed_identity, ist.num_ext_score += pt.ist.num_ext_score, ist.num_ext_ali += pt.ist.num_ext_ali;
+            sst.hitsAfterSeeding += pt.sst.hitsAfterSeeding, sst.hitsFailedPreExtendTest += pt.sst.hitsFailedPreExtendTest;
+            nPromising += pt.nPromising;
         }
-        else
-            pass(so1, all);
         uint64_t const nHsp   = bms.size();
         size_t const   nSeeds = (size_t)sst.hitsAfterSeeding;
 
@@ -411,13 +564,17 @@ int main(int argc, char ** argv)
             fmt = LX_OUT_SAM;
         else if (!ends(".m8"))
             throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
-        eng.check(lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
-                                   reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data()));
+        {
+            int const rcw = lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
+                                             reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data());
+            if (rcw != LX_OK)
+                throw std::runtime_error("cannot write " + opt.output);
+        }
 
         std::fprintf(stderr,
-                     "lambda3 %s (%s): %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> windows %llu -> traced %llu -> "
-                     "HSPs %llu -> written %llu (queries with hit: %llu)\n",
-                     opt.cmd.c_str(), program, qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, nPromising,
+                     "lambda3 %s (%s, %zu thread(s) on %zu device(s)): %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> "
+                     "windows %llu -> traced %llu -> HSPs %llu -> written %llu (queries with hit: %llu)\n",
+                     opt.cmd.c_str(), program, nWorkers, devices.size(), qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, nPromising,
                      (unsigned long long)(ist.num_ext_score - ist.hits_duplicate), (unsigned long long)ist.num_ext_ali,
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
         return 0;

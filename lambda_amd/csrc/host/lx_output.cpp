@@ -42,12 +42,14 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
     uint64_t const leftClip = m.q_start * transFac, rightClip = (frameLen - m.q_end) * transFac;
     if (hardClip)
     {
-        if ((qTrans ? leftFrameClip : 0) + leftClip > 0)
-            el.emplace_back('H', (qTrans ? leftFrameClip : 0) + leftClip);
+        if (leftFrameClip + leftClip > 0)
+            el.emplace_back('H', leftFrameClip + leftClip);
     }
     else
     {
-        if (qTrans && leftFrameClip > 0)
+        // (:126 takes |qFrameShift| - 1 for every program: 0 for the frames +-1 of BLASTN, 1 for the second bisulfite
+        // duplicate of a strand, frames +-2 of :778-782)
+        if (leftFrameClip > 0)
             el.emplace_back('H', leftFrameClip);
         if (leftClip > 0)
             el.emplace_back('S', leftClip);
@@ -79,6 +81,8 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
         }
         if (cnt)
             el.emplace_back('M', cnt * transFac);
+        if (i < m.n_ops && o[i] != 'D' && o[i] != 'I' && o[i] != 'M') // (not an op byte: the caller's offsets are wrong -- no endless loop)
+            return "*";
     }
     if (hardClip)
     {

@@ -37,6 +37,13 @@ inline constexpr uint8_t kMurphy10[27] = {/*A*/ 2, /*B*/ 7, /*C*/ 1, /*D*/ 7, /*
 // BioC++ dna5 ranks (A, C, G, N, T) -> dna4 (A, C, G, T); N converts to A like every non-dna4 letter does
 inline constexpr uint8_t kDna4[5] = {0, 1, 2, 0, 3};
 
+// views::reduce_to_bisulfite (src/view_reduce_to_bisulfite.hpp:44-52) over SeqAn Dna5 ranks (A, C, G, T, N): even frames take the
+// forward reduction (C and T fall together: ranks 0, 1, 2, 1), odd frames the reverse one (G and A: ranks 3, 4, 3, 5) -- one
+// alphabet of six letters, so that a forward word never matches a reverse subject.  N converts like A (the reference draws a
+// random letter for it, src/view_dna_n_to_random.hpp).
+inline constexpr uint8_t kBsFwd[5] = {0, 1, 2, 1, 0};
+inline constexpr uint8_t kBsRev[5] = {3, 4, 3, 5, 3};
+
 struct SeedParams // SearchOptions' seeding part, src/search_options.hpp:309-337
 {
     int seedLength = 10, seedOffset = 5, maxSeedDist = 0;
@@ -191,27 +198,27 @@ inline void searchHalfExact(ReducedIndex const & ix, uint8_t const * seed, int s
 inline bool seedLooksPromising(uint8_t const * q, uint64_t qLen, uint8_t const * s, uint64_t sLen, lx_match const & m, int seedLength,
                                int preScoring, double preScoringThresh, int8_t const * matrix)
 {
-    int64_t  effectiveQBegin = (int64_t)m.qryStart, effectiveSBegin = (int64_t)m.subjStart;
-    uint64_t actualLength    = m.qryEnd - m.qryStart;
-    uint64_t effectiveLength = std::max<uint64_t>((uint64_t)(seedLength * preScoring), actualLength);
-    if (effectiveLength > actualLength)
+    int64_t  qFrom = (int64_t)m.qryStart, sFrom = (int64_t)m.subjStart;
+    uint64_t seedSpan    = m.qryEnd - m.qryStart;
+    uint64_t span = std::max<uint64_t>((uint64_t)(seedLength * preScoring), seedSpan);
+    if (span > seedSpan)
     {
-        effectiveQBegin -= (int64_t)((effectiveLength - actualLength) / 2);
-        effectiveSBegin -= (int64_t)((effectiveLength - actualLength) / 2);
-        int64_t const mn = std::min(effectiveQBegin, effectiveSBegin);
+        qFrom -= (int64_t)((span - seedSpan) / 2);
+        sFrom -= (int64_t)((span - seedSpan) / 2);
+        int64_t const mn = std::min(qFrom, sFrom);
         if (mn < 0)
         {
-            effectiveQBegin -= mn;
-            effectiveSBegin -= mn;
-            effectiveLength += (uint64_t)mn; // (unsigned wrap-around of a negative addend, as in the reference)
+            qFrom -= mn;
+            sFrom -= mn;
+            span += (uint64_t)mn; // (unsigned wrap-around of a negative addend, as in the reference)
         }
-        effectiveLength = std::min({(uint64_t)(qLen - (uint64_t)effectiveQBegin), (uint64_t)(sLen - (uint64_t)effectiveSBegin), effectiveLength});
+        span = std::min({(uint64_t)(qLen - (uint64_t)qFrom), (uint64_t)(sLen - (uint64_t)sFrom), span});
     }
     int       sc = 0, maxScore = 0;
-    int const thresh = (int)(preScoringThresh * (double)effectiveLength);
-    for (uint64_t i = 0; i < effectiveLength; ++i)
+    int const thresh = (int)(preScoringThresh * (double)span);
+    for (uint64_t i = 0; i < span; ++i)
     {
-        sc += matrix[(q[(uint64_t)effectiveQBegin + i] & 31) * LX_ALPH + (s[(uint64_t)effectiveSBegin + i] & 31)];
+        sc += matrix[(q[(uint64_t)qFrom + i] & 31) * LX_ALPH + (s[(uint64_t)sFrom + i] & 31)];
         if (sc < 0)
             sc = 0;
         else if (sc > maxScore)
@@ -242,6 +249,7 @@ struct SeedingInput
     uint64_t const * sLen;
     int              alph;        // reduced alphabet size
     int8_t const *   matrix;
+    int8_t const *   matrixRev = nullptr; // bisulfite: the reverse scheme, used for hits on odd subject frames (:464-466)
     uint64_t         maxMatches;
     bool             halfExact, adaptive;
     int              preScoring;
@@ -253,7 +261,7 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                         std::vector<lx_match> & matches, SeedingStats & stats)
 {
     size_t           hitsThisSeq = 0, needlesSum = 0, needlesPos = 0;
-    constexpr size_t heuristicFactor = 10; // :629
+    constexpr size_t kOccFactor = 10; // :629
     std::vector<ReducedIndex::Cursor> cursors;
     for (size_t w = 0; w < which.size(); ++w)
     {
@@ -289,7 +297,7 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                     {
                         size_t desiredOccs = hitsThisSeq >= in.maxMatches
                                                ? 1
-                                               : (in.maxMatches - hitsThisSeq) * heuristicFactor /
+                                               : (in.maxMatches - hitsThisSeq) * kOccFactor /
                                                    std::max<size_t>((needlesSum - needlesPos - seedBegin) / (size_t)so.seedOffset, 1ul);
                         if (desiredOccs == 0)
                             desiredOccs = 1;
@@ -309,7 +317,7 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                             old_cursor = cursor;
                         }
                     }
-                    if (cursor.count() > heuristicFactor * in.maxMatches) // over-abundant (:729)
+                    if (cursor.count() > kOccFactor * in.maxMatches) // over-abundant (:729)
                         continue;
                     ix.locate(cursor,
                               [&](uint32_t subjNo, uint32_t subjOffset)
@@ -317,7 +325,7 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                                   lx_match const m{i, subjNo, seedBegin, seedBegin + seedLength, subjOffset, subjOffset + seedLength};
                                   ++stats.hitsAfterSeeding;
                                   if (!seedLooksPromising(res, L, in.sRes + in.sOff[subjNo], in.sLen[subjNo], m, so.seedLength, in.preScoring,
-                                                          in.preScoringThresh, in.matrix))
+                                                          in.preScoringThresh, (in.matrixRev && (subjNo & 1u)) ? in.matrixRev : in.matrix))
                                       ++stats.hitsFailedPreExtendTest;
                                   else
                                   {

@@ -25,7 +25,7 @@ struct DevAids
     bool     sweep_int;         // LX_SWEEP_INT          compact sweep in the integer domain instead of packed half        off
     bool     no_i16_sweep;      // LX_NO_I16_SWEEP       wide queries: int32 sweep instead of the packed 16-bit one        off
     int      pass2_mode;        // LX_PASS2_MODE         initial value of LX_OPT_PASS2_MODE (-1 = the library's default)   -1
-    unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 8)           0
+    unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 16)           0
     bool     extend_no_classes; // LX_EXTEND_NO_CLASSES  lx_extend_batch: no geometry-class binning of ragged lists        off
     bool     extend_no_sort;    // LX_EXTEND_NO_SORT     lx_extend_batch: no in-run sort by window length                  off
     bool     extend_no_mq;      // LX_EXTEND_NO_MQ       lx_extend_batch: ragged lists on the one-query-per-wavefront kernels      off

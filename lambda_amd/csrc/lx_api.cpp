@@ -690,6 +690,22 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             }
         }
     }
+    // Adaptive choice (the one-query-per-wavefront sweep; lx_extend_batch's multi-query plan keeps its sweep): few survivors
+    // last time -> plain pass 1, checkpoints for the survivors only.  Phase 2 of a split step follows what phase 1 decided.
+    if (phases & 1)
+    {
+        if (sweep && !mq && h->opt_adapt != 0 && h->surv_frac >= 0.0 && h->surv_frac * 1000.0 < (double)h->opt_adapt)
+        {
+            sweep      = false;
+            half_sweep = false;
+        }
+        h->last_sweep_choice = sweep;
+    }
+    else if (sweep && !h->last_sweep_choice)
+    {
+        sweep      = false;
+        half_sweep = false;
+    }
     if (sweep && (phases & 1))
     {
         uint64_t const batch_dw = half_sweep ? (n + 1) * sweep_stride : n * sweep_stride;
@@ -1019,6 +1035,10 @@ int lx_create(int device_id, lx_handle ** out)
     for (int s = 0; s < 2; ++s)
         if ((e = hipMalloc(reinterpret_cast<void **>(&h->sc_dev[s]), sizeof(lx::ScoringDev))) != hipSuccess)
             return bail("hipMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&h->p_count), 2 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess)
+        return bail("hipHostMalloc", e);
+    if ((e = hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming)) != hipSuccess)
+        return bail("hipEventCreate", e);
     *out = h;
     return LX_OK;
 }
@@ -1042,6 +1062,10 @@ void lx_destroy(lx_handle * h)
         (void)hipFree(h->d_ws_top);
     if (h->alt.d_ws_top)
         (void)hipFree(h->alt.d_ws_top);
+    if (h->ev_count)
+        (void)hipEventDestroy(h->ev_count);
+    if (h->p_count)
+        (void)hipHostFree(h->p_count);
     for (DevBuf * b : {&h->alt.d_trace, &h->alt.d_ends, &h->alt.d_sel_ext, &h->alt.d_sel_src, &h->alt.d_sel_runs, &h->alt.d_sel_score,
                        &h->alt.d_trace_score, &h->alt.d_ws})
         if (b->ptr)
@@ -1099,6 +1123,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
         case LX_OPT_EXTEND_CHUNK: h->opt_extend_chunk = value; return LX_OK;
         case LX_OPT_MQ_SWEEP: h->opt_mq = value > 2 ? 1 : value; return LX_OK;
+        case LX_OPT_ADAPT_PERMILLE: h->opt_adapt = std::min<uint64_t>(value, 1000); h->surv_frac = -1.0; return LX_OK;
         case LX_OPT_BAND:
             if (value > (1u << 20))
                 return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
@@ -1125,6 +1150,7 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_BAND: *value = h->opt_band; return LX_OK;
         case LX_OPT_EXTEND_CHUNK: *value = h->opt_extend_chunk; return LX_OK;
         case LX_OPT_MQ_SWEEP: *value = h->opt_mq; return LX_OK;
+        case LX_OPT_ADAPT_PERMILLE: *value = h->opt_adapt; return LX_OK;
         default: return LX_EINVAL;
     }
 }
@@ -1427,8 +1453,26 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
                         uint64_t n, void const * d_min_score, int32_t min_score_all, void * d_out_score,
                         void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count, void * stream_)
 {
-    return fused_impl(h, slot, d_q_res, d_s_res, d_ext, n, d_min_score, min_score_all, d_out_score, d_out_hsp, d_out_ops, d_ops_off,
-                      d_out_count, stream_, 3, false);
+    if (h && h->count_pending && hipEventQuery(h->ev_count) == hipSuccess)
+    {
+        // the previous call's survivor count has arrived: the adaptive choice of pass-2 mode (fused_impl) goes by it
+        h->count_pending = false;
+        if (h->count_n)
+            h->surv_frac = (double)h->p_count[1] / (double)h->count_n;
+    }
+    int const rc = fused_impl(h, slot, d_q_res, d_s_res, d_ext, n, d_min_score, min_score_all, d_out_score, d_out_hsp, d_out_ops, d_ops_off,
+                              d_out_count, stream_, 3, false);
+    if (rc == LX_OK && n != 0 && h->p_count && !h->count_pending)
+    {
+        hipStream_t const stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
+        if (hipMemcpyAsync(h->p_count, d_out_count, 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipEventRecord(h->ev_count, stream) == hipSuccess)
+        {
+            h->count_pending = true;
+            h->count_n       = n;
+        }
+    }
+    return rc;
 }
 
 } // extern "C"

@@ -17,7 +17,7 @@ unsigned lxi::host_threads(uint64_t n)
         unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
         if (lx::dev_aids().host_threads)
             c = lx::dev_aids().host_threads;
-        return std::max(1u, std::min(c, 8u));
+        return std::max(1u, std::min(c, 16u));
     }();
     return avail;
 }
@@ -1356,6 +1356,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         if (count > pr.cap_sel)
             return fail(h, LX_ESTATE, "survivor list longer than its capacity");
+        if (pr.slots)
+            h->surv_frac = (double)cnt[1] / (double)pr.slots; // (adaptive pass-2 mode of the next chunks: fused_impl)
         int rc2;
         if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
             (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) ||

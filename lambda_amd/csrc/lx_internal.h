@@ -164,6 +164,17 @@ struct lx_handle
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
     uint64_t opt_mq        = 1; // LX_OPT_MQ_SWEEP
+    // Adaptive pass 2 (LX_OPT_PASS2_MODE = 2): the share of the last batch's extensions that passed the cut-off.  Below
+    // LX_OPT_ADAPT_PERMILLE the single sweep's checkpoints are mostly written for nothing, and the step runs as plain pass 1 +
+    // checkpoints for the survivors only (mode 1) until the share rises again.  The device entry point never synchronises: it
+    // copies the count back behind its kernels and reads it at the next call if it has arrived by then.
+    double      surv_frac        = -1.0;   // < 0: unknown
+    uint64_t *  p_count          = nullptr; // pinned: [0] = slots, [1] = survivors of the last device-resident call
+    hipEvent_t  ev_count         = nullptr;
+    uint64_t    count_n          = 0;
+    bool        count_pending    = false;
+    bool        last_sweep_choice = true;  // what phase 1 of the current step decided (phase 2 follows it)
+    uint64_t    opt_adapt        = 30;     // LX_OPT_ADAPT_PERMILLE
     int      mq_cfg_call   = 0; // lx_extend_batch: the strip geometry (trace cfg) it chose for this call's chunks (0 = fused_impl picks per chunk)
     uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
     uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)

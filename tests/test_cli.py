@@ -298,3 +298,82 @@ def test_searchp_tblastn_translated_subjects(tmp_path):
             exact += 1
             assert (ss_, se_) == (sstart, send) and (int(x[6]), int(x[7])) == (1, 70), (x, sstart, send)
     assert exact >= 0.7 * len(truth), exact
+
+
+@pytest.mark.gpu
+def test_devices_split_gives_identical_output(tmp_path):
+    """The thread / device split of realMain (/root/reference/src/search.cpp:379-385): two handles on one GPU (`--devices 0,0`),
+    three worker threads (`-t 3`) and the single-handle run write byte-identical BLAST-tabular and SAM files."""
+    _make_config1(tmp_path, nq=300, ndb=800)
+    db, qry = tmp_path / "db.fasta", tmp_path / "q.fasta"
+    outs = {}
+    for tag, extra in (("one", ["--devices", "0"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0", "-t", "3"])):
+        for ext in ("m8", "sam"):
+            out = tmp_path / f"{tag}.{ext}"
+            r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out)] + extra, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert ("2 thread(s)" in r.stderr) == (tag == "two") and ("3 thread(s)" in r.stderr) == (tag == "three"), r.stderr
+            outs[(tag, ext)] = out.read_bytes()
+    assert len(outs[("one", "m8")].splitlines()) >= 50
+    for ext in ("m8", "sam"):
+        assert outs[("one", ext)] == outs[("two", ext)] == outs[("three", ext)]
+    r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(tmp_path / "x.m8"), "--devices", "7"], capture_output=True, text=True)
+    assert r.returncode != 0 and "device_id 7 out of range" in r.stderr
+
+
+@pytest.mark.gpu
+def test_searchbs_both_strands_and_conversions(tmp_path, oracle):
+    """searchbs (/root/reference/src/lambda.cpp:103; frames src/search_datastructures.hpp:380-385, schemes
+    src/bisulfite_scoring.hpp:67-93): bisulfite-converted reads -- C->T on the read's own strand (forward scheme, even subject
+    frame) or G->A (reverse scheme, odd subject frame), from either genome strand -- come back on the right chromosome, strand
+    and position; every written score is the oracle's for the frame pair the record names."""
+    from lambda_amd import capi
+    from tests import oracle_lib
+
+    rng = np.random.default_rng(9)
+    genome = ["".join("ACGT"[i] for i in rng.integers(0, 4, 30000)) for _ in range(2)]
+    comp = str.maketrans("ACGT", "TGCA")
+    reads, truth = [], []
+    for k in range(80):
+        c, a = int(rng.integers(0, 2)), int(rng.integers(0, 29800))
+        frag = genome[c][a:a + 150]
+        minus, ga = (k % 2 == 1), (k % 4 >= 2)
+        if minus:
+            frag = frag.translate(comp)[::-1]
+        r = list(frag)
+        for i, ch in enumerate(r):  # 99 % conversion
+            if not ga and ch == "C" and rng.random() < 0.99:
+                r[i] = "T"
+            if ga and ch == "G" and rng.random() < 0.99:
+                r[i] = "A"
+        for p in rng.integers(0, 150, 2):
+            r[p] = "ACGT"[int(rng.integers(0, 4))]
+        reads.append("".join(r))
+        truth.append((c, a, minus, ga))
+    _fasta(tmp_path / "g.fasta", [f"chr{i}" for i in range(2)], genome)
+    _fasta(tmp_path / "r.fasta", [f"read{k}" for k in range(80)], reads)
+    out = tmp_path / "o.m8"
+    r = subprocess.run([str(_cli()), "searchbs", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "g.fasta"), "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "searchbs (blastn" in r.stderr
+    best = {}
+    for l in out.read_text().splitlines():
+        x = l.split("\t")
+        best.setdefault(x[0], x)
+    ok = 0
+    for k, (c, a, minus, ga) in enumerate(truth):
+        x = best.get(f"read{k}")
+        if x and x[1] == f"chr{c}":
+            ss, se = int(x[8]), int(x[9])
+            if (ss > se) == minus and abs(min(ss, se) - 1 - a) <= 10 and float(x[10]) <= 1e-9:
+                ok += 1
+    assert ok >= 74, ok
+    # the SAM writer on the same search: flags carry the strand, the second bisulfite duplicate hard-clips one base
+    # (blastMatchOneCigar takes |qFrameShift| - 1 for every program, src/search_output.hpp:126)
+    sam = tmp_path / "o.sam"
+    r = subprocess.run([str(_cli()), "searchbs", "-q", str(tmp_path / "r.fasta"), "-d", str(tmp_path / "g.fasta"), "-o", str(sam)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    recs = [l.split("\t") for l in sam.read_text().splitlines() if not l.startswith("@")]
+    assert len(recs) >= 74 and {int(x[1]) & 16 for x in recs} == {0, 16}
