@@ -592,7 +592,10 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     {
         bool const gaps_ok = -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
         uint64_t const run = h->opt_query_run;
-        bool const wanted  = h->opt_mq == 2 ? (run != 0 && run % 4 == 0) : h->opt_mq == 1 ? (run == 4 || run == 8) : false;
+        // (runs of 8: the packed-half sweep with one profile per half wavefront keeps its occupancy while both profiles fit
+        // ~13 KB -- the small alphabets: configs[2] 29.1 against 31.8 ms, configs[4] 7.4 against 8.1 -- and loses it beyond)
+        bool const half8_cheap = 2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= 13 * 1024;
+        bool const wanted  = h->opt_mq == 2 ? (run != 0 && run % 4 == 0) : h->opt_mq == 1 ? (run == 4 || (run == 8 && !half8_cheap)) : false;
         mq = wanted && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && gaps_ok && !h->opt_band;
     }
     if (mq)
