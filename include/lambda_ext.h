@@ -162,6 +162,25 @@ enum
                                    150 x 176 with b = 64 the band removes 27 % of the cells and no step of the strip mapping */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
+
+/* Introspection, no device needed: how lx_extend_batch_dev would run a batch of n extensions of queries up to max_qlen and
+ * windows up to max_slen under the given options (the LX_OPT_* of the same names; survivor_share < 0 = unknown).  The
+ * library decides this in ONE function; this entry point shows its answer, and tests/test_plan.py walks it over query
+ * widths, run lengths and schemes.  family: 0 = no sweep (pass 1, then pass 2 on the survivors), 1 = packed-half sweep,
+ * 2 = packed-int16 sweep with compact codes over several panels, 3 = packed-int16 sweep with int16-pair slots, 4 = int32 sweep,
+ * 5 = multi-query sweep (byte profiles).  name = what lx_last_trace_kernel_name() reports after such a step. */
+typedef struct lx_step_plan
+{
+    int32_t  family, group_lanes, strip_cols, panels;
+    int32_t  compact_codes, queries_per_wavefront, may_decline, adapted;
+    uint64_t slot_bytes;  /* checkpoint bytes per extension */
+    uint64_t lds_bytes;   /* LDS of one wavefront of the sweep kernel */
+    uint64_t score_bound; /* a-priori bound of every intermediate for the widest admitted query */
+    char     name[160];
+} lx_step_plan;
+int lx_plan_step(lx_scoring const * sc, uint64_t max_qlen, uint64_t max_slen, uint64_t query_run, uint64_t n, uint64_t pass2_mode,
+                 uint64_t mq_sweep, uint64_t packed_half, uint64_t trace_bytes, double survivor_share, uint64_t adapt_permille,
+                 lx_step_plan * out);
 /* current value of an option (what the caller set or the default; never the library's internal growth of a workspace) */
 int lx_get_option(lx_handle const * h, int option, uint64_t * value);
 

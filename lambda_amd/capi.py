@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
     "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_plan_step",
 ]
 
 LX_OPT_MAX_SLEN = 4
@@ -239,6 +240,29 @@ def write_records(path, fmt: int, bms: np.ndarray, ops: bytes, q_ids, q_lens, s_
                                  _ptr(qoff) if qoff is not None else None)
     if rc != LX_OK:
         raise LambdaExtError(rc, "lx_write_records")
+
+
+class StepPlan(C.Structure):
+    _fields_ = [("family", C.c_int32), ("group_lanes", C.c_int32), ("strip_cols", C.c_int32), ("panels", C.c_int32),
+                ("compact_codes", C.c_int32), ("queries_per_wavefront", C.c_int32), ("may_decline", C.c_int32), ("adapted", C.c_int32),
+                ("slot_bytes", C.c_uint64), ("lds_bytes", C.c_uint64), ("score_bound", C.c_uint64), ("name", C.c_char * 160)]
+
+
+PLAN_NO_SWEEP, PLAN_HALF, PLAN_I16_COMPACT_WIDE, PLAN_I16_PAIRS, PLAN_INT32, PLAN_MQ = range(6)
+
+
+def plan_step(scoring, max_qlen: int, max_slen: int, query_run: int, n: int, pass2_mode: int = 2, mq_sweep: int = 1, packed_half: int = 1,
+              trace_bytes: int = 64 << 30, survivor_share: float = -1.0, adapt_permille: int = 30) -> StepPlan:
+    """lx_plan_step: how lx_extend_batch_dev would run such a batch (no device needed)."""
+    lib = load()
+    lib.lx_plan_step.argtypes = [C.c_void_p] + [C.c_uint64] * 8 + [C.c_double, C.c_uint64, C.c_void_p]
+    lib.lx_plan_step.restype = C.c_int
+    out = StepPlan()
+    rc = lib.lx_plan_step(C.byref(scoring), max_qlen, max_slen, query_run, n, pass2_mode, mq_sweep, packed_half, trace_bytes, survivor_share,
+                          adapt_permille, C.byref(out))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_plan_step")
+    return out
 
 
 def karlin_params(method: int, match: int = 2, mismatch: int = -3, gap_open: int = -11, gap_extend: int = -1) -> Karlin:

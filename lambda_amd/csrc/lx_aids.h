@@ -19,10 +19,8 @@ struct DevAids
     int      force_ckpt_cfg;    // LX_FORCE_CKPT_CFG     checkpoint geometry 1 = (8,19), 2 = (16,13) (0 = pick)            0
     bool     trace_overlap;     // LX_TRACE_OVERLAP=1    mode-0 pass 2: forward of chunk k+1 beside the backtrace of k     off
     uint64_t trace_chunks;      // LX_TRACE_CHUNKS       mode-0/1 pass 2: at least this many chunks                        1
-    bool     no_narrow_sweep;   // LX_NO_NARROW_SWEEP    keep (8,19) for queries <= 104 columns instead of (8,13)          off
     bool     no_wide_strips;    // LX_NO_WIDE_STRIPS     153-200 column queries: (16,13) strips instead of (8,25)                off
     bool     no_wide_compact;   // LX_NO_WIDE_COMPACT    queries wider than a panel: int16-pair slots instead of compact codes    off
-    bool     sweep_int;         // LX_SWEEP_INT          compact sweep in the integer domain instead of packed half        off
     bool     no_i16_sweep;      // LX_NO_I16_SWEEP       wide queries: int32 sweep instead of the packed 16-bit one        off
     int      pass2_mode;        // LX_PASS2_MODE         initial value of LX_OPT_PASS2_MODE (-1 = the library's default)   -1
     unsigned host_threads;      // LX_HOST_THREADS       cap of the host pool (0 = the affinity mask, at most 16)           0

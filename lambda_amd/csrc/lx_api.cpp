@@ -38,10 +38,8 @@ lx::DevAids const & lx::dev_aids()
             a.mq_set = 7;
         a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
         a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
-        a.no_narrow_sweep   = set("LX_NO_NARROW_SWEEP");
         a.no_wide_strips    = set("LX_NO_WIDE_STRIPS");
         a.no_wide_compact   = set("LX_NO_WIDE_COMPACT");
-        a.sweep_int         = set("LX_SWEEP_INT");
         a.no_i16_sweep      = set("LX_NO_I16_SWEEP");
         a.pass2_mode        = set("LX_PASS2_MODE") ? (int)std::min(std::max(num("LX_PASS2_MODE", 2), 0ll), 2ll) : -1;
         a.host_threads      = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
@@ -542,6 +540,185 @@ static int fused_pack(lx_handle * h, FusedExtra const * fx, uint64_t cap, void *
     return LX_OK;
 }
 
+// ---- the ONE place that decides how a fused step runs: which sweep kernel family (if any), geometry, panel count, slot
+// layout, queries per wavefront.  A pure function of the scheme's facts and the handle's options -- fused_impl follows it, and
+// lx_plan_step() shows it to tests/test_plan.py, which walks it over query widths, run lengths and schemes on the CPU.
+lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
+{
+    bool const shared = o.query_run != 0 && o.query_run % 8 == 0;
+
+    // Single sweep (LX_OPT_PASS2_MODE = 2): the checkpoint forward kernel runs once over ALL extensions -- it is pass 1
+    // and the forward half of pass 2 at the same time -- and the backtrace reads the checkpoints of the survivors in
+    // place.  Needs the checkpoints of the whole batch inside the trace budget and a shared-profile geometry.
+    bool sweep = false;
+    int  sweep_cfg = 0;
+    uint32_t sweep_steps = 0, sweep_panels = 1;
+    uint64_t sweep_stride = 0;   // uint32 per slot of the batch
+    uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
+    uint64_t ovf_cap = 0;
+    int      sweep_share = 0;
+    bool     half_sweep = false, may_decline = true, wide_compact = false;
+    int const nrows_sc = ((sc.alph + 1 + 3) / 4) * 4;
+    // Multi-query sweep (lx_sweep_mq.hip): query runs of 4 or 8 (2 / 4 lane groups per LDS profile) -- what lx_extend_batch
+    // makes of a ragged list --, or any multiple of 4 when LX_OPT_MQ_SWEEP = 2 asks for it.  Needs byte profiles (no
+    // substitution dearer than a gap's first character) and compact codes (that character costs at most 31).
+    bool mq = false;
+    {
+        bool const gaps_ok = -sc.gap_open <= lx::kC16MaxGap && sc.gap_open <= sc.gap_extend;
+        uint64_t const run = o.query_run;
+        // (runs of 8: the packed-half sweep with one profile per half wavefront keeps its occupancy while both profiles fit
+        // ~13 KB -- the small alphabets: configs[2] 29.1 against 31.8 ms, configs[4] 7.4 against 8.1 -- and loses it beyond)
+        bool const half8_cheap = 2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= 13 * 1024;
+        // (... and for queries beyond 208 columns a run that is a multiple of 8 but not of 16 has no packed sweep with compact
+        // codes of its own: the multi-query one serves it)
+        bool const odd8    = run % 8 == 0 && run % 16 != 0 && run != 0;
+        bool const wanted  = o.mq == 2 ? (run != 0 && run % 4 == 0) : o.mq == 1 ? (run == 4 || (odd8 && (!half8_cheap || o.max_qlen > 208))) : false;
+        mq = wanted && o.pass2 == 2 && o.f16 && sc.trace_ok && sc.b8_ok && gaps_ok && !o.band;
+    }
+    if (mq)
+    {
+        int const smax_entry = sc.smax_entry;
+        sweep_cfg    = o.mq_cfg_call ? o.mq_cfg_call : mq_cfg_for(o.max_qlen);
+        sweep_panels = (uint32_t)std::max<uint64_t>(1, (o.max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
+        mq           = (uint64_t)smax_entry * std::min(o.max_qlen, o.max_slen) < 32000 && o.max_slen <= 65535;
+        if (mq)
+        {
+            int const G    = 8;
+            sweep_steps    = (uint32_t)((o.max_slen + G - 1 + 15) & ~15ull);
+            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            sweep_stride   = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+            half_sweep     = true;
+            // lane groups per query: a wavefront's 16 slots hold 16 / 8 / 4 windows of one query, whatever divides the run
+            sweep_share    = (o.query_run % 16 == 0 ? 16 : o.query_run % 8 == 0 ? 8 : 4) / 2;
+            sweep          = (o.n + 1) * sweep_stride * 4 <= o.trace_bytes;
+            int64_t const worst = (int64_t)o.max_qlen * std::max(smax_entry, 0) + (int64_t)(-sc.gap_extend) * (sweep_steps + G + 2) +
+                                  (smax_entry - sc.gap_extend) + 2;
+            may_decline = worst > 2046 || sweep_panels > 1;
+            if (sweep && may_decline)
+                ovf_cap = std::min<uint64_t>(o.n, (o.trace_bytes - (o.n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
+            mq = sweep; // (a batch beyond the slot budget: the per-survivor paths below)
+            if (!sweep)
+                half_sweep = false;
+        }
+    }
+    if (!mq && o.pass2 == 2 && shared && sc.trace_ok && !o.band)
+    {
+        // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
+        sweep_cfg    = ckpt_cfg_for(o.max_qlen, o.f16 && o.query_run % 16 == 0);
+        // short queries (<= 104 columns, e.g. 100-residue reads): the (8,13) geometry where the packed-half sweep applies --
+        // a third fewer padded columns than (8,19)
+        bool const half_ok = o.f16 && -sc.gap_open <= lx::kC16MaxGap && sc.gap_open <= sc.gap_extend;
+        if (sweep_cfg == 1 && half_ok && o.max_qlen <= (uint64_t)lx::trace_cfg_panel(3) &&
+            (o.query_run % 16 == 0 || 2 * lx::score_pair_profile_bytes(1, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit()))
+            sweep_cfg = 3;
+        // 153 - 200 columns: 25-column strips of 8-lane groups (16 extensions of one query per wavefront, 7 steps of skew
+        // instead of 15, no padded column at 200) where the packed-half sweep applies
+        if (sweep_cfg == 2 && half_ok && !lx::dev_aids().no_wide_strips && o.max_qlen <= (uint64_t)lx::trace_cfg_panel(4) &&
+            o.query_run % 16 == 0)
+            sweep_cfg = 4;
+        sweep_panels = (uint32_t)std::max<uint64_t>(1, (o.max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
+        int const smax_entry = sc.smax_entry;
+        if (sweep_cfg != 0 && (uint64_t)smax_entry * std::min(o.max_qlen, o.max_slen) < 32000 && o.max_slen <= 65535)
+        {
+            int const G    = lx::trace_cfg_group(sweep_cfg);
+            sweep_steps    = (uint32_t)((o.max_slen + G - 1 + 15) & ~15ull);
+            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
+            // Packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query per
+            // wavefront, or runs of 8 with one query per half wavefront where two LDS profiles fit, i.e. for the small
+            // alphabets; (16,13): 8 extensions) and a gap's first character costs at most 31 (the compact checkpoint codes
+            // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
+            half_sweep = o.f16 && sweep_panels == 1 && -sc.gap_open <= lx::kC16MaxGap &&
+                         sc.gap_open <= sc.gap_extend &&
+                         (((sweep_cfg == 1 || sweep_cfg == 3 || sweep_cfg == 4) && o.query_run % 16 == 0) || sweep_cfg == 2);
+            // Queries wider than a panel: compact codes as well, one part per (8,19) panel, written by the packed int16 kernel
+            // (the half-precision one has no carry between panels); what scores beyond the codes' 2046 goes to the int32 launch
+            wide_compact = o.f16 && sweep_panels > 1 && sweep_cfg == 1 && o.query_run % 16 == 0 &&
+                           -sc.gap_open <= lx::kC16MaxGap && sc.gap_open <= sc.gap_extend &&
+                           !lx::dev_aids().no_wide_compact && !lx::dev_aids().no_i16_sweep;
+            half_sweep = half_sweep || wide_compact;
+            if (o.f16 && sweep_panels == 1 && -sc.gap_open <= lx::kC16MaxGap &&
+                sc.gap_open <= sc.gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && o.query_run % 8 == 0 &&
+                2 * lx::score_pair_profile_bytes(sweep_cfg == 3 ? 1 : 0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
+            {
+                half_sweep  = true;
+                sweep_share = 4;
+            }
+            if (half_sweep)
+            {
+                // compact slots for the batch (+ the spare slot idle halves write to), int16-pair slots for what the
+                // packed kernel declines in whatever the budget leaves
+                sweep_stride = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+                sweep        = (o.n + 1) * sweep_stride * 4 <= o.trace_bytes;
+                // (the packed kernel's exactness gate, lx_score_f16.hip: it cannot decline when even the worst query passes)
+                int64_t const worst = (int64_t)o.max_qlen * std::max(smax_entry, 0) +
+                                      (int64_t)(-sc.gap_extend) * (sweep_steps + G + 2) +
+                                      (smax_entry - sc.gap_extend) + 2; // (ScoringDev::smax = largest entry - ge)
+                may_decline = worst > 2046 || wide_compact;
+                if (sweep && may_decline)
+                    ovf_cap = std::min<uint64_t>(o.n, (o.trace_bytes - (o.n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
+            }
+            else
+            {
+                sweep_stride = sweep_stride32;
+                sweep        = o.n * sweep_stride * 4 <= o.trace_bytes;
+            }
+        }
+    }
+    // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16 kernel
+    // writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range test is left to
+    // the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
+    bool const i16_sweep = sweep && !half_sweep && o.f16 && !lx::dev_aids().no_i16_sweep && o.query_run % (sweep_cfg == 1 ? 16 : 8) == 0 &&
+                           sweep_cfg != 3 && sweep_cfg != 4;
+    // Adaptive choice (the one-query-per-wavefront sweep; lx_extend_batch's multi-query plan keeps its sweep): few survivors
+    // last time -> plain pass 1, checkpoints for the survivors only (mode 1).
+    bool const adapted = sweep && !mq && o.adapt != 0 && o.surv_frac >= 0.0 && o.surv_frac * 1000.0 < (double)o.adapt;
+    StepPlan pl{};
+    pl.shared       = shared;
+    pl.sweep        = sweep && !adapted;
+    pl.adapted      = adapted;
+    pl.family       = !pl.sweep ? kNoSweep : mq ? kMqSweep : wide_compact ? kI16CompactWide : half_sweep ? kHalfSweep : i16_sweep ? kI16Pairs : kInt32Sweep;
+    pl.cfg          = sweep_cfg;
+    pl.steps        = sweep_steps;
+    pl.panels       = sweep_panels;
+    pl.stride       = sweep_stride;
+    pl.stride32     = sweep_stride32;
+    pl.ovf_cap      = pl.sweep ? ovf_cap : 0;
+    pl.share        = sweep_share;
+    pl.compact      = pl.sweep && half_sweep;
+    pl.may_decline  = may_decline;
+    return pl;
+}
+
+// the sweep a plan names, as the launch sequence fused_impl issues for it (what lx_last_trace_kernel_name reports)
+void lxi::describe_plan(StepPlan const & pl, char * buf, size_t len)
+{
+    int const nameG = lx::trace_cfg_group(pl.cfg), nameC = lx::trace_cfg_panel(pl.cfg) / std::max(1, lx::trace_cfg_group(pl.cfg));
+    switch (pl.family)
+    {
+        case kMqSweep:
+            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %d queries per wavefront%s)", nameC, pl.panels > 1 ? "true" : "false",
+                     8 / std::max(1, pl.share), pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
+            break;
+        case kI16CompactWide:
+            snprintf(buf, len, "lx::sweep_pair16_kernel<%d,%d,true,true,true> (single sweep, compact codes; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
+                     nameG, nameC, nameG, nameC);
+            break;
+        case kHalfSweep:
+            if (pl.may_decline)
+                snprintf(buf, len, "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)", nameG, nameC,
+                         nameG, nameC);
+            else
+                snprintf(buf, len, "lx::score_pair_kernel<%d,%d,true> (single sweep)", nameG, nameC);
+            break;
+        case kI16Pairs:
+            snprintf(buf, len, "lx::sweep_pair16_kernel<%d,%d,%s> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)", nameG, nameC,
+                     pl.panels > 1 ? "true" : "false", nameG, nameC);
+            break;
+        case kInt32Sweep: snprintf(buf, len, "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", nameG, nameC); break;
+        default: snprintf(buf, len, "%s", pl.adapted ? "pass 1, then checkpoints for the survivors (few survived the last batch)" : "pass 1, then pass 2 on the survivors"); break;
+    }
+}
+
 int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext, uint64_t n,
                       void const * d_min_score, int32_t min_score_all, void * d_out_score, void * d_out_hsp, void * d_out_ops,
                       void const * d_ops_off, void * d_out_count, void * stream_, int phases, bool by_pos,
@@ -571,144 +748,32 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         h->ev_pool_used = 0;
         LX_HIP(h, hipEventRecord(h->ev0, stream));
     }
-    bool const shared = h->opt_query_run != 0 && h->opt_query_run % 8 == 0;
-
-    // Single sweep (LX_OPT_PASS2_MODE = 2): the checkpoint forward kernel runs once over ALL extensions -- it is pass 1
-    // and the forward half of pass 2 at the same time -- and the backtrace reads the checkpoints of the survivors in
-    // place.  Needs the checkpoints of the whole batch inside the trace budget and a shared-profile geometry.
-    bool sweep = false;
-    int  sweep_cfg = 0;
-    uint32_t sweep_steps = 0, sweep_panels = 1;
-    uint64_t sweep_stride = 0;   // uint32 per slot of the batch
-    uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
-    uint64_t ovf_cap = 0;
-    int      sweep_share = 0;
-    bool     half_sweep = false, may_decline = true, wide_compact = false;
-    int const nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
-    // Multi-query sweep (lx_sweep_mq.hip): query runs of 4 or 8 (2 / 4 lane groups per LDS profile) -- what lx_extend_batch
-    // makes of a ragged list --, or any multiple of 4 when LX_OPT_MQ_SWEEP = 2 asks for it.  Needs byte profiles (no
-    // substitution dearer than a gap's first character) and compact codes (that character costs at most 31).
-    bool mq = false;
-    {
-        bool const gaps_ok = -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
-        uint64_t const run = h->opt_query_run;
-        // (runs of 8: the packed-half sweep with one profile per half wavefront keeps its occupancy while both profiles fit
-        // ~13 KB -- the small alphabets: configs[2] 29.1 against 31.8 ms, configs[4] 7.4 against 8.1 -- and loses it beyond)
-        bool const half8_cheap = 2 * lx::score_pair_profile_bytes(0, nrows_sc) + 64 * 8 * 4 <= 13 * 1024;
-        bool const wanted  = h->opt_mq == 2 ? (run != 0 && run % 4 == 0) : h->opt_mq == 1 ? (run == 4 || (run == 8 && !half8_cheap)) : false;
-        mq = wanted && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && gaps_ok && !h->opt_band;
-    }
-    if (mq)
-    {
-        int smax_entry = 0;
-        for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
-            for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
-                smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-        sweep_cfg    = h->mq_cfg_call ? h->mq_cfg_call : mq_cfg_for(h->opt_max_qlen);
-        sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
-        mq           = (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535;
-        if (mq)
-        {
-            int const G    = 8;
-            sweep_steps    = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
-            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
-            sweep_stride   = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
-            half_sweep     = true;
-            sweep_share    = (int)std::min<uint64_t>(h->opt_query_run, 16) / 2; // lane groups per query
-            sweep          = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
-            int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) + (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) +
-                                  (smax_entry - h->sc_host[slot].gap_extend) + 2;
-            may_decline = worst > 2046 || sweep_panels > 1;
-            if (sweep && may_decline)
-                ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
-            mq = sweep; // (a batch beyond the slot budget: the per-survivor paths below)
-            if (!sweep)
-                half_sweep = false;
-        }
-    }
-    if (!mq && h->opt_pass2 == 2 && shared && h->trace_ok[slot] && !h->opt_band)
-    {
-        // one panel of (8,19) or (16,13); wider queries: several (16,13) panels, int32 sweep
-        sweep_cfg    = ckpt_cfg_for(h->opt_max_qlen, h->opt_f16 && h->opt_query_run % 16 == 0);
-        // short queries (<= 104 columns, e.g. 100-residue reads): the (8,13) geometry where the packed-half sweep applies --
-        // a third fewer padded columns than (8,19)
-        bool const half_ok = h->opt_f16 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend;
-        bool const no_narrow = lx::dev_aids().no_narrow_sweep; // A/B aid
-        if (sweep_cfg == 1 && half_ok && !no_narrow && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(3) &&
-            (h->opt_query_run % 16 == 0 || 2 * lx::score_pair_profile_bytes(1, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit()))
-            sweep_cfg = 3;
-        // 153 - 200 columns: 25-column strips of 8-lane groups (16 extensions of one query per wavefront, 7 steps of skew
-        // instead of 15, no padded column at 200) where the packed-half sweep applies
-        if (sweep_cfg == 2 && half_ok && !lx::dev_aids().no_wide_strips && h->opt_max_qlen <= (uint64_t)lx::trace_cfg_panel(4) &&
-            h->opt_query_run % 16 == 0)
-            sweep_cfg = 4;
-        sweep_panels = (uint32_t)std::max<uint64_t>(1, (h->opt_max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
-        int smax_entry = 0;
-        for (int a = 0; a < h->sc_host[slot].alphabet_size; ++a)
-            for (int b = 0; b < h->sc_host[slot].alphabet_size; ++b)
-                smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
-        if (sweep_cfg != 0 && (uint64_t)smax_entry * std::min(h->opt_max_qlen, h->opt_max_slen) < 32000 && h->opt_max_slen <= 65535)
-        {
-            int const G    = lx::trace_cfg_group(sweep_cfg);
-            sweep_steps    = (uint32_t)((h->opt_max_slen + G - 1 + 15) & ~15ull);
-            sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
-            // Packed half precision where its geometry matches the checkpoint layout ((8,19): 16 extensions of one query per
-            // wavefront, or runs of 8 with one query per half wavefront where two LDS profiles fit, i.e. for the small
-            // alphabets; (16,13): 8 extensions) and a gap's first character costs at most 31 (the compact checkpoint codes
-            // of Ckpt16Layout).  Wavefronts it declines leave the sentinel -1; the int32 kernel fills those in.
-            half_sweep = h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
-                         h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
-                         (((sweep_cfg == 1 || sweep_cfg == 3 || sweep_cfg == 4) && h->opt_query_run % 16 == 0) || sweep_cfg == 2);
-            // Queries wider than a panel: compact codes as well, one part per (8,19) panel, written by the packed int16 kernel
-            // (the half-precision one has no carry between panels); what scores beyond the codes' 2046 goes to the int32 launch
-            wide_compact = h->opt_f16 && sweep_panels > 1 && sweep_cfg == 1 && h->opt_query_run % 16 == 0 &&
-                           -h->sc_host[slot].gap_open <= lx::kC16MaxGap && h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend &&
-                           !lx::dev_aids().no_wide_compact && !lx::dev_aids().no_i16_sweep;
-            half_sweep = half_sweep || wide_compact;
-            if (h->opt_f16 && sweep_panels == 1 && -h->sc_host[slot].gap_open <= lx::kC16MaxGap &&
-                h->sc_host[slot].gap_open <= h->sc_host[slot].gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && h->opt_query_run % 8 == 0 &&
-                2 * lx::score_pair_profile_bytes(sweep_cfg == 3 ? 1 : 0, nrows_sc) + 64 * 8 * 4 <= pair_lds_limit())
-            {
-                half_sweep  = true;
-                sweep_share = 4;
-            }
-            if (half_sweep)
-            {
-                // compact slots for the batch (+ the spare slot idle halves write to), int16-pair slots for what the
-                // packed kernel declines in whatever the budget leaves
-                sweep_stride = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
-                sweep        = (n + 1) * sweep_stride * 4 <= h->opt_trace_bytes;
-                // (the packed kernel's exactness gate, lx_score_f16.hip: it cannot decline when even the worst query passes)
-                int64_t const worst = (int64_t)h->opt_max_qlen * std::max(smax_entry, 0) +
-                                      (int64_t)(-h->sc_host[slot].gap_extend) * (sweep_steps + G + 2) +
-                                      (smax_entry - h->sc_host[slot].gap_extend) + 2; // (ScoringDev::smax = largest entry - ge)
-                may_decline = worst > 2046 || wide_compact;
-                if (sweep && may_decline)
-                    ovf_cap = std::min<uint64_t>(n, (h->opt_trace_bytes - (n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
-            }
-            else
-            {
-                sweep_stride = sweep_stride32;
-                sweep        = n * sweep_stride * 4 <= h->opt_trace_bytes;
-            }
-        }
-    }
-    // Adaptive choice (the one-query-per-wavefront sweep; lx_extend_batch's multi-query plan keeps its sweep): few survivors
-    // last time -> plain pass 1, checkpoints for the survivors only.  Phase 2 of a split step follows what phase 1 decided.
+    // how this step runs: plan_step() decides, this function follows
+    SchemeFacts facts{};
+    facts.alph       = h->sc_host[slot].alphabet_size;
+    facts.gap_open   = h->sc_host[slot].gap_open;
+    facts.gap_extend = h->sc_host[slot].gap_extend;
+    facts.trace_ok   = h->trace_ok[slot];
+    facts.b8_ok      = h->b8_ok[slot];
+    for (int a = 0; a < facts.alph; ++a)
+        for (int b = 0; b < facts.alph; ++b)
+            facts.smax_entry = std::max<int>(facts.smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
+    StepOptions so{};
+    so.max_qlen = h->opt_max_qlen, so.max_slen = h->opt_max_slen, so.query_run = h->opt_query_run, so.pass2 = h->opt_pass2;
+    so.mq = h->opt_mq, so.f16 = h->opt_f16, so.band = h->opt_band, so.trace_bytes = h->opt_trace_bytes, so.n = n;
+    so.mq_cfg_call = h->mq_cfg_call, so.adapt = h->opt_adapt;
+    // (phase 2 of a split step follows what phase 1 decided: it sees the survivor share phase 1 saw)
     if (phases & 1)
-    {
-        if (sweep && !mq && h->opt_adapt != 0 && h->surv_frac >= 0.0 && h->surv_frac * 1000.0 < (double)h->opt_adapt)
-        {
-            sweep      = false;
-            half_sweep = false;
-        }
-        h->last_sweep_choice = sweep;
-    }
-    else if (sweep && !h->last_sweep_choice)
-    {
-        sweep      = false;
-        half_sweep = false;
-    }
+        h->plan_surv_frac = h->surv_frac;
+    so.surv_frac = h->plan_surv_frac;
+    StepPlan const plan = plan_step(facts, so);
+    bool const     shared = plan.shared;
+    bool const     sweep = plan.sweep, mq = plan.family == kMqSweep, wide_compact = plan.family == kI16CompactWide;
+    bool const     half_sweep = plan.compact, i16_sweep = plan.family == kI16Pairs, may_decline = plan.may_decline;
+    int const      sweep_cfg = plan.cfg, sweep_share = plan.share;
+    uint32_t const sweep_steps = plan.steps, sweep_panels = plan.panels;
+    uint64_t const sweep_stride = plan.stride, sweep_stride32 = plan.stride32, ovf_cap = plan.ovf_cap;
+    int const      nrows_sc = ((h->sc_host[slot].alphabet_size + 1 + 3) / 4) * 4;
     if (sweep && (phases & 1))
     {
         uint64_t const batch_dw = half_sweep ? (n + 1) * sweep_stride : n * sweep_stride;
@@ -734,7 +799,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         p.score_out      = static_cast<int32_t *>(d_out_score);
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows          = nrows_sc;
-        p.shared_profile = mq ? (int)std::min<uint64_t>(h->opt_query_run, 8) : 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query (mq: every run)
+        p.shared_profile = mq ? std::min(2 * sweep_share, 8) : 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query (mq: every run)
         p.cfg            = sweep_cfg;
         if (half_sweep)
         {
@@ -761,7 +826,6 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
             sp1.pair_share  = sweep_share;
-            bool const int_sweep = lx::dev_aids().sweep_int; // A/B: the compact sweep in the integer domain
             if (mq)
             {
                 sp1.ws         = p.ws;
@@ -781,17 +845,10 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
                 LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
                 LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream)); // the fix-up launch starts with an empty carry workspace
             }
-            else if (int_sweep && sweep_share == 0)
-                LX_HIP(h, lx::launch_sweep_pair16_compact(sweep_cfg, sp1, stream));
             else
                 LX_HIP(h, lx::launch_score_pair(sweep_pair, sp1, stream));
             p.fixup = 1;
         }
-        // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16
-        // kernel writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range
-        // test is left to the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
-        bool const i16_sweep = !half_sweep && h->opt_f16 && !lx::dev_aids().no_i16_sweep &&
-                               h->opt_query_run % (sweep_cfg == 1 ? 16 : 8) == 0 && sweep_cfg != 3 && sweep_cfg != 4;
         if (i16_sweep)
         {
             lx::ScoreParams sp1{};
@@ -820,23 +877,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             LX_HIP(h, lx::launch_ckpt_forward(p, stream));
         pt0.close();
         char buf[200];
-        int const nameG = lx::trace_cfg_group(sweep_cfg), nameC = lx::trace_cfg_panel(sweep_cfg) / lx::trace_cfg_group(sweep_cfg);
-        if (mq)
-            snprintf(buf, sizeof(buf), "lx::sweep_mq_kernel<%d,%s> (single sweep, %d queries per wavefront%s)", nameC, sweep_panels > 1 ? "true" : "false",
-                     8 / sweep_share, may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
-        else if (wide_compact)
-            snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<%d,%d,true,true,true> (single sweep, compact codes; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
-                     nameG, nameC, nameG, nameC);
-        else if (half_sweep && may_decline)
-            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
-                     nameG, nameC, nameG, nameC);
-        else if (half_sweep)
-            snprintf(buf, sizeof(buf), "lx::score_pair_kernel<%d,%d,true> (single sweep)", nameG, nameC);
-        else if (i16_sweep)
-            snprintf(buf, sizeof(buf), "lx::sweep_pair16_kernel<%d,%d,%s> (single sweep; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
-                     nameG, nameC, sweep_panels > 1 ? "true" : "false", nameG, nameC);
-        else
-            snprintf(buf, sizeof(buf), "lx::ckpt_forward_kernel<%d,%d,false> (single sweep)", nameG, nameC);
+        describe_plan(plan, buf, sizeof(buf));
         h->last_kernel       = buf;
         h->last_trace_kernel = buf;
     }
@@ -1187,6 +1228,71 @@ int lx_builtin_scoring(int scoring_method, int match, int mismatch, int gap_open
     {
         return LX_EINVAL;
     }
+    return LX_OK;
+}
+
+// what lx_set_scoring derives from a scheme besides the tables: pass 2 applies (every matrix - gap_extend in [-31, 31]),
+// byte profiles apply (0 <= matrix - gap_open <= 255), the largest entry
+static void scheme_facts(lx_scoring const * sc, lxi::SchemeFacts & f)
+{
+    f.alph       = sc->alphabet_size;
+    f.gap_open   = sc->gap_open;
+    f.gap_extend = sc->gap_extend;
+    f.trace_ok   = true;
+    f.b8_ok      = true;
+    f.smax_entry = 0;
+    for (int a = 0; a < sc->alphabet_size; ++a)
+        for (int b = 0; b < sc->alphabet_size; ++b)
+        {
+            int const v = sc->matrix[a * LX_ALPH + b];
+            if (v - sc->gap_extend < -31 || v - sc->gap_extend > 31)
+                f.trace_ok = false;
+            if (v - sc->gap_open < 0 || v - sc->gap_open > 255)
+                f.b8_ok = false;
+            f.smax_entry = std::max(f.smax_entry, v);
+        }
+}
+
+int lx_plan_step(lx_scoring const * sc, uint64_t max_qlen, uint64_t max_slen, uint64_t query_run, uint64_t n, uint64_t pass2_mode,
+                 uint64_t mq_sweep, uint64_t packed_half, uint64_t trace_bytes, double survivor_share, uint64_t adapt_permille,
+                 lx_step_plan * out)
+{
+    if (!sc || !out || sc->alphabet_size < 1 || sc->alphabet_size > LX_ALPH - 1 || sc->gap_extend >= 0 || sc->gap_open > sc->gap_extend)
+        return LX_EINVAL;
+    lxi::SchemeFacts f{};
+    scheme_facts(sc, f);
+    lxi::StepOptions o{};
+    o.max_qlen = max_qlen, o.max_slen = max_slen, o.query_run = query_run, o.n = n, o.pass2 = pass2_mode > 2 ? 1 : pass2_mode;
+    o.mq = mq_sweep > 2 ? 1 : mq_sweep, o.f16 = packed_half ? 1 : 0, o.trace_bytes = std::max<uint64_t>(trace_bytes, 1 << 20);
+    o.surv_frac = survivor_share, o.adapt = std::min<uint64_t>(adapt_permille, 1000);
+    lxi::StepPlan const pl = lxi::plan_step(f, o);
+    std::memset(out, 0, sizeof(*out));
+    out->family                = (int32_t)pl.family;
+    out->adapted               = pl.adapted ? 1 : 0;
+    lxi::describe_plan(pl, out->name, sizeof(out->name));
+    if (pl.family == lxi::kNoSweep)
+        return LX_OK;
+    int const G = lx::trace_cfg_group(pl.cfg), C = lx::trace_cfg_panel(pl.cfg) / G, nrows = ((sc->alphabet_size + 1 + 3) / 4) * 4;
+    out->group_lanes           = G;
+    out->strip_cols            = C;
+    out->panels                = (int32_t)pl.panels;
+    out->compact_codes         = pl.compact ? 1 : 0;
+    out->may_decline           = pl.may_decline ? 1 : 0;
+    out->slot_bytes            = pl.stride * 4;
+    int const per_wave         = pl.family == lxi::kInt32Sweep ? 64 / G : 2 * (64 / G); // extensions a wavefront holds
+    int const share_ext        = pl.family == lxi::kMqSweep ? 2 * pl.share : (pl.family == lxi::kHalfSweep && pl.share) ? 2 * pl.share : per_wave;
+    out->queries_per_wavefront = std::max(1, per_wave / std::max(1, share_ext));
+    int const pair_cfg         = pl.cfg == 1 ? 0 : pl.cfg == 3 ? 1 : pl.cfg == 4 ? 7 : 5;
+    switch (pl.family)
+    {
+        case lxi::kMqSweep: out->lds_bytes = lx::sweep_mq_lds_bytes(pl.cfg, nrows, pl.share); break;
+        case lxi::kInt32Sweep: out->lds_bytes = (uint64_t)out->queries_per_wavefront * nrows * ((C + 3) / 4 * G) * 4 + 64 * 4 * 4; break;
+        default: out->lds_bytes = (uint64_t)out->queries_per_wavefront * lx::score_pair_profile_bytes(pair_cfg, nrows) + 64 * 8 * 4; break;
+    }
+    // the largest value the widest admitted query can produce in a sweep that runs max_slen rows (the kernels' own tests are
+    // per wavefront, on the actual query: this is the a-priori bound may_decline is derived from)
+    out->score_bound = (uint64_t)((int64_t)max_qlen * std::max(f.smax_entry, 0) + (int64_t)(-sc->gap_extend) * ((int64_t)pl.steps + G + 2) +
+                                  (f.smax_entry - sc->gap_extend) + 2);
     return LX_OK;
 }
 

@@ -119,12 +119,9 @@ struct Ckpt16Layout
     }
     // uint4 index of the group of steps 8 o .. 8 o + 7 of lane g / of quad x of lane g's row checkpoint m
     __host__ __device__ static constexpr uint32_t bnd_oct_index(uint32_t o, uint32_t g) { return o * G + g; }
-#ifndef LX_C16_ROWCK_QUAD_MAJOR
-#define LX_C16_ROWCK_QUAD_MAJOR 0
-#endif
     __host__ __device__ static constexpr uint32_t rowck_quad_index(uint32_t m, uint32_t g, uint32_t x)
     {
-        return LX_C16_ROWCK_QUAD_MAJOR ? (m * (kCkDw / 4) + x) * G + g : (m * G + g) * (kCkDw / 4) + x;
+        return (m * G + g) * (kCkDw / 4) + x; // lane-major (quad-major was measured in round 2: no difference)
     }
 };
 

@@ -173,7 +173,7 @@ struct lx_handle
     hipEvent_t  ev_count         = nullptr;
     uint64_t    count_n          = 0;
     bool        count_pending    = false;
-    bool        last_sweep_choice = true;  // what phase 1 of the current step decided (phase 2 follows it)
+    double      plan_surv_frac   = -1.0;   // the share phase 1 of the current step planned with (phase 2 follows it)
     uint64_t    opt_adapt        = 30;     // LX_OPT_ADAPT_PERMILLE
     int      mq_cfg_call   = 0; // lx_extend_batch: the strip geometry (trace cfg) it chose for this call's chunks (0 = fused_impl picks per chunk)
     uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
@@ -264,6 +264,38 @@ int    pick_cfg(uint32_t qlen, bool shared);
 int    ckpt_cfg_for(uint64_t max_q, bool packed16 = false);
 int    check_async_error(lx_handle * h);
 int    error_for_flag(lx_handle * h, uint32_t flag);
+
+// ---- the plan of a fused step (plan_step in lx_api.cpp is the one place that makes it)
+struct SchemeFacts
+{
+    int  alph = 0, gap_open = 0, gap_extend = 0, smax_entry = 0;
+    bool trace_ok = false, b8_ok = false;
+};
+struct StepOptions
+{
+    uint64_t max_qlen = 0, max_slen = 0, query_run = 0, pass2 = 2, mq = 1, f16 = 1, band = 0, trace_bytes = 0, n = 0, adapt = 0;
+    int      mq_cfg_call = 0;
+    double   surv_frac   = -1.0;
+};
+enum SweepFamily
+{
+    kNoSweep        = 0, // pass 1, then pass 2 on the survivors (modes 0 / 1)
+    kHalfSweep      = 1, // lx_score_f16.hip score_pair_kernel<G,C,true>: packed half, compact codes, one panel
+    kI16CompactWide = 2, // lx_score_i16.hip sweep_pair16_kernel<8,19,true,true,true>: packed int16, compact codes, several panels
+    kI16Pairs       = 3, // lx_score_i16.hip sweep_pair16_kernel<G,C,MULTI>: packed int16, int16-pair slots
+    kInt32Sweep     = 4, // lx_ckpt.hip ckpt_forward_kernel<G,C,false,MULTI> alone
+    kMqSweep        = 5  // lx_sweep_mq.hip sweep_mq_kernel<C,MULTI>: byte profiles, up to four queries per wavefront
+};
+struct StepPlan
+{
+    bool        shared = false, sweep = false, adapted = false, compact = false, may_decline = true;
+    SweepFamily family = kNoSweep;
+    int         cfg = 0, share = 0;
+    uint32_t    steps = 0, panels = 1;
+    uint64_t    stride = 0, stride32 = 0, ovf_cap = 0;
+};
+StepPlan plan_step(SchemeFacts const & sc, StepOptions const & o);
+void     describe_plan(StepPlan const & pl, char * buf, size_t len);
 void   use_ctx(lx_handle * h, int which); // 0 = the handle's own working set, 1 = lx_handle::alt
 int    mq_cfg_for(uint64_t max_q);
 int    launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n, void * d_out, int cfg,

@@ -125,6 +125,19 @@ def test_mq_sweep_other_schemes(handle, oracle, scheme):
     check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
 
 
+def test_mq_sweep_runs_of_24(handle, oracle):
+    """A run that is a multiple of 8 but not of 16: wavefronts straddle two queries, eight windows each (found by the plan
+    table test: the first version promised the kernel one query per wavefront there)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(10, seed=4, lq_range=(210, 300), mean_windows=20.0, merged_frac=0.1)
+    slots, src = pack_runs(ext, 24)
+    got = run_fused(handle, q, s, slots, 24, 60, mq=1)
+    assert "sweep_mq_kernel" in got[5] and "2 queries per wavefront" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, 60, *got[:5])
+
+
 def test_mq_sweep_declined_extensions_go_to_the_int32_launch(handle, oracle):
     """Tryptophan-rich wide queries: best scores beyond the compact codes' 2046 -- the sweep leaves the sentinel for exactly
     those extensions (or declines the whole wavefront when the bound fails up front) and the int32 launch redoes them into
