@@ -158,8 +158,11 @@ enum
                                    min(_bandSize(q_len), s_len - q_len), the seed diagonal of a window built by _widenMatch
                                    that was not clipped at the subject's start.  Applies to every score / align / extend entry
                                    point; runs int32 kernels and direction bits (results are those of the oracle's
-                                   lxo_score_banded / lxo_align_banded), slower per cell than the full rectangle: at
-                                   150 x 176 with b = 64 the band removes 27 % of the cells and no step of the strip mapping */
+                                   lxo_score_banded / lxo_align_banded).  PERFORMANCE: band mode exists for its semantics only --
+                                   it is SLOWER per window than the full rectangle (headline batch: 51 ms per step with b = 64
+                                   against 15.7 ms without a band): at 150 x 176 with b = 64 the band removes 27 % of the cells and
+                                   no step of the strip mapping, and every remaining cell pays for its mask.  A caller who wants
+                                   throughput leaves the band off, which is also what the reference computes */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
 
@@ -221,7 +224,13 @@ int lx_score_batch_dev(lx_handle * h, int slot, void const * d_q_res, void const
                        uint64_t n, void * d_out_score, void * stream);
 
 /* ---- pass 2: traceback  (replaces _performAlignment<true>, src/search_algo.hpp:1296) --------- */
-/* ops: one byte per alignment column ('M','D','I'; 'D' = gap in the query row), begin -> end order.  The caller gives
+/* LIMIT: pass 2 (lx_align_batch*, and the second half of every lx_extend_batch* / lx_iterate_matches call) needs every
+ * (matrix entry - gap_extend) of the slot's scheme in [-31, 31] -- the tagged recurrence keeps two tag bits next to values
+ * scaled by 4 in 8-bit profile entries, there is no int32 fall-back for it.  Every scheme of the reference with its default
+ * costs satisfies this (BLOSUM45/62/80 with gap_extend -1 ... -2, +2/-3 nucleotide and bisulfite matrices); a user-chosen
+ * --match / --mismatch beyond that range (src/search_options.hpp:93-94) makes these calls return LX_EINVAL with that text.
+ * Pass 1 (lx_score_batch*) has no such limit.
+ * ops: one byte per alignment column ('M','D','I'; 'D' = gap in the query row), begin -> end order.  The caller gives
  * extension i a slot of q_len+s_len bytes at out_ops + ops_off[i]; its out_hsp[i].n_ops bytes are written at the END
  * of that slot, i.e. they start at out_ops + ops_off[i] + out_hsp[i].ops_shift. */
 int lx_align_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res,

@@ -12,8 +12,10 @@
 // What is different here: there is no FM-index (fmindex-collection is absent and out of scope).  The same questions -- how
 // often does this reduced word occur, where -- are answered by a sorted table of packed words: every database position
 // carries the key of its next kKeyLen reduced letters (base alphabet + 1, the extra digit pads sequence ends), a cursor is a
-// range of that table, extendRight narrows it by binary search.  Hit sets are identical to the FM-index's for words of up to
-// kKeyLen letters (18 for Li-10, 27 for nucleotides); elongation stops there.
+// range of that table, extendRight narrows it by binary search.  Beyond kKeyLen letters (18 for Li-10, 27 for nucleotides) the
+// table's order says nothing any more: a cursor then carries the list of its entries and extendRight filters it by the next
+// reduced letter of every occurrence -- so adaptive elongation goes on as far as the reference's does (:703-721) and the hit
+// sets equal the FM-index's for words of any length.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -57,13 +59,18 @@ public:
         uint64_t lo = 0, hi = 0; // range of the sorted table
         int      len = 0;        // letters matched
         uint64_t prefix = 0;     // the word so far, base (alph + 1)
-        uint64_t count() const { return hi - lo; }
-        bool     empty() const { return hi <= lo; }
+        bool                  listed = false; // the word is longer than the table's keys: `sel` lists the entries that match it
+        std::vector<uint32_t> sel;
+        uint64_t count() const { return listed ? sel.size() : hi - lo; }
+        bool     empty() const { return count() == 0; }
     };
 
     // red = reduced residues of all (frame-expanded) subject sequences, off/len per sequence; alph = reduced alphabet size
     void build(std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
     {
+        red_    = red.data();
+        off_    = off.data();
+        len_    = len.data();
         alph_   = alph;
         base_   = (uint64_t)alph + 1;
         keyLen_ = 0;
@@ -102,12 +109,26 @@ public:
     // the cursor of word + c; empty when the word does not occur (or the table's word length is exhausted)
     Cursor extendRight(Cursor const & cu, uint8_t c) const
     {
-        Cursor n = cu;
         if (cu.len >= keyLen_)
         {
-            n.hi = n.lo;
+            // beyond the keys: keep the occurrences whose next reduced letter is c (the sequences outlive the index)
+            Cursor n;
+            n.lo = cu.lo, n.hi = cu.hi, n.len = cu.len + 1, n.prefix = cu.prefix, n.listed = true;
+            auto keep = [&](uint32_t e)
+            {
+                Entry const & x = entries_[e];
+                if ((uint64_t)x.pos + (uint64_t)cu.len < len_[x.seq] && red_[off_[x.seq] + x.pos + (uint64_t)cu.len] == c)
+                    n.sel.push_back(e);
+            };
+            if (cu.listed)
+                for (uint32_t e : cu.sel)
+                    keep(e);
+            else
+                for (uint64_t e = cu.lo; e < cu.hi; ++e)
+                    keep((uint32_t)e);
             return n;
         }
+        Cursor n = cu;
         n.prefix = cu.prefix * base_ + c;
         n.len    = cu.len + 1;
         uint64_t const scale = pow_[keyLen_ - n.len], first = n.prefix * scale, last = first + (scale - 1);
@@ -120,6 +141,12 @@ public:
     template <typename F>
     void locate(Cursor const & cu, F && f) const // f(subject sequence, offset)
     {
+        if (cu.listed)
+        {
+            for (uint32_t e : cu.sel)
+                f(entries_[e].seq, entries_[e].pos);
+            return;
+        }
         for (uint64_t i = cu.lo; i < cu.hi; ++i)
             f(entries_[i].seq, entries_[i].pos);
     }
@@ -132,6 +159,9 @@ private:
     };
     std::vector<Entry>    entries_;
     std::vector<uint64_t> pow_;
+    uint8_t const *       red_ = nullptr; // the caller's reduced residues and sequence table (must outlive the index)
+    uint64_t const *      off_ = nullptr;
+    uint64_t const *      len_ = nullptr;
     uint64_t              base_ = 11;
     int                   alph_ = 10, keyLen_ = 18;
 };
@@ -151,10 +181,12 @@ inline void searchExact(ReducedIndex const & ix, uint8_t const * seed, int seedL
 
 // searchHalfExactImpl (:537-604): first half exact, then letter by letter every cursor below the error budget branches into all
 // letters of the alphabet (a different letter costs one error), the others continue with the seed's letter
+// exactPrefix = seedLength / 2 is the half-exact search; 0 = substitutions anywhere in the seed, what the reference runs with
+// --seed-half-exact 0 (search_one_error / search_pseudo over the whole seed, :486-531)
 inline void searchHalfExact(ReducedIndex const & ix, uint8_t const * seed, int seedLength, int maxSeedDist, int alph,
-                            std::vector<ReducedIndex::Cursor> & out)
+                            std::vector<ReducedIndex::Cursor> & out, int exactPrefix = -1)
 {
-    int const firstHalf = seedLength / 2, secondHalf = seedLength - firstHalf;
+    int const firstHalf = exactPrefix < 0 ? seedLength / 2 : std::min(exactPrefix, seedLength), secondHalf = seedLength - firstHalf;
     std::vector<std::pair<ReducedIndex::Cursor, int>> cur, nxt;
     ReducedIndex::Cursor                              c = ix.root();
     for (int i = 0; i < firstHalf; ++i)
@@ -286,8 +318,8 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                 if (seedBegin > L - (uint64_t)so.seedLength) // :663
                     break;
                 cursors.clear();
-                if (in.halfExact && so.maxSeedDist != 0)
-                    searchHalfExact(ix, red + seedBegin, so.seedLength, so.maxSeedDist, in.alph, cursors);
+                if (so.maxSeedDist != 0)
+                    searchHalfExact(ix, red + seedBegin, so.seedLength, so.maxSeedDist, in.alph, cursors, in.halfExact ? -1 : 0);
                 else
                     searchExact(ix, red + seedBegin, so.seedLength, cursors);
                 for (ReducedIndex::Cursor cursor : cursors)
@@ -303,7 +335,7 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
                             desiredOccs = 1;
                         ReducedIndex::Cursor old_cursor = cursor;
                         size_t               old_count  = cursor.count();
-                        while (seedBegin + seedLength < L && (int)seedLength < ix.keyLen())
+                        while (seedBegin + seedLength < L) // (:703: until the count drops under desiredOccs or the read ends)
                         {
                             cursor                 = ix.extendRight(cursor, red[seedBegin + seedLength]);
                             size_t const new_count = cursor.count();

@@ -541,6 +541,10 @@ static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res,
             h->opt_max_slen  = slen;
             h->opt_query_run = run;
             h->band_dev      = band_dev;
+            // lx_set_band_centres applies to ONE host-buffer call (include/lambda_ext.h): consumed here, whatever the outcome --
+            // a later call of another size must not fail on them, one of the same size must not reuse them silently
+            (void)hipStreamSynchronize(h->stream);
+            h->band_host.clear();
         }
     } const restore{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run, h->band_dev};
     h->opt_max_qlen  = max_q;
@@ -1427,7 +1431,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             }
                         });
         pos_off[count] = total;
-        h->ext_bytes.grow(total + 16);
+        if (!h->ext_bytes.grow(total + 16))
+            return fail(h, LX_ENOMEM, "out of host memory for %llu bytes of alignment ops", (unsigned long long)(total + 16));
         uint8_t * const dst = h->ext_bytes.data();
         t_u2 += ms(tu1, now());
         // (3) one pass over the chunk's slots: score and record of every extension, the survivors' ops

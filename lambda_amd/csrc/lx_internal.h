@@ -96,13 +96,17 @@ struct lx_handle
         size_t    cap = 0;
         uint8_t * data() { return p; }
         void      clear() {}
-        void      grow(size_t bytes)
+        bool      grow(size_t bytes) // false: out of memory (the old block and its contents stay)
         {
             if (bytes <= cap)
-                return;
+                return true;
             size_t const want = std::max(bytes + bytes / 2, (size_t)1 << 20);
-            p                 = static_cast<uint8_t *>(std::realloc(p, want));
-            cap               = p ? want : 0;
+            void * const np   = std::realloc(p, want);
+            if (!np)
+                return false;
+            p   = static_cast<uint8_t *>(np);
+            cap = want;
+            return true;
         }
         ~Bytes() { std::free(p); }
     } ext_bytes;

@@ -1,7 +1,8 @@
 // Host-only check of lambda_amd/csrc/host/lx_seeding.hpp (compiled and run by tests/test_seeding.py with g++):
 // the sorted word table against brute force over random reduced sequences -- exact words, half-exact words (first half
 // exact, at most one substitution in the second half: searchHalfExactImpl, /root/reference/src/search_algo.hpp:537-604),
-// cursor counts under extendRight, and the reduction tables' group structure.
+// one substitution anywhere (--seed-half-exact 0), words longer than the table's keys, cursor counts under extendRight, and the
+// reduction tables' group structure.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -113,6 +114,55 @@ int main()
                 ix.locate(c, [&](uint32_t s, uint32_t p) { got.emplace(s, p); });
             }
             CHECK(got == brute(1) && cnt == got.size()); // (every hit under exactly one cursor)
+            // --seed-half-exact 0: one substitution anywhere in the seed (search_one_error over the whole word, :486-531)
+            cur.clear();
+            got.clear();
+            cnt = 0;
+            searchHalfExact(ix, seed.data(), K, 1, alph, cur, 0);
+            for (auto const & c : cur)
+            {
+                cnt += c.count();
+                ix.locate(c, [&](uint32_t s, uint32_t p) { got.emplace(s, p); });
+            }
+            std::set<std::pair<uint32_t, uint32_t>> hamming1;
+            for (size_t s2 = 0; s2 < off.size(); ++s2)
+                for (uint64_t p = 0; p + K <= len[s2]; ++p)
+                {
+                    int d = 0;
+                    for (int i = 0; i < K; ++i)
+                        d += red[off[s2] + p + i] != seed[i];
+                    if (d <= 1)
+                        hamming1.emplace((uint32_t)s2, (uint32_t)p);
+                }
+            CHECK(got == hamming1 && cnt == got.size());
+        }
+        // words LONGER than the table's keys (adaptive elongation goes on to the read's end, :703-721): a repeat of 60 letters
+        // planted in three sequences; the cursor of its first keyLen + 20 letters must hold exactly the occurrences brute force finds
+        {
+            std::vector<uint8_t> rep(60);
+            for (auto & c : rep)
+                c = (uint8_t)(rng() % alph);
+            for (size_t s2 : {3u, 11u, 29u})
+                if (len[s2] >= 70)
+                    for (int i = 0; i < 60; ++i)
+                        red[off[s2] + 5 + i] = rep[i];
+            ix.build(red, off, len, alph);
+            int const K = ix.keyLen() + 20;
+            ReducedIndex::Cursor c = ix.root();
+            for (int i = 0; i < K && !c.empty(); ++i)
+                c = ix.extendRight(c, rep[i]);
+            std::set<std::pair<uint32_t, uint32_t>> got, want;
+            ix.locate(c, [&](uint32_t s2, uint32_t p) { got.emplace(s2, p); });
+            for (size_t s2 = 0; s2 < off.size(); ++s2)
+                for (uint64_t p = 0; p + K <= len[s2]; ++p)
+                    if (std::memcmp(&red[off[s2] + p], rep.data(), K) == 0)
+                        want.emplace((uint32_t)s2, (uint32_t)p);
+            CHECK(!want.empty() && got == want && c.count() == want.size());
+            ReducedIndex::Cursor const dead = ix.extendRight(c, (uint8_t)((rep[K] + 1) % alph)); // a letter no occurrence continues with
+            std::set<std::pair<uint32_t, uint32_t>> none;
+            ix.locate(dead, [&](uint32_t s2, uint32_t p) { none.emplace(s2, p); });
+            for (auto const & hp : none) // (whatever survives must really continue with that letter)
+                CHECK(red[off[hp.first] + hp.second + K] == (uint8_t)((rep[K] + 1) % alph));
         }
     }
     // seedLooksPromising: the planted diagonal passes, a random one does not

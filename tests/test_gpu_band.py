@@ -159,3 +159,24 @@ def test_banded_device_entry_points(banded, oracle):
             st = int(off[i]) + int(g["ops_shift"])
             assert bytes(ops[st: st + oh.n_ops]) == oops
     assert nsurv > 20 and int(d_count.cpu()[1]) == nsurv
+
+
+def test_band_centres_apply_to_one_call_only(banded, oracle):
+    """lx_set_band_centres is one-shot: the call after it runs with the default centres again, whatever its size --
+    it neither fails on a stale array of another length nor silently reuses one of the same length."""
+    h = banded
+    sc_p = SCHEMES["blosum62"]
+    h.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_batch_np(6, 120, 4, seed=8)
+    centres = np.full(len(ext), 30, dtype=np.int32)
+    h.set_band(5, centres)
+    with_centres = h.score_batch(q, s, ext)
+    again = h.score_batch(q, s, ext)            # same size: default centres now
+    shorter = h.score_batch(q, s, ext[:10])     # another size: no LX_EINVAL
+    for i, x in enumerate(ext):
+        qq, ss = _slices(q, s, x)
+        d0 = min(int(np.sqrt(x["q_len"])) + 1, int(x["s_len"]) - int(x["q_len"]))
+        assert with_centres[i] == oracle.score_banded(qq, ss, osc, 30 - 5, 30 + 5)
+        assert again[i] == oracle.score_banded(qq, ss, osc, d0 - 5, d0 + 5)
+    assert (shorter == again[:10]).all() and (with_centres != again).any()
