@@ -196,6 +196,31 @@ def pmc_traffic(kernel_name: str):
     return None, "no committed PMC profile for this kernel instantiation"
 
 
+def issue_ceiling():
+    """What gfx950 really issues for the packed sweep's instruction mix (3 packed adds, 3 packed max3, 1 permute per pair of
+    cells -- every one a half-rate VOP3P / VOP3 instruction) at the sweep's occupancy, from the committed run of
+    tools/ubench.hip (profiles/*_ubench_valu_issue_rates.txt, line "sweep_mix(x7) waves/SIMD=3"): lane-instructions per
+    second, and the ceiling it puts on the 10-ops-per-cell accounting of SURVEY.md section 8d when a cell costs the bare
+    recurrence's 3.75 lane-instructions.  The roofline's `frac` is against the guide's 157 Tops/s; this is the part of it
+    the instruction set lets a kernel of this formulation reach."""
+    rate, src = 35.1e12, "default (no committed ubench run found)"
+    try:
+        for f in sorted((ROOT / "profiles").glob("*_ubench_valu_issue_rates.txt"), reverse=True):
+            for line in f.read_text().splitlines():
+                if line.startswith("sweep_mix(x7)") and "waves/SIMD=3" in line:
+                    rate = float(line.split("=")[-1].split()[0]) * 1e12
+                    src = f"{f.name}: sweep_mix(x7) at 3 wavefronts per SIMD"
+                    raise StopIteration
+    except StopIteration:
+        pass
+    except Exception:
+        pass
+    bare = 3.75
+    tops = rate / bare * ALGO_OPS_PER_CELL / 1e12
+    return {"lane_instr_per_s": rate, "source": src, "bare_lane_instr_per_cell": bare, "ceiling_tops": round(tops, 2),
+            "issue_ceiling_frac": round(tops / PEAK_PACKED16_TOPS, 4)}
+
+
 def dry_run(args, w, world, rank):
     """No GPU: rendezvous over gloo, plan the sharding, gather the plans, print the line the real run would print (value
     null).  What the CPU tests and `python bench.py --gpus 2 --config 3 --dry-run` exercise."""
@@ -512,10 +537,13 @@ def main():
             gc = cells / (ms * 1e-3) / 1e9
             tops = gc * ALGO_OPS_PER_CELL / 1e3
             traffic, note = pmc_traffic(pmc_key)
-            packed = "pair" in kernel
+            packed = "pair" in kernel or "sweep_mq" in kernel
             peak = PEAK_PACKED16_TOPS if packed else PEAK_INT32_TOPS
             hbm = (algo_bytes + stored_bytes) / (ms * 1e-3) / 1e9
+            ceil = issue_ceiling() if packed else None
             return {
+                **({"issue_ceiling_frac": ceil["issue_ceiling_frac"], "frac_of_issue_ceiling": round(tops / ceil["ceiling_tops"], 4),
+                    "issue_ceiling": ceil} if ceil else {}),
                 "bound": "valu", "kernel": kernel, "achieved": round(tops, 3), "peak": round(peak, 2),
                 "unit": "Tops/s (%s lane-ops; 10 algorithmic ops per cell)" % ("packed 16-bit" if packed else "int32"),
                 "frac": round(tops / peak, 4),

@@ -58,5 +58,34 @@ for log, dst in (("bench.log", f"{tag}_bench_line.json"), ("bench_pass1.log", f"
     lines = [l for l in open(src / log) if l.startswith('{"metric"')]
     if lines:
         (out / dst).write_text(lines[-1])
+# the secondary lines of the round (configs 2-4, band, host path, ragged, survivor rates) and the ragged list's kernel stats
+for log in sorted(src.glob("bench_*.log")):
+    if log.name in ("bench_pass1.log",):
+        continue
+    lines = [l for l in open(log) if l.startswith('{"metric"')]
+    if lines:
+        (out / f"{tag}_{log.stem}.json").write_text(lines[-1])
+if (src / "host_curve.jsonl").exists():
+    (out / f"{tag}_host_curve.jsonl").write_text("".join(l for l in open(src / "host_curve.jsonl") if l.startswith("{")))
+rs = src / "stats_ragged" / "ragged_kernel_stats.csv"
+if rs.exists():
+    rows = list(csv.reader(open(rs)))
+    with open(out / f"{tag}_ragged_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "lx::" in r[0]:
+                w.writerow(r)
+lw = src / "pmc_write_lowsurv" / "pmc_counter_collection.csv"
+if lw.exists():
+    acc, n = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(lw)):
+        if "lx::" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"]] += float(r["Counter_Value"])
+            n[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    json.dump({"command": "rocprofv3 --pmc WRITE_SIZE -- python bench.py --steps 2 --warmup 3 --survivor-rate 0.02 --no-cpu-baseline",
+               "note": "WRITE_SIZE in KiB per launch: the adaptive pass-2 mode at 2 % survivors (pass 1 writes scores only; checkpoints "
+                       "are written for the survivors by ckpt_forward_kernel)",
+               "write_kib_per_launch": {k: acc[k] / len(n[k]) for k in acc}}, open(out / f"{tag}_pmc_write_survivors_0.02.json", "w"), indent=1)
 for k, d in kern.items():
     print(k[:60], {c: "%.4g" % x for c, x in d["counters_per_step_mean"].items()})

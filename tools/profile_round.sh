@@ -9,11 +9,16 @@ D=gpurun_out/${1:-r2prof}; mkdir -p $D; R=$PWD
 for c in 2 3 4; do (timeout 900 python bench.py --config $c --steps 5 --warmup 2) > $D/bench_config$c.log 2>&1; done
 (timeout 600 python bench.py --band 64 --steps 5 --warmup 2) > $D/bench_band64.log 2>&1
 (timeout 600 python bench.py --host-path --steps 5 --warmup 2) > $D/bench_host_path.log 2>&1
-(timeout 900 python bench.py --ragged --steps 3 --warmup 1) > $D/bench_ragged.log 2>&1
+(timeout 900 python bench.py --ragged --steps 5 --warmup 2) > $D/bench_ragged.log 2>&1
+for r in 0.02 0.1; do (timeout 600 python bench.py --steps 10 --warmup 3 --survivor-rate $r --no-cpu-baseline) > $D/bench_survivors_$r.log 2>&1; done
+(timeout 600 python bench.py --steps 10 --warmup 3 --survivor-rate 0.02 --adapt-permille 0 --no-cpu-baseline) > $D/bench_survivors_0.02_sweep.log 2>&1
+(timeout 600 python tools/host_curve.py 100) > $D/host_curve.jsonl 2>&1
 cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $R/$D/stats.log 2>&1
 (timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/$D/pmc_sq -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq.log 2>&1
 (timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $R/$D/pmc_sq_wait -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq_wait.log 2>&1
 (timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$D/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_fetch.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_write.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_ragged -o ragged -- python $R/tools/quick_ragged.py) > $R/$D/stats_ragged.log 2>&1
+(timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write_lowsurv -o pmc -- python $R/bench.py --steps 2 --warmup 3 --survivor-rate 0.02 --no-cpu-baseline) > $R/$D/pmc_write_lowsurv.log 2>&1
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -40

@@ -132,6 +132,13 @@ DEF_KERNEL(k_addfc, I_ADDFC)
 #define I_PKADDSEL(R) "v_pk_add_f16 " R ", " R ", %8 op_sel_hi:[1,0]\n"
 #define I_PKFMA(R) "v_pk_fma_f16 " R ", " R ", %8, %9\n"
 #define I_PKADDF32(R) "v_pk_add_f32 v[20:21], v[20:21], v[22:23]\n"
+// the packed sweep's own mix per pair of cells: 3 packed adds, 3 packed max3 (the two-operand maximum is encoded as one too),
+// 1 byte permute -- lx_score_f16.hip / lx_score_i16.hip / lx_sweep_mq.hip
+#define I_SWEEPMIX(R)                                                                                                       \
+    "v_pk_add_u16 " R ", " R ", %8\n v_pk_maximum3_f16 " R ", " R ", %8, %9\n v_pk_add_u16 " R ", " R ", %9\n"               \
+    "v_pk_maximum3_f16 " R ", " R ", %9, %8\n v_pk_maximum3_f16 " R ", " R ", %8, %8\n v_pk_add_u16 " R ", " R ", %8\n"       \
+    "v_perm_b32 " R ", " R ", %8, %9\n"
+DEF_KERNEL(k_sweepmix, I_SWEEPMIX)
 DEF_KERNEL(k_cnds, I_CNDS) DEF_KERNEL(k_bfi, I_BFI) DEF_KERNEL(k_pkaddsel, I_PKADDSEL) DEF_KERNEL(k_pkfma, I_PKFMA)
 
 // LDS: ds_read_b32 with a lane-linear address pattern
@@ -220,5 +227,15 @@ int main()
     for (int w : {8})
         for (auto & t : tab)
             run(t.n, t.k, d_out, w, t.ops);
+    // what the DP kernels are priced against: the packed classes and the sweep's own instruction mix at the occupancies the
+    // sweeps run at (2 and 3 wavefronts per SIMD); "sweep_mix" executes 7 instructions per template: multiply its rate by 7
+    printf("---- occupancy of the sweeps (sweep_mix: x 7 lane-instructions per counted one)\n");
+    for (int w : {2, 3, 4, 8})
+    {
+        run("v_pk_add_u16", k_pkaddu, d_out, w, 2);
+        run("pk_maximum3_f16", k_pkmax3f, d_out, w, 4);
+        run("v_perm_b32", k_perm, d_out, w, 1);
+        run("sweep_mix(x7)", k_sweepmix, d_out, w, 7);
+    }
     return 0;
 }
