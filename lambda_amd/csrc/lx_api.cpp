@@ -433,6 +433,11 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
     uint64_t const want_chunks = lx::dev_aids().trace_chunks;
     chunk                      = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
     hipStream_t const bstream  = overlap ? h->stream2 : stream;
+    // a trace buffer that is already there and holds a fair chunk is used as it is: the fused step sizes this list for the
+    // worst case (every extension survives), and growing a buffer of tens of GB costs seconds -- the adaptive mode-1 step
+    // after a run of single sweeps would pay that once; chunks beyond the device-side count exit at once
+    if (d_count && h->d_trace.cap / nbuf / std::max<uint64_t>(per_ext, 1) >= 65536)
+        chunk = std::min<uint64_t>(chunk, h->d_trace.cap / nbuf / per_ext / 8 * 8);
     chunk                      = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
     int rc;
     if ((rc = ensure(h, h->d_trace, nbuf * chunk * per_ext)) || (rc = ensure(h, h->d_ends, nbuf * chunk * sizeof(lx::EndCell))))
