@@ -35,8 +35,14 @@ while time.time() - t0 < budget:
     lq = int(rng.integers(min_lq, max_lq))
     wpq = int(rng.choice([5, 8, 16, 24, 32, 40]))
     nq = int(rng.integers(4, 24))
-    q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=int(rng.integers(1, 1 << 30)), alphabet=alpha,
-                                    sub_rate=float(rng.uniform(0.0, 0.4)), indel_rate=float(rng.uniform(0.0, 0.08)))
+    if rng.random() < 0.4:
+        # a list as lambda hands it over: mixed query lengths, a few windows per query, merged windows (the multi-query plan)
+        q, s, ext = synth.make_ragged_lists_np(int(rng.integers(6, 40)), seed=int(rng.integers(1, 1 << 30)), alphabet=alpha,
+                                               lq_range=(min_lq, max(min_lq + 1, max_lq)), mean_windows=float(rng.uniform(1.5, 9.0)),
+                                               merged_frac=float(rng.uniform(0.0, 0.3)), sub_rate=float(rng.uniform(0.0, 0.4)))
+    else:
+        q, s, ext = synth.make_batch_np(nq, lq, wpq, seed=int(rng.integers(1, 1 << 30)), alphabet=alpha,
+                                        sub_rate=float(rng.uniform(0.0, 0.4)), indel_rate=float(rng.uniform(0.0, 0.08)))
     ext = ext.copy()
     cut = rng.random(len(ext))
     full = ext["s_len"].copy()
