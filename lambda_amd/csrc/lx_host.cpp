@@ -1491,7 +1491,18 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint64_t       o0        = 0;
         while (o0 < nsb)
         {
-            uint64_t       o1   = std::min(nsb, o0 + per_chunk);
+            // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is
+            // sized for the chunk's widest query and longest window, which are its FIRST sub-block's (the order descends), plus
+            // room for the int32 overflow slots of what the sweep may decline
+            uint64_t cap_sb = per_chunk;
+            {
+                uint32_t const key0   = sb_key[sb_order[o0]];
+                uint64_t const panels = std::max<uint64_t>(1, 0xfffu - (key0 >> 16)), steps = ((0xffffu - (key0 & 0xffffu)) + 8 - 1 + 15) & ~15ull;
+                uint64_t const stride = panels * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
+                uint64_t const fit    = h->opt_trace_bytes / std::max<uint64_t>(stride, 1) / kSub;
+                cap_sb                = std::max<uint64_t>(4, std::min(per_chunk, fit / 4 * 4));
+            }
+            uint64_t       o1   = std::min(nsb, o0 + cap_sb);
             auto first_not = [&](uint64_t lo, uint64_t hi, auto same) // first position in (lo, hi] whose class differs (same(lo) holds)
             {
                 if (same(hi - 1))
