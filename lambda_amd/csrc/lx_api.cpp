@@ -1127,16 +1127,22 @@ void lx_destroy(lx_handle * h)
         }
     for (auto & ln : h->xb)
     {
-        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt, &ln.d_len})
+        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt, &ln.d_len, &ln.d_orig})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len})
+        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len, &ln.p_orig})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt, ln.ev_mid})
             if (ev)
                 (void)hipEventDestroy(ev);
     }
+    for (DevBuf * b : {&h->d_ext_all, &h->d_min_all, &h->d_score_all})
+        if (b->ptr)
+            (void)hipFree(b->ptr);
+    for (lx_handle::Pinned * b : {&h->p_all, &h->p_score_all})
+        if (b->ptr)
+            (void)hipHostFree(b->ptr);
     for (hipEvent_t ev : {h->evF[0], h->evF[1], h->evB[0], h->evB[1], h->evS})
         if (ev)
             (void)hipEventDestroy(ev);

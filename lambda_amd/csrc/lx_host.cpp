@@ -944,7 +944,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // 34.5 % / 39.9 % padded and 22.7-24.2 ms.  Class of a query = its panel count.  Sort key: most panels first, longest windows
     // first -- the wavefronts with the most work start first, the chunks with the most survivors are unpacked beside the later
     // chunks' kernels, and the call ends with a small chunk.
-    int mq_cfg = 1;
+    int      mq_cfg   = 1;
+    uint64_t mq_cells = 0; // sum q_len * s_len of the list (lx_last_extend_stats)
     auto mq_class = [&](uint32_t lq) -> uint32_t
     {
         return (uint32_t)std::min<uint64_t>(1023, ((uint64_t)lq + lx::trace_cfg_panel(mq_cfg) - 1) / lx::trace_cfg_panel(mq_cfg));
@@ -1003,9 +1004,11 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         sb_key.resize(nsb);
         sb_order.resize(nsb);
         sb_tmp.resize(nsb);
+        std::vector<uint64_t> tcells_plan(nthreads, 0);
         parallel_ranges(nruns, nthreads,
-                        [&](unsigned, uint64_t rlo, uint64_t rhi)
+                        [&](unsigned t, uint64_t rlo, uint64_t rhi)
                         {
+                            uint64_t cells_t = 0;
                             for (uint64_t r = rlo; r < rhi; ++r)
                             {
                                 uint32_t const cls = mq_key_class(mq_class(ext[idx[starts[r]]].q_len));
@@ -1014,14 +1017,21 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 {
                                     uint32_t mx = 0;
                                     for (uint64_t j = k; j < std::min(starts[r + 1], k + kSub); ++j)
+                                    {
                                         mx = std::max(mx, ext[idx[j]].s_len);
+                                        cells_t += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
+                                    }
                                     sb_first[o] = (uint32_t)k;
                                     // (longest first inside a class: the wavefronts that run longest start first, the tail of
                                     // the launch is made of short ones)
                                     sb_key[o]   = (cls << 16) | (0xffffu - std::min<uint32_t>(mx, 0xffffu));
                                 }
                             }
+                            tcells_plan[t] = cells_t;
                         });
+        mq_cells = 0;
+        for (uint64_t c : tcells_plan)
+            mq_cells += c;
         // LSD radix sort of the sub-block numbers by key: three passes of 10 bits (keys have 28)
         for (uint64_t o = 0; o < nsb; ++o)
             sb_order[o] = (uint32_t)o;
@@ -1268,7 +1278,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         return launch_chunk(L, slots, max_q, max_s, kRun);
     };
 
-    // ---- sub-blocks o0 .. o1 of the sorted plan -> slots in lane L's pinned staging -> uploads and kernels queued
+    // ---- sub-blocks o0 .. o1 of the sorted plan -> the slots' caller indices in lane L's pinned staging -> upload, gather of the
+    // slot records on the device, kernels, scatter of the scores into caller order.  The plan's order is a permutation of the
+    // caller's list: the host only touches 4 bytes per slot here (the 24-byte records and their cut-offs are gathered from the
+    // device copy of the list at HBM speed, not by cache misses of a few host threads).
     auto enqueue_mq = [&](int L, uint64_t o0, uint64_t o1) -> int
     {
         auto const          t0 = now();
@@ -1279,66 +1292,198 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint64_t const slots = (o1 - o0) * kSub;
         pr.slots   = slots;
         pr.cap_sel = (slots + 7) / 8 * 8 + 8;
-        pr.slot_src.resize(slots);
         int rc2;
-        if ((rc2 = ensure_pinned(h, ln.p_ext, slots * sizeof(lx_extension))) || (rc2 = ensure_pinned(h, ln.p_min, slots * sizeof(int32_t))))
+        if ((rc2 = ensure_pinned(h, ln.p_orig, slots * sizeof(uint32_t))))
             return rc2;
-        lx_extension * const slot_ext = static_cast<lx_extension *>(ln.p_ext.ptr);
-        int32_t * const      slot_min = static_cast<int32_t *>(ln.p_min.ptr);
-        uint32_t * const     slot_src = pr.slot_src.data();
-        uint64_t const       panel    = (uint64_t)lx::trace_cfg_panel(mq_cfg);
-        std::vector<uint64_t> tq(nthreads, 1), ts(nthreads, 1), tcells(nthreads, 0), tpad(nthreads, 0);
-        // whole wavefronts (four sub-blocks) per thread share, so that the executed-cells estimate sees each wavefront once
+        uint32_t * const slot_orig = static_cast<uint32_t *>(ln.p_orig.ptr);
+        uint64_t const   panel     = (uint64_t)lx::trace_cfg_panel(mq_cfg);
+        std::vector<uint64_t> tpad(nthreads, 0), tmaxs(nthreads, 1);
+        // whole wavefronts (four sub-blocks) per thread share, so that the executed-cells estimate sees each wavefront once: a
+        // wavefront sweeps as many panels as its widest query needs, each for as many steps as its longest window has rows --
+        // the panels are its FIRST sub-block's (the order descends), the rows the largest of its four (a wavefront may straddle
+        // two panel counts); both are in the sort key
         parallel_ranges((o1 - o0 + 3) / 4, nthreads,
                         [&](unsigned t, uint64_t wlo, uint64_t whi)
                         {
-                            uint64_t mq_ = 1, ms_ = 1, cells = 0, padded = 0; // (locals: the per-thread slots share cache lines)
+                            uint64_t padded = 0, smax = 1; // (locals: the per-thread slots share cache lines)
                             for (uint64_t w = wlo; w < whi; ++w)
                             {
-                                uint64_t wmax = 0, wq = 1;
+                                uint64_t wmax = 0;
                                 for (uint64_t o = o0 + 4 * w; o < std::min(o1, o0 + 4 * w + 4); ++o)
                                 {
                                     uint32_t const sb    = sb_order[o];
+                                    wmax                 = std::max<uint64_t>(wmax, 0xffffu - (sb_key[sb] & 0xffffu));
                                     uint64_t const first = sb_first[sb];
                                     uint64_t       cnt   = 1;
                                     while (cnt < kSub && !newrun[first + cnt])
                                         ++cnt;
                                     uint64_t const so = (o - o0) * kSub;
                                     for (uint64_t j = 0; j < kSub; ++j)
-                                    {
-                                        uint32_t const     orig = idx[first + std::min(j, cnt - 1)];
-                                        lx_extension const x    = ext[orig];
-                                        slot_ext[so + j]        = x;
-                                        slot_src[so + j]        = j < cnt ? orig : 0xffffffffu;
-                                        slot_min[so + j]        = j < cnt ? (min_score ? min_score[orig] : min_score_all) : 0x7fffffff;
-                                        if (j < cnt)
-                                            cells += (uint64_t)x.q_len * x.s_len;
-                                        wmax = std::max<uint64_t>(wmax, x.s_len);
-                                        wq   = std::max<uint64_t>(wq, x.q_len);
-                                    }
+                                        slot_orig[so + j] = idx[first + std::min(j, cnt - 1)] | (j < cnt ? 0u : 0x80000000u);
                                 }
-                                ms_ = std::max(ms_, wmax);
-                                mq_ = std::max(mq_, wq);
-                                // (a wavefront sweeps as many panels as its widest query needs, each for as many steps as its
-                                // longest window has rows)
-                                padded += 16 * ((wq + panel - 1) / panel * panel) * (wmax + 7);
+                                uint32_t const key = sb_key[sb_order[o0 + 4 * w]];
+                                padded += 16 * ((uint64_t)(0xfffu - (key >> 16)) * panel) * (wmax + 7);
+                                smax = std::max(smax, wmax);
                             }
-                            tq[t]     = mq_;
-                            ts[t]     = ms_;
-                            tcells[t] = cells;
-                            tpad[t]   = padded;
+                            tpad[t]  = padded;
+                            tmaxs[t] = smax;
                         });
-        uint64_t max_q = 1, max_s = 1;
+        uint64_t max_s = 1;
         for (unsigned t = 0; t < nthreads; ++t)
         {
-            max_q = std::max(max_q, tq[t]);
-            max_s = std::max(max_s, ts[t]);
-            h->xb_stats[2] += tcells[t];
             h->xb_stats[3] += tpad[t];
+            max_s = std::max(max_s, tmaxs[t]);
         }
         h->xb_stats[1] += slots;
+        // the promises of the chunk: its first sub-block's panel count (as a query width), the longest window of any sub-block
+        uint32_t const key0  = sb_key[sb_order[o0]];
+        uint64_t const max_q = (uint64_t)(0xfffu - (key0 >> 16)) * panel;
+        if (max_s >= 0xffffu) // (keys clamp at 65 535 rows: the true lengths then)
+            for (uint64_t o = o0; o < o1; ++o)
+                if ((sb_key[sb_order[o]] & 0xffffu) == 0)
+                    for (uint64_t j = sb_first[sb_order[o]], c = 0; c < kSub && (c == 0 || !newrun[j]); ++j, ++c)
+                        max_s = std::max<uint64_t>(max_s, ext[idx[j]].s_len);
         t_prep += ms(t0, now());
-        return launch_chunk(L, slots, max_q, max_s, kSub);
+
+        auto const t1 = now();
+        uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
+        if ((rc2 = ensure(h, ln.d_orig, slots * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) ||
+            (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) ||
+            (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) || (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) ||
+            (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) ||
+            (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+            return rc2;
+        LX_HIP(h, hipMemcpyAsync(ln.d_orig.ptr, slot_orig, slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+        use_ctx(h, 0);
+        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+        LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(h->d_ext_all.ptr), min_score ? static_cast<int32_t const *>(h->d_min_all.ptr) : nullptr,
+                                         min_score_all, static_cast<uint32_t const *>(ln.d_orig.ptr), slots, static_cast<lx::Extension *>(ln.d_ext.ptr),
+                                         static_cast<int32_t *>(ln.d_min.ptr), h->stream));
+        h->opt_max_qlen  = max_q;
+        h->opt_max_slen  = max_s;
+        h->opt_query_run = kSub;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
+        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr,
+                              d_cnt, h->stream, 3, true, &fx)))
+            return rc2;
+        LX_HIP(h, lx::launch_slot_scatter(static_cast<uint32_t const *>(ln.d_orig.ptr), slots, static_cast<int32_t const *>(ln.d_score.ptr),
+                                          static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
+        LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // this chunk's error word
+        LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
+        in_flight[L] = true;
+        t_issue += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- results of a multi-query chunk: the survivors' records and ops, addressed by caller index (the device translated the
+    // list); the scores of every extension come back once, in caller order, at the end of the call
+    auto collect_mq = [&](int L) -> int
+    {
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        in_flight[L]           = false;
+        auto const t0          = now();
+        LX_HIP(h, hipEventSynchronize(ln.ev_cnt));
+        uint64_t const * const cnt = static_cast<uint64_t const *>(ln.p_cnt.ptr);
+        uint64_t const count = cnt[0], nrle = cnt[2];
+        {
+            uint32_t flags[2];
+            std::memcpy(flags, cnt + 3, sizeof(flags));
+            int const rcf = error_for_flag(h, flags[1]);
+            if (rcf)
+                return rcf;
+        }
+        if (count > pr.cap_sel)
+            return fail(h, LX_ESTATE, "survivor list longer than its capacity");
+        if (pr.slots)
+            h->surv_frac = (double)cnt[1] / (double)pr.slots;
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
+            (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) || (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
+            return rc2;
+        if (count)
+        {
+            LX_HIP(h, hipMemcpyAsync(ln.p_hsp.ptr, ln.d_hsp.ptr, count * sizeof(lx_hsp), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_src.ptr, ln.d_src.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(ln.p_len.ptr, ln.d_len.ptr, count * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream3));
+            if (nrle)
+                LX_HIP(h, hipMemcpyAsync(ln.p_rle.ptr, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
+        }
+        LX_HIP(h, hipStreamSynchronize(h->stream3));
+        auto const t1 = now();
+        t_wait += ms(t0, t1);
+        lx_hsp const * const   hs       = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
+        uint32_t const * const src_orig = static_cast<uint32_t const *>(ln.p_src.ptr);
+        uint8_t const * const  codes    = static_cast<uint8_t const *>(ln.p_rle.ptr);
+        uint32_t const * const code_len = static_cast<uint32_t const *>(ln.p_len.ptr);
+        std::vector<uint64_t> & pos_off = h->xb_off;
+        pos_off.resize(count + 1);
+        std::vector<uint64_t> part(nthreads + 1, 0);
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t sum = 0;
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t const len = (src_orig[e] != 0xffffffffu && hs[e].score > 0) ? (want_rle ? (uint64_t)code_len[e] : (uint64_t)hs[e].n_ops) : 0;
+                                pos_off[e] = len;
+                                sum += len;
+                            }
+                            part[t + 1] = sum;
+                        });
+        part[0] = ops_total;
+        for (unsigned t = 0; t < nthreads; ++t)
+            part[t + 1] += part[t];
+        uint64_t const total = part[nthreads];
+        if (!h->ext_bytes.grow(total + 16))
+            return fail(h, LX_ENOMEM, "out of host memory for %llu bytes of alignment ops", (unsigned long long)(total + 16));
+        uint8_t * const dst = h->ext_bytes.data();
+        std::vector<uint64_t> untraced(nthreads, ~0ull);
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t at = part[t];
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                uint64_t const len = pos_off[e];
+                                uint32_t const orig = src_orig[e];
+                                if (orig == 0xffffffffu)
+                                    continue;
+                                lx_hsp r = hs[e];
+                                if (r.score < 0)
+                                {
+                                    untraced[t] = std::min<uint64_t>(untraced[t], orig);
+                                    continue;
+                                }
+                                uint8_t const * const c = codes + (uint32_t)r.ops_shift;
+                                if (r.score > 0 && want_rle)
+                                    std::memcpy(dst + at, c, (size_t)len);
+                                else if (r.score > 0)
+                                    rle_expand(c, r.n_ops, dst + at);
+                                r.ops_shift       = 0;
+                                out_hsp[orig]     = r;
+                                out_ops_off[orig] = at;
+                                at += len;
+                            }
+                        });
+        for (uint64_t u : untraced)
+            if (u != ~0ull)
+                return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
+        ops_total = total;
+        t_unpack += ms(t1, now());
+        return LX_OK;
     };
 
     // ---- results of the chunk in lane L -> the caller's arrays
@@ -1488,7 +1633,31 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // starts a new chunk only when both sides fill the chip a few times (a chunk's slots are sized for its widest query;
         // a launch of a few hundred wavefronts costs its latency)
         uint64_t const per_chunk = std::max<uint64_t>(4, chunk_target / kSub / 4 * 4), min_chunk = std::min<uint64_t>(per_chunk, 16384);
-        uint64_t       o0        = 0;
+        h->xb_stats[2] = mq_cells;
+        // the caller's list and cut-offs onto the device (pinned staging, filled by the pool), scores in caller order zeroed
+        {
+            auto const tu0 = now();
+            uint64_t const ext_bytes = n * sizeof(lx_extension), min_bytes = min_score ? n * sizeof(int32_t) : 0;
+            if ((rc = ensure_pinned(h, h->p_all, ext_bytes + min_bytes + 16)) || (rc = ensure(h, h->d_ext_all, ext_bytes + 16)) ||
+                (rc = ensure(h, h->d_min_all, min_bytes + 16)) || (rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) ||
+                (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16)))
+                return rc;
+            uint8_t * const stage_all = static_cast<uint8_t *>(h->p_all.ptr);
+            parallel_ranges(n, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                std::memcpy(stage_all + lo * sizeof(lx_extension), ext + lo, (hi - lo) * sizeof(lx_extension));
+                                if (min_score)
+                                    std::memcpy(stage_all + ext_bytes + lo * sizeof(int32_t), min_score + lo, (hi - lo) * sizeof(int32_t));
+                            });
+            LX_HIP(h, hipMemcpyAsync(h->d_ext_all.ptr, stage_all, ext_bytes, hipMemcpyHostToDevice, h->stream));
+            if (min_score)
+                LX_HIP(h, hipMemcpyAsync(h->d_min_all.ptr, stage_all + ext_bytes, min_bytes, hipMemcpyHostToDevice, h->stream));
+            LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
+            t_prep += ms(tu0, now());
+        }
+        bool     rows_cleared = false;
+        uint64_t o0           = 0;
         while (o0 < nsb)
         {
             // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is
@@ -1496,8 +1665,24 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // room for the int32 overflow slots of what the sweep may decline
             uint64_t cap_sb = per_chunk;
             {
-                uint32_t const key0   = sb_key[sb_order[o0]];
-                uint64_t const panels = std::max<uint64_t>(1, 0xfffu - (key0 >> 16)), steps = ((0xffffu - (key0 & 0xffffu)) + 8 - 1 + 15) & ~15ull;
+                uint32_t const key0 = sb_key[sb_order[o0]];
+                uint64_t       smax = 1; // (the classes of a chunk descend in panels, not in rows: the longest window of the range)
+                for (uint64_t o = o0; o < std::min(nsb, o0 + per_chunk);)
+                {
+                    uint32_t const c_at = sb_key[sb_order[o]] >> 16;
+                    smax                = std::max<uint64_t>(smax, 0xffffu - (sb_key[sb_order[o]] & 0xffffu)); // first of its class = its longest
+                    uint64_t lo = o, hi = std::min(nsb, o0 + per_chunk);
+                    if ((sb_key[sb_order[hi - 1]] >> 16) == c_at)
+                        break;
+                    --hi;
+                    while (hi - lo > 1)
+                    {
+                        uint64_t const mid = lo + (hi - lo) / 2;
+                        ((sb_key[sb_order[mid]] >> 16) == c_at ? lo : hi) = mid;
+                    }
+                    o = hi;
+                }
+                uint64_t const panels = std::max<uint64_t>(1, 0xfffu - (key0 >> 16)), steps = (smax + 8 - 1 + 15) & ~15ull;
                 uint64_t const stride = panels * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
                 uint64_t const fit    = h->opt_trace_bytes / std::max<uint64_t>(stride, 1) / kSub;
                 cap_sb                = std::max<uint64_t>(4, std::min(per_chunk, fit / 4 * 4));
@@ -1530,14 +1715,49 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 at = nx;
             }
             int const L = c & 1;
-            if (in_flight[L] && (rc = collect(L)))
+            if (in_flight[L] && (rc = collect_mq(L)))
                 return rc;
             if ((rc = enqueue_mq(L, o0, o1)))
                 return rc;
-            if (in_flight[L ^ 1] && (rc = collect(L ^ 1)))
+            if (!rows_cleared)
+            {
+                // (beside the first chunk's kernels) every row starts as "no alignment"; the survivors' rows are written by
+                // collect_mq, the scores of all rows at the end of the call
+                auto const tz0 = now();
+                parallel_ranges(n, nthreads,
+                                [&](unsigned, uint64_t lo, uint64_t hi)
+                                {
+                                    std::memset(static_cast<void *>(out_hsp + lo), 0, (hi - lo) * sizeof(lx_hsp));
+                                    std::memset(out_ops_off + lo, 0, (hi - lo) * sizeof(uint64_t));
+                                });
+                rows_cleared = true;
+                t_unpack += ms(tz0, now());
+            }
+            if (in_flight[L ^ 1] && (rc = collect_mq(L ^ 1)))
                 return rc;
             o0 = o1;
             ++c;
+        }
+        for (int L : {c & 1, (c & 1) ^ 1})
+            if (in_flight[L] && (rc = collect_mq(L)))
+                return rc;
+        // the scores of every extension, in caller order
+        {
+            auto const ts0 = now();
+            LX_HIP(h, hipMemcpyAsync(h->p_score_all.ptr, h->d_score_all.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+            LX_HIP(h, hipStreamSynchronize(h->stream));
+            int32_t const * const sa = static_cast<int32_t const *>(h->p_score_all.ptr);
+            parallel_ranges(n, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t i = lo; i < hi; ++i)
+                                {
+                                    out_score[i] = sa[i];
+                                    if (out_hsp[i].n_ops == 0)
+                                        out_hsp[i].score = sa[i];
+                                }
+                            });
+            t_unpack += ms(ts0, now());
         }
         k0 = live;
     }

@@ -46,6 +46,10 @@ int        trace_cfg_panel(int cfg);
 int        trace_cfg_group(int cfg);
 int        trace_cfg_words(int cfg);
 hipError_t launch_select(SelectParams const & p, hipStream_t stream);
+hipError_t launch_slot_gather(Extension const * ext_all, int32_t const * min_all, int32_t min_score_all, uint32_t const * orig, uint64_t slots,
+                              Extension * out_ext, int32_t * out_min, hipStream_t stream);
+hipError_t launch_slot_scatter(uint32_t const * orig, uint64_t slots, int32_t const * score, int32_t * score_all, uint32_t * src,
+                               uint64_t const * count_ptr, uint64_t cap, hipStream_t stream);
 uint64_t   ckpt_slot_dwords(int cfg, uint32_t steps_cap);
 uint64_t   ckpt16_slot_dwords(int cfg, uint32_t steps_cap);
 hipError_t launch_ckpt_forward(TraceParams const & p, hipStream_t stream);
@@ -118,10 +122,13 @@ struct lx_handle
     };
     struct XbLane
     {
-        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len;
-        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len;
+        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len, p_orig;
+        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len, d_orig;
         hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr, ev_mid = nullptr;
     } xb[2];
+    // multi-query plan: the caller's whole list, its cut-offs and the scores in caller order, on the device / in pinned staging
+    DevBuf      d_ext_all, d_min_all, d_score_all;
+    Pinned      p_all, p_score_all;
     hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
     hipStream_t stream4 = nullptr; // kernels of lx_extend_batch's odd chunks (the even ones run on `stream`)
     // lx_extend_batch keeps two chunks on the GPU at once, each on its own stream with its own working set: the buffers the

@@ -12,6 +12,8 @@
 // profile).  HBM-bound integer work: 28 B read per candidate, 28 B written per survivor.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "lx_device.h"
 
 namespace lx
@@ -232,6 +234,61 @@ __global__ __launch_bounds__(kSelBlock) void select_flat_write_kernel(SelectPara
 }
 
 // workgroups of the count / write kernels = entries of SelectParams::block_tot (two uint64 each)
+// ---- lx_extend_batch's multi-query plan: the plan's slot order is a permutation of the caller's list (sub-blocks sorted by
+// length across queries), so the per-slot records are GATHERED from a device copy of the caller's list and the scores
+// SCATTERED back into caller order here -- random accesses of 24-byte records at HBM speed instead of cache misses on the host.
+// orig[o] = index in the caller's list | 0x80000000 for a filler slot (a copy of its sub-block's last window that never survives).
+__global__ __launch_bounds__(256) void slot_gather_kernel(Extension const * __restrict__ ext_all, int32_t const * __restrict__ min_all, int32_t min_score_all,
+                                                          uint32_t const * __restrict__ orig, uint64_t slots, Extension * __restrict__ out_ext,
+                                                          int32_t * __restrict__ out_min)
+{
+    uint64_t const o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= slots)
+        return;
+    uint32_t const so = orig[o], i = so & 0x7fffffffu;
+    out_ext[o] = ext_all[i];
+    out_min[o] = (so >> 31) ? 0x7fffffff : (min_all ? min_all[i] : min_score_all);
+}
+
+// score of every real slot into caller order; the survivor list's slot numbers (src[e]) become caller indices
+__global__ __launch_bounds__(256) void slot_scatter_kernel(uint32_t const * __restrict__ orig, uint64_t slots, int32_t const * __restrict__ score,
+                                                           int32_t * __restrict__ score_all, uint32_t * __restrict__ src, uint64_t const * __restrict__ count_ptr,
+                                                           uint64_t cap)
+{
+    uint64_t const o = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < slots)
+    {
+        uint32_t const so = orig[o];
+        if (!(so >> 31))
+            score_all[so] = score[o];
+    }
+    if (o < cap && o < count_ptr[0])
+    {
+        uint32_t const slot = src[o];
+        src[o]              = slot == 0xffffffffu ? slot : (orig[slot] & 0x7fffffffu);
+    }
+}
+
+hipError_t launch_slot_gather(Extension const * ext_all, int32_t const * min_all, int32_t min_score_all, uint32_t const * orig, uint64_t slots,
+                              Extension * out_ext, int32_t * out_min, hipStream_t stream)
+{
+    if (slots == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(slot_gather_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, ext_all, min_all, min_score_all, orig, slots,
+                       out_ext, out_min);
+    return hipGetLastError();
+}
+
+hipError_t launch_slot_scatter(uint32_t const * orig, uint64_t slots, int32_t const * score, int32_t * score_all, uint32_t * src,
+                               uint64_t const * count_ptr, uint64_t cap, hipStream_t stream)
+{
+    uint64_t const n = std::max(slots, cap);
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(slot_scatter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, orig, slots, score, score_all, src, count_ptr, cap);
+    return hipGetLastError();
+}
+
 uint64_t select_blocks(uint64_t nruns) { return (nruns + kSelBlock - 1) / kSelBlock; }
 
 hipError_t launch_select(SelectParams const & p, hipStream_t stream)

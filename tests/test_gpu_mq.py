@@ -172,3 +172,40 @@ def test_mq_sweep_rejects_mixed_queries_in_a_sub_block(handle):
     ext["q_off"][2] = ext["q_off"][5]  # second half of the first sub-block names another query
     with pytest.raises(capi.LambdaExtError):
         run_fused(handle, q, s, ext, 4, 50)
+
+
+@pytest.mark.parametrize("seed,lq_range,merged", [(1, (20, 330), 0.3), (2, (100, 620), 0.2), (3, (30, 110), 0.0), (4, (140, 160), 0.5)])
+def test_host_plan_on_ragged_lists(handle, oracle, seed, lq_range, merged):
+    """lx_extend_batch on lists as lambda hands them over (mixed query lengths, few windows per query, merged windows): the
+    multi-query plan -- sub-blocks sorted across queries, one chunk spanning several panel counts (whose longest window is not
+    its first sub-block's: found by tools/stress_parity.py), records gathered and scores scattered on the device -- against the
+    oracle, in the caller's order; random list order included."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(40, seed=100 + seed, lq_range=lq_range, mean_windows=4.0, merged_frac=merged)
+    rng = np.random.default_rng(seed)
+    if seed % 2 == 0:
+        ext = ext[rng.permutation(len(ext))]
+    ext = ext.copy()
+    ext["s_len"][::17] = 0  # a few dead extensions: score 0, no record
+    want = oracle.score_batch(q, s, ext, osc, threads=8)
+    cutoff = 55
+    mins = np.where(np.arange(len(ext)) % 5 == 0, cutoff + 40, cutoff).astype(np.int32)  # per-extension cut-offs
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)  # (the session's handle: other tests leave mode 1 behind)
+    try:
+        score, hsp, off, ops = handle.extend_batch(q, s, ext, mins)
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+    assert "sweep_mq_kernel" in handle.last_trace_kernel_name()
+    assert (score == want).all()
+    surv = np.nonzero((want >= mins) & (ext["s_len"] > 0))[0]
+    assert len(surv) > 10
+    dead = np.setdiff1d(np.arange(len(ext)), surv)
+    assert (hsp["n_ops"][dead] == 0).all() and (hsp["score"][dead] == want[dead]).all()
+    for i, (oh, oops) in zip(surv, oracle.align_batch(q, s, ext[surv], osc)):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, ext[i])
+        st = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[st: st + oh.n_ops]) == oops, (i, ext[i])
