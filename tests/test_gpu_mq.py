@@ -174,16 +174,17 @@ def test_mq_sweep_rejects_mixed_queries_in_a_sub_block(handle):
         run_fused(handle, q, s, ext, 4, 50)
 
 
-@pytest.mark.parametrize("seed,lq_range,merged", [(1, (20, 330), 0.3), (2, (100, 620), 0.2), (3, (30, 110), 0.0), (4, (140, 160), 0.5)])
-def test_host_plan_on_ragged_lists(handle, oracle, seed, lq_range, merged):
+@pytest.mark.parametrize("seed,lq_range,merged,nq,chunk", [(1, (20, 330), 0.3, 40, 0), (2, (100, 620), 0.2, 40, 0), (3, (30, 110), 0.0, 40, 0),
+                                                           (4, (140, 160), 0.5, 40, 0), (5, (40, 420), 0.2, 500, 1024), (6, (40, 420), 0.1, 500, 1500)])
+def test_host_plan_on_ragged_lists(handle, oracle, seed, lq_range, merged, nq, chunk):
     """lx_extend_batch on lists as lambda hands them over (mixed query lengths, few windows per query, merged windows): the
-    multi-query plan -- sub-blocks sorted across queries, one chunk spanning several panel counts (whose longest window is not
+    multi-query plan -- sub-blocks sorted across queries, many small chunks or one chunk spanning several panel counts (whose longest window is not
     its first sub-block's: found by tools/stress_parity.py), records gathered and scores scattered on the device -- against the
     oracle, in the caller's order; random list order included."""
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
     osc = oracle_lib.scoring_from(sc_p)
-    q, s, ext = synth.make_ragged_lists_np(40, seed=100 + seed, lq_range=lq_range, mean_windows=4.0, merged_frac=merged)
+    q, s, ext = synth.make_ragged_lists_np(nq, seed=100 + seed, lq_range=lq_range, mean_windows=4.0, merged_frac=merged)
     rng = np.random.default_rng(seed)
     if seed % 2 == 0:
         ext = ext[rng.permutation(len(ext))]
@@ -193,10 +194,12 @@ def test_host_plan_on_ragged_lists(handle, oracle, seed, lq_range, merged):
     cutoff = 55
     mins = np.where(np.arange(len(ext)) % 5 == 0, cutoff + 40, cutoff).astype(np.int32)  # per-extension cut-offs
     handle.set_option(capi.LX_OPT_PASS2_MODE, 2)  # (the session's handle: other tests leave mode 1 behind)
+    handle.set_option(capi.LX_OPT_EXTEND_CHUNK, chunk)  # small chunks: the pipeline's two lanes, several chunks per panel count
     try:
         score, hsp, off, ops = handle.extend_batch(q, s, ext, mins)
     finally:
         handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
     assert "sweep_mq_kernel" in handle.last_trace_kernel_name()
     assert (score == want).all()
     surv = np.nonzero((want >= mins) & (ext["s_len"] > 0))[0]
