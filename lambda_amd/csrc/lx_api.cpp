@@ -394,12 +394,12 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
             smax_entry = std::max<int>(smax_entry, h->sc_host[slot].matrix[a * LX_ALPH + b]);
     // checkpoint mode (lx_ckpt.hip): shared-profile geometries (8,19) / (16,13), scores that fit int16; queries wider
     // than 208 columns take several (16,13) panels
-    bool const ckpt = !h->opt_band && h->opt_pass2 >= 1 && share_slots >= 4 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
+    bool const ckpt = !h->opt_band && h->opt_pass2 >= 1 && share_slots >= 2 && (uint64_t)smax_entry * std::min(max_q, max_s) < 32000 && max_s <= 65535; // (longer windows: direction bits)
     // Direction bits beyond one panel: the 16-lane geometry that pads the query less ((16,13) needs the shared profile).
     auto padded = [&](int c) { return (max_q + lx::trace_cfg_panel(c) - 1) / lx::trace_cfg_panel(c) * lx::trace_cfg_panel(c); };
     int const cfg = (h->opt_band && !(share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1))) ? 0 // (band mode: (8,19) or generic)
-                    : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1
-                    : (share_slots >= 4 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
+                    : (share_slots >= 2 && max_q <= (uint64_t)lx::trace_cfg_panel(1)) ? 1
+                    : (share_slots >= 2 && max_q <= (uint64_t)lx::trace_cfg_panel(2)) ? 2
                     : ckpt                                                             ? ckpt_cfg_for(max_q)
                     : (share_slots >= 4 && padded(2) < padded(0))                      ? 2
                                                                                       : 0;
@@ -902,7 +902,9 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     // filter (:1251-1283) as an integer cut-off, compaction in input order, runs padded to whole wavefronts
     uint32_t const run    = shared ? (uint32_t)h->opt_query_run : 1u;
     // half a wavefront of the 8-lane geometry, a whole one of the 16-lane; the single sweep's backtrace needs no padding
-    uint32_t const pad_to = (shared && !sweep) ? 4u : 1u;
+    // (the adaptive step has few survivors, one or two to a query: its lists pad every query's to 2 slots -- four LDS profiles
+    // per wavefront of the int32 forward kernel -- instead of 4: 2.6 x -> 1.9 x the survivors' cells at 2 % survivors)
+    uint32_t const pad_to = (shared && !sweep) ? (plan.adapted ? 2u : 4u) : 1u;
     uint64_t const nruns  = (n + run - 1) / run;
     uint64_t const cap    = (n + (shared ? nruns * 3 : 0) + 7) / 8 * 8;
     if ((rc = ensure(h, h->d_sel_ext, cap * sizeof(lx_extension))) || (rc = ensure(h, h->d_sel_src, cap * sizeof(uint32_t))) ||
@@ -988,7 +990,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     // pass 2 on the survivors (:1293-1296); the grid covers the worst case, wavefronts beyond *d_out_count exit
     rc = align_dev_impl(h, slot, d_q_res, d_s_res, static_cast<lx::Extension const *>(h->d_sel_ext.ptr), cap,
                         static_cast<lx::Hsp *>(d_out_hsp), static_cast<uint8_t *>(d_out_ops),
-                        static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? 4 : 0,
+                        static_cast<uint64_t const *>(d_ops_off), stream, h->opt_max_qlen, h->opt_max_slen, shared ? (int)pad_to : 0,
                         static_cast<uint32_t const *>(h->d_sel_src.ptr), static_cast<uint64_t const *>(d_out_count),
                         static_cast<int32_t const *>(h->d_sel_score.ptr), by_pos, fx ? fx->ops_stride : 0);
     if (rc)

@@ -950,3 +950,68 @@ def test_extend_batch_with_a_window_beyond_65535_residues(handle, oracle):
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops, i
     assert hsp[len(ext2) - 1]["s_begin"] >= 61_000
+
+
+def test_adaptive_pass2_follows_the_survivor_share(handle, oracle):
+    """LX_OPT_ADAPT_PERMILLE: after a batch in which few extensions passed the cut-off, the next step runs plain pass 1 and
+    checkpoints for the survivors only (the reference's order, /root/reference/src/search_algo.hpp:1246 / :1251-1283 / :1296)
+    instead of the single sweep -- and goes back to the sweep when many survive again.  Same results either way."""
+    import torch
+
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    dev = torch.device("cuda:0")
+    names = []
+
+    def run(homolog_frac, seed):
+        q, s, ext = synth.make_batch_np(120, 150, 16, seed=seed, homolog_frac=homolog_frac)
+        n = len(ext)
+        pad = np.zeros(256, np.uint8)
+        d_q = torch.from_numpy(np.concatenate([q, pad])).to(dev)
+        d_s = torch.from_numpy(np.concatenate([s, pad])).to(dev)
+        d_ext = torch.from_numpy(ext.view(np.uint8).copy()).to(dev)
+        sizes = ext["q_len"].astype(np.uint64) + ext["s_len"].astype(np.uint64)
+        off = np.zeros(n, dtype=np.uint64)
+        off[1:] = np.cumsum(sizes)[:-1]
+        d_off = torch.from_numpy(off.view(np.int64)).to(dev)
+        d_ops = torch.zeros(int(sizes.sum()) + 16, dtype=torch.uint8, device=dev)
+        d_hsp = torch.full((n * 48,), 0xEE, dtype=torch.uint8, device=dev)
+        d_score = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_count = torch.zeros(2, dtype=torch.int64, device=dev)
+        handle.extend_batch_dev(d_q, d_s, d_ext, n, 91, d_score, d_hsp, d_ops, d_off, d_count)
+        handle.synchronize()
+        names.append(handle.last_trace_kernel_name())
+        want = oracle.score_batch(q, s, ext, osc, threads=8)
+        assert (d_score.cpu().numpy() == want).all()
+        surv = np.nonzero(want >= 91)[0]
+        assert int(d_count.cpu().numpy()[1]) == len(surv)
+        hsp = np.frombuffer(d_hsp.cpu().numpy().tobytes(), dtype=capi.HSP_DTYPE)
+        ops = d_ops.cpu().numpy()
+        for i, (oh, oops) in zip(surv, oracle.align_batch(q, s, ext[surv], osc)):
+            g = hsp[i]
+            assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+                   (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), i
+            st = int(off[i]) + int(g["ops_shift"])
+            assert bytes(ops[st: st + oh.n_ops]) == oops
+        return len(surv) / n
+
+    handle.set_option(capi.LX_OPT_MAX_QLEN, 150)
+    handle.set_option(capi.LX_OPT_MAX_SLEN, 176)
+    handle.set_option(capi.LX_OPT_QUERY_RUN, 16)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    handle.set_option(capi.LX_OPT_ADAPT_PERMILLE, 30)  # (also forgets what the handle has seen so far)
+    try:
+        f1 = run(0.01, 11)   # unknown share: the sweep
+        f2 = run(0.01, 12)   # 1 % survived last time: adapted
+        f3 = run(0.5, 13)    # still adapted (the share it knows is the last batch's)
+        f4 = run(0.5, 14)    # half survived last time: the sweep again
+    finally:
+        handle.set_option(capi.LX_OPT_MAX_QLEN, 0)
+        handle.set_option(capi.LX_OPT_MAX_SLEN, 0)
+        handle.set_option(capi.LX_OPT_QUERY_RUN, 0)
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+    assert f1 < 0.03 and f2 < 0.03 and f3 > 0.3 and f4 > 0.3
+    assert "single sweep" in names[0] and "single sweep" in names[3], names
+    assert "single sweep" not in names[1] and "single sweep" not in names[2], names
+    assert "ckpt_forward_kernel" in names[1] and "ckpt_forward_kernel" in names[2], names
