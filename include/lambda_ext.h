@@ -260,7 +260,14 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
  * n_ops = 0; the ops of a survivor i are *out_ops + out_ops_off[i] + out_hsp[i].ops_shift (the callee lays them out
  * compactly; the buffer belongs to the handle and stays valid until its next lx_extend_batch[_rle] call).  The list is
  * processed as a pipeline of chunks (uploads, kernels, downloads and the host's share overlap); only scores, the
- * survivors' records and their run-length coded ops cross PCIe. */
+ * survivors' records and their run-length coded ops cross PCIe.  A list that is not uniform -- what
+ * _widenAndPreprocessMatches really hands over: queries of mixed lengths, a few windows each, merged windows of up to three
+ * times the length (:1136-1175) -- is planned for the multi-query sweep (LX_OPT_MQ_SWEEP): sub-blocks of 4 windows of one
+ * query, sorted by length across queries, four sub-blocks to a wavefront; the records are gathered from a device copy of the
+ * list and the scores scattered back into the caller's order on the device.  lx_last_extend_stats() reports extensions,
+ * slots, cells and the cells the wavefronts executed (padding included) of the last call.
+ * Throughput depends on the batch size -- a call has a fixed cost of ~0.7 ms (INTEGRATION.md has the curve): hand over the
+ * windows of at least ~1 000 queries per call. */
 int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                     lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                     lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
