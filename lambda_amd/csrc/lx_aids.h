@@ -27,8 +27,6 @@ struct DevAids
     bool     extend_no_classes; // LX_EXTEND_NO_CLASSES  lx_extend_batch: no geometry-class binning of ragged lists        off
     bool     extend_no_sort;    // LX_EXTEND_NO_SORT     lx_extend_batch: no in-run sort by window length                  off
     bool     extend_no_mq;      // LX_EXTEND_NO_MQ       lx_extend_batch: ragged lists on the one-query-per-wavefront kernels      off
-    bool     extend_two_streams;// LX_EXTEND_TWO_STREAMS lx_extend_batch: odd chunks' kernels on a second stream + working set (measured: slower)  off
-    bool     extend_bt_overlap; // LX_EXTEND_BT_OVERLAP=1 lx_extend_batch: a chunk's backtrace on a second stream beside the next chunk's sweep (measured: slower)  off
     uint64_t extend_run;        // LX_EXTEND_RUN         lx_extend_batch: pad query runs to 8 or 16 slots (0 = by estimated work)  0
     uint64_t extend_chunk;      // LX_EXTEND_CHUNK       default of LX_OPT_EXTEND_CHUNK (extensions per pipeline chunk)    640 Ki
     int      bt_waves_per_cu;   // LX_BT_WAVES_PER_CU    persistent wavefronts of the backtrace per CU (0 = what fits)     0

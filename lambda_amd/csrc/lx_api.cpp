@@ -46,8 +46,6 @@ lx::DevAids const & lx::dev_aids()
         a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
         a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
-        a.extend_two_streams = set("LX_EXTEND_TWO_STREAMS");
-        a.extend_bt_overlap  = num("LX_EXTEND_BT_OVERLAP", 0) != 0;
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
@@ -97,7 +95,7 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
         return LX_OK;
     if (b.ptr)
     {
-        LX_HIP(h, hipDeviceSynchronize()); // (kernels of either chunk stream may still read the old block)
+        LX_HIP(h, hipDeviceSynchronize()); // (kernels on a caller's stream may still read the old block)
         LX_HIP(h, hipFree(b.ptr));
         b.ptr = nullptr;
         b.cap = 0;
@@ -106,24 +104,6 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
     LX_HIP(h, hipMalloc(&b.ptr, want));
     b.cap = want;
     return LX_OK;
-}
-
-void use_ctx(lx_handle * h, int which)
-{
-    if (h->ctx_active == which)
-        return;
-    lx_handle::FusedCtx & a = h->alt;
-    std::swap(h->d_trace, a.d_trace);
-    std::swap(h->d_ends, a.d_ends);
-    std::swap(h->d_sel_ext, a.d_sel_ext);
-    std::swap(h->d_sel_src, a.d_sel_src);
-    std::swap(h->d_sel_runs, a.d_sel_runs);
-    std::swap(h->d_sel_score, a.d_sel_score);
-    std::swap(h->d_trace_score, a.d_trace_score);
-    std::swap(h->d_ws, a.d_ws);
-    std::swap(h->d_ws_top, a.d_ws_top);
-    std::swap(h->ws_grown, a.ws_grown);
-    h->ctx_active = which;
 }
 
 int bind(lx_handle * h)
@@ -1065,11 +1045,10 @@ int lx_create(int device_id, lx_handle ** out)
     if ((e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess)
         return bail("hipEventCreate", e);
     if ((e = hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking)) != hipSuccess)
+        (e = hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking)) != hipSuccess)
         return bail("hipStreamCreate", e);
     for (auto & ln : h->xb)
-        for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt, &ln.ev_mid})
+        for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt})
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
     for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
@@ -1078,10 +1057,6 @@ int lx_create(int device_id, lx_handle ** out)
     if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc", e);
     if ((e = hipMemset(h->d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
-        return bail("hipMemset", e);
-    if ((e = hipMalloc(reinterpret_cast<void **>(&h->alt.d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
-        return bail("hipMalloc", e);
-    if ((e = hipMemset(h->alt.d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMemset", e);
     for (int s = 0; s < 2; ++s)
         if ((e = hipMalloc(reinterpret_cast<void **>(&h->sc_dev[s]), sizeof(lx::ScoringDev))) != hipSuccess)
@@ -1111,17 +1086,11 @@ void lx_destroy(lx_handle * h)
             (void)hipFree(h->sc_dev[s]);
     if (h->d_ws_top)
         (void)hipFree(h->d_ws_top);
-    if (h->alt.d_ws_top)
-        (void)hipFree(h->alt.d_ws_top);
     if (h->ev_count)
         (void)hipEventDestroy(h->ev_count);
     if (h->p_count)
         (void)hipHostFree(h->p_count);
-    for (DevBuf * b : {&h->alt.d_trace, &h->alt.d_ends, &h->alt.d_sel_ext, &h->alt.d_sel_src, &h->alt.d_sel_runs, &h->alt.d_sel_score,
-                       &h->alt.d_trace_score, &h->alt.d_ws})
-        if (b->ptr)
-            (void)hipFree(b->ptr);
-    for (hipStream_t st : {h->stream2, h->stream3, h->stream4})
+    for (hipStream_t st : {h->stream2, h->stream3})
         if (st)
         {
             (void)hipStreamSynchronize(st);
@@ -1135,7 +1104,7 @@ void lx_destroy(lx_handle * h)
         for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len, &ln.p_orig})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
-        for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt, ln.ev_mid})
+        for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt})
             if (ev)
                 (void)hipEventDestroy(ev);
     }

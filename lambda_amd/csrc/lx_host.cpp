@@ -1066,8 +1066,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamSynchronize(h->stream2);
             (void)hipStreamSynchronize(h->stream3);
-            (void)hipStreamSynchronize(h->stream4);
-            use_ctx(h, 0);
             h->mq_cfg_call   = 0;
             h->opt_max_qlen  = qlen;
             h->opt_max_slen  = slen;
@@ -1081,13 +1079,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
     if (sref.upload)
         LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
-    // (the odd chunks' kernels run on stream4: they wait for the residues too)
-    LX_HIP(h, hipEventRecord(h->evS, h->stream));
-    LX_HIP(h, hipStreamWaitEvent(h->stream4, h->evS, 0));
-    // (measured: two chunks side by side on the GPU LOSE -- ragged list 28.5 against 24.4 ms, headline batch 40.0 against 31.3 ms:
-    // the persistent-lane backtrace of one chunk gets its wavefronts late while the other chunk's sweep holds the CUs, and the
-    // results the host waits for arrive later; kept behind LX_EXTEND_TWO_STREAMS for re-measurement)
-    bool const two_streams = lx::dev_aids().extend_two_streams;
+    // (measured in round 3 and removed again: two chunks' kernels side by side on two streams -- ragged list 28.5 against 24.4 ms,
+    // headline batch 40.0 against 31.3 ms -- and a chunk's backtrace on a second stream beside the next chunk's sweep -- no gain on
+    // the ragged list, 34.9 against 29.0 ms on the headline: kernels side by side cost more than their tails and latencies save)
 
     uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
     h->ext_bytes.clear();
@@ -1124,13 +1118,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
         // two chunks on the GPU at once: lane 1's kernels on their own stream with the handle's second working set -- the
         // tail of one chunk's sweep and its latency-bound backtrace run beside the other chunk's sweep
-        hipStream_t const ks = (two_streams && L == 1) ? h->stream4 : h->stream;
-        // LX_EXTEND_BT_OVERLAP=1: every chunk's sweep and selection on `stream`, in order; its backtrace -- one lane per survivor,
-        // bound by the latency of its walks when a chunk has few survivors -- on stream4, beside the NEXT chunk's sweep, the two
-        // chunks on the handle's two working sets.  Measured: no gain on the ragged list (27-29 ms either way), a loss on the
-        // headline batch (34.9 against 29.0 ms) -- kernels side by side cost more than their tails and latencies save.  Off.
-        bool const bt_beside = !two_streams && lx::dev_aids().extend_bt_overlap;
-        use_ctx(h, ((two_streams || bt_beside) && L == 1) ? 1 : 0);
+        hipStream_t const ks = h->stream;
         LX_HIP(h, hipStreamWaitEvent(ks, ln.ev_up, 0));
         h->opt_max_qlen  = max_q;
         h->opt_max_slen  = max_s;
@@ -1143,21 +1131,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         fx.rle_cap    = pr.cap_sel * stride;
         fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
         fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
-        hipStream_t ke = ks; // the stream the chunk's last kernel runs on
-        if (bt_beside)
-        {
-            if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
-                                  nullptr, d_cnt, ks, 1, true, &fx)))
-                return rc2;
-            LX_HIP(h, hipEventRecord(ln.ev_mid, ks));
-            LX_HIP(h, hipStreamWaitEvent(h->stream4, ln.ev_mid, 0));
-            ke = h->stream4;
-            if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
-                                  nullptr, d_cnt, ke, 2, true, &fx)))
-                return rc2;
-        }
-        else if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
-                                   nullptr, d_cnt, ks, 3, true, &fx)))
+        hipStream_t const ke = ks;
+        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+                              nullptr, d_cnt, ks, 3, true, &fx)))
             return rc2;
         // the device's error word of THIS chunk, saved in stream order (the next chunk's prepare_workspace clears it): it comes
         // back with the counts and is checked in collect()
@@ -1356,7 +1332,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             return rc2;
         LX_HIP(h, hipMemcpyAsync(ln.d_orig.ptr, slot_orig, slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
         LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
-        use_ctx(h, 0);
         LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
         LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(h->d_ext_all.ptr), min_score ? static_cast<int32_t const *>(h->d_min_all.ptr) : nullptr,
                                          min_score_all, static_cast<uint32_t const *>(ln.d_orig.ptr), slots, static_cast<lx::Extension *>(ln.d_ext.ptr),

@@ -124,24 +124,12 @@ struct lx_handle
     {
         Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len, p_orig;
         DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len, d_orig;
-        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr, ev_mid = nullptr;
+        hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
     } xb[2];
     // multi-query plan: the caller's whole list, its cut-offs and the scores in caller order, on the device / in pinned staging
     DevBuf      d_ext_all, d_min_all, d_score_all;
     Pinned      p_all, p_score_all;
     hipStream_t stream3 = nullptr; // uploads of lx_extend_batch (stream2 carries its downloads)
-    hipStream_t stream4 = nullptr; // kernels of lx_extend_batch's odd chunks (the even ones run on `stream`)
-    // lx_extend_batch keeps two chunks on the GPU at once, each on its own stream with its own working set: the buffers the
-    // fused step owns (checkpoint slots, end cells, selection lists, carry workspace, counters).  The second set lives here
-    // and is swapped with the members of the same name around every odd chunk (lxi::use_ctx; the host side of a handle is
-    // single-threaded, the kernels keep the pointers they were launched with).
-    struct FusedCtx
-    {
-        DevBuf     d_trace, d_ends, d_sel_ext, d_sel_src, d_sel_runs, d_sel_score, d_trace_score, d_ws;
-        uint32_t * d_ws_top = nullptr;
-        uint64_t   ws_grown = 0;
-    } alt;
-    int ctx_active = 0;
     std::string last_kernel; // human-readable name of the most recent DP kernel geometry (profiling aid)
     std::string last_trace_kernel;
     // per-phase HIP events of the most recent call: phase 0 score, 1 select, 2 trace forward, 3 backtrace
@@ -307,7 +295,6 @@ struct StepPlan
 };
 StepPlan plan_step(SchemeFacts const & sc, StepOptions const & o);
 void     describe_plan(StepPlan const & pl, char * buf, size_t len);
-void   use_ctx(lx_handle * h, int which); // 0 = the handle's own working set, 1 = lx_handle::alt
 int    mq_cfg_for(uint64_t max_q);
 int    launch_score_list(lx_handle * h, int slot, void const * d_q, void const * d_s, void const * d_ext, uint64_t n, void * d_out, int cfg,
                          bool multi, bool shared, hipStream_t stream, int pair_cfg = -1, int pair_share = 0);
