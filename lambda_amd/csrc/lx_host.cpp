@@ -761,6 +761,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     }
     if (live == 0)
         return LX_OK;
+    hm.mark("scan");
     bool const as_given = live == n && monotone;
     idx.resize(live);
     if (!as_given)
@@ -795,6 +796,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                         });
     newrun[live] = 1;
+    hm.mark("order");
     // positions where the runs of one query slice begin, + the sentinel `live` (two parallel passes over newrun)
     std::vector<uint64_t> & starts = h->xb_starts;
     starts.clear();
@@ -937,6 +939,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     constexpr uint64_t kSub = 4;
     std::vector<uint32_t> & sb_first = h->xb_sbfirst, & sb_key = h->xb_sbkey, & sb_order = h->xb_sborder, & sb_tmp = h->xb_sbtmp;
     uint64_t nsb = 0;
+    hm.mark("classes+sort");
     // ONE strip geometry per call, the one that sweeps the fewest padded columns over the whole list (weighted by the
     // instructions a column costs at that width): every further geometry is a further pair of launches, and the backtrace of a
     // chunk with a few ten thousand survivors is bound by the latency of its longest walks (~1 ms), not by its work -- measured
@@ -1032,6 +1035,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         mq_cells = 0;
         for (uint64_t c : tcells_plan)
             mq_cells += c;
+        hm.mark("sub-blocks");
         // LSD radix sort of the sub-block numbers by key: three passes of 10 bits (keys have 28)
         for (uint64_t o = 0; o < nsb; ++o)
             sb_order[o] = (uint32_t)o;
@@ -1054,7 +1058,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             sb_order.swap(sb_tmp);
         }
     }
-    hm.mark("validate");
+    hm.mark("plan-sort");
 
     // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
     struct Guard

@@ -138,3 +138,47 @@ def test_config4_bisulfite_both_slots_full_size(handle, oracle):
     assert [b.direction.slot for b in pl.batches] == [0, 1] and all(b.n_queries == 250_000 for b in pl.batches)
     for b in pl.batches:
         _run_call(handle, oracle, w, b.direction, b.n_queries, b.seed, "score_pair_kernel<8,19,true>", bs_rule=1)
+
+
+def test_ragged_list_full_size_through_the_host_entry_point(handle, oracle):
+    """The ragged seed list of `bench.py --ragged` (50 000 queries of 50-400 aa, 596 k windows, a tenth of them merged: what
+    _widenAndPreprocessMatches hands over, /root/reference/src/search_algo.hpp:1136-1175) through lx_extend_batch -- the
+    multi-query plan, records gathered and scores scattered on the device -- checked against (1) lx_score_batch on the same
+    list, i.e. other kernels (one query per wavefront, geometry per query) for EVERY score, (2) the filter's decisions and the
+    rows of the filtered-out extensions, (3) the column-count identities of every HSP, (4) the oracle on 3 000 sampled
+    survivors, merged windows over-sampled."""
+    sc_p = capi.builtin_scoring(62, gap_open=-11, gap_extend=-1)
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(50_000, seed=0x1A3BDA07)
+    handle.set_subjects(s)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    try:
+        score, hsp, off, ops = handle.extend_batch(q, None, ext, 91, copy_ops=False)
+        name = handle.last_trace_kernel_name()
+        st = handle.last_extend_stats()
+        want = handle.score_batch(q, None, ext)
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_subjects(None)
+    assert "sweep_mq_kernel" in name, name
+    assert st[0] == len(ext) and st[1] >= len(ext) and st[2] == int((ext["q_len"].astype(np.uint64) * ext["s_len"]).sum())
+    assert 1.0 - st[2] / st[3] < 0.45  # padded share of the executed cells (round 2: 0.57)
+    assert (score == want).all()                                                          # (1)
+    surv = want >= 91
+    assert ((hsp["n_ops"] > 0) == surv).all() and (hsp["score"] == want).all()           # (2)
+    t = hsp[surv]
+    gaps = t["num_gap_opens"].astype(np.int64) + t["num_gap_extensions"]
+    assert (t["n_ops"] == t["num_matches"].astype(np.int64) + t["num_mismatches"] + gaps).all()   # (3)
+    assert ((t["q_end"].astype(np.int64) - t["q_begin"]) + (t["s_end"].astype(np.int64) - t["s_begin"]) ==
+            2 * (t["num_matches"].astype(np.int64) + t["num_mismatches"]) + gaps).all()
+    rng = np.random.default_rng(5)                                                         # (4)
+    sidx = np.nonzero(surv)[0]
+    merged = sidx[ext["s_len"][sidx] > ext["q_len"][sidx] + 2 * (np.sqrt(ext["q_len"][sidx]).astype(np.int64) + 1)]
+    pick = np.unique(np.concatenate([rng.choice(sidx, 2000, replace=False), rng.choice(merged, min(1000, len(merged)), replace=False)]))
+    for i, (oh, oops) in zip(pick, oracle.align_batch(q, s, ext[pick], osc)):
+        g = hsp[i]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, ext[i])
+        a = int(off[i]) + int(g["ops_shift"])
+        assert bytes(ops[a: a + oh.n_ops]) == oops, (i, ext[i])
