@@ -72,6 +72,9 @@ def parse(argv=None):
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
                     "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
+    ap.add_argument("--entry", choices=("bytes", "rle", "list"), default="bytes", help="--host-path / --ragged: lx_extend_batch (ops as column bytes, n "
+                    "records), lx_extend_batch_rle (run-length codes, n records) or lx_extend_batch_list (the survivors as a list, as the "
+                    "reference's filter loop leaves them)")
     ap.add_argument("--survivor-rate", type=float, default=None, help="share of homologous windows in the synthetic batch (default 0.5: "
                     "half of the windows pass the e-value cut-off, far more than a real seed set); 0.02 / 0.1 show the adaptive pass-2 mode "
                     "(LX_OPT_ADAPT_PERMILLE)")
@@ -291,12 +294,16 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
         del d_q, d_s
     h.set_subjects(np.concatenate(s_all))
     cells_rank = sum(float((e["q_len"].astype(np.float64) * e["s_len"]).sum()) for _, _, e in parts)
-    keep = [None] * len(parts)
+    keep, counts = [None] * len(parts), [0] * len(parts)
 
     def step():
         surv = 0
         for i, (slot, q, ext) in enumerate(parts):
-            r = h.extend_batch(q, None, ext, min_score, slot=slot, copy_ops=False, out=keep[i])
+            if args.entry == "list":
+                r = h.extend_batch_list(q, None, ext, min_score, slot=slot, copy=False, out_score=None if keep[i] is None else keep[i][0])
+                keep[i], counts[i] = (r[0], None, None), len(r[1])  # (the list's views die with the next call)
+                continue
+            r = h.extend_batch(q, None, ext, min_score, slot=slot, copy_ops=False, out=keep[i], rle=args.entry == "rle")
             keep[i] = r[:3]  # the caller keeps its result arrays between calls, like lambda's per-thread holders
             surv += int((r[1]["n_ops"] > 0).sum()) if args.steps <= 1 else 0
         return surv
@@ -309,7 +316,7 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
     for _ in range(args.steps):
         step()
     dt = time.perf_counter() - t0
-    survivors = sum(int((k[1]["n_ops"] > 0).sum()) for k in keep)
+    survivors = sum(counts) if args.entry == "list" else sum(int((k[1]["n_ops"] > 0).sum()) for k in keep)
     tot = torch.tensor([dt, cells_rank, float(sum(len(e) for _, _, e in parts)), float(survivors)], dtype=torch.float64, device=dev)
     if use_dist:
         mx = tot.clone()
@@ -331,7 +338,8 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
                        "baseline_config": args.config, "host_path": True, "ragged": bool(args.ragged),
                        "padding": (lambda st: {"extensions": st[0], "slots": st[1], "cells": st[2], "executed_cells": st[3],
                                                "padded_share_of_executed_cells": round(1 - st[2] / max(st[3], 1), 4)})(h.last_extend_stats()),
-                       "entry_point": "lx_extend_batch(host buffers; subjects resident via lx_set_subjects; result arrays kept by the caller)",
+                       "entry_point": {"bytes": "lx_extend_batch", "rle": "lx_extend_batch_rle", "list": "lx_extend_batch_list"}[args.entry] +
+                                      "(host buffers; subjects resident via lx_set_subjects; result arrays kept by the caller)",
                        "extensions_job": int(total_ext), "gcells_job": round(total_cells / 1e9, 3), "survivors_job": int(total_surv),
                        "bytes_up_per_step_rank0": int(up),
                        "bytes_down_per_step_rank0_approx": int(total_ext / world * 4 + total_surv / world * 60),

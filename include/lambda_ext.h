@@ -281,6 +281,28 @@ int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t
                         lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                         lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
 int lx_expand_ops(uint8_t const * codes, int32_t n_ops, uint8_t * out /* n_ops bytes */);
+
+/* The same with the result in the form the reference's filter loop leaves behind: it ERASES the matches that fail the
+ * e-value / bit-score test from its list (src/search_algo.hpp:1251-1283) and goes on with the survivors only (:1287-1385).
+ * out_score[n] as ever (the filter's statistics need every score); the survivors come back as a list -- position in the
+ * caller's list, record, run-length codes as lx_extend_batch_rle -- in buffers that belong to the handle and stay valid
+ * until its next lx_extend_batch* call.  The order of the list is the order the device finished the chunks in (ascending
+ * positions for a list that is grouped by query and uniform; otherwise grouped by chunk): `index` says which row is whose.
+ * This is the fastest host entry point: nothing of size n except the scores is written on the host (lx_extend_batch fills
+ * n records of 48 bytes, which at millions of extensions per call costs as much as the kernels). */
+typedef struct lx_survivor_list
+{
+    uint64_t         count;
+    uint32_t const * index;       /* [count] position in the caller's list                                            */
+    lx_hsp const *   hsp;         /* [count] ops_shift = 0                                                            */
+    uint64_t const * codes_off;   /* [count] the codes of survivor k start at codes + codes_off[k] and end where their
+                                     lengths add up to hsp[k].n_ops                                                   */
+    uint8_t const *  codes;
+    uint64_t         codes_bytes;
+} lx_survivor_list;
+int lx_extend_batch_list(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                         lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                         lx_survivor_list * out);
 /* Padding of the last lx_extend_batch[_rle] call: out4 = {extensions with residues, slots after padding every query's run
  * to 8 / 16, cells (sum q_len * s_len), cells the wavefronts execute (whole panels x the longest window of each block)}. */
 int lx_last_extend_stats(lx_handle const * h, uint64_t * out4);

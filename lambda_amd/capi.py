@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_extend_batch_list", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
     "lx_plan_step",
 ]
 
@@ -95,6 +95,12 @@ class Scoring(C.Structure):
 
 
 EXT_DTYPE = np.dtype([("q_off", "<u8"), ("s_off", "<u8"), ("q_len", "<u4"), ("s_len", "<u4")])
+class SurvivorList(C.Structure):
+    """lx_survivor_list (include/lambda_ext.h)."""
+    _fields_ = [("count", C.c_uint64), ("index", C.c_void_p), ("hsp", C.c_void_p), ("codes_off", C.c_void_p), ("codes", C.c_void_p),
+                ("codes_bytes", C.c_uint64)]
+
+
 HSP_DTYPE = np.dtype([("score", "<i4"), ("q_begin", "<i4"), ("q_end", "<i4"), ("s_begin", "<i4"), ("s_end", "<i4"),
                       ("n_ops", "<i4"), ("num_matches", "<i4"), ("num_mismatches", "<i4"), ("num_positives", "<i4"),
                       ("num_gap_opens", "<i4"), ("num_gap_extensions", "<i4"), ("ops_shift", "<i4")])
@@ -168,6 +174,7 @@ def load():
     lib.lx_set_subjects.argtypes = [vp, vp, u64]
     lib.lx_extend_batch.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp, i32, vp, vp, vp, C.POINTER(vp), C.POINTER(u64)]
     lib.lx_extend_batch_rle.argtypes = lib.lx_extend_batch.argtypes
+    lib.lx_extend_batch_list.argtypes = [vp, i32, vp, u64, vp, u64, vp, u64, vp, i32, vp, C.POINTER(SurvivorList)]
     lib.lx_expand_ops.argtypes = [vp, i32, vp]
     lib.lx_last_extend_stats.argtypes = [vp, vp]
     lib.lx_set_frames.argtypes = [i32, i32, u64, u64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -460,6 +467,30 @@ class Handle:
             return score, hsp, off, np.zeros(1, np.uint8)
         ops = np.ctypeslib.as_array((C.c_uint8 * int(nb.value)).from_address(p.value))
         return score, hsp, off, ops.copy() if copy_ops else ops
+
+    def extend_batch_list(self, q_res, s_res, ext, min_score, slot: int = 0, copy: bool = True, out_score=None):
+        """lx_extend_batch_list: the scores of every extension and the survivors of the filter as a list.  Returns
+        (scores, index, hsp, codes_off, codes): `index[k]` is survivor k's position in `ext`; copy=False gives views of the
+        handle's buffers that the next extend_batch* call invalidates."""
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        s_res = None if s_res is None else np.ascontiguousarray(s_res, dtype=np.uint8)
+        ext = np.ascontiguousarray(ext, dtype=EXT_DTYPE)
+        n = len(ext)
+        per = None if np.isscalar(min_score) else np.ascontiguousarray(min_score, dtype=np.int32)
+        score = out_score if out_score is not None else np.zeros(n, dtype=np.int32)
+        sl = SurvivorList()
+        self._check(self.lib.lx_extend_batch_list(self.h, slot, _ptr(q_res), q_res.size, _sptr(s_res), _ssize(s_res), _ptr(ext), n,
+                                                  None if per is None else _ptr(per), 0 if per is not None else int(min_score),
+                                                  _ptr(score), C.byref(sl)))
+        k = int(sl.count)
+        if not k:
+            return score, np.zeros(0, np.uint32), np.zeros(0, HSP_DTYPE), np.zeros(0, np.uint64), np.zeros(1, np.uint8)
+        view = lambda ptr, dtype, count: np.frombuffer((C.c_uint8 * (count * np.dtype(dtype).itemsize)).from_address(ptr), dtype=dtype, count=count)
+        index, hsp, off = view(sl.index, np.uint32, k), view(sl.hsp, HSP_DTYPE, k), view(sl.codes_off, np.uint64, k)
+        codes = view(sl.codes, np.uint8, max(int(sl.codes_bytes), 1))
+        if copy:
+            index, hsp, off, codes = index.copy(), hsp.copy(), off.copy(), codes.copy()
+        return score, index, hsp, off, codes
 
     def last_extend_stats(self):
         """(extensions, slots, cells, executed cells) of the last extend_batch call."""

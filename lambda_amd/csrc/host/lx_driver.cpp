@@ -237,31 +237,54 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         minScore[i]       = cutOffFor(qLengthOf[i]);
     }
     std::vector<int32_t>  scores(n, 0);
-    std::vector<lx_hsp>   hspAll(n);
-    std::vector<uint64_t> opsOffAll(n);
+    std::vector<lx_hsp>   hspAll;    // band mode only (n records, column bytes)
+    std::vector<uint64_t> opsOffAll;
     uint8_t const *       ops      = nullptr;
     uint64_t              opsBytes = 0;
-    // (the ops arrive as run-length codes -- the form they cross PCIe in -- and only the HSPs that pass the identity cut-off
-    // are expanded into column bytes below; band mode returns column bytes)
+    // (the survivors arrive as a list -- the form the filter loop leaves behind, :1251-1283 -- with their ops as run-length
+    // codes, the form they cross PCIe in; only the HSPs that pass the identity cut-off are expanded into column bytes below.
+    // Band mode returns n records and column bytes)
     uint64_t bandNow = 0;
     (void)lx_get_option(h, LX_OPT_BAND, &bandNow);
-    bool const rle = bandNow == 0;
-    int rc = (rle ? lx_extend_batch_rle : lx_extend_batch)(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0,
-                                                            scores.data(), hspAll.data(), opsOffAll.data(), &ops, &opsBytes);
+    bool const       rle = bandNow == 0;
+    lx_survivor_list list{};
+    int              rc;
+    if (rle)
+        rc = lx_extend_batch_list(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), &list);
+    else
+    {
+        hspAll.resize(n);
+        opsOffAll.resize(n);
+        rc = lx_extend_batch(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), hspAll.data(),
+                             opsOffAll.data(), &ops, &opsBytes);
+    }
     if (rc != LX_OK)
         return rc;
 
     // the filter's statistics (:1260, :1274) from the scores of pass 1
-    std::vector<uint32_t> surv; // indices into `matches`
-    surv.reserve(n);
+    std::vector<uint32_t> surv;   // indices into `matches`
+    std::vector<uint32_t> listAt; // list mode: where match i stands in the survivor list
+    surv.reserve(rle ? list.count : n);
     for (uint64_t i = 0; i < n; ++i)
     {
         if (scores[i] >= minScore[i])
-            surv.push_back((uint32_t)i);
+        {
+            if (!rle)
+                surv.push_back((uint32_t)i);
+        }
         else if (params->min_bitscore >= 0 && computeBitScore(scores[i], params->karlin) < params->min_bitscore)
             ++res->stats.failed_bitscore;
         else
             ++res->stats.failed_evalue;
+    }
+    if (rle)
+    {
+        listAt.assign(n, 0xffffffffu);
+        for (uint64_t k = 0; k < list.count; ++k)
+        {
+            surv.push_back(list.index[k]);
+            listAt[list.index[k]] = (uint32_t)k;
+        }
     }
     if (surv.empty())
         return LX_OK;
@@ -277,7 +300,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     for (uint32_t k : surv)
     {
         lx_match const & m = matches[k];
-        lx_hsp const &   a = hspAll[k];
+        lx_hsp const &   a = rle ? list.hsp[listAt[k]] : hspAll[k];
         lx_blast_match   bm{};
         bm.qry_id  = m.qryId;
         bm.subj_id = m.subjId;
@@ -313,7 +336,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
         bm.e_value   = evalue(a.score, qLengthOf[k]);
         bm.ops_off   = res->ops.size();
         bm.n_ops     = (uint32_t)a.n_ops;
-        uint8_t const * const first = ops + opsOffAll[k] + a.ops_shift;
+        uint8_t const * const first = rle ? list.codes + list.codes_off[listAt[k]] : ops + opsOffAll[k] + a.ops_shift;
         if (rle)
         {
             res->ops.resize(res->ops.size() + (size_t)a.n_ops);

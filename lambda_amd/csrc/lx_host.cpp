@@ -689,8 +689,12 @@ int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
 
 static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                            lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
-                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, bool want_rle)
+                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, int mode)
 {
+    // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
+    // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
+    bool const want_rle = mode >= 1, as_list = mode == 2;
+    h->res_count = 0;
     int rc = bind(h);
     if (rc)
         return rc;
@@ -698,7 +702,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     if ((rc = resolve_subjects(h, s_res, s_bytes, sref)))
         return rc;
     s_bytes = sref.bytes;
-    HostMarks hm(want_rle ? "lx_extend_batch_rle" : "lx_extend_batch");
+    HostMarks hm(as_list ? "lx_extend_batch_list" : want_rle ? "lx_extend_batch_rle" : "lx_extend_batch");
 
     // ---- validate; is the list grouped by query (lambda's lists are sorted by query)?  The loops over the list are spread
     // over a few host threads: at millions of extensions per call they would otherwise cost more than the kernels.
@@ -736,9 +740,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             }
                             if (x.q_len == 0 || x.s_len == 0)
                             {
-                                out_score[i]   = 0;
-                                out_hsp[i]     = lx_hsp{};
-                                out_ops_off[i] = 0;
+                                out_score[i] = 0;
+                                if (!as_list)
+                                {
+                                    out_hsp[i]     = lx_hsp{};
+                                    out_ops_off[i] = 0;
+                                }
                                 continue;
                             }
                             if (prev != ~0ull && x.q_off < ext[prev].q_off)
@@ -1120,9 +1127,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipMemcpyAsync(ln.d_ext.ptr, slot_ext, slots * sizeof(lx_extension), hipMemcpyHostToDevice, h->stream3));
         LX_HIP(h, hipMemcpyAsync(ln.d_min.ptr, slot_min, slots * sizeof(int32_t), hipMemcpyHostToDevice, h->stream3));
         LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
-        // two chunks on the GPU at once: lane 1's kernels on their own stream with the handle's second working set -- the
-        // tail of one chunk's sweep and its latency-bound backtrace run beside the other chunk's sweep
-        hipStream_t const ks = h->stream;
+        hipStream_t const ks = h->stream; // (all chunks' kernels in one stream: side by side they were measured slower, see above)
         LX_HIP(h, hipStreamWaitEvent(ks, ln.ev_up, 0));
         h->opt_max_qlen  = max_q;
         h->opt_max_slen  = max_s;
@@ -1366,6 +1371,67 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         return LX_OK;
     };
 
+    // ---- list form (lx_extend_batch_list): the chunk's survivors are appended to the handle's result buffers -- position in the
+    // caller's list, record, where the codes begin -- and the chunk's codes to h->ext_bytes as one block; of the host's arrays
+    // of size n only the scores are touched
+    auto append_list = [&](int L, uint64_t count, uint64_t nrle, uint32_t const * slot_src /* NULL: the device translated */) -> int
+    {
+        lx_handle::XbLane &    ln    = h->xb[L];
+        lx_hsp const * const   hs    = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
+        uint32_t const * const src   = static_cast<uint32_t const *>(ln.p_src.ptr);
+        uint8_t const * const  codes = static_cast<uint8_t const *>(ln.p_rle.ptr);
+        std::vector<uint64_t>  part(nthreads + 1, 0), untraced(nthreads, ~0ull);
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t k = 0, bad = ~0ull; // (locals: the per-thread slots share cache lines)
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                if (src[e] == 0xffffffffu) // padding of the survivor list
+                                    continue;
+                                if (hs[e].score < 0)
+                                    bad = std::min<uint64_t>(bad, slot_src ? slot_src[src[e]] : src[e]);
+                                else
+                                    ++k;
+                            }
+                            part[t + 1] = k;
+                            untraced[t] = bad;
+                        });
+        for (uint64_t u : untraced)
+            if (u != ~0ull)
+                return fail(h, LX_EOVERFLOW, "extension %llu could not be traced", (unsigned long long)u);
+        for (unsigned t = 0; t < nthreads; ++t)
+            part[t + 1] += part[t];
+        uint64_t const base = h->res_count, total = base + part[nthreads];
+        if (!h->res_index.grow(total * sizeof(uint32_t) + 16) || !h->res_hsp.grow(total * sizeof(lx_hsp) + 16) ||
+            !h->res_off.grow(total * sizeof(uint64_t) + 16) || !h->ext_bytes.grow(ops_total + nrle + 16))
+            return fail(h, LX_ENOMEM, "out of host memory for %llu survivors", (unsigned long long)total);
+        uint32_t * const res_index = reinterpret_cast<uint32_t *>(h->res_index.data());
+        lx_hsp * const   res_hsp   = reinterpret_cast<lx_hsp *>(h->res_hsp.data());
+        uint64_t * const res_off   = reinterpret_cast<uint64_t *>(h->res_off.data());
+        uint8_t * const  dst       = h->ext_bytes.data() + ops_total;
+        parallel_ranges(count, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        {
+                            uint64_t k = base + part[t];
+                            for (uint64_t e = lo; e < hi; ++e)
+                            {
+                                if (src[e] == 0xffffffffu)
+                                    continue;
+                                lx_hsp r     = hs[e];
+                                res_index[k] = slot_src ? slot_src[src[e]] : src[e];
+                                res_off[k]   = ops_total + (uint32_t)r.ops_shift;
+                                r.ops_shift  = 0;
+                                res_hsp[k]   = r;
+                                ++k;
+                            }
+                        });
+        parallel_ranges(nrle, nthreads, [&](unsigned, uint64_t lo, uint64_t hi) { std::memcpy(dst + lo, codes + lo, hi - lo); });
+        h->res_count = total;
+        ops_total += nrle;
+        return LX_OK;
+    };
+
     // ---- results of a multi-query chunk: the survivors' records and ops, addressed by caller index (the device translated the
     // list); the scores of every extension come back once, in caller order, at the end of the call
     auto collect_mq = [&](int L) -> int
@@ -1403,6 +1469,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipStreamSynchronize(h->stream3));
         auto const t1 = now();
         t_wait += ms(t0, t1);
+        if (as_list)
+        {
+            rc2 = append_list(L, count, nrle, nullptr);
+            t_unpack += ms(t1, now());
+            return rc2;
+        }
         lx_hsp const * const   hs       = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
         uint32_t const * const src_orig = static_cast<uint32_t const *>(ln.p_src.ptr);
         uint8_t const * const  codes    = static_cast<uint8_t const *>(ln.p_rle.ptr);
@@ -1509,6 +1581,19 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint8_t const * const  codes   = static_cast<uint8_t const *>(ln.p_rle.ptr);
         uint32_t const * const code_len = static_cast<uint32_t const *>(ln.p_len.ptr);
         uint32_t const * const slot_src = pr.slot_src.data();
+        if (as_list)
+        {
+            parallel_ranges(pr.slots, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t o = lo; o < hi; ++o)
+                                    if (slot_src[o] != 0xffffffffu)
+                                        out_score[slot_src[o]] = sc[o];
+                            });
+            rc2 = append_list(L, count, nrle, slot_src);
+            t_unpack += ms(t1, now());
+            return rc2;
+        }
         // (1) per survivor: how many bytes its ops take in the handle's buffer (column bytes, or the codes themselves),
         //     and which list position a slot has
         std::vector<uint64_t> & pos_off  = h->xb_off;
@@ -1698,7 +1783,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 return rc;
             if ((rc = enqueue_mq(L, o0, o1)))
                 return rc;
-            if (!rows_cleared)
+            if (!rows_cleared && !as_list)
             {
                 // (beside the first chunk's kernels) every row starts as "no alignment"; the survivors' rows are written by
                 // collect_mq, the scores of all rows at the end of the call
@@ -1732,7 +1817,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 for (uint64_t i = lo; i < hi; ++i)
                                 {
                                     out_score[i] = sa[i];
-                                    if (out_hsp[i].n_ops == 0)
+                                    if (!as_list && out_hsp[i].n_ops == 0)
                                         out_hsp[i].score = sa[i];
                                 }
                             });
@@ -1779,8 +1864,13 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     if (hm.on)
         fprintf(stderr, "[lx host ms]   pipeline of %d chunks: prepare %.1f, issue %.1f, wait for the GPU %.1f, unpack %.1f (lengths %.1f, offsets %.1f)\n", c, t_prep, t_issue,
                 t_wait, t_unpack, t_u1, t_u2);
-    *out_ops       = h->ext_bytes.data();
-    *out_ops_bytes = ops_total;
+    if (as_list)
+        h->xb_ops_total = ops_total;
+    else
+    {
+        *out_ops       = h->ext_bytes.data();
+        *out_ops_bytes = ops_total;
+    }
     return LX_OK;
 }
 
@@ -1806,7 +1896,7 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
         return host_banded(h, slot, 2, q_res, q_bytes, s_res, s_bytes, ext, n, nullptr, min_score, min_score_all, out_score, out_hsp, nullptr,
                            nullptr, out_ops_off, out_ops, out_ops_bytes);
     return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
-                           out_ops_bytes, false);
+                           out_ops_bytes, 0);
 }
 
 int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
@@ -1830,7 +1920,38 @@ int lx_extend_batch_rle(lx_handle * h, int slot, uint8_t const * q_res, uint64_t
     if (h->opt_band)
         return fail(h, LX_EINVAL, "lx_extend_batch_rle: band mode returns column bytes only (lx_extend_batch)");
     return extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, out_hsp, out_ops_off, out_ops,
-                           out_ops_bytes, true);
+                           out_ops_bytes, 1);
+}
+
+int lx_extend_batch_list(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                         lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                         lx_survivor_list * out)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (out)
+        *out = lx_survivor_list{};
+    if (n == 0)
+        return LX_OK;
+    if (!ext || !out_score || !out || (!q_res && q_bytes))
+        return fail(h, LX_EINVAL, "NULL argument");
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    if (h->opt_band)
+        return fail(h, LX_EINVAL, "lx_extend_batch_list: band mode returns column bytes only (lx_extend_batch)");
+    int const rc = extend_pipeline(h, slot, q_res, q_bytes, s_res, s_bytes, ext, n, min_score, min_score_all, out_score, nullptr, nullptr, nullptr,
+                                   nullptr, 2);
+    if (rc != LX_OK)
+        return rc;
+    out->count       = h->res_count;
+    out->index       = reinterpret_cast<uint32_t const *>(h->res_index.data());
+    out->hsp         = reinterpret_cast<lx_hsp const *>(h->res_hsp.data());
+    out->codes_off   = reinterpret_cast<uint64_t const *>(h->res_off.data());
+    out->codes       = h->ext_bytes.data();
+    out->codes_bytes = h->res_count ? h->xb_ops_total : 0;
+    return LX_OK;
 }
 
 int lx_last_extend_stats(lx_handle const * h, uint64_t * out4)

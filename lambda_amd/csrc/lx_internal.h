@@ -113,7 +113,11 @@ struct lx_handle
             return true;
         }
         ~Bytes() { std::free(p); }
-    } ext_bytes;
+    };
+    Bytes ext_bytes;
+    // lx_extend_batch_list: the survivors of the last call (positions in the caller's list, records, where their codes begin)
+    Bytes    res_index, res_hsp, res_off;
+    uint64_t res_count = 0, xb_ops_total = 0;
     // lx_extend_batch's two chunks in flight: pinned staging, device buffers, events
     struct Pinned
     {
