@@ -1,4 +1,5 @@
-"""Randomised parity stress of the fused step on host buffers (lx_extend_batch) against the CPU oracle: random query
+"""Randomised parity stress of the fused step on host buffers (lx_extend_batch) against the CPU oracle (every third case also through
+lx_extend_batch_list): random query
 lengths (all sweep geometries and the fall-backs), run lengths, schemes, gap costs, mutation rates, truncated / empty
 windows, cut-offs and pass-2 modes.  Development aid: `python tools/stress_parity.py SECONDS [SEED [MAX_QUERY_LENGTH [MIN_QUERY_LENGTH]]]` on a GPU box; the
 committed parity tests are tests/test_gpu_*.py."""
@@ -69,6 +70,19 @@ while time.time() - t0 < budget:
                bytes(ops[int(off[i]) + int(g["ops_shift"]): int(off[i]) + int(g["ops_shift"]) + oh.n_ops]) != oops:
                 ok = False
                 print("ALIGN MISMATCH", i, ext[i], tuple(g), (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops))
+                break
+    if ok and case % 3 == 0:
+        # the list form of the same call: the same scores, exactly the survivors, the same records, codes that expand to the same ops
+        score_l, index, hsp_l, off_l, codes = h.extend_batch_list(q, s, ext, cutoff)
+        live = np.nonzero((want >= cutoff) & (ext["s_len"] > 0) & (ext["q_len"] > 0))[0]
+        ok = (score_l == want).all() and len(index) == len(live) and (np.sort(index) == live).all()
+        for k in (range(len(index)) if ok else ()):
+            i, g = int(index[k]), hsp[int(index[k])]
+            same = all(hsp_l[f][k] == g[f] for f in ("score", "q_begin", "q_end", "s_begin", "s_end", "n_ops", "num_matches", "num_gap_opens"))
+            st = int(off[i]) + int(g["ops_shift"])
+            if not same or capi.Handle.expand_ops(codes[int(off_l[k]): int(off_l[k]) + int(g["n_ops"])], int(g["n_ops"])) != bytes(ops[st: st + int(g["n_ops"])]):
+                ok = False
+                print("LIST MISMATCH", i, ext[i], tuple(g), tuple(hsp_l[k]))
                 break
     if not ok:
         bad += 1
