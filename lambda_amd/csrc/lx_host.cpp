@@ -1693,10 +1693,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     int      c  = 0;
     if (use_mq)
     {
-        // chunks = ranges of the sorted sub-blocks, about chunk_target slots, whole wavefronts; a change of the panel count
-        // starts a new chunk only when both sides fill the chip a few times (a chunk's slots are sized for its widest query;
-        // a launch of a few hundred wavefronts costs its latency)
-        uint64_t const per_chunk = std::max<uint64_t>(4, chunk_target / kSub / 4 * 4), min_chunk = std::min<uint64_t>(per_chunk, 16384);
+        // chunks = ranges of the sorted sub-blocks, about chunk_target slots, whole wavefronts.  A chunk may span panel counts
+        // (its slots are sized for its widest query, its narrower queries run the multi-panel kernel over one panel): a chunk
+        // boundary wherever the panel count changes was measured on the ragged list of bench.py and costs more than it saves
+        // -- 3 chunks 20.8 ms, 2 chunks 18.9 ms: every chunk pays the fixed cost of a backtrace launch (~0.5-1 ms), the
+        // single-panel kernel saves a tenth of a 0.8 ms sweep
+        uint64_t const per_chunk = std::max<uint64_t>(4, chunk_target / kSub / 4 * 4);
         h->xb_stats[2] = mq_cells;
         // the caller's list and cut-offs onto the device (pinned staging, filled by the pool), scores in caller order zeroed
         {
@@ -1752,32 +1754,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 cap_sb                = std::max<uint64_t>(4, std::min(per_chunk, fit / 4 * 4));
             }
             uint64_t       o1   = std::min(nsb, o0 + cap_sb);
-            auto first_not = [&](uint64_t lo, uint64_t hi, auto same) // first position in (lo, hi] whose class differs (same(lo) holds)
-            {
-                if (same(hi - 1))
-                    return hi;
-                --hi;
-                while (hi - lo > 1)
-                {
-                    uint64_t const mid = lo + (hi - lo) / 2;
-                    (same(mid) ? lo : hi) = mid;
-                }
-                return hi;
-            };
-            // panel-count boundaries inside [o0, o1): cut at the first one that leaves a chunk of at least min_chunk sub-blocks
-            for (uint64_t at = o0;;)
-            {
-                uint32_t const c_at = sb_key[sb_order[at]] >> 16;
-                uint64_t const nx   = first_not(at, o1, [&](uint64_t o) { return (sb_key[sb_order[o]] >> 16) == c_at; });
-                if (nx >= o1)
-                    break;
-                if (nx - o0 >= min_chunk && o1 - nx >= min_chunk) // (neither side becomes a launch of a few hundred wavefronts)
-                {
-                    o1 = nx;
-                    break;
-                }
-                at = nx;
-            }
             int const L = c & 1;
             if (in_flight[L] && (rc = collect_mq(L)))
                 return rc;
