@@ -505,6 +505,51 @@ int lx_write_records(char const * path, int format, int write_header, char const
                      uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                      uint64_t const * q_ascii_off);
 
+/* The output options of the reference's command line (src/search_options.hpp:224-379, parsed :716-816): which tabular columns,
+ * which optional SAM tags, whether a SAM record carries the sequence and how it clips.  Initialise with
+ * lx_output_options_default (= the reference's defaults: the 12 standard columns; tags "AS NM ae ai qf"; sequence "uniq";
+ * hard clips; no @SQ lines), then change what the caller asked for. */
+enum
+{
+    LX_SAM_SEQ_NEVER  = 0, /* --sam-bam-seq never  (:765-770) */
+    LX_SAM_SEQ_UNIQ   = 1, /*               uniq: omitted iff frame and query range equal the previous match's (:536-553) */
+    LX_SAM_SEQ_ALWAYS = 2
+};
+typedef struct lx_output_options
+{
+    char const * columns;             /* --output-columns: space-separated NCBI specifiers; NULL = "std".  Supported: std qseqid
+                                         qlen sseqid slen qstart qend sstart send evalue bitscore score length pident nident
+                                         mismatch positive gapopen gaps ppos frames qframe sframe staxids lcataxid            */
+    char const * sam_tags;            /* --sam-bam-tags: space-separated keys of SamBamExtraTags (src/search_output.hpp:29-76):
+                                         AS OC NM IH ar ae ai ap qf qs sf st ls lt; NULL = "AS NM ae ai qf" (:351)            */
+    int32_t      sam_seq;             /* LX_SAM_SEQ_*                                                                         */
+    int32_t      sam_hard_clip;       /* --sam-bam-clip hard (1, default) | soft (0)                                          */
+    int32_t      sam_with_ref_header; /* --sam-with-refheader: one @SQ line per subject (:276-286)                            */
+    int32_t      version_to_output;   /* --version-to-outputfile: `version` into the tabular version line / an @PG line       */
+    char const * version;             /* (the reference writes SEQAN_APP_VERSION; this library has no lambda version: the
+                                         caller names one)                                                                    */
+    char const * command_line;        /* @PG CL: (src/search_output.hpp:391-399)                                              */
+    char const * db_name;             /* "# Database:" of .m9 -- the reference writes the index path (search_algo.hpp:320)    */
+    int32_t      genetic_code;        /* translated queries: the table the frames were made with (tags qs / OC)               */
+    int32_t      reserved;
+    /* taxonomy columns (staxids / st, lcataxid / lt, ls): NULL = "*" / 0, as for an index without taxonomy */
+    lx_tax_tree const *  tax;
+    uint64_t const *     lca_qid;     /* lx_compute_lca's output: n_lca (n_qid, taxon) pairs in list order                    */
+    uint32_t const *     lca_tax;
+    uint64_t             n_lca;
+    char const * const * tax_names;   /* scientific name per taxon (tag ls), NULL = "*"                                       */
+} lx_output_options;
+void lx_output_options_default(lx_output_options * o);
+/* lx_write_records with options (NULL = defaults).  LX_EINVAL also for an unknown column specifier or tag key (the reference
+ * throws "Unknown column specifier", :755-758, :803-806); lx_last_output_error() has the text. */
+int lx_write_records_ex(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
+                        uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
+                        uint64_t const * q_ascii_off, lx_output_options const * opt);
+/* myWriteFooter (src/search_output.hpp:739-750): .m9 ends with "# BLAST processed N queries" (N = records written), the other
+ * formats have no footer. */
+int lx_write_footer(char const * path, int format, uint64_t n_records);
+char const * lx_last_output_error(void);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 /* Blocks until everything queued on the handle's stream has finished. */
 int lx_synchronize(lx_handle * h);

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_extend_batch_list", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_extend_batch_list", "lx_write_records_ex", "lx_write_footer", "lx_output_options_default", "lx_last_output_error", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
     "lx_plan_step",
 ]
 
@@ -201,6 +201,11 @@ def load():
     lib.lx_postprocess_records.argtypes = [vp, u64, u64, C.POINTER(RecordStats)]
     lib.lx_postprocess_records.restype = u64
     lib.lx_write_records.argtypes = [C.c_char_p, i32, i32, C.c_char_p, vp, u64, vp, C.POINTER(SeqNames), vp, vp]
+    lib.lx_write_records_ex.argtypes = [C.c_char_p, i32, i32, C.c_char_p, vp, u64, vp, C.POINTER(SeqNames), vp, vp, C.POINTER(OutputOptions)]
+    lib.lx_write_footer.argtypes = [C.c_char_p, i32, u64]
+    lib.lx_output_options_default.argtypes = [C.POINTER(OutputOptions)]
+    lib.lx_output_options_default.restype = None
+    lib.lx_last_output_error.restype = C.c_char_p
     lib.lx_compute_lca.argtypes = [vp, u64, C.POINTER(TaxTree), vp, vp, C.POINTER(u64)]
     _lib = lib
     return lib
@@ -231,8 +236,38 @@ def postprocess_records(bms: np.ndarray, max_matches: int = 25):
     return m[: int(n)], st
 
 
+class OutputOptions(C.Structure):
+    """lx_output_options (include/lambda_ext.h): the reference's output options, src/search_options.hpp:224-379."""
+    _fields_ = [("columns", C.c_char_p), ("sam_tags", C.c_char_p), ("sam_seq", C.c_int32), ("sam_hard_clip", C.c_int32),
+                ("sam_with_ref_header", C.c_int32), ("version_to_output", C.c_int32), ("version", C.c_char_p), ("command_line", C.c_char_p),
+                ("db_name", C.c_char_p), ("genetic_code", C.c_int32), ("reserved", C.c_int32), ("tax", C.c_void_p), ("lca_qid", C.c_void_p),
+                ("lca_tax", C.c_void_p), ("n_lca", C.c_uint64), ("tax_names", C.c_void_p)]
+
+
+LX_SAM_SEQ_NEVER, LX_SAM_SEQ_UNIQ, LX_SAM_SEQ_ALWAYS = 0, 1, 2
+
+
+def output_options(**kw) -> OutputOptions:
+    """lx_output_options_default, then the given fields (str values are encoded)."""
+    o = OutputOptions()
+    load().lx_output_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v.encode() if isinstance(v, str) else v)
+    return o
+
+
+def last_output_error() -> str:
+    return (load().lx_last_output_error() or b"").decode()
+
+
+def write_footer(path, fmt: int, n_records: int):
+    rc = load().lx_write_footer(str(path).encode(), fmt, C.c_uint64(n_records))
+    if rc != LX_OK:
+        raise LambdaExtError(rc, "lx_write_footer")
+
+
 def write_records(path, fmt: int, bms: np.ndarray, ops: bytes, q_ids, q_lens, s_ids, s_lens, program="blastp",
-                  write_header=True, q_ascii: bytes | None = None, q_ascii_off=None):
+                  write_header=True, q_ascii: bytes | None = None, q_ascii_off=None, options: OutputOptions | None = None):
     m = np.ascontiguousarray(bms, dtype=BLAST_MATCH_DTYPE)
     qa = (C.c_char_p * len(q_ids))(*[x.encode() for x in q_ids])
     sa = (C.c_char_p * len(s_ids))(*[x.encode() for x in s_ids])
@@ -242,11 +277,11 @@ def write_records(path, fmt: int, bms: np.ndarray, ops: bytes, q_ids, q_lens, s_
     o = np.frombuffer(ops + b"\0", dtype=np.uint8)
     qasc = np.frombuffer(q_ascii, dtype=np.uint8) if q_ascii else None
     qoff = np.ascontiguousarray(q_ascii_off, dtype=np.uint64) if q_ascii_off is not None else None
-    rc = load().lx_write_records(str(path).encode(), fmt, 1 if write_header else 0, program.encode(), _ptr(m), len(m),
-                                 _ptr(o), C.byref(names), _ptr(qasc) if qasc is not None else None,
-                                 _ptr(qoff) if qoff is not None else None)
+    rc = load().lx_write_records_ex(str(path).encode(), fmt, 1 if write_header else 0, program.encode(), _ptr(m), len(m), _ptr(o),
+                                    C.byref(names), _ptr(qasc) if qasc is not None else None, _ptr(qoff) if qoff is not None else None,
+                                    C.byref(options) if options is not None else None)
     if rc != LX_OK:
-        raise LambdaExtError(rc, "lx_write_records")
+        raise LambdaExtError(rc, "lx_write_records: " + last_output_error())
 
 
 class StepPlan(C.Structure):

@@ -5,8 +5,12 @@
 //                   [--devices 0,1,...] [-t THREADS]
 //
 // What it mirrors from the reference, and what it does not:
-//   * subcommand split and the handful of options of the hot path (src/lambda.cpp:30-118; src/search_options.hpp:88-107,
-//     :290-337): -q, -o (format from the extension, :684-710), -e, -n, --seed-length, --seed-offset;
+//   * subcommand split and the search command line (src/lambda.cpp:30-118; src/search_options.hpp:143-816): -q, -o (format from
+//     the extension, :684-710), -e, --bit-score, --percent-identity, -n, the seeding options (--seed-length/-offset/-delta[0],
+//     --search0, --adaptive-seeding, --seed-half-exact), --pre-scoring[-threshold], the scoring options (-s 45|62|80 for
+//     proteins, --score-match/-mismatch for nucleotides, --score-gap, --score-gap-open), the profiles (-p fast | sensitive |
+//     pairs-default | pairs-sensitive: they overwrite the seeding options, :634-681), the output options (--output-columns,
+//     --sam-bam-tags/-seq/-clip, --sam-with-refheader, --version-to-outputfile), -g, --input-alphabet;
 //   * the thread split of realMain (src/search.cpp:379-385): -t worker threads (default: one per device of --devices, default
 //     all visible devices), each with its own handle -- one LocalDataHolder per thread there, one lx_handle = device + stream
 //     here --, the queries dealt to them in contiguous ranges, the records concatenated in range order before _writeRecord;
@@ -189,6 +193,16 @@ struct Options
     int         preScoring  = 2;    // :104
     double      preScoringThresh = 2.0;
     int         idCutOff    = 0;
+    int         minBitScore = -1;   // :96, --bit-score
+    int         seedDelta0  = 0;    // searchOpts0.maxSeedDist (:314, :322, :331)
+    std::string profile     = "none"; // :107, -p
+    int         scoringMethod = 62; // :89, -s (searchp)
+    int         match = 2, misMatch = -3; // :93-94 (searchn / searchbs)
+    int         gapOpen = -11, gapExtend = -1; // :91-92; -5 / -2 outside the protein domain (:293-294)
+    // output (:224-379): columns of .m8 / .m9, tags / sequence / clipping of .sam
+    std::string outputColumns = "std", samTags = "AS NM ae ai qf", samSeq = "uniq", samClip = "hard";
+    bool        samWithRefHeader = false, versionToOutput = true;
+    std::string commandLine;
     std::vector<int> devices;         // --devices (default: every visible device)
     int         threads     = 0;    // -t (default: one per device)
     std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
@@ -235,6 +249,26 @@ Options parse(int argc, char ** argv)
     o.preScoringThresh = prot ? 2.0 : bs ? 1.5 : 1.4;
     if (bs)
         o.maxEValue = 1e-9;
+    if (!prot)
+        o.gapOpen = -5, o.gapExtend = -2;
+    for (int i = 1; i < argc; ++i) // (the reference keeps the command line from the subcommand on, :106-109)
+        o.commandLine += std::string(i > 1 ? " " : "") + argv[i];
+    auto onOff = [](std::string const & v) // sharg's bool options take 0 / 1 / true / false; the help pages write ON / OFF
+    {
+        std::string u;
+        for (char c : v)
+            u += (char)std::toupper((unsigned char)c);
+        if (u == "1" || u == "TRUE" || u == "ON")
+            return true;
+        if (u == "0" || u == "FALSE" || u == "OFF")
+            return false;
+        throw std::runtime_error("expected 0 / 1 / true / false / ON / OFF, got " + v);
+    };
+    auto inRange = [](std::string const & name, double v, double lo, double hi)
+    {
+        if (v < lo || v > hi)
+            throw std::runtime_error("Value " + std::to_string(v) + " of option " + name + " is not in range [" + std::to_string(lo) + "," + std::to_string(hi) + "].");
+    };
     for (int i = 2; i < argc; ++i)
     {
         std::string a = argv[i];
@@ -264,12 +298,69 @@ Options parse(int argc, char ** argv)
             o.seedLength0 = std::stoi(val());
         else if (a == "--seed-offset0")
             o.seedOffset0 = std::stoi(val());
+        else if (a == "--seed-delta0")
+            o.seedDelta0 = std::stoi(val());
         else if (a == "--search0")
-            o.search0 = std::stoi(val()) != 0;
+            o.search0 = onOff(val());
         else if (a == "--adaptive-seeding")
-            o.adaptive = std::stoi(val()) != 0;
+            o.adaptive = onOff(val());
         else if (a == "--seed-half-exact")
-            o.halfExact = std::stoi(val()) != 0;
+            o.halfExact = onOff(val());
+        else if (a == "--pre-scoring") // (the validator's range is 1..10, :488-497; 0 = off is what the description offers)
+        {
+            o.preScoring = std::stoi(val());
+            inRange(a, o.preScoring, 0, 10);
+        }
+        else if (a == "--pre-scoring-threshold")
+        {
+            o.preScoringThresh = std::stod(val());
+            inRange(a, o.preScoringThresh, 0, 20);
+        }
+        else if (a == "--bit-score")
+        {
+            o.minBitScore = std::stoi(val());
+            inRange(a, o.minBitScore, -1, 1000);
+        }
+        else if ((a == "-s" || a == "--scoring-scheme") && prot) // :510-521
+        {
+            o.scoringMethod = std::stoi(val());
+            if (o.scoringMethod != 45 && o.scoringMethod != 62 && o.scoringMethod != 80)
+                throw std::runtime_error("--scoring-scheme takes 45, 62 or 80");
+        }
+        else if (a == "--score-match" && !prot) // :523-540
+            o.match = std::stoi(val());
+        else if (a == "--score-mismatch" && !prot)
+            o.misMatch = std::stoi(val());
+        else if (a == "--score-gap")
+            o.gapExtend = std::stoi(val());
+        else if (a == "--score-gap-open")
+            o.gapOpen = std::stoi(val());
+        else if (a == "-p" || a == "--profile")
+        {
+            o.profile = val();
+            if (o.profile != "none" && o.profile != "fast" && o.profile != "sensitive" && o.profile != "pairs-default" && o.profile != "pairs-sensitive")
+                throw std::runtime_error("--profile takes none, fast, sensitive, pairs-default or pairs-sensitive");
+        }
+        else if (a == "--output-columns")
+            o.outputColumns = val();
+        else if (a == "--sam-bam-tags")
+            o.samTags = val();
+        else if (a == "--sam-bam-seq")
+        {
+            o.samSeq = val();
+            if (o.samSeq != "always" && o.samSeq != "uniq" && o.samSeq != "never")
+                throw std::runtime_error("--sam-bam-seq takes always, uniq or never");
+        }
+        else if (a == "--sam-bam-clip")
+        {
+            o.samClip = val();
+            if (o.samClip != "hard" && o.samClip != "soft")
+                throw std::runtime_error("--sam-bam-clip takes hard or soft");
+        }
+        else if (a == "--sam-with-refheader")
+            o.samWithRefHeader = onOff(val());
+        else if (a == "--version-to-outputfile")
+            o.versionToOutput = onOff(val());
         else if (a == "-r" || a == "--alphabet-reduction")
         {
             o.reduction = val();
@@ -302,21 +393,47 @@ Options parse(int argc, char ** argv)
             if (o.dbAlphabet != "auto" && o.dbAlphabet != "dna5" && o.dbAlphabet != "aminoacid")
                 throw std::runtime_error("--db-alphabet takes auto, dna5 or aminoacid");
         }
-        else if (a == "-a" || a == "--query-alphabet")
+        else if (a == "-a" || a == "--query-alphabet" || a == "--input-alphabet") // (the reference's name is --input-alphabet, :172-185)
         {
             o.qryAlphabet = val();
             if (o.qryAlphabet != "auto" && o.qryAlphabet != "dna5" && o.qryAlphabet != "aminoacid")
                 throw std::runtime_error("--query-alphabet takes auto, dna5 or aminoacid");
         }
-        else if (a == "-v" || a == "--verbosity" || a == "--version-to-outputfile" || a == "-p" ||
-                 a == "--profile")
+        else if (a == "-v" || a == "--verbosity" || a == "--lazy-query")
             (void)val(); // accepted for command-line compatibility, no effect here
         else
             throw std::runtime_error("unknown option " + a);
     }
     if (o.query.empty() || o.db.empty())
         throw std::runtime_error("-q and -d are required");
-    if (o.seedLength < 2 || o.seedLength0 < 2 || o.seedOffset < 1 || o.seedOffset0 < 1 || o.seedDelta < 0)
+    // "Setting a profile other than none always overwrites manually given command line arguments" (:563-566, applied :634-681)
+    if (o.profile == "fast")
+    {
+        if (!prot)
+        {
+            o.search0   = false;
+            o.seedDelta = 0;
+            if (!bs)
+                o.seedOffset = 9;
+        }
+        else
+            o.seedLength0 = 12, o.seedOffset0 = 8, o.seedLength = 10, o.seedOffset = 5, o.seedDelta = 0;
+    }
+    else if (o.profile != "none") // sensitive, pairs-default, pairs-sensitive
+    {
+        if (prot)
+            o.seedLength0 = 9, o.seedOffset0 = 4, o.seedLength = 8, o.seedOffset = 3, o.preScoring = 3, o.preScoringThresh = 1.9;
+        else if (bs)
+            o.seedLength0 = 16, o.seedOffset0 = 8, o.seedLength = 15, o.seedOffset = 10;
+        else
+            o.seedOffset0 = 3, o.seedOffset = 3;
+        if (o.profile.rfind("pairs", 0) == 0)
+            o.search0 = false;
+        if (o.profile == "pairs-sensitive")
+            --o.seedLength;
+    }
+    if (o.seedLength < 2 || o.seedLength0 < 2 || o.seedOffset < 1 || o.seedOffset0 < 1 || o.seedDelta < 0 || o.seedDelta > 3 || o.seedDelta0 < 0 ||
+        o.seedDelta0 > 5)
         throw std::runtime_error("seed length / offset / delta out of range");
     return o;
 }
@@ -347,12 +464,12 @@ int main(int argc, char ** argv)
         // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234): bisulfite = two matrices over SeqAn Dna5
         // (forward: slot 0, reverse: slot 1, :176-186), statistics from the match / mismatch scheme
         lx_scoring sc, scRev;
-        int const  gapOpen = prot ? -11 : -5, gapExtend = prot ? -1 : -2;
-        lambda_amd::builtinScoring(prot ? 62 : bs ? -1 : 0, 2, -3, gapOpen, gapExtend, sc);
+        int const  gapOpen = opt.gapOpen, gapExtend = opt.gapExtend;
+        lambda_amd::builtinScoring(prot ? opt.scoringMethod : bs ? -1 : 0, opt.match, opt.misMatch, gapOpen, gapExtend, sc);
         if (bs)
-            lambda_amd::builtinScoring(-2, 2, -3, gapOpen, gapExtend, scRev);
+            lambda_amd::builtinScoring(-2, opt.match, opt.misMatch, gapOpen, gapExtend, scRev);
         lx_karlin ka;
-        if (!lambda_amd::karlinParams(prot ? 62 : 0, 2, -3, gapOpen, gapExtend, ka))
+        if (!lambda_amd::karlinParams(prot ? opt.scoringMethod : 0, opt.match, opt.misMatch, gapOpen, gapExtend, ka))
             throw std::runtime_error("Could not compute Karlin-Altschul-Values for Scoring Scheme."); // :232-233
 
         // ---- devices and worker threads (src/search.cpp:379-385: one LocalDataHolder per thread; here one handle per thread)
@@ -413,7 +530,7 @@ int main(int argc, char ** argv)
             dbTotal += l;
         lx_search_params sp{};
         sp.max_evalue       = opt.maxEValue;
-        sp.min_bitscore     = -1;
+        sp.min_bitscore     = opt.minBitScore;
         sp.id_cutoff        = opt.idCutOff;
         sp.db_total_length  = dbTotal;
         sp.query_translated = blastx ? 1 : 0;
@@ -424,7 +541,7 @@ int main(int argc, char ** argv)
         sp.s_frame_mode     = bs ? LX_FRAMES_BISULFITE : sTrans ? LX_FRAMES_TRANSLATED : LX_FRAMES_NONE;
         sp.karlin           = ka;
 
-        lambda_amd::SeedParams const so1{opt.seedLength, opt.seedOffset, opt.seedDelta}, so0{opt.seedLength0, opt.seedOffset0, 0};
+        lambda_amd::SeedParams const so1{opt.seedLength, opt.seedOffset, opt.seedDelta}, so0{opt.seedLength0, opt.seedOffset0, opt.seedDelta0};
         // what a worker keeps for its range of reads
         struct Part
         {
@@ -565,9 +682,23 @@ int main(int argc, char ** argv)
         else if (!ends(".m8"))
             throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
         {
-            int const rcw = lx_write_records(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
-                                             reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data());
+            lx_output_options oo;
+            lx_output_options_default(&oo);
+            oo.columns             = opt.outputColumns.c_str();
+            oo.sam_tags            = opt.samTags.c_str();
+            oo.sam_seq             = opt.samSeq == "never" ? LX_SAM_SEQ_NEVER : opt.samSeq == "uniq" ? LX_SAM_SEQ_UNIQ : LX_SAM_SEQ_ALWAYS;
+            oo.sam_hard_clip       = opt.samClip == "hard";
+            oo.sam_with_ref_header = opt.samWithRefHeader;
+            oo.version_to_output   = opt.versionToOutput;
+            oo.version             = "3.0.0-lx"; // (the reference release this front end follows, src/CMakeLists.txt:14-19)
+            oo.command_line        = opt.commandLine.c_str();
+            oo.db_name             = opt.db.c_str(); // the index path there (src/search_algo.hpp:320)
+            oo.genetic_code        = opt.geneticCode;
+            int const rcw = lx_write_records_ex(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
+                                                reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data(), &oo);
             if (rcw != LX_OK)
+                throw std::runtime_error(*lx_last_output_error() ? lx_last_output_error() : ("cannot write " + opt.output).c_str());
+            if (lx_write_footer(opt.output.c_str(), fmt, rst.qrys_with_hit) != LX_OK) // myWriteFooter, src/search.cpp
                 throw std::runtime_error("cannot write " + opt.output);
         }
 

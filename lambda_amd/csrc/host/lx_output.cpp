@@ -4,9 +4,12 @@
 //   _writeRecord          /root/reference/src/search_algo.hpp:820-913   (sort, dedupe, bit-score order, top-N)
 //   myWriteHeader         src/search_output.hpp:305-461
 //   myWriteRecord         src/search_output.hpp:463-733                  (tabular via seqan::writeRecord; SAM records)
-//   blastMatchOneCigar    src/search_output.hpp:115-194                  (soft clips, no frame clips for untranslated)
-// Scope: BLASTP, BLASTN in all formats; BLASTX / TBLASTN / TBLASTX in the tabular formats (nucleotide coordinates).  The number formats of the tabular columns are SeqAn2's
-// (source absent): [UPSTREAM-RECALL] pident %.2f, evalue %.1e, bitscore %.1f, 1-based inclusive positions.
+//   blastMatchOneCigar    src/search_output.hpp:115-194                  (hard or soft clips, frame clips always hard)
+//   blastMatchTwoCigar    src/search_output.hpp:197-298                  (the protein-space cigar of tag OC)
+//   the output options    src/search_options.hpp:224-379, :716-816       (lx_output_options: columns, SAM tags, sequence, clipping)
+// Scope: every program in the tabular formats and in SAM; not BAM and not the pairwise .m0 report (seqan's writers, absent).  The
+// number formats of the tabular columns are SeqAn2's (source absent): [UPSTREAM-RECALL] pident %.2f, evalue %.1e, bitscore %.1f,
+// 1-based inclusive positions.
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -18,6 +21,7 @@
 #include <vector>
 
 #include "../../../include/lambda_ext.h"
+#include "scoring_tables.hpp"
 
 namespace
 {
@@ -102,6 +106,147 @@ std::string cigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen
     for (auto const & e : el)
         c += std::to_string(e.second) + e.first;
     return c;
+}
+
+// The protein-space cigar of tag OC: blastMatchOneCigar for a protein query (transFac 1, no frame clips: BLASTP / TBLASTN,
+// src/search_output.hpp:517-521) and the protCigar half of blastMatchTwoCigar for a translated one (:197-298: clips in
+// protein space, hard or soft like the DNA cigar, never reversed).
+std::string protCigarOf(lx_blast_match const & m, uint8_t const * ops, uint64_t qLen, bool hardClip, bool qTrans)
+{
+    uint64_t const leftFrameClip = (uint64_t)std::abs((int)m.q_frame) - (m.q_frame != 0 ? 1 : 0);
+    uint64_t const frameLen      = qTrans ? (qLen - leftFrameClip) / 3 : qLen;
+    uint64_t const leftClip = m.q_start, rightClip = frameLen >= m.q_end ? frameLen - m.q_end : 0;
+    std::string    c;
+    auto           add = [&](char op, uint64_t cnt)
+    {
+        if (cnt)
+            c += std::to_string(cnt) + op;
+    };
+    add(hardClip ? 'H' : 'S', leftClip);
+    uint8_t const * o = ops + m.ops_off;
+    for (uint32_t i = 0; i < m.n_ops;)
+    {
+        if (o[i] != 'D' && o[i] != 'I' && o[i] != 'M')
+            return "*";
+        uint32_t const i0 = i;
+        while (i < m.n_ops && o[i] == o[i0])
+            ++i;
+        add((char)o[i0], i - i0);
+    }
+    add(hardClip ? 'H' : 'S', rightClip);
+    return c.empty() ? "*" : c;
+}
+
+thread_local std::string g_output_error;
+
+// SamBamExtraTags, src/search_output.hpp:29-76: keys and descriptions in the order of the enum (= the order of the header line)
+struct SamTag
+{
+    char const * key, * desc;
+};
+enum
+{
+    kTagBitScore, kTagProtCigar, kTagEditDistance, kTagMatchCount, kTagScore, kTagEValue, kTagPIdent, kTagPPos, kTagQFrame, kTagProtSeq,
+    kTagSFrame, kTagSTaxIds, kTagLcaId, kTagLcaTaxId, kNumSamTags
+};
+constexpr SamTag kSamTags[kNumSamTags] = {
+    {"AS", "bit score"},
+    {"OC", "query protein cigar (* for BLASTN)"},
+    {"NM", "edit distance (in protein space unless BLASTN)"},
+    {"IH", "number of matches this query has"},
+    {"ar", "raw score"},
+    {"ae", "expect value"},
+    {"ai", "% identity (in protein space unless BLASTN) "},
+    {"ap", "% positive (in protein space unless BLASTN)"},
+    {"qf", "query frame"},
+    {"qs", "query protein sequence (* for BLASTN)"},
+    {"sf", "subject frame"},
+    {"st", "subject taxonomy IDs (* if n/a)"},
+    {"ls", "lowest common ancestor scientific name"},
+    {"lt", "lowest common ancestor taxonomy ID"},
+};
+
+std::vector<std::string> splitWords(char const * text)
+{
+    std::vector<std::string> out;
+    std::string              cur;
+    for (char const * p = text; p && *p; ++p)
+    {
+        if (std::isspace((unsigned char)*p))
+        {
+            if (!cur.empty())
+                out.push_back(cur);
+            cur.clear();
+        }
+        else
+            cur += *p;
+    }
+    if (!cur.empty())
+        out.push_back(cur);
+    return out;
+}
+
+// --sam-bam-tags (src/search_options.hpp:772-806): every key must be one of the fourteen; the order given is not preserved
+bool resolveTags(char const * text, bool (&tags)[kNumSamTags])
+{
+    for (std::string const & w : splitWords(text ? text : "AS NM ae ai qf")) // :351
+    {
+        int t = 0;
+        while (t < kNumSamTags && w != kSamTags[t].key)
+            ++t;
+        if (t == kNumSamTags)
+        {
+            g_output_error = "Unknown column specifier \"" + w + "\". Please see \"--sam-bam-tags help\" for valid options.";
+            return false;
+        }
+        tags[t] = true;
+    }
+    return true;
+}
+
+// --output-columns (src/search_options.hpp:716-760): NCBI's specifiers as seqan::BlastMatchField labels them; "std" = the twelve
+// standard columns.  The descriptions are the "# Fields:" labels of .m9 (NCBI's).  Not offered: the columns that need sequence
+// data or database titles the writer is not given (qseq, sseq, btop, stitle, ...), and the GI / accession variants.
+struct Column
+{
+    char const * label, * desc;
+};
+enum
+{
+    kColQSeqId, kColSSeqId, kColPIdent, kColLength, kColMismatch, kColGapOpen, kColQStart, kColQEnd, kColSStart, kColSEnd, kColEValue,
+    kColBitScore, kColQLen, kColSLen, kColScore, kColNIdent, kColPositive, kColGaps, kColPPos, kColFrames, kColQFrame, kColSFrame,
+    kColSTaxIds, kColLcaTaxId, kNumColumns
+};
+constexpr Column kColumns[kNumColumns] = {
+    {"qseqid", "query id"},       {"sseqid", "subject id"},      {"pident", "% identity"},  {"length", "alignment length"},
+    {"mismatch", "mismatches"},   {"gapopen", "gap opens"},      {"qstart", "q. start"},    {"qend", "q. end"},
+    {"sstart", "s. start"},       {"send", "s. end"},            {"evalue", "evalue"},      {"bitscore", "bit score"},
+    {"qlen", "query length"},     {"slen", "subject length"},    {"score", "score"},        {"nident", "identical"},
+    {"positive", "positives"},    {"gaps", "gaps"},              {"ppos", "% positives"},   {"frames", "query/sbjct frames"},
+    {"qframe", "query frame"},    {"sframe", "sbjct frame"},     {"staxids", "subject tax ids"}, {"lcataxid", "lowest common ancestor taxonomy ID"},
+};
+
+bool resolveColumns(char const * text, std::vector<int> & cols)
+{
+    for (std::string const & w : splitWords(text ? text : "std"))
+    {
+        if (w == "std")
+        {
+            for (int c = kColQSeqId; c <= kColBitScore; ++c)
+                cols.push_back(c);
+            continue;
+        }
+        int c = 0;
+        while (c < kNumColumns && w != kColumns[c].label)
+            ++c;
+        if (c == kNumColumns)
+        {
+            g_output_error = "Unknown column specifier \"" + w + "\". Please see -oc help for valid options.";
+            return false;
+        }
+        cols.push_back(c);
+    }
+    return !cols.empty();
 }
 
 void reverseComplementAscii(std::string & seq)
@@ -260,16 +405,67 @@ int lx_compute_lca(lx_blast_match const * m, uint64_t n, lx_tax_tree const * tre
     return LX_OK;
 }
 
+void lx_output_options_default(lx_output_options * o)
+{
+    if (!o)
+        return;
+    *o               = lx_output_options{};
+    o->sam_seq       = LX_SAM_SEQ_UNIQ; // src/search_options.hpp:339
+    o->sam_hard_clip = 1;               // :360
+    o->genetic_code  = 1;               // :170
+}
+
+char const * lx_last_output_error(void)
+{
+    return g_output_error.c_str();
+}
+
+int lx_write_footer(char const * path, int format, uint64_t n_records)
+{
+    if (!path)
+        return LX_EINVAL;
+    if (format != LX_OUT_BLAST_TAB_COMMENTS)
+        return LX_OK;
+    std::FILE * f = std::fopen(path, "a");
+    if (!f)
+        return LX_EINVAL;
+    std::fprintf(f, "# BLAST processed %llu queries\n", (unsigned long long)n_records); // [UPSTREAM-RECALL] seqan::writeFooter
+    std::fclose(f);
+    return LX_OK;
+}
+
 int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
                      uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                      uint64_t const * q_ascii_off)
 {
+    return lx_write_records_ex(path, format, write_header, program, m, n, ops, names, q_res_ascii, q_ascii_off, nullptr);
+}
+
+int lx_write_records_ex(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
+                        uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
+                        uint64_t const * q_ascii_off, lx_output_options const * opt_in)
+{
+    g_output_error.clear();
     if (!path || !names || (!m && n) || !program)
         return LX_EINVAL;
+    lx_output_options opt;
+    lx_output_options_default(&opt);
+    if (opt_in)
+        opt = *opt_in;
     bool const isN    = std::strcmp(program, "blastn") == 0;
     bool const qTrans = std::strcmp(program, "blastx") == 0 || std::strcmp(program, "tblastx") == 0;  // qIsTranslated
     bool const sTrans = std::strcmp(program, "tblastn") == 0 || std::strcmp(program, "tblastx") == 0; // sIsTranslated
     if (!isN && !qTrans && !sTrans && std::strcmp(program, "blastp") != 0)
+        return LX_EINVAL;
+    // what the caller asked for is resolved before the file is touched (the reference fails while parsing its options)
+    std::vector<int> cols;
+    bool             tags[kNumSamTags] = {};
+    if (format == LX_OUT_SAM)
+    {
+        if (!resolveTags(opt.sam_tags, tags))
+            return LX_EINVAL;
+    }
+    else if (!resolveColumns(opt.columns, cols))
         return LX_EINVAL;
     std::FILE * f = std::fopen(path, write_header ? "w" : "a");
     if (!f)
@@ -277,25 +473,90 @@ int lx_write_records(char const * path, int format, int write_header, char const
     std::string upper(program);
     for (char & c : upper)
         c = (char)std::toupper((unsigned char)c);
+    // taxonomy of a subject / of a query's record (NULL trees: "*" and 0, as for an index without taxonomy)
+    auto taxIdsOf = [&](uint64_t n_sid) -> std::string
+    {
+        if (!opt.tax || n_sid >= opt.tax->n_s || opt.tax->s_tax_off[n_sid + 1] == opt.tax->s_tax_off[n_sid])
+            return "*";
+        std::string out;
+        for (uint64_t x = opt.tax->s_tax_off[n_sid]; x < opt.tax->s_tax_off[n_sid + 1]; ++x)
+            out += (out.empty() ? "" : ";") + std::to_string(opt.tax->s_tax_ids[x]);
+        return out;
+    };
+    uint64_t lcaAt = 0; // (the pairs are in list order, like the records)
+    auto lcaOf = [&](uint64_t n_qid) -> uint32_t
+    {
+        while (lcaAt < opt.n_lca && opt.lca_qid && opt.lca_qid[lcaAt] != n_qid)
+            ++lcaAt;
+        return (lcaAt < opt.n_lca && opt.lca_qid && opt.lca_tax) ? opt.lca_tax[lcaAt] : 0u;
+    };
+    // the protein sequence of a query frame (tags qs / OC): the query itself (BLASTP, TBLASTN), its translation (BLASTX, TBLASTX)
+    uint64_t    protOfQid = ~0ull;
+    std::string protFrames[6];
+    auto frameProtein = [&](lx_blast_match const & b) -> std::string
+    {
+        if (!q_res_ascii || !q_ascii_off)
+            return std::string();
+        char const *   src  = reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid];
+        uint64_t const qLen = names->q_lens[b.n_qid];
+        if (!qTrans)
+            return std::string(src, qLen);
+        if (b.q_frame == 0 || std::abs((int)b.q_frame) > 3)
+            return std::string();
+        if (protOfQid != b.n_qid)
+        {
+            std::vector<uint8_t> nt(qLen), aa(2 * qLen + 8);
+            for (uint64_t i = 0; i < qLen; ++i)
+                switch (std::toupper((unsigned char)src[i]))
+                {
+                    case 'A': nt[i] = 0; break;
+                    case 'C': nt[i] = 1; break;
+                    case 'G': nt[i] = 2; break;
+                    case 'T': case 'U': nt[i] = 4; break;
+                    default: nt[i] = 3;
+                }
+            uint64_t fo[6], fl[6];
+            if (lx_translate_six_frames(nt.data(), qLen, opt.genetic_code, aa.data(), aa.size(), fo, fl) != LX_OK)
+                return std::string();
+            for (int fr = 0; fr < 6; ++fr)
+            {
+                protFrames[fr].resize(fl[fr]);
+                for (uint64_t i = 0; i < fl[fr]; ++i)
+                    protFrames[fr][i] = lambda_amd::kSeqanOrder[std::min<uint8_t>(aa[fo[fr] + i], 26)];
+            }
+            protOfQid = b.n_qid;
+        }
+        return protFrames[b.q_frame > 0 ? b.q_frame - 1 : 2 - b.q_frame];
+    };
 
     if (format == LX_OUT_SAM)
     {
-        if (write_header) // src/search_output.hpp:382-460 (SAM without reference header records)
+        if (write_header) // src/search_output.hpp:347-460
         {
             std::fprintf(f, "@HD\tVN:1.4\tGO:query\n");
+            // --sam-with-refheader: seqan's writeHeader adds one @SQ per subject from the context ([UPSTREAM-RECALL] behind @HD)
+            if (opt.sam_with_ref_header)
+                for (uint64_t i = 0; i < names->n_s; ++i)
+                    std::fprintf(f, "@SQ\tSN:%s\tLN:%llu\n", firstWord(names->s_ids[i]).c_str(), (unsigned long long)names->s_lens[i]);
+            if (opt.version_to_output) // :391-399
+                std::fprintf(f, "@PG\tID:lambda\tPN:lambda\tVN:%s\tCL:%s\n", opt.version ? opt.version : "", opt.command_line ? opt.command_line : "");
             std::fprintf(f, "@CO\tLambda is a high performance BLAST compatible local aligner, please see http://seqan.de/lambda "
                             "for more information.\n");
             std::fprintf(f, "@CO\tSAM/BAM dialect documentation is available here: https://github.com/seqan/lambda/wiki/Output-Formats\n");
             std::fprintf(f, "@CO\tIf you use any results found by Lambda, please cite Hauswedell et al. (2014) doi: "
                             "10.1093/bioinformatics/btu439\n");
-            std::fprintf(f, "@CO\tOptional tags as follow\tAS:bit score\tNM:edit distance (in protein space unless BLASTN)\tae:expect "
-                            "value\tai:%% identity (in protein space unless BLASTN) \tqf:query frame\n");
+            std::string tagLine = "Optional tags as follow"; // :424-437
+            for (int t = 0; t < kNumSamTags; ++t)
+                if (tags[t])
+                    tagLine += std::string("\t") + kSamTags[t].key + ":" + kSamTags[t].desc;
+            std::fprintf(f, "@CO\t%s\n", tagLine.c_str());
         }
         for (uint64_t lo = 0; lo < n;)
         {
             uint64_t hi = lo + 1;
             while (hi < n && m[hi].n_qid == m[lo].n_qid)
                 ++hi;
+            uint32_t const lca = (tags[kTagLcaTaxId] || tags[kTagLcaId]) ? lcaOf(m[lo].n_qid) : 0u;
             for (uint64_t k = lo; k < hi; ++k)
             {
                 lx_blast_match const & b = m[k];
@@ -306,42 +567,48 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 }
                 int const         flag = ((k == lo) ? 0 : 256) | (b.q_frame < 0 ? 16 : 0); // secondary (:505, :723), RC (:506-507)
                 std::string const qn = firstWord(names->q_ids[b.n_qid]), sn = firstWord(names->s_ids[b.n_sid]);
-                // BLASTP: no DNA cigar and no SEQ ("*"); BLASTN: cigar with soft clips and, for the first record of a
-                // query region, the read sequence (samBamSeq = uniq, :536-553)
-                std::string cigar = "*", seq = "*";
-                // samBamSeq = uniq (:536-553): the sequence once per query region and frame
-                bool const writeSeq = (k == lo) || b.q_frame != m[k - 1].q_frame || b.q_start != m[k - 1].q_start ||
-                                      b.q_end != m[k - 1].q_end;
+                bool const        hard = opt.sam_hard_clip != 0;
+                // the DNA cigar: every program but BLASTP / TBLASTN, whose query is protein (:513-531)
+                std::string cigar = "*", seq = "*", protCigar = "*";
+                if (isN || qTrans)
+                    cigar = cigarOf(b, ops, names->q_lens[b.n_qid], hard, qTrans);
+                if (tags[kTagProtCigar] && !isN) // OC: protein-space cigar, clips like the DNA one, never reversed (:197-298)
+                    protCigar = protCigarOf(b, ops, names->q_lens[b.n_qid], hard, qTrans);
+                // --sam-bam-seq (:533-553): always, never, or once per query region and frame
+                bool writeSeq = opt.sam_seq >= LX_SAM_SEQ_ALWAYS;
+                if (opt.sam_seq == LX_SAM_SEQ_UNIQ)
+                    writeSeq = (k == lo) || b.q_frame != m[k - 1].q_frame || b.q_start != m[k - 1].q_start || b.q_end != m[k - 1].q_end;
                 uint64_t const qLen = names->q_lens[b.n_qid];
-                if (isN)
+                if (isN && writeSeq && q_res_ascii && q_ascii_off)
                 {
-                    cigar = cigarOf(b, ops, qLen, false);
-                    if (writeSeq && q_res_ascii && q_ascii_off)
-                    {
-                        seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], qLen);
-                        if (b.q_frame < 0) // the aligned sequence is the reverse-complement frame
-                            reverseComplementAscii(seq);
-                    }
+                    // the aligned sequence is the frame's (the reverse complement on the minus strand); hard clips keep only the
+                    // matched part of it (:555-582)
+                    seq.assign(reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid], qLen);
+                    if (b.q_frame < 0)
+                        reverseComplementAscii(seq);
+                    if (hard)
+                        seq = b.q_end <= qLen && b.q_start <= b.q_end ? seq.substr(b.q_start, b.q_end - b.q_start) : std::string("*");
                 }
-                else if (qTrans)
+                else if (qTrans && writeSeq && q_res_ascii && q_ascii_off && b.q_frame != 0)
                 {
-                    // nucleotide-space CIGAR (:528-531) and the part of the untranslated read that the frame covers,
-                    // soft-clip mode of _untranslateSequence (:84-109, :590-598): [|f| - 1, 3 L + |f| - 1) from the read's
-                    // start on the plus strand, from its end (then reverse-complemented) on the minus strand
-                    cigar = cigarOf(b, ops, qLen, false, true);
-                    if (writeSeq && q_res_ascii && q_ascii_off && b.q_frame != 0)
+                    // _untranslateSequence (:84-109, :583-598): protein [a, e) of frame f covers the nucleotides
+                    // [3a + |f| - 1, 3e + |f| - 1) of the strand that was read -- from the read's start on the plus strand,
+                    // from its end (then reverse-complemented) on the minus strand; soft clips keep the whole frame
+                    uint64_t const fc = (uint64_t)std::abs((int)b.q_frame) - 1, L = (qLen - fc) / 3;
+                    uint64_t const a = hard ? b.q_start : 0, e = hard ? b.q_end : L;
+                    char const *   src = reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid];
+                    if (e > L || a > e)
+                        seq = "*";
+                    else if (b.q_frame > 0)
+                        seq.assign(src + 3 * a + fc, 3 * (e - a));
+                    else
                     {
-                        uint64_t const fc = (uint64_t)std::abs((int)b.q_frame) - 1, L = (qLen - fc) / 3;
-                        char const *   src = reinterpret_cast<char const *>(q_res_ascii) + q_ascii_off[b.n_qid];
-                        if (b.q_frame > 0)
-                            seq.assign(src + fc, 3 * L);
-                        else
-                        {
-                            seq.assign(src + (qLen - (3 * L + fc)), 3 * L);
-                            reverseComplementAscii(seq);
-                        }
+                        seq.assign(src + (qLen - (3 * e + fc)), 3 * (e - a));
+                        reverseComplementAscii(seq);
                     }
-                } // BLASTP / TBLASTN: the query is protein -- no DNA cigar (:526-531), no SEQ (:599)
+                } // BLASTP / TBLASTN: the query is protein -- no SEQ (:599)
+                if (seq.empty())
+                    seq = "*";
                 // POS: a translated subject is reported in nucleotide space (:493-499; the minus-strand branch there
                 // subtracts from the QUERY length -- restated as it stands)
                 uint64_t pos = b.s_start;
@@ -353,10 +620,41 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 }
                 std::fprintf(f, "%s\t%d\t%s\t%llu\t255\t%s\t*\t0\t0\t%s\t*", qn.c_str(), flag, sn.c_str(),
                              (unsigned long long)(pos + 1), cigar.c_str(), seq.c_str());
-                // tags in the order of myWriteRecord: ae, AS, ai, qf, NM (:611-716)
-                std::fprintf(f, "\tae:f:%g\tAS:i:%u\tai:i:%u\tqf:i:%d\tNM:i:%u\n", (double)(float)b.e_value,
-                             (unsigned)(uint16_t)b.bit_score, (unsigned)(uint8_t)b.identity, (int)b.q_frame,
-                             (unsigned)(b.alignment_length - b.num_matches));
+                // tags in the order myWriteRecord appends them (:601-719), with the widths it casts to
+                if (tags[kTagEValue])
+                    std::fprintf(f, "\tae:f:%g", (double)(float)b.e_value);
+                if (tags[kTagBitScore])
+                    std::fprintf(f, "\tAS:i:%u", (unsigned)(uint16_t)b.bit_score);
+                if (tags[kTagScore])
+                    std::fprintf(f, "\tar:i:%u", (unsigned)(uint8_t)b.score); // (uint8_t in the reference, :612-616: scores beyond 255 wrap)
+                if (tags[kTagPIdent])
+                    std::fprintf(f, "\tai:i:%u", (unsigned)(uint8_t)b.identity);
+                if (tags[kTagPPos])
+                    std::fprintf(f, "\tap:i:%u", (unsigned)(uint16_t)(b.alignment_length ? 100.0 * b.num_positives / b.alignment_length : 0.0));
+                if (tags[kTagQFrame])
+                    std::fprintf(f, "\tqf:i:%d", (int)(int8_t)b.q_frame);
+                if (tags[kTagSFrame])
+                    std::fprintf(f, "\tsf:i:%d", (int)(int8_t)b.s_frame);
+                if (tags[kTagSTaxIds])
+                    std::fprintf(f, "\tst:Z:%s", taxIdsOf(b.n_sid).c_str());
+                if (tags[kTagLcaId])
+                    std::fprintf(f, "\tls:Z:%s", (opt.tax_names && opt.tax && lca < opt.tax->n_taxa && opt.tax_names[lca]) ? opt.tax_names[lca] : "*");
+                if (tags[kTagLcaTaxId])
+                    std::fprintf(f, "\tlt:i:%u", lca);
+                if (tags[kTagProtSeq]) // :669-689
+                {
+                    std::string prot = (isN || !writeSeq) ? std::string() : frameProtein(b);
+                    if (!prot.empty() && hard)
+                        prot = b.q_end <= prot.size() && b.q_start <= b.q_end ? prot.substr(b.q_start, b.q_end - b.q_start) : std::string();
+                    std::fprintf(f, "\tqs:Z:%s", prot.empty() ? "*" : prot.c_str());
+                }
+                if (tags[kTagProtCigar])
+                    std::fprintf(f, "\tOC:Z:%s", protCigar.c_str());
+                if (tags[kTagEditDistance])
+                    std::fprintf(f, "\tNM:i:%u", (unsigned)(b.alignment_length - b.num_matches));
+                if (tags[kTagMatchCount])
+                    std::fprintf(f, "\tIH:i:%u", (unsigned)(hi - lo));
+                std::fputc('\n', f);
             }
             lo = hi;
         }
@@ -364,6 +662,14 @@ int lx_write_records(char const * path, int format, int write_header, char const
     else
     {
         bool const comments = format == LX_OUT_BLAST_TAB_COMMENTS;
+        // "# <PROGRAM> 2.2.26+", followed by lambda's tag when the version goes to the output file (src/search_output.hpp:313-345)
+        std::string versionLine = upper + " 2.2.26+";
+        if (opt.version_to_output)
+            versionLine += std::string(" [created by LAMBDA") + (opt.version ? std::string("-") + opt.version : std::string()) +
+                           ", see http://seqan.de/lambda and please cite correctly in your academic work]";
+        std::string fields;
+        for (int c : cols)
+            fields += (fields.empty() ? "" : ", ") + std::string(kColumns[c].desc);
         for (uint64_t lo = 0; lo < n;)
         {
             uint64_t hi = lo + 1;
@@ -371,13 +677,14 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 ++hi;
             if (comments)
             {
-                std::fprintf(f, "# %s 2.2.26+ [created by LAMBDA, see http://seqan.de/lambda and please cite correctly in your academic work]\n",
-                             upper.c_str());
-                std::fprintf(f, "# Query: %s\n# Database: %s\n", names->q_ids[m[lo].n_qid], "lambda_ext");
-                std::fprintf(f, "# Fields: query id, subject id, %% identity, alignment length, mismatches, gap opens, q. start, "
-                                "q. end, s. start, s. end, evalue, bit score\n# %llu hits found\n",
-                             (unsigned long long)(hi - lo));
+                std::fprintf(f, "# %s\n", versionLine.c_str());
+                std::fprintf(f, "# Query: %s\n# Database: %s\n", names->q_ids[m[lo].n_qid], opt.db_name ? opt.db_name : "lambda_ext");
+                std::fprintf(f, "# Fields: %s\n# %llu hits found\n", fields.c_str(), (unsigned long long)(hi - lo));
             }
+            uint32_t lca = 0;
+            for (int c : cols)
+                if (c == kColLcaTaxId)
+                    lca = lcaOf(m[lo].n_qid);
             for (uint64_t k = lo; k < hi; ++k)
             {
                 lx_blast_match const & b = m[k];
@@ -419,10 +726,42 @@ int lx_write_records(char const * path, int format, int write_header, char const
                 }
                 if (sTrans)
                     untranslate(b.s_start, b.s_end, b.s_frame, names->s_lens[b.n_sid], ss, se);
-                std::fprintf(f, "%s\t%s\t%.2f\t%d\t%d\t%d\t%llu\t%llu\t%llu\t%llu\t%.1e\t%.1f\n",
-                             firstWord(names->q_ids[b.n_qid]).c_str(), firstWord(names->s_ids[b.n_sid]).c_str(),
-                             (double)b.identity, b.alignment_length, b.num_mismatches, b.num_gap_opens, qs, qe, ss, se,
-                             b.e_value, b.bit_score);
+                bool first = true;
+                for (int c : cols)
+                {
+                    if (!first)
+                        std::fputc('\t', f);
+                    first = false;
+                    switch (c)
+                    {
+                        case kColQSeqId: std::fputs(firstWord(names->q_ids[b.n_qid]).c_str(), f); break;
+                        case kColSSeqId: std::fputs(firstWord(names->s_ids[b.n_sid]).c_str(), f); break;
+                        case kColQLen: std::fprintf(f, "%llu", (unsigned long long)names->q_lens[b.n_qid]); break;
+                        case kColSLen: std::fprintf(f, "%llu", (unsigned long long)names->s_lens[b.n_sid]); break;
+                        case kColQStart: std::fprintf(f, "%llu", qs); break;
+                        case kColQEnd: std::fprintf(f, "%llu", qe); break;
+                        case kColSStart: std::fprintf(f, "%llu", ss); break;
+                        case kColSEnd: std::fprintf(f, "%llu", se); break;
+                        case kColEValue: std::fprintf(f, "%.1e", b.e_value); break;
+                        case kColBitScore: std::fprintf(f, "%.1f", b.bit_score); break;
+                        case kColScore: std::fprintf(f, "%d", b.score); break;
+                        case kColLength: std::fprintf(f, "%d", b.alignment_length); break;
+                        case kColPIdent: std::fprintf(f, "%.2f", (double)b.identity); break;
+                        case kColNIdent: std::fprintf(f, "%d", b.num_matches); break;
+                        case kColMismatch: std::fprintf(f, "%d", b.num_mismatches); break;
+                        case kColPositive: std::fprintf(f, "%d", b.num_positives); break;
+                        case kColGapOpen: std::fprintf(f, "%d", b.num_gap_opens); break;
+                        case kColGaps: std::fprintf(f, "%d", b.num_gap_opens + b.num_gap_extensions); break; // every gap character
+                        case kColPPos: std::fprintf(f, "%.2f", b.alignment_length ? 100.0 * b.num_positives / b.alignment_length : 0.0); break;
+                        case kColFrames: std::fprintf(f, "%d/%d", (int)b.q_frame, (int)b.s_frame); break;
+                        case kColQFrame: std::fprintf(f, "%d", (int)b.q_frame); break;
+                        case kColSFrame: std::fprintf(f, "%d", (int)b.s_frame); break;
+                        case kColSTaxIds: std::fputs(taxIdsOf(b.n_sid).c_str(), f); break;
+                        case kColLcaTaxId: std::fprintf(f, "%u", lca); break;
+                        default: break;
+                    }
+                }
+                std::fputc('\n', f);
             }
             lo = hi;
         }

@@ -243,13 +243,17 @@ def test_searchp_blastx_frames_and_coordinates(tmp_path):
         assert x[2] == f"sp{j}" and (int(x[1]) & 16 != 0) == (qstart > qend), x
         el = [(int(n), c) for n, c in re.findall(r"(\d+)([MIDSH])", x[5])]
         assert sum(n for n, c in el if c in "MISH") == len(reads[k]), x      # every nucleotide of the read is accounted for
-        assert all(n % 3 == 0 for n, c in el if c in "MIDS")                    # codon-sized runs; only frame clips are free
+        assert all(n % 3 == 0 for n, c in el if c in "MIDS")                    # codon-sized runs; the hard clips hold the frame clips
         assert len(x[9]) == sum(n for n, c in el if c in "MIS")                 # SEQ = the read minus the hard clips
         frame = int([t for t in x if t.startswith("qf:i:")][0][5:])
+        # hard clips (the reference's default): SEQ is the matched part of the strand that was read; its first base stands behind
+        # the clip in front of the alignment -- the cigar's first element, or its last on the minus strand (the list is reversed there)
         if frame > 0:
-            assert x[9] == reads[k][frame - 1: frame - 1 + len(x[9])]
+            lead = el[0][0] if el[0][1] == "H" else 0
+            assert lead % 3 == frame - 1 and x[9] == reads[k][lead: lead + len(x[9])]
         else:
-            assert x[9] == reads[k].translate(comp)[::-1][-frame - 1: -frame - 1 + len(x[9])]
+            lead = el[-1][0] if el[-1][1] == "H" else 0
+            assert lead % 3 == -frame - 1 and x[9] == reads[k].translate(comp)[::-1][lead: lead + len(x[9])]
 
 
 @pytest.mark.gpu
@@ -310,7 +314,9 @@ def test_devices_split_gives_identical_output(tmp_path):
     for tag, extra in (("one", ["--devices", "0"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0", "-t", "3"])):
         for ext in ("m8", "sam"):
             out = tmp_path / f"{tag}.{ext}"
-            r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out)] + extra, capture_output=True, text=True)
+            # (--version-to-outputfile 0, as the reference's own CLI tests pass it: no @PG line with the command line in the SAM header)
+            r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out), "--version-to-outputfile", "0"] + extra,
+                               capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
             assert ("2 thread(s)" in r.stderr) == (tag == "two") and ("3 thread(s)" in r.stderr) == (tag == "three"), r.stderr
             outs[(tag, ext)] = out.read_bytes()
@@ -377,3 +383,73 @@ def test_searchbs_both_strands_and_conversions(tmp_path, oracle):
     assert r.returncode == 0, r.stderr
     recs = [l.split("\t") for l in sam.read_text().splitlines() if not l.startswith("@")]
     assert len(recs) >= 74 and {int(x[1]) & 16 for x in recs} == {0, 16}
+
+
+def test_cli_rejects_bad_option_values(tmp_path):
+    """Option validation happens before any device is touched (the reference's sharg validators, src/search_options.hpp:224-560)."""
+    _fasta(tmp_path / "q.fasta", ["q"], ["ACDEFGHIKLMNPQRSTVWY" * 3])
+    _fasta(tmp_path / "d.fasta", ["s"], ["ACDEFGHIKLMNPQRSTVWY" * 5])
+    base = [str(_cli()), "searchp", "-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "d.fasta"), "-o", str(tmp_path / "o.m8")]
+    for bad, msg in ((["-s", "50"], "--scoring-scheme takes 45, 62 or 80"), (["-p", "quick"], "--profile takes"), (["--sam-bam-clip", "medium"], "hard or soft"),
+                     (["--bit-score", "2000"], "not in range"), (["--score-match", "3"], "unknown option --score-match"),  # (nucleotide domains only)
+                     (["--sam-bam-seq", "often"], "always, uniq or never"), (["--seed-delta", "7"], "out of range")):
+        r = subprocess.run(base + bad, capture_output=True, text=True)
+        assert r.returncode != 0 and msg in r.stderr, (bad, r.stderr)
+    r = subprocess.run([str(_cli()), "searchn"] + base[2:] + ["-s", "62"], capture_output=True, text=True)
+    assert r.returncode != 0 and "unknown option -s" in r.stderr  # (protein domain only)
+
+
+@pytest.mark.gpu
+def test_cli_profiles_scoring_and_output_options(tmp_path, oracle):
+    """The rest of the search command line (src/search_options.hpp:224-681): profiles overwrite the seeding parameters, the scoring options
+    reach the DP (every HSP re-scored on the oracle under BLOSUM80 11/2), --bit-score filters, --output-columns / .m9 comments and footer,
+    SAM tags / clipping."""
+    qs, db, truth = _make_config1(tmp_path, nq=200, ndb=2000)
+    common = ["-q", str(tmp_path / "q.fasta"), "-d", str(tmp_path / "db.fasta")]
+    out = tmp_path / "o.m9"
+    r = subprocess.run([str(_cli()), "searchp"] + common + ["-o", str(out), "-p", "sensitive", "-s", "80", "--score-gap", "-2", "--score-gap-open", "-9",
+                        "--bit-score", "40", "--output-columns", "std score qlen slen", "--version-to-outputfile", "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = out.read_text().splitlines()
+    assert lines[0] == "# BLASTP 2.2.26+" and lines[2] == f"# Database: {tmp_path / 'db.fasta'}"
+    assert lines[3].endswith("evalue, bit score, score, query length, subject length")
+    rows = [l.split("\t") for l in lines if not l.startswith("#")]
+    nrec = sum(1 for l in lines if l.startswith("# Query:"))
+    assert lines[-1] == f"# BLAST processed {nrec} queries" and len(rows) > 30 and all(len(x) == 15 for x in rows)
+    assert all(float(x[11]) >= 40 for x in rows)
+    sc_p = capi.builtin_scoring(80, gap_open=-9, gap_extend=-2)  # (lambda's option values, as on the command line)
+    osc = oracle_lib.scoring_from(sc_p)
+    rank = {c: i for i, c in enumerate(ORDER)}
+    enc = lambda s: np.array([rank[c] for c in s], dtype=np.uint8)
+    for x in rows[:200]:
+        k, j = int(x[0][1:]), int(x[1][2:])
+        qa, qb, sa, sb = int(x[6]) - 1, int(x[7]), int(x[8]) - 1, int(x[9])
+        s_, qe, se = oracle.score(enc(qs[k][qa:qb]), enc(db[j][sa:sb]), osc)
+        assert s_ == int(x[12]) and (qe, se) == (qb - qa, sb - sa), x
+        assert int(x[13]) == len(qs[k]) and int(x[14]) == len(db[j])
+    # the fast profile finds no more than the default search; both run
+    n = {}
+    for prof in ("none", "fast"):
+        o = tmp_path / f"{prof}.m8"
+        r = subprocess.run([str(_cli()), "searchp"] + common + ["-o", str(o), "-p", prof], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        n[prof] = len({l.split("\t")[0] for l in o.read_text().splitlines()})
+    assert 0 < n["fast"] <= n["none"]
+    # SAM: tags and clipping
+    sam = tmp_path / "o.sam"
+    r = subprocess.run([str(_cli()), "searchp"] + common + ["-o", str(sam), "--sam-bam-tags", "AS ar OC qs IH", "--sam-bam-seq", "always",
+                        "--sam-with-refheader", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = sam.read_text().splitlines()
+    assert sum(1 for l in txt if l.startswith("@SQ")) == 2000 and any(l.startswith("@PG\tID:lambda") and "searchp -q" in l for l in txt)
+    recs = [l.split("\t") for l in txt if not l.startswith("@")]
+    assert len(recs) > 30
+    for f in recs[:100]:
+        tags = dict((t[:2], t[5:]) for t in f[11:])
+        assert set(tags) == {"AS", "ar", "OC", "qs", "IH"} and f[5] == "*" and f[9] == "*"
+        k = int(f[0][1:])
+        # hard clips: the protein cigar's M / I columns are the residues of qs, and qs is a piece of the query
+        import re
+        ops = re.findall(r"(\d+)([MIDHS])", tags["OC"])
+        assert sum(int(c) for c, o in ops if o in "MI") == len(tags["qs"]) and tags["qs"] in qs[k]
+        assert sum(int(c) for c, o in ops if o in "MIH") == len(qs[k])

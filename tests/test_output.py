@@ -64,8 +64,9 @@ def test_sam_writer_blastn_cigar_and_tags(tmp_path):
                  dtype=capi.BLAST_MATCH_DTYPE)
     read = b"ACGTACGTACGTACGTACGTACGTACGT"[:qlen]
     p = tmp_path / "out.sam"
+    soft = capi.output_options(sam_hard_clip=0)  # --sam-bam-clip soft
     capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1 x"], [qlen], ["chr1", "chr2"], [1000, 1000], program="blastn",
-                       q_ascii=read, q_ascii_off=[0])
+                       q_ascii=read, q_ascii_off=[0], options=soft)
     lines = [l for l in p.read_text().splitlines() if not l.startswith("@")]
     f0, f1 = lines[0].split("\t"), lines[1].split("\t")
     assert f0[:9] == ["read1", "0", "chr1", "51", "255", "3S10M2D5M1I4M5S", "*", "0", "0"]
@@ -73,6 +74,11 @@ def test_sam_writer_blastn_cigar_and_tags(tmp_path):
     assert f0[11:] == ["ae:f:0.0002", "AS:i:40", "ai:i:77", "qf:i:1", f"NM:i:{len(ops) - 17}"]
     assert f1[1] == "256" and f1[2] == "chr2" and f1[9] == "*"  # secondary; same query region -> sequence not repeated
     assert p.read_text().startswith("@HD\tVN:1.4\tGO:query\n")
+    # the reference's default is hard clips (src/search_options.hpp:360, :812): the clipped bases leave CIGAR and SEQ
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1 x"], [qlen], ["chr1", "chr2"], [1000, 1000], program="blastn",
+                       q_ascii=read, q_ascii_off=[0])
+    h0, h1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
+    assert h0[5] == "3H10M2D5M1I4M5H" and h0[9] == read[3:23].decode() and h1[9] == "*"
 
 
 def test_sam_writer_blastp_has_no_cigar(tmp_path):
@@ -97,8 +103,9 @@ def test_sam_writer_translated_query_cigar_clips_and_sequence(tmp_path):
     plus["s_frame"], minus["s_frame"] = 3, -1
     m = np.array([plus, minus], dtype=capi.BLAST_MATCH_DTYPE)
     p = tmp_path / "x.sam"
+    soft = capi.output_options(sam_hard_clip=0)
     capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1"], [qlen], ["s0", "s1"], [900, 900], program="tblastx",
-                       q_ascii=read, q_ascii_off=[0])
+                       q_ascii=read, q_ascii_off=[0], options=soft)
     f0, f1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
     assert f0[1] == "0" and f0[5] == "1H6S12M3D9M3S1H"
     assert f0[9] == read[1:31].decode()
@@ -110,9 +117,15 @@ def test_sam_writer_translated_query_cigar_clips_and_sequence(tmp_path):
     assert "qf:i:2" in f0 and "qf:i:-3" in f1
     # BLASTX: the subject is protein -- plain position
     capi.write_records(p, capi.LX_OUT_SAM, m[:1], ops, ["read1"], [qlen], ["s0", "s1"], [900, 900], program="blastx",
-                       q_ascii=read, q_ascii_off=[0])
+                       q_ascii=read, q_ascii_off=[0], options=soft)
     g = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")][0]
     assert g[3] == "6" and g[5] == "1H6S12M3D9M3S1H"
+    # hard clips (the default): frame clip and local clip merge into one H, SEQ is the matched codons only (:84-109 with qStart, qEnd)
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["read1"], [qlen], ["s0", "s1"], [900, 900], program="tblastx",
+                       q_ascii=read, q_ascii_off=[0])
+    h0, h1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
+    assert h0[5] == "7H12M3D9M4H" and h0[9] == read[1 + 6: 1 + 27].decode()
+    assert h1[5] == "3H9M3D12M8H" and h1[9] == "".join(comp[c] for c in reversed(read[qlen - (27 + 2): qlen - (6 + 2)].decode()))
     # TBLASTN: protein query -- no DNA cigar, no sequence, translated subject position
     t = rec(0, 0, 2, 9, 5, 13, 40.0, alen=len(ops), nm=6, n_ops=len(ops), frame=0)
     t["s_frame"] = 2
@@ -134,7 +147,7 @@ def test_sam_writer_blastn_minus_strand_cigar_is_reversed(tmp_path):
     read = b"ACGGTCATTGCAAGCTTAGGCATCGATAC"[:qlen]
     p = tmp_path / "rc.sam"
     capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["r"], [qlen], ["c1", "c2"], [500, 500], program="blastn",
-                       q_ascii=read, q_ascii_off=[0])
+                       q_ascii=read, q_ascii_off=[0], options=capi.output_options(sam_hard_clip=0))
     f0, f1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
     assert f0[1] == "0" and f0[5] == "2S6M1I9M3D4M7S"
     assert f1[1] == str(256 | 16) and f1[5] == "7S4M3D9M1I6M2S"  # the same elements, back to front
@@ -218,3 +231,89 @@ def test_lca_of_a_query_follows_write_record():
     one["n_sid"] = [0, 1]
     with pytest.raises(capi.LambdaExtError):
         capi.compute_lca(one, parents2, heights2, np.array([0, 1, 2], dtype=np.uint64), np.array([a, b], dtype=np.uint32))
+
+
+def test_sam_tags_sequence_modes_and_reference_header(tmp_path):
+    """--sam-bam-tags / --sam-bam-seq / --sam-with-refheader / --version-to-outputfile (src/search_options.hpp:276-379, :762-812): every
+    optional tag of SamBamExtraTags (src/search_output.hpp:29-76) in the order myWriteRecord appends them (:601-719), with the widths it
+    casts to; the header line lists the chosen tags in the order of the enum."""
+    ops = b"M" * 10 + b"D" * 2 + b"M" * 8
+    qlen = 4 + 18 + 3
+    a = rec(0, 0, 4, 22, 50, 70, 300.7, score=300, alen=len(ops), nm=15, n_ops=len(ops), ev=2e-30, ident=75.0)
+    b = rec(0, 1, 4, 22, 10, 30, 40.2, score=44, alen=len(ops), nm=12, n_ops=len(ops), ev=2e-3, ident=60.0)
+    m = np.array([a, b], dtype=capi.BLAST_MATCH_DTYPE)
+    m["num_positives"] = [17, 14]
+    prot = b"MKVLAAGIVGLLLAQWERTYCDEFG"[:qlen]
+    p = tmp_path / "t.sam"
+    o = capi.output_options(sam_tags="lt ls st sf qs OC IH ar ap AS NM ae ai qf", sam_seq=capi.LX_SAM_SEQ_ALWAYS, sam_with_ref_header=1,
+                            version_to_output=1, version="3.0.0", command_line="lambda3 searchp -q q.fa")
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["q1 some description"], [qlen], ["s0", "s1 x"], [500, 600], program="blastp",
+                       q_ascii=prot, q_ascii_off=[0], options=o)
+    txt = p.read_text().splitlines()
+    assert txt[0] == "@HD\tVN:1.4\tGO:query" and txt[1:3] == ["@SQ\tSN:s0\tLN:500", "@SQ\tSN:s1\tLN:600"]
+    assert txt[3] == "@PG\tID:lambda\tPN:lambda\tVN:3.0.0\tCL:lambda3 searchp -q q.fa"
+    co = [l for l in txt if l.startswith("@CO\tOptional tags as follow")][0].split("\t")[2:]
+    assert [c.split(":")[0] for c in co] == ["AS", "OC", "NM", "IH", "ar", "ae", "ai", "ap", "qf", "qs", "sf", "st", "ls", "lt"]
+    f0, f1 = [l.split("\t") for l in txt if not l.startswith("@")]
+    # BLASTP: no DNA cigar, no SEQ; the protein cigar and sequence travel in OC / qs (hard clips: the matched part only)
+    assert f0[5] == "*" and f0[9] == "*"
+    assert f0[11:] == ["ae:f:2e-30", "AS:i:300", f"ar:i:{300 % 256}", "ai:i:75", f"ap:i:{int(100 * 17 / len(ops))}", "qf:i:0", "sf:i:0", "st:Z:*",
+                       "ls:Z:*", "lt:i:0", "qs:Z:" + prot[4:22].decode(), "OC:Z:4H10M2D8M3H", f"NM:i:{len(ops) - 15}", "IH:i:2"]
+    assert f1[1] == "256" and "qs:Z:" + prot[4:22].decode() in f1  # --sam-bam-seq always
+    # uniq: the second record covers the same query range -> "*"; never: both
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["q1"], [qlen], ["s0", "s1"], [500, 600], program="blastp", q_ascii=prot, q_ascii_off=[0],
+                       options=capi.output_options(sam_tags="qs", sam_hard_clip=0))
+    g0, g1 = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")]
+    assert g0[11:] == ["qs:Z:" + prot.decode()] and g1[11:] == ["qs:Z:*"]  # soft clips: the whole query
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["q1"], [qlen], ["s0", "s1"], [500, 600], program="blastp", q_ascii=prot, q_ascii_off=[0],
+                       options=capi.output_options(sam_tags="qs", sam_seq=capi.LX_SAM_SEQ_NEVER))
+    assert all(l.endswith("qs:Z:*") for l in p.read_text().splitlines() if not l.startswith("@"))
+    with pytest.raises(capi.LambdaExtError, match="Unknown column specifier \"zz\""):
+        capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["q1"], [qlen], ["s0", "s1"], [500, 600], options=capi.output_options(sam_tags="AS zz"))
+
+
+def test_sam_protein_cigar_and_sequence_of_a_translated_query(tmp_path):
+    """Tags OC / qs for BLASTX: the protein half of blastMatchTwoCigar (src/search_output.hpp:197-298: clips in protein space, never
+    reversed) and the frame's translation (hard clips: the matched residues)."""
+    read = b"ACGTTGCAAGGCTTAACCGGTTAAGGCCTTAG"  # 32 nt
+    ops = b"MMMMDMMM"
+    minus = rec(0, 0, 2, 9, 5, 13, 39.0, alen=len(ops), nm=6, n_ops=len(ops), frame=-3)
+    m = np.array([minus], dtype=capi.BLAST_MATCH_DTYPE)
+    p = tmp_path / "x.sam"
+    capi.write_records(p, capi.LX_OUT_SAM, m, ops, ["r"], [len(read)], ["s0"], [900], program="blastx", q_ascii=read, q_ascii_off=[0],
+                       options=capi.output_options(sam_tags="OC qs"))
+    f = [l.split("\t") for l in p.read_text().splitlines() if not l.startswith("@")][0]
+    assert f[5] == "3H9M3D12M8H"          # DNA cigar: reversed on the minus strand
+    assert f[12] == "OC:Z:2H4M1D3M1H"     # protein cigar: as the alignment runs
+    # frame -3 = the reverse complement read from its third base
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = "".join(comp[c] for c in reversed(read.decode()))
+    from tests.test_translate import dna, prot
+    frame = prot(capi.translate_six_frames(dna(rc[2:]))[0])
+    assert f[11] == "qs:Z:" + frame[2:9]
+
+
+def test_tabular_columns_version_line_and_footer(tmp_path):
+    """--output-columns (src/search_options.hpp:224-232, :716-760): the NCBI specifiers, "std" = the twelve standard ones; the .m9
+    comment block names them; the version line carries lambda's tag only with --version-to-outputfile (src/search_output.hpp:313-345);
+    myWriteFooter closes an .m9 (:739-750)."""
+    ops = b"M" * 12 + b"I" * 3 + b"M" * 15
+    m = np.array([rec(0, 1, 4, 34, 99, 126, 61.23, score=148, alen=30, nm=24, n_ops=30, ev=3.2e-12, ident=80.0, frame=1)], dtype=capi.BLAST_MATCH_DTYPE)
+    m["num_gap_opens"], m["num_gap_extensions"], m["num_positives"], m["s_frame"] = 1, 2, 26, 0
+    p = tmp_path / "c.m9"
+    o = capi.output_options(columns="qseqid qlen sseqid slen score nident positive gaps ppos frames qframe sframe staxids lcataxid std", db_name="db.lba")
+    capi.write_records(p, capi.LX_OUT_BLAST_TAB_COMMENTS, m, ops, ["q0 desc"], [40], ["s0", "s1 t"], [300, 400], options=o)
+    capi.write_footer(p, capi.LX_OUT_BLAST_TAB_COMMENTS, 1)
+    lines = p.read_text().splitlines()
+    assert lines[0] == "# BLASTP 2.2.26+" and lines[2] == "# Database: db.lba"
+    assert lines[3].startswith("# Fields: query id, query length, subject id, subject length, score, identical, positives, gaps, % positives, "
+                               "query/sbjct frames, query frame, sbjct frame, subject tax ids, lowest common ancestor taxonomy ID, query id, subject id, % identity")
+    assert lines[5].split("\t") == ["q0", "40", "s1", "400", "148", "24", "26", "3", "86.67", "1/0", "1", "0", "*", "0",
+                                    "q0", "s1", "80.00", "30", "6", "1", "5", "34", "100", "126", "3.2e-12", "61.2"]
+    assert lines[-1] == "# BLAST processed 1 queries"
+    capi.write_records(p, capi.LX_OUT_BLAST_TAB_COMMENTS, m, ops, ["q0"], [40], ["s0", "s1"], [300, 400],
+                       options=capi.output_options(version_to_output=1, version="3.0.0"))
+    assert p.read_text().splitlines()[0] == ("# BLASTP 2.2.26+ [created by LAMBDA-3.0.0, see http://seqan.de/lambda and please cite correctly "
+                                             "in your academic work]")
+    with pytest.raises(capi.LambdaExtError, match="Unknown column specifier \"qseq\""):
+        capi.write_records(p, capi.LX_OUT_BLAST_TAB, m, ops, ["q0"], [40], ["s0", "s1"], [300, 400], options=capi.output_options(columns="std qseq"))
