@@ -76,6 +76,15 @@ if rs.exists():
         for r in rows[1:]:
             if "lx::" in r[0]:
                 w.writerow(r)
+hs = src / "stats_host" / "host_kernel_stats.csv"  # the five chunks of lx_extend_batch_list on the headline batch
+if hs.exists():
+    rows = list(csv.reader(open(hs)))
+    with open(out / f"{tag}_host_path_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "lx::" in r[0]:
+                w.writerow(r)
 lw = src / "pmc_write_lowsurv" / "pmc_counter_collection.csv"
 if lw.exists():
     acc, n = collections.defaultdict(float), collections.defaultdict(set)

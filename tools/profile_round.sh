@@ -10,6 +10,7 @@ for c in 2 3 4; do (timeout 900 python bench.py --config $c --steps 5 --warmup 2
 (timeout 600 python bench.py --band 64 --steps 5 --warmup 2) > $D/bench_band64.log 2>&1
 (timeout 600 python bench.py --host-path --steps 5 --warmup 2) > $D/bench_host_path.log 2>&1
 (timeout 900 python bench.py --ragged --steps 5 --warmup 2) > $D/bench_ragged.log 2>&1
+for e in rle list; do (timeout 600 python bench.py --host-path --entry $e --steps 5 --warmup 2) > $D/bench_host_path_$e.log 2>&1; (timeout 900 python bench.py --ragged --entry $e --steps 5 --warmup 2) > $D/bench_ragged_$e.log 2>&1; done
 for r in 0.02 0.1; do (timeout 600 python bench.py --steps 10 --warmup 3 --survivor-rate $r --no-cpu-baseline) > $D/bench_survivors_$r.log 2>&1; done
 (timeout 600 python bench.py --steps 10 --warmup 3 --survivor-rate 0.02 --adapt-permille 0 --no-cpu-baseline) > $D/bench_survivors_0.02_sweep.log 2>&1
 (timeout 600 python tools/host_curve.py 100) > $D/host_curve.jsonl 2>&1
@@ -20,5 +21,6 @@ cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$D/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_fetch.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_write.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_ragged -o ragged -- python $R/tools/quick_ragged.py) > $R/$D/stats_ragged.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_host -o host -- python $R/bench.py --host-path --entry list --steps 5 --warmup 2) > $R/$D/stats_host.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write_lowsurv -o pmc -- python $R/bench.py --steps 2 --warmup 3 --survivor-rate 0.02 --no-cpu-baseline) > $R/$D/pmc_write_lowsurv.log 2>&1
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -40
