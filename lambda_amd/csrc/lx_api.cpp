@@ -557,7 +557,8 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
         // (... and for queries beyond 208 columns a run that is a multiple of 8 but not of 16 has no packed sweep with compact
         // codes of its own: the multi-query one serves it)
         bool const odd8    = run % 8 == 0 && run % 16 != 0 && run != 0;
-        bool const wanted  = o.mq == 2 ? (run != 0 && run % 4 == 0) : o.mq == 1 ? (run == 4 || (odd8 && (!half8_cheap || o.max_qlen > 208))) : false;
+        // (run 2 = the free packing: pairs of one query, at most four queries per wavefront -- only this sweep serves it)
+        bool const wanted  = run == 2 ? o.mq >= 1 : o.mq == 2 ? (run != 0 && run % 4 == 0) : o.mq == 1 ? (run == 4 || (odd8 && (!half8_cheap || o.max_qlen > 208))) : false;
         mq = wanted && o.pass2 == 2 && o.f16 && sc.trace_ok && sc.b8_ok && gaps_ok && !o.band;
     }
     if (mq)
@@ -574,7 +575,8 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             sweep_stride   = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
             half_sweep     = true;
             // lane groups per query: a wavefront's 16 slots hold 16 / 8 / 4 windows of one query, whatever divides the run
-            sweep_share    = (o.query_run % 16 == 0 ? 16 : o.query_run % 8 == 0 ? 8 : 4) / 2;
+            // (1 = the free packing: a lane group's pair shares a query, up to four queries per wavefront in any split)
+            sweep_share    = o.query_run == 2 ? 1 : (o.query_run % 16 == 0 ? 16 : o.query_run % 8 == 0 ? 8 : 4) / 2;
             sweep          = (o.n + 1) * sweep_stride * 4 <= o.trace_bytes;
             int64_t const worst = (int64_t)o.max_qlen * std::max(smax_entry, 0) + (int64_t)(-sc.gap_extend) * (sweep_steps + G + 2) +
                                   (smax_entry - sc.gap_extend) + 2;
@@ -681,8 +683,9 @@ void lxi::describe_plan(StepPlan const & pl, char * buf, size_t len)
     switch (pl.family)
     {
         case kMqSweep:
-            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %d queries per wavefront%s)", nameC, pl.panels > 1 ? "true" : "false",
-                     8 / std::max(1, pl.share), pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
+            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.panels > 1 ? "true" : "false",
+                     pl.share == 1 ? "free packing: up to " : "", pl.share == 1 ? 4 : 8 / std::max(1, pl.share),
+                     pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
             break;
         case kI16CompactWide:
             snprintf(buf, len, "lx::sweep_pair16_kernel<%d,%d,true,true,true> (single sweep, compact codes; + int32 fix-up lx::ckpt_forward_kernel<%d,%d,false>)",
@@ -1264,6 +1267,8 @@ int lx_plan_step(lx_scoring const * sc, uint64_t max_qlen, uint64_t max_slen, ui
     int const per_wave         = pl.family == lxi::kInt32Sweep ? 64 / G : 2 * (64 / G); // extensions a wavefront holds
     int const share_ext        = pl.family == lxi::kMqSweep ? 2 * pl.share : (pl.family == lxi::kHalfSweep && pl.share) ? 2 * pl.share : per_wave;
     out->queries_per_wavefront = std::max(1, per_wave / std::max(1, share_ext));
+    if (pl.family == lxi::kMqSweep && pl.share == 1)
+        out->queries_per_wavefront = 4; // (free packing: up to four, in any split of the eight lane groups)
     int const pair_cfg         = pl.cfg == 1 ? 0 : pl.cfg == 3 ? 1 : pl.cfg == 4 ? 7 : 5;
     switch (pl.family)
     {

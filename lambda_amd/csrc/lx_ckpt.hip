@@ -1368,6 +1368,17 @@ static hipError_t launch_ckpt_forward_cfg(TraceParams const & p, hipStream_t str
     int const    slots = (Geo::kGroups + share - 1) / share;
     size_t const lds   = ((size_t)slots * (size_t)p.nrows * Geo::kRowDw + 64 * 4) * sizeof(uint32_t);
     bool const multi = p.panels_cap > 1;
+    if (lds > 64 * 1024)
+    {
+        // (profiles shared by pairs only -- the fix-up of the free multi-query packing: four int32 profiles of a 152-column panel
+        // are 68 KB; gfx950 gives a workgroup up to 160 KB, beyond 64 KB on request)
+        hipError_t const ea = multi ? hipFuncSetAttribute(reinterpret_cast<void const *>(&ckpt_forward_kernel<G, C, false, true>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                    : hipFuncSetAttribute(reinterpret_cast<void const *>(&ckpt_forward_kernel<G, C, false, false>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess || p.score_in)
+            return ea != hipSuccess ? ea : hipErrorInvalidValue;
+    }
     if (p.score_in && multi)
         hipLaunchKernelGGL((ckpt_forward_kernel<G, C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else if (p.score_in)

@@ -126,9 +126,63 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         if (lsB != 0)
             sB += x.s_off;
     }
-    // p.pair_share lane groups (0 = all eight) use one LDS profile: the extensions of such a sub-block share the query
-    int const share_g = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
-    int const blk     = grp / share_g;
+    // p.pair_share lane groups (0 = all eight) use one LDS profile: the extensions of such a sub-block share the query.
+    // p.pair_share == 1 is the FREE packing: the two windows of a lane group share a query, the eight lane groups hold windows
+    // of at most kFreeSlots queries in any split (5 + 2 + 1, ...); the queries get their profile slots in order of appearance.
+    constexpr int kFreeSlots = 4;
+    bool const free_mode = p.pair_share == 1;
+    int const  share_g   = free_mode ? Geo::kGroups : (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
+    int        blk       = grp / share_g;
+    // free packing: the wavefront's queries (uniform values) and this lane group's slot among them
+    uint64_t fq[kFreeSlots] = {0, 0, 0, 0};
+    int      fl[kFreeSlots] = {0, 0, 0, 0};
+    int      nfree = 0;
+    bool     too_many = false;
+    if (free_mode)
+    {
+        if (actA && actB && (q_offB != q_off || lqB != lq)) // the pair promise
+            atomicExch(p.err, 2);
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < Geo::kGroups; ++k)
+        {
+            int const      lead = k * G;
+            uint64_t const uq   = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(q_off >> 32), lead) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q_off, lead);
+            int const ul = __builtin_amdgcn_readlane(lq, lead);
+            if (__builtin_amdgcn_readlane(actA ? 1 : 0, lead) == 0)
+                continue; // (uniform) a lane group beyond the list: no query of its own
+            int j = -1;
+#pragma unroll
+            for (int t = 0; t < kFreeSlots; ++t)
+                if (t < nfree && fq[t] == uq && fl[t] == ul)
+                    j = t;
+            if (j < 0)
+            {
+                if (nfree < kFreeSlots)
+                {
+#pragma unroll
+                    for (int t = 0; t < kFreeSlots; ++t)
+                        if (t == nfree)
+                        {
+                            fq[t] = uq;
+                            fl[t] = ul;
+                        }
+                    j = nfree++;
+                }
+                else
+                {
+                    too_many = true; // a fifth query: the promise is broken -- reported, the wavefront left to the int32 launch
+                    j        = 0;
+                }
+            }
+            mine = grp == k ? j : mine;
+        }
+        blk = mine;
+        if (too_many && lane == 0)
+            atomicExch(p.err, 2);
+    }
+    else
     {
         // the caller promised one query per sub-block: verify against the sub-block's first lane, fail loudly otherwise
         int const      leader  = blk * share_g * G;
@@ -174,7 +228,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     for (int off = G / 2; off >= 1; off >>= 1)
         bound += __shfl_xor(bound, off);
     bool const broken  = (lq_max > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > p.steps_cap;
-    bool const too_big = broken || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (MULTI ? kMqLimit : 2046)) != 0 ||
+    // (free packing with a fifth query: declined as a whole -- the int32 launch shares profiles by pairs and copes)
+    bool const too_big = broken || too_many || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (MULTI ? kMqLimit : 2046)) != 0 ||
                          (-ge) * (G + 2) + (-sc->g2) * 2 + 256 > kMqBias;
     if (too_big)
     {
@@ -231,7 +286,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     bool const writable = !MULTI || npanels == 1 || carry != nullptr; // (workspace exhausted: reported, nothing kept)
 
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
-    int const          nslots    = Geo::kGroups / share_g;
+    int const          nslots    = free_mode ? kFreeSlots : Geo::kGroups / share_g;
     uint32_t const     slot_dw   = (uint32_t)blk * (uint32_t)(nrows * Geo::kRowDw);
     uint32_t const     slot_byte = slot_dw * 4u;
     uint64_t const     panel_dw  = L16::slot_dwords(p.steps_cap);
@@ -252,55 +307,71 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             __builtin_amdgcn_wave_barrier(); // (the previous panel's staged codes have left)
             uint32_t * const tab = lds + nslots * (nrows * Geo::kRowDw);
             reinterpret_cast<uint4 *>(tab)[lane] = reinterpret_cast<uint4 const *>(sc->mat_b8)[lane];
-            auto letters = [&](int d) -> uint32_t // the query letters of columns 4d .. 4d+3 of this lane's strip, one per byte
-            {
-                int const j0 = col0 + 4 * d;
-                uint32_t  w  = 0x1f1f1f1fu;
-                if (j0 < lq)
-                    w = *reinterpret_cast<unaligned_u32 const *>(q + j0); // (the residue buffers carry slack behind their end)
-                return w;
-            };
-            uint32_t wcur = letters(0);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            int const r = grp % share_g;
-#pragma unroll 1
-            for (int d = 0; d < Geo::kD; ++d)
+            // one profile: query qp of length lqp into the slot at dword sdw; `share` lane groups write it, this one is number r
+            auto build_profile = [&](uint8_t const * qp, int lqp, uint32_t sdw, int share, int r)
             {
-                uint32_t const wnext = d + 1 < Geo::kD ? letters(d + 1) : 0u;
-                uint32_t       rows[4][8];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
+                auto letters = [&](int d) -> uint32_t // the query letters of columns 4d .. 4d+3 of this lane's strip, one per byte
                 {
-                    int const c  = 4 * d + cc;
-                    int const j  = col0 + c;
-                    uint32_t  ql = kAlph - 1; // pad rank: a row of zeros
-                    if (c < C && j < lq)
-                        ql = (wcur >> (8 * cc)) & (kAlph - 1);
-                    uint4 const * mrow = reinterpret_cast<uint4 const *>(reinterpret_cast<uint8_t const *>(tab) + ql * kAlph);
-                    uint4 const   lo = mrow[0], hi = mrow[1];
-                    rows[cc][0] = lo.x; rows[cc][1] = lo.y; rows[cc][2] = lo.z; rows[cc][3] = lo.w;
-                    rows[cc][4] = hi.x; rows[cc][5] = hi.y; rows[cc][6] = hi.z; rows[cc][7] = hi.w;
-                }
-                wcur = wnext;
-                uint32_t * dst = lds + slot_dw + Geo::dw_index(d, g);
-#pragma unroll
-                for (int w = 0; w < 8; ++w)
+                    int const j0 = col0 + 4 * d;
+                    uint32_t  w  = 0x1f1f1f1fu;
+                    if (j0 < lqp)
+                        w = *reinterpret_cast<unaligned_u32 const *>(qp + j0); // (the residue buffers carry slack behind their end)
+                    return w;
+                };
+                uint32_t wcur = letters(0);
+#pragma unroll 1
+                for (int d = 0; d < Geo::kD; ++d)
                 {
-                    if (4 * w < nrows && (w % share_g) == r)
+                    uint32_t const wnext = d + 1 < Geo::kD ? letters(d + 1) : 0u;
+                    uint32_t       rows[4][8];
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc)
                     {
+                        int const c  = 4 * d + cc;
+                        int const j  = col0 + c;
+                        uint32_t  ql = kAlph - 1; // pad rank: a row of zeros
+                        if (c < C && j < lqp)
+                            ql = (wcur >> (8 * cc)) & (kAlph - 1);
+                        uint4 const * mrow = reinterpret_cast<uint4 const *>(reinterpret_cast<uint8_t const *>(tab) + ql * kAlph);
+                        uint4 const   lo = mrow[0], hi = mrow[1];
+                        rows[cc][0] = lo.x; rows[cc][1] = lo.y; rows[cc][2] = lo.z; rows[cc][3] = lo.w;
+                        rows[cc][4] = hi.x; rows[cc][5] = hi.y; rows[cc][6] = hi.z; rows[cc][7] = hi.w;
+                    }
+                    wcur = wnext;
+                    uint32_t * dst = lds + sdw + Geo::dw_index(d, g);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
+                    for (int w = 0; w < 8; ++w)
+                    {
+                        if (4 * w < nrows && (w % share) == r)
                         {
-                            // byte b of the matrix rows of columns 0..3 -> one dword [c0,c1,c2,c3] for subject letter 4w+b
-                            uint32_t const sel = (uint32_t)b | ((uint32_t)(4 + b) << 8) | 0x0c0c0000u;
-                            uint32_t const x01 = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
-                            uint32_t const x23 = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
-                            dst[(4 * w + b) * Geo::kRowDw] = x01 | (x23 << 16);
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                            {
+                                // byte b of the matrix rows of columns 0..3 -> one dword [c0,c1,c2,c3] for subject letter 4w+b
+                                uint32_t const sel = (uint32_t)b | ((uint32_t)(4 + b) << 8) | 0x0c0c0000u;
+                                uint32_t const x01 = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
+                                uint32_t const x23 = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
+                                dst[(4 * w + b) * Geo::kRowDw] = x01 | (x23 << 16);
+                            }
                         }
                     }
                 }
+            };
+            if (free_mode)
+            {
+                // every query of the wavefront in turn, all eight lane groups on each (group r writes the letters 4r .. 4r+3)
+#pragma unroll 1
+                for (int j = 0; j < nfree; ++j)
+                {
+                    uint64_t const uq = j == 0 ? fq[0] : j == 1 ? fq[1] : j == 2 ? fq[2] : fq[3];
+                    int const      ul = j == 0 ? fl[0] : j == 1 ? fl[1] : j == 2 ? fl[2] : fl[3];
+                    build_profile(p.q_res + uq, ul, (uint32_t)j * (uint32_t)(nrows * Geo::kRowDw), Geo::kGroups, grp);
+                }
             }
+            else
+                build_profile(q, lq, slot_dw, share_g, grp % share_g);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -685,7 +756,7 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
     int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
     if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0)
         return hipErrorInvalidValue;
-    size_t const lds = ((size_t)(Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+    size_t const lds = ((size_t)(p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
     if (p.panels_cap > 1)
         hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
@@ -709,7 +780,7 @@ size_t sweep_mq_lds_bytes(int trace_cfg, int nrows, int share)
 {
     int const C = trace_cfg == 1 ? 19 : trace_cfg == 3 ? 13 : 11;
     int const s = (share > 0 && share < 8) ? share : 8;
-    return ((size_t)(8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
+    return ((size_t)(share == 1 ? 4 : 8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
 }
 
 } // namespace lx

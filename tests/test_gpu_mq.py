@@ -212,3 +212,89 @@ def test_host_plan_on_ragged_lists(handle, oracle, seed, lq_range, merged, nq, c
                (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (i, ext[i])
         st = int(off[i]) + int(g["ops_shift"])
         assert bytes(ops[st: st + oh.n_ops]) == oops, (i, ext[i])
+
+
+def pack_free(ext, rng, max_queries=4):
+    """Slots for LX_OPT_QUERY_RUN = 2, the free packing: the two windows of a lane group (slots 2k, 2k + 1) share a query, a
+    wavefront's 16 slots hold windows of at most four queries in any split; an odd window gets a copy as its partner, a wavefront
+    that meets a fifth query is closed with copies of its last window (src -1 = filler)."""
+    order = np.lexsort((ext["s_len"], ext["q_len"], ext["q_off"]))
+    slots, src = [], []
+    cur = []  # queries of the open wavefront
+
+    def close():
+        while len(slots) % 16:
+            slots.append(slots[-1])
+            src.append(-1)
+        cur.clear()
+
+    k = 0
+    while k < len(order):
+        kk = k
+        while kk < len(order) and ext["q_off"][order[kk]] == ext["q_off"][order[k]] and ext["q_len"][order[kk]] == ext["q_len"][order[k]]:
+            kk += 1
+        key = (int(ext["q_off"][order[k]]), int(ext["q_len"][order[k]]))
+        take = int(rng.integers(1, 14))  # (cut runs at random places: a query may return in a later wavefront)
+        for j in range(k, kk, 2):
+            if len(slots) % 16 == 0:
+                cur.clear()
+            if key not in cur:
+                if len(cur) == max_queries:
+                    close()
+                cur.append(key)
+            pair = list(order[j:min(kk, j + 2)])
+            slots += [ext[i] for i in pair] + [ext[pair[-1]]] * (2 - len(pair))
+            src += [int(i) for i in pair] + [-1] * (2 - len(pair))
+            take -= 1
+            if take == 0 and rng.random() < 0.3:
+                close()
+        k = kk
+    close()
+    return np.array(slots, dtype=ext.dtype), np.array(src)
+
+
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((105, 152), "sweep_mq_kernel<19,false>"),
+                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((60, 456), "sweep_mq_kernel<19,true>")])
+def test_mq_sweep_free_packing(handle, oracle, lq_range, expect):
+    """LX_OPT_QUERY_RUN = 2: pairs of one query, up to four queries per wavefront in any split of its eight lane groups (5 + 2 + 1,
+    7 + 1, ...), profile slots in order of appearance -- what lx_extend_batch's plan streams the windows of a ragged list into."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(60 if lq_range[1] <= 208 else 24, seed=31 + lq_range[0], lq_range=lq_range, mean_windows=4.0, merged_frac=0.15)
+    slots, src = pack_free(ext, np.random.default_rng(lq_range[1]))
+    per_wave = [len({(int(x["q_off"]), int(x["q_len"])) for x in slots[w: w + 16]}) for w in range(0, len(slots), 16)]
+    assert max(per_wave) == 4 and min(per_wave) >= 1 and len(set(per_wave)) >= 3  # one to four queries per wavefront
+    cutoff = 60
+    got = run_fused(handle, q, s, slots, 2, cutoff, mq=1)
+    assert expect in got[5] and "free packing: up to 4 queries per wavefront" in got[5], got[5]
+    # (fillers are copies: they score like their originals; the check is per slot)
+    check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
+
+
+def test_mq_sweep_free_packing_declined_and_broken_promises(handle, oracle):
+    """Free packing: extensions beyond the compact codes go to the int32 launch, which shares its profiles by pairs; a fifth query in
+    a wavefront or a lane group with two queries is a broken promise (LX_ESTATE)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(12, seed=11, lq_range=(230, 300), mean_windows=5.0, merged_frac=0.1)
+    starts = np.unique(ext["q_off"])
+    for k, qo in enumerate(starts):
+        if k % 3 == 0:
+            sel = np.nonzero(ext["q_off"] == qo)[0]
+            L = int(ext["q_len"][sel[0]])
+            q[qo:qo + L] = 22
+            for i in sel[::2]:
+                s[ext["s_off"][i]: ext["s_off"][i] + ext["s_len"][i]] = 22
+    slots, src = pack_free(ext, np.random.default_rng(1))
+    got = run_fused(handle, q, s, slots, 2, 60, mq=1)
+    assert "int32 fix-up" in got[5] and got[0].max() > 2046
+    check_against_oracle(oracle, osc, q, s, slots, 60, *got[:5])
+    q2, s2, e2 = synth.make_batch_np(8, 120, 2, seed=2)  # eight queries, one pair each: five queries in the first wavefront
+    with pytest.raises(capi.LambdaExtError):
+        run_fused(handle, q2, s2, e2, 2, 50, mq=1)
+    e3 = np.concatenate([e2[:4], e2[:4], e2[:4], e2[:4]])
+    e3[1] = e2[5]  # the first lane group names two queries
+    with pytest.raises(capi.LambdaExtError):
+        run_fused(handle, q2, s2, e3, 2, 50, mq=1)
