@@ -273,7 +273,8 @@ int lx_extend_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_b
                     lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
 
 /* The same with the ops in the form they cross PCIe in: run-length codes instead of one byte per column -- one byte per run,
- * (op << 6) | (length - 1) with op 0 = 'M', 1 = 'D', 2 = 'I', runs longer than 64 columns split, begin -> end order.  The codes
+ * (op << 6) | (length - 1) with op 0 = 'M', 1 = 'D', 2 = 'I', runs longer than 64 columns split (the remainder first, then
+ * pieces of 64: one alignment has one code string), begin -> end order.  The codes
  * of a survivor i start at *out_ops + out_ops_off[i] and end where their lengths add up to out_hsp[i].n_ops (the number of
  * alignment columns, as ever); out_hsp[i].ops_shift is 0.  This is what a binding that fills SeqAn's gapped rows wants (ArrayGaps
  * stores run lengths) and what lx_iterate_matches uses; lx_expand_ops turns one survivor's codes into column bytes. */

@@ -936,31 +936,59 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             });
         }
     }
-    // ---- multi-query plan: every run is cut into sub-blocks of 4 windows (the shortest first -- the runs are sorted by window
-    // length), a sub-block's key is (geometry class of its query, its longest window), the sub-blocks of the WHOLE list are
-    // sorted by key (stable LSD radix sort) and dealt four to a wavefront: the windows that share a wavefront take about the
-    // same number of steps whatever their queries, a merged window (up to 3 x longer, src/search_algo.hpp:1153-1157) stretches
-    // only wavefronts of its like, and a query with five windows fills two sub-blocks, not a wavefront.  An incomplete
-    // sub-block is filled with copies of its last window (as the reference pads its SIMD batches, :1063-1067): they cost
-    // what the window costs and never survive (cut-off INT_MAX).
-    constexpr uint64_t kSub = 4;
+    // ---- multi-query plan (free packing of lx_sweep_mq.hip: the two windows of a lane group share a query, a wavefront's 16 slots
+    // hold windows of at most four queries in any split).  Inside a run the windows are sorted by length; those clearly longer than
+    // the run's median -- the merged windows, up to 3 x longer (src/search_algo.hpp:1153-1157) -- go to the POOL in sub-blocks of 4
+    // (filled up with the run's longest ordinary windows), the sub-blocks of the whole list are sorted by (panels, longest window)
+    // and dealt four to a wavefront: a long window stretches three companions, not fifteen.  Everything else is STREAMED: the runs
+    // in order of (panels, ordinary window length), their windows pair by pair into wavefronts that are closed when they hold eight
+    // pairs or meet a fifth query -- the windows of a wavefront take about the same number of steps, and a query with five windows
+    // costs three lane groups, not two sub-blocks.  What is missing to a pair or a wavefront is filled with copies of the last
+    // window (as the reference pads its SIMD batches, :1063-1067): they cost what the window costs and never survive (cut-off
+    // INT_MAX).  The plan is the slot list of the whole call (the caller's index per slot) + panels and longest window per
+    // wavefront; chunks are ranges of wavefronts.
+    constexpr uint64_t kSub = 4, kWave = 16;
+    std::vector<uint32_t> & plan_slot = h->xb_slot, & wf_pan = h->xb_wfpan, & wf_maxs = h->xb_wfmaxs;
     std::vector<uint32_t> & sb_first = h->xb_sbfirst, & sb_key = h->xb_sbkey, & sb_order = h->xb_sborder, & sb_tmp = h->xb_sbtmp;
-    uint64_t nsb = 0;
+    uint64_t nwf = 0;
     hm.mark("classes+sort");
     // ONE strip geometry per call, the one that sweeps the fewest padded columns over the whole list (weighted by the
     // instructions a column costs at that width): every further geometry is a further pair of launches, and the backtrace of a
     // chunk with a few ten thousand survivors is bound by the latency of its longest walks (~1 ms), not by its work -- measured
     // on the ragged list of bench.py: (8,11) + (8,13) + (8,19) chosen per query 28.5 % padded cells but 27-31 ms, one geometry
-    // 34.5 % / 39.9 % padded and 22.7-24.2 ms.  Class of a query = its panel count.  Sort key: most panels first, longest windows
-    // first -- the wavefronts with the most work start first, the chunks with the most survivors are unpacked beside the later
-    // chunks' kernels, and the call ends with a small chunk.
+    // 34.5 % / 39.9 % padded and 22.7-24.2 ms.
     int      mq_cfg   = 1;
     uint64_t mq_cells = 0; // sum q_len * s_len of the list (lx_last_extend_stats)
-    auto mq_class = [&](uint32_t lq) -> uint32_t
+    auto mq_panels = [&](uint32_t lq) -> uint32_t
     {
-        return (uint32_t)std::min<uint64_t>(1023, ((uint64_t)lq + lx::trace_cfg_panel(mq_cfg) - 1) / lx::trace_cfg_panel(mq_cfg));
+        return (uint32_t)std::min<uint64_t>(1023, std::max<uint64_t>(1, ((uint64_t)lq + lx::trace_cfg_panel(mq_cfg) - 1) / lx::trace_cfg_panel(mq_cfg)));
     };
-    auto mq_key_class = [](uint32_t cls) -> uint32_t { return 0xfffu - cls; };
+    std::vector<uint64_t> & pool_at = h->xb_grp; // per run: first position of its pool part
+    std::vector<uint32_t> & run_key = h->xb_runkey, & run_order = h->xb_runorder, & run_tmp = h->xb_runtmp;
+    std::vector<uint8_t> &  sb_cnt = h->xb_sbcnt; // windows of a sub-block (the lowest of a run may have fewer than four)
+    uint64_t nsb = 0, pool_wf = 0;
+    // LSD radix sort by key: three passes of 10 bits (keys have 28)
+    auto radix_sort = [](std::vector<uint32_t> & order, std::vector<uint32_t> & tmp, std::vector<uint32_t> const & key, uint64_t count)
+    {
+        for (int pass = 0; pass < 3; ++pass)
+        {
+            int const shift = 10 * pass;
+            uint32_t  hist[1025] = {0};
+            for (uint64_t o = 0; o < count; ++o)
+                ++hist[((key[order[o]] >> shift) & 1023u) + 1];
+            bool one_bucket = false;
+            for (int bk = 0; bk < 1024; ++bk)
+            {
+                one_bucket = one_bucket || hist[bk + 1] == count;
+                hist[bk + 1] += hist[bk];
+            }
+            if (one_bucket)
+                continue;
+            for (uint64_t o = 0; o < count; ++o)
+                tmp[hist[(key[order[o]] >> shift) & 1023u]++] = order[o];
+            order.swap(tmp);
+        }
+    };
     if (use_mq)
     {
         if (starts.empty())
@@ -975,7 +1003,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 double c[3] = {0, 0, 0};
                                 for (uint64_t r = rlo; r < rhi; ++r)
                                 {
-                                    uint64_t const lq = ext[idx[starts[r]]].q_len, nw = (starts[r + 1] - starts[r] + kSub - 1) / kSub * kSub;
+                                    uint64_t const lq = ext[idx[starts[r]]].q_len, nw = (starts[r + 1] - starts[r] + 1) / 2 * 2;
                                     for (int k = 0; k < 3; ++k)
                                     {
                                         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]);
@@ -1006,66 +1034,189 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             }
         }
         h->mq_cfg_call = mq_cfg;
-        std::vector<uint64_t> sb_off(nruns + 1, 0);
-        for (uint64_t r = 0; r < nruns; ++r)
-            sb_off[r + 1] = sb_off[r] + (starts[r + 1] - starts[r] + kSub - 1) / kSub;
-        nsb = sb_off[nruns];
-        sb_first.resize(nsb);
-        sb_key.resize(nsb);
-        sb_order.resize(nsb);
-        sb_tmp.resize(nsb);
-        std::vector<uint64_t> tcells_plan(nthreads, 0);
+        // (1) per run: where its pool begins (the long windows + what fills their last sub-block up), its sub-blocks, its cells
+        pool_at.assign(nruns, 0);
+        std::vector<uint64_t> sb_off(nruns + 1, 0), tcells_plan(nthreads, 0);
+        run_key.resize(nruns);
         parallel_ranges(nruns, nthreads,
                         [&](unsigned t, uint64_t rlo, uint64_t rhi)
                         {
                             uint64_t cells_t = 0;
                             for (uint64_t r = rlo; r < rhi; ++r)
                             {
-                                uint32_t const cls = mq_key_class(mq_class(ext[idx[starts[r]]].q_len));
-                                uint64_t       o   = sb_off[r];
-                                for (uint64_t k = starts[r]; k < starts[r + 1]; k += kSub, ++o)
-                                {
-                                    uint32_t mx = 0;
-                                    for (uint64_t j = k; j < std::min(starts[r + 1], k + kSub); ++j)
-                                    {
-                                        mx = std::max(mx, ext[idx[j]].s_len);
-                                        cells_t += (uint64_t)ext[idx[j]].q_len * ext[idx[j]].s_len;
-                                    }
-                                    sb_first[o] = (uint32_t)k;
-                                    // (longest first inside a class: the wavefronts that run longest start first, the tail of
-                                    // the launch is made of short ones)
-                                    sb_key[o]   = (cls << 16) | (0xffffu - std::min<uint32_t>(mx, 0xffffu));
-                                }
+                                uint64_t const a = starts[r], b = starts[r + 1];
+                                uint64_t const med = ext[idx[a + (b - a - 1) / 2]].s_len, thr = med + std::max<uint64_t>(8, med / 8);
+                                uint64_t       cut = b; // first long window
+                                while (cut > a && ext[idx[cut - 1]].s_len > thr)
+                                    --cut;
+                                for (uint64_t k = a; k < b; ++k)
+                                    cells_t += (uint64_t)ext[idx[k]].q_len * ext[idx[k]].s_len;
+                                uint64_t const nsb_r = (b - cut + kSub - 1) / kSub;
+                                pool_at[r]           = nsb_r * kSub >= b - a ? a : b - nsb_r * kSub;
+                                sb_off[r + 1]        = nsb_r;
+                                // the streamed part's place in the packing order: most panels first, longest windows first
+                                if (pool_at[r] != a)
+                                    run_key[r] = ((0xfffu - mq_panels(ext[idx[a]].q_len)) << 16) |
+                                                 (0xffffu - std::min<uint32_t>(ext[idx[pool_at[r] - 1]].s_len, 0xffffu));
                             }
                             tcells_plan[t] = cells_t;
                         });
         mq_cells = 0;
         for (uint64_t c : tcells_plan)
             mq_cells += c;
+        for (uint64_t r = 0; r < nruns; ++r)
+            sb_off[r + 1] += sb_off[r];
+        nsb = sb_off[nruns];
+        sb_first.resize(nsb);
+        sb_key.resize(nsb);
+        sb_order.resize(nsb);
+        sb_tmp.resize(nsb);
+        sb_cnt.resize(nsb);
+        // the pool's sub-blocks: sub-block j of a run (0 = its longest windows) = positions [max(pool, b - 4 (j + 1)), b - 4 j)
+        parallel_ranges(nruns, nthreads,
+                        [&](unsigned, uint64_t rlo, uint64_t rhi)
+                        {
+                            for (uint64_t r = rlo; r < rhi; ++r)
+                            {
+                                uint32_t const cls = 0xfffu - mq_panels(ext[idx[starts[r]]].q_len);
+                                uint64_t       e   = starts[r + 1];
+                                for (uint64_t o = sb_off[r]; o < sb_off[r + 1]; ++o)
+                                {
+                                    uint64_t const first = std::max<uint64_t>(pool_at[r], e >= kSub ? e - kSub : 0);
+                                    sb_first[o] = (uint32_t)first;
+                                    sb_cnt[o]   = (uint8_t)(e - first);
+                                    // (most panels first, longest first inside a panel count: the wavefronts that run longest
+                                    // start first, the tail of the launch is made of short ones)
+                                    sb_key[o] = (cls << 16) | (0xffffu - std::min<uint32_t>(ext[idx[e - 1]].s_len, 0xffffu));
+                                    e         = first;
+                                }
+                            }
+                        });
         hm.mark("sub-blocks");
-        // LSD radix sort of the sub-block numbers by key: three passes of 10 bits (keys have 28)
         for (uint64_t o = 0; o < nsb; ++o)
             sb_order[o] = (uint32_t)o;
-        for (int pass = 0; pass < 3; ++pass)
+        radix_sort(sb_order, sb_tmp, sb_key, nsb);
+        // the pool's part of the plan: four sub-blocks per wavefront.  It goes to the GPU first (the chunk loop below) -- the longest
+        // windows of the list -- and the streamed part is planned beside its kernels (plan_stream)
+        pool_wf = (nsb + 3) / 4;
+        nwf     = pool_wf;
+        if (plan_slot.size() < nwf * kWave)
+            plan_slot.resize(nwf * kWave);
+        if (wf_pan.size() < nwf)
         {
-            int const shift = 10 * pass;
-            uint32_t  hist[1025] = {0};
-            for (uint64_t o = 0; o < nsb; ++o)
-                ++hist[((sb_key[sb_order[o]] >> shift) & 1023u) + 1];
-            bool one_bucket = false;
-            for (int b = 0; b < 1024; ++b)
-            {
-                one_bucket = one_bucket || hist[b + 1] == nsb;
-                hist[b + 1] += hist[b];
-            }
-            if (one_bucket)
-                continue;
-            for (uint64_t o = 0; o < nsb; ++o)
-                sb_tmp[hist[(sb_key[sb_order[o]] >> shift) & 1023u]++] = sb_order[o];
-            sb_order.swap(sb_tmp);
+            wf_pan.resize(nwf);
+            wf_maxs.resize(nwf);
         }
+        parallel_ranges(pool_wf, nthreads,
+                        [&](unsigned, uint64_t wlo, uint64_t whi)
+                        {
+                            for (uint64_t w = wlo; w < whi; ++w)
+                            {
+                                uint32_t pan = 0, maxs = 0;
+                                for (uint64_t o = 4 * w; o < 4 * w + 4; ++o)
+                                {
+                                    // (a wavefront that the pool cannot fill repeats its last sub-block as fillers)
+                                    bool const     real  = o < nsb;
+                                    uint32_t const sb    = sb_order[std::min(o, nsb - 1)];
+                                    uint64_t const first = sb_first[sb], cnt = sb_cnt[sb];
+                                    // (the longest window first, like the streamed pairs; the last one is repeated as filler)
+                                    for (uint64_t j = 0; j < kSub; ++j)
+                                        plan_slot[w * kWave + (o - 4 * w) * kSub + j] =
+                                          idx[first + cnt - 1 - std::min(j, cnt - 1)] | ((real && j < cnt) ? 0u : 0x80000000u);
+                                    pan  = std::max(pan, 0xfffu - (sb_key[sb] >> 16));
+                                    for (uint64_t j = 0; j < cnt; ++j)
+                                        maxs = std::max(maxs, ext[idx[first + j]].s_len);
+                                }
+                                wf_pan[w]  = pan;
+                                wf_maxs[w] = maxs;
+                            }
+                        });
+        hm.mark("pool");
     }
-    hm.mark("plan-sort");
+    // (2) the streamed part: runs in order of (panels, ordinary window length), most panels and longest first
+    auto plan_stream = [&]()
+    {
+        uint64_t const nruns = starts.size() - 1;
+        run_order.resize(nruns);
+        run_tmp.resize(nruns);
+        uint64_t nstream_runs = 0;
+        for (uint64_t r = 0; r < nruns; ++r)
+            if (pool_at[r] != starts[r]) // (else the whole run stands in the pool)
+                run_order[nstream_runs++] = (uint32_t)r;
+        radix_sort(run_order, run_tmp, run_key, nstream_runs);
+        // every thread packs a contiguous share of the sorted runs into wavefronts of its own (a share starts a new wavefront):
+        // once to count them, once -- the offsets known -- to write the plan
+        std::vector<uint64_t> wf_at(nthreads + 1, pool_wf);
+        auto pack = [&](uint64_t lo, uint64_t hi, uint32_t * out_slot, uint32_t * out_pan, uint32_t * out_maxs) -> uint64_t
+        {
+            uint32_t wq[4] = {0, 0, 0, 0}; // runs of the open wavefront
+            uint32_t nq = 0, npairs = 0, pan = 0, maxs = 0, last = 0;
+            uint64_t done = 0;             // wavefronts closed
+            auto close = [&]()
+            {
+                if (npairs == 0)
+                    return;
+                if (out_slot)
+                {
+                    for (uint32_t k = 2 * npairs; k < kWave; ++k)
+                        out_slot[done * kWave + k] = last | 0x80000000u;
+                    out_pan[done]  = pan;
+                    out_maxs[done] = maxs;
+                }
+                ++done;
+                nq = npairs = pan = maxs = 0;
+            };
+            for (uint64_t x = lo; x < hi; ++x)
+            {
+                uint32_t const r  = run_order[x];
+                uint32_t const rp = 0xfffu - (run_key[r] >> 16);
+                // (longest first: the order descends over the runs, so it does inside one)
+                for (uint64_t e = pool_at[r]; e > starts[r];)
+                {
+                    if (npairs == kWave / 2)
+                        close();
+                    bool known = false;
+                    for (uint32_t k = 0; k < nq; ++k)
+                        known = known || wq[k] == r;
+                    if (!known)
+                    {
+                        if (nq == 4)
+                            close();
+                        wq[nq++] = r;
+                    }
+                    bool const two = e - 1 > starts[r];
+                    if (out_slot)
+                    {
+                        uint32_t const i0 = idx[e - 1], i1 = two ? idx[e - 2] : (i0 | 0x80000000u);
+                        out_slot[done * kWave + 2 * npairs]     = i0;
+                        out_slot[done * kWave + 2 * npairs + 1] = i1;
+                        last = i1;
+                        maxs = std::max(maxs, ext[i0].s_len);
+                        pan  = std::max(pan, rp);
+                    }
+                    ++npairs;
+                    e -= two ? 2 : 1;
+                }
+            }
+            close();
+            return done;
+        };
+        parallel_ranges(nstream_runs, nthreads, [&](unsigned t, uint64_t lo, uint64_t hi) { wf_at[t + 1] = pack(lo, hi, nullptr, nullptr, nullptr); });
+        for (unsigned t = 0; t < nthreads; ++t)
+            wf_at[t + 1] += wf_at[t];
+        nwf = wf_at[nthreads];
+        if (plan_slot.size() < nwf * kWave)
+            plan_slot.resize(nwf * kWave);
+        if (wf_pan.size() < nwf)
+        {
+            wf_pan.resize(nwf);
+            wf_maxs.resize(nwf);
+        }
+        parallel_ranges(nstream_runs, nthreads,
+                        [&](unsigned t, uint64_t lo, uint64_t hi)
+                        { (void)pack(lo, hi, plan_slot.data() + wf_at[t] * kWave, wf_pan.data() + wf_at[t], wf_maxs.data() + wf_at[t]); });
+    };
+    hm.mark("plan");
 
     // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
     struct Guard
@@ -1263,18 +1414,18 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         return launch_chunk(L, slots, max_q, max_s, kRun);
     };
 
-    // ---- sub-blocks o0 .. o1 of the sorted plan -> the slots' caller indices in lane L's pinned staging -> upload, gather of the
-    // slot records on the device, kernels, scatter of the scores into caller order.  The plan's order is a permutation of the
-    // caller's list: the host only touches 4 bytes per slot here (the 24-byte records and their cut-offs are gathered from the
+    // ---- wavefronts w0 .. w1 of the plan -> the slots' caller indices in lane L's pinned staging -> upload, gather of the slot
+    // records on the device, kernels, scatter of the scores into caller order.  The plan's order is a permutation of the caller's
+    // list (+ fillers): the host only touches 4 bytes per slot here (the 24-byte records and their cut-offs are gathered from the
     // device copy of the list at HBM speed, not by cache misses of a few host threads).
-    auto enqueue_mq = [&](int L, uint64_t o0, uint64_t o1) -> int
+    auto enqueue_mq = [&](int L, uint64_t w0, uint64_t w1) -> int
     {
         auto const          t0 = now();
         lx_handle::XbLane & ln = h->xb[L];
         XbPrep &            pr = prep[L];
-        pr.k0 = o0;
-        pr.k1 = o1;
-        uint64_t const slots = (o1 - o0) * kSub;
+        pr.k0 = w0;
+        pr.k1 = w1;
+        uint64_t const slots = (w1 - w0) * kWave;
         pr.slots   = slots;
         pr.cap_sel = (slots + 7) / 8 * 8 + 8;
         int rc2;
@@ -1282,52 +1433,34 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             return rc2;
         uint32_t * const slot_orig = static_cast<uint32_t *>(ln.p_orig.ptr);
         uint64_t const   panel     = (uint64_t)lx::trace_cfg_panel(mq_cfg);
-        std::vector<uint64_t> tpad(nthreads, 0), tmaxs(nthreads, 1);
-        // whole wavefronts (four sub-blocks) per thread share, so that the executed-cells estimate sees each wavefront once: a
-        // wavefront sweeps as many panels as its widest query needs, each for as many steps as its longest window has rows --
-        // the panels are its FIRST sub-block's (the order descends), the rows the largest of its four (a wavefront may straddle
-        // two panel counts); both are in the sort key
-        parallel_ranges((o1 - o0 + 3) / 4, nthreads,
+        std::vector<uint64_t> tpad(nthreads, 0), tmaxs(nthreads, 1), tpan(nthreads, 1);
+        // (what the wavefronts execute: every one sweeps as many panels as its widest query needs, each for as many steps as its
+        // longest window has rows)
+        parallel_ranges(w1 - w0, nthreads,
                         [&](unsigned t, uint64_t wlo, uint64_t whi)
                         {
-                            uint64_t padded = 0, smax = 1; // (locals: the per-thread slots share cache lines)
-                            for (uint64_t w = wlo; w < whi; ++w)
+                            uint64_t padded = 0, smax = 1, pmax = 1; // (locals: the per-thread slots share cache lines)
+                            std::memcpy(slot_orig + wlo * kWave, plan_slot.data() + (w0 + wlo) * kWave, (whi - wlo) * kWave * sizeof(uint32_t));
+                            for (uint64_t w = w0 + wlo; w < w0 + whi; ++w)
                             {
-                                uint64_t wmax = 0;
-                                for (uint64_t o = o0 + 4 * w; o < std::min(o1, o0 + 4 * w + 4); ++o)
-                                {
-                                    uint32_t const sb    = sb_order[o];
-                                    wmax                 = std::max<uint64_t>(wmax, 0xffffu - (sb_key[sb] & 0xffffu));
-                                    uint64_t const first = sb_first[sb];
-                                    uint64_t       cnt   = 1;
-                                    while (cnt < kSub && !newrun[first + cnt])
-                                        ++cnt;
-                                    uint64_t const so = (o - o0) * kSub;
-                                    for (uint64_t j = 0; j < kSub; ++j)
-                                        slot_orig[so + j] = idx[first + std::min(j, cnt - 1)] | (j < cnt ? 0u : 0x80000000u);
-                                }
-                                uint32_t const key = sb_key[sb_order[o0 + 4 * w]];
-                                padded += 16 * ((uint64_t)(0xfffu - (key >> 16)) * panel) * (wmax + 7);
-                                smax = std::max(smax, wmax);
+                                padded += kWave * ((uint64_t)wf_pan[w] * panel) * ((uint64_t)wf_maxs[w] + 7);
+                                smax = std::max<uint64_t>(smax, wf_maxs[w]);
+                                pmax = std::max<uint64_t>(pmax, wf_pan[w]);
                             }
                             tpad[t]  = padded;
                             tmaxs[t] = smax;
+                            tpan[t]  = pmax;
                         });
-        uint64_t max_s = 1;
+        // the promises of the chunk: its widest query (as a panel count) and its longest window
+        uint64_t max_s = 1, max_pan = 1;
         for (unsigned t = 0; t < nthreads; ++t)
         {
             h->xb_stats[3] += tpad[t];
-            max_s = std::max(max_s, tmaxs[t]);
+            max_s   = std::max(max_s, tmaxs[t]);
+            max_pan = std::max(max_pan, tpan[t]);
         }
         h->xb_stats[1] += slots;
-        // the promises of the chunk: its first sub-block's panel count (as a query width), the longest window of any sub-block
-        uint32_t const key0  = sb_key[sb_order[o0]];
-        uint64_t const max_q = (uint64_t)(0xfffu - (key0 >> 16)) * panel;
-        if (max_s >= 0xffffu) // (keys clamp at 65 535 rows: the true lengths then)
-            for (uint64_t o = o0; o < o1; ++o)
-                if ((sb_key[sb_order[o]] & 0xffffu) == 0)
-                    for (uint64_t j = sb_first[sb_order[o]], c = 0; c < kSub && (c == 0 || !newrun[j]); ++j, ++c)
-                        max_s = std::max<uint64_t>(max_s, ext[idx[j]].s_len);
+        uint64_t const max_q = max_pan * panel;
         t_prep += ms(t0, now());
 
         auto const t1 = now();
@@ -1347,7 +1480,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                          static_cast<int32_t *>(ln.d_min.ptr), h->stream));
         h->opt_max_qlen  = max_q;
         h->opt_max_slen  = max_s;
-        h->opt_query_run = kSub;
+        h->opt_query_run = 2; // (the free packing: pairs of one query, at most four queries per wavefront)
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
         fx.ops_stride = stride;
@@ -1693,12 +1826,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     int      c  = 0;
     if (use_mq)
     {
-        // chunks = ranges of the sorted sub-blocks, about chunk_target slots, whole wavefronts.  A chunk may span panel counts
-        // (its slots are sized for its widest query, its narrower queries run the multi-panel kernel over one panel): a chunk
-        // boundary wherever the panel count changes was measured on the ragged list of bench.py and costs more than it saves
-        // -- 3 chunks 20.8 ms, 2 chunks 18.9 ms: every chunk pays the fixed cost of a backtrace launch (~0.5-1 ms), the
-        // single-panel kernel saves a tenth of a 0.8 ms sweep
-        uint64_t const per_chunk = std::max<uint64_t>(4, chunk_target / kSub / 4 * 4);
+        // chunks = ranges of the plan's wavefronts, about chunk_target slots.  A chunk may span panel counts (its slots are sized
+        // for its widest query, its narrower queries run the multi-panel kernel over one panel): a chunk boundary wherever the
+        // panel count changes was measured on the ragged list of bench.py and costs more than it saves -- 3 chunks 20.8 ms,
+        // 2 chunks 18.9 ms: every chunk pays the fixed cost of a backtrace launch (~0.5-1 ms), the single-panel kernel saves a
+        // tenth of a 0.8 ms sweep
+        uint64_t const per_chunk = std::max<uint64_t>(1, chunk_target / kWave);
         h->xb_stats[2] = mq_cells;
         // the caller's list and cut-offs onto the device (pinned staging, filled by the pool), scores in caller order zeroed
         {
@@ -1722,42 +1855,40 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
             t_prep += ms(tu0, now());
         }
-        bool     rows_cleared = false;
-        uint64_t o0           = 0;
-        while (o0 < nsb)
+        bool     rows_cleared = false, stream_planned = false;
+        uint64_t w0           = 0;
+        for (;;)
         {
-            // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is
-            // sized for the chunk's widest query and longest window, which are its FIRST sub-block's (the order descends), plus
-            // room for the int32 overflow slots of what the sweep may decline
-            uint64_t cap_sb = per_chunk;
+            if (w0 >= nwf)
             {
-                uint32_t const key0 = sb_key[sb_order[o0]];
-                uint64_t       smax = 1; // (the classes of a chunk descend in panels, not in rows: the longest window of the range)
-                for (uint64_t o = o0; o < std::min(nsb, o0 + per_chunk);)
-                {
-                    uint32_t const c_at = sb_key[sb_order[o]] >> 16;
-                    smax                = std::max<uint64_t>(smax, 0xffffu - (sb_key[sb_order[o]] & 0xffffu)); // first of its class = its longest
-                    uint64_t lo = o, hi = std::min(nsb, o0 + per_chunk);
-                    if ((sb_key[sb_order[hi - 1]] >> 16) == c_at)
-                        break;
-                    --hi;
-                    while (hi - lo > 1)
-                    {
-                        uint64_t const mid = lo + (hi - lo) / 2;
-                        ((sb_key[sb_order[mid]] >> 16) == c_at ? lo : hi) = mid;
-                    }
-                    o = hi;
-                }
-                uint64_t const panels = std::max<uint64_t>(1, 0xfffu - (key0 >> 16)), steps = (smax + 8 - 1 + 15) & ~15ull;
-                uint64_t const stride = panels * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
-                uint64_t const fit    = h->opt_trace_bytes / std::max<uint64_t>(stride, 1) / kSub;
-                cap_sb                = std::max<uint64_t>(4, std::min(per_chunk, fit / 4 * 4));
+                // the pool's wavefronts are queued (or there are none): the streamed part of the plan is made now, beside their kernels
+                if (stream_planned)
+                    break;
+                auto const tp0 = now();
+                plan_stream();
+                stream_planned = true;
+                t_prep += ms(tp0, now());
+                continue;
             }
-            uint64_t       o1   = std::min(nsb, o0 + cap_sb);
+            // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is sized
+            // for the chunk's widest query and longest window, plus room for the int32 overflow slots of what the sweep may
+            // decline -- the chunk ends where one more wavefront would break the budget
+            uint64_t w1 = w0, pmax = 1, smax = 1;
+            while (w1 < nwf && w1 - w0 < per_chunk)
+            {
+                uint64_t const p2 = std::max<uint64_t>(pmax, wf_pan[w1]), s2 = std::max<uint64_t>(smax, wf_maxs[w1]);
+                uint64_t const steps  = (s2 + 8 - 1 + 15) & ~15ull;
+                uint64_t const stride = p2 * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
+                if (w1 > w0 && (w1 + 1 - w0) * kWave * stride > h->opt_trace_bytes)
+                    break;
+                pmax = p2;
+                smax = s2;
+                ++w1;
+            }
             int const L = c & 1;
             if (in_flight[L] && (rc = collect_mq(L)))
                 return rc;
-            if ((rc = enqueue_mq(L, o0, o1)))
+            if ((rc = enqueue_mq(L, w0, w1)))
                 return rc;
             if (!rows_cleared && !as_list)
             {
@@ -1775,7 +1906,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             }
             if (in_flight[L ^ 1] && (rc = collect_mq(L ^ 1)))
                 return rc;
-            o0 = o1;
+            w0 = w1;
             ++c;
         }
         for (int L : {c & 1, (c & 1) ^ 1})

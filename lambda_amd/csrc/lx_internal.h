@@ -89,7 +89,10 @@ struct lx_handle
     std::vector<uint8_t>      xb_newrun;
     uint64_t                  xb_stats[4] = {0, 0, 0, 0}; // lx_extend_batch: extensions, slots, cells, cells executed (padding included)
     std::vector<uint64_t>     xb_grp, xb_off, xb_starts;
-    std::vector<uint32_t>     xb_sbfirst, xb_sbkey, xb_sborder, xb_sbtmp; // multi-query plan: sub-blocks of 4 windows
+    std::vector<uint32_t>     xb_sbfirst, xb_sbkey, xb_sborder, xb_sbtmp; // multi-query plan: the pool's sub-blocks of 4 windows
+    std::vector<uint8_t>      xb_sbcnt;
+    std::vector<uint32_t>     xb_runkey, xb_runorder, xb_runtmp;          // ... the streamed runs in packing order
+    std::vector<uint32_t>     xb_slot, xb_wfpan, xb_wfmaxs;               // ... the plan: caller index per slot, panels / longest window per wavefront
     std::vector<lx_extension> xb_ext;
     std::vector<int32_t>      xb_min, xb_score;
     std::vector<uint8_t> ext_ops; // band mode: the ops of the last lx_extend_batch call (handed out by pointer)

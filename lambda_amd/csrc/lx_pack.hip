@@ -3,7 +3,7 @@
 // The backtrace kernels write one op byte per alignment column ('M', 'D', 'I') into worst-case slots of q_len + s_len
 // bytes: 326 B per 150 x 176 extension, of which an alignment has a handful of runs.  What crosses PCIe in
 // lx_extend_batch is therefore the run-length form: one byte per run, (op << 6) | (length - 1) with op 0 = 'M',
-// 1 = 'D', 2 = 'I', runs longer than 64 columns split -- begin -> end order, the n_ops of the record say where a
+// 1 = 'D', 2 = 'I', runs longer than 64 columns split (remainder first) -- begin -> end order, the n_ops of the record say where a
 // survivor's codes end.  One lane per survivor: two passes over its op bytes (count the codes; write them), space in the
 // dense code stream handed out per wavefront (one atomic per wavefront), the record's ops_shift becomes the offset of
 // the survivor's first code in that stream.  The gapped rows the reference keeps after _adaptTraceSegmentsTo
@@ -78,20 +78,23 @@ __global__ __launch_bounds__(256) void rle_pack_kernel(PackParams p)
         }
         else
         {
-            uint8_t * out = p.rle + at;
-            uint32_t  cur = ops[0], len = 0;
-            for (int32_t k = 0; k < h.n_ops; ++k)
+            // written back to front, so that a run of more than 64 columns is cut where the checkpoint backtrace cuts it (it
+            // walks end -> begin and emits codes itself: the remainder comes first, the 64s behind it) -- one alignment, one code
+            // string, whichever pass-2 mode produced it
+            uint8_t * out = p.rle + at + ncodes;
+            uint32_t  cur = ops[h.n_ops - 1], len = 0;
+            for (int32_t k = h.n_ops - 1; k >= 0; --k)
             {
                 uint32_t const op = ops[k];
                 if (op != cur || len == 64)
                 {
-                    *out++ = (uint8_t)((op_code(cur) << 6) | (len - 1));
+                    *--out = (uint8_t)((op_code(cur) << 6) | (len - 1));
                     cur    = op;
                     len    = 0;
                 }
                 ++len;
             }
-            *out = (uint8_t)((op_code(cur) << 6) | (len - 1));
+            *--out = (uint8_t)((op_code(cur) << 6) | (len - 1));
         }
     }
     h.ops_shift = (int32_t)(uint32_t)at; // (a chunk's stream stays far below 2^31 bytes)
