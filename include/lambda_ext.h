@@ -106,8 +106,10 @@ char const * lx_last_error(lx_handle const * h); /* h may be NULL: error of the 
  *   LX_OPT_MAX_QLEN        longest query slice the *_dev calls will see (0 = unknown -> generic geometry)
  *   LX_OPT_QUERY_RUN       promise for the *_dev calls: extensions come in runs of this many consecutive entries
  *                          that share one query slice (a multiple of 8, or 4 for the multi-query sweep; 0 = no promise).  Lets a wavefront
- *                          build one LDS profile instead of one per extension.  A violated promise is detected on
- *                          the device and reported as LX_ESTATE by lx_synchronize().
+ *                          build one LDS profile instead of one per extension.  2 = the multi-query sweep's free packing:
+ *                          entries 2k and 2k + 1 share a query slice and every aligned block of 16 entries holds windows of
+ *                          at most four query slices, in any split (what lx_extend_batch streams a ragged list into).  A
+ *                          violated promise is detected on the device and reported as LX_ESTATE by lx_synchronize().
  *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB; with
  *                          LX_OPT_MAX_SLEN set it grows by itself to 8 bytes per subject row of the batch)
  *   (LX_OPT_BS_MATCH_RULE is the one option that is not a tuning knob: it selects which of the reference's two
@@ -139,7 +141,7 @@ enum
     LX_OPT_EXTEND_CHUNK    = 10, /* extensions per chunk of lx_extend_batch's pipeline (0 = default, ~640 k; at least 1024):
                                    smaller chunks start returning results earlier, larger ones amortise the per-chunk launches */
     LX_OPT_MQ_SWEEP        = 11, /* multi-query single sweep (ragged seed lists: up to four queries per wavefront, byte profiles
-                                   in LDS): 1 (default) = where LX_OPT_QUERY_RUN is 4 or 8 -- which is what lx_extend_batch
+                                   in LDS): 1 (default) = where LX_OPT_QUERY_RUN is 2, 4 or 8 -- 2 is what lx_extend_batch
                                    makes of a list whose queries have few windows each; 2 = for every run that is a multiple
                                    of 4; 0 = never (runs of 8 / 16 on the one-query-per-wavefront kernels).  Needs what the
                                    single sweep needs and a scheme in which no substitution costs more than a gap's first
@@ -262,9 +264,10 @@ int lx_extend_batch_dev(lx_handle * h, int slot, void const * d_q_res, void cons
  * processed as a pipeline of chunks (uploads, kernels, downloads and the host's share overlap); only scores, the
  * survivors' records and their run-length coded ops cross PCIe.  A list that is not uniform -- what
  * _widenAndPreprocessMatches really hands over: queries of mixed lengths, a few windows each, merged windows of up to three
- * times the length (:1136-1175) -- is planned for the multi-query sweep (LX_OPT_MQ_SWEEP): sub-blocks of 4 windows of one
- * query, sorted by length across queries, four sub-blocks to a wavefront; the records are gathered from a device copy of the
- * list and the scores scattered back into the caller's order on the device.  lx_last_extend_stats() reports extensions,
+ * times the length (:1136-1175) -- is planned for the multi-query sweep (LX_OPT_MQ_SWEEP): a wavefront's 16 slots hold windows
+ * of up to four queries, the long (merged) windows of the list pooled in sub-blocks of 4 and dealt by length, the others
+ * streamed pair by pair in order of length; the records are gathered from a device copy of the list and the scores scattered
+ * back into the caller's order on the device.  lx_last_extend_stats() reports extensions,
  * slots, cells and the cells the wavefronts executed (padding included) of the last call.
  * Throughput depends on the batch size -- a call has a fixed cost of ~0.7 ms (INTEGRATION.md has the curve): hand over the
  * windows of at least ~1 000 queries per call. */
