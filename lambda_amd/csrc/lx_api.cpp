@@ -46,6 +46,7 @@ lx::DevAids const & lx::dev_aids()
         a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
         a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
+        a.mq_no_narrow      = set("LX_MQ_NO_NARROW");
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
@@ -816,6 +817,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.pair_share  = sweep_share;
             if (mq)
             {
+                sp1.narrow     = lx::dev_aids().mq_no_narrow ? 0 : 1;
                 sp1.ws         = p.ws;
                 sp1.ws_top     = p.ws_top;
                 sp1.ws_cap     = p.ws_cap;

@@ -603,6 +603,27 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     int              lq = 0, ls = 0;
     int              i = 0, j = 0, end_i = 0, end_j = 0;
     int              res_col = C, res_row = 0x7fffffff; // resolution of the end cell inside the first tile
+    // The multi-query sweep may run an extension's LAST panel with narrower strips (kEndNarrowShift): columns from nar_j0 on
+    // lie in strips of nar_cw columns, strip nar_st0 first.  Panel starts, strip numbering and the row grids are as ever.
+    int              nar_cw = C, nar_j0 = 0x7fffffff, nar_st0 = 0x7fffffff;
+    // strip, first column and width of the strip that holds column aj
+    auto locate = [&](int aj, int & st, int & j0, int & cw)
+    {
+        if (aj >= nar_j0)
+        {
+            int const jl = aj - nar_j0;
+            int const gl = nar_cw == (C + 1) / 2 ? jl / ((C + 1) / 2) : jl / ((C + 3) / 4);
+            st = nar_st0 + gl;
+            j0 = nar_j0 + gl * nar_cw;
+            cw = nar_cw;
+        }
+        else
+        {
+            st = aj / C;
+            j0 = st * C;
+            cw = C;
+        }
+    };
     int              mode = 0;                          // 0 = H, 1 = F (vertical), 2 = E (horizontal)
     int              left = 0;
     int32_t          nm = 0, nx = 0, np = 0, go = 0, gx = 0;
@@ -716,11 +737,19 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         j                  = ec.q_end - 1;
         // single-sweep mode: only the strip of the end cell is known (ec.q_end = -(strip + 1)).  The column is read off the
         // first tile (its last computed rows hold the end row), unless the strip reached the best score in ...
+        {
+            int const code = (ec.flags >> kEndNarrowShift) & 3;
+            int const last = max(1, (lq + G * C - 1) / (G * C)) - 1; // the extension's last panel
+            nar_cw  = narrow_strip_cols(C, code);
+            nar_j0  = code ? last * (G * C) : 0x7fffffff;
+            nar_st0 = code ? last * G : 0x7fffffff;
+        }
         need_col = ec.q_end < 0;
         if (need_col)
         {
             int const st = -ec.q_end - 1;
-            j            = st * C + (C - 1); // provisional: the whole strip is computed
+            // provisional: the whole strip is computed
+            j = st >= nar_st0 ? nar_j0 + (st - nar_st0) * nar_cw + (nar_cw - 1) : st * C + (C - 1);
             // ... several rows: the tile phases scan the strip from the step block of the first such row to its end
             // (scan mode: one block per phase, in step with the tiles of the other lanes), keeping the lowest column
             // and, for it, the lowest row
@@ -1029,7 +1058,9 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
                 {
                     bool const on = ci >= 0 && cj >= 0;
                     int const ai = max(ci, 0), aj = max(cj, 0);
-                    int const st = aj / C, j0 = st * C, c = aj - j0;
+                    int st, j0, cw;
+                    locate(aj, st, j0, cw);
+                    int const c  = aj - j0;
                     int const gl = st % G;
                     int const m  = (ai + gl) / kCkptEvery;
                     int const r_base = m * kCkptEvery - gl;       // row of tile row 0
@@ -1058,7 +1089,8 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         if (tile_need)
         {
         // ---- the tile of the current cell: strip st, step block m (step k = row + strip)
-        int const st = j / C, j0 = st * C;
+        int st, j0, cw; // (cw: columns of the strip that are real -- the others are treated like columns beyond the query)
+        locate(j, st, j0, cw);
         int const pn = st / G, gl = st % G; // panel and lane of this strip (one panel: gl = st)
         int const m  = (i + gl) / kCkptEvery;
         int const k_base = m * kCkptEvery;  // first step of the block
@@ -1123,7 +1155,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
 #pragma unroll
             for (int c = 0; c < C; ++c)
             {
-                uint32_t const r = (j0 + c < lq) ? ((qd[c >> 2] >> (8 * (c & 3))) & (kAlph - 1)) : (uint32_t)(kAlph - 1);
+                uint32_t const r = (c < cw && j0 + c < lq) ? ((qd[c >> 2] >> (8 * (c & 3))) & (kAlph - 1)) : (uint32_t)(kAlph - 1);
                 qoff2[c >> 1]    = (c & 1) ? (qoff2[c >> 1] | ((r * kAlph) << 16)) : r * kAlph;
             }
         }

@@ -76,6 +76,7 @@ struct ScoreParams
     int32_t            nrows;          // profile rows = alph + 1 (host copy of sc->alph + 1, sizes the LDS slot)
     int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
     int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
+    int32_t            narrow;         // multi-query sweep: 1 = a query's last panel may run narrower strips (kEndNarrowShift)
     // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
     // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
     uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)
@@ -99,6 +100,16 @@ struct EndCell
 constexpr int32_t kEndAmbiguous = 1;
 constexpr int32_t kEndCompact      = 2; // the slot was written by the packed-half sweep: compact 16-bit codes (Ckpt16Layout)
 constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extension's slot in the overflow area (0 = none)
+// (flags >> 2) & 3: the strips of the extension's LAST panel are C (0), (C + 1) / 2 (1) or (C + 3) / 4 (2) columns wide -- the
+// multi-query sweep runs a query's last panel with narrower strips when that covers what is left of the query (a query of 160
+// columns sweeps 152 + 8 * 5 = 192 columns, not 304); the backtrace maps columns to strips accordingly.  Panel starts do not move.
+constexpr int     kEndNarrowShift   = 2;
+__host__ __device__ constexpr int narrow_strip_cols(int C, int code) { return code == 0 ? C : code == 1 ? (C + 1) / 2 : (C + 3) / 4; }
+// the code for a panel that has `rem` columns of the query left (rem >= 1), G lanes per group
+__host__ __device__ constexpr int narrow_code_for(int C, int G, int rem)
+{
+    return rem <= G * ((C + 3) / 4) ? 2 : rem <= G * ((C + 1) / 2) ? 1 : 0;
+}
 
 // Compact checkpoint slots of the packed-half single sweep (lx_score_f16.hip writes, lx_ckpt.hip's backtrace reads).
 // A boundary pair (H of a strip's last column, E entering the next strip) and a row-checkpoint pair (H of a cell, the

@@ -948,7 +948,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // INT_MAX).  The plan is the slot list of the whole call (the caller's index per slot) + panels and longest window per
     // wavefront; chunks are ranges of wavefronts.
     constexpr uint64_t kSub = 4, kWave = 16;
-    std::vector<uint32_t> & plan_slot = h->xb_slot, & wf_pan = h->xb_wfpan, & wf_maxs = h->xb_wfmaxs;
+    std::vector<uint32_t> & plan_slot = h->xb_slot, & wf_pan = h->xb_wfpan, & wf_maxs = h->xb_wfmaxs; // (wf_pan: columns per lane)
     std::vector<uint32_t> & sb_first = h->xb_sbfirst, & sb_key = h->xb_sbkey, & sb_order = h->xb_sborder, & sb_tmp = h->xb_sbtmp;
     uint64_t nwf = 0;
     hm.mark("classes+sort");
@@ -959,9 +959,16 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // 34.5 % / 39.9 % padded and 22.7-24.2 ms.
     int      mq_cfg   = 1;
     uint64_t mq_cells = 0; // sum q_len * s_len of the list (lx_last_extend_stats)
+    // columns per lane a query sweeps over all its panels (its class in the plan's keys; what a wavefront executes is 8 of them per
+    // step): whole panels, the last one with the narrowest strips that cover what is left (lx_device.h: narrow_code_for)
     auto mq_panels = [&](uint32_t lq) -> uint32_t
     {
-        return (uint32_t)std::min<uint64_t>(1023, std::max<uint64_t>(1, ((uint64_t)lq + lx::trace_cfg_panel(mq_cfg) - 1) / lx::trace_cfg_panel(mq_cfg)));
+        int const      C     = lx::trace_cfg_panel(mq_cfg) / 8;
+        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(mq_cfg);
+        uint64_t const P     = std::max<uint64_t>(1, ((uint64_t)lq + panel - 1) / panel);
+        int const      rem   = (int)((uint64_t)std::max<uint32_t>(lq, 1) - (P - 1) * panel);
+        int const      code  = lx::dev_aids().mq_no_narrow ? 0 : lx::narrow_code_for(C, 8, rem);
+        return (uint32_t)std::min<uint64_t>(0xfff, (P - 1) * (uint64_t)C + (uint64_t)lx::narrow_strip_cols(C, code));
     };
     std::vector<uint64_t> & pool_at = h->xb_grp; // per run: first position of its pool part
     std::vector<uint32_t> & run_key = h->xb_runkey, & run_order = h->xb_runorder, & run_tmp = h->xb_runtmp;
@@ -1006,8 +1013,11 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     uint64_t const lq = ext[idx[starts[r]]].q_len, nw = (starts[r + 1] - starts[r] + 1) / 2 * 2;
                                     for (int k = 0; k < 3; ++k)
                                     {
-                                        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]);
-                                        c[k] += (double)nw * (double)((lq + panel - 1) / panel * panel);
+                                        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]), P = std::max<uint64_t>(1, (lq + panel - 1) / panel);
+                                        int const      Cc = (int)panel / 8, rem = (int)(std::max<uint64_t>(lq, 1) - (P - 1) * panel);
+                                        int const      code = lx::dev_aids().mq_no_narrow ? 0 : lx::narrow_code_for(Cc, 8, rem);
+                                        // (a step costs 3.75 instructions per column and 12 besides, whatever the strip width)
+                                        c[k] += (double)nw * ((double)(P - 1) * (3.75 * Cc + 12.0) + 3.75 * lx::narrow_strip_cols(Cc, code) + 12.0);
                                     }
                                 }
                                 for (int k = 0; k < 3; ++k)
@@ -1020,8 +1030,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 double c = 0;
                 for (unsigned t = 0; t < nthreads; ++t)
                     c += tc[3 * t + k];
-                double const C = (double)lx::trace_cfg_panel(cand[k]) / 8.0;
-                c *= (3.75 * C + 12.0) / C * (cand[k] == 1 ? 1.0 : 1.04); // (narrower strips: more tiles per walk in the backtrace)
+                // (narrower strips: more panels -- carries, profile builds -- and more tiles per walk in the backtrace; measured on
+                // the ragged list of bench.py: 22.2 / 21.5 ms with 13 / 11 columns against 19.7 ms with 19, at 8 / 10 % fewer cells)
+                c *= cand[k] == 1 ? 1.0 : 1.15;
                 if (!(set & (1 << k)) && forced != cand[k])
                     continue;
                 if (forced == cand[k])
@@ -1443,7 +1454,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             std::memcpy(slot_orig + wlo * kWave, plan_slot.data() + (w0 + wlo) * kWave, (whi - wlo) * kWave * sizeof(uint32_t));
                             for (uint64_t w = w0 + wlo; w < w0 + whi; ++w)
                             {
-                                padded += kWave * ((uint64_t)wf_pan[w] * panel) * ((uint64_t)wf_maxs[w] + 7);
+                                padded += kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7);
                                 smax = std::max<uint64_t>(smax, wf_maxs[w]);
                                 pmax = std::max<uint64_t>(pmax, wf_pan[w]);
                             }
@@ -1460,7 +1471,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             max_pan = std::max(max_pan, tpan[t]);
         }
         h->xb_stats[1] += slots;
-        uint64_t const max_q = max_pan * panel;
+        uint64_t const max_q = (max_pan + panel / 8 - 1) / (panel / 8) * panel; // (whole panels: the slots have one part per panel)
         t_prep += ms(t0, now());
 
         auto const t1 = now();
@@ -1878,7 +1889,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             {
                 uint64_t const p2 = std::max<uint64_t>(pmax, wf_pan[w1]), s2 = std::max<uint64_t>(smax, wf_maxs[w1]);
                 uint64_t const steps  = (s2 + 8 - 1 + 15) & ~15ull;
-                uint64_t const stride = p2 * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
+                uint64_t const pc     = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+                uint64_t const stride = (p2 + pc - 1) / pc * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
                 if (w1 > w0 && (w1 + 1 - w0) * kWave * stride > h->opt_trace_bytes)
                     break;
                 pmax = p2;

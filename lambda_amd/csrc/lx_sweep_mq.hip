@@ -24,6 +24,8 @@
 // leaves the sentinel and is redone by the int32 launch into an overflow slot, like a wavefront the range test declines.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "lx_dp_common.h"
 
 namespace lx
@@ -214,16 +216,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     // ---- range test (wave-uniform): an upper bound of every finite intermediate must stay below the limit -- the codes'
     // 2046 for one panel (tested up front), the 16-bit patterns' for wider queries (their codes are tested afterwards)
     int bound = 0;
-    for (int pn = 0; pn < npanels; ++pn)
-    {
-#pragma unroll
-        for (int c = 0; c < C; ++c)
-        {
-            int const j = pn * Geo::kPanel + g * C + c;
-            if (j < lq)
-                bound += sc->rowmax[q[j] & (kAlph - 1)];
-        }
-    }
+    for (int j = g; j < lq; j += G) // (every column of the query once, whichever strip sweeps it)
+        bound += sc->rowmax[q[j] & (kAlph - 1)];
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1)
         bound += __shfl_xor(bound, off);
@@ -296,9 +290,31 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     // over the panels swept so far, per extension: best strip value, its (global) strip, first row, "met again later"
     int runA = 0, stripA = 0, rrowA = 0, rtieA = 0, runB = 0, stripB = 0, rrowB = 0, rtieB = 0;
 
+    // strip width of this lane group's LAST panel as swept (code of kEndNarrowShift), for the backtrace
+    int const my_panels = max(1, (lq + Geo::kPanel - 1) / Geo::kPanel);
+    int       my_code   = 0;
+
     for (int panel = 0; panel < npanels; ++panel)
     {
-        int const col0 = panel * Geo::kPanel + g * C;
+        // The panel's strip width, one for the wavefront: full width while any of its queries goes on behind this panel, else
+        // the narrowest of C, (C + 1) / 2, (C + 3) / 4 columns per lane that covers what its queries have left.
+        int code = 0;
+        if (p.narrow)
+        {
+            int const rem  = lq - panel * Geo::kPanel;
+            int       mine = panel < my_panels - 1 ? 0 : rem >= 1 ? narrow_code_for(C, G, rem) : 2; // (no column left: any width)
+            mine           = actA ? mine : 2;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+                mine = min(mine, __shfl_xor(mine, off));
+            code = __builtin_amdgcn_readfirstlane(mine);
+        }
+        if (panel == my_panels - 1)
+            my_code = code;
+        auto panel_body = [&](auto ce_tag)
+        {
+        constexpr int CE   = decltype(ce_tag)::value; // columns per lane in this panel
+        int const     col0 = panel * Geo::kPanel + g * CE;
         // ---- profile: prof[slot][t][piece][g] = bytes (s(q_col, t) - go) of the lane's columns, four per dword.  The lane
         // groups of a sub-block share the work: group r writes the letters 4w .. 4w+3 with w % share == r.  The 1 KB table is
         // copied into the (still idle) staging area first, so that the per-column row reads are LDS reads -- two dependent
@@ -322,9 +338,9 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 };
                 uint32_t wcur = letters(0);
 #pragma unroll 1
-                for (int d = 0; d < Geo::kD; ++d)
+                for (int d = 0; d < (CE + 3) / 4; ++d)
                 {
-                    uint32_t const wnext = d + 1 < Geo::kD ? letters(d + 1) : 0u;
+                    uint32_t const wnext = d + 1 < (CE + 3) / 4 ? letters(d + 1) : 0u;
                     uint32_t       rows[4][8];
 #pragma unroll
                     for (int cc = 0; cc < 4; ++cc)
@@ -332,7 +348,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                         int const c  = 4 * d + cc;
                         int const j  = col0 + c;
                         uint32_t  ql = kAlph - 1; // pad rank: a row of zeros
-                        if (c < C && j < lqp)
+                        if (c < CE && j < lqp)
                             ql = (wcur >> (8 * cc)) & (kAlph - 1);
                         uint4 const * mrow = reinterpret_cast<uint4 const *>(reinterpret_cast<uint8_t const *>(tab) + ql * kAlph);
                         uint4 const   lo = mrow[0], hi = mrow[1];
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             q2       rowmax = as_q2(0u);
             q2       h      = Z, hprev = Z, A = Z;
 #pragma unroll
-            for (int c = 0; c < C; ++c)
+            for (int c = 0; c < CE; ++c)
             {
                 // (entry of column c vs letter tA | entry of column c vs letter tB), zero-extended bytes
                 uint32_t const sel = 0x0c000c00u | (uint32_t)(c & 3) | ((uint32_t)(4 + (c & 3)) << 16);
@@ -488,7 +504,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 if (c & 1)
                     rowmax = qmax3(rowmax, hprev, h);
             }
-            if (C & 1)
+            if (CE & 1)
                 rowmax = qmax(rowmax, h);
             sendA = A;
             sendE = Ecur;
@@ -526,7 +542,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             uint32_t code[2 * L16::kCkDw];
 #pragma unroll
             for (int c = 0; c < 2 * L16::kCkDw; ++c)
-                code[c] = c < C ? ((qbits((Arow[c < C ? c : 0] - F0[c < C ? c : 0]) - geA) << 11) | qbits(Arow[c < C ? c : 0] - ziA)) : 0u;
+                code[c] = c < CE ? ((qbits((Arow[c < CE ? c : 0] - F0[c < CE ? c : 0]) - geA) << 11) | qbits(Arow[c < CE ? c : 0] - ziA)) : 0u;
             uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4);
             uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
@@ -723,6 +739,13 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             }
         }
         __builtin_amdgcn_wave_barrier();
+        }; // panel_body
+        if (code == 0)
+            panel_body(std::integral_constant<int, C>{});
+        else if (code == 1)
+            panel_body(std::integral_constant<int, (C + 1) / 2>{});
+        else
+            panel_body(std::integral_constant<int, (C + 3) / 4>{});
     } // panels
 
     auto finish = [&](int run, int rstrip, int rrow, int rtie, bool act, uint64_t e)
@@ -738,7 +761,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 ec.score = run;
                 ec.q_end = -(rstrip + 1); // the backtrace finds the column inside this strip
                 ec.s_end = rrow + 1;
-                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact;
+                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact | (my_code << kEndNarrowShift);
             }
             p.ends[e]      = ec;
             p.out_score[e] = (writable && !declined) ? run : -1;
