@@ -298,3 +298,20 @@ def test_mq_sweep_free_packing_declined_and_broken_promises(handle, oracle):
     e3[1] = e2[5]  # the first lane group names two queries
     with pytest.raises(capi.LambdaExtError):
         run_fused(handle, q2, s2, e3, 2, 50, mq=1)
+
+
+@pytest.mark.parametrize("lq_range", [(33, 40), (70, 80), (153, 160), (185, 192), (225, 232), (305, 312), (340, 344), (381, 384)])
+def test_mq_sweep_narrow_last_panel(handle, oracle, lq_range):
+    """A query's last panel runs the narrowest strips that cover what is left of it -- 19, 10 or 5 columns per lane at 152-column
+    panels (lx_device.h: narrow_code_for) --, recorded in the end cell's flags for the backtrace.  Query lengths that leave 1-40 /
+    41-80 / 81-152 columns for the last of one, two and three panels; all queries of a list in one width class, so that whole
+    wavefronts take the narrow path (a wavefront runs the widest strips any of its queries needs)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(24, seed=500 + lq_range[0], lq_range=lq_range, mean_windows=6.0, merged_frac=0.15)
+    slots, src = pack_free(ext, np.random.default_rng(lq_range[0]))
+    cutoff = 40
+    got = run_fused(handle, q, s, slots, 2, cutoff, mq=1)
+    assert "sweep_mq_kernel" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])

@@ -20,7 +20,7 @@ cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $R/$D/pmc_sq_wait -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq_wait.log 2>&1
 (timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$D/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_fetch.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_write.log 2>&1
-(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_ragged -o ragged -- python $R/tools/quick_ragged.py) > $R/$D/stats_ragged.log 2>&1
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_ragged -o ragged -- python $R/bench.py --ragged --entry list --steps 5 --warmup 2) > $R/$D/stats_ragged.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_host -o host -- python $R/bench.py --host-path --entry list --steps 5 --warmup 2) > $R/$D/stats_host.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write_lowsurv -o pmc -- python $R/bench.py --steps 2 --warmup 3 --survivor-rate 0.02 --no-cpu-baseline) > $R/$D/pmc_write_lowsurv.log 2>&1
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -40
