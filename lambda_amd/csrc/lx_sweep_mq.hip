@@ -20,6 +20,13 @@
 //     hand A of their last column to the right.  7.5 packed instructions per two cells, as before;
 //   * pad letters (rows beyond the window, columns beyond the query) have entry 0, i.e. score like a gap's first character:
 //     such a cell is never above its neighbours, so it can neither start, nor extend, nor end a best local alignment.
+// Two refinements of the unit:
+//   * free packing (pair_share = 1, LX_OPT_QUERY_RUN = 2): what the LDS limits is the number of profiles per wavefront (four),
+//     not how the lane groups are dealt to them -- a lane group's two windows share a query, the eight lane groups hold windows
+//     of up to four queries in any split, numbered in order of appearance;
+//   * narrow last panel (ScoreParams::narrow): the panel body exists for C, (C + 1) / 2 and (C + 3) / 4 columns per lane; a
+//     wavefront runs a panel with the narrowest width that covers what any of its queries has left there, and records the width
+//     of an extension's last panel in its end cell (kEndNarrowShift) for the backtrace.
 // Slots are the compact 16-bit codes of Ckpt16Layout (one part per panel); an extension whose best score is beyond 2046
 // leaves the sentinel and is redone by the int32 launch into an overflow slot, like a wavefront the range test declines.
 #include <hip/hip_runtime.h>

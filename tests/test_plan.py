@@ -1,5 +1,5 @@
 """The ONE selection function of the fused step (plan_step, lambda_amd/csrc/lx_api.cpp) walked on the CPU through lx_plan_step:
-query widths 1 ... 1 300 x query runs {0, 4, 7, 8, 16, 24, 32} x the four scoring schemes of the reference's programs.  Every
+query widths 1 ... 1 300 x query runs {0, 2, 4, 7, 8, 16, 24, 32} x the four scoring schemes of the reference's programs.  Every
 choice must be the documented one for its (width, run, alphabet) and must satisfy its own preconditions: the panels hold the
 query, the wavefront's LDS fits, compact codes only with gap costs they can hold, an int32 fix-up launch exactly where the
 a-priori bound of the widest admitted query exceeds the codes' 2046 (or the sweep tests the codes after the fact).  A wrong
@@ -11,11 +11,13 @@ import pytest
 from lambda_amd import capi
 from tests.test_oracle import SCHEMES
 
-RUNS = (0, 4, 7, 8, 16, 24, 32)
+RUNS = (0, 2, 4, 7, 8, 16, 24, 32)
 
 
 def _expected(name, q, run, nrows):
     small = nrows <= 8  # nucleotide / bisulfite alphabets: two packed-half profiles cost no occupancy
+    if run == 2:  # the free packing: pairs of one query, up to four queries per wavefront -- only the multi-query sweep serves it
+        return capi.PLAN_MQ, 4
     if run == 0 or run % 4 != 0:
         return capi.PLAN_NO_SWEEP, None
     if run == 4:
@@ -77,6 +79,8 @@ def test_plan_follows_budget_survivors_and_switches():
     assert capi.plan_step(sc, 150, 176, 4, 100_000, survivor_share=0.01).family == capi.PLAN_MQ
     # the options: LX_OPT_MQ_SWEEP = 0 / 2, LX_OPT_PACKED_HALF = 0, LX_OPT_PASS2_MODE
     assert capi.plan_step(sc, 150, 176, 8, 1000, mq_sweep=0).family == capi.PLAN_HALF  # two profiles per wavefront at reduced occupancy
+    assert capi.plan_step(sc, 150, 176, 2, 1000, mq_sweep=0).family == capi.PLAN_NO_SWEEP  # pairs have no other sweep
+    assert b"free packing" in capi.plan_step(sc, 150, 176, 2, 1000).name
     assert capi.plan_step(sc, 150, 176, 32, 1000, mq_sweep=2).family == capi.PLAN_MQ
     assert capi.plan_step(sc, 150, 176, 32, 1000, packed_half=0).family == capi.PLAN_INT32
     assert capi.plan_step(sc, 150, 176, 32, 1000, pass2_mode=1).family == capi.PLAN_NO_SWEEP
