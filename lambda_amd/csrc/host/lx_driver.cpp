@@ -7,15 +7,25 @@
 //   _expandAlign (coordinates)   :1032-1035
 // The DP itself never runs here: both passes go to the GPU through lx_extend_batch.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <numeric>
+#include <string>
 #include <tuple>
 #include <vector>
 
 #include "blast_stats.hpp"
 #include "lambda_ext.hpp"
 #include "scoring_tables.hpp"
+
+// the library's host threads (lx_host.cpp): width of the pool, and f(0) ... f(nthreads - 1) run side by side
+namespace lxi
+{
+unsigned pool_width();
+void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
+} // namespace lxi
 
 namespace lambda_amd
 {
@@ -42,14 +52,87 @@ inline auto tie(lx_match const & m)
     return std::tie(m.qryId, m.subjId, m.qryStart, m.qryEnd, m.subjStart, m.subjEnd);
 }
 
+// The reference calls iterateMatches per thread on a block of <= 10 queries (src/search_options.hpp:71); a GPU wants the seed
+// lists of thousands of queries per call, and then this function's own loops (a sort of the list, the slices, the records) cost
+// as much as the kernels unless they are spread over the library's host threads (lx_host.cpp's pool).
+inline constexpr uint64_t kParallelFrom = 32768; // list sizes below this stay on the calling thread
+template <typename F>
+inline void parallelRanges(uint64_t n, F && body) // body(thread, lo, hi) over a partition of [0, n)
+{
+    unsigned const nt = n >= kParallelFrom ? std::max(1u, lxi::pool_width()) : 1u;
+    if (nt <= 1)
+    {
+        body(0u, (uint64_t)0, n);
+        return;
+    }
+    uint64_t const step = (n + nt - 1) / nt;
+    lxi::pool_run(nt, [&](unsigned t) { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
+}
+
 // src/search_algo.hpp:1136-1175; returns the new size, *duplicates gets the number removed (hitsDuplicate)
 inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t const * qLens, uint64_t const * sLens,
                                           uint64_t * duplicates)
 {
     uint64_t const before = n;
+    auto const     less   = [](lx_match const & a, lx_match const & b) { return tie(a) < tie(b); };
+    // A list that comes grouped by query (what seeding emits) is cut at query boundaries into one piece per host thread: the
+    // sort key begins with the query, the merge only ever joins windows of one (query, subject) pair, so the pieces are
+    // independent and the result is the serial one.
+    unsigned const nt = n >= kParallelFrom ? std::max(1u, lxi::pool_width()) : 1u;
+    bool           grouped = nt > 1;
+    for (uint64_t i = 1; i < n && grouped; ++i)
+        grouped = m[i - 1].qryId <= m[i].qryId;
+    if (grouped)
+    {
+        std::vector<uint64_t> cut(nt + 1, n), kept(nt, 0);
+        cut[0] = 0;
+        for (unsigned t = 1; t < nt; ++t)
+        {
+            uint64_t c = std::max(cut[t - 1], n * t / nt);
+            while (c < n && c > 0 && m[c].qryId == m[c - 1].qryId)
+                ++c;
+            cut[t] = c;
+        }
+        lxi::pool_run(nt,
+                      [&](unsigned t)
+                      {
+                          uint64_t const lo = cut[t], hi = cut[t + 1];
+                          for (uint64_t i = lo; i < hi; ++i)
+                              widenMatch(m[i], qLens[m[i].qryId], sLens[m[i].subjId]);
+                          std::sort(m + lo, m + hi, less);
+                          for (uint64_t i = lo; i + 1 < hi; ++i)
+                          {
+                              lx_match & l = m[i];
+                              lx_match & r = m[i + 1];
+                              if (l.qryId == r.qryId && l.subjId == r.subjId && l.subjEnd >= r.subjStart)
+                              {
+                                  l.subjEnd   = r.subjEnd;
+                                  r.subjStart = l.subjStart;
+                              }
+                          }
+                          for (uint64_t i = hi; i-- > lo + 1;)
+                          {
+                              lx_match & r = m[i];
+                              lx_match & l = m[i - 1];
+                              if (r.qryId == l.qryId && r.subjId == l.subjId && r.subjStart < l.subjEnd)
+                                  l = r;
+                          }
+                          kept[t] = (uint64_t)(std::unique(m + lo, m + hi, [](lx_match const & a, lx_match const & b) { return tie(a) == tie(b); }) - (m + lo));
+                      });
+        uint64_t w = 0;
+        for (unsigned t = 0; t < nt; ++t) // the pieces close ranks (the first stays where it is)
+        {
+            if (w != cut[t] && kept[t])
+                std::memmove(static_cast<void *>(m + w), m + cut[t], kept[t] * sizeof(lx_match));
+            w += kept[t];
+        }
+        if (duplicates)
+            *duplicates += before - w;
+        return w;
+    }
     for (uint64_t i = 0; i < n; ++i)
         widenMatch(m[i], qLens[m[i].qryId], sLens[m[i].subjId]);
-    std::sort(m, m + n, [](lx_match const & a, lx_match const & b) { return tie(a) < tie(b); });
+    std::sort(m, m + n, less);
     if (n > 1)
     {
         for (uint64_t i = 0; i + 1 < n; ++i)
@@ -175,20 +258,39 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     using namespace lambda_amd;
     int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
     res->stats.num_ext_score += n_matches; // lH.stats.numExtScore (:1187)
+    // LX_HOST_TIMING=1: where this function's own time goes (the extension prints its breakdown itself)
+    static bool const timing = std::getenv("LX_HOST_TIMING") != nullptr;
+    auto              tlast  = std::chrono::steady_clock::now();
+    std::string       tline;
+    auto mark = [&](char const * what)
+    {
+        if (!timing)
+            return;
+        auto const now = std::chrono::steady_clock::now();
+        char       buf[64];
+        std::snprintf(buf, sizeof(buf), " %s %.1f", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+        tline += buf;
+        tlast = now;
+    };
 
     // pre-sort and filter (:1198)
     uint64_t const n = widenAndPreprocessMatches(matches, n_matches, q_seq_len, s_seq_len, &res->stats.hits_duplicate);
+    mark("widen+merge");
 
     // create blast matches from Lambda matches (:1200-1227); the window is the DP's (query slice, subject slice)
     std::vector<lx_extension> ext(n);
-    for (uint64_t i = 0; i < n; ++i)
-    {
-        lx_match const & m = matches[i];
-        ext[i].q_off       = q_seq_off[m.qryId] + m.qryStart;
-        ext[i].q_len       = (uint32_t)(m.qryEnd - m.qryStart);
-        ext[i].s_off       = s_seq_off[m.subjId] + m.subjStart;
-        ext[i].s_len       = (uint32_t)(m.subjEnd - m.subjStart);
-    }
+    parallelRanges(n,
+                   [&](unsigned, uint64_t lo, uint64_t hi)
+                   {
+                       for (uint64_t i = lo; i < hi; ++i)
+                       {
+                           lx_match const & m = matches[i];
+                           ext[i].q_off       = q_seq_off[m.qryId] + m.qryStart;
+                           ext[i].q_len       = (uint32_t)(m.qryEnd - m.qryStart);
+                           ext[i].s_off       = s_seq_off[m.subjId] + m.subjStart;
+                           ext[i].s_len       = (uint32_t)(m.subjEnd - m.subjStart);
+                       }
+                   });
     // The reference sorts the list by lengths to minimise SIMD padding (:1229-1235), runs the extensions WITHOUT
     // alignment (:1246), filters by bit score and e-value (:1251-1283), runs the survivors WITH alignment (:1293-1296)
     // and stably re-sorts by query (:1299).  Here both passes are one call: bit score and e-value are monotone in the
@@ -230,12 +332,24 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     };
     std::vector<int32_t>  minScore(n);
     std::vector<uint64_t> qLengthOf(n);
+    // (the cut-off of every query length that occurs, found once on this thread -- the list is grouped by query: one look per
+    // run --, then handed out to the matches by all of them)
+    parallelRanges(n,
+                   [&](unsigned, uint64_t lo, uint64_t hi)
+                   {
+                       for (uint64_t i = lo; i < hi; ++i)
+                           qLengthOf[i] = q_orig_len ? q_orig_len[matches[i].qryId / qFrames] : q_seq_len[matches[i].qryId];
+                   });
     for (uint64_t i = 0; i < n; ++i)
-    {
-        uint64_t const nq = matches[i].qryId / qFrames;
-        qLengthOf[i]      = q_orig_len ? q_orig_len[nq] : q_seq_len[matches[i].qryId];
-        minScore[i]       = cutOffFor(qLengthOf[i]);
-    }
+        if (i == 0 || qLengthOf[i] != qLengthOf[i - 1])
+            (void)cutOffFor(qLengthOf[i]);
+    parallelRanges(n,
+                   [&](unsigned, uint64_t lo, uint64_t hi)
+                   {
+                       for (uint64_t i = lo; i < hi; ++i)
+                           minScore[i] = cutOffs.find(qLengthOf[i])->second; // (reads only: every length is in the map)
+                   });
+    mark("slices+cut-offs");
     std::vector<int32_t>  scores(n, 0);
     std::vector<lx_hsp>   hspAll;    // band mode only (n records, column bytes)
     std::vector<uint64_t> opsOffAll;
@@ -260,6 +374,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     }
     if (rc != LX_OK)
         return rc;
+    mark("extension");
 
     // the filter's statistics (:1260, :1274) from the scores of pass 1
     std::vector<uint32_t> surv;   // indices into `matches`
@@ -286,6 +401,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
             listAt[list.index[k]] = (uint32_t)k;
         }
     }
+    mark("statistics");
     if (surv.empty())
         return LX_OK;
     res->stats.num_ext_ali += surv.size(); // :1287
@@ -296,56 +412,102 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
                          std::make_tuple(matches[b].qryId / qFrames, ext[b].q_len, ext[b].s_len, b);
               });
 
-    // compute the rest of the match properties (:1302-1325)
-    for (uint32_t k : surv)
+    // compute the rest of the match properties (:1302-1325).  Two passes over the survivors, each spread over the host threads:
+    // the records (and which of them pass the identity cut-off), then -- the offsets known -- their ops.
+    uint64_t const              ns = surv.size();
+    std::vector<lx_blast_match> recs(ns);
+    std::vector<uint8_t>        keep(ns, 0);
+    parallelRanges(ns,
+                   [&](unsigned, uint64_t lo, uint64_t hi)
+                   {
+                       EValueContext ev = evalue; // (its cache of length adjustments is not shared)
+                       for (uint64_t x = lo; x < hi; ++x)
+                       {
+                           uint32_t const   k = surv[x];
+                           lx_match const & m = matches[k];
+                           lx_hsp const &   a = rle ? list.hsp[listAt[k]] : hspAll[k];
+                           lx_blast_match   bm{};
+                           bm.qry_id  = m.qryId;
+                           bm.subj_id = m.subjId;
+                           bm.n_qid   = m.qryId / qFrames;
+                           bm.n_sid   = m.subjId / sFrames;
+                           {
+                               int32_t qf = 0, sf = 0; // _setFrames, :1223
+                               lx_set_frames(params->q_frame_mode, params->s_frame_mode, m.qryId, m.subjId, &qf, &sf);
+                               bm.q_frame = (int16_t)qf;
+                               bm.s_frame = (int16_t)sf;
+                           }
+                           // _expandAlign: positions relative to the infix become positions in the sequence (:1032-1035)
+                           bm.q_start = m.qryStart + a.q_begin;
+                           bm.q_end   = m.qryStart + a.q_end;
+                           bm.s_start = m.subjStart + a.s_begin;
+                           bm.s_end   = m.subjStart + a.s_end;
+                           bm.score   = a.score;
+                           bm.alignment_length   = a.n_ops;
+                           bm.num_matches        = a.num_matches;
+                           bm.num_mismatches     = a.num_mismatches;
+                           bm.num_positives      = a.num_positives;
+                           bm.num_gap_opens      = a.num_gap_opens;
+                           bm.num_gap_extensions = a.num_gap_extensions;
+                           bm.identity = a.n_ops ? (float)(100.0 * static_cast<float>(a.num_matches) / static_cast<float>(a.n_ops)) : 0.0f;
+                           if (!(bm.identity < params->id_cutoff)) // :1310-1315
+                           {
+                               // the reference keeps the values of the filter where it computed them and computes the others now
+                               // (:1318-1322): the same formulas on the same score either way
+                               bm.bit_score = computeBitScore(a.score, params->karlin);
+                               bm.e_value   = ev(a.score, qLengthOf[k]);
+                               bm.n_ops     = (uint32_t)a.n_ops;
+                               keep[x]      = 1;
+                           }
+                           recs[x] = bm;
+                       }
+                   });
+    uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size();
+    uint64_t       nkeep = 0, nops = 0;
+    for (uint64_t x = 0; x < ns; ++x)
     {
-        lx_match const & m = matches[k];
-        lx_hsp const &   a = rle ? list.hsp[listAt[k]] : hspAll[k];
-        lx_blast_match   bm{};
-        bm.qry_id  = m.qryId;
-        bm.subj_id = m.subjId;
-        bm.n_qid   = m.qryId / qFrames;
-        bm.n_sid   = m.subjId / sFrames;
-        {
-            int32_t qf = 0, sf = 0; // _setFrames, :1223
-            lx_set_frames(params->q_frame_mode, params->s_frame_mode, m.qryId, m.subjId, &qf, &sf);
-            bm.q_frame = (int16_t)qf;
-            bm.s_frame = (int16_t)sf;
-        }
-        // _expandAlign: positions relative to the infix become positions in the sequence (:1032-1035)
-        bm.q_start = m.qryStart + a.q_begin;
-        bm.q_end   = m.qryStart + a.q_end;
-        bm.s_start = m.subjStart + a.s_begin;
-        bm.s_end   = m.subjStart + a.s_end;
-        bm.score   = a.score;
-        bm.alignment_length   = a.n_ops;
-        bm.num_matches        = a.num_matches;
-        bm.num_mismatches     = a.num_mismatches;
-        bm.num_positives      = a.num_positives;
-        bm.num_gap_opens      = a.num_gap_opens;
-        bm.num_gap_extensions = a.num_gap_extensions;
-        bm.identity = a.n_ops ? (float)(100.0 * static_cast<float>(a.num_matches) / static_cast<float>(a.n_ops)) : 0.0f;
-        if (bm.identity < params->id_cutoff) // :1310-1315
+        if (!keep[x])
         {
             ++res->stats.failed_identity;
             continue;
         }
-        // the reference keeps the values of the filter where it computed them and computes the others now (:1318-1322):
-        // the same formulas on the same score either way
-        bm.bit_score = computeBitScore(a.score, params->karlin);
-        bm.e_value   = evalue(a.score, qLengthOf[k]);
-        bm.ops_off   = res->ops.size();
-        bm.n_ops     = (uint32_t)a.n_ops;
-        uint8_t const * const first = rle ? list.codes + list.codes_off[listAt[k]] : ops + opsOffAll[k] + a.ops_shift;
-        if (rle)
-        {
-            res->ops.resize(res->ops.size() + (size_t)a.n_ops);
-            (void)lx_expand_ops(first, a.n_ops, res->ops.data() + bm.ops_off);
-        }
-        else
-            res->ops.insert(res->ops.end(), first, first + a.n_ops);
-        res->matches.push_back(bm);
+        recs[x].ops_off = ops0 + nops; // (ops_off of a dropped record stays unused)
+        nops += recs[x].n_ops;
+        ++nkeep;
     }
+    res->matches.resize(rec0 + nkeep);
+    res->ops.resize(ops0 + nops);
+    {
+        // where the kept records go: their rank among the kept ones (a prefix count per thread share)
+        std::vector<uint64_t> rank(ns);
+        uint64_t              r = 0;
+        for (uint64_t x = 0; x < ns; ++x)
+        {
+            rank[x] = r;
+            r += keep[x];
+        }
+        parallelRanges(ns,
+                       [&](unsigned, uint64_t lo, uint64_t hi)
+                       {
+                           for (uint64_t x = lo; x < hi; ++x)
+                           {
+                               if (!keep[x])
+                                   continue;
+                               uint32_t const         k  = surv[x];
+                               lx_blast_match const & bm = recs[x];
+                               lx_hsp const &         a  = rle ? list.hsp[listAt[k]] : hspAll[k];
+                               uint8_t const * const first = rle ? list.codes + list.codes_off[listAt[k]] : ops + opsOffAll[k] + a.ops_shift;
+                               if (rle)
+                                   (void)lx_expand_ops(first, a.n_ops, res->ops.data() + bm.ops_off);
+                               else
+                                   std::memcpy(res->ops.data() + bm.ops_off, first, (size_t)a.n_ops);
+                               res->matches[rec0 + rank[x]] = bm;
+                           }
+                       });
+    }
+    mark("records");
+    if (timing)
+        std::fprintf(stderr, "[lx host ms] iterateMatchesFullSimd (%llu matches):%s\n", (unsigned long long)n_matches, tline.c_str());
     return LX_OK;
 }
 

@@ -28,6 +28,19 @@ lxi::HostPool & lxi::host_pool()
     return p;
 }
 
+// for the Level-2 driver (host/lx_driver.cpp), which is written against the C ABI and borrows only the threads
+namespace lxi
+{
+unsigned pool_width()
+{
+    return host_threads(1u << 30);
+}
+void pool_run(unsigned nthreads, std::function<void(unsigned)> f)
+{
+    host_pool().run(nthreads, std::move(f));
+}
+} // namespace lxi
+
 static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                        lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
                        int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
