@@ -307,8 +307,9 @@ typedef struct lx_survivor_list
 int lx_extend_batch_list(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                          lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
                          lx_survivor_list * out);
-/* Padding of the last lx_extend_batch[_rle] call: out4 = {extensions with residues, slots after padding every query's run
- * to 8 / 16, cells (sum q_len * s_len), cells the wavefronts execute (whole panels x the longest window of each block)}. */
+/* Padding of the last lx_extend_batch* call: out4 = {extensions with residues, slots (windows + fillers), cells (sum q_len *
+ * s_len), cells the wavefronts execute (per wavefront: 16 slots x the columns its widest query sweeps -- whole panels, the last
+ * one with narrower strips where that covers the query -- x the steps of its longest window)}. */
 int lx_last_extend_stats(lx_handle const * h, uint64_t * out4);
 
 /* ---- pre-extension filter (seedLooksPromising, src/search_algo.hpp:426-481) ------------------ */
