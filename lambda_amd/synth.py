@@ -189,7 +189,7 @@ def make_ragged_lists_np(n_queries: int, seed: int, alphabet: np.ndarray = STD20
     b_e = (np.sqrt(lq_e).astype(np.int64) + 1)
     ls_e = lq_e + 2 * b_e
     merged = rng.random(n_ext) < merged_frac
-    ls_e = np.where(merged, rng.integers(ls_e, 3 * lq_e + 1), ls_e)
+    ls_e = np.where(merged, rng.integers(ls_e, np.maximum(3 * lq_e, ls_e) + 1), ls_e)  # (tiny queries: Lq + 2b exceeds 3 Lq)
     s_off = np.concatenate([[0], np.cumsum(ls_e)[:-1]])
     s_idx = rng.integers(0, na, int(ls_e.sum()), dtype=np.uint8)
     homolog = np.nonzero(rng.random(n_ext) < homolog_frac)[0]

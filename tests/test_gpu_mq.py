@@ -315,3 +315,72 @@ def test_mq_sweep_narrow_last_panel(handle, oracle, lq_range):
     got = run_fused(handle, q, s, slots, 2, cutoff, mq=1)
     assert "sweep_mq_kernel" in got[5], got[5]
     check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
+
+
+def _check_host_list(handle, oracle, q, s, ext, cutoff, sample=400):
+    osc = oracle_lib.scoring_from(SCHEMES["blosum62"])
+    want = oracle.score_batch(q, s, ext, osc, threads=8)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    try:
+        score, index, hsp, off, codes = handle.extend_batch_list(q, s, ext, cutoff)
+        name = handle.last_trace_kernel_name()
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+    assert (score == want).all()
+    live = np.nonzero((want >= cutoff) & (ext["s_len"] > 0) & (ext["q_len"] > 0))[0]
+    assert len(index) == len(live) and (np.sort(index) == live).all()
+    rng = np.random.default_rng(0)
+    pick = rng.choice(len(index), min(sample, len(index)), replace=False)
+    for k, (oh, oops) in zip(pick, oracle.align_batch(q, s, ext[index[pick]], osc)):
+        g = hsp[k]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == \
+               (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops), (k, ext[index[k]])
+        n_ops, c, done = int(g["n_ops"]), int(off[k]), 0
+        while done < n_ops:
+            done += (int(codes[c]) & 63) + 1
+            c += 1
+        assert capi.Handle.expand_ops(codes[int(off[k]): c], n_ops) == oops
+    return name
+
+
+def test_host_plan_extreme_list_shapes(handle, oracle):
+    """The pool + stream plan on lists far from the average: one query with thousands of windows of every length beside hundreds
+    of queries with a single window (wavefronts closed by a fifth query after four pairs), queries of 1-12 residues (one narrow
+    panel, windows shorter than the lane skew), and a list where every window is a merged one."""
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    rng = np.random.default_rng(42)
+    # (a) one huge run + many singletons
+    q1, s1, e1 = synth.make_ragged_lists_np(1, seed=1, lq_range=(180, 181), mean_windows=3000.0, merged_frac=0.3)
+    q2, s2, e2 = synth.make_ragged_lists_np(400, seed=2, lq_range=(30, 330), mean_windows=1.0, merged_frac=0.0)
+    e2 = e2.copy()
+    e2["q_off"] += len(q1)
+    e2["s_off"] += len(s1)
+    q, s, ext = np.concatenate([q1, q2]), np.concatenate([s1, s2]), np.concatenate([e1, e2])
+    assert len(e1) > 500
+    name = _check_host_list(handle, oracle, q, s, ext, 50)
+    assert "sweep_mq_kernel" in name and "free packing" in name
+    # (b) tiny queries
+    q, s, ext = synth.make_ragged_lists_np(300, seed=3, lq_range=(1, 12), mean_windows=3.0, merged_frac=0.2)
+    _check_host_list(handle, oracle, q, s, ext, 8)
+    # (c) every window a merged one (random lengths up to 3 Lq): everything stands in the pool or is streamed with a wide spread
+    q, s, ext = synth.make_ragged_lists_np(150, seed=4, lq_range=(60, 260), mean_windows=6.0, merged_frac=1.0)
+    _check_host_list(handle, oracle, q, s, ext, 45)
+
+
+def test_host_plan_with_a_window_beyond_the_checkpoint_rows(handle, oracle):
+    """A 70 000-residue window inside a ragged list: its chunk leaves the sweep (the checkpoint slots address 65 535 rows) and is
+    traced through the direction bits, the other chunks stay on the multi-query sweep; results as ever."""
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    rng = np.random.default_rng(5)
+    q, s, ext = synth.make_ragged_lists_np(80, seed=6, lq_range=(60, 200), mean_windows=4.0, merged_frac=0.1)
+    long_s = synth.STD20[rng.integers(0, 20, 70_000)].astype(np.uint8)
+    L = int(ext["q_len"][0])
+    long_s[40_000: 40_000 + L] = q[int(ext["q_off"][0]): int(ext["q_off"][0]) + L]
+    ext = np.concatenate([ext[:1], ext]).copy()
+    ext[0]["s_off"], ext[0]["s_len"] = len(s), len(long_s)
+    s = np.concatenate([s, long_s])
+    handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 1024)
+    try:
+        _check_host_list(handle, oracle, q, s, ext, 50, sample=100)
+    finally:
+        handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
