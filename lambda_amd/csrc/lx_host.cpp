@@ -952,14 +952,15 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // ---- multi-query plan (free packing of lx_sweep_mq.hip: the two windows of a lane group share a query, a wavefront's 16 slots
     // hold windows of at most four queries in any split).  Inside a run the windows are sorted by length; those clearly longer than
     // the run's median -- the merged windows, up to 3 x longer (src/search_algo.hpp:1153-1157) -- go to the POOL in sub-blocks of 4
-    // (filled up with the run's longest ordinary windows), the sub-blocks of the whole list are sorted by (panels, longest window)
+    // (filled up with the run's longest ordinary windows), the sub-blocks of the whole list are sorted by (columns per lane their query
+    // sweeps -- whole panels + the narrow last one --, longest window)
     // and dealt four to a wavefront: a long window stretches three companions, not fifteen.  Everything else is STREAMED: the runs
-    // in order of (panels, ordinary window length), their windows pair by pair into wavefronts that are closed when they hold eight
+    // in order of (columns per lane, ordinary window length), their windows pair by pair into wavefronts that are closed when they hold eight
     // pairs or meet a fifth query -- the windows of a wavefront take about the same number of steps, and a query with five windows
     // costs three lane groups, not two sub-blocks.  What is missing to a pair or a wavefront is filled with copies of the last
     // window (as the reference pads its SIMD batches, :1063-1067): they cost what the window costs and never survive (cut-off
-    // INT_MAX).  The plan is the slot list of the whole call (the caller's index per slot) + panels and longest window per
-    // wavefront; chunks are ranges of wavefronts.
+    // INT_MAX).  The plan is the slot list of the whole call (the caller's index per slot) + columns per lane and longest window
+    // per wavefront; chunks are ranges of wavefronts.
     constexpr uint64_t kSub = 4, kWave = 16;
     std::vector<uint32_t> & plan_slot = h->xb_slot, & wf_pan = h->xb_wfpan, & wf_maxs = h->xb_wfmaxs; // (wf_pan: columns per lane)
     std::vector<uint32_t> & sb_first = h->xb_sbfirst, & sb_key = h->xb_sbkey, & sb_order = h->xb_sborder, & sb_tmp = h->xb_sbtmp;
