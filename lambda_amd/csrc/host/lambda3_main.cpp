@@ -11,9 +11,10 @@
 //     proteins, --score-match/-mismatch for nucleotides, --score-gap, --score-gap-open), the profiles (-p fast | sensitive |
 //     pairs-default | pairs-sensitive: they overwrite the seeding options, :634-681), the output options (--output-columns,
 //     --sam-bam-tags/-seq/-clip, --sam-with-refheader, --version-to-outputfile), -g, --input-alphabet;
-//   * the thread split of realMain (src/search.cpp:379-385): -t worker threads (default: one per device of --devices, default
-//     all visible devices), each with its own handle -- one LocalDataHolder per thread there, one lx_handle = device + stream
-//     here --, the queries dealt to them in contiguous ranges, the records concatenated in range order before _writeRecord;
+//   * the thread split of realMain (src/search.cpp:379-385): one worker per entry of --devices (default: all visible devices), each
+//     with its own handle -- one LocalDataHolder per thread there, one lx_handle = device + stream here --, the queries dealt to
+//     them in contiguous ranges, the records concatenated in range order before _writeRecord; -t host threads (default: what
+//     the machine grants) build the word table and are shared out among the workers for the seeding of their reads;
 //   * searchbs (src/lambda.cpp:103; domain_t::bisulfite, src/search_options.hpp:127, :261-264, :328): four query frames
 //     (strand x bisulfite duplicate), two subject frames, the 6-letter reduction of src/view_reduce_to_bisulfite.hpp for
 //     seeding, both scoring schemes (src/bisulfite_scoring.hpp:67-93), iterateMatches' bisulfite branch (:1367-1379);
@@ -25,8 +26,11 @@
 //     exact seeds 10/5 first, then (queries without a result) half-exact seeds 11/3 with one substitution in the second
 //     half, adaptive elongation, over-abundant seeds dropped, seedLooksPromising per hit (src/search_algo.hpp:426-762,
 //     :1391-1457; defaults src/search_options.hpp:309-337).  Everything after seeding follows the reference too.
+#include <sched.h>
+
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -204,7 +208,7 @@ struct Options
     bool        samWithRefHeader = false, versionToOutput = true;
     std::string commandLine;
     std::vector<int> devices;         // --devices (default: every visible device)
-    int         threads     = 0;    // -t (default: one per device)
+    int         threads     = 0;    // -t host threads for the word table and the seeding (default: what the machine grants)
     std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
     std::string dbAlphabet  = "auto"; // searchp: "dna5" = six-frame translated subjects (TBLASTN / TBLASTX)
 };
@@ -438,6 +442,22 @@ Options parse(int argc, char ** argv)
     return o;
 }
 
+// host threads this process may use: the hardware's, capped by the affinity mask and the cgroup's CPU quota
+unsigned grantedThreads()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0)
+        n = std::min<unsigned>(n, (unsigned)CPU_COUNT(&set));
+    std::ifstream f("/sys/fs/cgroup/cpu.max");
+    std::string   quota;
+    double        period = 0;
+    if (f >> quota >> period && quota != "max" && period > 0)
+        n = std::min<unsigned>(n, std::max(1u, (unsigned)(std::stod(quota) / period + 0.5)));
+    return std::min(n, 64u);
+}
+
 } // namespace
 
 int main(int argc, char ** argv)
@@ -445,6 +465,9 @@ int main(int argc, char ** argv)
     try
     {
         Options const opt  = parse(argc, argv);
+        auto const    tStart = std::chrono::steady_clock::now();
+        auto          msSince = [](std::chrono::steady_clock::time_point a)
+        { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
         bool const    prot = opt.cmd == "searchp", bs = opt.cmd == "searchbs";
         // searchp with nucleotide queries is BLASTX: six translated frames per query against the protein database
         bool const    blastx = prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
@@ -460,6 +483,7 @@ int main(int argc, char ** argv)
         readFasta(opt.db, prot, false, db, sTrans, opt.geneticCode, bs ? 1 : 0);
         if (qs.ids.empty() || db.ids.empty())
             throw std::runtime_error("empty query or database file");
+        double const msRead = msSince(tStart);
 
         // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234): bisulfite = two matrices over SeqAn Dna5
         // (forward: slot 0, reverse: slot 1, :176-186), statistics from the match / mismatch scheme
@@ -479,7 +503,12 @@ int main(int argc, char ** argv)
                 devices.push_back(d);
         if (devices.empty())
             throw std::runtime_error("no HIP device available (this front end has no CPU path)");
-        size_t const nWorkers = std::max<size_t>(1, std::min<size_t>(opt.threads > 0 ? (size_t)opt.threads : devices.size(), qs.ids.size()));
+        // one worker = one handle per entry of --devices (a device may be listed twice); -t host threads in all, shared out among
+        // the workers for the seeding of their reads (the reference: -t OpenMP threads, each with its own LocalDataHolder; a GPU
+        // wants few, large extension batches, the seeding wants every core)
+        size_t const   nWorkers = std::max<size_t>(1, std::min<size_t>(devices.size(), qs.ids.size()));
+        unsigned const nThreads = opt.threads > 0 ? (unsigned)opt.threads : grantedThreads();
+        unsigned const seedThreads = std::max(1u, nThreads / (unsigned)nWorkers);
 
         // ---- seeding (search(), src/search_algo.hpp:611-762) over a sorted table of reduced words instead of the FM-index
         uint8_t const * redTab = nullptr;
@@ -507,9 +536,11 @@ int main(int argc, char ** argv)
                 red[i] = redTab ? redTab[set.res[i] < (prot ? 27 : 5) ? set.res[i] : 0] : set.res[i];
             return red;
         };
+        auto const                 tIndex = std::chrono::steady_clock::now();
         std::vector<uint8_t> const qRed = reduce(qs), dbRed = reduce(db);
         lambda_amd::ReducedIndex   ix;
-        ix.build(dbRed, db.off, db.len, alph);
+        ix.build(dbRed, db.off, db.len, alph, nThreads);
+        double const msIndex = msSince(tIndex);
         lambda_amd::SeedingInput sin{};
         sin.qRes = qs.res.data(), sin.qRed = qRed.data(), sin.qOff = qs.off.data(), sin.qLen = qs.len.data(), sin.nQSeq = qs.off.size();
         sin.qNumFrames       = qFrames;
@@ -550,6 +581,7 @@ int main(int argc, char ** argv)
             lx_iterate_stats            ist{};
             lambda_amd::SeedingStats    sst{};
             size_t                      nPromising = 0;
+            double                      msSeed = 0, msExtend = 0;
             std::string                 error;
         };
         std::vector<Part> parts(nWorkers);
@@ -575,16 +607,20 @@ int main(int argc, char ** argv)
                     std::vector<lx_match> matches;
                     if (std::getenv("LAMBDA3_TRACE"))
                         std::fprintf(stderr, "[worker %zu] seeding %zu frame sequences (seed %d/%d, delta %d)\n", w, which.size(), so.seedLength, so.seedOffset, so.maxSeedDist);
-                    lambda_amd::seedQueries(ix, sin, so, which, matches, pt.sst);
+                    auto const tSeed = std::chrono::steady_clock::now();
+                    lambda_amd::seedQueriesParallel(ix, sin, so, which, matches, pt.sst, seedThreads);
+                    pt.msSeed += msSince(tSeed);
                     pt.nPromising += matches.size();
                     if (std::getenv("LAMBDA3_TRACE"))
                         std::fprintf(stderr, "[worker %zu] %zu promising seeds -> extension\n", w, matches.size());
                     if (matches.empty())
                         return;
                     lx_iterate_result * res = nullptr;
+                    auto const          tExt = std::chrono::steady_clock::now();
                     eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
                                                  qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(), db.off.size(), matches.data(),
                                                  matches.size(), &sp, &res));
+                    pt.msExtend += msSince(tExt);
                     uint64_t const         n  = lx_iterate_result_count(res);
                     lx_blast_match const * bm = lx_iterate_result_matches(res);
                     uint64_t const         ob = pt.ops.size();
@@ -630,6 +666,7 @@ int main(int argc, char ** argv)
                 pt.error = e.what();
             }
         };
+        auto const tSearch = std::chrono::steady_clock::now();
         {
             std::vector<std::thread> pool;
             for (size_t w = 1; w < nWorkers; ++w)
@@ -638,12 +675,15 @@ int main(int argc, char ** argv)
             for (auto & t : pool)
                 t.join();
         }
+        double const msSearch = msSince(tSearch);
+        auto const   tOut     = std::chrono::steady_clock::now();
         // the ranges are disjoint and ascending: concatenation in range order is the order one thread would have produced
         std::vector<lx_blast_match> bms;
         std::vector<uint8_t>        ops;
         lx_iterate_stats            ist{};
         lambda_amd::SeedingStats    sst{};
         size_t                      nPromising = 0;
+        double                      msSeedMax = 0, msExtendMax = 0;
         for (Part & pt : parts)
         {
             if (!pt.error.empty())
@@ -659,6 +699,8 @@ int main(int argc, char ** argv)
             ist.failed_identity += pt.ist.failed_identity, ist.num_ext_score += pt.ist.num_ext_score, ist.num_ext_ali += pt.ist.num_ext_ali;
             sst.hitsAfterSeeding += pt.sst.hitsAfterSeeding, sst.hitsFailedPreExtendTest += pt.sst.hitsFailedPreExtendTest;
             nPromising += pt.nPromising;
+            msSeedMax   = std::max(msSeedMax, pt.msSeed);
+            msExtendMax = std::max(msExtendMax, pt.msExtend);
         }
         uint64_t const nHsp   = bms.size();
         size_t const   nSeeds = (size_t)sst.hitsAfterSeeding;
@@ -703,11 +745,16 @@ int main(int argc, char ** argv)
         }
 
         std::fprintf(stderr,
-                     "lambda3 %s (%s, %zu thread(s) on %zu device(s)): %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> "
+                     "lambda3 %s (%s, %u host thread(s), %zu handle(s) on %zu device(s)): %zu queries, %zu subjects (%llu residues); seeds %zu -> promising %zu -> "
                      "windows %llu -> traced %llu -> HSPs %llu -> written %llu (queries with hit: %llu)\n",
-                     opt.cmd.c_str(), program, nWorkers, devices.size(), qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, nPromising,
+                     opt.cmd.c_str(), program, nThreads, nWorkers, devices.size(), qs.ids.size(), db.ids.size(), (unsigned long long)dbTotal, nSeeds, nPromising,
                      (unsigned long long)(ist.num_ext_score - ist.hits_duplicate), (unsigned long long)ist.num_ext_ali,
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
+        // where the wall clock went (the reference prints its own at verbosity 2, src/search.cpp): per worker the slowest counts
+        std::fprintf(stderr,
+                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding %.0f + extension on the GPU incl. widen / merge / "
+                     "statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
+                     msRead, msIndex, msSearch, msSeedMax, msExtendMax, msSince(tOut), msSince(tStart));
         return 0;
     }
     catch (std::exception const & e)

@@ -18,7 +18,9 @@
 // sets equal the FM-index's for words of any length.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -46,6 +48,31 @@ inline constexpr uint8_t kDna4[5] = {0, 1, 2, 0, 3};
 inline constexpr uint8_t kBsFwd[5] = {0, 1, 2, 1, 0};
 inline constexpr uint8_t kBsRev[5] = {3, 4, 3, 5, 3};
 
+// f(chunk) for chunk = 0 .. nChunks-1 on up to nThreads host threads, chunks handed out in order (the reference spreads its
+// batches over OpenMP threads the same way, src/search.cpp:379-385: schedule(dynamic))
+template <typename F>
+inline void parallelChunks(unsigned nThreads, size_t nChunks, F && f)
+{
+    if (nThreads <= 1 || nChunks <= 1)
+    {
+        for (size_t c = 0; c < nChunks; ++c)
+            f(c);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto                run = [&]()
+    {
+        for (size_t c = next.fetch_add(1); c < nChunks; c = next.fetch_add(1))
+            f(c);
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < std::min<size_t>(nThreads, nChunks); ++t)
+        pool.emplace_back(run);
+    run();
+    for (std::thread & t : pool)
+        t.join();
+}
+
 struct SeedParams // SearchOptions' seeding part, src/search_options.hpp:309-337
 {
     int seedLength = 10, seedOffset = 5, maxSeedDist = 0;
@@ -65,8 +92,10 @@ public:
         bool     empty() const { return count() == 0; }
     };
 
-    // red = reduced residues of all (frame-expanded) subject sequences, off/len per sequence; alph = reduced alphabet size
-    void build(std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
+    // red = reduced residues of all (frame-expanded) subject sequences, off/len per sequence; alph = reduced alphabet size.
+    // The table is made on nThreads host threads: keys per sequence, a scatter by the words' first kTopLen letters, every bucket
+    // sorted on its own -- by (key, sequence, position), so that the table does not depend on the number of threads.
+    void build(std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph, unsigned nThreads = 1)
     {
         red_    = red.data();
         off_    = off.data();
@@ -79,28 +108,85 @@ public:
         pow_.assign(keyLen_ + 1, 1);
         for (int i = 1; i <= keyLen_; ++i)
             pow_[i] = pow_[i - 1] * base_;
-        uint64_t total = 0;
-        for (uint64_t l : len)
-            total += l;
-        entries_.clear();
-        entries_.reserve(total);
-        for (size_t s = 0; s < off.size(); ++s)
+        size_t const          nSeq = off.size();
+        std::vector<uint64_t> first(nSeq + 1, 0); // entry index of every sequence's first position
+        for (size_t s = 0; s < nSeq; ++s)
+            first[s + 1] = first[s] + len[s];
+        uint64_t const total = first[nSeq];
+        constexpr int  kTopLen = 3;
+        uint64_t const topDiv = pow_[keyLen_ - kTopLen];
+        size_t const   nBuckets = (size_t)pow_[kTopLen];
+        std::vector<Entry> raw(total);
+        // contiguous ranges of sequences of about equal residue counts
+        size_t const        nParts = std::max<size_t>(1, std::min<size_t>(nSeq, (size_t)nThreads * 4));
+        std::vector<size_t> cut(nParts + 1, nSeq);
+        cut[0] = 0;
+        for (size_t part = 1, s = 0; part < nParts; ++part)
         {
-            // rolling key of the next keyLen_ letters, pad digit `alph` beyond the sequence end
-            uint64_t const L = len[s];
-            if (L == 0)
-                continue;
-            uint64_t key = 0;
-            for (int i = 0; i < keyLen_; ++i)
-                key = key * base_ + ((uint64_t)i < L ? red[off[s] + i] : (uint64_t)alph);
-            for (uint64_t p = 0; p < L; ++p)
-            {
-                entries_.push_back(Entry{key, (uint32_t)s, (uint32_t)p});
-                uint64_t const next = p + keyLen_ < L ? red[off[s] + p + keyLen_] : (uint64_t)alph;
-                key                 = (key % pow_[keyLen_ - 1]) * base_ + next;
-            }
+            while (s < nSeq && first[s] < total * part / nParts)
+                ++s;
+            cut[part] = s;
         }
-        std::sort(entries_.begin(), entries_.end(), [](Entry const & a, Entry const & b) { return a.key < b.key; });
+        std::vector<std::vector<uint64_t>> counts(nParts, std::vector<uint64_t>(nBuckets, 0));
+        parallelChunks(nThreads, nParts,
+                       [&](size_t part)
+                       {
+                           std::vector<uint64_t> & cnt = counts[part];
+                           for (size_t s = cut[part]; s < cut[part + 1]; ++s)
+                           {
+                               // rolling key of the next keyLen_ letters, pad digit `alph` beyond the sequence end
+                               uint64_t const L = len[s];
+                               if (L == 0)
+                                   continue;
+                               uint64_t key = 0;
+                               for (int i = 0; i < keyLen_; ++i)
+                                   key = key * base_ + ((uint64_t)i < L ? red[off[s] + i] : (uint64_t)alph);
+                               Entry * out = raw.data() + first[s];
+                               for (uint64_t p = 0; p < L; ++p)
+                               {
+                                   out[p] = Entry{key, (uint32_t)s, (uint32_t)p};
+                                   ++cnt[key / topDiv];
+                                   uint64_t const next = p + keyLen_ < L ? red[off[s] + p + keyLen_] : (uint64_t)alph;
+                                   key                 = (key % pow_[keyLen_ - 1]) * base_ + next;
+                               }
+                           }
+                       });
+        // where every (bucket, part) starts in the sorted table
+        std::vector<uint64_t> bucketAt(nBuckets + 1, 0);
+        for (size_t b = 0, at = 0; b < nBuckets; ++b)
+        {
+            bucketAt[b] = at;
+            for (size_t part = 0; part < nParts; ++part)
+            {
+                uint64_t const c = counts[part][b];
+                counts[part][b]  = at;
+                at += c;
+            }
+            bucketAt[b + 1] = at;
+        }
+        entries_.assign(total, Entry{});
+        parallelChunks(nThreads, nParts,
+                       [&](size_t part)
+                       {
+                           std::vector<uint64_t> & at = counts[part];
+                           for (uint64_t e = first[cut[part]]; e < first[cut[part + 1]]; ++e)
+                               entries_[at[raw[e].key / topDiv]++] = raw[e];
+                       });
+        raw.clear();
+        raw.shrink_to_fit();
+        // the big buckets first, so that the last threads do not start one when the others are done
+        std::vector<uint32_t> order(nBuckets);
+        for (size_t b = 0; b < nBuckets; ++b)
+            order[b] = (uint32_t)b;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucketAt[a + 1] - bucketAt[a] > bucketAt[b + 1] - bucketAt[b]; });
+        parallelChunks(nThreads, nBuckets,
+                       [&](size_t k)
+                       {
+                           uint32_t const b = order[k];
+                           std::sort(entries_.begin() + (std::ptrdiff_t)bucketAt[b], entries_.begin() + (std::ptrdiff_t)bucketAt[b + 1],
+                                     [](Entry const & x, Entry const & y)
+                                     { return x.key != y.key ? x.key < y.key : x.seq != y.seq ? x.seq < y.seq : x.pos < y.pos; });
+                       });
     }
 
     int    keyLen() const { return keyLen_; }
@@ -369,6 +455,50 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
             }
         }
         needlesPos += L; // :759
+    }
+}
+
+// The same over nThreads host threads: reads are independent (every bookkeeping value of seedQueries is reset at a read's first
+// frame), so `which` is cut at read boundaries, the pieces are searched side by side and their matches concatenated in order --
+// the list one thread would have produced.
+inline void seedQueriesParallel(ReducedIndex const & ix, SeedingInput const & in, SeedParams const & so, std::vector<uint64_t> const & which,
+                                std::vector<lx_match> & matches, SeedingStats & stats, unsigned nThreads)
+{
+    size_t const n = which.size();
+    if (nThreads <= 1 || n < 64)
+    {
+        seedQueries(ix, in, so, which, matches, stats);
+        return;
+    }
+    size_t const        nPieces = std::min<size_t>((size_t)nThreads * 8, n / 16 + 1);
+    std::vector<size_t> cut(nPieces + 1, n);
+    cut[0] = 0;
+    for (size_t k = 1; k < nPieces; ++k)
+    {
+        size_t w = std::max(cut[k - 1], n * k / nPieces);
+        while (w < n && which[w] % (uint64_t)in.qNumFrames != 0)
+            ++w;
+        cut[k] = w;
+    }
+    std::vector<std::vector<lx_match>> part(nPieces);
+    std::vector<SeedingStats>          pst(nPieces);
+    parallelChunks(nThreads, nPieces,
+                   [&](size_t k)
+                   {
+                       if (cut[k] >= cut[k + 1])
+                           return;
+                       std::vector<uint64_t> const mine(which.begin() + (std::ptrdiff_t)cut[k], which.begin() + (std::ptrdiff_t)cut[k + 1]);
+                       seedQueries(ix, in, so, mine, part[k], pst[k]);
+                   });
+    size_t total = matches.size();
+    for (auto const & v : part)
+        total += v.size();
+    matches.reserve(total);
+    for (size_t k = 0; k < nPieces; ++k)
+    {
+        matches.insert(matches.end(), part[k].begin(), part[k].end());
+        stats.hitsAfterSeeding += pst[k].hitsAfterSeeding;
+        stats.hitsFailedPreExtendTest += pst[k].hitsFailedPreExtendTest;
     }
 }
 

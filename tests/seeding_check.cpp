@@ -165,6 +165,84 @@ int main()
                 CHECK(red[off[hp.first] + hp.second + K] == (uint8_t)((rep[K] + 1) % alph));
         }
     }
+    // the table and the seeding on several host threads: the same cursors and the same match list as one thread gives
+    {
+        int const             alph = 10;
+        std::vector<uint8_t>  red, res;
+        std::vector<uint64_t> off, len;
+        for (int s = 0; s < 300; ++s)
+        {
+            off.push_back(red.size());
+            uint64_t const L = (s % 37 == 0) ? 0 : 5 + rng() % 400; // (empty sequences too)
+            len.push_back(L);
+            for (uint64_t i = 0; i < L; ++i)
+            {
+                res.push_back((uint8_t)(rng() % 20));
+                red.push_back(kLi10[res.back()]);
+            }
+        }
+        ReducedIndex one, many;
+        one.build(red, off, len, alph, 1);
+        many.build(red, off, len, alph, 5);
+        for (int trial = 0; trial < 200; ++trial)
+        {
+            size_t const s0 = rng() % off.size();
+            if (len[s0] < 12)
+                continue;
+            uint64_t const       p = rng() % (len[s0] - 11);
+            ReducedIndex::Cursor a = one.root(), b = many.root();
+            for (int i = 0; i < 11 && !a.empty(); ++i)
+            {
+                a = one.extendRight(a, red[off[s0] + p + i]);
+                b = many.extendRight(b, red[off[s0] + p + i]);
+                CHECK(a.lo == b.lo && a.hi == b.hi);
+            }
+            std::vector<std::pair<uint32_t, uint32_t>> ha, hb;
+            one.locate(a, [&](uint32_t s, uint32_t q) { ha.emplace_back(s, q); });
+            many.locate(b, [&](uint32_t s, uint32_t q) { hb.emplace_back(s, q); });
+            CHECK(ha == hb && std::is_sorted(ha.begin(), ha.end())); // (equal words: by sequence, then position)
+        }
+        // reads: mutated pieces of the database, two frames per read (the second one the same letters: what matters is the reset)
+        std::vector<uint8_t>  qres, qred;
+        std::vector<uint64_t> qoff, qlen, which;
+        for (int r = 0; r < 400; ++r)
+        {
+            size_t s0 = rng() % off.size();
+            while (len[s0] < 60)
+                s0 = rng() % off.size();
+            uint64_t const p = rng() % (len[s0] - 50);
+            for (int frame = 0; frame < 2; ++frame)
+            {
+                qoff.push_back(qres.size());
+                qlen.push_back(r % 29 == 0 ? 6 : 50); // (reads too short for a seed are skipped)
+                for (uint64_t i = 0; i < qlen.back(); ++i)
+                {
+                    uint8_t const c = (i % 11 == 7) ? (uint8_t)((res[off[s0] + p + i] + 1 + r % 3) % 20) : res[off[s0] + p + i];
+                    qres.push_back(c);
+                    qred.push_back(kLi10[c]);
+                }
+                which.push_back(qoff.size() - 1);
+            }
+        }
+        int8_t m[LX_ALPH * LX_ALPH];
+        for (int a = 0; a < 32; ++a)
+            for (int b = 0; b < 32; ++b)
+                m[a * LX_ALPH + b] = a == b ? 5 : -2;
+        SeedingInput in{};
+        in.qRes = qres.data(), in.qRed = qred.data(), in.qOff = qoff.data(), in.qLen = qlen.data(), in.nQSeq = qoff.size();
+        in.qNumFrames = 2, in.unknownRank = 25;
+        in.sRes = res.data(), in.sOff = off.data(), in.sLen = len.data();
+        in.alph = alph, in.matrix = m, in.maxMatches = 25, in.halfExact = true, in.adaptive = true, in.preScoring = 2, in.preScoringThresh = 2.0;
+        for (SeedParams const so : {SeedParams{10, 5, 0}, SeedParams{11, 3, 1}})
+        {
+            std::vector<lx_match> a, b;
+            SeedingStats          sa, sb;
+            seedQueries(one, in, so, which, a, sa);
+            seedQueriesParallel(many, in, so, which, b, sb, 7);
+            CHECK(!a.empty() && a.size() == b.size() && sa.hitsAfterSeeding == sb.hitsAfterSeeding && sa.hitsFailedPreExtendTest == sb.hitsFailedPreExtendTest);
+            CHECK(a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(lx_match)) == 0);
+        }
+    }
     // seedLooksPromising: the planted diagonal passes, a random one does not
     {
         int8_t m[LX_ALPH * LX_ALPH];

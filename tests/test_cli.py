@@ -307,22 +307,25 @@ def test_searchp_tblastn_translated_subjects(tmp_path):
 @pytest.mark.gpu
 def test_devices_split_gives_identical_output(tmp_path):
     """The thread / device split of realMain (/root/reference/src/search.cpp:379-385): two handles on one GPU (`--devices 0,0`),
-    three worker threads (`-t 3`) and the single-handle run write byte-identical BLAST-tabular and SAM files."""
+    one / three / all granted host threads for the word table and the seeding (`-t`) write byte-identical BLAST-tabular and SAM
+    files."""
     _make_config1(tmp_path, nq=300, ndb=800)
     db, qry = tmp_path / "db.fasta", tmp_path / "q.fasta"
     outs = {}
-    for tag, extra in (("one", ["--devices", "0"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0", "-t", "3"])):
+    for tag, extra in (("one", ["--devices", "0", "-t", "1"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0", "-t", "3"]),
+                       ("two-five", ["--devices", "0,0", "-t", "5"])):
         for ext in ("m8", "sam"):
             out = tmp_path / f"{tag}.{ext}"
             # (--version-to-outputfile 0, as the reference's own CLI tests pass it: no @PG line with the command line in the SAM header)
             r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out), "--version-to-outputfile", "0"] + extra,
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
-            assert ("2 thread(s)" in r.stderr) == (tag == "two") and ("3 thread(s)" in r.stderr) == (tag == "three"), r.stderr
+            assert ("2 handle(s)" in r.stderr) == tag.startswith("two") and ("3 host thread(s)" in r.stderr) == (tag == "three"), r.stderr
+            assert ("1 host thread(s)" in r.stderr) == (tag == "one") and "lambda3 times [ms]" in r.stderr, r.stderr
             outs[(tag, ext)] = out.read_bytes()
     assert len(outs[("one", "m8")].splitlines()) >= 50
     for ext in ("m8", "sam"):
-        assert outs[("one", ext)] == outs[("two", ext)] == outs[("three", ext)]
+        assert outs[("one", ext)] == outs[("two", ext)] == outs[("three", ext)] == outs[("two-five", ext)]
     r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(tmp_path / "x.m8"), "--devices", "7"], capture_output=True, text=True)
     assert r.returncode != 0 and "device_id 7 out of range" in r.stderr
 

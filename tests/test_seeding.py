@@ -9,7 +9,7 @@ ROOT = Path(__file__).resolve().parent.parent
 
 def test_seeding_against_brute_force(tmp_path):
     exe = tmp_path / "seeding_check"
-    r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", str(ROOT / "tests" / "seeding_check.cpp"), "-o", str(exe)],
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-pthread", str(ROOT / "tests" / "seeding_check.cpp"), "-o", str(exe)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
