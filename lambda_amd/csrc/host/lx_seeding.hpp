@@ -187,6 +187,27 @@ public:
                                      [](Entry const & x, Entry const & y)
                                      { return x.key != y.key ? x.key < y.key : x.seq != y.seq ? x.seq < y.seq : x.pos < y.pos; });
                        });
+        // where the words with every prefix of preLen_ letters begin: the first letters of a seed cost one table read each instead
+        // of two binary searches over the whole table (the probes that miss every cache)
+        preLen_ = 1;
+        while (preLen_ + 1 < keyLen_ && pow_[preLen_ + 1] <= (4u << 20))
+            ++preLen_;
+        uint64_t const preDiv = pow_[keyLen_ - preLen_];
+        pre_.assign((size_t)pow_[preLen_] + 1, total);
+        size_t const nCuts = std::max<size_t>(1, (size_t)nThreads * 4);
+        parallelChunks(nThreads, nCuts,
+                       [&](size_t k)
+                       {
+                           uint64_t const lo = total * k / nCuts, hi = total * (k + 1) / nCuts;
+                           // pre_[w] = first entry whose word is >= w: every w in (word of entry e-1, word of entry e] begins at e
+                           uint64_t prev = lo == 0 ? 0 : entries_[lo - 1].key / preDiv + 1;
+                           for (uint64_t e = lo; e < hi; ++e)
+                           {
+                               uint64_t const w = entries_[e].key / preDiv;
+                               for (; prev <= w; ++prev)
+                                   pre_[prev] = e;
+                           }
+                       });
     }
 
     int    keyLen() const { return keyLen_; }
@@ -217,11 +238,63 @@ public:
         Cursor n = cu;
         n.prefix = cu.prefix * base_ + c;
         n.len    = cu.len + 1;
+        if (n.len <= preLen_)
+        {
+            uint64_t const span = pow_[preLen_ - n.len];
+            n.lo                = pre_[n.prefix * span];
+            n.hi                = pre_[(n.prefix + 1) * span];
+            return n;
+        }
         uint64_t const scale = pow_[keyLen_ - n.len], first = n.prefix * scale, last = first + (scale - 1);
+        if (cu.hi - cu.lo <= 16) // a handful of neighbouring entries: one pass over them instead of two binary searches
+        {
+            uint64_t a = cu.lo;
+            while (a < cu.hi && entries_[a].key < first)
+                ++a;
+            uint64_t z = a;
+            while (z < cu.hi && entries_[z].key <= last)
+                ++z;
+            n.lo = a, n.hi = z;
+            return n;
+        }
         auto const     b = entries_.begin() + (std::ptrdiff_t)cu.lo, e = entries_.begin() + (std::ptrdiff_t)cu.hi;
         n.lo = (uint64_t)(std::lower_bound(b, e, first, [](Entry const & x, uint64_t k) { return x.key < k; }) - entries_.begin());
-        n.hi = (uint64_t)(std::upper_bound(b, e, last, [](uint64_t k, Entry const & x) { return k < x.key; }) - entries_.begin());
+        n.hi = (uint64_t)(std::lower_bound(entries_.begin() + (std::ptrdiff_t)n.lo, e, last + 1, [](Entry const & x, uint64_t k) { return x.key < k; }) - entries_.begin());
         return n;
+    }
+
+    // the cursors of word + r for every letter r = 0 .. alph-1 (out[r]; empty ones included): the children of a table range lie
+    // side by side in letter order, so one boundary search per letter does (a scan when the range is short) instead of two
+    void extendAll(Cursor const & cu, Cursor * out) const
+    {
+        int const nl = cu.len + 1;
+        if (cu.len >= keyLen_ || nl <= preLen_)
+        {
+            for (int r = 0; r < alph_; ++r)
+                out[r] = extendRight(cu, (uint8_t)r);
+            return;
+        }
+        uint64_t const scale = pow_[keyLen_ - nl], word0 = cu.prefix * base_;
+        uint64_t       at    = cu.lo;
+        for (int r = 0; r <= alph_; ++r)
+        {
+            // first entry of [at, hi) whose word of nl letters is >= word0 + r
+            uint64_t const first = (word0 + (uint64_t)r) * scale;
+            if (cu.hi - at <= 24)
+                while (at < cu.hi && entries_[at].key < first)
+                    ++at;
+            else
+                at = (uint64_t)(std::lower_bound(entries_.begin() + (std::ptrdiff_t)at, entries_.begin() + (std::ptrdiff_t)cu.hi, first,
+                                                 [](Entry const & x, uint64_t k) { return x.key < k; }) -
+                                entries_.begin());
+            if (r > 0)
+                out[r - 1].hi = at;
+            if (r < alph_)
+            {
+                out[r].lo = at, out[r].len = nl, out[r].prefix = word0 + (uint64_t)r, out[r].listed = false;
+                out[r].sel.clear();
+            }
+        }
     }
 
     template <typename F>
@@ -244,7 +317,8 @@ private:
         uint32_t seq, pos;
     };
     std::vector<Entry>    entries_;
-    std::vector<uint64_t> pow_;
+    std::vector<uint64_t> pow_, pre_; // pre_[w] = first entry whose first preLen_ letters are >= the word w
+    int                   preLen_ = 0;
     uint8_t const *       red_ = nullptr; // the caller's reduced residues and sequence table (must outlive the index)
     uint64_t const *      off_ = nullptr;
     uint64_t const *      len_ = nullptr;
@@ -290,12 +364,11 @@ inline void searchHalfExact(ReducedIndex const & ix, uint8_t const * seed, int s
         {
             if (errors < maxSeedDist)
             {
+                ReducedIndex::Cursor kids[32];
+                ix.extendAll(cursor, kids);
                 for (int r = 0; r < alph; ++r)
-                {
-                    ReducedIndex::Cursor n = ix.extendRight(cursor, (uint8_t)r);
-                    if (!n.empty())
-                        nxt.emplace_back(n, errors + ((uint8_t)r != want));
-                }
+                    if (!kids[r].empty())
+                        nxt.emplace_back(kids[r], errors + ((uint8_t)r != want));
             }
             else
             {
