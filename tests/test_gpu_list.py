@@ -86,6 +86,31 @@ def test_list_of_a_ragged_seed_list(handle, seed, shuffle, chunk):
     assert len(index) > 100
 
 
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_mid_size_ragged_list_on_several_host_threads(handle, oracle, shuffle):
+    """Between 24 000 and 250 000 extensions the host's loops (validation, order, plan, unpacking) run on a few threads, one per
+    24 000 extensions: a ragged list of that size -- the multi-query plan, grouped by query or in random order, dead extensions --
+    gives the oracle's scores, and the list entry the rows of the run-length entry."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_ragged_lists_np(12_000, seed=77, lq_range=(40, 300), mean_windows=5.0, merged_frac=0.15)
+    assert 24_000 < len(ext) < 250_000
+    if shuffle:
+        ext = ext[np.random.default_rng(9).permutation(len(ext))]
+    ext = ext.copy()
+    ext["s_len"][::23] = 0
+    mins = np.where(np.arange(len(ext)) % 4 == 0, 95, 55).astype(np.int32)
+    index, _ = check_list_against_rle(handle, q, s, ext, mins, 0, expect_kernel="sweep_mq_kernel")
+    assert len(index) > 5_000
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(sc_p), threads=8)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    try:
+        score = handle.extend_batch_list(q, s, ext, mins)[0]
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+    assert (score == want).all()
+
+
 def test_list_with_no_survivor_and_with_an_empty_list(handle):
     handle.set_scoring(SCHEMES["blosum62"], 0)
     q, s, ext = synth.make_batch_np(64, 120, 8, seed=3)
