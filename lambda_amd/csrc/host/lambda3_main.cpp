@@ -20,9 +20,15 @@
 //     seeding, both scoring schemes (src/bisulfite_scoring.hpp:67-93), iterateMatches' bisulfite branch (:1367-1379);
 //   * the per-batch flow of realMain (src/search.cpp:389-459): seeding -> seedLooksPromising -> iterateMatches ->
 //     writeRecords, with the three middle stages on the GPU through the C ABI;
+//   * mkindexp | mkindexn | mkindexbs (src/lambda.cpp:86-88, src/mkindex_options.hpp:96-262: -d, -i with the .lba / .lta name and the
+//     refusal to overwrite, -r, -g, --input-alphabet, --truncate-ids, --db-index-type, -t) and `search* -i INDEX`: the index file
+//     holds what the reference's holds (the options that fix the types, ids, sequences in the translated alphabet; no taxonomy)
+//     with this front end's word table in the FM-index's place -- its own format, not the reference's cereal archive; the
+//     searches take the domain, the reduction and the subjects' genetic code from it and refuse an index of another domain
+//     with the reference's messages (src/search.cpp:157-207);
 //   * NOT the FM-index: the reference searches an index built by `lambda3 mkindexp` (fmindex-collection, absent here,
-//     out of scope).  This front end takes the database as FASTA (-d) and answers the seeding stage's questions from a
-//     sorted table of reduced words (host/lx_seeding.hpp) -- with the reference's seeding semantics: Li-10 reduction,
+//     out of scope).  This front end answers the seeding stage's questions from a
+//     sorted table of reduced words (host/lx_seeding.hpp), read from its index file (-i) or made in memory from FASTA (-d) -- with the reference's seeding semantics: Li-10 reduction,
 //     exact seeds 10/5 first, then (queries without a result) half-exact seeds 11/3 with one substitution in the second
 //     half, adaptive elongation, over-abundant seeds dropped, seedLooksPromising per hit (src/search_algo.hpp:426-762,
 //     :1391-1457; defaults src/search_options.hpp:309-337).  Everything after seeding follows the reference too.
@@ -209,6 +215,11 @@ struct Options
     std::string commandLine;
     std::vector<int> devices;         // --devices (default: every visible device)
     int         threads     = 0;    // -t host threads for the word table and the seeding (default: what the machine grants)
+    // mkindex* (src/mkindex_options.hpp:96-262): -d the database (FASTA), -i the index file to write
+    std::string index;                // -i of mkindex* (default: DATABASE.lba, :132, :249-250)
+    std::string dbIndexType = "fm";   // --db-index-type fm | bifm (:157-165; recorded, the word table answers both)
+    bool        truncateIds = false;  // --truncate-ids (:167-173)
+    bool        geneticCodeGiven = false;
     std::string qryAlphabet = "auto"; // searchp: "aminoacid" = BLASTP, "dna5" = BLASTX, "auto" = decide from the letters
     std::string dbAlphabet  = "auto"; // searchp: "dna5" = six-frame translated subjects (TBLASTN / TBLASTX)
 };
@@ -239,12 +250,13 @@ Options parse(int argc, char ** argv)
 {
     Options o;
     if (argc < 2)
-        throw std::runtime_error("usage: lambda3 searchp|searchn|searchbs -q QUERY.fasta -d DB.fasta -o OUT.{m8,m9,sam} [-e EVALUE] [-n N] "
-                                 "[--devices 0,1,...] [-t THREADS]");
+        throw std::runtime_error("usage: lambda3 searchp|searchn|searchbs -q QUERY.fasta (-i DB.lba | -d DB.fasta) -o OUT.{m8,m9,sam} [-e EVALUE] [-n N] "
+                                 "[--devices 0,1,...] [-t THREADS]\n       lambda3 mkindexp|mkindexn|mkindexbs -d DB.fasta [-i DB.lba] [-r li10|murphy10|none] [-g CODE] [-t THREADS]");
     o.cmd = argv[1];
-    if (o.cmd != "searchp" && o.cmd != "searchn" && o.cmd != "searchbs")
-        throw std::runtime_error("unknown subcommand '" + o.cmd + "' (searchp, searchn and searchbs are in scope)");
-    bool const prot = o.cmd == "searchp", bs = o.cmd == "searchbs";
+    bool const mk = o.cmd == "mkindexp" || o.cmd == "mkindexn" || o.cmd == "mkindexbs";
+    if (o.cmd != "searchp" && o.cmd != "searchn" && o.cmd != "searchbs" && !mk)
+        throw std::runtime_error("unknown subcommand '" + o.cmd + "' (searchp, searchn, searchbs, mkindexp, mkindexn, mkindexbs: src/lambda.cpp:86-88)");
+    bool const prot = o.cmd == "searchp" || o.cmd == "mkindexp", bs = o.cmd == "searchbs" || o.cmd == "mkindexbs";
     // per-domain defaults, src/search_options.hpp:309-337 (bisulfite: :261-264, :328-336)
     o.seedLength0      = prot ? 10 : bs ? 17 : 14;
     o.seedOffset0      = prot ? 5 : bs ? 10 : 9;
@@ -284,6 +296,18 @@ Options parse(int argc, char ** argv)
         };
         if (a == "-q" || a == "--query")
             o.query = val();
+        else if (mk && (a == "-i" || a == "--index"))
+            o.index = val();
+        else if (mk && a == "--db-index-type")
+        {
+            o.dbIndexType = val();
+            if (o.dbIndexType != "fm" && o.dbIndexType != "bifm")
+                throw std::runtime_error("--db-index-type takes fm or bifm");
+        }
+        else if (mk && a == "--truncate-ids")
+            o.truncateIds = true;
+        else if (mk && (a == "-m" || a == "--acc-tax-map" || a == "-x" || a == "--tax-dump-dir"))
+            throw std::runtime_error(a + ": the taxonomy part of the index (src/mkindex_options.hpp:113-128) is not built by this front end");
         else if (a == "-d" || a == "--database" || a == "-i" || a == "--index")
             o.db = val();
         else if (a == "-o" || a == "--output")
@@ -372,7 +396,10 @@ Options parse(int argc, char ** argv)
                 throw std::runtime_error("--alphabet-reduction takes none, murphy10 or li10");
         }
         else if (a == "-g" || a == "--genetic-code")
-            o.geneticCode = std::stoi(val());
+        {
+            o.geneticCode      = std::stoi(val());
+            o.geneticCodeGiven = true;
+        }
         else if (a == "--percent-identity")
             o.idCutOff = std::stoi(val());
         else if (a == "--device" || a == "--devices")
@@ -399,17 +426,32 @@ Options parse(int argc, char ** argv)
         }
         else if (a == "-a" || a == "--query-alphabet" || a == "--input-alphabet") // (the reference's name is --input-alphabet, :172-185)
         {
-            o.qryAlphabet = val();
-            if (o.qryAlphabet != "auto" && o.qryAlphabet != "dna5" && o.qryAlphabet != "aminoacid")
-                throw std::runtime_error("--query-alphabet takes auto, dna5 or aminoacid");
+            std::string & which = mk ? o.dbAlphabet : o.qryAlphabet; // (mkindexp: the database's, src/mkindex_options.hpp:189-197)
+            which               = val();
+            if (which != "auto" && which != "dna5" && which != "aminoacid")
+                throw std::runtime_error("--input-alphabet takes auto, dna5 or aminoacid");
         }
         else if (a == "-v" || a == "--verbosity" || a == "--lazy-query")
             (void)val(); // accepted for command-line compatibility, no effect here
         else
             throw std::runtime_error("unknown option " + a);
     }
+    if (mk)
+    {
+        if (o.db.empty())
+            throw std::runtime_error("-d is required");
+        if (o.index.empty())
+            o.index = o.db + ".lba"; // :249-250
+        auto ends = [&](char const * suf)
+        { return o.index.size() >= std::strlen(suf) && o.index.compare(o.index.size() - std::strlen(suf), std::string::npos, suf) == 0; };
+        if (!ends(".lba") && !ends(".lta")) // :133, :145
+            throw std::runtime_error("the index file name must end in .lba or .lta");
+        if (std::ifstream(o.index).good()) // :252-256
+            throw std::runtime_error("ERROR: An output file already exists at " + o.index + "\n       Remove it, or choose a different location.");
+        return o;
+    }
     if (o.query.empty() || o.db.empty())
-        throw std::runtime_error("-q and -d are required");
+        throw std::runtime_error("-q and -d (a FASTA file) or -i (an index made by lambda3 mkindex*) are required");
     // "Setting a profile other than none always overwrites manually given command line arguments" (:563-566, applied :634-681)
     if (o.profile == "fast")
     {
@@ -442,6 +484,120 @@ Options parse(int argc, char ** argv)
     return o;
 }
 
+// ---- the index file of `lambda3 mkindex*`.  It holds what the reference's index_file holds (src/shared_definitions.hpp:343-379:
+// the options that fix the types, the ids, the sequences in the translated alphabet) except the taxonomy, and this front end's
+// word table in place of the FM-index.  NOT the reference's on-disk format: that is a cereal archive of fmindex-collection
+// objects, neither of which is available here; a file of the reference is recognised by the missing magic and refused.
+constexpr char kIndexMagic[8] = {'L', 'X', 'I', 'N', 'D', 'E', 'X', '1'};
+// AlphabetEnum / DbIndexType with the reference's numbering (src/shared_definitions.hpp:62-66, :127-136)
+enum : uint8_t { kAlphUndefined = 0, kAlphDna3Bs = 1, kAlphDna4 = 2, kAlphDna5 = 3, kAlphAminoAcid = 4, kAlphMurphy10 = 5, kAlphLi10 = 6 };
+struct IndexFileOptions // index_file_options, :318-341
+{
+    uint64_t generation = 0; // supportedIndexGeneration, :316
+    uint8_t  indexType = 0, origAlph = kAlphUndefined, transAlph = kAlphUndefined, redAlph = kAlphUndefined, geneticCode = 1, pad[3] = {0, 0, 0};
+};
+char const * alphName(uint8_t a) // _alphabetEnumToName, :138-160
+{
+    static char const * const names[] = {"UNDEFINED", "dna3bs", "dna4", "dna5", "aminoacid", "murphy10", "li10"};
+    return a < 7 ? names[a] : "?";
+}
+
+bool isIndexFile(std::string const & path)
+{
+    std::ifstream f(path, std::ios::binary);
+    char          m[8] = {0};
+    return f.read(m, 8) && std::memcmp(m, kIndexMagic, 8) == 0;
+}
+
+void writeIndexFile(std::string const & path, IndexFileOptions const & io, SeqSet const & db, lambda_amd::ReducedIndex const & ix)
+{
+    FILE * f = std::fopen(path.c_str(), "wb");
+    if (!f)
+        throw std::runtime_error("cannot write " + path);
+    bool ok    = true;
+    auto write = [&](void const * p, size_t bytes) { ok = ok && (bytes == 0 || std::fwrite(p, 1, bytes, f) == bytes); };
+    auto u64   = [&](uint64_t v) { write(&v, sizeof(v)); };
+    write(kIndexMagic, 8);
+    write(&io, sizeof(io));
+    u64(db.ids.size());
+    for (std::string const & id : db.ids)
+    {
+        u64(id.size());
+        write(id.data(), id.size());
+    }
+    u64(db.off.size());
+    write(db.off.data(), db.off.size() * sizeof(uint64_t));
+    write(db.len.data(), db.len.size() * sizeof(uint64_t));
+    u64(db.orig_len.size());
+    write(db.orig_len.data(), db.orig_len.size() * sizeof(uint64_t));
+    u64(db.res.size());
+    write(db.res.data(), db.res.size());
+    ix.save(write);
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok)
+    {
+        std::remove(path.c_str());
+        throw std::runtime_error("error while writing " + path);
+    }
+}
+
+// everything but the word table (which wants the reduced residues first); the file stays open in *fp
+void readIndexHead(std::string const & path, IndexFileOptions & io, SeqSet & db, FILE ** fp)
+{
+    FILE * f = std::fopen(path.c_str(), "rb");
+    if (!f)
+        throw std::runtime_error("cannot open " + path);
+    auto bad = [&](char const * what) -> std::runtime_error
+    {
+        std::fclose(f);
+        return std::runtime_error("index file " + path + ": " + what);
+    };
+    auto read = [&](void * p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, f) == bytes; };
+    char m[8];
+    if (!read(m, 8) || std::memcmp(m, kIndexMagic, 8) != 0)
+        throw bad("not an index of this front end (an index of the reference -- a cereal archive of an fmindex-collection FM-index -- cannot be "
+                  "read here: run lambda3 mkindexp|mkindexn|mkindexbs on the FASTA file)");
+    if (!read(&io, sizeof(io)))
+        throw bad("truncated");
+    if (io.generation != 0) // :316 "bump this on incompatible changes"; src/search.cpp readIndexOptions
+        throw bad("unsupported index generation");
+    uint64_t n = 0;
+    auto     count = [&](uint64_t limit) -> uint64_t
+    {
+        uint64_t v = 0;
+        if (!read(&v, sizeof(v)) || v > limit)
+            throw bad("truncated or corrupt");
+        return v;
+    };
+    n = count(1ull << 40);
+    db.ids.resize(n);
+    for (std::string & id : db.ids)
+    {
+        id.resize(count(1ull << 24));
+        if (!read(id.data(), id.size()))
+            throw bad("truncated");
+    }
+    n = count(1ull << 40);
+    db.off.resize(n);
+    db.len.resize(n);
+    if (!read(db.off.data(), n * sizeof(uint64_t)) || !read(db.len.data(), n * sizeof(uint64_t)))
+        throw bad("truncated");
+    n = count(1ull << 40);
+    db.orig_len.resize(n);
+    if (!read(db.orig_len.data(), n * sizeof(uint64_t)))
+        throw bad("truncated");
+    n = count(1ull << 46);
+    db.res.resize(n);
+    if (!read(db.res.data(), n))
+        throw bad("truncated");
+    if (db.orig_len.size() != db.ids.size() || db.off.empty() || db.off.size() % db.ids.size() != 0)
+        throw bad("inconsistent sequence tables");
+    for (size_t i = 0; i < db.off.size(); ++i)
+        if (db.len[i] > db.res.size() || db.off[i] > db.res.size() - db.len[i])
+            throw bad("a sequence lies outside the residues");
+    *fp = f;
+}
+
 // host threads this process may use: the hardware's, capped by the affinity mask and the cgroup's CPU quota
 unsigned grantedThreads()
 {
@@ -468,22 +624,137 @@ int main(int argc, char ** argv)
         auto const    tStart = std::chrono::steady_clock::now();
         auto          msSince = [](std::chrono::steady_clock::time_point a)
         { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
-        bool const    prot = opt.cmd == "searchp", bs = opt.cmd == "searchbs";
+        bool const    mk = opt.cmd.rfind("mkindex", 0) == 0;
+        bool const    prot = opt.cmd == "searchp" || opt.cmd == "mkindexp", bs = opt.cmd == "searchbs" || opt.cmd == "mkindexbs";
+        // -i / -d names an index made by `lambda3 mkindex*`, or the database as FASTA (the table is then made in memory)
+        bool const    fromIndex = !mk && isIndexFile(opt.db);
+        SeqSet           qs, db;
+        IndexFileOptions ifo;
+        FILE *           indexFile = nullptr;
+        if (fromIndex)
+        {
+            readIndexHead(opt.db, ifo, db, &indexFile);
+            // the index fixes the domain (src/search.cpp:189-207)
+            try
+            {
+                if (prot && ifo.transAlph != kAlphAminoAcid)
+                    throw std::runtime_error("Attempting to use nucleotide or bisulfite index for protein search.");
+                if (!prot && ifo.transAlph != kAlphDna5)
+                    throw std::runtime_error(bs ? "Attempting to use protein index for bisulfite search." : "Attempting to use protein index for nucleotide search.");
+                if (!prot && !bs && ifo.redAlph != kAlphDna4)
+                    throw std::runtime_error("Attempting to use bisulfite index for nucleotide search.");
+                if (bs && ifo.redAlph != kAlphDna3Bs)
+                    throw std::runtime_error("Attempting to use nucleotid index for bisulfite search.");
+            }
+            catch (...)
+            {
+                std::fclose(indexFile);
+                throw;
+            }
+        }
+        std::string const reduction = !fromIndex ? opt.reduction : ifo.redAlph == kAlphLi10 ? "li10" : ifo.redAlph == kAlphMurphy10 ? "murphy10" : "none";
         // searchp with nucleotide queries is BLASTX: six translated frames per query against the protein database
-        bool const    blastx = prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
+        bool const    blastx = !mk && prot && (opt.qryAlphabet == "dna5" || (opt.qryAlphabet == "auto" && looksLikeDna(opt.query)));
         // searchp against a nucleotide database translates the subjects instead (TBLASTN), or both sides (TBLASTX)
-        bool const    sTrans  = prot && (opt.dbAlphabet == "dna5" || (opt.dbAlphabet == "auto" && looksLikeDna(opt.db)));
+        bool const    sTrans  = fromIndex ? (prot && ifo.origAlph != ifo.transAlph)
+                                          : prot && (opt.dbAlphabet == "dna5" || (opt.dbAlphabet == "auto" && looksLikeDna(opt.db)));
+        // genetic code: the subjects' is the index's; the queries' is -g, else the index's (src/search.cpp:157-178)
+        int const geneticCodeDb  = fromIndex ? (int)ifo.geneticCode : opt.geneticCode;
+        int const geneticCodeQry = (opt.geneticCodeGiven || !fromIndex || !sTrans) ? opt.geneticCode : (int)ifo.geneticCode;
+        if (fromIndex && sTrans && geneticCodeQry != geneticCodeDb)
+            std::cerr << "WARNING: The genetic code used when creating the index: " << geneticCodeDb
+                      << "\n         is not the same as now selected for the query sequences: " << geneticCodeQry
+                      << "\n         Are you sure this is what you want?\n";
         // frames per sequence, src/search_datastructures.hpp:380-385
         int const     qFrames = bs ? 4 : blastx ? 6 : prot ? 1 : 2;
         int const     sFrames = bs ? 2 : sTrans ? 6 : 1;
         char const *  program = blastx ? (sTrans ? "tblastx" : "blastx") : sTrans ? "tblastn" : prot ? "blastp" : "blastn";
 
-        SeqSet qs, db;
-        readFasta(opt.query, prot, !prot, qs, blastx, opt.geneticCode, bs ? 2 : 0);
-        readFasta(opt.db, prot, false, db, sTrans, opt.geneticCode, bs ? 1 : 0);
-        if (qs.ids.empty() || db.ids.empty())
+        if (!mk)
+            readFasta(opt.query, prot, !prot, qs, blastx, geneticCodeQry, bs ? 2 : 0);
+        if (!fromIndex)
+        {
+            std::ifstream probe(opt.db, std::ios::binary);
+            char          c = 0;
+            while (probe.get(c) && std::isspace((unsigned char)c))
+                ;
+            if (probe && c != '>')
+                throw std::runtime_error(opt.db + " is neither a FASTA file nor an index of this front end (an index written by the reference -- a cereal "
+                                         "archive of an fmindex-collection FM-index -- cannot be read here: run lambda3 mkindexp|mkindexn|mkindexbs on the FASTA file)");
+            readFasta(opt.db, prot, false, db, sTrans, geneticCodeDb, bs ? 1 : 0);
+        }
+        if ((!mk && qs.ids.empty()) || db.ids.empty())
             throw std::runtime_error("empty query or database file");
+        if (fromIndex && db.off.size() != db.ids.size() * (size_t)sFrames)
+            throw std::runtime_error("index file " + opt.db + ": the frames of its sequences do not fit its alphabets");
+        if (mk && opt.truncateIds) // src/mkindex_algo.hpp:123
+            for (std::string & id : db.ids)
+                id.resize(std::min(id.size(), id.find_first_of(" \t")));
         double const msRead = msSince(tStart);
+        unsigned const nThreads = opt.threads > 0 ? (unsigned)opt.threads : grantedThreads();
+
+        // ---- the reduced alphabet of the seeding stage and the word table over the reduced database (the FM-index's place)
+        uint8_t const * redTab = nullptr;
+        int             alph   = 27;
+        if (prot && reduction == "li10")
+            redTab = lambda_amd::kLi10, alph = 10;
+        else if (prot && reduction == "murphy10")
+            redTab = lambda_amd::kMurphy10, alph = 10;
+        else if (bs)
+            alph = 6;
+        else if (!prot)
+            redTab = lambda_amd::kDna4, alph = 4;
+        // bisulfite: the reduction alternates with the frame (even: forward, odd: reverse; src/view_reduce_to_bisulfite.hpp:132-136)
+        auto reduce = [&](SeqSet const & set)
+        {
+            std::vector<uint8_t> red(set.res.size());
+            if (bs)
+            {
+                for (size_t f = 0; f < set.off.size(); ++f)
+                    for (uint64_t i = 0; i < set.len[f]; ++i)
+                        red[set.off[f] + i] = ((f & 1) ? lambda_amd::kBsRev : lambda_amd::kBsFwd)[std::min<uint8_t>(set.res[set.off[f] + i], 4)];
+                return red;
+            }
+            for (size_t i = 0; i < set.res.size(); ++i)
+                red[i] = redTab ? redTab[set.res[i] < (prot ? 27 : 5) ? set.res[i] : 0] : set.res[i];
+            return red;
+        };
+        auto const                 tIndex = std::chrono::steady_clock::now();
+        std::vector<uint8_t> const dbRed = reduce(db);
+        lambda_amd::ReducedIndex   ix;
+        if (fromIndex)
+        {
+            bool const ok = ix.load([&](void * p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, indexFile) == bytes; }, dbRed, db.off, db.len) &&
+                            ix.alphabet() == alph;
+            std::fclose(indexFile);
+            if (!ok)
+                throw std::runtime_error("index file " + opt.db + ": the word table is truncated or does not fit the sequences");
+        }
+        else
+            ix.build(dbRed, db.off, db.len, alph, nThreads);
+        double const msIndex = msSince(tIndex);
+        if (mk)
+        {
+            // mkindexp | mkindexn | mkindexbs (src/mkindex.cpp): the options that fix the types, ids, sequences, table -> one file
+            IndexFileOptions out;
+            out.indexType   = opt.dbIndexType == "bifm" ? 1 : 0;
+            out.origAlph    = prot ? (sTrans ? kAlphDna5 : kAlphAminoAcid) : kAlphDna5; // :206-224, :235
+            out.transAlph   = prot ? kAlphAminoAcid : kAlphDna5;
+            out.redAlph     = bs ? kAlphDna3Bs : !prot ? kAlphDna4 : reduction == "li10" ? kAlphLi10 : reduction == "murphy10" ? kAlphMurphy10 : kAlphAminoAcid;
+            out.geneticCode = (uint8_t)geneticCodeDb;
+            auto const tWrite = std::chrono::steady_clock::now();
+            writeIndexFile(opt.index, out, db, ix);
+            uint64_t residues = 0;
+            for (auto l : db.len)
+                residues += l;
+            std::fprintf(stderr,
+                         "lambda3 %s: %zu sequences (%llu residues in %d frame(s); original alphabet %s, translated %s, reduced %s, genetic code %d) -> %s\n"
+                         "lambda3 times [ms]: read %.0f, reduce + word table %.0f (%u host thread(s)), write %.0f, total %.0f\n",
+                         opt.cmd.c_str(), db.ids.size(), (unsigned long long)residues, sFrames, alphName(out.origAlph), alphName(out.transAlph),
+                         alphName(out.redAlph), (int)out.geneticCode, opt.index.c_str(), msRead, msIndex, nThreads, msSince(tWrite), msSince(tStart));
+            return 0;
+        }
+        std::vector<uint8_t> const qRed = reduce(qs);
 
         // ---- scoring + statistics (prepareScoring, src/search_algo.hpp:166-234): bisulfite = two matrices over SeqAn Dna5
         // (forward: slot 0, reverse: slot 1, :176-186), statistics from the match / mismatch scheme
@@ -507,40 +778,9 @@ int main(int argc, char ** argv)
         // the workers for the seeding of their reads (the reference: -t OpenMP threads, each with its own LocalDataHolder; a GPU
         // wants few, large extension batches, the seeding wants every core)
         size_t const   nWorkers = std::max<size_t>(1, std::min<size_t>(devices.size(), qs.ids.size()));
-        unsigned const nThreads = opt.threads > 0 ? (unsigned)opt.threads : grantedThreads();
         unsigned const seedThreads = std::max(1u, nThreads / (unsigned)nWorkers);
 
-        // ---- seeding (search(), src/search_algo.hpp:611-762) over a sorted table of reduced words instead of the FM-index
-        uint8_t const * redTab = nullptr;
-        int             alph   = 27;
-        if (prot && opt.reduction == "li10")
-            redTab = lambda_amd::kLi10, alph = 10;
-        else if (prot && opt.reduction == "murphy10")
-            redTab = lambda_amd::kMurphy10, alph = 10;
-        else if (bs)
-            alph = 6;
-        else if (!prot)
-            redTab = lambda_amd::kDna4, alph = 4;
-        // bisulfite: the reduction alternates with the frame (even: forward, odd: reverse; src/view_reduce_to_bisulfite.hpp:132-136)
-        auto reduce = [&](SeqSet const & set)
-        {
-            std::vector<uint8_t> red(set.res.size());
-            if (bs)
-            {
-                for (size_t f = 0; f < set.off.size(); ++f)
-                    for (uint64_t i = 0; i < set.len[f]; ++i)
-                        red[set.off[f] + i] = ((f & 1) ? lambda_amd::kBsRev : lambda_amd::kBsFwd)[std::min<uint8_t>(set.res[set.off[f] + i], 4)];
-                return red;
-            }
-            for (size_t i = 0; i < set.res.size(); ++i)
-                red[i] = redTab ? redTab[set.res[i] < (prot ? 27 : 5) ? set.res[i] : 0] : set.res[i];
-            return red;
-        };
-        auto const                 tIndex = std::chrono::steady_clock::now();
-        std::vector<uint8_t> const qRed = reduce(qs), dbRed = reduce(db);
-        lambda_amd::ReducedIndex   ix;
-        ix.build(dbRed, db.off, db.len, alph, nThreads);
-        double const msIndex = msSince(tIndex);
+        // ---- seeding (search(), src/search_algo.hpp:611-762) over the sorted table of reduced words
         lambda_amd::SeedingInput sin{};
         sin.qRes = qs.res.data(), sin.qRed = qRed.data(), sin.qOff = qs.off.data(), sin.qLen = qs.len.data(), sin.nQSeq = qs.off.size();
         sin.qNumFrames       = qFrames;
@@ -735,7 +975,7 @@ int main(int argc, char ** argv)
             oo.version             = "3.0.0-lx"; // (the reference release this front end follows, src/CMakeLists.txt:14-19)
             oo.command_line        = opt.commandLine.c_str();
             oo.db_name             = opt.db.c_str(); // the index path there (src/search_algo.hpp:320)
-            oo.genetic_code        = opt.geneticCode;
+            oo.genetic_code        = geneticCodeQry;
             int const rcw = lx_write_records_ex(opt.output.c_str(), fmt, 1, program, bms.data(), nOut, ops.data(), &names,
                                                 reinterpret_cast<uint8_t const *>(qs.ascii.data()), qs.ascii_off.data(), &oo);
             if (rcw != LX_OK)

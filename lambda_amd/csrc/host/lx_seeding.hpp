@@ -190,7 +190,7 @@ public:
         // where the words with every prefix of preLen_ letters begin: the first letters of a seed cost one table read each instead
         // of two binary searches over the whole table (the probes that miss every cache)
         preLen_ = 1;
-        while (preLen_ + 1 < keyLen_ && pow_[preLen_ + 1] <= (4u << 20))
+        while (preLen_ + 1 < keyLen_ && pow_[preLen_ + 1] <= std::min<uint64_t>(4u << 20, std::max<uint64_t>(1024, total)))
             ++preLen_;
         uint64_t const preDiv = pow_[keyLen_ - preLen_];
         pre_.assign((size_t)pow_[preLen_] + 1, total);
@@ -309,6 +309,59 @@ public:
         for (uint64_t i = cu.lo; i < cu.hi; ++i)
             f(entries_[i].seq, entries_[i].pos);
     }
+
+    // The table as it stands, for an index file (lambda3 mkindex*): geometry, entries, prefix table.  load() takes the
+    // reduced residues and the sequence table the entries refer to (they are not part of the table) and checks the sizes.
+    template <typename Write>
+    void save(Write && write) const // write(pointer, bytes)
+    {
+        int32_t const  geo[4] = {alph_, keyLen_, preLen_, 0};
+        uint64_t const cnt[2] = {entries_.size(), pre_.size()};
+        write(geo, sizeof(geo));
+        write(cnt, sizeof(cnt));
+        write(entries_.data(), entries_.size() * sizeof(Entry));
+        write(pre_.data(), pre_.size() * sizeof(uint64_t));
+    }
+    template <typename Read>
+    bool load(Read && read, std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len) // read(pointer, bytes) -> bool
+    {
+        int32_t  geo[4];
+        uint64_t cnt[2];
+        if (!read(geo, sizeof(geo)) || !read(cnt, sizeof(cnt)))
+            return false;
+        uint64_t total = 0;
+        for (uint64_t l : len)
+            total += l;
+        alph_ = geo[0], keyLen_ = geo[1], preLen_ = geo[2];
+        base_ = (uint64_t)alph_ + 1;
+        if (alph_ < 2 || alph_ > 31 || keyLen_ < 2 || keyLen_ > 63 || preLen_ < 1 || preLen_ >= keyLen_ || cnt[0] != total)
+            return false;
+        pow_.assign(keyLen_ + 1, 1);
+        for (int i = 1; i <= keyLen_; ++i)
+        {
+            if (pow_[i - 1] > (~0ull / 2) / base_)
+                return false;
+            pow_[i] = pow_[i - 1] * base_;
+        }
+        if (cnt[1] != pow_[preLen_] + 1)
+            return false;
+        entries_.resize(cnt[0]);
+        pre_.resize(cnt[1]);
+        if (!read(entries_.data(), entries_.size() * sizeof(Entry)) || !read(pre_.data(), pre_.size() * sizeof(uint64_t)))
+            return false;
+        // (cheap sanity of what the searches rely on: the prefix table ascends to the entry count, the entries name sequences that exist)
+        if (pre_.back() != total || pre_.front() != 0)
+            return false;
+        for (size_t w = 1; w < pre_.size(); ++w)
+            if (pre_[w] < pre_[w - 1])
+                return false;
+        for (Entry const & e : entries_)
+            if (e.seq >= len.size() || e.pos >= len[e.seq])
+                return false;
+        red_ = red.data(), off_ = off.data(), len_ = len.data();
+        return true;
+    }
+    int alphabet() const { return alph_; }
 
 private:
     struct Entry

@@ -69,7 +69,109 @@ def test_cli_fails_loudly_without_gpu(tmp_path):
                         str(tmp_path / "o.m8")], capture_output=True, text=True)
     assert r.returncode != 0 and "ERROR" in r.stderr and not (tmp_path / "o.m8").exists()
     r = subprocess.run([str(_cli()), "mkindexp"], capture_output=True, text=True)
+    assert r.returncode != 0 and "-d is required" in r.stderr
+    r = subprocess.run([str(_cli()), "mkindexx"], capture_output=True, text=True)
     assert r.returncode != 0 and "unknown subcommand" in r.stderr
+
+
+def _small_dbs(tmp):
+    """A protein database, a nucleotide one (three contigs) and reads cut from it, for the index tests."""
+    rng = np.random.default_rng(41)
+    prots = ["".join(STD[i] for i in rng.integers(0, 20, int(rng.integers(80, 400)))) for _ in range(60)]
+    _fasta(tmp / "db.fasta", [f"sp{j} protein number {j}" for j in range(len(prots))], prots)
+    pq = []
+    for k in range(40):
+        j = int(rng.integers(0, len(prots)))
+        a = int(rng.integers(0, len(prots[j]) - 70))
+        r = list(prots[j][a:a + 70])
+        for p_ in rng.integers(0, 70, 6):
+            r[p_] = STD[int(rng.integers(0, 20))]
+        pq.append("".join(r))
+    _fasta(tmp / "pq.fasta", [f"q{k}" for k in range(len(pq))], pq)
+    genome = ["".join("ACGT"[i] for i in rng.integers(0, 4, 6000)) for _ in range(3)]
+    _fasta(tmp / "g.fasta", [f"chr{i} contig" for i in range(3)], genome)
+    comp = str.maketrans("ACGT", "TGCA")
+    reads = []
+    for k in range(40):
+        c, a = int(rng.integers(0, 3)), int(rng.integers(0, 5800))
+        r = list(genome[c][a:a + 150])
+        for p_ in rng.integers(0, 150, 3):
+            r[p_] = "ACGT"[int(rng.integers(0, 4))]
+        r = "".join(r)
+        reads.append(r.translate(comp)[::-1] if k % 2 else r)
+    _fasta(tmp / "r.fasta", [f"read{k}" for k in range(len(reads))], reads)
+    bs = ["".join("T" if (ch == "C" and rng.random() < 0.99) else ch for ch in r) for r in reads]
+    _fasta(tmp / "bs.fasta", [f"bsread{k}" for k in range(len(bs))], bs)
+
+
+def test_mkindex_writes_an_index_without_a_gpu(tmp_path):
+    """mkindexp | mkindexn | mkindexbs (/root/reference/src/lambda.cpp:86-88, src/mkindex_options.hpp:96-262): -d the database, -i the
+    index (default DATABASE.lba, the name must end in .lba / .lta, an existing file is never overwritten); needs no device.  A
+    search refuses an index of another domain with the reference's messages (src/search.cpp:189-207) before it looks for one."""
+    _small_dbs(tmp_path)
+    cli = str(_cli())
+    run = lambda *a: subprocess.run([cli, *a], capture_output=True, text=True)
+    r = run("mkindexp", "-d", str(tmp_path / "db.fasta"))
+    assert r.returncode == 0 and (tmp_path / "db.fasta.lba").stat().st_size > 10_000, r.stderr
+    assert "original alphabet aminoacid, translated aminoacid, reduced li10" in r.stderr and "60 sequences" in r.stderr
+    assert (tmp_path / "db.fasta.lba").read_bytes()[:8] == b"LXINDEX1"
+    r = run("mkindexp", "-d", str(tmp_path / "db.fasta"))
+    assert r.returncode != 0 and "An output file already exists" in r.stderr
+    r = run("mkindexp", "-d", str(tmp_path / "db.fasta"), "-i", str(tmp_path / "x.idx"))
+    assert r.returncode != 0 and ".lba or .lta" in r.stderr
+    r = run("mkindexp", "-d", str(tmp_path / "db.fasta"), "-i", str(tmp_path / "t.lba"), "-m", "acc2tax")
+    assert r.returncode != 0 and "taxonomy" in r.stderr
+    r = run("mkindexn", "-d", str(tmp_path / "g.fasta"), "-i", str(tmp_path / "g.lba"), "-t", "3")
+    assert r.returncode == 0 and "reduced dna4" in r.stderr and "in 1 frame(s)" in r.stderr, r.stderr
+    r = run("mkindexbs", "-d", str(tmp_path / "g.fasta"), "-i", str(tmp_path / "gbs.lta"))
+    assert r.returncode == 0 and "reduced dna3bs" in r.stderr and "in 2 frame(s)" in r.stderr, r.stderr
+    r = run("mkindexp", "-d", str(tmp_path / "g.fasta"), "-i", str(tmp_path / "gp.lba"), "-g", "4", "-r", "murphy10", "--truncate-ids")
+    assert r.returncode == 0 and "original alphabet dna5, translated aminoacid, reduced murphy10, genetic code 4" in r.stderr and "in 6 frame(s)" in r.stderr
+    # the table does not depend on the number of threads
+    r = run("mkindexn", "-d", str(tmp_path / "g.fasta"), "-i", str(tmp_path / "g1.lba"), "-t", "1")
+    assert r.returncode == 0 and (tmp_path / "g1.lba").read_bytes() == (tmp_path / "g.lba").read_bytes()
+    for cmd, idx, msg in (("searchn", "db.fasta.lba", "Attempting to use protein index for nucleotide search."),
+                          ("searchp", "g.lba", "Attempting to use nucleotide or bisulfite index for protein search."),
+                          ("searchbs", "g.lba", "Attempting to use nucleotid index for bisulfite search."),
+                          ("searchn", "gbs.lta", "Attempting to use bisulfite index for nucleotide search."),
+                          ("searchbs", "db.fasta.lba", "Attempting to use protein index for bisulfite search.")):
+        r = run(cmd, "-q", str(tmp_path / "r.fasta"), "-i", str(tmp_path / idx), "-o", str(tmp_path / "o.m8"))
+        assert r.returncode != 0 and msg in r.stderr, (cmd, idx, r.stderr)
+    (tmp_path / "junk.lba").write_bytes(bytes(range(256)) * 4)
+    r = run("searchp", "-q", str(tmp_path / "pq.fasta"), "-i", str(tmp_path / "junk.lba"), "-o", str(tmp_path / "o.m8"))
+    assert r.returncode != 0 and "neither a FASTA file nor an index of this front end" in r.stderr
+    blob = (tmp_path / "g.lba").read_bytes()
+    (tmp_path / "cut.lba").write_bytes(blob[: len(blob) // 2])
+    r = run("searchn", "-q", str(tmp_path / "r.fasta"), "-i", str(tmp_path / "cut.lba"), "-o", str(tmp_path / "o.m8"))
+    assert r.returncode != 0 and "index file" in r.stderr and "truncated" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_search_on_an_index_equals_search_on_the_fasta_file(tmp_path):
+    """`search* -i INDEX` (the reference's only way, src/search_options.hpp:200) writes what `-d DB.fasta` writes, byte for byte:
+    BLASTP, BLASTN, bisulfite, TBLASTN with another genetic code and reduction (both taken from the index)."""
+    _small_dbs(tmp_path)
+    cli = str(_cli())
+    cases = (("searchp", "mkindexp", "pq.fasta", "db.fasta", [], []),
+             ("searchn", "mkindexn", "r.fasta", "g.fasta", [], []),
+             ("searchbs", "mkindexbs", "bs.fasta", "g.fasta", [], []),
+             ("searchp", "mkindexp", "pq.fasta", "g.fasta", ["-g", "4", "-r", "murphy10"], ["--db-alphabet", "dna5"]))
+    for n, (search, mk, qry, db, mkopt, fopt) in enumerate(cases):
+        idx = tmp_path / f"case{n}.lba"
+        r = subprocess.run([cli, mk, "-d", str(tmp_path / db), "-i", str(idx)] + mkopt, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for ext in ("m8", "sam"):
+            common = ["-q", str(tmp_path / qry), "--version-to-outputfile", "0", "-e", "10"]
+            a = subprocess.run([cli, search, "-i", str(idx), "-o", str(tmp_path / f"i{n}.{ext}")] + common, capture_output=True, text=True)
+            b = subprocess.run([cli, search, "-d", str(tmp_path / db), "-o", str(tmp_path / f"d{n}.{ext}")] + common + mkopt + fopt, capture_output=True, text=True)
+            assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+            ia, db_ = (tmp_path / f"i{n}.{ext}").read_text(), (tmp_path / f"d{n}.{ext}").read_text()
+            if ext == "sam":  # (the header names the database file)
+                ia, db_ = [l for l in ia.splitlines() if not l.startswith("@")], [l for l in db_.splitlines() if not l.startswith("@")]
+            assert ia == db_, (search, db, ext)
+            if n < 3:
+                assert len(ia) >= 20, (search, len(ia))
+        assert ("tblastn" in a.stderr) == (n == 3), a.stderr
 
 
 @pytest.mark.gpu
