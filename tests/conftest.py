@@ -10,6 +10,14 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    # The product library from exactly this tree, BEFORE any test module is imported: a module that loads it while it is stale
+    # keeps the stale one for the whole session (capi.load() caches).  A failure here is reported by the lx_lib fixture.
+    try:
+        from lambda_amd import build
+
+        build.build_product()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
