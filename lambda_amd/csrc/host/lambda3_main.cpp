@@ -42,6 +42,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -51,6 +52,7 @@
 #include "blast_stats.hpp"
 #include "lambda_ext.hpp"
 #include "lx_seeding.hpp"
+#include "lx_seeding_gpu.hpp"
 #include "scoring_tables.hpp"
 
 namespace
@@ -214,6 +216,8 @@ struct Options
     bool        samWithRefHeader = false, versionToOutput = true;
     std::string commandLine;
     std::vector<int> devices;         // --devices (default: every visible device)
+    std::string seeding     = "gpu";  // --seeding gpu | host: where search() runs (host/lx_seeding_gpu.hpp -- one lane per read, reads the
+                                      // device declines go to the host --, host/lx_seeding.hpp on the -t threads)
     int         threads     = 0;    // -t host threads for the word table and the seeding (default: what the machine grants)
     // mkindex* (src/mkindex_options.hpp:96-262): -d the database (FASTA), -i the index file to write
     std::string index;                // -i of mkindex* (default: DATABASE.lba, :132, :249-250)
@@ -418,6 +422,12 @@ Options parse(int argc, char ** argv)
         }
         else if (a == "-t" || a == "--threads")
             o.threads = std::stoi(val());
+        else if (a == "--seeding")
+        {
+            o.seeding = val();
+            if (o.seeding != "host" && o.seeding != "gpu")
+                throw std::runtime_error("--seeding takes host or gpu");
+        }
         else if (a == "--db-alphabet")
         {
             o.dbAlphabet = val();
@@ -822,6 +832,7 @@ int main(int argc, char ** argv)
             lambda_amd::SeedingStats    sst{};
             size_t                      nPromising = 0;
             double                      msSeed = 0, msExtend = 0;
+            size_t                      nDeclined = 0, nPassesOnHost = 0; // reads the GPU seeding stage left to the host; passes whose match buffer was full
             std::string                 error;
         };
         std::vector<Part> parts(nWorkers);
@@ -842,13 +853,38 @@ int main(int argc, char ** argv)
                 // the database stays on the GPU for the whole run (the reference keeps it in the index file it maps at start-up)
                 eng.check(lx_set_subjects(eng.raw(), db.res.data(), db.res.size()));
                 // one pass of the batch loop of realMain (src/search.cpp:426-459): seed, extend (GPU), collect
+                std::unique_ptr<lambda_amd::GpuSeeder> gpuSeeder;
+                if (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix))
+                    gpuSeeder.reset(new lambda_amd::GpuSeeder(devices[w % devices.size()], ix, sin, dbRed, db.off.size(), db.res.size(), qs.res.size()));
                 auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
                 {
                     std::vector<lx_match> matches;
                     if (std::getenv("LAMBDA3_TRACE"))
                         std::fprintf(stderr, "[worker %zu] seeding %zu frame sequences (seed %d/%d, delta %d)\n", w, which.size(), so.seedLength, so.seedOffset, so.maxSeedDist);
                     auto const tSeed = std::chrono::steady_clock::now();
-                    lambda_amd::seedQueriesParallel(ix, sin, so, which, matches, pt.sst, seedThreads);
+                    bool onHost = !gpuSeeder;
+                    if (gpuSeeder)
+                    {
+                        // the device takes the reads; those it declines (words far beyond the table's keys with many occurrences) are
+                        // seeded here, a full match buffer sends the whole pass here
+                        std::vector<uint64_t> declined;
+                        if (!gpuSeeder->seed(so, which, matches, pt.sst, declined))
+                        {
+                            onHost = true;
+                            ++pt.nPassesOnHost;
+                        }
+                        else if (!declined.empty())
+                        {
+                            std::vector<uint64_t> rest;
+                            for (uint64_t rd : declined)
+                                for (int f = 0; f < qFrames && rd + (uint64_t)f < qs.off.size(); ++f)
+                                    rest.push_back(rd + (uint64_t)f);
+                            lambda_amd::seedQueriesParallel(ix, sin, so, rest, matches, pt.sst, seedThreads);
+                            pt.nDeclined += declined.size();
+                        }
+                    }
+                    if (onHost)
+                        lambda_amd::seedQueriesParallel(ix, sin, so, which, matches, pt.sst, seedThreads);
                     pt.msSeed += msSince(tSeed);
                     pt.nPromising += matches.size();
                     if (std::getenv("LAMBDA3_TRACE"))
@@ -924,6 +960,7 @@ int main(int argc, char ** argv)
         lambda_amd::SeedingStats    sst{};
         size_t                      nPromising = 0;
         double                      msSeedMax = 0, msExtendMax = 0;
+        size_t                      nDeclined = 0, nPassesOnHost = 0;
         for (Part & pt : parts)
         {
             if (!pt.error.empty())
@@ -939,6 +976,7 @@ int main(int argc, char ** argv)
             ist.failed_identity += pt.ist.failed_identity, ist.num_ext_score += pt.ist.num_ext_score, ist.num_ext_ali += pt.ist.num_ext_ali;
             sst.hitsAfterSeeding += pt.sst.hitsAfterSeeding, sst.hitsFailedPreExtendTest += pt.sst.hitsFailedPreExtendTest;
             nPromising += pt.nPromising;
+            nDeclined += pt.nDeclined, nPassesOnHost += pt.nPassesOnHost;
             msSeedMax   = std::max(msSeedMax, pt.msSeed);
             msExtendMax = std::max(msExtendMax, pt.msExtend);
         }
@@ -992,9 +1030,10 @@ int main(int argc, char ** argv)
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
         // where the wall clock went (the reference prints its own at verbosity 2, src/search.cpp): per worker the slowest counts
         std::fprintf(stderr,
-                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding %.0f + extension on the GPU incl. widen / merge / "
-                     "statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
-                     msRead, msIndex, msSearch, msSeedMax, msExtendMax, msSince(tOut), msSince(tStart));
+                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu pass(es) left to "
+                     "the host] + extension on the GPU incl. widen / merge / statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
+                     msRead, msIndex, msSearch, (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix)) ? "GPU" : "host", msSeedMax, nDeclined,
+                     nPassesOnHost, msExtendMax, msSince(tOut), msSince(tStart));
         return 0;
     }
     catch (std::exception const & e)

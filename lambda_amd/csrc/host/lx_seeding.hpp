@@ -363,12 +363,20 @@ public:
     }
     int alphabet() const { return alph_; }
 
-private:
     struct Entry
     {
         uint64_t key;
         uint32_t seq, pos;
     };
+    // the table's parts as they stand (what the GPU seeding stage uploads, host/lx_seeding_gpu.hpp)
+    Entry const *    entriesData() const { return entries_.data(); }
+    uint64_t         entriesCount() const { return entries_.size(); }
+    uint64_t const * prefixData() const { return pre_.data(); }
+    uint64_t         prefixCount() const { return pre_.size(); }
+    int              prefixLen() const { return preLen_; }
+    uint64_t         power(int i) const { return pow_[(size_t)i]; }
+
+private:
     std::vector<Entry>    entries_;
     std::vector<uint64_t> pow_, pre_; // pre_[w] = first entry whose first preLen_ letters are >= the word w
     int                   preLen_ = 0;

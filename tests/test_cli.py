@@ -175,6 +175,66 @@ def test_search_on_an_index_equals_search_on_the_fasta_file(tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_seeding_equals_host_seeding(tmp_path):
+    """search() of the reference (/root/reference/src/search_algo.hpp:611-762) on the GPU -- one lane per read
+    (host/lx_seeding_gpu.hpp) -- against the host restatement (host/lx_seeding.hpp, itself checked against brute force): the same
+    seed and match counts and byte-identical output for every program and seeding mode; a database of repeats, where the device
+    declines reads (more than 32 occurrences of a word longer than the table's keys) and the host seeds them; a match buffer that is
+    too small (the whole pass goes to the host)."""
+    import os
+    import re
+
+    _small_dbs(tmp_path)
+    rng = np.random.default_rng(77)
+    # BLASTX reads: coding sequence of pieces of the protein database
+    prots = ["".join(rec.splitlines()[1:]) for rec in (tmp_path / "db.fasta").read_text().split(">")[1:]]
+    nts = []
+    for k in range(30):
+        p_ = prots[int(rng.integers(0, len(prots)))]
+        a = int(rng.integers(0, len(p_) - 60))
+        nts.append("".join(CODONS[c][int(rng.integers(0, len(CODONS[c])))] for c in p_[a:a + 60]))
+    _fasta(tmp_path / "x.fasta", [f"xr{k}" for k in range(len(nts))], nts)
+    # repeats: one 60-residue motif in 45 proteins (beyond the 32 occurrences a device cursor holds past the key length) and reads of it
+    motif = "".join(STD[i] for i in rng.integers(0, 20, 60))
+    rep = ["".join(STD[i] for i in rng.integers(0, 20, 40)) + motif + "".join(STD[i] for i in rng.integers(0, 20, int(rng.integers(5, 60)))) for _ in range(45)]
+    rep += ["".join(STD[i] for i in rng.integers(0, 20, 200)) for _ in range(20)]
+    _fasta(tmp_path / "rep.fasta", [f"rp{j}" for j in range(len(rep))], rep)
+    rq = [motif[int(a):int(a) + 45] for a in rng.integers(0, 15, 12)] + [rep[50][20:90], rep[55][100:170]]
+    _fasta(tmp_path / "rq.fasta", [f"rq{k}" for k in range(len(rq))], rq)
+    cli = str(_cli())
+    cases = [("searchp", "pq.fasta", "db.fasta", [], {}), ("searchp", "pq.fasta", "db.fasta", ["-p", "sensitive"], {}),
+             ("searchp", "pq.fasta", "db.fasta", ["--seed-half-exact", "0", "--seed-delta", "1", "--search0", "0"], {}),
+             ("searchp", "pq.fasta", "db.fasta", ["--adaptive-seeding", "0", "-r", "murphy10"], {}),
+             ("searchn", "r.fasta", "g.fasta", [], {}), ("searchn", "r.fasta", "g.fasta", ["-p", "fast"], {}),
+             ("searchbs", "bs.fasta", "g.fasta", [], {}),
+             ("searchp", "x.fasta", "db.fasta", [], {}),                       # BLASTX
+             ("searchp", "pq.fasta", "g.fasta", ["--db-alphabet", "dna5"], {}),  # TBLASTN
+             ("searchp", "rq.fasta", "rep.fasta", ["-n", "100"], {}),          # repeats: the device declines reads
+             ("searchp", "pq.fasta", "db.fasta", [], {"LAMBDA3_SEED_CAP": "7"})]  # match buffer too small: the pass goes to the host
+    for n, (cmd, qry, db, extra, env) in enumerate(cases):
+        outs, counts, err = {}, {}, {}
+        for where in ("gpu", "host"):
+            out = tmp_path / f"s{n}.{where}.m8"
+            r = subprocess.run([cli, cmd, "-q", str(tmp_path / qry), "-d", str(tmp_path / db), "-o", str(out), "-e", "10", "--seeding", where] + extra,
+                               capture_output=True, text=True, env={**os.environ, **env})
+            assert r.returncode == 0, r.stderr
+            outs[where], err[where] = out.read_bytes(), r.stderr
+            counts[where] = re.search(r"seeds (\d+) -> promising (\d+) -> windows (\d+)", r.stderr).groups()
+            assert f"seeding on the {'GPU' if where == 'gpu' else 'host'}" in r.stderr
+        assert counts["gpu"] == counts["host"], (cmd, extra, counts)
+        assert outs["gpu"] == outs["host"], (cmd, extra)
+        left = re.search(r"\[(\d+) read\(s\) and (\d+) pass\(es\) left to the host\]", err["gpu"]).groups()
+        if db == "rep.fasta":
+            assert int(left[0]) >= 10 and len(outs["gpu"].splitlines()) >= 100, (left, err["gpu"])
+        elif env:
+            assert int(left[1]) >= 1, err["gpu"]
+        else:
+            assert left == ("0", "0"), err["gpu"]
+        if n in (0, 4, 6, 7):
+            assert int(counts["gpu"][1]) >= 20, (cmd, counts)
+
+
+@pytest.mark.gpu
 def test_searchp_config1_end_to_end(tmp_path, oracle):
     qs, db, truth = _make_config1(tmp_path)
     out = tmp_path / "out.m8"

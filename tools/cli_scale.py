@@ -1,7 +1,7 @@
 """End-to-end run of the lambda3 front end at a size where the stages can be told apart: SURVEY.md section 8(d) config 1's
 recipe (log-normal protein lengths, 30 % of the queries mutated copies of database regions) scaled up, default 100 000 queries
 of 150 aa against 100 000 proteins.  Prints the front end's own summary and its stage times (stderr of the CLI).
-    python tools/cli_scale.py [n_queries] [n_db] [threads]"""
+    python tools/cli_scale.py [n_queries] [n_db] [threads (0 = default)] [front-end options ...]"""
 import math, subprocess, sys, tempfile, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -11,6 +11,7 @@ from lambda_amd import build
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 ndb = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 threads = sys.argv[3] if len(sys.argv) > 3 else "0"
+extra = sys.argv[4:]  # further options for the front end, e.g. --seeding gpu
 lq = 150
 STD = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
 rng = np.random.default_rng(0x1A3BDA01)
@@ -45,9 +46,13 @@ with open(tmp / "q.fasta", "wb") as f:
         f.write(b">q%d\n" % k + out.tobytes() + b"\n")
 cli = build.build_cli()
 t0 = time.perf_counter()
-r = subprocess.run([str(cli), "searchp", "-q", str(tmp / "q.fasta"), "-d", str(tmp / "db.fasta"), "-o", str(tmp / "out.m8")] + (["-t", threads] if threads != "0" else []),
+import os, shlex
+wrap = shlex.split(os.environ.get("LX_CLI_WRAP", ""))  # e.g. "rocprofv3 --kernel-trace --stats -d DIR -o cli --" (per-kernel times of the run)
+r = subprocess.run(wrap + [str(cli), "searchp", "-q", str(tmp / "q.fasta"), "-d", str(tmp / "db.fasta"), "-o", str(tmp / "out.m8")] + (["-t", threads] if threads != "0" else []) + extra,
                    capture_output=True, text=True)
 dt = time.perf_counter() - t0
 print(r.stderr.strip())
 rows = sum(1 for _ in open(tmp / "out.m8")) if r.returncode == 0 else -1
+import hashlib
+print("output sha256", hashlib.sha256(open(tmp / "out.m8", "rb").read()).hexdigest()[:16] if r.returncode == 0 else "-")
 print(f"rc {r.returncode}; {nq} queries ({planted} planted) x {ndb} subjects ({int(off[-1])} residues): {dt:.2f} s wall, {rows} records")
