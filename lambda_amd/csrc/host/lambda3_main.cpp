@@ -35,6 +35,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <array>
 #include <cctype>
 #include <chrono>
 #include <cstdio>
@@ -69,8 +70,17 @@ struct SeqSet
 
 uint8_t aaRank(char c) // SeqAn2 AminoAcid rank (src/seqan2_to_biocpp.hpp:352-366)
 {
-    char const * p = std::strchr(lambda_amd::kSeqanOrder, std::toupper((unsigned char)c));
-    return p && *p ? (uint8_t)(p - lambda_amd::kSeqanOrder) : 25; // unknown -> X
+    static auto const table = []()
+    {
+        std::array<uint8_t, 256> t;
+        for (int ch = 0; ch < 256; ++ch)
+        {
+            char const * p = std::strchr(lambda_amd::kSeqanOrder, std::toupper(ch));
+            t[(size_t)ch]  = (ch != 0 && p && *p) ? (uint8_t)(p - lambda_amd::kSeqanOrder) : 25; // unknown -> X
+        }
+        return t;
+    }();
+    return table[(unsigned char)c];
 }
 
 uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets pass it through, :392-393)
@@ -160,8 +170,16 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
         }
         out.off.push_back(out.res.size());
         out.len.push_back(cur.size());
-        for (char c : cur)
-            out.res.push_back(protein ? aaRank(c) : dnaRank(c));
+        {
+            size_t const at = out.res.size();
+            out.res.resize(at + cur.size());
+            if (protein)
+                for (size_t k = 0; k < cur.size(); ++k)
+                    out.res[at + k] = aaRank(cur[k]);
+            else
+                for (size_t k = 0; k < cur.size(); ++k)
+                    out.res[at + k] = dnaRank(cur[k]);
+        }
         if (addRevComp) // qryNumFrames = 2 for BLASTN (src/search_datastructures.hpp:380-385)
         {
             out.off.push_back(out.res.size());
@@ -183,6 +201,8 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
             flush();
             out.ids.push_back(line.substr(1));
         }
+        else if (line.find_first_of(" \t\v\f") == std::string::npos)
+            cur += line;
         else
             for (char c : line)
                 if (!std::isspace((unsigned char)c))
