@@ -885,16 +885,13 @@ int main(int argc, char ** argv)
                     bool onHost = !gpuSeeder;
                     if (gpuSeeder)
                     {
-                        // the device takes the reads; those it declines (words far beyond the table's keys with many occurrences) are
-                        // seeded here, a full match buffer sends the whole pass here
+                        // the device takes the reads; those it declines (words far beyond the table's keys with many occurrences) and
+                        // those of a launch whose match buffer filled up are seeded here
                         std::vector<uint64_t> declined;
-                        if (!gpuSeeder->seed(so, which, matches, pt.sst, declined))
+                        pt.nPassesOnHost += gpuSeeder->seed(so, which, matches, pt.sst, declined);
+                        if (!declined.empty())
                         {
-                            onHost = true;
-                            ++pt.nPassesOnHost;
-                        }
-                        else if (!declined.empty())
-                        {
+                            std::sort(declined.begin(), declined.end());
                             std::vector<uint64_t> rest;
                             for (uint64_t rd : declined)
                                 for (int f = 0; f < qFrames && rd + (uint64_t)f < qs.off.size(); ++f)
@@ -1050,7 +1047,7 @@ int main(int argc, char ** argv)
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
         // where the wall clock went (the reference prints its own at verbosity 2, src/search.cpp): per worker the slowest counts
         std::fprintf(stderr,
-                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu pass(es) left to "
+                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu launch(es) left to "
                      "the host] + extension on the GPU incl. widen / merge / statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
                      msRead, msIndex, msSearch, (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix)) ? "GPU" : "host", msSeedMax, nDeclined,
                      nPassesOnHost, msExtendMax, msSince(tOut), msSince(tStart));

@@ -14,12 +14,13 @@
 //     list); a range of more than 32 entries at that point, or a seed longer than kMaxSecond letters behind its exact part,
 //     sends the READ to the host (flag per read; the front end seeds those reads with seedQueries) -- results are identical by
 //     construction, the device only declines.
-//   * Matches leave through one atomic counter (a full buffer is reported; the front end then seeds everything on the host).
+//   * Matches leave through one atomic counter (a full buffer is reported; the reads of that launch then go to the host).
 //     Their order is the lanes', not the host's: iterateMatches sorts its span first (src/search_algo.hpp:1141), so the order of
 //     the list carries no meaning.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
@@ -419,67 +420,76 @@ public:
     }
 
     // `which`: frame sequences, all frames of a read adjacent and in order (as seedQueries takes them).  Appends the matches of
-    // the reads the device took and lists in `declinedReads` the first frame sequence of every read it left to the host.
-    // Returns false when the match buffer was too small (nothing appended: the caller seeds on the host).
-    bool seed(SeedParams const & so, std::vector<uint64_t> const & which, std::vector<lx_match> & matches, SeedingStats & stats,
-              std::vector<uint64_t> & declinedReads)
+    // the reads the device took and lists in `declinedReads` the first frame sequence of every read it left to the host: reads a
+    // lane declined, and all reads of a launch whose match buffer filled up (returned: the number of such launches).  The reads go
+    // to the device in launches of at most kLaunchReads (the match buffer holds 64 matches per read of a launch).
+    static constexpr uint64_t kLaunchReads = 4u << 20;
+    size_t seed(SeedParams const & so, std::vector<uint64_t> const & which, std::vector<lx_match> & matches, SeedingStats & stats,
+                std::vector<uint64_t> & declinedReads)
     {
         LXS_HIP(hipSetDevice(device_));
         std::vector<uint64_t> reads;
         for (uint64_t i : which)
             if (i % (uint64_t)d_.qNumFrames == 0)
                 reads.push_back(i);
-        if (reads.empty())
-            return true;
-        reads_.upload(reads.data(), reads.size());
-        declined_.reserve(reads.size());
-        LXS_HIP(hipMemset(declined_.p, 0, reads.size()));
-        uint64_t cap = std::max<uint64_t>(1u << 20, 64ull * reads.size());
+        uint64_t launchReads = kLaunchReads;
+        if (char const * forced = std::getenv("LAMBDA3_SEED_LAUNCH")) // (development aid: several launches on a small input)
+            launchReads = std::max<uint64_t>(1, std::strtoull(forced, nullptr, 10));
+        size_t full = 0;
+        for (uint64_t a = 0; a < reads.size(); a += launchReads)
+            full += seedLaunch(so, reads.data() + a, std::min<uint64_t>(launchReads, reads.size() - a), matches, stats, declinedReads) ? 0 : 1;
+        return full;
+    }
+
+private:
+    bool seedLaunch(SeedParams const & so, uint64_t const * reads, uint64_t nReads, std::vector<lx_match> & matches, SeedingStats & stats,
+                    std::vector<uint64_t> & declinedReads)
+    {
+        reads_.upload(reads, nReads);
+        declined_.reserve(nReads);
+        LXS_HIP(hipMemset(declined_.p, 0, nReads));
+        uint64_t cap = std::max<uint64_t>(1u << 20, 64ull * nReads);
         if (char const * forced = std::getenv("LAMBDA3_SEED_CAP")) // (development aid: a small buffer exercises the "buffer full" path)
             cap = std::max<uint64_t>(1, std::strtoull(forced, nullptr, 10));
         out_.reserve(cap);
         LXS_HIP(hipMemset(counters_.p, 0, 4 * sizeof(unsigned long long)));
         SeedDev p     = d_;
         p.seedLength  = so.seedLength, p.seedOffset = so.seedOffset, p.maxSeedDist = so.maxSeedDist;
-        p.reads       = reads_.p, p.nReads = reads.size();
+        p.reads       = reads_.p, p.nReads = nReads;
         p.out         = out_.p, p.counters = counters_.p, p.outCap = cap, p.declined = declined_.p;
-        hipLaunchKernelGGL(seed_reads_kernel, dim3((unsigned)((reads.size() + 63) / 64)), dim3(64), 0, 0, p);
+        hipLaunchKernelGGL(seed_reads_kernel, dim3((unsigned)((nReads + 63) / 64)), dim3(64), 0, 0, p);
         LXS_HIP(hipGetLastError());
         unsigned long long cnt[4];
         LXS_HIP(hipMemcpy(cnt, counters_.p, sizeof(cnt), hipMemcpyDeviceToHost)); // (synchronises)
         if (cnt[3] != 0)
+        {
+            // the buffer filled up: nothing of this launch is kept, its reads are the host's
+            declinedReads.insert(declinedReads.end(), reads, reads + nReads);
             return false;
-        std::vector<uint8_t> decl(reads.size());
-        LXS_HIP(hipMemcpy(decl.data(), declined_.p, reads.size(), hipMemcpyDeviceToHost));
+        }
+        std::vector<uint8_t> decl(nReads);
+        LXS_HIP(hipMemcpy(decl.data(), declined_.p, nReads, hipMemcpyDeviceToHost));
         size_t const at = matches.size();
         matches.resize(at + cnt[0]);
         if (cnt[0])
             LXS_HIP(hipMemcpy(matches.data() + at, out_.p, cnt[0] * sizeof(lx_match), hipMemcpyDeviceToHost));
-        bool any = false;
-        for (size_t k = 0; k < reads.size(); ++k)
+        std::vector<uint64_t> mine;
+        for (size_t k = 0; k < nReads; ++k)
             if (decl[k])
-            {
-                declinedReads.push_back(reads[k]);
-                any = true;
-            }
-        if (any)
+                mine.push_back(reads[k]);
+        if (!mine.empty())
         {
             // a declined read's matches are the host's to make: drop what the device wrote for it (it counted nothing)
-            std::vector<uint8_t> isDeclined;
-            uint64_t             maxRead = 0;
-            for (uint64_t rd : declinedReads)
-                maxRead = std::max(maxRead, rd);
-            isDeclined.assign(maxRead / (uint64_t)d_.qNumFrames + 1, 0);
-            for (uint64_t rd : declinedReads)
-                isDeclined[rd / (uint64_t)d_.qNumFrames] = 1;
+            std::sort(mine.begin(), mine.end());
             size_t o = at;
             for (size_t k = at; k < matches.size(); ++k)
             {
-                uint64_t const rd = matches[k].qryId / (uint64_t)d_.qNumFrames;
-                if (!(rd < isDeclined.size() && isDeclined[rd]))
+                uint64_t const rd = matches[k].qryId - matches[k].qryId % (uint64_t)d_.qNumFrames;
+                if (!std::binary_search(mine.begin(), mine.end(), rd))
                     matches[o++] = matches[k];
             }
             matches.resize(o);
+            declinedReads.insert(declinedReads.end(), mine.begin(), mine.end());
         }
         stats.hitsAfterSeeding += cnt[1];
         stats.hitsFailedPreExtendTest += cnt[2];

@@ -180,7 +180,7 @@ def test_gpu_seeding_equals_host_seeding(tmp_path):
     (host/lx_seeding_gpu.hpp) -- against the host restatement (host/lx_seeding.hpp, itself checked against brute force): the same
     seed and match counts and byte-identical output for every program and seeding mode; a database of repeats, where the device
     declines reads (more than 32 occurrences of a word longer than the table's keys) and the host seeds them; a match buffer that is
-    too small (the whole pass goes to the host)."""
+    too small (the reads of that launch go to the host); several launches per pass."""
     import os
     import re
 
@@ -210,7 +210,8 @@ def test_gpu_seeding_equals_host_seeding(tmp_path):
              ("searchp", "x.fasta", "db.fasta", [], {}),                       # BLASTX
              ("searchp", "pq.fasta", "g.fasta", ["--db-alphabet", "dna5"], {}),  # TBLASTN
              ("searchp", "rq.fasta", "rep.fasta", ["-n", "100"], {}),          # repeats: the device declines reads
-             ("searchp", "pq.fasta", "db.fasta", [], {"LAMBDA3_SEED_CAP": "7"})]  # match buffer too small: the pass goes to the host
+             ("searchp", "pq.fasta", "db.fasta", [], {"LAMBDA3_SEED_CAP": "7"}),  # match buffer too small: the launch's reads go to the host
+             ("searchn", "r.fasta", "g.fasta", [], {"LAMBDA3_SEED_LAUNCH": "7"})]  # several launches per pass
     for n, (cmd, qry, db, extra, env) in enumerate(cases):
         outs, counts, err = {}, {}, {}
         for where in ("gpu", "host"):
@@ -223,11 +224,11 @@ def test_gpu_seeding_equals_host_seeding(tmp_path):
             assert f"seeding on the {'GPU' if where == 'gpu' else 'host'}" in r.stderr
         assert counts["gpu"] == counts["host"], (cmd, extra, counts)
         assert outs["gpu"] == outs["host"], (cmd, extra)
-        left = re.search(r"\[(\d+) read\(s\) and (\d+) pass\(es\) left to the host\]", err["gpu"]).groups()
+        left = re.search(r"\[(\d+) read\(s\) and (\d+) launch\(es\) left to the host\]", err["gpu"]).groups()
         if db == "rep.fasta":
             assert int(left[0]) >= 10 and len(outs["gpu"].splitlines()) >= 100, (left, err["gpu"])
-        elif env:
-            assert int(left[1]) >= 1, err["gpu"]
+        elif "LAMBDA3_SEED_CAP" in env:
+            assert int(left[1]) >= 1 and int(left[0]) >= 40, err["gpu"]
         else:
             assert left == ("0", "0"), err["gpu"]
         if n in (0, 4, 6, 7):
