@@ -597,6 +597,10 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     uint64_t         pos = 0;         // its position in the list
     EndCell          ec{};
     uint32_t const * slot = nullptr;
+    // compact slots whose wavefront's W = 128 / G slots are interleaved (ScoreParams::wave_slots, kEndWaveSlots): uint4 units between two
+    // groups of eight steps / two row checkpoints of ONE window, dwords from `slot` to its first row checkpoint
+    uint32_t         oct_mul = G, ck_mul = G * (L16::kCkDw / 4);
+    uint64_t         ck16_off = 0;
     uint8_t const *  q = nullptr, * s = nullptr;
     uint8_t *        ops_al = nullptr;
     uint32_t         cap = 0, a0 = 0, apos = 0, acc = 0, n = 0;
@@ -646,20 +650,23 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (uint64_t)pn * (c16 ? panel16_dw : panel_dw)); };
     auto rowck_of = [&](uint32_t pn)
     {
-        return reinterpret_cast<uint4 const *>(slot + (c16 ? (uint64_t)pn * panel16_dw + L16::bnd_dwords(p.steps_cap)
+        return reinterpret_cast<uint4 const *>(slot + (c16 ? (uint64_t)pn * panel16_dw + ck16_off
                                                            : (uint64_t)pn * panel_dw + Lay::bnd_dwords(p.steps_cap)));
     };
+    // Ckpt16Layout's index functions with the slots' spacing
+    auto oct16_index = [&](uint32_t o, uint32_t g_) -> uint32_t { return o * oct_mul + g_; };
+    auto ck16_index  = [&](uint32_t m_, uint32_t g_, uint32_t x_) -> uint32_t { return m_ * ck_mul + g_ * (L16::kCkDw / 4) + x_; };
     // word (H, F) of column c of strip st's row checkpoint m; word (H, E) of strip st's boundary at step k
     auto rowck_word = [&](uint32_t m, uint32_t st, uint32_t c) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(rowck_of(st / G) + L16::rowck_quad_index(m, st % G, c / 8))[c % 8]);
+            return expand(reinterpret_cast<uint16_t const *>(rowck_of(st / G) + ck16_index(m, st % G, c / 8))[c % 8]);
         return reinterpret_cast<uint32_t const *>(rowck_of(st / G) + rowck_quad_index<G, Lay::kCkDw>(m, st % G, c / 4))[c % 4];
     };
     auto bnd_word_of = [&](uint32_t st, uint32_t k) -> uint32_t
     {
         if (c16)
-            return expand(reinterpret_cast<uint16_t const *>(bnd_of(st / G) + L16::bnd_oct_index(k / 8, st % G))[k & 7]);
+            return expand(reinterpret_cast<uint16_t const *>(bnd_of(st / G) + oct16_index(k / 8, st % G))[k & 7]);
         return reinterpret_cast<uint32_t const *>(bnd_of(st / G) + bnd_quad_index<G>(k / 4, st % G))[k & 3];
     };
     // ops are produced end -> begin into the slot [0, cap): apos = misalignment of the slot start + offset of the next byte
@@ -727,6 +734,18 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         c16                = (ec.flags & kEndCompact) != 0;
         uint32_t const ovf = (uint32_t)ec.flags >> kEndOverflowShift;
         slot               = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
+        oct_mul            = G;
+        ck_mul             = G * (L16::kCkDw / 4);
+        ck16_off           = L16::bnd_dwords(p.steps_cap);
+        if (!ovf && (ec.flags & kEndWaveSlots))
+        {
+            constexpr uint32_t kW = 128 / G; // windows of a packed-half wavefront
+            uint64_t const     w  = se % kW;
+            slot     = p.trace + (se - w) * p.slot_stride + w * (G * 4);
+            oct_mul  = kW * G;
+            ck_mul   = kW * G * (L16::kCkDw / 4);
+            ck16_off = (uint64_t)kW * L16::bnd_dwords(p.steps_cap) - w * (G * 4) + w * (G * L16::kCkDw);
+        }
         q                  = p.q_res + x.q_off;
         s                  = p.s_res + x.s_off;
         uint8_t * const ops = p.out_ops + (p.ops_off ? p.ops_off[po] : po * p.ops_stride);
@@ -1116,7 +1135,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
 #pragma unroll
                 for (int xq = 0; xq < L16::kCkDw / 4; ++xq)
                 {
-                    uint4 const    v    = rowck[L16::rowck_quad_index((uint32_t)(m - 1), (uint32_t)gl, (uint32_t)xq)];
+                    uint4 const    v    = rowck[ck16_index((uint32_t)(m - 1), (uint32_t)gl, (uint32_t)xq)];
                     uint32_t const d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
@@ -1176,7 +1195,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
             {
                 // half of the 16-byte group of eight steps
                 int const   qs = qd + qshift;
-                uint2 const v  = reinterpret_cast<uint2 const *>(bndL + L16::bnd_oct_index((uint32_t)qs / 2, (uint32_t)gL))[qs & 1];
+                uint2 const v  = reinterpret_cast<uint2 const *>(bndL + oct16_index((uint32_t)qs / 2, (uint32_t)gL))[qs & 1];
                 return make_uint4(expand(v.x & 0xffffu), expand(v.x >> 16), expand(v.y & 0xffffu), expand(v.y >> 16));
             }
             return bndL[bnd_quad_index<G>((uint32_t)(qd + qshift), (uint32_t)gL)];

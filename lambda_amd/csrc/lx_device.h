@@ -81,6 +81,11 @@ struct ScoreParams
     // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
     uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)
     uint64_t           ckpt_stride;
+    // 1 (set for the packed-half sweep, which always lays its slots out like this): the W = 2 * 64 / G slots of a wavefront's windows are INTERLEAVED piece by piece -- group
+    // of eight steps o of window w at [o][w][lane], row checkpoint m at [m][w][lane][quad] behind all boundary groups -- so that
+    // what one store instruction writes (the same piece of 16 windows) is one contiguous 2 KB instead of 16 lines 7.7 KB apart;
+    // the buffer holds ceil(n / W) * W slots, no spare one.  The end cell says so (kEndWaveSlots), the backtrace reads accordingly.
+    int32_t            wave_slots;
     uint32_t           steps_cap;
     struct EndCell *   ends;        // [n]
     uint32_t           panels_cap;  // packed-int16 sweep: bound on ceil(Lq / panel); the slot holds that many parts
@@ -104,6 +109,8 @@ constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extens
 // multi-query sweep runs a query's last panel with narrower strips when that covers what is left of the query (a query of 160
 // columns sweeps 152 + 8 * 5 = 192 columns, not 304); the backtrace maps columns to strips accordingly.  Panel starts do not move.
 constexpr int     kEndNarrowShift   = 2;
+// the compact slots of the extension's WAVEFRONT are interleaved (ScoreParams::wave_slots): bit 4
+constexpr int32_t kEndWaveSlots     = 16;
 __host__ __device__ constexpr int narrow_strip_cols(int C, int code) { return code == 0 ? C : code == 1 ? (C + 1) / 2 : (C + 3) / 4; }
 // the code for a panel that has `rem` columns of the query left (rem >= 1), G lanes per group
 __host__ __device__ constexpr int narrow_code_for(int C, int G, int rem)

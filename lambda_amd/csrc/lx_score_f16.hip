@@ -267,9 +267,15 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
     h2       nZc = -(Z * C24); // -Z 2^-24, kept in step with Z
     h2       cmax = as_h2(kHalfNegInf2); // best un-skewed row maximum of the current chunk
     using Lay = Ckpt16Layout<G, C>;
-    // (slot p.n is a spare one that idle halves write to)
-    uint32_t * const slotA = CKPT ? p.ckpt + (actA ? eA : p.n) * p.ckpt_stride : nullptr;
-    uint32_t * const slotB = CKPT ? p.ckpt + (actB ? eB : p.n) * p.ckpt_stride : nullptr;
+    // (slot p.n is a spare one that idle halves write to; wave_slots: the W slots of this wavefront interleaved piece by piece --
+    // lx_device.h --, every half owns its place there)
+    constexpr uint32_t kW       = 2 * Geo::kGroups;
+    constexpr bool     wslots   = CKPT; // (always, for this kernel's checkpoints: a run-time choice costs the steady loop its registers)
+    uint32_t * const   waveBase = CKPT ? p.ckpt + (uint64_t)blockIdx.x * kW * p.ckpt_stride : nullptr;
+    uint32_t * const   slotA    = !CKPT ? nullptr : wslots ? waveBase + (2 * grp) * (G * 4) : p.ckpt + (actA ? eA : p.n) * p.ckpt_stride;
+    uint32_t * const   slotB    = !CKPT ? nullptr : wslots ? waveBase + (2 * grp + 1) * (G * 4) : p.ckpt + (actB ? eB : p.n) * p.ckpt_stride;
+    uint32_t const     octMul   = wslots ? kW * G : G;                          // uint4 units between two groups of eight steps
+    uint32_t const     ckMul    = (wslots ? kW * G : G) * (Lay::kCkDw / 4);     // ... between two row checkpoints
     // staging of the boundary codes: [step % 8][lane] -- lane-minor, free of bank conflicts
     uint32_t * const stage = lds + ((Geo::kGroups + share_g - 1) / share_g) * (nrows * Geo::kRowDw) + lane;
 
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 cw[u] = stage[u * 64];
-            uint32_t const oi = Lay::bnd_oct_index((uint32_t)k0 / 8, (uint32_t)g);
+            uint32_t const oi = ((uint32_t)k0 / 8) * octMul + (uint32_t)g; // (Lay::bnd_oct_index with the slots' spacing)
             reinterpret_cast<uint4 *>(slotA)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x05040100u), __builtin_amdgcn_perm(cw[3], cw[2], 0x05040100u),
                                                               __builtin_amdgcn_perm(cw[5], cw[4], 0x05040100u), __builtin_amdgcn_perm(cw[7], cw[6], 0x05040100u));
             reinterpret_cast<uint4 *>(slotB)[oi] = make_uint4(__builtin_amdgcn_perm(cw[1], cw[0], 0x07060302u), __builtin_amdgcn_perm(cw[3], cw[2], 0x07060302u),
@@ -397,7 +403,8 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
                                            __builtin_elementwise_fma(Hrow[c < C ? c : 0] - F0[c < C ? c : 0], C24, nGEc))
                                 : 0u;
             uint32_t const base0 = (uint32_t)(Lay::bnd_dwords(p.steps_cap) / 4);
-            uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base0, * const dB = reinterpret_cast<uint4 *>(slotB) + base0;
+            uint4 * const  dA = wslots ? reinterpret_cast<uint4 *>(waveBase) + kW * base0 + (2 * grp) * (G * (Lay::kCkDw / 4)) : reinterpret_cast<uint4 *>(slotA) + base0;
+            uint4 * const  dB = wslots ? reinterpret_cast<uint4 *>(waveBase) + kW * base0 + (2 * grp + 1) * (G * (Lay::kCkDw / 4)) : reinterpret_cast<uint4 *>(slotB) + base0;
 #pragma unroll
             for (int x = 0; x < Lay::kCkDw / 4; ++x)
             {
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
                     wa[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x05040100u);
                     wb[b]       = __builtin_amdgcn_perm(code[c + 1], code[c], 0x07060302u);
                 }
-                uint32_t const qi = Lay::rowck_quad_index((uint32_t)(k0 + 3) / 16, (uint32_t)g, (uint32_t)x);
+                uint32_t const qi = ((uint32_t)(k0 + 3) / 16) * ckMul + (uint32_t)g * (Lay::kCkDw / 4) + (uint32_t)x; // (Lay::rowck_quad_index, spaced)
                 dA[qi] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
                 dB[qi] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
             }
@@ -526,7 +533,7 @@ LX_UNROLL(LX_F16_UNROLL)
                     ec.score = gbest;
                     ec.q_end = -(gstrip + 1); // the backtrace finds the column inside this strip
                     ec.s_end = grow + 1;
-                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndCompact; // compact slot
+                    ec.flags = (gtie ? kEndAmbiguous : 0) | kEndCompact | kEndWaveSlots; // compact slot, interleaved per wavefront
                 }
                 p.ends[e]      = ec;
                 p.out_score[e] = gbest;
