@@ -660,12 +660,21 @@ int main(int argc, char ** argv)
         bool const    fromIndex = !mk && isIndexFile(opt.db);
         SeqSet           qs, db;
         IndexFileOptions ifo;
-        FILE *           indexFile = nullptr;
+        struct FileCloser
+        {
+            void operator()(FILE * f) const
+            {
+                if (f)
+                    std::fclose(f);
+            }
+        };
+        std::unique_ptr<FILE, FileCloser> indexFileOwner; // (closed on every way out of main)
+        FILE *                            indexFile = nullptr;
         if (fromIndex)
         {
             readIndexHead(opt.db, ifo, db, &indexFile);
+            indexFileOwner.reset(indexFile);
             // the index fixes the domain (src/search.cpp:189-207)
-            try
             {
                 if (prot && ifo.transAlph != kAlphAminoAcid)
                     throw std::runtime_error("Attempting to use nucleotide or bisulfite index for protein search.");
@@ -675,11 +684,6 @@ int main(int argc, char ** argv)
                     throw std::runtime_error("Attempting to use bisulfite index for nucleotide search.");
                 if (bs && ifo.redAlph != kAlphDna3Bs)
                     throw std::runtime_error("Attempting to use nucleotid index for bisulfite search.");
-            }
-            catch (...)
-            {
-                std::fclose(indexFile);
-                throw;
             }
         }
         std::string const reduction = !fromIndex ? opt.reduction : ifo.redAlph == kAlphLi10 ? "li10" : ifo.redAlph == kAlphMurphy10 ? "murphy10" : "none";
@@ -756,7 +760,7 @@ int main(int argc, char ** argv)
         {
             bool const ok = ix.load([&](void * p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, indexFile) == bytes; }, dbRed, db.off, db.len) &&
                             ix.alphabet() == alph;
-            std::fclose(indexFile);
+            indexFileOwner.reset();
             if (!ok)
                 throw std::runtime_error("index file " + opt.db + ": the word table is truncated or does not fit the sequences");
         }
