@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <new>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -73,6 +74,39 @@ inline void parallelChunks(unsigned nThreads, size_t nChunks, F && f)
         t.join();
 }
 
+// n elements of a trivial type, NOT initialised (std::vector would write 16 bytes per database residue on one thread before the
+// threads that fill the table get to touch it)
+template <typename T>
+class PlainBuffer
+{
+    T *    p_ = nullptr;
+    size_t n_ = 0;
+
+public:
+    PlainBuffer() = default;
+    PlainBuffer(PlainBuffer const &) = delete;
+    PlainBuffer & operator=(PlainBuffer const &) = delete;
+    ~PlainBuffer() { ::operator delete(p_); }
+    void resize(size_t n) // (contents are lost)
+    {
+        ::operator delete(p_);
+        p_ = nullptr;
+        n_ = 0;
+        if (n)
+            p_ = static_cast<T *>(::operator new(n * sizeof(T)));
+        n_ = n;
+    }
+    T *       data() { return p_; }
+    T const * data() const { return p_; }
+    size_t    size() const { return n_; }
+    T *       begin() { return p_; }
+    T *       end() { return p_ + n_; }
+    T const * begin() const { return p_; }
+    T const * end() const { return p_ + n_; }
+    T &       operator[](size_t i) { return p_[i]; }
+    T const & operator[](size_t i) const { return p_[i]; }
+};
+
 struct SeedParams // SearchOptions' seeding part, src/search_options.hpp:309-337
 {
     int seedLength = 10, seedOffset = 5, maxSeedDist = 0;
@@ -113,10 +147,11 @@ public:
         for (size_t s = 0; s < nSeq; ++s)
             first[s + 1] = first[s] + len[s];
         uint64_t const total = first[nSeq];
-        constexpr int  kTopLen = 3;
+        int const      kTopLen = std::min(3, keyLen_ - 1);
         uint64_t const topDiv = pow_[keyLen_ - kTopLen];
         size_t const   nBuckets = (size_t)pow_[kTopLen];
-        std::vector<Entry> raw(total);
+        PlainBuffer<Entry> raw;
+        raw.resize(total);
         // contiguous ranges of sequences of about equal residue counts
         size_t const        nParts = std::max<size_t>(1, std::min<size_t>(nSeq, (size_t)nThreads * 4));
         std::vector<size_t> cut(nParts + 1, nSeq);
@@ -127,6 +162,17 @@ public:
                 ++s;
             cut[part] = s;
         }
+#ifdef LX_SEED_BUILD_TIMING // (development aid, tools/dev/seed_bench.cpp: where the table's time goes)
+        auto tMark = std::chrono::steady_clock::now();
+        auto mark  = [&](char const * what)
+        {
+            auto const now = std::chrono::steady_clock::now();
+            std::printf("  table: %s %.0f ms\n", what, std::chrono::duration<double, std::milli>(now - tMark).count());
+            tMark = now;
+        };
+#else
+        auto mark = [](char const *) {};
+#endif
         std::vector<std::vector<uint64_t>> counts(nParts, std::vector<uint64_t>(nBuckets, 0));
         parallelChunks(nThreads, nParts,
                        [&](size_t part)
@@ -151,6 +197,7 @@ public:
                                }
                            }
                        });
+        mark("keys + counts");
         // where every (bucket, part) starts in the sorted table
         std::vector<uint64_t> bucketAt(nBuckets + 1, 0);
         for (size_t b = 0, at = 0; b < nBuckets; ++b)
@@ -164,7 +211,7 @@ public:
             }
             bucketAt[b + 1] = at;
         }
-        entries_.assign(total, Entry{});
+        entries_.resize(total);
         parallelChunks(nThreads, nParts,
                        [&](size_t part)
                        {
@@ -172,21 +219,45 @@ public:
                            for (uint64_t e = first[cut[part]]; e < first[cut[part + 1]]; ++e)
                                entries_[at[raw[e].key / topDiv]++] = raw[e];
                        });
-        raw.clear();
-        raw.shrink_to_fit();
+        mark("scatter");
+        raw.resize(0);
         // the big buckets first, so that the last threads do not start one when the others are done
         std::vector<uint32_t> order(nBuckets);
         for (size_t b = 0; b < nBuckets; ++b)
             order[b] = (uint32_t)b;
         std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return bucketAt[a + 1] - bucketAt[a] > bucketAt[b + 1] - bucketAt[b]; });
+        // a bucket (the words' first kTopLen letters) is dealt once more by the next kTopLen letters -- it fits the caches --, and what
+        // is left to compare is a handful of entries per piece (one sort of the whole bucket costs three times as much)
+        int const      subLen = std::min(kTopLen, keyLen_ - kTopLen);
+        uint64_t const subDiv = pow_[keyLen_ - kTopLen - subLen], subMod = pow_[subLen];
+        auto const     less   = [](Entry const & x, Entry const & y) { return x.key != y.key ? x.key < y.key : x.seq != y.seq ? x.seq < y.seq : x.pos < y.pos; };
         parallelChunks(nThreads, nBuckets,
                        [&](size_t k)
                        {
-                           uint32_t const b = order[k];
-                           std::sort(entries_.begin() + (std::ptrdiff_t)bucketAt[b], entries_.begin() + (std::ptrdiff_t)bucketAt[b + 1],
-                                     [](Entry const & x, Entry const & y)
-                                     { return x.key != y.key ? x.key < y.key : x.seq != y.seq ? x.seq < y.seq : x.pos < y.pos; });
+                           uint32_t const b  = order[k];
+                           Entry * const  lo = entries_.begin() + bucketAt[b];
+                           size_t const   n  = (size_t)(bucketAt[b + 1] - bucketAt[b]);
+                           if (n < 64 || subLen < 1)
+                           {
+                               std::sort(lo, lo + n, less);
+                               return;
+                           }
+                           std::vector<uint32_t> at((size_t)subMod + 1, 0);
+                           for (size_t e = 0; e < n; ++e)
+                               ++at[(size_t)((lo[e].key / subDiv) % subMod) + 1];
+                           for (size_t d = 0; d < (size_t)subMod; ++d)
+                               at[d + 1] += at[d];
+                           std::vector<uint32_t> const first(at);
+                           PlainBuffer<Entry>          tmp;
+                           tmp.resize(n);
+                           for (size_t e = 0; e < n; ++e)
+                               tmp[at[(size_t)((lo[e].key / subDiv) % subMod)]++] = lo[e];
+                           for (size_t d = 0; d < (size_t)subMod; ++d)
+                               if (first[d + 1] - first[d] > 1)
+                                   std::sort(tmp.begin() + first[d], tmp.begin() + first[d + 1], less);
+                           std::copy(tmp.begin(), tmp.end(), lo);
                        });
+        mark("bucket sorts");
         // where the words with every prefix of preLen_ letters begin: the first letters of a seed cost one table read each instead
         // of two binary searches over the whole table (the probes that miss every cache)
         preLen_ = 1;
@@ -208,6 +279,7 @@ public:
                                    pre_[prev] = e;
                            }
                        });
+        mark("prefix table");
     }
 
     int    keyLen() const { return keyLen_; }
@@ -377,7 +449,7 @@ public:
     uint64_t         power(int i) const { return pow_[(size_t)i]; }
 
 private:
-    std::vector<Entry>    entries_;
+    PlainBuffer<Entry>    entries_;
     std::vector<uint64_t> pow_, pre_; // pre_[w] = first entry whose first preLen_ letters are >= the word w
     int                   preLen_ = 0;
     uint8_t const *       red_ = nullptr; // the caller's reduced residues and sequence table (must outlive the index)

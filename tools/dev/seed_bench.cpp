@@ -1,5 +1,6 @@
 // Development aid: times the host seeding stage alone (no GPU): g++ -O2 -std=c++17 -pthread tools/dev/seed_bench.cpp -o /tmp/seed_bench
 //   /tmp/seed_bench [n_queries] [n_db] [threads]
+#define LX_SEED_BUILD_TIMING 1
 #include <chrono>
 #include <cmath>
 #include <cstdio>
