@@ -85,15 +85,14 @@ uint8_t aaRank(char c) // SeqAn2 AminoAcid rank (src/seqan2_to_biocpp.hpp:352-36
 
 uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets pass it through, :392-393)
 {
-    switch (std::toupper((unsigned char)c))
+    static auto const table = []()
     {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T':
-        case 'U': return 4;
-        default: return 3;
-    }
+        std::array<uint8_t, 256> t;
+        t.fill(3);
+        t['A'] = t['a'] = 0, t['C'] = t['c'] = 1, t['G'] = t['g'] = 2, t['T'] = t['t'] = t['U'] = t['u'] = 4;
+        return t;
+    }();
+    return table[(unsigned char)c];
 }
 
 uint8_t dnaRankSeqan(char c) // SeqAn Dna5 rank A,C,G,T,N: the bisulfite schemes are matrices over it (src/bisulfite_scoring.hpp:54-93)
@@ -185,8 +184,10 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
             out.off.push_back(out.res.size());
             out.len.push_back(cur.size());
             static uint8_t const comp[5] = {4, 2, 1, 3, 0};
-            for (size_t i = cur.size(); i-- > 0;)
-                out.res.push_back(comp[dnaRank(cur[i])]);
+            size_t const at = out.res.size(), n = cur.size();
+            out.res.resize(at + n);
+            for (size_t k = 0; k < n; ++k) // (the forward frame's ranks stand right before)
+                out.res[at + k] = comp[out.res[at - 1 - k]];
         }
         cur.clear();
     };
