@@ -97,15 +97,14 @@ uint8_t dnaRank(char c) // BioC++ dna5 rank A,C,G,N,T (Simple-scored alphabets p
 
 uint8_t dnaRankSeqan(char c) // SeqAn Dna5 rank A,C,G,T,N: the bisulfite schemes are matrices over it (src/bisulfite_scoring.hpp:54-93)
 {
-    switch (std::toupper((unsigned char)c))
+    static auto const table = []()
     {
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T':
-        case 'U': return 3;
-        default: return 4;
-    }
+        std::array<uint8_t, 256> t;
+        t.fill(4);
+        t['A'] = t['a'] = 0, t['C'] = t['c'] = 1, t['G'] = t['g'] = 2, t['T'] = t['t'] = t['U'] = t['u'] = 3;
+        return t;
+    }();
+    return table[(unsigned char)c];
 }
 
 // translate = six protein frames per nucleotide sequence (BLASTX queries: qryNumFrames = 6, translate_join)
@@ -150,12 +149,14 @@ void readFasta(std::string const & path, bool protein, bool addRevComp, SeqSet &
                 out.off.push_back(out.res.size());
                 out.len.push_back(cur.size());
                 static uint8_t const comp[5] = {3, 2, 1, 0, 4};
+                size_t const at = out.res.size(), n = cur.size();
+                out.res.resize(at + n);
                 if (!rc)
-                    for (char c : cur)
-                        out.res.push_back(dnaRankSeqan(c));
+                    for (size_t k = 0; k < n; ++k)
+                        out.res[at + k] = dnaRankSeqan(cur[k]);
                 else
-                    for (size_t i = cur.size(); i-- > 0;)
-                        out.res.push_back(comp[dnaRankSeqan(cur[i])]);
+                    for (size_t k = 0; k < n; ++k)
+                        out.res[at + k] = comp[dnaRankSeqan(cur[n - 1 - k])];
             };
             push(false);
             push(false);
