@@ -82,10 +82,64 @@ inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t con
     bool           grouped = nt > 1;
     for (uint64_t i = 1; i < n && grouped; ++i)
         grouped = m[i - 1].qryId <= m[i].qryId;
-    if (grouped)
+    // A list in any other order (the GPU seeding stage emits the matches in the order its lanes made them) is dealt to buckets of
+    // consecutive queries first -- per-thread counts, one scatter into a second array --, and the pieces are runs of whole buckets:
+    // each still holds every match of its queries, which is all the pieces need (they sort themselves).
+    std::vector<lx_match> dealt;
+    std::vector<uint64_t> cut(nt + 1, n), kept(nt, 0);
+    cut[0] = 0;
+    if (nt > 1 && !grouped)
     {
-        std::vector<uint64_t> cut(nt + 1, n), kept(nt, 0);
-        cut[0] = 0;
+        uint64_t maxQ = 0;
+        {
+            std::vector<uint64_t> tmax(nt, 0);
+            uint64_t const        step = (n + nt - 1) / nt;
+            lxi::pool_run(nt,
+                          [&](unsigned t)
+                          {
+                              uint64_t mx = 0;
+                              for (uint64_t i = std::min(n, t * step); i < std::min(n, (t + 1) * step); ++i)
+                                  mx = std::max(mx, m[i].qryId);
+                              tmax[t] = mx;
+                          });
+            for (uint64_t v : tmax)
+                maxQ = std::max(maxQ, v);
+        }
+        uint64_t const nb = std::min<uint64_t>(maxQ + 1, 4096), perBucket = (maxQ + nb) / nb; // bucket of query q: q / perBucket
+        std::vector<std::vector<uint64_t>> at(nt, std::vector<uint64_t>(nb + 1, 0));
+        uint64_t const                     step = (n + nt - 1) / nt;
+        lxi::pool_run(nt,
+                      [&](unsigned t)
+                      {
+                          for (uint64_t i = std::min(n, t * step); i < std::min(n, (t + 1) * step); ++i)
+                              ++at[t][m[i].qryId / perBucket];
+                      });
+        std::vector<uint64_t> bucketAt(nb + 1, 0);
+        uint64_t              o = 0;
+        for (uint64_t b = 0; b < nb; ++b)
+        {
+            bucketAt[b] = o;
+            for (unsigned t = 0; t < nt; ++t)
+            {
+                uint64_t const c = at[t][b];
+                at[t][b]         = o;
+                o += c;
+            }
+        }
+        bucketAt[nb] = o;
+        dealt.resize(n);
+        lxi::pool_run(nt,
+                      [&](unsigned t)
+                      {
+                          for (uint64_t i = std::min(n, t * step); i < std::min(n, (t + 1) * step); ++i)
+                              dealt[at[t][m[i].qryId / perBucket]++] = m[i];
+                      });
+        for (unsigned t = 1; t < nt; ++t) // the bucket boundary at or behind the even share
+            cut[t] = std::max(cut[t - 1], *std::lower_bound(bucketAt.begin(), bucketAt.end(), n * t / nt));
+        grouped = true;
+    }
+    else if (grouped)
+    {
         for (unsigned t = 1; t < nt; ++t)
         {
             uint64_t c = std::max(cut[t - 1], n * t / nt);
@@ -93,6 +147,12 @@ inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t con
                 ++c;
             cut[t] = c;
         }
+    }
+    if (grouped)
+    {
+        lx_match * const dst = m;
+        if (!dealt.empty())
+            m = dealt.data(); // (the pieces are made in the second array and close ranks in the caller's)
         lxi::pool_run(nt,
                       [&](unsigned t)
                       {
@@ -122,8 +182,8 @@ inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t con
         uint64_t w = 0;
         for (unsigned t = 0; t < nt; ++t) // the pieces close ranks (the first stays where it is)
         {
-            if (w != cut[t] && kept[t])
-                std::memmove(static_cast<void *>(m + w), m + cut[t], kept[t] * sizeof(lx_match));
+            if ((m != dst || w != cut[t]) && kept[t])
+                std::memmove(static_cast<void *>(dst + w), m + cut[t], kept[t] * sizeof(lx_match));
             w += kept[t];
         }
         if (duplicates)

@@ -91,6 +91,29 @@ def test_blast_statistics_match_oracle(oracle):
         capi.karlin_params(62, gap_open=-3, gap_extend=-3)  # no published values -> prepareScoring would throw
 
 
+def test_widen_and_preprocess_large_lists_in_any_order(oracle):
+    """Lists beyond the size where the driver's loops go to the host threads: grouped by query (one piece per thread, cut at
+    query boundaries) and in RANDOM order (what the GPU seeding stage hands over: dealt to buckets of consecutive queries first) give
+    what one thread gives -- the oracle's list."""
+    rng = np.random.default_rng(11)
+    n = 120_000
+    m = np.zeros(n, dtype=capi.MATCH_DTYPE)
+    m["qryId"] = np.sort(rng.integers(0, 9000, n))
+    m["subjId"] = rng.integers(0, 40, n)
+    qlens = rng.integers(30, 200, 9000).astype(np.uint64)
+    slens = rng.integers(300, 2000, 40).astype(np.uint64)
+    m["qryStart"] = rng.integers(0, 20, n)
+    m["qryEnd"] = m["qryStart"] + 10
+    m["subjStart"] = (rng.integers(0, 1500, n) // 7) * 7  # duplicates and overlaps abound
+    m["subjEnd"] = m["subjStart"] + 10
+    want = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlens, slens)
+    for order in (np.arange(n), rng.permutation(n), np.arange(n)[::-1]):
+        got = capi.widen_and_preprocess(m[order], qlens, slens)
+        assert len(got) == len(want) and len(got) < n
+        for f in ("qryId", "subjId", "qryStart", "qryEnd", "subjStart", "subjEnd"):
+            assert (got[f] == want[f]).all(), f
+
+
 def test_rank_bridge():
     """lx_convert_ranks = seqan2_to_rank_inner (src/seqan2_to_biocpp.hpp:352-395): aa27 moves X behind Z, bisulfite
     dna5 moves N behind T, match/mismatch alphabets pass through; out-of-alphabet ranks are an error."""
