@@ -575,7 +575,7 @@ class Handle:
             total = int((bms["ops_off"].astype(np.uint64) + bms["n_ops"].astype(np.uint64)).max())  # (not the last record's: bisulfite runs two passes)
             obuf = (C.c_char * max(total, 1)).from_address(self.lib.lx_iterate_result_ops(res))
             allops = bytes(obuf)
-            ops = [allops[int(b["ops_off"]):int(b["ops_off"]) + int(b["n_ops"])] for b in bms]
+            ops = [allops[o:o + k] for o, k in zip(bms["ops_off"].tolist(), bms["n_ops"].tolist())]  # (record scalars one by one cost 0.7 ms per thousand)
             return bms, ops, stats
         finally:
             self.lib.lx_iterate_result_free(res)
