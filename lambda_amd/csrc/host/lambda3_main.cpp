@@ -706,8 +706,33 @@ int main(int argc, char ** argv)
         int const     sFrames = bs ? 2 : sTrans ? 6 : 1;
         char const *  program = blastx ? (sTrans ? "tblastx" : "blastx") : sTrans ? "tblastn" : prot ? "blastp" : "blastn";
 
-        if (!mk)
-            readFasta(opt.query, prot, !prot, qs, blastx, geneticCodeQry, bs ? 2 : 0);
+        // the queries are read beside the database (two files, two threads; -t 1 keeps it to one)
+        std::string qryError;
+        std::thread qryReader;
+        auto        readQueries = [&]()
+        {
+            try
+            {
+                readFasta(opt.query, prot, !prot, qs, blastx, geneticCodeQry, bs ? 2 : 0);
+            }
+            catch (std::exception const & e)
+            {
+                qryError = e.what();
+            }
+        };
+        struct Joiner // (joined on every way out)
+        {
+            std::thread & t;
+            ~Joiner()
+            {
+                if (t.joinable())
+                    t.join();
+            }
+        } joiner{qryReader};
+        if (!mk && opt.threads != 1)
+            qryReader = std::thread(readQueries);
+        else if (!mk)
+            readQueries();
         if (!fromIndex)
         {
             std::ifstream probe(opt.db, std::ios::binary);
@@ -719,6 +744,10 @@ int main(int argc, char ** argv)
                                          "archive of an fmindex-collection FM-index -- cannot be read here: run lambda3 mkindexp|mkindexn|mkindexbs on the FASTA file)");
             readFasta(opt.db, prot, false, db, sTrans, geneticCodeDb, bs ? 1 : 0);
         }
+        if (qryReader.joinable())
+            qryReader.join();
+        if (!qryError.empty())
+            throw std::runtime_error(qryError);
         if ((!mk && qs.ids.empty()) || db.ids.empty())
             throw std::runtime_error("empty query or database file");
         if (fromIndex && db.off.size() != db.ids.size() * (size_t)sFrames)
