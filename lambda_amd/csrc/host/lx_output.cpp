@@ -20,8 +20,16 @@
 #include <tuple>
 #include <vector>
 
+#include <functional>
+
 #include "../../../include/lambda_ext.h"
 #include "scoring_tables.hpp"
+
+namespace lxi // the library's host threads (lx_host.cpp)
+{
+unsigned pool_width();
+void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
+} // namespace lxi
 
 namespace
 {
@@ -670,6 +678,12 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
         std::string fields;
         for (int c : cols)
             fields += (fields.empty() ? "" : ", ") + std::string(kColumns[c].desc);
+        for (uint64_t k = 0; k < n; ++k)
+            if (m[k].n_qid >= names->n_q || m[k].n_sid >= names->n_s)
+            {
+                std::fclose(f);
+                return LX_EINVAL;
+            }
         for (uint64_t lo = 0; lo < n;)
         {
             uint64_t hi = lo + 1;
@@ -685,14 +699,11 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
             for (int c : cols)
                 if (c == kColLcaTaxId)
                     lca = lcaOf(m[lo].n_qid);
-            for (uint64_t k = lo; k < hi; ++k)
+            // one record -> one line, appended to `out` (the same text whichever thread makes it)
+            auto formatRecord = [&](lx_blast_match const & b, uint32_t lca, std::string & out)
             {
-                lx_blast_match const & b = m[k];
-                if (b.n_qid >= names->n_q || b.n_sid >= names->n_s)
-                {
-                    std::fclose(f);
-                    return LX_EINVAL;
-                }
+                char tmp[64];
+                auto put = [&](char const * fmt, auto... args) { out.append(tmp, (size_t)std::snprintf(tmp, sizeof(tmp), fmt, args...)); };
                 // 1-based inclusive; a hit of the reverse-complemented query is reported BLAST-style on the forward query
                 // strand with descending subject coordinates
                 unsigned long long qs = b.q_start + 1, qe = b.q_end, ss = b.s_start + 1, se = b.s_end;
@@ -730,38 +741,66 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
                 for (int c : cols)
                 {
                     if (!first)
-                        std::fputc('\t', f);
+                        out.push_back('\t');
                     first = false;
                     switch (c)
                     {
-                        case kColQSeqId: std::fputs(firstWord(names->q_ids[b.n_qid]).c_str(), f); break;
-                        case kColSSeqId: std::fputs(firstWord(names->s_ids[b.n_sid]).c_str(), f); break;
-                        case kColQLen: std::fprintf(f, "%llu", (unsigned long long)names->q_lens[b.n_qid]); break;
-                        case kColSLen: std::fprintf(f, "%llu", (unsigned long long)names->s_lens[b.n_sid]); break;
-                        case kColQStart: std::fprintf(f, "%llu", qs); break;
-                        case kColQEnd: std::fprintf(f, "%llu", qe); break;
-                        case kColSStart: std::fprintf(f, "%llu", ss); break;
-                        case kColSEnd: std::fprintf(f, "%llu", se); break;
-                        case kColEValue: std::fprintf(f, "%.1e", b.e_value); break;
-                        case kColBitScore: std::fprintf(f, "%.1f", b.bit_score); break;
-                        case kColScore: std::fprintf(f, "%d", b.score); break;
-                        case kColLength: std::fprintf(f, "%d", b.alignment_length); break;
-                        case kColPIdent: std::fprintf(f, "%.2f", (double)b.identity); break;
-                        case kColNIdent: std::fprintf(f, "%d", b.num_matches); break;
-                        case kColMismatch: std::fprintf(f, "%d", b.num_mismatches); break;
-                        case kColPositive: std::fprintf(f, "%d", b.num_positives); break;
-                        case kColGapOpen: std::fprintf(f, "%d", b.num_gap_opens); break;
-                        case kColGaps: std::fprintf(f, "%d", b.num_gap_opens + b.num_gap_extensions); break; // every gap character
-                        case kColPPos: std::fprintf(f, "%.2f", b.alignment_length ? 100.0 * b.num_positives / b.alignment_length : 0.0); break;
-                        case kColFrames: std::fprintf(f, "%d/%d", (int)b.q_frame, (int)b.s_frame); break;
-                        case kColQFrame: std::fprintf(f, "%d", (int)b.q_frame); break;
-                        case kColSFrame: std::fprintf(f, "%d", (int)b.s_frame); break;
-                        case kColSTaxIds: std::fputs(taxIdsOf(b.n_sid).c_str(), f); break;
-                        case kColLcaTaxId: std::fprintf(f, "%u", lca); break;
+                        case kColQSeqId: out += firstWord(names->q_ids[b.n_qid]).c_str(); break;
+                        case kColSSeqId: out += firstWord(names->s_ids[b.n_sid]).c_str(); break;
+                        case kColQLen: put("%llu", (unsigned long long)names->q_lens[b.n_qid]); break;
+                        case kColSLen: put("%llu", (unsigned long long)names->s_lens[b.n_sid]); break;
+                        case kColQStart: put("%llu", qs); break;
+                        case kColQEnd: put("%llu", qe); break;
+                        case kColSStart: put("%llu", ss); break;
+                        case kColSEnd: put("%llu", se); break;
+                        case kColEValue: put("%.1e", b.e_value); break;
+                        case kColBitScore: put("%.1f", b.bit_score); break;
+                        case kColScore: put("%d", b.score); break;
+                        case kColLength: put("%d", b.alignment_length); break;
+                        case kColPIdent: put("%.2f", (double)b.identity); break;
+                        case kColNIdent: put("%d", b.num_matches); break;
+                        case kColMismatch: put("%d", b.num_mismatches); break;
+                        case kColPositive: put("%d", b.num_positives); break;
+                        case kColGapOpen: put("%d", b.num_gap_opens); break;
+                        case kColGaps: put("%d", b.num_gap_opens + b.num_gap_extensions); break; // every gap character
+                        case kColPPos: put("%.2f", b.alignment_length ? 100.0 * b.num_positives / b.alignment_length : 0.0); break;
+                        case kColFrames: put("%d/%d", (int)b.q_frame, (int)b.s_frame); break;
+                        case kColQFrame: put("%d", (int)b.q_frame); break;
+                        case kColSFrame: put("%d", (int)b.s_frame); break;
+                        case kColSTaxIds: out += taxIdsOf(b.n_sid).c_str(); break;
+                        case kColLcaTaxId: put("%u", lca); break;
                         default: break;
                     }
                 }
-                std::fputc('\n', f);
+                out.push_back('\n');
+            };
+            bool hasLca = false;
+            for (int c : cols)
+                hasLca = hasLca || c == kColLcaTaxId;
+            if (!comments && !hasLca && lo == 0 && n >= 65536 && lxi::pool_width() > 1)
+            {
+                // a plain table of many records: the lines are made on the library's host threads, piece by piece, and written in order
+                unsigned const           nt = lxi::pool_width();
+                std::vector<std::string> piece(nt);
+                uint64_t const           step = (n + nt - 1) / nt;
+                lxi::pool_run(nt,
+                              [&](unsigned t)
+                              {
+                                  std::string & out = piece[t];
+                                  out.reserve((size_t)(std::min(n, (t + 1) * step) - std::min(n, t * step)) * 96);
+                                  for (uint64_t k = std::min(n, t * step); k < std::min(n, (t + 1) * step); ++k)
+                                      formatRecord(m[k], 0u, out);
+                              });
+                for (std::string const & out : piece)
+                    std::fwrite(out.data(), 1, out.size(), f);
+                break;
+            }
+            std::string line;
+            for (uint64_t k = lo; k < hi; ++k)
+            {
+                line.clear();
+                formatRecord(m[k], lca, line);
+                std::fwrite(line.data(), 1, line.size(), f);
             }
             lo = hi;
         }

@@ -317,3 +317,27 @@ def test_tabular_columns_version_line_and_footer(tmp_path):
                                              "in your academic work]")
     with pytest.raises(capi.LambdaExtError, match="Unknown column specifier \"qseq\""):
         capi.write_records(p, capi.LX_OUT_BLAST_TAB, m, ops, ["q0"], [40], ["s0", "s1"], [300, 400], options=capi.output_options(columns="std qseq"))
+
+
+def test_large_table_written_on_several_threads_equals_small_pieces(tmp_path):
+    """A plain table of many records is formatted on the library's host threads (pieces written in order): the file must be the
+    concatenation of what the same records give written in small pieces (below the size where the threads come in), both strands and
+    odd values included."""
+    rng = np.random.default_rng(3)
+    n, nq, ns = 70_000, 9_000, 50
+    qids = np.sort(rng.integers(0, nq, n))
+    recs = []
+    for k in range(n):
+        qs = int(rng.integers(0, 30))
+        recs.append(rec(int(qids[k]), int(rng.integers(0, ns)), qs, qs + int(rng.integers(5, 60)), int(rng.integers(0, 900)), int(rng.integers(900, 1000)),
+                        float(rng.integers(200, 9000)) / 10, score=int(rng.integers(20, 400)), ev=float(10.0 ** -rng.integers(1, 80)),
+                        ident=float(rng.integers(2000, 10000)) / 100, frame=int(rng.choice([1, -1]))))
+    m = np.array(recs, dtype=capi.BLAST_MATCH_DTYPE)
+    q_ids, s_ids = [f"q{i} d" for i in range(nq)], [f"s{i}" for i in range(ns)]
+    q_lens, s_lens = [100] * nq, [1000] * ns
+    whole = tmp_path / "whole.m8"
+    capi.write_records(whole, capi.LX_OUT_BLAST_TAB, m, b"", q_ids, q_lens, s_ids, s_lens, program="blastn")
+    pieces = tmp_path / "pieces.m8"
+    for a in range(0, n, 10_000):
+        capi.write_records(pieces, capi.LX_OUT_BLAST_TAB, m[a:a + 10_000], b"", q_ids, q_lens, s_ids, s_lens, program="blastn", write_header=(a == 0))
+    assert whole.read_bytes() == pieces.read_bytes() and len(whole.read_text().splitlines()) == n
