@@ -238,6 +238,7 @@ struct Options
     bool        samWithRefHeader = false, versionToOutput = true;
     std::string commandLine;
     std::vector<int> devices;         // --devices (default: every visible device)
+    std::string table       = "auto"; // --table gpu | host | auto: where the word table is made (auto: search* on the GPU, mkindex* on the host)
     std::string seeding     = "gpu";  // --seeding gpu | host: where search() runs (host/lx_seeding_gpu.hpp -- one lane per read, reads the
                                       // device declines go to the host --, host/lx_seeding.hpp on the -t threads)
     int         threads     = 0;    // -t host threads for the word table and the seeding (default: what the machine grants)
@@ -444,6 +445,12 @@ Options parse(int argc, char ** argv)
         }
         else if (a == "-t" || a == "--threads")
             o.threads = std::stoi(val());
+        else if (a == "--table")
+        {
+            o.table = val();
+            if (o.table != "gpu" && o.table != "host" && o.table != "auto")
+                throw std::runtime_error("--table takes gpu, host or auto");
+        }
         else if (a == "--seeding")
         {
             o.seeding = val();
@@ -784,9 +791,14 @@ int main(int argc, char ** argv)
                 red[i] = redTab ? redTab[set.res[i] < (prot ? 27 : 5) ? set.res[i] : 0] : set.res[i];
             return red;
         };
+        if (!mk || opt.table == "gpu") // (before the first device is touched: the library's own wording)
+            for (int d : opt.devices)
+                if (d < 0 || d >= lx_device_count())
+                    throw std::runtime_error("device_id " + std::to_string(d) + " out of range [0," + std::to_string(lx_device_count()) + ")");
         auto const                 tIndex = std::chrono::steady_clock::now();
         std::vector<uint8_t> const dbRed = reduce(db);
         lambda_amd::ReducedIndex   ix;
+        bool                       tableOnGpu = false;
         if (fromIndex)
         {
             bool const ok = ix.load([&](void * p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, indexFile) == bytes; }, dbRed, db.off, db.len) &&
@@ -796,7 +808,17 @@ int main(int argc, char ** argv)
                 throw std::runtime_error("index file " + opt.db + ": the word table is truncated or does not fit the sequences");
         }
         else
-            ix.build(dbRed, db.off, db.len, alph, nThreads);
+        {
+            // on the GPU (keys, one radix sort, prefix table: host/lx_seeding_gpu.hpp) where there is one to take it, else on the -t
+            // host threads; the same table either way
+            bool const wantGpu = opt.table == "gpu" || (opt.table == "auto" && !mk);
+            if (wantGpu && lx_device_count() > 0)
+                tableOnGpu = lambda_amd::buildTableOnGpu(opt.devices.empty() ? 0 : opt.devices[0], ix, dbRed, db.off, db.len, alph);
+            else if (opt.table == "gpu")
+                throw std::runtime_error("--table gpu: no HIP device available");
+            if (!tableOnGpu)
+                ix.build(dbRed, db.off, db.len, alph, nThreads);
+        }
         double const msIndex = msSince(tIndex);
         if (mk)
         {
@@ -814,9 +836,10 @@ int main(int argc, char ** argv)
                 residues += l;
             std::fprintf(stderr,
                          "lambda3 %s: %zu sequences (%llu residues in %d frame(s); original alphabet %s, translated %s, reduced %s, genetic code %d) -> %s\n"
-                         "lambda3 times [ms]: read %.0f, reduce + word table %.0f (%u host thread(s)), write %.0f, total %.0f\n",
+                         "lambda3 times [ms]: read %.0f, reduce + word table %.0f (%s), write %.0f, total %.0f\n",
                          opt.cmd.c_str(), db.ids.size(), (unsigned long long)residues, sFrames, alphName(out.origAlph), alphName(out.transAlph),
-                         alphName(out.redAlph), (int)out.geneticCode, opt.index.c_str(), msRead, msIndex, nThreads, msSince(tWrite), msSince(tStart));
+                         alphName(out.redAlph), (int)out.geneticCode, opt.index.c_str(), msRead, msIndex, tableOnGpu ? "on the GPU" : (std::to_string(nThreads) + " host thread(s)").c_str(),
+                         msSince(tWrite), msSince(tStart));
             return 0;
         }
         std::vector<uint8_t> const qRed = reduce(qs);
@@ -1082,9 +1105,9 @@ int main(int argc, char ** argv)
                      (unsigned long long)nHsp, (unsigned long long)nOut, (unsigned long long)rst.qrys_with_hit);
         // where the wall clock went (the reference prints its own at verbosity 2, src/search.cpp): per worker the slowest counts
         std::fprintf(stderr,
-                     "lambda3 times [ms]: read %.0f, reduce + word table %.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu launch(es) left to "
+                     "lambda3 times [ms]: read %.0f, reduce + word table %s%.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu launch(es) left to "
                      "the host] + extension on the GPU incl. widen / merge / statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
-                     msRead, msIndex, msSearch, (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix)) ? "GPU" : "host", msSeedMax, nDeclined,
+                     msRead, fromIndex ? "(read from the index) " : tableOnGpu ? "(on the GPU) " : "", msIndex, msSearch, (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix)) ? "GPU" : "host", msSeedMax, nDeclined,
                      nPassesOnHost, msExtendMax, msSince(tOut), msSince(tStart));
         return 0;
     }

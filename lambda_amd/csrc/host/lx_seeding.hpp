@@ -282,6 +282,32 @@ public:
         mark("prefix table");
     }
 
+    // For a table made elsewhere (the GPU builder, host/lx_seeding_gpu.hpp): the geometry build() would choose for this database,
+    // then room for the entries and the prefix table, which the caller fills -- sorted by (word, sequence, position) -- before
+    // the first search.  total = number of residues.
+    void prepareExternal(std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
+    {
+        red_    = red.data();
+        off_    = off.data();
+        len_    = len.data();
+        alph_   = alph;
+        base_   = (uint64_t)alph + 1;
+        keyLen_ = 0;
+        for (uint64_t lim = ~0ull / 2, p = 1; p <= lim / base_; p *= base_)
+            ++keyLen_;
+        pow_.assign(keyLen_ + 1, 1);
+        for (int i = 1; i <= keyLen_; ++i)
+            pow_[i] = pow_[i - 1] * base_;
+        uint64_t total = 0;
+        for (uint64_t l : len)
+            total += l;
+        preLen_ = 1;
+        while (preLen_ + 1 < keyLen_ && pow_[preLen_ + 1] <= std::min<uint64_t>(4u << 20, std::max<uint64_t>(1024, total)))
+            ++preLen_;
+        entries_.resize(total);
+        pre_.resize((size_t)pow_[preLen_] + 1);
+    }
+
     int    keyLen() const { return keyLen_; }
     Cursor root() const { return Cursor{0, entries_.size(), 0, 0}; }
 
@@ -447,6 +473,8 @@ public:
     uint64_t         prefixCount() const { return pre_.size(); }
     int              prefixLen() const { return preLen_; }
     uint64_t         power(int i) const { return pow_[(size_t)i]; }
+    Entry *          entriesForFill() { return entries_.data(); } // (after prepareExternal)
+    uint64_t *       prefixForFill() { return pre_.data(); }
 
 private:
     PlainBuffer<Entry>    entries_;

@@ -19,6 +19,7 @@
 //     the list carries no meaning.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -338,6 +339,61 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
         atomicAdd(p.counters + 2, nFailed);
 }
 
+// ---- the word table on the GPU: the keys of all positions (one thread each), one radix sort of (key, sequence << 32 | position)
+// pairs -- rocPRIM's device-wide sort through hipCUB: a library primitive, like a GEMM would be; stable, and the pairs start in
+// (sequence, position) order, so equal words end up ordered by sequence and position as in the host's table --, the entries
+// interleaved, the prefix table by one binary search per prefix.  The same table bit for bit (`lambda3 mkindex* --table gpu|host`
+// write identical files).
+__global__ void table_keys_kernel(uint8_t const * red, uint64_t const * off, uint64_t const * len, uint64_t const * first, uint64_t nSeq, uint64_t total,
+                                  int keyLen, uint64_t base, int alph, uint64_t * keys, uint64_t * vals)
+{
+    uint64_t const e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total)
+        return;
+    uint64_t a = 0, b = nSeq; // the sequence that holds entry e: last s with first[s] <= e (empty sequences share a start)
+    while (b - a > 1)
+    {
+        uint64_t const mid = a + (b - a) / 2;
+        if (first[mid] <= e)
+            a = mid;
+        else
+            b = mid;
+    }
+    while (a + 1 < nSeq && first[a + 1] <= e) // (skip empty sequences that start where the next one does)
+        ++a;
+    uint64_t const pos = e - first[a], L = len[a];
+    uint8_t const * r  = red + off[a] + pos;
+    uint64_t        key = 0;
+    for (int i = 0; i < keyLen; ++i)
+        key = key * base + (pos + (uint64_t)i < L ? (uint64_t)r[i] : (uint64_t)alph);
+    keys[e] = key;
+    vals[e] = (a << 32) | pos;
+}
+
+__global__ void table_entries_kernel(uint64_t const * keys, uint64_t const * vals, uint64_t total, ReducedIndex::Entry * out)
+{
+    uint64_t const e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < total)
+        out[e] = ReducedIndex::Entry{keys[e], (uint32_t)(vals[e] >> 32), (uint32_t)vals[e]};
+}
+
+__global__ void table_prefix_kernel(uint64_t const * keys, uint64_t total, uint64_t preDiv, uint64_t nPre, uint64_t * pre)
+{
+    uint64_t const w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nPre)
+        return;
+    uint64_t a = 0, b = total; // first entry whose first preLen letters are >= the word w
+    while (a < b)
+    {
+        uint64_t const mid = a + (b - a) / 2;
+        if (keys[mid] / preDiv < w)
+            a = mid + 1;
+        else
+            b = mid;
+    }
+    pre[w] = a;
+}
+
 #define LXS_HIP(call)                                                                                                  \
     do                                                                                                                 \
     {                                                                                                                  \
@@ -496,5 +552,81 @@ private:
         return true;
     }
 };
+
+// Fills `ix` with the table made on `device`.  false: not attempted (a table of 2^31 entries or more, or one that does not fit the
+// device's free memory) -- the caller builds on the host.
+inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
+{
+    uint64_t total = 0;
+    for (uint64_t l : len)
+        total += l;
+    if (total == 0 || total >= 0x7fffffffull || off.size() >= 0xffffffffull) // (the sort takes an int count)
+        return false;
+    for (uint64_t l : len)
+        if (l >= 0xffffffffull)
+            return false;
+    LXS_HIP(hipSetDevice(device));
+    size_t freeB = 0, totalB = 0;
+    LXS_HIP(hipMemGetInfo(&freeB, &totalB));
+    if ((double)total * 72.0 + (double)red.size() + (64 << 20) > (double)freeB) // keys + values twice, entries, sort workspace
+        return false;
+    ix.prepareExternal(red, off, len, alph);
+    size_t const          nSeq = off.size();
+    std::vector<uint64_t> first(nSeq + 1, 0);
+    for (size_t s = 0; s < nSeq; ++s)
+        first[s + 1] = first[s] + len[s];
+    auto dev = [](size_t bytes) -> void *
+    {
+        void * p = nullptr;
+        LXS_HIP(hipMalloc(&p, std::max<size_t>(bytes, 16)));
+        return p;
+    };
+    struct Free
+    {
+        std::vector<void *> ptrs;
+        ~Free()
+        {
+            for (void * p : ptrs)
+                (void)hipFree(p);
+        }
+    } owned;
+    auto take = [&](size_t bytes)
+    {
+        owned.ptrs.push_back(dev(bytes));
+        return owned.ptrs.back();
+    };
+    uint8_t *  dRed   = static_cast<uint8_t *>(take(red.size() + 64));
+    uint64_t * dOff   = static_cast<uint64_t *>(take(nSeq * 8));
+    uint64_t * dLen   = static_cast<uint64_t *>(take(nSeq * 8));
+    uint64_t * dFirst = static_cast<uint64_t *>(take((nSeq + 1) * 8));
+    uint64_t * k0 = static_cast<uint64_t *>(take(total * 8)), * k1 = static_cast<uint64_t *>(take(total * 8));
+    uint64_t * v0 = static_cast<uint64_t *>(take(total * 8)), * v1 = static_cast<uint64_t *>(take(total * 8));
+    LXS_HIP(hipMemcpy(dRed, red.data(), red.size(), hipMemcpyHostToDevice));
+    LXS_HIP(hipMemcpy(dOff, off.data(), nSeq * 8, hipMemcpyHostToDevice));
+    LXS_HIP(hipMemcpy(dLen, len.data(), nSeq * 8, hipMemcpyHostToDevice));
+    LXS_HIP(hipMemcpy(dFirst, first.data(), (nSeq + 1) * 8, hipMemcpyHostToDevice));
+    int const      keyLen = ix.keyLen(), preLen = ix.prefixLen();
+    uint64_t const base = (uint64_t)alph + 1;
+    unsigned const blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(table_keys_kernel, dim3(blocks), dim3(256), 0, 0, dRed, dOff, dLen, dFirst, (uint64_t)nSeq, total, keyLen, base, alph, k0, v0);
+    LXS_HIP(hipGetLastError());
+    int bits = 1;
+    while (bits < 64 && (ix.power(keyLen) - 1) >> bits)
+        ++bits;
+    size_t tempBytes = 0;
+    LXS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, k0, k1, v0, v1, (int)total, 0, bits));
+    void * temp = take(tempBytes);
+    LXS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, k0, k1, v0, v1, (int)total, 0, bits));
+    ReducedIndex::Entry * dEntries = static_cast<ReducedIndex::Entry *>(take(total * sizeof(ReducedIndex::Entry)));
+    hipLaunchKernelGGL(table_entries_kernel, dim3(blocks), dim3(256), 0, 0, k1, v1, total, dEntries);
+    LXS_HIP(hipGetLastError());
+    uint64_t const nPre = ix.prefixCount();
+    uint64_t *     dPre = static_cast<uint64_t *>(take(nPre * 8));
+    hipLaunchKernelGGL(table_prefix_kernel, dim3((unsigned)((nPre + 255) / 256)), dim3(256), 0, 0, k1, total, ix.power(keyLen - preLen), nPre, dPre);
+    LXS_HIP(hipGetLastError());
+    LXS_HIP(hipMemcpy(ix.entriesForFill(), dEntries, total * sizeof(ReducedIndex::Entry), hipMemcpyDeviceToHost));
+    LXS_HIP(hipMemcpy(ix.prefixForFill(), dPre, nPre * 8, hipMemcpyDeviceToHost));
+    return true;
+}
 
 } // namespace lambda_amd

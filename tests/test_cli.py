@@ -159,7 +159,11 @@ def test_search_on_an_index_equals_search_on_the_fasta_file(tmp_path):
     for n, (search, mk, qry, db, mkopt, fopt) in enumerate(cases):
         idx = tmp_path / f"case{n}.lba"
         r = subprocess.run([cli, mk, "-d", str(tmp_path / db), "-i", str(idx)] + mkopt, capture_output=True, text=True)
-        assert r.returncode == 0, r.stderr
+        assert r.returncode == 0 and "host thread(s)), write" in r.stderr, r.stderr
+        # the word table made on the GPU (keys, one radix sort, prefix table) is the host's, bit for bit
+        r = subprocess.run([cli, mk, "-d", str(tmp_path / db), "-i", str(tmp_path / f"case{n}g.lba"), "--table", "gpu"] + mkopt, capture_output=True, text=True)
+        assert r.returncode == 0 and "(on the GPU), write" in r.stderr, r.stderr
+        assert (tmp_path / f"case{n}g.lba").read_bytes() == idx.read_bytes()
         for ext in ("m8", "sam"):
             common = ["-q", str(tmp_path / qry), "--version-to-outputfile", "0", "-e", "10"]
             a = subprocess.run([cli, search, "-i", str(idx), "-o", str(tmp_path / f"i{n}.{ext}")] + common, capture_output=True, text=True)
