@@ -799,6 +799,7 @@ int main(int argc, char ** argv)
         std::vector<uint8_t> const dbRed = reduce(db);
         lambda_amd::ReducedIndex   ix;
         bool                       tableOnGpu = false;
+        lambda_amd::DeviceTable    deviceTable; // (the table where the GPU builder left it, for the seeding stage on that device)
         if (fromIndex)
         {
             bool const ok = ix.load([&](void * p, size_t bytes) { return bytes == 0 || std::fread(p, 1, bytes, indexFile) == bytes; }, dbRed, db.off, db.len) &&
@@ -813,7 +814,8 @@ int main(int argc, char ** argv)
             // host threads; the same table either way
             bool const wantGpu = opt.table == "gpu" || (opt.table == "auto" && !mk);
             if (wantGpu && lx_device_count() > 0)
-                tableOnGpu = lambda_amd::buildTableOnGpu(opt.devices.empty() ? 0 : opt.devices[0], ix, dbRed, db.off, db.len, alph);
+                tableOnGpu = lambda_amd::buildTableOnGpu(opt.devices.empty() ? 0 : opt.devices[0], ix, dbRed, db.off, db.len, alph,
+                                                         (!mk && opt.seeding == "gpu") ? &deviceTable : nullptr);
             else if (opt.table == "gpu")
                 throw std::runtime_error("--table gpu: no HIP device available");
             if (!tableOnGpu)
@@ -933,7 +935,7 @@ int main(int argc, char ** argv)
                 // one pass of the batch loop of realMain (src/search.cpp:426-459): seed, extend (GPU), collect
                 std::unique_ptr<lambda_amd::GpuSeeder> gpuSeeder;
                 if (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix))
-                    gpuSeeder.reset(new lambda_amd::GpuSeeder(devices[w % devices.size()], ix, sin, dbRed, db.off.size(), db.res.size(), qs.res.size()));
+                    gpuSeeder.reset(new lambda_amd::GpuSeeder(devices[w % devices.size()], ix, sin, dbRed, db.off.size(), db.res.size(), qs.res.size(), &deviceTable));
                 auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
                 {
                     std::vector<lx_match> matches;

@@ -402,6 +402,27 @@ __global__ void table_prefix_kernel(uint64_t const * keys, uint64_t total, uint6
             throw std::runtime_error(std::string("GPU seeding: ") + #call + ": " + hipGetErrorString(e_));             \
     } while (0)
 
+// the table as the GPU builder left it on its device: the seeding stage of a worker on that device reads it where it is
+struct DeviceTable
+{
+    int                   device  = -1;
+    ReducedIndex::Entry * entries = nullptr;
+    uint64_t *            pre     = nullptr;
+    DeviceTable() = default;
+    DeviceTable(DeviceTable const &) = delete;
+    DeviceTable & operator=(DeviceTable const &) = delete;
+    ~DeviceTable()
+    {
+        if (device >= 0 && hipSetDevice(device) == hipSuccess)
+        {
+            if (entries)
+                (void)hipFree(entries);
+            if (pre)
+                (void)hipFree(pre);
+        }
+    }
+};
+
 // The table, the subjects and the queries of one worker on its device; seed() runs one pass of the batch loop.
 class GpuSeeder
 {
@@ -446,13 +467,17 @@ class GpuSeeder
 public:
     // (cursors are 32-bit ranges of the table; a seed's second part is held on a stack of kMaxSecond levels)
     static bool canTake(ReducedIndex const & ix) { return ix.entriesCount() < 0xffffffffull && ix.keyLen() < 64; }
-    GpuSeeder(int device, ReducedIndex const & ix, SeedingInput const & in, std::vector<uint8_t> const & sRed, uint64_t nSSeq, uint64_t sBytes, uint64_t qBytes)
+    GpuSeeder(int device, ReducedIndex const & ix, SeedingInput const & in, std::vector<uint8_t> const & sRed, uint64_t nSSeq, uint64_t sBytes, uint64_t qBytes,
+              DeviceTable const * resident = nullptr)
         : device_(device)
     {
         LXS_HIP(hipSetDevice(device_));
-
-        entries_.upload(ix.entriesData(), ix.entriesCount());
-        pre_.upload(ix.prefixData(), ix.prefixCount());
+        bool const adopt = resident && resident->device == device_ && resident->entries && resident->pre;
+        if (!adopt)
+        {
+            entries_.upload(ix.entriesData(), ix.entriesCount());
+            pre_.upload(ix.prefixData(), ix.prefixCount());
+        }
         sRes_.upload(in.sRes, sBytes);
         sRed_.upload(sRed.data(), sRed.size());
         sOff_.upload(in.sOff, nSSeq);
@@ -465,7 +490,7 @@ public:
         if (in.matrixRev)
             matrixRev_.upload(in.matrixRev, LX_ALPH * LX_ALPH);
         counters_.reserve(4);
-        d_.entries = entries_.p, d_.pre = pre_.p, d_.base = (uint64_t)ix.alphabet() + 1, d_.preLen = ix.prefixLen(), d_.keyLen = ix.keyLen(), d_.alph = ix.alphabet();
+        d_.entries = adopt ? resident->entries : entries_.p, d_.pre = adopt ? resident->pre : pre_.p, d_.base = (uint64_t)ix.alphabet() + 1, d_.preLen = ix.prefixLen(), d_.keyLen = ix.keyLen(), d_.alph = ix.alphabet();
         for (int k = 0; k <= ix.keyLen() && k < 64; ++k)
             d_.pow[k] = ix.power(k);
         d_.sRes = sRes_.p, d_.sRed = sRed_.p, d_.sOff = sOff_.p, d_.sLen = sLen_.p;
@@ -555,7 +580,8 @@ private:
 
 // Fills `ix` with the table made on `device`.  false: not attempted (a table of 2^31 entries or more, or one that does not fit the
 // device's free memory) -- the caller builds on the host.
-inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph)
+inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> const & red, std::vector<uint64_t> const & off, std::vector<uint64_t> const & len, int alph,
+                            DeviceTable * keep = nullptr)
 {
     uint64_t total = 0;
     for (uint64_t l : len)
@@ -587,7 +613,8 @@ inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> 
         ~Free()
         {
             for (void * p : ptrs)
-                (void)hipFree(p);
+                if (p)
+                    (void)hipFree(p);
         }
     } owned;
     auto take = [&](size_t bytes)
@@ -626,6 +653,13 @@ inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> 
     LXS_HIP(hipGetLastError());
     LXS_HIP(hipMemcpy(ix.entriesForFill(), dEntries, total * sizeof(ReducedIndex::Entry), hipMemcpyDeviceToHost));
     LXS_HIP(hipMemcpy(ix.prefixForFill(), dPre, nPre * 8, hipMemcpyDeviceToHost));
+    if (keep) // the entries and the prefix table stay where they are for the seeding stage
+    {
+        for (void *& p : owned.ptrs)
+            if (p == dEntries || p == dPre)
+                p = nullptr;
+        keep->device = device, keep->entries = dEntries, keep->pre = dPre;
+    }
     return true;
 }
 
