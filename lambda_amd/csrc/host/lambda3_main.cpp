@@ -814,8 +814,20 @@ int main(int argc, char ** argv)
             // host threads; the same table either way
             bool const wantGpu = opt.table == "gpu" || (opt.table == "auto" && !mk);
             if (wantGpu && lx_device_count() > 0)
-                tableOnGpu = lambda_amd::buildTableOnGpu(opt.devices.empty() ? 0 : opt.devices[0], ix, dbRed, db.off, db.len, alph,
-                                                         (!mk && opt.seeding == "gpu") ? &deviceTable : nullptr);
+            {
+                try
+                {
+                    tableOnGpu = lambda_amd::buildTableOnGpu(opt.devices.empty() ? 0 : opt.devices[0], ix, dbRed, db.off, db.len, alph,
+                                                             (!mk && opt.seeding == "gpu") ? &deviceTable : nullptr);
+                }
+                catch (std::exception const & e) // (e.g. the device ran out of memory after all: the host threads make the table)
+                {
+                    if (opt.table == "gpu")
+                        throw;
+                    std::cerr << "WARNING: the word table is made on the host threads (" << e.what() << ")\n";
+                    tableOnGpu = false;
+                }
+            }
             else if (opt.table == "gpu")
                 throw std::runtime_error("--table gpu: no HIP device available");
             if (!tableOnGpu)
@@ -912,6 +924,7 @@ int main(int argc, char ** argv)
             lambda_amd::SeedingStats    sst{};
             size_t                      nPromising = 0;
             double                      msSeed = 0, msExtend = 0;
+            bool                        gpuSeeding = false; // the seeding stage of this worker ran on its device
             size_t                      nDeclined = 0, nPassesOnHost = 0; // reads the GPU seeding stage left to the host; passes whose match buffer was full
             std::string                 error;
         };
@@ -935,7 +948,16 @@ int main(int argc, char ** argv)
                 // one pass of the batch loop of realMain (src/search.cpp:426-459): seed, extend (GPU), collect
                 std::unique_ptr<lambda_amd::GpuSeeder> gpuSeeder;
                 if (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix))
-                    gpuSeeder.reset(new lambda_amd::GpuSeeder(devices[w % devices.size()], ix, sin, dbRed, db.off.size(), db.res.size(), qs.res.size(), &deviceTable));
+                    try
+                    {
+                        gpuSeeder.reset(new lambda_amd::GpuSeeder(devices[w % devices.size()], ix, sin, dbRed, db.off.size(), db.res.size(), qs.res.size(), &deviceTable));
+                    }
+                    catch (std::exception const & e) // (the table and the sequences did not fit beside the extension's buffers: host threads)
+                    {
+                        std::cerr << "WARNING: seeding on the host threads (" << e.what() << ")\n";
+                        gpuSeeder.reset();
+                    }
+                pt.gpuSeeding = gpuSeeder != nullptr;
                 auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
                 {
                     std::vector<lx_match> matches;
@@ -1038,6 +1060,7 @@ int main(int argc, char ** argv)
         size_t                      nPromising = 0;
         double                      msSeedMax = 0, msExtendMax = 0;
         size_t                      nDeclined = 0, nPassesOnHost = 0;
+        bool                        anyGpuSeeding = false;
         for (Part & pt : parts)
         {
             if (!pt.error.empty())
@@ -1054,6 +1077,7 @@ int main(int argc, char ** argv)
             sst.hitsAfterSeeding += pt.sst.hitsAfterSeeding, sst.hitsFailedPreExtendTest += pt.sst.hitsFailedPreExtendTest;
             nPromising += pt.nPromising;
             nDeclined += pt.nDeclined, nPassesOnHost += pt.nPassesOnHost;
+            anyGpuSeeding = anyGpuSeeding || pt.gpuSeeding;
             msSeedMax   = std::max(msSeedMax, pt.msSeed);
             msExtendMax = std::max(msExtendMax, pt.msExtend);
         }
@@ -1109,7 +1133,7 @@ int main(int argc, char ** argv)
         std::fprintf(stderr,
                      "lambda3 times [ms]: read %.0f, reduce + word table %s%.0f, search %.0f (seeding on the %s %.0f [%zu read(s) and %zu launch(es) left to "
                      "the host] + extension on the GPU incl. widen / merge / statistics %.0f on the slowest worker), records + output %.0f, total %.0f\n",
-                     msRead, fromIndex ? "(read from the index) " : tableOnGpu ? "(on the GPU) " : "", msIndex, msSearch, (opt.seeding == "gpu" && lambda_amd::GpuSeeder::canTake(ix)) ? "GPU" : "host", msSeedMax, nDeclined,
+                     msRead, fromIndex ? "(read from the index) " : tableOnGpu ? "(on the GPU) " : "", msIndex, msSearch, anyGpuSeeding ? "GPU" : "host", msSeedMax, nDeclined,
                      nPassesOnHost, msExtendMax, msSince(tOut), msSince(tStart));
         return 0;
     }
