@@ -2,7 +2,7 @@
 // section 8f rows N2/N3): plumbing for BASELINE.json configs[0], not a port of the reference's driver.
 //
 //   lambda3 searchp -q queries.fasta -d db.fasta -o out.m8 [-e 1e-2] [-n 25] [--seed-length 10] [--seed-offset 5]
-//                   [--devices 0,1,...] [-t THREADS]
+//                   [--devices 0,1,...] [-t THREADS] [--table gpu|host|auto] [--seeding gpu|host]
 //
 // What it mirrors from the reference, and what it does not:
 //   * subcommand split and the search command line (src/lambda.cpp:30-118; src/search_options.hpp:143-816): -q, -o (format from
