@@ -29,6 +29,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -72,7 +73,7 @@ def parse(argv=None):
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
                     "level 1/2): PCIe and the host's share included, subjects resident (lx_set_subjects); a secondary line, never `value` of the headline")
-    ap.add_argument("--entry", choices=("bytes", "rle", "list"), default="bytes", help="--host-path / --ragged: lx_extend_batch (ops as column bytes, n "
+    ap.add_argument("--entry", choices=("bytes", "rle", "list", "host", "dev"), default="bytes", help="--host-path / --ragged: lx_extend_batch (ops as column bytes, n "
                     "records), lx_extend_batch_rle (run-length codes, n records) or lx_extend_batch_list (the survivors as a list, as the "
                     "reference's filter loop leaves them)")
     ap.add_argument("--survivor-rate", type=float, default=None, help="share of homologous windows in the synthetic batch (default 0.5: "
@@ -86,6 +87,11 @@ def parse(argv=None):
     ap.add_argument("--ragged", action="store_true", help="--host-path on a ragged seed list as lambda really produces them (query lengths "
                     "50-400, windows per query geometric with mean 12, 10 %% merged windows of up to 3 Lq): GCUPS and the padded share")
     ap.add_argument("--ragged-queries", type=int, default=50_000)
+    ap.add_argument("--iterate", action="store_true", help="time lx_iterate_matches_dev -- the whole of iterateMatchesFullSimd on a DEVICE match "
+                    "list (widen, sort, merge, unique, both passes, records) -- on a synthetic seed list of configs[2]'s size; --entry host: "
+                    "lx_iterate_matches on the same list in host memory")
+    ap.add_argument("--iterate-reads", type=int, default=1_000_000)
+    ap.add_argument("--iterate-mbp", type=float, default=100.0)
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
     return ap.parse_args(argv)
 
@@ -181,22 +187,49 @@ def cpu_baseline(w, sample_queries: int, cores: int, note: str = ""):
     }
 
 
+def kernel_instantiation(name: str) -> str:
+    """`lx::score_pair_kernel<8,19,true>` from either spelling of a kernel's name: the library's ("lx::score_pair_kernel<8,19,true>
+    (single sweep)") or rocprofv3's ("void lx::score_pair_kernel<8, 19, true>(lx::ScoreParams)").  The template arguments are part
+    of the identity: `<8,19,true>` writes 23 GB of checkpoints per launch, `<8,19>` writes the scores."""
+    s = name.strip()
+    if s.startswith("void "):
+        s = s[5:]
+    m = re.match(r"([A-Za-z_][\w:]*)\s*(<[^()]*>)?", s)
+    if not m:
+        return s.replace(" ", "")
+    base = m.group(1)
+    if base.startswith("lx::"):
+        base = base[4:]  # the namespace is not part of what distinguishes two profiles
+    return (base + (m.group(2) or "")).replace(" ", "")
+
+
 def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch of a kernel (kernel_name = substring of its rocprofv3 name) from the committed rocprofv3 PMC
-    passes (profiles/*_pmc.json): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 correction in
-    MI355X_MICROARCH.md.  PMC counters cannot be read from inside a timed run, so this is the figure of the profiled run of
-    the headline command; None if no profile of this kernel instantiation is committed."""
-    try:
-        files = sorted((ROOT / "profiles").glob("*_pmc.json"))
-        for f in reversed(files):
-            for name, d in json.loads(f.read_text())["kernels"].items():
-                c = d.get("counters_per_step_mean", d.get("counters_per_launch_mean", {}))
-                if kernel_name in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                    return ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-                            f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {name} on the headline batch")
-    except Exception:
-        pass
-    return None, "no committed PMC profile for this kernel instantiation"
+    """HBM bytes per launch of ONE kernel instantiation (kernel_name in the library's or rocprofv3's spelling, compared by
+    `kernel_instantiation`: full template argument list, not a substring) from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json, newest name first): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950
+    correction in MI355X_MICROARCH.md.  PMC counters cannot be read from inside a timed run, so this is the figure of the
+    profiled run of the same command.  Returns (bytes or None, note); files of another shape (no "kernels" table) are skipped
+    and a file that cannot be read is NAMED in the note instead of being swallowed."""
+    want = kernel_instantiation(kernel_name)
+    skipped = []
+    for f in sorted((ROOT / "profiles").glob("*_pmc.json"), reverse=True):
+        try:
+            kernels = json.loads(f.read_text()).get("kernels")
+        except Exception as e:  # unreadable / not JSON: say so, go on to the older profiles
+            skipped.append(f"{f.name}: {type(e).__name__}: {e}")
+            continue
+        if not isinstance(kernels, dict):
+            continue  # a profile of something else (e.g. the front end's seeding kernel): no per-kernel table
+        for name, d in kernels.items():
+            if not isinstance(d, dict) or kernel_instantiation(name) != want:
+                continue
+            c = d.get("counters_per_launch_mean") or d.get("counters_per_step_mean") or {}
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
+                        f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {name}"
+                        + (f"; skipped {'; '.join(skipped)}" if skipped else ""))
+    return None, (f"no committed PMC profile holds FETCH_SIZE and WRITE_SIZE of {want}"
+                  + (f"; skipped {'; '.join(skipped)}" if skipped else ""))
 
 
 def issue_ceiling():
@@ -354,6 +387,89 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
         dist.destroy_process_group()
 
 
+def iterate_path(args, world, rank, local_rank, dev, use_dist):
+    """The Level-2 driver as a caller sees it: ONE call = iterateMatchesFullSimd (/root/reference/src/search_algo.hpp:1177-1332) over
+    the seed list of a whole read set -- widen, sort, merge, unique (:1136-1175), pass 1, filter, pass 2, records -- wall clock
+    around K calls, the matches in device memory (`lx_iterate_matches_dev`, the sequence sets resident) or, `--entry host`, in host
+    memory (`lx_iterate_matches`).  Synthetic list of BASELINE configs[2]'s size (lambda_amd/synth.py make_seed_list_np)."""
+    import torch
+    import torch.distributed as dist
+
+    from lambda_amd import capi, synth, workloads
+
+    w = workloads.WORKLOADS[2]
+    d = w.directions[0]
+    h = capi.Handle(local_rank)
+    m_, ma, mi, go, ge = d.scoring
+    h.set_scoring(capi.builtin_scoring(m_, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
+    h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+    ka = capi.karlin_params(*w.karlin)
+    q, qoff, qlen, qorig, s, soff, slen, m = synth.make_seed_list_np(args.iterate_reads, args.iterate_mbp, seed=0x1A3BDA03 + rank)
+    params = capi.SearchParams(w.max_evalue, -1, 0, int(slen.sum()), 0, 2, 1, 0, capi.LX_FRAMES_REVCOMP, capi.LX_FRAMES_NONE, ka)
+    h.set_subjects(s)
+    on_dev = args.entry != "host"
+    if on_dev:
+        h.set_subject_seqs(soff, slen)
+        h.set_queries(q, qoff, qlen, qorig, 2)
+        d_m = torch.from_numpy(m.view(np.uint8).copy()).to(dev)
+        torch.cuda.synchronize()
+    import ctypes as C
+
+    lib = capi.load()
+
+    def timed_call():
+        r = C.c_void_p()
+        if on_dev:
+            t0 = time.perf_counter()
+            h._check(lib.lx_iterate_matches_dev(h.h, 0, d_m.data_ptr(), len(m), C.byref(params), C.byref(r)))
+            return r, time.perf_counter() - t0
+        mm = m.copy()  # (the host entry point works in place, like the reference's span)
+        t0 = time.perf_counter()
+        h._check(lib.lx_iterate_matches(h.h, 0, capi._ptr(q), q.size, capi._ptr(qoff), capi._ptr(qlen), len(qoff), capi._ptr(qorig), None, 0,
+                                        capi._ptr(soff), capi._ptr(slen), len(soff), capi._ptr(mm), len(mm), C.byref(params), C.byref(r)))
+        return r, time.perf_counter() - t0
+
+    stats = None
+    for _ in range(max(args.warmup, 1)):
+        r, _ = timed_call()
+        stats = (int(lib.lx_iterate_result_count(r)), lib.lx_iterate_result_stats(r))
+        lib.lx_iterate_result_free(r)
+    if use_dist:
+        dist.barrier()
+    times = []
+    for _ in range(args.steps):
+        r, dt = timed_call()
+        times.append(dt)
+        lib.lx_iterate_result_free(r)  # (the caller's to free: not part of the call)
+    dt = float(sum(times))
+    n_hsp, st = stats
+    n_win = len(m) - st.hits_duplicate
+    xs = h.last_extend_stats()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ms per call of the Level-2 driver (iterateMatchesFullSimd: widen + sort + merge + unique, pass 1, filter, pass 2, records) on a "
+                      + ("DEVICE match list, lx_iterate_matches_dev" if on_dev else "HOST match list, lx_iterate_matches") + "; searchn scheme of configs[2]",
+            "value": round(dt / args.steps * 1e3, 3), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_min": round(min(times) * 1e3, 3), "ms_max": round(max(times) * 1e3, 3),
+            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f16x2 (exact small integers) + int32 + u64 sort words",
+            "data": "synthetic",
+            "config": {"workload": f"seed list of {args.iterate_reads} reads x {int(qorig[0])} bp (two query frames each) against {args.iterate_mbp:g} Mbp in "
+                                   f"{len(soff)} contigs: {len(m)} matches in the order a seeding kernel's lanes emit them -> {n_win} windows "
+                                   f"({xs[2] / 1e9:.1f} Gcells) -> {st.num_ext_ali} traced -> {n_hsp} HSPs; E <= {w.max_evalue:g}",
+                       "entry_point": "lx_iterate_matches_dev (matches in device memory, sequence sets resident: lx_set_queries / lx_set_subjects / "
+                                      "lx_set_subject_seqs)" if on_dev else "lx_iterate_matches (host buffers, subjects resident)",
+                       "matches": len(m), "windows": int(n_win), "traced": int(st.num_ext_ali), "hsps": n_hsp,
+                       "padding": {"extensions": xs[0], "slots": xs[1], "cells": xs[2], "executed_cells": xs[3]}},
+            "gcups_of_window_cells": round(xs[2] * args.steps / dt / 1e9, 1),
+            "matches_per_s": round(len(m) * args.steps / dt, 1),
+            "roofline": None, "cpu_baseline": None,
+            "note": "secondary line: prices the whole driver call around the kernels of the headline line",
+        }), flush=True)
+    h.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
 class DevBatch:
     """One device call's inputs and outputs, resident in HBM."""
 
@@ -418,6 +534,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
+    if args.iterate:
+        return iterate_path(args, world, rank, local_rank, dev, use_dist)
     if args.host_path or args.ragged:
         return host_path(args, w, pl, world, rank, local_rank, dev, use_dist)
 
@@ -544,7 +662,8 @@ def main():
             checkpoint bytes the kernel additionally writes for pass 2, and the PMC traffic -- is reported next to it."""
             gc = cells / (ms * 1e-3) / 1e9
             tops = gc * ALGO_OPS_PER_CELL / 1e3
-            traffic, note = pmc_traffic(pmc_key)
+            headline = args.config == 1 and args.lq is None and args.windows is None and args.band <= 0
+            traffic, note = pmc_traffic(pmc_key) if headline else (None, "PMC passes are committed for the headline batch only")
             packed = "pair" in kernel or "sweep_mq" in kernel
             peak = PEAK_PACKED16_TOPS if packed else PEAK_INT32_TOPS
             hbm = (algo_bytes + stored_bytes) / (ms * 1e-3) / 1e9
@@ -560,9 +679,9 @@ def main():
                 "hbm": {"bound": "hbm", "achieved": round(hbm, 2), "peak": 8000, "unit": "GB/s", "frac": round(hbm / 8000, 4),
                         "algorithmic_bytes_per_launch": algo_bytes, "checkpoint_bytes_written_per_launch": stored_bytes,
                         "write_amplification": round((algo_bytes + stored_bytes) / algo_bytes, 2)},
-                "traffic": traffic if (args.config == 1 and args.lq is None and args.windows is None) else None,
-                "traffic_note": note if (args.config == 1 and args.lq is None and args.windows is None)
-                                else "PMC passes are committed for the headline batch only",
+                "traffic": traffic,
+                "traffic_over_algorithmic": round(traffic / algo_bytes, 2) if traffic else None,
+                "traffic_note": note,
             }
 
         # algorithmic bytes of pass 1: every window once, every query once per run, one 24-byte
@@ -576,18 +695,17 @@ def main():
             pair_bytes = 2 if "score_pair_kernel" in kernel_name else 4
             strip = 13 if "<16,13" in kernel_name else 19
             stored = last.n * (ls * (-(-lq // strip)) * pair_bytes + (ls / 16.0) * lq * pair_bytes + 16)
-        r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], last.cells,
-                           "score_pair_kernel" if "score_pair_kernel" in kernel_name else "score_kernel", algo_bytes, stored)
+        r_score = roofline(kernel_name, phase_ms[0][0], phase_ms[0][1], last.cells, kernel_name, algo_bytes, stored)
         rooflines = [r_score]
         if not args.pass1_only and phase_ms[2][0] > 0:
             cells2 = float(survivors_last) * lq * ls
             if "ckpt" in trace_kernel_name:
                 strips = -(-lq // 19)
                 stored2 = survivors_last * (ls * strips * 4 + (ls / 16.0) * lq * 4)
-                pmc_key = "ckpt_forward_kernel"
+                pmc_key = trace_kernel_name
             else:
                 stored2 = survivors_last * lq * ls / 2.0  # 4 direction bits per cell
-                pmc_key = "trace_forward_kernel"
+                pmc_key = trace_kernel_name
             algo2 = survivors_last * (ls + lq / 4.0 + ALGO_BYTES_PER_EXT_EXTRA + 4)
             rooflines.append(roofline(trace_kernel_name, phase_ms[2][0], phase_ms[2][1], cells2, pmc_key, algo2, stored2))
         rooflines.sort(key=lambda r: -r["kernel_ms_per_launch"])

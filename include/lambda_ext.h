@@ -445,6 +445,29 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
                        uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
                        uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
                        lx_iterate_result ** out);
+
+/* The same for matches that stand in DEVICE memory -- where a seeding stage on the GPU leaves them -- over sequence sets that are
+ * resident on the handle's device: _widenMatch (src/search_algo.hpp:919-938), the sort, both merge passes and unique of
+ * _widenAndPreprocessMatches (:1136-1175), the slices (:1200-1227) and the filter's cut-offs (:1251-1283) run as kernels; only the
+ * finished window list (24 bytes per window) comes down for the plan of the sweep, the extension reads list and cut-offs where the
+ * kernels wrote them.  Results are lx_iterate_matches' (same order, same records, same statistics).
+ *   lx_set_queries       the (frame-expanded) query set: residues, where each sequence lies, q_orig_len[n_qseq / qry_num_frames]
+ *                        (NULL: the sequences' own lengths) -- what lH.transQrySeqs / qrySeqs are to the reference's thread;
+ *                        replaces the previous set; nothing of the caller's is referenced after the call returns
+ *   lx_set_subjects      the subject residues (above), lx_set_subject_seqs where each (frame) subject lies in them
+ *   d_matches            n_matches lx_match records in device memory of the handle's device, finished before the call (the call
+ *                        runs on the handle's stream); not modified
+ * params->qry_num_frames must be the value the queries were set with; params->band is not served here (lx_iterate_matches).
+ * LX_EINVAL: a match names a sequence outside the sets or lies beyond its subject's end. */
+int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off, uint64_t const * q_seq_len, uint64_t n_qseq,
+                   uint64_t const * q_orig_len, int32_t qry_num_frames);
+int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t const * s_seq_len, uint64_t n_sseq);
+int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint64_t n_matches, lx_search_params const * params,
+                           lx_iterate_result ** out);
+/* _widenAndPreprocessMatches (:1136-1175) alone on a device match list over the resident sets: the window list comes back as
+ * lx_match records in `out` (room for n_matches), *out_n of them -- what lx_widen_and_preprocess leaves in its span.  bisulfite != 0:
+ * ordered by subjId % 2 first, as iterateMatches' bisulfite branch sorts (:1369-1372). */
+int lx_widen_and_preprocess_dev(lx_handle * h, void const * d_matches, uint64_t n_matches, int32_t bisulfite, lx_match * out, uint64_t * out_n);
 uint64_t               lx_iterate_result_count(lx_iterate_result const * r);
 lx_blast_match const * lx_iterate_result_matches(lx_iterate_result const * r);
 uint8_t const *        lx_iterate_result_ops(lx_iterate_result const * r);

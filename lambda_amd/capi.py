@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_set_band_centres", "lx_set_band_centres_dev",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
-    "lx_iterate_matches",
+    "lx_iterate_matches", "lx_set_queries", "lx_set_subject_seqs", "lx_iterate_matches_dev", "lx_widen_and_preprocess_dev",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
@@ -188,6 +188,10 @@ def load():
     lib.lx_widen_and_preprocess.restype = u64
     lib.lx_iterate_matches.argtypes = [vp, i32, vp, u64, vp, vp, u64, vp, vp, u64, vp, vp, u64, vp, u64,
                                        C.POINTER(SearchParams), C.POINTER(vp)]
+    lib.lx_set_queries.argtypes = [vp, vp, u64, vp, vp, u64, vp, i32]
+    lib.lx_set_subject_seqs.argtypes = [vp, vp, vp, u64]
+    lib.lx_iterate_matches_dev.argtypes = [vp, i32, vp, u64, C.POINTER(SearchParams), C.POINTER(vp)]
+    lib.lx_widen_and_preprocess_dev.argtypes = [vp, vp, u64, i32, vp, C.POINTER(u64)]
     lib.lx_iterate_result_count.argtypes = [vp]
     lib.lx_iterate_result_count.restype = u64
     lib.lx_iterate_result_matches.argtypes = [vp]
@@ -565,6 +569,36 @@ class Handle:
         self._check(self.lib.lx_iterate_matches(self.h, slot, _ptr(q_res), q_res.size, _ptr(q_off), _ptr(q_len), len(q_off),
                                                 _ptr(q_orig), _sptr(s_res), _ssize(s_res), _ptr(s_off), _ptr(s_len),
                                                 len(s_off), _ptr(m), len(m), C.byref(params), C.byref(res)))
+        return self._take_iterate_result(res)
+
+    def set_queries(self, q_res, q_off, q_len, q_orig_len=None, qry_num_frames: int = 1):
+        """lx_set_queries: the (frame-expanded) query set becomes resident on the device (for iterate_matches_dev)."""
+        q_res = np.ascontiguousarray(q_res, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.uint64)
+        q_orig = None if q_orig_len is None else np.ascontiguousarray(q_orig_len, dtype=np.uint64)
+        self._check(self.lib.lx_set_queries(self.h, _ptr(q_res), q_res.size, _ptr(q_off), _ptr(q_len), len(q_off),
+                                            None if q_orig is None else _ptr(q_orig), qry_num_frames))
+
+    def set_subject_seqs(self, s_off, s_len):
+        s_off = np.ascontiguousarray(s_off, dtype=np.uint64)
+        s_len = np.ascontiguousarray(s_len, dtype=np.uint64)
+        self._check(self.lib.lx_set_subject_seqs(self.h, _ptr(s_off), _ptr(s_len), len(s_off)))
+
+    def iterate_matches_dev(self, d_matches, n: int, params: "SearchParams", slot: int = 0):
+        """lx_iterate_matches_dev on a device tensor holding n lx_match records (48 bytes each); results as iterate_matches."""
+        res = C.c_void_p()
+        self._check(self.lib.lx_iterate_matches_dev(self.h, slot, d_matches.data_ptr() if n else None, n, C.byref(params), C.byref(res)))
+        return self._take_iterate_result(res)
+
+    def widen_and_preprocess_dev(self, d_matches, n: int, bisulfite: bool = False):
+        """lx_widen_and_preprocess_dev: the window list of a device match list (n lx_match records) as a MATCH_DTYPE array."""
+        out = np.zeros(max(n, 1), dtype=MATCH_DTYPE)
+        cnt = C.c_uint64(0)
+        self._check(self.lib.lx_widen_and_preprocess_dev(self.h, d_matches.data_ptr() if n else None, n, 1 if bisulfite else 0, _ptr(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
+
+    def _take_iterate_result(self, res):
         try:
             n = int(self.lib.lx_iterate_result_count(res))
             stats = self.lib.lx_iterate_result_stats(res)

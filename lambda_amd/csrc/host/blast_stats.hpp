@@ -146,14 +146,20 @@ struct EValueContext
     uint64_t                               dbTotalLength;
     bool                                   queryTranslated;
     std::unordered_map<uint64_t, uint64_t> cachedLengthAdjustments;
+    uint64_t                               lastLength = ~0ull, lastAdjustment = 0; // (lists come grouped by query: the previous answer is usually the next)
 
     double operator()(int32_t score, uint64_t ql)
     {
-        ql      = ql / (queryTranslated ? 3 : 1);
-        auto it = cachedLengthAdjustments.find(ql);
-        if (it == cachedLengthAdjustments.end())
-            it = cachedLengthAdjustments.emplace(ql, lengthAdjustment(dbTotalLength, ql, ka)).first;
-        uint64_t const adj = it->second;
+        ql = ql / (queryTranslated ? 3 : 1);
+        if (ql != lastLength)
+        {
+            auto it = cachedLengthAdjustments.find(ql);
+            if (it == cachedLengthAdjustments.end())
+                it = cachedLengthAdjustments.emplace(ql, lengthAdjustment(dbTotalLength, ql, ka)).first;
+            lastLength     = ql;
+            lastAdjustment = it->second;
+        }
+        uint64_t const adj = lastAdjustment;
         return computeEValue(score, ql - adj, dbTotalLength - adj, ka);
     }
 };

@@ -958,19 +958,45 @@ int main(int argc, char ** argv)
                         gpuSeeder.reset();
                     }
                 pt.gpuSeeding = gpuSeeder != nullptr;
+                // with the seeding on the device its matches stay there: the sequence sets become resident for the Level-2 kernels
+                // (LAMBDA3_HOST_LIST=1: the matches come down and go through lx_iterate_matches, the A/B switch of the tests)
+                bool const deviceList = gpuSeeder && !std::getenv("LAMBDA3_HOST_LIST");
+                if (deviceList)
+                {
+                    eng.check(lx_set_subject_seqs(eng.raw(), db.off.data(), db.len.data(), db.off.size()));
+                    eng.check(lx_set_queries(eng.raw(), qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(), qs.orig_len.data(), qFrames));
+                }
                 auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
                 {
                     std::vector<lx_match> matches;
                     if (std::getenv("LAMBDA3_TRACE"))
                         std::fprintf(stderr, "[worker %zu] seeding %zu frame sequences (seed %d/%d, delta %d)\n", w, which.size(), so.seedLength, so.seedOffset, so.maxSeedDist);
                     auto const tSeed = std::chrono::steady_clock::now();
-                    bool onHost = !gpuSeeder;
+                    bool     onHost   = !gpuSeeder;
+                    uint64_t onDevice = 0; // matches the seeding kernel left in device memory (a pass of one launch, nothing declined)
                     if (gpuSeeder)
                     {
                         // the device takes the reads; those it declines (words far beyond the table's keys with many occurrences) and
                         // those of a launch whose match buffer filled up are seeded here
-                        std::vector<uint64_t> declined;
-                        pt.nPassesOnHost += gpuSeeder->seed(so, which, matches, pt.sst, declined);
+                        std::vector<uint64_t>          declined;
+                        lambda_amd::SeedingStats const sstBefore = pt.sst;
+                        try
+                        {
+                            pt.nPassesOnHost += gpuSeeder->seed(so, which, matches, pt.sst, declined, deviceList ? &onDevice : nullptr);
+                        }
+                        catch (std::exception const & e)
+                        {
+                            // a HIP error in the seeding stage (its match buffer did not fit, ...): this pass and the following ones are
+                            // seeded on the host threads, from a clean slate
+                            std::cerr << "WARNING: seeding on the host threads from here on (" << e.what() << ")\n";
+                            gpuSeeder.reset();
+                            pt.gpuSeeding = false;
+                            matches.clear();
+                            declined.clear();
+                            onDevice = 0;
+                            pt.sst   = sstBefore;
+                            onHost   = true;
+                        }
                         if (!declined.empty())
                         {
                             std::sort(declined.begin(), declined.end());
@@ -985,16 +1011,19 @@ int main(int argc, char ** argv)
                     if (onHost)
                         lambda_amd::seedQueriesParallel(ix, sin, so, which, matches, pt.sst, seedThreads);
                     pt.msSeed += msSince(tSeed);
-                    pt.nPromising += matches.size();
+                    pt.nPromising += matches.size() + onDevice;
                     if (std::getenv("LAMBDA3_TRACE"))
-                        std::fprintf(stderr, "[worker %zu] %zu promising seeds -> extension\n", w, matches.size());
-                    if (matches.empty())
+                        std::fprintf(stderr, "[worker %zu] %zu promising seeds -> extension\n", w, matches.size() + (size_t)onDevice);
+                    if (matches.empty() && onDevice == 0)
                         return;
                     lx_iterate_result * res = nullptr;
                     auto const          tExt = std::chrono::steady_clock::now();
-                    eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
-                                                 qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(), db.off.size(), matches.data(),
-                                                 matches.size(), &sp, &res));
+                    if (onDevice) // the Level-2 driver on the list where the seeding kernel left it (include/lambda_ext.h)
+                        eng.check(lx_iterate_matches_dev(eng.raw(), 0, gpuSeeder->devMatches(), onDevice, &sp, &res));
+                    else
+                        eng.check(lx_iterate_matches(eng.raw(), 0, qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(),
+                                                     qs.orig_len.data(), nullptr, 0, db.off.data(), db.len.data(), db.off.size(), matches.data(),
+                                                     matches.size(), &sp, &res));
                     pt.msExtend += msSince(tExt);
                     uint64_t const         n  = lx_iterate_result_count(res);
                     lx_blast_match const * bm = lx_iterate_result_matches(res);

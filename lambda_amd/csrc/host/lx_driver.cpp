@@ -18,14 +18,8 @@
 
 #include "blast_stats.hpp"
 #include "lambda_ext.hpp"
+#include "lx_iterate_common.hpp"
 #include "scoring_tables.hpp"
-
-// the library's host threads (lx_host.cpp): width of the pool, and f(0) ... f(nthreads - 1) run side by side
-namespace lxi
-{
-unsigned pool_width();
-void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
-} // namespace lxi
 
 namespace lambda_amd
 {
@@ -50,23 +44,6 @@ inline void widenMatch(lx_match & m, uint64_t const qLen, uint64_t const sLen)
 inline auto tie(lx_match const & m)
 {
     return std::tie(m.qryId, m.subjId, m.qryStart, m.qryEnd, m.subjStart, m.subjEnd);
-}
-
-// The reference calls iterateMatches per thread on a block of <= 10 queries (src/search_options.hpp:71); a GPU wants the seed
-// lists of thousands of queries per call, and then this function's own loops (a sort of the list, the slices, the records) cost
-// as much as the kernels unless they are spread over the library's host threads (lx_host.cpp's pool).
-inline constexpr uint64_t kParallelFrom = 32768; // list sizes below this stay on the calling thread
-template <typename F>
-inline void parallelRanges(uint64_t n, F && body) // body(thread, lo, hi) over a partition of [0, n)
-{
-    unsigned const nt = n >= kParallelFrom ? std::max(1u, lxi::pool_width()) : 1u;
-    if (nt <= 1)
-    {
-        body(0u, (uint64_t)0, n);
-        return;
-    }
-    uint64_t const step = (n + nt - 1) / nt;
-    lxi::pool_run(nt, [&](unsigned t) { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
 }
 
 // src/search_algo.hpp:1136-1175; returns the new size, *duplicates gets the number removed (hitsDuplicate)
@@ -221,13 +198,6 @@ inline uint64_t widenAndPreprocessMatches(lx_match * m, uint64_t n, uint64_t con
 
 } // namespace lambda_amd
 
-struct lx_iterate_result
-{
-    std::vector<lx_blast_match> matches;
-    std::vector<uint8_t>        ops;
-    lx_iterate_stats            stats{};
-};
-
 extern "C" {
 
 int lx_karlin_params(int scoring_method, int match, int mismatch, int gap_open_lambda, int gap_extend, lx_karlin * out)
@@ -316,7 +286,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
                                   lx_iterate_result * res)
 {
     using namespace lambda_amd;
-    int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
+    int const qFrames = std::max(1, params->qry_num_frames);
     res->stats.num_ext_score += n_matches; // lH.stats.numExtScore (:1187)
     // LX_HOST_TIMING=1: where this function's own time goes (the extension prints its breakdown itself)
     static bool const timing = std::getenv("LX_HOST_TIMING") != nullptr;
@@ -358,38 +328,7 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
     // cut-off per extension -- found with the very double formulas below, hence identical decisions -- and the list
     // stays in match order (sorted by query since widen/merge: one LDS profile per run).  The reference's two stable
     // sorts only fix the order of the survivors, which is restored afterwards: (query, lengths, list position).
-    EValueContext evalue{params->karlin, params->db_total_length, params->query_translated != 0, {}};
-    auto passes = [&](int32_t score, uint64_t qLength)
-    {
-        if (params->min_bitscore >= 0 && computeBitScore(score, params->karlin) < params->min_bitscore)
-            return false;
-        if (params->max_evalue >= 0 && evalue(score, qLength) > params->max_evalue)
-            return false;
-        return true;
-    };
-    std::unordered_map<uint64_t, int32_t> cutOffs; // by query length
-    auto cutOffFor = [&](uint64_t qLength)
-    {
-        auto it = cutOffs.find(qLength);
-        if (it != cutOffs.end())
-            return it->second;
-        int32_t const top = 1 << 30;
-        int32_t       cut = 0x7fffffff;
-        if (passes(0, qLength))
-            cut = 0;
-        else if (passes(top, qLength))
-        {
-            int32_t lo = 0, hi = top; // passes(lo) false, passes(hi) true
-            while (hi - lo > 1)
-            {
-                int32_t const mid = lo + (hi - lo) / 2;
-                (passes(mid, qLength) ? hi : lo) = mid;
-            }
-            cut = hi;
-        }
-        cutOffs.emplace(qLength, cut);
-        return cut;
-    };
+    CutOffs               cutOffFor(params);
     std::vector<int32_t>  minScore(n);
     std::vector<uint64_t> qLengthOf(n);
     // (the cut-off of every query length that occurs, found once on this thread -- the list is grouped by query: one look per
@@ -407,168 +346,78 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
                    [&](unsigned, uint64_t lo, uint64_t hi)
                    {
                        for (uint64_t i = lo; i < hi; ++i)
-                           minScore[i] = cutOffs.find(qLengthOf[i])->second; // (reads only: every length is in the map)
+                           minScore[i] = cutOffFor.byLength.find(qLengthOf[i])->second; // (reads only: every length is in the map)
                    });
     mark("slices+cut-offs");
-    std::vector<int32_t>  scores(n, 0);
-    std::vector<lx_hsp>   hspAll;    // band mode only (n records, column bytes)
-    std::vector<uint64_t> opsOffAll;
-    uint8_t const *       ops      = nullptr;
-    uint64_t              opsBytes = 0;
+    std::vector<int32_t> scores(n, 0);
     // (the survivors arrive as a list -- the form the filter loop leaves behind, :1251-1283 -- with their ops as run-length
-    // codes, the form they cross PCIe in; only the HSPs that pass the identity cut-off are expanded into column bytes below.
+    // codes, the form they cross PCIe in; only the HSPs that pass the identity cut-off are expanded into column bytes.
     // Band mode returns n records and column bytes)
     uint64_t bandNow = 0;
     (void)lx_get_option(h, LX_OPT_BAND, &bandNow);
-    bool const       rle = bandNow == 0;
-    lx_survivor_list list{};
-    int              rc;
-    if (rle)
-        rc = lx_extend_batch_list(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), &list);
-    else
+    auto const window = [&](uint64_t i)
     {
-        hspAll.resize(n);
-        opsOffAll.resize(n);
-        rc = lx_extend_batch(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), hspAll.data(),
-                             opsOffAll.data(), &ops, &opsBytes);
+        lx_match const & m = matches[i];
+        return WindowView{m.qryId, m.subjId, m.qryStart, m.subjStart, ext[i].q_len, ext[i].s_len, qLengthOf[i]};
+    };
+    if (bandNow == 0)
+    {
+        lx_survivor_list list{};
+        int              rc = lx_extend_batch_list(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), &list);
+        if (rc != LX_OK)
+            return rc;
+        mark("extension");
+        rc = finishSurvivors(n, window, scores.data(), [&](uint64_t i) { return minScore[i]; }, list, params, res);
+        mark("statistics+records");
+        if (timing)
+            std::fprintf(stderr, "[lx host ms] iterateMatchesFullSimd (%llu matches):%s\n", (unsigned long long)n_matches, tline.c_str());
+        return rc;
     }
+    // band mode: n records and column bytes from lx_extend_batch; the survivors become a list over them
+    std::vector<lx_hsp>   hspAll(n);
+    std::vector<uint64_t> opsOffAll(n);
+    uint8_t const *       ops      = nullptr;
+    uint64_t              opsBytes = 0;
+    int rc = lx_extend_batch(h, slot, q_res, q_bytes, s_res, s_bytes, ext.data(), n, minScore.data(), 0, scores.data(), hspAll.data(), opsOffAll.data(),
+                             &ops, &opsBytes);
     if (rc != LX_OK)
         return rc;
     mark("extension");
-
-    // the filter's statistics (:1260, :1274) from the scores of pass 1
-    std::vector<uint32_t> surv;   // indices into `matches`
-    std::vector<uint32_t> listAt; // list mode: where match i stands in the survivor list
-    surv.reserve(rle ? list.count : n);
+    std::vector<uint32_t> index;
+    std::vector<lx_hsp>   hsps;
+    std::vector<uint64_t> codesOff;
+    std::vector<uint8_t>  codes;
     for (uint64_t i = 0; i < n; ++i)
-    {
-        if (scores[i] >= minScore[i])
+        if (scores[i] >= minScore[i] && ext[i].q_len != 0 && ext[i].s_len != 0)
         {
-            if (!rle)
-                surv.push_back((uint32_t)i);
+            // (column bytes -> one run-length code per run, the form finishSurvivors expands)
+            lx_hsp const &  a     = hspAll[i];
+            uint8_t const * first = ops + opsOffAll[i] + a.ops_shift;
+            index.push_back((uint32_t)i);
+            codesOff.push_back(codes.size());
+            for (int32_t c = 0; c < a.n_ops;)
+            {
+                int32_t e = c + 1;
+                while (e < a.n_ops && first[e] == first[c] && e - c < 64)
+                    ++e;
+                codes.push_back((uint8_t)(((first[c] == 'D' ? 1 : first[c] == 'I' ? 2 : 0) << 6) | (e - c - 1)));
+                c = e;
+            }
+            hsps.push_back(a);
+            hsps.back().ops_shift = 0;
         }
-        else if (params->min_bitscore >= 0 && computeBitScore(scores[i], params->karlin) < params->min_bitscore)
-            ++res->stats.failed_bitscore;
-        else
-            ++res->stats.failed_evalue;
-    }
-    if (rle)
-    {
-        listAt.assign(n, 0xffffffffu);
-        for (uint64_t k = 0; k < list.count; ++k)
-        {
-            surv.push_back(list.index[k]);
-            listAt[list.index[k]] = (uint32_t)k;
-        }
-    }
-    mark("statistics");
-    if (surv.empty())
-        return LX_OK;
-    res->stats.num_ext_ali += surv.size(); // :1287
-    std::sort(surv.begin(), surv.end(),
-              [&](uint32_t a, uint32_t b)
-              {
-                  return std::make_tuple(matches[a].qryId / qFrames, ext[a].q_len, ext[a].s_len, a) <
-                         std::make_tuple(matches[b].qryId / qFrames, ext[b].q_len, ext[b].s_len, b);
-              });
-
-    // compute the rest of the match properties (:1302-1325).  Two passes over the survivors, each spread over the host threads:
-    // the records (and which of them pass the identity cut-off), then -- the offsets known -- their ops.
-    uint64_t const              ns = surv.size();
-    std::vector<lx_blast_match> recs(ns);
-    std::vector<uint8_t>        keep(ns, 0);
-    parallelRanges(ns,
-                   [&](unsigned, uint64_t lo, uint64_t hi)
-                   {
-                       EValueContext ev = evalue; // (its cache of length adjustments is not shared)
-                       for (uint64_t x = lo; x < hi; ++x)
-                       {
-                           uint32_t const   k = surv[x];
-                           lx_match const & m = matches[k];
-                           lx_hsp const &   a = rle ? list.hsp[listAt[k]] : hspAll[k];
-                           lx_blast_match   bm{};
-                           bm.qry_id  = m.qryId;
-                           bm.subj_id = m.subjId;
-                           bm.n_qid   = m.qryId / qFrames;
-                           bm.n_sid   = m.subjId / sFrames;
-                           {
-                               int32_t qf = 0, sf = 0; // _setFrames, :1223
-                               lx_set_frames(params->q_frame_mode, params->s_frame_mode, m.qryId, m.subjId, &qf, &sf);
-                               bm.q_frame = (int16_t)qf;
-                               bm.s_frame = (int16_t)sf;
-                           }
-                           // _expandAlign: positions relative to the infix become positions in the sequence (:1032-1035)
-                           bm.q_start = m.qryStart + a.q_begin;
-                           bm.q_end   = m.qryStart + a.q_end;
-                           bm.s_start = m.subjStart + a.s_begin;
-                           bm.s_end   = m.subjStart + a.s_end;
-                           bm.score   = a.score;
-                           bm.alignment_length   = a.n_ops;
-                           bm.num_matches        = a.num_matches;
-                           bm.num_mismatches     = a.num_mismatches;
-                           bm.num_positives      = a.num_positives;
-                           bm.num_gap_opens      = a.num_gap_opens;
-                           bm.num_gap_extensions = a.num_gap_extensions;
-                           bm.identity = a.n_ops ? (float)(100.0 * static_cast<float>(a.num_matches) / static_cast<float>(a.n_ops)) : 0.0f;
-                           if (!(bm.identity < params->id_cutoff)) // :1310-1315
-                           {
-                               // the reference keeps the values of the filter where it computed them and computes the others now
-                               // (:1318-1322): the same formulas on the same score either way
-                               bm.bit_score = computeBitScore(a.score, params->karlin);
-                               bm.e_value   = ev(a.score, qLengthOf[k]);
-                               bm.n_ops     = (uint32_t)a.n_ops;
-                               keep[x]      = 1;
-                           }
-                           recs[x] = bm;
-                       }
-                   });
-    uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size();
-    uint64_t       nkeep = 0, nops = 0;
-    for (uint64_t x = 0; x < ns; ++x)
-    {
-        if (!keep[x])
-        {
-            ++res->stats.failed_identity;
-            continue;
-        }
-        recs[x].ops_off = ops0 + nops; // (ops_off of a dropped record stays unused)
-        nops += recs[x].n_ops;
-        ++nkeep;
-    }
-    res->matches.resize(rec0 + nkeep);
-    res->ops.resize(ops0 + nops);
-    {
-        // where the kept records go: their rank among the kept ones (a prefix count per thread share)
-        std::vector<uint64_t> rank(ns);
-        uint64_t              r = 0;
-        for (uint64_t x = 0; x < ns; ++x)
-        {
-            rank[x] = r;
-            r += keep[x];
-        }
-        parallelRanges(ns,
-                       [&](unsigned, uint64_t lo, uint64_t hi)
-                       {
-                           for (uint64_t x = lo; x < hi; ++x)
-                           {
-                               if (!keep[x])
-                                   continue;
-                               uint32_t const         k  = surv[x];
-                               lx_blast_match const & bm = recs[x];
-                               lx_hsp const &         a  = rle ? list.hsp[listAt[k]] : hspAll[k];
-                               uint8_t const * const first = rle ? list.codes + list.codes_off[listAt[k]] : ops + opsOffAll[k] + a.ops_shift;
-                               if (rle)
-                                   (void)lx_expand_ops(first, a.n_ops, res->ops.data() + bm.ops_off);
-                               else
-                                   std::memcpy(res->ops.data() + bm.ops_off, first, (size_t)a.n_ops);
-                               res->matches[rec0 + rank[x]] = bm;
-                           }
-                       });
-    }
-    mark("records");
+    lx_survivor_list list{};
+    list.count       = index.size();
+    list.index       = index.data();
+    list.hsp         = hsps.data();
+    list.codes_off   = codesOff.data();
+    list.codes       = codes.data();
+    list.codes_bytes = codes.size();
+    rc               = finishSurvivors(n, window, scores.data(), [&](uint64_t i) { return minScore[i]; }, list, params, res);
+    mark("statistics+records");
     if (timing)
         std::fprintf(stderr, "[lx host ms] iterateMatchesFullSimd (%llu matches):%s\n", (unsigned long long)n_matches, tline.c_str());
-    return LX_OK;
+    return rc;
 }
 
 extern "C" {

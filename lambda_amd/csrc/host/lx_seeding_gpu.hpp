@@ -503,12 +503,17 @@ public:
     // `which`: frame sequences, all frames of a read adjacent and in order (as seedQueries takes them).  Appends the matches of
     // the reads the device took and lists in `declinedReads` the first frame sequence of every read it left to the host: reads a
     // lane declined, and all reads of a launch whose match buffer filled up (returned: the number of such launches).  The reads go
-    // to the device in launches of at most kLaunchReads (the match buffer holds 64 matches per read of a launch).
+    // to the device in launches of at most kLaunchReads (the match buffer holds 64 matches per read of a launch, as far as the
+    // device's free memory allows).
+    // `onDevice` (optional): a pass that is ONE launch which nothing declined leaves its matches where the kernel wrote them --
+    // devMatches() / *onDevice of them, for lx_iterate_matches_dev -- and appends nothing to `matches`.
     static constexpr uint64_t kLaunchReads = 4u << 20;
     size_t seed(SeedParams const & so, std::vector<uint64_t> const & which, std::vector<lx_match> & matches, SeedingStats & stats,
-                std::vector<uint64_t> & declinedReads)
+                std::vector<uint64_t> & declinedReads, uint64_t * onDevice = nullptr)
     {
         LXS_HIP(hipSetDevice(device_));
+        if (onDevice)
+            *onDevice = 0;
         std::vector<uint64_t> reads;
         for (uint64_t i : which)
             if (i % (uint64_t)d_.qNumFrames == 0)
@@ -517,19 +522,30 @@ public:
         if (char const * forced = std::getenv("LAMBDA3_SEED_LAUNCH")) // (development aid: several launches on a small input)
             launchReads = std::max<uint64_t>(1, std::strtoull(forced, nullptr, 10));
         size_t full = 0;
+        bool const oneLaunch = reads.size() <= launchReads;
         for (uint64_t a = 0; a < reads.size(); a += launchReads)
-            full += seedLaunch(so, reads.data() + a, std::min<uint64_t>(launchReads, reads.size() - a), matches, stats, declinedReads) ? 0 : 1;
+            full += seedLaunch(so, reads.data() + a, std::min<uint64_t>(launchReads, reads.size() - a), matches, stats, declinedReads,
+                               oneLaunch ? onDevice : nullptr) ? 0 : 1;
         return full;
     }
+    lx_match const * devMatches() const { return out_.p; }
 
 private:
     bool seedLaunch(SeedParams const & so, uint64_t const * reads, uint64_t nReads, std::vector<lx_match> & matches, SeedingStats & stats,
-                    std::vector<uint64_t> & declinedReads)
+                    std::vector<uint64_t> & declinedReads, uint64_t * onDevice)
     {
         reads_.upload(reads, nReads);
         declined_.reserve(nReads);
         LXS_HIP(hipMemset(declined_.p, 0, nReads));
         uint64_t cap = std::max<uint64_t>(1u << 20, 64ull * nReads);
+        if (cap > out_.n)
+        {
+            // (no more than half of what the device has left beside the extension's buffers: a launch whose buffer fills up is the
+            // host's, which is slow but right; a failed allocation would end the search)
+            size_t freeB = 0, totalB = 0;
+            LXS_HIP(hipMemGetInfo(&freeB, &totalB));
+            cap = std::max<uint64_t>(out_.n, std::min<uint64_t>(cap, (freeB + out_.n * sizeof(lx_match)) / 2 / sizeof(lx_match)));
+        }
         if (char const * forced = std::getenv("LAMBDA3_SEED_CAP")) // (development aid: a small buffer exercises the "buffer full" path)
             cap = std::max<uint64_t>(1, std::strtoull(forced, nullptr, 10));
         out_.reserve(cap);
@@ -550,6 +566,14 @@ private:
         }
         std::vector<uint8_t> decl(nReads);
         LXS_HIP(hipMemcpy(decl.data(), declined_.p, nReads, hipMemcpyDeviceToHost));
+        if (onDevice && matches.empty() && std::all_of(decl.begin(), decl.end(), [](uint8_t d) { return d == 0; }))
+        {
+            // nothing declined: the matches stay in out_ for the Level-2 kernels
+            *onDevice = cnt[0];
+            stats.hitsAfterSeeding += cnt[1];
+            stats.hitsFailedPreExtendTest += cnt[2];
+            return true;
+        }
         size_t const at = matches.size();
         matches.resize(at + cnt[0]);
         if (cnt[0])

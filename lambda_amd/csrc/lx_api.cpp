@@ -47,6 +47,7 @@ lx::DevAids const & lx::dev_aids()
         a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
         a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
         a.mq_no_narrow      = set("LX_MQ_NO_NARROW");
+        a.mq_no_solo        = set("LX_MQ_NO_SOLO");
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
@@ -558,8 +559,11 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
         // (... and for queries beyond 208 columns a run that is a multiple of 8 but not of 16 has no packed sweep with compact
         // codes of its own: the multi-query one serves it)
         bool const odd8    = run % 8 == 0 && run % 16 != 0 && run != 0;
-        // (run 2 = the free packing: pairs of one query, at most four queries per wavefront -- only this sweep serves it)
-        bool const wanted  = run == 2 ? o.mq >= 1 : o.mq == 2 ? (run != 0 && run % 4 == 0) : o.mq == 1 ? (run == 4 || (odd8 && (!half8_cheap || o.max_qlen > 208))) : false;
+        // (run 2 = the free packing: pairs of one query, at most four queries per wavefront -- only this sweep serves it;
+        // run 1 = the solo packing: no promise, a byte profile per window, where 16 of them fit a wavefront's LDS share: the
+        // alphabets of at most 6 rows -- nucleotides, bisulfite)
+        bool const solo_fits = lx::sweep_mq_lds_bytes(1, sc.alph + 1, -1) <= 20 * 1024;
+        bool const wanted  = run == 1 ? (o.mq >= 1 && solo_fits) : run == 2 ? o.mq >= 1 : o.mq == 2 ? (run != 0 && run % 4 == 0) : o.mq == 1 ? (run == 4 || (odd8 && (!half8_cheap || o.max_qlen > 208))) : false;
         mq = wanted && o.pass2 == 2 && o.f16 && sc.trace_ok && sc.b8_ok && gaps_ok && !o.band;
     }
     if (mq)
@@ -577,7 +581,7 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             half_sweep     = true;
             // lane groups per query: a wavefront's 16 slots hold 16 / 8 / 4 windows of one query, whatever divides the run
             // (1 = the free packing: a lane group's pair shares a query, up to four queries per wavefront in any split)
-            sweep_share    = o.query_run == 2 ? 1 : (o.query_run % 16 == 0 ? 16 : o.query_run % 8 == 0 ? 8 : 4) / 2;
+            sweep_share    = o.query_run == 1 ? -1 : o.query_run == 2 ? 1 : (o.query_run % 16 == 0 ? 16 : o.query_run % 8 == 0 ? 8 : 4) / 2; // (-1: solo)
             sweep          = (o.n + 1) * sweep_stride * 4 <= o.trace_bytes;
             int64_t const worst = (int64_t)o.max_qlen * std::max(smax_entry, 0) + (int64_t)(-sc.gap_extend) * (sweep_steps + G + 2) +
                                   (smax_entry - sc.gap_extend) + 2;
@@ -685,7 +689,7 @@ void lxi::describe_plan(StepPlan const & pl, char * buf, size_t len)
     {
         case kMqSweep:
             snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.panels > 1 ? "true" : "false",
-                     pl.share == 1 ? "free packing: up to " : "", pl.share == 1 ? 4 : 8 / std::max(1, pl.share),
+                     pl.share < 0 ? "solo packing: up to " : pl.share == 1 ? "free packing: up to " : "", pl.share < 0 ? 16 : pl.share == 1 ? 4 : 8 / std::max(1, pl.share),
                      pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
             break;
         case kI16CompactWide:
@@ -793,7 +797,8 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         p.score_out      = static_cast<int32_t *>(d_out_score);
         p.err            = reinterpret_cast<int32_t *>(h->d_ws_top + 1);
         p.nrows          = nrows_sc;
-        p.shared_profile = mq ? std::min(2 * sweep_share, 8) : 64 / lx::trace_cfg_group(sweep_cfg); // every wavefront holds one query (mq: every run)
+        // every wavefront holds one query (mq: every run; the solo packing: every window its own)
+        p.shared_profile = mq ? (sweep_share < 0 ? 1 : std::min(2 * sweep_share, 8)) : 64 / lx::trace_cfg_group(sweep_cfg);
         p.cfg            = sweep_cfg;
         if (half_sweep)
         {
@@ -819,9 +824,14 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.ckpt_stride = sweep_stride;
             sp1.steps_cap   = sweep_steps;
             sp1.ends        = p.ends;
-            sp1.pair_share  = sweep_share;
+            sp1.pair_share  = std::max(sweep_share, 0);
             if (mq)
             {
+                if (sweep_share < 0) // the solo packing: rows for the alphabet's letters and the pad letter, no more
+                {
+                    sp1.solo  = 1;
+                    sp1.nrows = h->sc_host[slot].alphabet_size + 1;
+                }
                 sp1.narrow     = lx::dev_aids().mq_no_narrow ? 0 : 1;
                 sp1.ws         = p.ws;
                 sp1.ws_top     = p.ws_top;
@@ -1124,6 +1134,18 @@ void lx_destroy(lx_handle * h)
     for (DevBuf * b : {&h->d_ext_all, &h->d_min_all, &h->d_score_all})
         if (b->ptr)
             (void)hipFree(b->ptr);
+    {
+        auto & l2 = h->l2;
+        for (DevBuf * b : {&l2.d_qres, &l2.d_qoff, &l2.d_qlen, &l2.d_qband, &l2.d_qevlen, &l2.d_soff, &l2.d_slen, &l2.d_pair[0], &l2.d_pair[1], &l2.d_s0[0],
+                           &l2.d_s0[1], &l2.d_hist, &l2.d_head, &l2.d_tail, &l2.d_tot, &l2.d_win, &l2.d_cut, &l2.d_cnt, &l2.d_up, &l2.d_plan, &l2.d_wf})
+            if (b->ptr)
+                (void)hipFree(b->ptr);
+        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up})
+            if (b->ptr)
+                (void)hipHostFree(b->ptr);
+        if (l2.ev_win)
+            (void)hipEventDestroy(l2.ev_win);
+    }
     for (lx_handle::Pinned * b : {&h->p_all, &h->p_score_all})
         if (b->ptr)
             (void)hipHostFree(b->ptr);
@@ -1275,14 +1297,14 @@ int lx_plan_step(lx_scoring const * sc, uint64_t max_qlen, uint64_t max_slen, ui
     out->may_decline           = pl.may_decline ? 1 : 0;
     out->slot_bytes            = pl.stride * 4;
     int const per_wave         = pl.family == lxi::kInt32Sweep ? 64 / G : 2 * (64 / G); // extensions a wavefront holds
-    int const share_ext        = pl.family == lxi::kMqSweep ? 2 * pl.share : (pl.family == lxi::kHalfSweep && pl.share) ? 2 * pl.share : per_wave;
+    int const share_ext        = pl.family == lxi::kMqSweep ? std::max(1, 2 * pl.share) : (pl.family == lxi::kHalfSweep && pl.share) ? 2 * pl.share : per_wave;
     out->queries_per_wavefront = std::max(1, per_wave / std::max(1, share_ext));
     if (pl.family == lxi::kMqSweep && pl.share == 1)
         out->queries_per_wavefront = 4; // (free packing: up to four, in any split of the eight lane groups)
     int const pair_cfg         = pl.cfg == 1 ? 0 : pl.cfg == 3 ? 1 : pl.cfg == 4 ? 7 : 5;
     switch (pl.family)
     {
-        case lxi::kMqSweep: out->lds_bytes = lx::sweep_mq_lds_bytes(pl.cfg, nrows, pl.share); break;
+        case lxi::kMqSweep: out->lds_bytes = lx::sweep_mq_lds_bytes(pl.cfg, pl.share < 0 ? sc->alphabet_size + 1 : nrows, pl.share); break;
         case lxi::kInt32Sweep: out->lds_bytes = (uint64_t)out->queries_per_wavefront * nrows * ((C + 3) / 4 * G) * 4 + 64 * 4 * 4; break;
         default: out->lds_bytes = (uint64_t)out->queries_per_wavefront * lx::score_pair_profile_bytes(pair_cfg, nrows) + 64 * 8 * 4; break;
     }

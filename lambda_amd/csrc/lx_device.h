@@ -77,6 +77,7 @@ struct ScoreParams
     int32_t            fixup;          // 1: only extensions whose out_score is the sentinel -1 are (re)computed
     int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
     int32_t            narrow;         // multi-query sweep: 1 = a query's last panel may run narrower strips (kEndNarrowShift)
+    int32_t            solo;           // multi-query sweep: 1 = every window has a profile of its own (16 per wavefront: the small alphabets)
     // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
     // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
     uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)

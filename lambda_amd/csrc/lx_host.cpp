@@ -704,8 +704,11 @@ int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
 
 static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                            lx_extension const * ext, uint64_t n, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
-                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, int mode)
+                           lx_hsp * out_hsp, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes, int mode,
+                           lxi::ResidentInput const * ri = nullptr)
 {
+    // ri (lx_level2_host.cpp): the query residues and the caller's list + cut-offs stand on the device already (q_res is NULL, q_bytes the
+    // resident size; `ext` / `min_score` are the host's copies of the same list, for the plan)
     // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
@@ -719,6 +722,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     s_bytes = sref.bytes;
     HostMarks hm(as_list ? "lx_extend_batch_list" : want_rle ? "lx_extend_batch_rle" : "lx_extend_batch");
 
+    // A plan that was made on the device (lx_level2_host.cpp: the solo packing of a resident window list -- a sort by width and
+    // length, 16 windows to a wavefront): nothing of the list is looked at here, `ext` may be NULL.
+    bool const preplanned = ri && ri->d_plan;
     // ---- validate; is the list grouped by query (lambda's lists are sorted by query)?  The loops over the list are spread
     // over a few host threads: at millions of extensions per call they would otherwise cost more than the kernels.
     unsigned const nthreads = host_threads(n);
@@ -732,9 +738,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // is the identity and the runs begin where the slice changes)
     std::vector<uint32_t> & idx    = h->xb_idx;
     std::vector<uint8_t> &  newrun = h->xb_newrun;
-    idx.resize(n);
-    newrun.resize(n + 1);
-    parallel_ranges(n, nthreads,
+    if (!preplanned)
+    {
+        idx.resize(n);
+        newrun.resize(n + 1);
+    }
+    parallel_ranges(preplanned ? 0 : n, nthreads,
                     [&](unsigned t, uint64_t lo, uint64_t hi)
                     {
                         Part     pt;           // (a local: the per-thread slots share cache lines)
@@ -781,11 +790,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         live += pt.live;
         monotone = monotone && pt.monotone;
     }
+    if (preplanned)
+        live = n;
     if (live == 0)
         return LX_OK;
     hm.mark("scan");
-    bool const as_given = live == n && monotone;
-    idx.resize(live);
+    bool const as_given = (live == n && monotone) || preplanned;
+    if (!preplanned)
+        idx.resize(live);
     if (!as_given)
     {
         std::vector<uint64_t> first(nthreads + 1, 0);
@@ -809,7 +821,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                   });
     auto same_slice = [&](uint32_t a, uint32_t b) { return ext[a].q_off == ext[b].q_off && ext[a].q_len == ext[b].q_len; };
     // where the runs of one query slice begin in the ordered list
-    newrun.resize(live + 1);
+    if (!preplanned)
+        newrun.resize(live + 1);
     if (!as_given)
         parallel_ranges(live, nthreads,
                         [&](unsigned, uint64_t lo, uint64_t hi)
@@ -817,7 +830,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             for (uint64_t k = lo; k < hi; ++k)
                                 newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                         });
-    newrun[live] = 1;
+    if (!preplanned)
+        newrun[live] = 1;
     hm.mark("order");
     // positions where the runs of one query slice begin, + the sentinel `live` (two parallel passes over newrun)
     std::vector<uint64_t> & starts = h->xb_starts;
@@ -855,6 +869,18 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         use_mq = h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap &&
                  sh.gap_open <= sh.gap_extend && !lx::dev_aids().extend_no_mq;
     }
+    // The SOLO packing of that sweep (lx_sweep_mq.hip, LX_OPT_QUERY_RUN = 1): a byte profile per window, 16 windows of any queries
+    // per wavefront -- where 16 profiles fit a wavefront's share of the LDS, i.e. the alphabets of at most six rows (nucleotides,
+    // bisulfite).  A read set's seed list has one or two windows per read: at four queries per wavefront three slots in four
+    // were fillers (configs[2]-sized list: 4.1 M slots for 1.25 M windows).  The plan is then a sort: all windows by (columns per
+    // lane, length), longest first, 16 to a wavefront.
+    bool const use_solo = preplanned || (use_mq && !lx::dev_aids().mq_no_solo && lx::sweep_mq_lds_bytes(1, h->sc_host[slot].alphabet_size + 1, -1) <= 20 * 1024);
+    if (preplanned)
+    {
+        if (!use_mq || !as_list)
+            return fail(h, LX_ESTATE, "a device plan needs the multi-query sweep and the list form");
+    }
+    else
     // Mixed query lengths (a real seed list; the synthetic batches have one): a chunk runs the kernel geometry of its longest
     // query, so runs are dealt to geometry classes first -- one panel of 152 columns, one of 208, two / three / ... panels of
     // 152 -- and every class goes through the pipeline by itself.  Inside a run the windows are ordered by length (merged
@@ -939,7 +965,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                             });
         }
-        if (ragged_s && !no_sort)
+        if (ragged_s && !no_sort && !(use_mq && use_solo)) // (the solo plan sorts all windows itself)
         {
             run_starts(starts);
             parallel_ranges(starts.size() - 1, nthreads,
@@ -1012,7 +1038,16 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             order.swap(tmp);
         }
     };
-    if (use_mq)
+    if (use_mq && preplanned)
+    {
+        mq_cfg         = ri->mq_cfg;
+        h->mq_cfg_call = mq_cfg;
+        mq_cells       = ri->cells;
+        nwf = pool_wf  = ri->nwf;
+        wf_pan.assign(ri->wf_pan, ri->wf_pan + nwf);
+        wf_maxs.assign(ri->wf_maxs, ri->wf_maxs + nwf);
+    }
+    else if (use_mq)
     {
         if (starts.empty())
             run_starts(starts);
@@ -1026,7 +1061,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 double c[3] = {0, 0, 0};
                                 for (uint64_t r = rlo; r < rhi; ++r)
                                 {
-                                    uint64_t const lq = ext[idx[starts[r]]].q_len, nw = (starts[r + 1] - starts[r] + 1) / 2 * 2;
+                                    uint64_t const lq = ext[idx[starts[r]]].q_len, nw = use_solo ? starts[r + 1] - starts[r] : (starts[r + 1] - starts[r] + 1) / 2 * 2;
                                     for (int k = 0; k < 3; ++k)
                                     {
                                         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]), P = std::max<uint64_t>(1, (lq + panel - 1) / panel);
@@ -1061,6 +1096,108 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             }
         }
         h->mq_cfg_call = mq_cfg;
+        if (use_solo)
+        {
+            // keys: most columns per lane first, longest window first inside a width (28 bits); a stable LSD radix sort over the
+            // host threads (10 bits per pass: per-thread counts of a contiguous share, one scan, one scatter)
+            std::vector<uint32_t> & key = h->xb_sbkey, & ord = h->xb_sborder, & tmp = h->xb_sbtmp;
+            key.resize(live);
+            ord.resize(live);
+            tmp.resize(live);
+            std::vector<uint64_t> tcells_plan(nthreads, 0);
+            std::vector<uint32_t> tor(nthreads, 0), tand(nthreads, ~0u);
+            parallel_ranges(live, nthreads,
+                            [&](unsigned t, uint64_t lo, uint64_t hi)
+                            {
+                                uint64_t cells_t = 0;
+                                uint32_t o = 0, a = ~0u;
+                                for (uint64_t k = lo; k < hi; ++k)
+                                {
+                                    lx_extension const & x = ext[idx[k]];
+                                    cells_t += (uint64_t)x.q_len * x.s_len;
+                                    uint32_t const kk = ((0xfffu - mq_panels(x.q_len)) << 16) | (0xffffu - std::min<uint32_t>(x.s_len, 0xffffu));
+                                    key[k] = kk;
+                                    ord[k] = (uint32_t)k;
+                                    o |= kk;
+                                    a &= kk;
+                                }
+                                tcells_plan[t] = cells_t;
+                                tor[t]         = o;
+                                tand[t]        = a;
+                            });
+            mq_cells = 0;
+            uint32_t varying = 0; // bits in which the keys differ
+            {
+                uint32_t o = 0, a = ~0u;
+                for (unsigned t = 0; t < nthreads; ++t)
+                {
+                    mq_cells += tcells_plan[t];
+                    o |= tor[t];
+                    a &= tand[t];
+                }
+                varying = o & ~a;
+            }
+            std::vector<uint32_t> cnt((size_t)nthreads * 1024);
+            for (int shift = 0; shift < 30; shift += 10)
+            {
+                if (!((varying >> shift) & 1023u))
+                    continue;
+                parallel_ranges(live, nthreads,
+                                [&](unsigned t, uint64_t lo, uint64_t hi)
+                                {
+                                    uint32_t * const c = cnt.data() + (size_t)t * 1024;
+                                    std::fill(c, c + 1024, 0u);
+                                    for (uint64_t k = lo; k < hi; ++k)
+                                        ++c[(key[ord[k]] >> shift) & 1023u];
+                                });
+                uint32_t at = 0;
+                for (int b = 0; b < 1024; ++b)
+                    for (unsigned t = 0; t < nthreads; ++t)
+                    {
+                        uint32_t const c          = cnt[(size_t)t * 1024 + b];
+                        cnt[(size_t)t * 1024 + b] = at;
+                        at += c;
+                    }
+                parallel_ranges(live, nthreads,
+                                [&](unsigned t, uint64_t lo, uint64_t hi)
+                                {
+                                    uint32_t * const c = cnt.data() + (size_t)t * 1024;
+                                    for (uint64_t k = lo; k < hi; ++k)
+                                        tmp[c[(key[ord[k]] >> shift) & 1023u]++] = ord[k];
+                                });
+                ord.swap(tmp);
+            }
+            nwf     = (live + kWave - 1) / kWave;
+            pool_wf = nwf;
+            if (plan_slot.size() < nwf * kWave)
+                plan_slot.resize(nwf * kWave);
+            if (wf_pan.size() < nwf)
+            {
+                wf_pan.resize(nwf);
+                wf_maxs.resize(nwf);
+            }
+            parallel_ranges(nwf, nthreads,
+                            [&](unsigned, uint64_t wlo, uint64_t whi)
+                            {
+                                for (uint64_t w = wlo; w < whi; ++w)
+                                {
+                                    uint32_t pan = 0, maxs = 0;
+                                    for (uint64_t j = 0; j < kWave; ++j)
+                                    {
+                                        uint64_t const o = w * kWave + j;
+                                        uint32_t const i = idx[ord[std::min(o, live - 1)]]; // (the last wavefront repeats the last window as filler)
+                                        plan_slot[o]     = i | (o < live ? 0u : 0x80000000u);
+                                        pan              = std::max(pan, mq_panels(ext[i].q_len));
+                                        maxs             = std::max(maxs, ext[i].s_len);
+                                    }
+                                    wf_pan[w]  = pan;
+                                    wf_maxs[w] = maxs;
+                                }
+                            });
+            hm.mark("solo plan");
+        }
+        else
+        {
         // (1) per run: where its pool begins (the long windows + what fills their last sub-block up), its sub-blocks, its cells
         pool_at.assign(nruns, 0);
         std::vector<uint64_t> sb_off(nruns + 1, 0), tcells_plan(nthreads, 0);
@@ -1159,6 +1296,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                             }
                         });
         hm.mark("pool");
+        } // (!use_solo)
     }
     // (2) the streamed part: runs in order of (panels, ordinary window length), most panels and longest first
     auto plan_stream = [&]()
@@ -1262,10 +1400,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
     } const guard{h, h->opt_max_qlen, h->opt_max_slen, h->opt_query_run};
 
-    if ((rc = ensure(h, h->d_q, q_bytes + kSlack)))
-        return rc;
-    if (q_bytes)
-        LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    if (!ri)
+    {
+        if ((rc = ensure(h, h->d_q, q_bytes + kSlack)))
+            return rc;
+        if (q_bytes)
+            LX_HIP(h, hipMemcpyAsync(h->d_q.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
+    }
+    void const * const d_qptr = ri ? ri->d_q : h->d_q.ptr;
     if (sref.upload)
         LX_HIP(h, hipMemcpyAsync(sref.dev, s_res, s_bytes, hipMemcpyHostToDevice, h->stream));
     // (measured in round 3 and removed again: two chunks' kernels side by side on two streams -- ragged list 28.5 against 24.4 ms,
@@ -1319,7 +1461,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
         fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
         hipStream_t const ke = ks;
-        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
+        if ((rc2 = fused_impl(h, slot, d_qptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr,
                               nullptr, d_cnt, ks, 3, true, &fx)))
             return rc2;
         // the device's error word of THIS chunk, saved in stream order (the next chunk's prepare_workspace clears it): it comes
@@ -1456,7 +1598,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         pr.slots   = slots;
         pr.cap_sel = (slots + 7) / 8 * 8 + 8;
         int rc2;
-        if ((rc2 = ensure_pinned(h, ln.p_orig, slots * sizeof(uint32_t))))
+        if (!preplanned && (rc2 = ensure_pinned(h, ln.p_orig, slots * sizeof(uint32_t))))
             return rc2;
         uint32_t * const slot_orig = static_cast<uint32_t *>(ln.p_orig.ptr);
         uint64_t const   panel     = (uint64_t)lx::trace_cfg_panel(mq_cfg);
@@ -1467,7 +1609,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                         [&](unsigned t, uint64_t wlo, uint64_t whi)
                         {
                             uint64_t padded = 0, smax = 1, pmax = 1; // (locals: the per-thread slots share cache lines)
-                            std::memcpy(slot_orig + wlo * kWave, plan_slot.data() + (w0 + wlo) * kWave, (whi - wlo) * kWave * sizeof(uint32_t));
+                            if (!preplanned)
+                                std::memcpy(slot_orig + wlo * kWave, plan_slot.data() + (w0 + wlo) * kWave, (whi - wlo) * kWave * sizeof(uint32_t));
                             for (uint64_t w = w0 + wlo; w < w0 + whi; ++w)
                             {
                                 padded += kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7);
@@ -1492,22 +1635,28 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
 
         auto const t1 = now();
         uint64_t const stride = (max_q + max_s + 3) & ~3ull; // one ops slot per position of the survivor list
-        if ((rc2 = ensure(h, ln.d_orig, slots * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) ||
+        if ((!preplanned && (rc2 = ensure(h, ln.d_orig, slots * sizeof(uint32_t)))) || (rc2 = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) ||
             (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) ||
             (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) || (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) ||
             (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) ||
             (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
             (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
             return rc2;
-        LX_HIP(h, hipMemcpyAsync(ln.d_orig.ptr, slot_orig, slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
-        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
-        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
-        LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(h->d_ext_all.ptr), min_score ? static_cast<int32_t const *>(h->d_min_all.ptr) : nullptr,
-                                         min_score_all, static_cast<uint32_t const *>(ln.d_orig.ptr), slots, static_cast<lx::Extension *>(ln.d_ext.ptr),
+        // (a device plan: the chunk's slots are a piece of it)
+        uint32_t const * const d_orig = preplanned ? ri->d_plan + w0 * kWave : static_cast<uint32_t const *>(ln.d_orig.ptr);
+        if (!preplanned)
+        {
+            LX_HIP(h, hipMemcpyAsync(ln.d_orig.ptr, slot_orig, slots * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
+            LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+            LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+        }
+        LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(ri ? ri->d_ext_all : h->d_ext_all.ptr),
+                                         (min_score || (ri && ri->d_min_all)) ? static_cast<int32_t const *>(ri ? ri->d_min_all : h->d_min_all.ptr) : nullptr,
+                                         min_score_all, d_orig, slots, static_cast<lx::Extension *>(ln.d_ext.ptr),
                                          static_cast<int32_t *>(ln.d_min.ptr), h->stream));
         h->opt_max_qlen  = max_q;
         h->opt_max_slen  = max_s;
-        h->opt_query_run = 2; // (the free packing: pairs of one query, at most four queries per wavefront)
+        h->opt_query_run = use_solo ? 1 : 2; // (the solo packing: no promise; the free packing: pairs of one query, at most four queries per wavefront)
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
         fx.ops_stride = stride;
@@ -1516,10 +1665,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         fx.rle_cap    = pr.cap_sel * stride;
         fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
         fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
-        if ((rc2 = fused_impl(h, slot, h->d_q.ptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr,
+        if ((rc2 = fused_impl(h, slot, d_qptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr,
                               d_cnt, h->stream, 3, true, &fx)))
             return rc2;
-        LX_HIP(h, lx::launch_slot_scatter(static_cast<uint32_t const *>(ln.d_orig.ptr), slots, static_cast<int32_t const *>(ln.d_score.ptr),
+        LX_HIP(h, lx::launch_slot_scatter(d_orig, slots, static_cast<int32_t const *>(ln.d_score.ptr),
                                           static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
         LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // this chunk's error word
         LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
@@ -1864,25 +2013,29 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             auto const tu0 = now();
             uint64_t const ext_bytes = n * sizeof(lx_extension), min_bytes = min_score ? n * sizeof(int32_t) : 0;
-            if ((rc = ensure_pinned(h, h->p_all, ext_bytes + min_bytes + 16)) || (rc = ensure(h, h->d_ext_all, ext_bytes + 16)) ||
-                (rc = ensure(h, h->d_min_all, min_bytes + 16)) || (rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) ||
-                (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16)))
+            if ((rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) || (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16)))
                 return rc;
-            uint8_t * const stage_all = static_cast<uint8_t *>(h->p_all.ptr);
-            parallel_ranges(n, nthreads,
-                            [&](unsigned, uint64_t lo, uint64_t hi)
-                            {
-                                std::memcpy(stage_all + lo * sizeof(lx_extension), ext + lo, (hi - lo) * sizeof(lx_extension));
-                                if (min_score)
-                                    std::memcpy(stage_all + ext_bytes + lo * sizeof(int32_t), min_score + lo, (hi - lo) * sizeof(int32_t));
-                            });
-            LX_HIP(h, hipMemcpyAsync(h->d_ext_all.ptr, stage_all, ext_bytes, hipMemcpyHostToDevice, h->stream));
-            if (min_score)
-                LX_HIP(h, hipMemcpyAsync(h->d_min_all.ptr, stage_all + ext_bytes, min_bytes, hipMemcpyHostToDevice, h->stream));
+            if (!ri) // (a resident list stands where the Level-2 kernels wrote it)
+            {
+                if ((rc = ensure_pinned(h, h->p_all, ext_bytes + min_bytes + 16)) || (rc = ensure(h, h->d_ext_all, ext_bytes + 16)) ||
+                    (rc = ensure(h, h->d_min_all, min_bytes + 16)))
+                    return rc;
+                uint8_t * const stage_all = static_cast<uint8_t *>(h->p_all.ptr);
+                parallel_ranges(n, nthreads,
+                                [&](unsigned, uint64_t lo, uint64_t hi)
+                                {
+                                    std::memcpy(stage_all + lo * sizeof(lx_extension), ext + lo, (hi - lo) * sizeof(lx_extension));
+                                    if (min_score)
+                                        std::memcpy(stage_all + ext_bytes + lo * sizeof(int32_t), min_score + lo, (hi - lo) * sizeof(int32_t));
+                                });
+                LX_HIP(h, hipMemcpyAsync(h->d_ext_all.ptr, stage_all, ext_bytes, hipMemcpyHostToDevice, h->stream));
+                if (min_score)
+                    LX_HIP(h, hipMemcpyAsync(h->d_min_all.ptr, stage_all + ext_bytes, min_bytes, hipMemcpyHostToDevice, h->stream));
+            }
             LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
             t_prep += ms(tu0, now());
         }
-        bool     rows_cleared = false, stream_planned = false;
+        bool     rows_cleared = false, stream_planned = use_solo; // (the solo plan is whole before the first chunk)
         uint64_t w0           = 0;
         for (;;)
         {
@@ -2088,6 +2241,41 @@ int lx_extend_batch_list(lx_handle * h, int slot, uint8_t const * q_res, uint64_
     out->codes_bytes = h->res_count ? h->xb_ops_total : 0;
     return LX_OK;
 }
+
+} // extern "C"
+
+// does lx_extend_batch* serve this slot's lists with the solo packing of the multi-query sweep (a byte profile per window)?
+bool lxi::solo_plan_applies(lx_handle const * h, int slot)
+{
+    lx_scoring const & sh = h->sc_host[slot];
+    return h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap && sh.gap_open <= sh.gap_extend &&
+           !lx::dev_aids().extend_no_mq && !lx::dev_aids().mq_no_solo && !h->opt_band && lx::sweep_mq_lds_bytes(1, sh.alphabet_size + 1, -1) <= 20 * 1024;
+}
+
+// lx_extend_batch_list for the Level-2 driver on the device (lx_level2_host.cpp): query residues, window list and cut-offs are resident
+int lxi::extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,
+                              int32_t * out_score, lx_survivor_list * out)
+{
+    *out = lx_survivor_list{};
+    if (n == 0)
+        return LX_OK;
+    if (slot < 0 || slot > 1 || !h->have_sc[slot])
+        return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
+    if (n > 0xfffffff0ull / 2)
+        return fail(h, LX_EINVAL, "at most 2^31 extensions per call");
+    int const rc = extend_pipeline(h, slot, nullptr, ri.q_bytes, nullptr, 0, ext, n, min_score, 0, out_score, nullptr, nullptr, nullptr, nullptr, 2, &ri);
+    if (rc != LX_OK)
+        return rc;
+    out->count       = h->res_count;
+    out->index       = reinterpret_cast<uint32_t const *>(h->res_index.data());
+    out->hsp         = reinterpret_cast<lx_hsp const *>(h->res_hsp.data());
+    out->codes_off   = reinterpret_cast<uint64_t const *>(h->res_off.data());
+    out->codes       = h->ext_bytes.data();
+    out->codes_bytes = h->res_count ? h->xb_ops_total : 0;
+    return LX_OK;
+}
+
+extern "C" {
 
 int lx_last_extend_stats(lx_handle const * h, uint64_t * out4)
 {

@@ -189,6 +189,23 @@ struct lx_handle
     DevBuf   d_band;                     // ... uploaded
     uint64_t opt_pass2     = 2; // LX_OPT_PASS2_MODE: 0 = direction bits (lx_trace.hip), 1 = checkpoints (lx_ckpt.hip), 2 = single sweep; each where applicable
     uint64_t db_bytes      = 0; // lx_set_subjects: size of the resident subject buffer (0 = none)
+    // Level 2 on the device (lx_level2_host.cpp): the resident sequence sets (lx_set_queries, lx_set_subject_seqs) and the buffers of
+    // the list work -- sort words (two of each), digit counts, scan values, windows
+    struct Level2
+    {
+        std::vector<uint64_t> q_off, s_off, s_len;
+        std::vector<uint32_t> q_len, q_evlen, evlens; // evlens: the distinct e-value lengths of the query set
+        uint64_t              q_bytes = 0, max_slen = 0, s_extent = 0; // s_extent: where the last subject ends in the residue buffer
+        uint32_t              max_evlen = 0;
+        int                   q_frames  = 1;
+        DevBuf                d_qres, d_qoff, d_qlen, d_qband, d_qevlen, d_soff, d_slen;
+        DevBuf                d_pair[2], d_s0[2], d_hist, d_head, d_tail, d_tot, d_win, d_cut, d_cnt, d_up, d_plan, d_wf;
+        Pinned                p_cnt, p_win, p_up;
+        std::vector<lx_extension> ext;   // host copies of the window list, its cut-offs and scores
+        std::vector<int32_t>      min, score;
+        std::vector<uint32_t>     wf_pan, wf_maxs; // a device plan's wavefronts
+        hipEvent_t                ev_win = nullptr; // the window list has arrived on the host
+    } l2;
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
 
@@ -342,6 +359,27 @@ int align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * d_s, 
 int fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * d_s_res, void const * d_ext, uint64_t n, void const * d_min_score,
                int32_t min_score_all, void * d_out_score, void * d_out_hsp, void * d_out_ops, void const * d_ops_off, void * d_out_count,
                void * stream_, int phases, bool by_pos, FusedExtra const * fx = nullptr);
+
+// what stands on the device already when the Level-2 driver (lx_level2_host.cpp) calls the extension pipeline
+struct ResidentInput
+{
+    void const * d_q       = nullptr; // query residues
+    uint64_t     q_bytes   = 0;
+    void const * d_ext_all = nullptr; // the caller's list (lx::Extension) and its cut-offs, in the order of the host's copies
+    void const * d_min_all = nullptr;
+    // a plan made on the device (the solo packing): the slot list (16 per wavefront: position in the list, bit 31 = filler), and
+    // on the host per wavefront the columns per lane its widest query sweeps and its longest window, the strip geometry
+    // (trace cfg), the list's cells
+    uint32_t const * d_plan  = nullptr;
+    uint64_t         nwf     = 0;
+    uint32_t const * wf_pan  = nullptr;
+    uint32_t const * wf_maxs = nullptr;
+    int              mq_cfg  = 0;
+    uint64_t         cells   = 0;
+};
+bool solo_plan_applies(lx_handle const * h, int slot);
+int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,
+                         int32_t * out_score, lx_survivor_list * out);
 
 unsigned host_threads(uint64_t n);
 

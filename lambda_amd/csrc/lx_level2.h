@@ -1,0 +1,86 @@
+// lx_level2.h -- device side of the Level-2 driver (lx_level2.hip) as the host sees it (lx_level2_host.cpp): the list work that
+// iterateMatchesFullSimd does around the two DP passes (/root/reference/src/search_algo.hpp:1136-1175, :1200-1227), on the
+// matches where the seeding stage left them -- in HBM.  Not part of the ABI; include/lambda_ext.h is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "lx_device.h"
+
+namespace lx
+{
+
+// A match as the sort sees it.  After _widenMatch (src/search_algo.hpp:919-938) a match is a function of (qryId, subjId,
+// s0 = the diagonal's subject position: subjStart - qryStart, clipped at 0) alone -- qryStart = 0, qryEnd = the query's length,
+// subjStart = max(0, s0 - band), subjEnd = min(s0 + qLen + band, sLen) -- and both window ends are non-decreasing in s0, so the
+// order of the reference's sort key (qryId, subjId, qryStart, qryEnd, subjStart, subjEnd; src/search_datastructures.hpp:60)
+// IS the order of (qryId, subjId, s0); matches that tie under the reference's key are equal records.
+//   word `pair` = bisulfite flag (subjId % 2, the major key of iterateMatches' bisulfite branch, :1369-1372) << 63 | qryId << 32 | subjId
+//   word `s0`
+// The sort is a least-significant-digit radix sort over the bits the call can have set (kL2DigitBits per pass; hand-written:
+// per-tile digit counts -> one scan per digit over the tiles -> stable scatter with wavefront match masks).
+constexpr int      kL2DigitBits  = 8;
+constexpr int      kL2SortBlock  = 256;                       // threads per workgroup of the sort kernels
+constexpr int      kL2SortItems  = 16;                        // keys per thread
+constexpr uint64_t kL2SortTile   = (uint64_t)kL2SortBlock * kL2SortItems;
+constexpr int      kL2ScanBlock  = 256;
+constexpr int      kL2ScanItems  = 8;
+constexpr uint64_t kL2ScanTile   = (uint64_t)kL2ScanBlock * kL2ScanItems;
+
+// Mirrors lx_match (src/search_datastructures.hpp:46-61).
+struct Match
+{
+    uint64_t qryId, subjId, qryStart, qryEnd, subjStart, subjEnd;
+};
+
+// One DP window after widen + merge + unique: what the reference's span holds when _widenAndPreprocessMatches returns
+// (qryStart = 0 and qryEnd = the query's length are implied).
+struct L2Window
+{
+    uint32_t q, s;     // frame-expanded ids
+    uint64_t beg, end; // subjStart, subjEnd
+};
+static_assert(sizeof(L2Window) == 24, "L2Window layout");
+
+// the two sequence sets, resident on the handle's device (lx_set_queries, lx_set_subject_seqs)
+struct L2Sets
+{
+    uint64_t const * q_off;   // [n_qseq] where the (frame) query lies in the query residue buffer
+    uint32_t const * q_len;   // [n_qseq]
+    uint32_t const * q_band;  // [n_qseq] _bandSize(q_len), src/search_misc.hpp:46-50 (made on the host: the very double sqrt)
+    uint32_t const * q_evlen; // [n_qseq] the query length the e-value is computed for (bm.qLength, :1213): index of the cut-off table
+    uint64_t const * s_off;   // [n_sseq]
+    uint64_t const * s_len;   // [n_sseq]
+    uint64_t         n_qseq, n_sseq;
+};
+
+struct L2Params
+{
+    L2Sets           sets;
+    uint64_t         n;          // matches
+    Extension *      ext_out;    // [<= n] the DP windows as (query slice, subject slice) pairs, :1200-1227
+    int32_t *        min_out;    // [<= n] score cut-off per window (the filter of :1251-1283 as an integer test)
+    L2Window *       win_out;    // [<= n]
+    int32_t const *  cut_by_len; // [max q_evlen + 1]
+    uint64_t *       count_out;  // [0] = windows, [1] = first window of an odd subject frame (bisulfite split), [2] = error flag
+    int              bisulfite;
+};
+
+hipError_t l2_launch_keys(void const * d_matches, L2Params const & p, uint64_t * pair, uint64_t * s0, uint64_t * flag, hipStream_t stream);
+// sorts (pair, s0) by the bits set in pair_bits / s0_bits (masks of the bits any key of the call can have set); the sorted words
+// end up in *pair / *s0 (the two buffers of a word swap roles); ghist: [(tiles + 1) * 256 + 256] uint32
+hipError_t l2_launch_sort(uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t n, uint64_t pair_bits, uint64_t s0_bits,
+                          uint32_t * ghist, hipStream_t stream);
+// merge passes + unique + windows; head / tail: [n] uint32, block_tot: [tiles of kL2ScanTile + 1] uint32
+hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint32_t * head, uint32_t * tail, uint32_t * block_tot,
+                           hipStream_t stream);
+// the solo plan of the multi-query sweep for a window list: cost sums per part and strip geometry (out[8]: part 0's
+// cost at 19 / 13 / 11 columns and cells, then part 1's; cnt = {windows, first window of part 1} in device memory), and the plan
+hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream);
+hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
+                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream);
+uint64_t   l2_sort_tiles(uint64_t n);
+uint64_t   l2_scan_tiles(uint64_t n);
+
+} // namespace lx

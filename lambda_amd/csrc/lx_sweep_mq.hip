@@ -135,11 +135,16 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         if (lsB != 0)
             sB += x.s_off;
     }
+    // p.solo: the SOLO packing (LX_OPT_QUERY_RUN = 1) -- no promise at all: every window has a query and an LDS profile of its own,
+    // 16 per wavefront.  For the alphabets whose byte profiles are small enough (nucleotides: 5 letters + pad): a read set's seed
+    // list has one or two windows per read, and four queries per wavefront would leave three lanes in four to fillers.
+    bool const            solo_mode = p.solo != 0;
+    uint8_t const * const qB        = p.q_res + q_offB;
     // p.pair_share lane groups (0 = all eight) use one LDS profile: the extensions of such a sub-block share the query.
     // p.pair_share == 1 is the FREE packing: the two windows of a lane group share a query, the eight lane groups hold windows
     // of at most kFreeSlots queries in any split (5 + 2 + 1, ...); the queries get their profile slots in order of appearance.
     constexpr int kFreeSlots = 4;
-    bool const free_mode = p.pair_share == 1;
+    bool const free_mode = !solo_mode && p.pair_share == 1;
     int const  share_g   = free_mode ? Geo::kGroups : (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
     int        blk       = grp / share_g;
     // free packing: the wavefront's queries (uniform values) and this lane group's slot among them
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         if (too_many && lane == 0)
             atomicExch(p.err, 2);
     }
-    else
+    else if (!solo_mode)
     {
         // the caller promised one query per sub-block: verify against the sub-block's first lane, fail loudly otherwise
         int const      leader  = blk * share_g * G;
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
 
     int ls_max = max(lsA, lsB);
     int ls_min = min(actA ? lsA : 0x7fffffff, actB ? lsB : 0x7fffffff);
-    int lq_max = lq;
+    int lq_max = max(lq, actB ? lqB : 0);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1)
     {
@@ -225,9 +230,17 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     int bound = 0;
     for (int j = g; j < lq; j += G) // (every column of the query once, whichever strip sweeps it)
         bound += sc->rowmax[q[j] & (kAlph - 1)];
+    int boundB = 0;
+    if (solo_mode && actB)
+        for (int j = g; j < lqB; j += G)
+            boundB += sc->rowmax[qB[j] & (kAlph - 1)];
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1)
+    {
         bound += __shfl_xor(bound, off);
+        boundB += __shfl_xor(boundB, off);
+    }
+    bound = max(bound, boundB);
     bool const broken  = (lq_max > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > p.steps_cap;
     // (free packing with a fifth query: declined as a whole -- the int32 launch shares profiles by pairs and copes)
     bool const too_big = broken || too_many || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (MULTI ? kMqLimit : 2046)) != 0 ||
@@ -287,9 +300,11 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     bool const writable = !MULTI || npanels == 1 || carry != nullptr; // (workspace exhausted: reported, nothing kept)
 
     constexpr uint32_t kRowBytes = Geo::kRowDw * 4;
-    int const          nslots    = free_mode ? kFreeSlots : Geo::kGroups / share_g;
-    uint32_t const     slot_dw   = (uint32_t)blk * (uint32_t)(nrows * Geo::kRowDw);
-    uint32_t const     slot_byte = slot_dw * 4u;
+    int const          nslots    = solo_mode ? 2 * Geo::kGroups : free_mode ? kFreeSlots : Geo::kGroups / share_g;
+    // (solo: slots 2 grp and 2 grp + 1; a lane group whose second half is beyond the list reads its first half's rows -- pad letters)
+    uint32_t const     slot_dw   = (uint32_t)(solo_mode ? 2 * grp : blk) * (uint32_t)(nrows * Geo::kRowDw);
+    uint32_t const     slot_dwB  = (solo_mode && actB) ? slot_dw + (uint32_t)(nrows * Geo::kRowDw) : slot_dw;
+    uint32_t const     slot_byte = slot_dw * 4u, slot_byteB = slot_dwB * 4u;
     uint64_t const     panel_dw  = L16::slot_dwords(p.steps_cap);
     uint32_t * const   stage     = lds + nslots * (nrows * Geo::kRowDw) + lane; // [step % 8][lane]: lane-minor, conflict-free
 
@@ -298,8 +313,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     int runA = 0, stripA = 0, rrowA = 0, rtieA = 0, runB = 0, stripB = 0, rrowB = 0, rtieB = 0;
 
     // strip width of this lane group's LAST panel as swept (code of kEndNarrowShift), for the backtrace
-    int const my_panels = max(1, (lq + Geo::kPanel - 1) / Geo::kPanel);
-    int       my_code   = 0;
+    int const my_panels = max(1, (lq + Geo::kPanel - 1) / Geo::kPanel), my_panelsB = max(1, (lqB + Geo::kPanel - 1) / Geo::kPanel);
+    int       my_code   = 0, my_codeB = 0;
 
     for (int panel = 0; panel < npanels; ++panel)
     {
@@ -311,6 +326,11 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             int const rem  = lq - panel * Geo::kPanel;
             int       mine = panel < my_panels - 1 ? 0 : rem >= 1 ? narrow_code_for(C, G, rem) : 2; // (no column left: any width)
             mine           = actA ? mine : 2;
+            if (solo_mode && actB)
+            {
+                int const remB = lqB - panel * Geo::kPanel;
+                mine           = min(mine, panel < my_panelsB - 1 ? 0 : remB >= 1 ? narrow_code_for(C, G, remB) : 2);
+            }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1)
                 mine = min(mine, __shfl_xor(mine, off));
@@ -318,6 +338,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         }
         if (panel == my_panels - 1)
             my_code = code;
+        if (panel == my_panelsB - 1)
+            my_codeB = code;
         auto panel_body = [&](auto ce_tag)
         {
         constexpr int CE   = decltype(ce_tag)::value; // columns per lane in this panel
@@ -376,7 +398,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                                 uint32_t const sel = (uint32_t)b | ((uint32_t)(4 + b) << 8) | 0x0c0c0000u;
                                 uint32_t const x01 = __builtin_amdgcn_perm(rows[1][w], rows[0][w], sel);
                                 uint32_t const x23 = __builtin_amdgcn_perm(rows[3][w], rows[2][w], sel);
-                                dst[(4 * w + b) * Geo::kRowDw] = x01 | (x23 << 16);
+                                if (4 * w + b < nrows) // (the solo packing's slots end with the pad letter's row)
+                                    dst[(4 * w + b) * Geo::kRowDw] = x01 | (x23 << 16);
                             }
                         }
                     }
@@ -392,6 +415,13 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     int const      ul = j == 0 ? fl[0] : j == 1 ? fl[1] : j == 2 ? fl[2] : fl[3];
                     build_profile(p.q_res + uq, ul, (uint32_t)j * (uint32_t)(nrows * Geo::kRowDw), Geo::kGroups, grp);
                 }
+            }
+            else if (solo_mode)
+            {
+                // every lane group its own two
+                build_profile(q, lq, slot_dw, 1, 0);
+                if (actB)
+                    build_profile(qB, lqB, slot_dwB, 1, 0);
             }
             else
                 build_profile(q, lq, slot_dw, share_g, grp % share_g);
@@ -459,7 +489,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         auto step = [&](uint32_t tA, uint32_t tB, int k, int u)
         {
             char const * const ra = reinterpret_cast<char const *>(lds) + slot_byte + tA * kRowBytes;
-            char const * const rb = reinterpret_cast<char const *>(lds) + slot_byte + tB * kRowBytes;
+            char const * const rb = reinterpret_cast<char const *>(lds) + slot_byteB + tB * kRowBytes;
             uint32_t           pa[Geo::kD], pb[Geo::kD];
             if constexpr (Geo::kN4 != 0)
             {
@@ -755,7 +785,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             panel_body(std::integral_constant<int, (C + 3) / 4>{});
     } // panels
 
-    auto finish = [&](int run, int rstrip, int rrow, int rtie, bool act, uint64_t e)
+    auto finish = [&](int run, int rstrip, int rrow, int rtie, bool act, uint64_t e, int code)
     {
         if (is_first && act)
         {
@@ -768,14 +798,14 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 ec.score = run;
                 ec.q_end = -(rstrip + 1); // the backtrace finds the column inside this strip
                 ec.s_end = rrow + 1;
-                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact | (my_code << kEndNarrowShift);
+                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact | (code << kEndNarrowShift);
             }
             p.ends[e]      = ec;
             p.out_score[e] = (writable && !declined) ? run : -1;
         }
     };
-    finish(runA, stripA, rrowA, rtieA, actA, eA);
-    finish(runB, stripB, rrowB, rtieB, actB, eB);
+    finish(runA, stripA, rrowA, rtieA, actA, eA, my_code);
+    finish(runB, stripB, rrowB, rtieB, actB, eB, solo_mode ? my_codeB : my_code);
 }
 
 template <int C>
@@ -786,7 +816,7 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
     int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
     if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0)
         return hipErrorInvalidValue;
-    size_t const lds = ((size_t)(p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
+    size_t const lds = ((size_t)(p.solo ? 2 * Geo::kGroups : p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
     if (p.panels_cap > 1)
         hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
@@ -810,7 +840,8 @@ size_t sweep_mq_lds_bytes(int trace_cfg, int nrows, int share)
 {
     int const C = trace_cfg == 1 ? 19 : trace_cfg == 3 ? 13 : 11;
     int const s = (share > 0 && share < 8) ? share : 8;
-    return ((size_t)(share == 1 ? 4 : 8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
+    // (share -1: the solo packing, a profile per window)
+    return ((size_t)(share < 0 ? 16 : share == 1 ? 4 : 8 / s) * (size_t)nrows * (size_t)((C + 3) / 4 * 8) + 64 * 8) * sizeof(uint32_t);
 }
 
 } // namespace lx

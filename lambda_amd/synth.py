@@ -214,3 +214,66 @@ def make_ragged_lists_np(n_queries: int, seed: int, alphabet: np.ndarray = STD20
         s_idx[rep(s_off[homolog] + a_h) + k] = val
     ext["q_off"], ext["q_len"], ext["s_off"], ext["s_len"] = q_off[qid], lq_e, s_off, ls_e
     return alphabet[q_idx].astype(np.uint8), alphabet[s_idx].astype(np.uint8), ext
+
+
+def make_seed_list_np(n_reads: int, genome_mbp: float, seed: int, read_len: int = 150, seeds_per_read: int = 12, contigs: int = 20,
+                      homolog_frac: float = 0.75, sub_rate: float = 0.02, spurious_per_read: float = 0.5):
+    """A seed list of the kind `lambda3 searchn` hands to iterateMatches (/root/reference/src/search_algo.hpp:1364-1385) at BASELINE
+    configs[2]'s size: reads of `read_len` bp cut from a random genome (both strands, `sub_rate` substitutions; the rest random),
+    every read as two query frames (itself, its reverse complement: add_reverse_complement, src/shared_definitions.hpp:260), for
+    every homologous read `seeds_per_read` seed hits along its diagonal on the frame that matches (a tenth of them one base off the
+    diagonal, as seeds next to an indel are) + spurious hits elsewhere.  Ranks: A, C, G, T = 0, 1, 2, 4 (BioC++ dna5 without N).
+    Returns q_res, q_off, q_len (frame-expanded, 2 n_reads), q_orig_len (n_reads), s_res, s_off, s_len, matches (MATCH_DTYPE, in the
+    arbitrary order a seeding kernel's lanes emit them)."""
+    from .capi import MATCH_DTYPE
+
+    rng = np.random.default_rng(seed)
+    nt = np.array([0, 1, 2, 4], dtype=np.uint8)
+    comp = np.zeros(5, dtype=np.uint8)
+    comp[[0, 1, 2, 4]] = [4, 2, 1, 0]
+    clen = int(genome_mbp * 1e6 / contigs)
+    s_len = np.full(contigs, clen, dtype=np.uint64)
+    s_off = (np.arange(contigs, dtype=np.uint64) * np.uint64(clen))
+    s_res = nt[rng.integers(0, 4, clen * contigs, dtype=np.uint8)]
+    homolog = rng.random(n_reads) < homolog_frac
+    ctg = rng.integers(0, contigs, n_reads)
+    pos = rng.integers(0, clen - read_len, n_reads)
+    minus = rng.random(n_reads) < 0.5
+    idx = (s_off[ctg].astype(np.int64) + pos)[:, None] + np.arange(read_len)[None, :]
+    fwd = s_res[idx]  # the genome's strand
+    sub = rng.integers(0, 65536, fwd.shape, dtype=np.uint16) < np.uint16(sub_rate * 65536)
+    fwd[sub] = nt[rng.integers(0, 4, int(sub.sum()))]
+    fwd[~homolog] = nt[rng.integers(0, 4, (int((~homolog).sum()), read_len))]
+    rc = comp[fwd[:, ::-1]]
+    # frame 0 = the read, frame 1 = its reverse complement; a minus-strand read IS rc, so its frame 1 carries the genome's strand
+    frames = np.empty((n_reads, 2, read_len), dtype=np.uint8)
+    frames[:, 0] = np.where(minus[:, None], rc, fwd)
+    frames[:, 1] = np.where(minus[:, None], fwd, rc)
+    q_res = frames.reshape(-1)
+    q_len = np.full(2 * n_reads, read_len, dtype=np.uint64)
+    q_off = np.arange(2 * n_reads, dtype=np.uint64) * np.uint64(read_len)
+    q_orig_len = np.full(n_reads, read_len, dtype=np.uint64)
+    L = 10
+    hr = np.nonzero(homolog)[0]
+    k = seeds_per_read
+    qs = rng.integers(0, read_len - L, (len(hr), k))
+    off_diag = (rng.random((len(hr), k)) < 0.1) * rng.integers(-1, 2, (len(hr), k))
+    m1 = np.zeros(len(hr) * k, dtype=MATCH_DTYPE)
+    m1["qryId"] = np.repeat(2 * hr + minus[hr], k)
+    m1["subjId"] = np.repeat(ctg[hr], k)
+    m1["qryStart"] = qs.reshape(-1)
+    m1["qryEnd"] = m1["qryStart"] + L
+    m1["subjStart"] = np.clip(np.repeat(pos[hr], k) + qs.reshape(-1) + off_diag.reshape(-1), 0, clen - L)
+    m1["subjEnd"] = m1["subjStart"] + L
+    ns = int(n_reads * spurious_per_read)
+    m2 = np.zeros(ns, dtype=MATCH_DTYPE)
+    m2["qryId"] = rng.integers(0, 2 * n_reads, ns)
+    m2["subjId"] = rng.integers(0, contigs, ns)
+    m2["qryStart"] = rng.integers(0, read_len - L, ns)
+    m2["qryEnd"] = m2["qryStart"] + L
+    m2["subjStart"] = rng.integers(0, clen - L, ns)
+    m2["subjEnd"] = m2["subjStart"] + L
+    m = np.concatenate([m1, m2])
+    # lanes own reads and finish in no particular order: blocks of a few thousand reads' matches, shuffled
+    blk = np.argsort(rng.permutation(len(m) // 4096 + 1).repeat(4096)[:len(m)] * (1 << 32) + m["qryId"] // 128, kind="stable")
+    return q_res, q_off, q_len, q_orig_len, s_res, s_off, s_len, m[blk]

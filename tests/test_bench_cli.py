@@ -99,3 +99,28 @@ def test_bisulfite_conversion_of_synthetic_reads():
     w0 = s[: synth.window_len(100)][b: b + 100]
     # the window still holds the unconverted read: where it has C the read has T, everything else is equal
     assert ((w0 == q[:100]) | ((w0 == 1) & (q[:100] == 3))).all() and (w0 == 1).any()
+
+
+def test_pmc_traffic_matches_the_full_instantiation_and_reports_what_it_skipped(tmp_path, monkeypatch):
+    """a profile of another shape (no "kernels" table) made the driver's line lose its traffic figure, and a
+    substring match attached the 24 GB of `score_pair_kernel<8, 19, true>` (checkpoint writer) to `<8, 19>` (writes the scores)."""
+    import bench
+
+    for spelling in ("score_pair_kernel<8, 19, true>", "lx::score_pair_kernel<8,19,true> (single sweep)",
+                     "void lx::score_pair_kernel<8, 19, true>(lx::ScoreParams)"):
+        t, note = bench.pmc_traffic(spelling)
+        assert t is not None and 1e10 < t < 5e10, (spelling, note)   # 24.4 GB per headline launch
+        assert "score_pair_kernel<8, 19, true>" in note
+    for other in ("score_pair_kernel<8, 19>", "lx::score_pair_kernel<8,19>", "score_pair_kernel", "score_pair_kernel<8, 19, false>"):
+        t, note = bench.pmc_traffic(other)
+        assert t is None and "no committed PMC profile" in note, (other, t)
+    # files that are not a per-kernel table, or not JSON at all, neither hide the good profile nor vanish silently
+    good = json.loads((ROOT / "profiles" / "r03_bench_pmc.json").read_text())
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r03_bench_pmc.json").write_text(json.dumps(good))
+    (tmp_path / "profiles" / "r09_other_kernel_pmc.json").write_text(json.dumps({"kernel": "x", "SQ_WAVES": 1}))
+    (tmp_path / "profiles" / "r10_broken_pmc.json").write_text("{not json")
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    t, note = bench.pmc_traffic("score_pair_kernel<8, 19, true>")
+    assert t is not None and "r10_broken_pmc.json" in note and "r03_bench_pmc.json" in note
+    assert bench.kernel_instantiation("lx::select_scan_kernel(lx::SelectParams, unsigned long)") == "select_scan_kernel"

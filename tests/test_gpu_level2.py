@@ -1,0 +1,238 @@
+"""GPU parity of the Level-2 driver on a DEVICE match list (lambda_amd/csrc/lx_level2.hip + lx_level2_host.cpp): widen, sort, merge,
+unique (/root/reference/src/search_algo.hpp:919-938, :1136-1175), the slices and cut-offs (:1200-1227, :1251-1283) as kernels over
+resident sequence sets, then the two passes and the records (:1287-1325).  Checked against the CPU oracle's restatement
+(oracle/lx_oracle.c through tests/oracle_lib.py, tests/oracle_driver.py) and, record for record, against lx_iterate_matches on the
+same list from host memory."""
+import numpy as np
+import pytest
+
+from lambda_amd import capi, synth
+from tests import oracle_driver, oracle_lib
+from tests.test_gpu_trace import _driver_case
+from tests.test_oracle import SCHEMES
+
+pytestmark = pytest.mark.gpu
+
+
+def _to_device(m):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(m).view(np.uint8).copy()).to("cuda:0")
+
+
+def _random_matches(rng, n, nq, ns, qlens, slens, sorted_by_query=True, step=7):
+    m = np.zeros(n, dtype=capi.MATCH_DTYPE)
+    q = rng.integers(0, nq, n)
+    m["qryId"] = np.sort(q) if sorted_by_query else q
+    m["subjId"] = rng.integers(0, ns, n)
+    sl = slens[m["subjId"]].astype(np.int64)
+    ql = qlens[m["qryId"]].astype(np.int64)
+    m["qryStart"] = (rng.random(n) * np.maximum(ql - 10, 1)).astype(np.uint64)
+    m["qryEnd"] = np.minimum(m["qryStart"] + 10, ql.astype(np.uint64))
+    m["subjStart"] = ((rng.random(n) * np.maximum(sl - 10, 1)).astype(np.int64) // step * step).astype(np.uint64)  # duplicates and overlaps abound
+    m["subjEnd"] = np.minimum(m["subjStart"] + 10, sl.astype(np.uint64))
+    return m
+
+
+@pytest.mark.parametrize("shape", ["few subjects", "many subjects", "tiny", "long subjects"])
+def test_widen_sort_merge_unique_on_device_equals_oracle(handle, oracle, shape):
+    """The window list of the kernels is the oracle's _widenAndPreprocessMatches list, element for element, whatever order the
+    matches arrive in (the seeding kernel's lanes emit them in theirs)."""
+    rng = np.random.default_rng(5)
+    nq, ns, n, step = {"few subjects": (9000, 40, 150_000, 7), "many subjects": (300, 50_000, 120_000, 1), "tiny": (3, 2, 200, 3),
+                       "long subjects": (5000, 3, 100_000, 1)}[shape]
+    qlens = rng.integers(30, 200, nq).astype(np.uint64)
+    slens = (rng.integers(300, 2000, ns) if shape != "long subjects" else rng.integers(3_000_000, 5_000_000, ns)).astype(np.uint64)
+    m = _random_matches(rng, n, nq, ns, qlens, slens, step=step)
+    qoff = np.concatenate([[0], np.cumsum(qlens)[:-1]]).astype(np.uint64)
+    soff = np.concatenate([[0], np.cumsum(slens)[:-1]]).astype(np.uint64)
+    handle.set_queries(np.zeros(int(qlens.sum()), np.uint8), qoff, qlens)
+    handle.set_subject_seqs(soff, slens)
+    want = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlens, slens)
+    assert len(want) < n
+    for order in (np.arange(n), rng.permutation(n), np.arange(n)[::-1]):
+        got = handle.widen_and_preprocess_dev(_to_device(m[order]), n)
+        assert len(got) == len(want)
+        for f in ("qryId", "subjId", "qryStart", "qryEnd", "subjStart", "subjEnd"):
+            assert (got[f] == want[f]).all(), (shape, f)
+    # bisulfite order: subjId % 2 is the major key (src/search_algo.hpp:1369-1372), each half the oracle's list of its matches
+    got = handle.widen_and_preprocess_dev(_to_device(m), n, bisulfite=True)
+    halves = [oracle.widen_and_preprocess(m[m["subjId"] % 2 == k].astype(oracle_lib.MATCH_DTYPE), qlens, slens) for k in (0, 1)]
+    want_bs = np.concatenate(halves)
+    assert len(got) == len(want_bs)
+    for f in ("qryId", "subjId", "qryStart", "qryEnd", "subjStart", "subjEnd"):
+        assert (got[f] == want_bs[f]).all(), (shape, f)
+
+
+def test_widen_on_device_clips_and_chains_like_the_oracle(handle, oracle):
+    """Hand-made edge cases: windows clipped at both subject ends, a chain of overlaps that merges transitively, touching windows
+    (subjEnd == subjStart merges: `>=`, :1150), exact duplicates, one match, queries longer than the subject."""
+    qlens = np.array([50, 120, 400, 9], dtype=np.uint64)
+    slens = np.array([300, 60, 5000], dtype=np.uint64)
+    rows = []
+    for q in range(4):
+        for s in range(3):
+            L = int(slens[s])
+            for ss in (0, 1, 5, L // 2, L // 2, L // 2 + 1, min(L // 2 + 40, L - 2), L - 10, L - 1):
+                for qs in (0, 3, int(qlens[q]) - 1):
+                    rows.append((q, s, qs, min(qs + 10, int(qlens[q])), ss, min(ss + 10, L)))
+    # a chain: every window overlaps the next one only
+    for k in range(25):
+        rows.append((1, 2, 0, 10, 100 + 130 * k, 110 + 130 * k))
+    # touching: band(120) = 11 -> window [ss - 11, ss + 131); the next one starts exactly where this one ends
+    rows.append((1, 2, 0, 10, 4000, 4010))
+    rows.append((1, 2, 0, 10, 4000 + 142, 4010 + 142))
+    m = np.array(rows, dtype=capi.MATCH_DTYPE)
+    qoff = np.concatenate([[0], np.cumsum(qlens)[:-1]]).astype(np.uint64)
+    soff = np.concatenate([[0], np.cumsum(slens)[:-1]]).astype(np.uint64)
+    handle.set_queries(np.zeros(int(qlens.sum()), np.uint8), qoff, qlens)
+    handle.set_subject_seqs(soff, slens)
+    want = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlens, slens)
+    got = handle.widen_and_preprocess_dev(_to_device(m), len(m))
+    assert len(got) == len(want)
+    assert (got.view(np.uint64) == want.view(np.uint64)).all()
+    one = handle.widen_and_preprocess_dev(_to_device(m[:1]), 1)
+    assert (one.view(np.uint64) == oracle.widen_and_preprocess(m[:1].astype(oracle_lib.MATCH_DTYPE), qlens, slens).view(np.uint64)).all()
+    assert len(handle.widen_and_preprocess_dev(None, 0)) == 0
+
+
+def test_device_list_errors_are_loud(handle):
+    qlens = np.array([50, 60], dtype=np.uint64)
+    slens = np.array([300, 200], dtype=np.uint64)
+    handle.set_queries(np.zeros(110, np.uint8), np.array([0, 50], np.uint64), qlens)
+    handle.set_subject_seqs(np.array([0, 300], np.uint64), slens)
+    ok = np.array([(0, 1, 0, 10, 20, 30)], dtype=capi.MATCH_DTYPE)
+    assert len(handle.widen_and_preprocess_dev(_to_device(ok), 1)) == 1
+    for bad in ((2, 0, 0, 10, 20, 30), (0, 2, 0, 10, 20, 30), (0, 1, 0, 10, 200, 210), (0, 1, 5, 15, 400, 410)):
+        with pytest.raises(capi.LambdaExtError):
+            handle.widen_and_preprocess_dev(_to_device(np.array([ok[0], bad], dtype=capi.MATCH_DTYPE)), 2)
+
+
+def _assert_records_equal(a, ao, b, bo):
+    assert len(a) == len(b)
+    assert a.tobytes() == b.tobytes()
+    assert ao == bo
+
+
+@pytest.mark.parametrize("filters", [(1e-2, -1, 0), (-1.0, 40, 0), (10.0, -1, 35), (-1.0, -1, 0)])
+def test_iterate_matches_dev_against_the_oracle_driver(handle, oracle, filters):
+    max_e, min_bits, idcut = filters
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    ka = capi.karlin_params(62)
+    oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
+    rng = np.random.default_rng(2024)
+    q, qoff, qlen, s, soff, slen, m = _driver_case(rng)
+    db_total = int(slen.sum())
+    params = capi.SearchParams(max_e, min_bits, idcut, db_total, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    order = rng.permutation(len(m))
+    bms, ops, stats = handle.iterate_matches_dev(_to_device(m[order]), len(m), params)
+    want, wstats = oracle_driver.iterate_matches(oracle, osc, oka, q, qoff, qlen, qlen, s, soff, slen,
+                                                 m.astype(oracle_lib.MATCH_DTYPE), max_e, min_bits, idcut, db_total)
+    assert (stats.hits_duplicate, stats.failed_bitscore, stats.failed_evalue, stats.failed_identity) == \
+           (wstats["hits_duplicate"], wstats["failed_bitscore"], wstats["failed_evalue"], wstats["failed_identity"])
+    assert stats.num_ext_score == len(m)
+    assert len(bms) == len(want) and len(want) > 20
+    for g, w, o in zip(bms, want, ops):
+        for k in ("qry_id", "subj_id", "n_qid", "n_sid", "q_start", "q_end", "s_start", "s_end", "score", "alignment_length",
+                  "num_matches", "num_mismatches", "num_positives", "num_gap_opens", "num_gap_extensions"):
+            assert int(g[k]) == w[k], (k, g, w)
+        assert o == w["ops"]
+        assert g["identity"] == np.float32(w["identity"])
+        assert abs(g["bit_score"] - w["bit_score"]) <= 1e-6 * abs(w["bit_score"])  # the contract: 1e-6 relative
+        assert abs(g["e_value"] - w["e_value"]) <= 1e-6 * abs(w["e_value"])
+    # ... and the host entry point on the same list gives the same bytes
+    hb, ho, hs = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, m, params)
+    _assert_records_equal(bms, ops, hb, ho)
+
+
+def _seed_list(rng, nq, ns, hits_per_q, lq_range=(50, 400), alphabet=None, frames=1):
+    alphabet = synth.STD20 if alphabet is None else alphabet
+    qlen = rng.integers(lq_range[0], lq_range[1], nq).astype(np.uint64)
+    slen = rng.integers(600, 2500, ns).astype(np.uint64)
+    qoff = np.concatenate([[0], np.cumsum(qlen)[:-1]]).astype(np.uint64)
+    soff = np.concatenate([[0], np.cumsum(slen)[:-1]]).astype(np.uint64)
+    q = alphabet[rng.integers(0, len(alphabet), int(qlen.sum()))].astype(np.uint8)
+    s = alphabet[rng.integers(0, len(alphabet), int(slen.sum()))].astype(np.uint8)
+    nh = nq * hits_per_q
+    a = np.repeat(np.arange(nq), hits_per_q)
+    b = rng.integers(0, ns, nh)
+    L = 10
+    qs = (rng.random(nh) * (qlen[a] - L)).astype(np.int64)
+    ss = (rng.random(nh) * (slen[b] - L)).astype(np.int64)
+    for i in np.nonzero(rng.random(nh) < 0.5)[0]:  # homologous region around half of the seeds
+        lo = min(qs[i], ss[i])
+        hi = min(int(qlen[a[i]]) - qs[i], int(slen[b[i]]) - ss[i])
+        seg = q[int(qoff[a[i]]) + qs[i] - lo: int(qoff[a[i]]) + qs[i] + hi].copy()
+        mut = rng.random(len(seg)) < 0.25
+        seg[mut] = alphabet[rng.integers(0, len(alphabet), int(mut.sum()))]
+        s[int(soff[b[i]]) + ss[i] - lo: int(soff[b[i]]) + ss[i] + hi] = seg
+    m = np.zeros(nh, dtype=capi.MATCH_DTYPE)
+    m["qryId"], m["subjId"], m["qryStart"], m["qryEnd"], m["subjStart"], m["subjEnd"] = a, b, qs, qs + L, ss, ss + L
+    # a second seed on most diagonals and near-by ones: duplicates and merges (:1144-1173)
+    extra = m[rng.random(nh) < 0.6].copy()
+    shift = rng.integers(0, 30, len(extra)).astype(np.uint64)
+    extra["qryStart"] = np.minimum(extra["qryStart"] + shift, qlen[extra["qryId"]] - L)
+    extra["qryEnd"] = extra["qryStart"] + L
+    extra["subjStart"] = np.minimum(extra["subjStart"] + shift + rng.integers(0, 3, len(extra)).astype(np.uint64), slen[extra["subjId"]] - L)
+    extra["subjEnd"] = extra["subjStart"] + L
+    return q, qoff, qlen, s, soff, slen, np.concatenate([m, extra])
+
+
+@pytest.mark.parametrize("scheme,order", [("blosum62", "shuffled"), ("blosum62", "grouped"), ("nucl", "reversed")])
+def test_iterate_matches_dev_large_list_equals_host_entry(handle, scheme, order):
+    """A list of the size a GPU seeding stage hands over (beyond where the drivers go parallel; several chunks of the pipeline;
+    ragged queries -> the multi-query sweep): the device list gives lx_iterate_matches' records, byte for byte."""
+    sc_p = SCHEMES[scheme]
+    handle.set_scoring(sc_p, 0)
+    rng = np.random.default_rng(77)
+    dna = scheme == "nucl"
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 6000, 500, 12, lq_range=(140, 160) if dna else (50, 400),
+                                                 alphabet=np.arange(4, dtype=np.uint8) if dna else None)
+    ka = capi.karlin_params(0, 2, -3, -5, -2) if dna else capi.karlin_params(62)
+    params = capi.SearchParams(1e-2, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    n = len(m)
+    assert n > 100_000
+    perm = {"shuffled": rng.permutation(n), "grouped": np.arange(n), "reversed": np.arange(n)[::-1]}[order]
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    db, do, ds = handle.iterate_matches_dev(_to_device(m[perm]), n, params)
+    hb, ho, hs = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, m[perm], params)
+    assert len(db) > 5000
+    _assert_records_equal(db, do, hb, ho)
+    for f in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity", "num_ext_score", "num_ext_ali"):
+        assert getattr(ds, f) == getattr(hs, f), f
+    assert ds.hits_duplicate > 1000
+
+
+def test_iterate_matches_dev_bisulfite_and_frames(handle, oracle):
+    """iterateMatches' bisulfite branch (:1367-1379): even subject frames with the forward scheme, odd ones with the reverse
+    scheme, HSPs stably re-sorted by query; four query frames, two subject frames, the bisulfite overload of
+    computeAlignmentStats -- against lx_iterate_matches and the oracle driver."""
+    fwd, rev = SCHEMES["bs_fwd"], SCHEMES["bs_rev"]
+    handle.set_scoring(fwd, 0)
+    handle.set_scoring(rev, 1)
+    rng = np.random.default_rng(31)
+    nreads, nsub = 300, 6
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, nreads * 4, nsub * 2, 6, lq_range=(100, 150), alphabet=np.arange(4, dtype=np.uint8))
+    ka = capi.karlin_params(0, 2, -3, -5, -2)
+    qorig = qlen[::4].copy()
+    params = capi.SearchParams(1e-3, -1, 0, int(slen.sum()) * 100, 0, 4, 2, 1, capi.LX_FRAMES_BISULFITE, capi.LX_FRAMES_BISULFITE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qorig, 4)
+    perm = rng.permutation(len(m))
+    db, do, ds = handle.iterate_matches_dev(_to_device(m[perm]), len(m), params)
+    hb, ho, hs = handle.iterate_matches(q, qoff, qlen, qorig, None, soff, slen, m[perm], params)
+    assert len(db) > 100 and (np.diff(db["n_qid"].astype(np.int64)) >= 0).all()
+    assert set(np.unique(db["subj_id"] % 2)) == {0, 1}
+    _assert_records_equal(db, do, hb, ho)
+    for f in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity", "num_ext_score", "num_ext_ali"):
+        assert getattr(ds, f) == getattr(hs, f), f
+    with pytest.raises(capi.LambdaExtError):  # the queries were set with four frames
+        handle.iterate_matches_dev(_to_device(m), len(m), capi.SearchParams(1e-3, -1, 0, 1000, 0, 2, 2, 1, capi.LX_FRAMES_BISULFITE, capi.LX_FRAMES_BISULFITE, ka))

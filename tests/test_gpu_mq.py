@@ -384,3 +384,82 @@ def test_host_plan_with_a_window_beyond_the_checkpoint_rows(handle, oracle):
         _check_host_list(handle, oracle, q, s, ext, 50, sample=100)
     finally:
         handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
+
+
+@pytest.mark.parametrize("scheme", ["nucl", "bs_fwd", "bs_rev"])
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((105, 152), "sweep_mq_kernel<19,false>"), ((140, 160), "sweep_mq_kernel"),
+                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((60, 456), "sweep_mq_kernel<19,true>")])
+def test_mq_sweep_solo_packing(handle, oracle, scheme, lq_range, expect):
+    """LX_OPT_QUERY_RUN = 1, the solo packing: no promise at all -- every window has its query and its byte profile, 16 windows of
+    up to 16 queries per wavefront in ANY order (lx_sweep_mq.hip); for the alphabets whose 16 profiles fit a wavefront's LDS share
+    (nucleotides, bisulfite).  Widths of one to three panels, narrow last panels, the two halves of a lane group in different
+    width classes; the list in random order (what a seed list of single-window reads looks like after sorting by length)."""
+    sc_p = SCHEMES[scheme]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(60 if lq_range[1] <= 208 else 24, seed=900 + lq_range[0], alphabet=np.arange(4, dtype=np.uint8), lq_range=lq_range,
+                                           mean_windows=3.0, merged_frac=0.15, sub_rate=0.1)
+    rng = np.random.default_rng(lq_range[1])
+    slots = ext[rng.permutation(len(ext))]
+    per_wave = [len({(int(x["q_off"]), int(x["q_len"])) for x in slots[w: w + 16]}) for w in range(0, len(slots), 16)]
+    assert max(per_wave) > 8  # far beyond the four queries of the free packing
+    cutoff = 40
+    got = run_fused(handle, q, s, slots, 1, cutoff, mq=1)
+    assert expect in got[5] and "solo packing: up to 16 queries per wavefront" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, cutoff, *got[:5])
+
+
+def test_mq_sweep_solo_packing_declined_extensions(handle, oracle):
+    """Solo packing, windows beyond what the sweep's range test admits (long merged windows: |ge| x rows alone passes 2046) and scores
+    beyond the compact codes in several panels: the int32 launch redoes them, every window with a profile of its own."""
+    sc_p = SCHEMES["nucl"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(30, seed=41, alphabet=np.arange(4, dtype=np.uint8), lq_range=(120, 700), mean_windows=3.0, merged_frac=0.2, sub_rate=0.05)
+    # a few windows of 1 200 rows (the a-priori bound of their wavefronts exceeds the codes) and self-hits of the longest queries
+    # (scores beyond 2046 / 2 per match = queries beyond 1 023 columns do not occur here; 700 x 2 = 1 400 stays inside)
+    big = np.argsort(ext["q_len"])[-6:]
+    extra = ext[big].copy()
+    extra["s_len"] = np.minimum(1200, len(s) - extra["s_off"].astype(np.int64)).astype(np.uint32)
+    slots = np.concatenate([ext, extra])
+    slots = slots[np.random.default_rng(3).permutation(len(slots))]
+    got = run_fused(handle, q, s, slots, 1, 40, mq=1)
+    assert "solo packing" in got[5] and "int32 fix-up" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, 40, *got[:5])
+
+
+@pytest.mark.parametrize("scheme", ["nucl", "bs_rev"])
+def test_host_plan_solo_on_read_lists(handle, oracle, scheme):
+    """lx_extend_batch_list on a list as `searchn` produces it -- one or two windows per read, some merged -- takes the solo plan
+    (all windows sorted by width and length, 16 to a wavefront): scores of every window and the survivors' records against the
+    oracle; padding far below the free packing's."""
+    sc_p = SCHEMES[scheme]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    q, s, ext = synth.make_ragged_lists_np(3000, seed=8, alphabet=np.arange(4, dtype=np.uint8), lq_range=(100, 151), mean_windows=1.3, merged_frac=0.1, sub_rate=0.05)
+    ext = ext[np.random.default_rng(2).permutation(len(ext))]
+    want = oracle.score_batch(q, s, ext, osc, threads=8)
+    cutoff = 60
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
+    handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 1024)  # several chunks
+    try:
+        score, index, hsp, off, codes = handle.extend_batch_list(q, s, ext, cutoff)
+        name = handle.last_trace_kernel_name()
+        st = handle.last_extend_stats()
+    finally:
+        handle.set_option(capi.LX_OPT_PASS2_MODE, 1)
+        handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
+    assert "solo packing" in name, name
+    assert st[1] < 1.02 * len(ext) + 16  # slots: the windows and the last wavefront's fillers
+    assert (score == want).all()
+    live = np.nonzero(want >= cutoff)[0]
+    assert len(index) == len(live) and (np.sort(index) == live).all() and len(live) > 100
+    pick = np.random.default_rng(0).choice(len(index), 300, replace=False)
+    for k, (oh, oops) in zip(pick, oracle.align_batch(q, s, ext[index[pick]], osc)):
+        g = hsp[k]
+        assert (g["score"], g["q_begin"], g["q_end"], g["s_begin"], g["s_end"], g["n_ops"]) == (oh.score, oh.q_begin, oh.q_end, oh.s_begin, oh.s_end, oh.n_ops)
+        n_ops, c, done = int(g["n_ops"]), int(off[k]), 0
+        while done < n_ops:
+            done += (int(codes[c]) & 63) + 1
+            c += 1
+        assert capi.Handle.expand_ops(codes[int(off[k]): c], n_ops) == oops

@@ -89,3 +89,24 @@ def test_plan_follows_budget_survivors_and_switches():
     p = capi.plan_step(wide_gap, 150, 176, 32, 1000)
     assert p.family in (capi.PLAN_I16_PAIRS, capi.PLAN_INT32) and p.compact_codes == 0
     assert capi.plan_step(wide_gap, 150, 176, 4, 1000).family == capi.PLAN_NO_SWEEP
+
+
+def test_solo_packing_only_where_sixteen_profiles_fit():
+    """LX_OPT_QUERY_RUN = 1 -- no promise, a byte profile per window (lx_sweep_mq.hip's solo packing) -- is served where 16 profiles
+    fit a wavefront's share of the LDS: nucleotide and bisulfite schemes (5 letters + pad), one to several panels; 16 protein
+    profiles (27 letters) do not fit, and there 1 is what 0 is: no promise, no sweep."""
+    prot = capi.builtin_scoring(62, gap_open=-11, gap_extend=-1)
+    for lq in (100, 150, 300, 900):
+        pl = capi.plan_step(prot, lq, lq + 30, 1, 10_000)
+        assert "sweep_mq_kernel" not in pl.name.decode()
+    for method in (0, -1, -2):
+        sc = capi.builtin_scoring(method, match=2, mismatch=-3, gap_open=-5, gap_extend=-2)
+        for lq, slen in ((100, 130), (150, 176), (150, 2000), (400, 450), (1000, 1100)):
+            pl = capi.plan_step(sc, lq, slen, 1, 10_000)
+            name = pl.name.decode()
+            assert "solo packing: up to 16 queries per wavefront" in name, (method, lq, name)
+            assert pl.queries_per_wavefront == 16 and pl.lds_bytes <= 20 * 1024 and pl.compact_codes == 1
+            assert pl.panels * pl.group_lanes * pl.strip_cols >= lq
+            # a fix-up launch exactly where the a-priori bound exceeds the codes or the panels are several
+            assert bool(pl.may_decline) == (pl.score_bound > 2046 or pl.panels > 1), (lq, slen, pl.score_bound)
+            assert ("int32 fix-up" in name) == bool(pl.may_decline)
