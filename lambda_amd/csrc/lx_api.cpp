@@ -48,6 +48,9 @@ lx::DevAids const & lx::dev_aids()
         a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
         a.mq_no_narrow      = set("LX_MQ_NO_NARROW");
         a.mq_no_solo        = set("LX_MQ_NO_SOLO");
+        a.mq_no_wide        = set("LX_MQ_NO_WIDE");
+        a.mq_no_merge       = set("LX_MQ_NO_MERGE");
+        a.mq_merge_below    = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
@@ -544,7 +547,7 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
     uint64_t sweep_stride32 = 0; // ... of an int16-pair slot (the whole batch's, or the overflow area's)
     uint64_t ovf_cap = 0;
     int      sweep_share = 0;
-    bool     half_sweep = false, may_decline = true, wide_compact = false;
+    bool     half_sweep = false, may_decline = true, wide_compact = false, mq_wide = false;
     int const nrows_sc = ((sc.alph + 1 + 3) / 4) * 4;
     // Multi-query sweep (lx_sweep_mq.hip): query runs of 4 or 8 (2 / 4 lane groups per LDS profile) -- what lx_extend_batch
     // makes of a ragged list --, or any multiple of 4 when LX_OPT_MQ_SWEEP = 2 asks for it.  Needs byte profiles (no
@@ -577,7 +580,9 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             int const G    = 8;
             sweep_steps    = (uint32_t)((o.max_slen + G - 1 + 15) & ~15ull);
             sweep_stride32 = (uint64_t)sweep_panels * lx::ckpt_slot_dwords(sweep_cfg, sweep_steps);
-            sweep_stride   = (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
+            // (mq_wide: int16-pair slots from the sweep itself -- lists whose windows score beyond the compact codes, lx_host.cpp)
+            mq_wide        = o.mq_wide && sweep_cfg == 1;
+            sweep_stride   = mq_wide ? sweep_stride32 : (uint64_t)sweep_panels * lx::ckpt16_slot_dwords(sweep_cfg, sweep_steps);
             half_sweep     = true;
             // lane groups per query: a wavefront's 16 slots hold 16 / 8 / 4 windows of one query, whatever divides the run
             // (1 = the free packing: a lane group's pair shares a query, up to four queries per wavefront in any split)
@@ -585,12 +590,12 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             sweep          = (o.n + 1) * sweep_stride * 4 <= o.trace_bytes;
             int64_t const worst = (int64_t)o.max_qlen * std::max(smax_entry, 0) + (int64_t)(-sc.gap_extend) * (sweep_steps + G + 2) +
                                   (smax_entry - sc.gap_extend) + 2;
-            may_decline = worst > 2046 || sweep_panels > 1;
+            may_decline = mq_wide ? worst > 0x7BFF - 2048 : (worst > 2046 || sweep_panels > 1);
             if (sweep && may_decline)
                 ovf_cap = std::min<uint64_t>(o.n, (o.trace_bytes - (o.n + 1) * sweep_stride * 4) / (sweep_stride32 * 4));
             mq = sweep; // (a batch beyond the slot budget: the per-survivor paths below)
             if (!sweep)
-                half_sweep = false;
+                half_sweep = mq_wide = false;
         }
     }
     if (!mq && o.pass2 == 2 && shared && sc.trace_ok && !o.band)
@@ -676,7 +681,9 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
     pl.stride32     = sweep_stride32;
     pl.ovf_cap      = pl.sweep ? ovf_cap : 0;
     pl.share        = sweep_share;
-    pl.compact      = pl.sweep && half_sweep;
+    pl.compact      = pl.sweep && half_sweep && !mq_wide;
+    pl.packed       = pl.sweep && half_sweep;
+    pl.wide         = pl.sweep && mq_wide;
     pl.may_decline  = may_decline;
     return pl;
 }
@@ -688,7 +695,7 @@ void lxi::describe_plan(StepPlan const & pl, char * buf, size_t len)
     switch (pl.family)
     {
         case kMqSweep:
-            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.panels > 1 ? "true" : "false",
+            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.wide ? "true,true" : pl.panels > 1 ? "true" : "false",
                      pl.share < 0 ? "solo packing: up to " : pl.share == 1 ? "free packing: up to " : "", pl.share < 0 ? 16 : pl.share == 1 ? 4 : 8 / std::max(1, pl.share),
                      pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
             break;
@@ -754,15 +761,55 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     StepOptions so{};
     so.max_qlen = h->opt_max_qlen, so.max_slen = h->opt_max_slen, so.query_run = h->opt_query_run, so.pass2 = h->opt_pass2;
     so.mq = h->opt_mq, so.f16 = h->opt_f16, so.band = h->opt_band, so.trace_bytes = h->opt_trace_bytes, so.n = n;
-    so.mq_cfg_call = h->mq_cfg_call, so.adapt = h->opt_adapt;
+    so.mq_cfg_call = h->mq_cfg_call, so.adapt = h->opt_adapt, so.mq_wide = h->mq_wide_call;
     // (phase 2 of a split step follows what phase 1 decided: it sees the survivor share phase 1 saw)
     if (phases & 1)
         h->plan_surv_frac = h->surv_frac;
     so.surv_frac = h->plan_surv_frac;
-    StepPlan const plan = plan_step(facts, so);
+    // Two slot regions (lx_extend_batch's multi-query plan: the pool's long windows first, the streamed ones behind them): the slots
+    // of [0, split.n1) are sized for (q1, s1), those behind for (q2, s2) -- the budget test sees the list as so many slots of the
+    // larger size
+    lx_handle::MqSplit const split = h->mq_split;
+    auto region = [&](StepPlan const & pl, uint64_t max_q, uint64_t max_s, uint32_t & steps, uint32_t & panels) -> uint64_t // dwords per slot
+    {
+        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(pl.cfg);
+        steps  = (uint32_t)((max_s + 8 - 1 + 15) & ~15ull);
+        panels = (uint32_t)std::max<uint64_t>(1, (max_q + panel - 1) / panel);
+        return (uint64_t)panels * (pl.wide ? lx::ckpt_slot_dwords(pl.cfg, steps) : lx::ckpt16_slot_dwords(pl.cfg, steps));
+    };
+    StepPlan plan{};
+    uint32_t steps1 = 0, panels1 = 0, steps2 = 0, panels2 = 0;
+    uint64_t stride1 = 0, stride2 = 0;
+    bool     split_on = false;
+    if (split.n1 != 0 && split.n1 < n && split.n1 % 16 == 0)
+    {
+        so.n = 1; // (which sweep, which slot sizes -- the budget test comes with the real footprint)
+        StepPlan const probe = plan_step(facts, so);
+        if (probe.family == kMqSweep && probe.stride != 0)
+        {
+            stride1 = region(probe, split.q1, split.s1, steps1, panels1);
+            stride2 = region(probe, split.q2, split.s2, steps2, panels2);
+            uint64_t const dw = split.n1 * stride1 + (n - split.n1 + 1) * stride2;
+            so.n     = std::max<uint64_t>(1, std::min<uint64_t>(n, dw / probe.stride));
+            StepPlan const again = plan_step(facts, so);
+            // (the same sweep, only a smaller slot count in its budget test -- anything else: one region)
+            if (again.family == kMqSweep && again.cfg == probe.cfg && again.wide == probe.wide && again.share == probe.share && steps1 <= again.steps &&
+                steps2 <= again.steps && panels1 <= again.panels && panels2 <= again.panels && dw * 4 <= so.trace_bytes)
+            {
+                plan     = again;
+                split_on = true;
+                // (room for what the sweep declines: whatever the budget leaves behind the two regions -- not capped by the slot count
+                // the budget test was given)
+                plan.ovf_cap = (plan.may_decline && plan.stride32 != 0) ? std::min<uint64_t>(n, (so.trace_bytes - dw * 4) / (plan.stride32 * 4)) : 0;
+            }
+        }
+        so.n = n;
+    }
+    if (!split_on)
+        plan = plan_step(facts, so);
     bool const     shared = plan.shared;
     bool const     sweep = plan.sweep, mq = plan.family == kMqSweep, wide_compact = plan.family == kI16CompactWide;
-    bool const     half_sweep = plan.compact, i16_sweep = plan.family == kI16Pairs, may_decline = plan.may_decline;
+    bool const     half_sweep = plan.packed, i16_sweep = plan.family == kI16Pairs, may_decline = plan.may_decline;
     int const      sweep_cfg = plan.cfg, sweep_share = plan.share;
     uint32_t const sweep_steps = plan.steps, sweep_panels = plan.panels;
     uint64_t const sweep_stride = plan.stride, sweep_stride32 = plan.stride32, ovf_cap = plan.ovf_cap;
@@ -772,7 +819,10 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     bool const     wave_slots = half_sweep && !mq && !wide_compact; // (= launch_score_pair: always one panel)
     uint64_t const wave_w     = 128 / (uint64_t)lx::trace_cfg_group(sweep_cfg); // windows of a packed-half wavefront
     // the batch's slots (+ the spare slot of the compact layouts; whole wavefronts of slots when they are interleaved)
-    uint64_t const batch_dw = wave_slots ? (n + wave_w - 1) / wave_w * wave_w * sweep_stride : half_sweep ? (n + 1) * sweep_stride : n * sweep_stride;
+    uint64_t const batch_dw = split_on     ? split.n1 * stride1 + (n - split.n1 + 1) * stride2
+                              : wave_slots ? (n + wave_w - 1) / wave_w * wave_w * sweep_stride
+                              : half_sweep ? (n + 1) * sweep_stride
+                                           : n * sweep_stride;
     if (sweep && (phases & 1))
     {
         if ((rc = ensure(h, h->d_trace, (batch_dw + ovf_cap * sweep_stride32) * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
@@ -827,6 +877,19 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.pair_share  = std::max(sweep_share, 0);
             if (mq)
             {
+                if (split_on)
+                {
+                    sp1.ckpt_stride  = stride1;
+                    sp1.steps_cap    = steps1;
+                    sp1.split_n      = split.n1;
+                    sp1.ckpt2        = p.trace + split.n1 * stride1;
+                    sp1.ckpt_stride2 = stride2;
+                    sp1.steps_cap2   = steps2;
+                    sp1.panels_cap2  = panels2;
+                }
+                sp1.wide        = plan.wide ? 1 : 0;
+                sp1.stat_beyond = h->d_ws_top + 6;
+                LX_HIP(h, hipMemsetAsync(h->d_ws_top + 6, 0, sizeof(uint32_t), stream));
                 if (sweep_share < 0) // the solo packing: rows for the alphabet's letters and the pad letter, no more
                 {
                     sp1.solo  = 1;
@@ -836,7 +899,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
                 sp1.ws         = p.ws;
                 sp1.ws_top     = p.ws_top;
                 sp1.ws_cap     = p.ws_cap;
-                sp1.panels_cap = sweep_panels;
+                sp1.panels_cap = split_on ? panels1 : sweep_panels;
                 LX_HIP(h, lx::launch_sweep_mq(sweep_cfg, sp1, stream));
                 if (sweep_panels > 1) // the fix-up launch starts with an empty carry workspace
                     LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
@@ -979,6 +1042,15 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         {
             p.ovf        = p.trace + batch_dw; // int16-pair slots of what the packed kernel declined
             p.ovf_stride = sweep_stride32;
+        }
+        if (split_on)
+        {
+            p.slot_stride  = stride1;
+            p.steps_cap1   = steps1;
+            p.split_n      = split.n1;
+            p.trace2       = p.trace + split.n1 * stride1;
+            p.slot_stride2 = stride2;
+            p.steps_cap2   = steps2;
         }
         PhaseTimer ptb(h, stream, 3);
         LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));

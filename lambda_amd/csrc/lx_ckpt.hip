@@ -589,7 +589,8 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     }
     int const ge = p.sc->ge, g2 = p.sc->g2;                 // a gap of k characters costs g2 + k ge
     int const ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go;       // tile DP: values x 4 (go = first gap character)
-    uint64_t const panel_dw = Lay::slot_dwords(p.steps_cap);
+    // (per extension since the sweep's slots may lie in two regions of different geometry: TraceParams::split_n)
+    uint64_t panel_dw = Lay::slot_dwords(p.steps_cap), panel16_dw = L16::slot_dwords(p.steps_cap), bnd_dw = Lay::bnd_dwords(p.steps_cap);
 
     // ---- state of the extension this lane is working on
     bool             have = false, blocked = false, done = false, need_col = false, scan = false, c16 = false;
@@ -646,12 +647,12 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     };
     // A query wider than one panel has one part per panel in its slot (int16 pairs or compact codes): global strip st = panel * G +
     // lane; a strip's step for row r is r + lane.
-    uint64_t const panel16_dw = L16::slot_dwords(p.steps_cap); // (compact codes: one part per panel as well)
+    // (compact codes: one part per panel as well)
     auto bnd_of = [&](uint32_t pn) { return reinterpret_cast<uint4 const *>(slot + (uint64_t)pn * (c16 ? panel16_dw : panel_dw)); };
     auto rowck_of = [&](uint32_t pn)
     {
         return reinterpret_cast<uint4 const *>(slot + (c16 ? (uint64_t)pn * panel16_dw + ck16_off
-                                                           : (uint64_t)pn * panel_dw + Lay::bnd_dwords(p.steps_cap)));
+                                                           : (uint64_t)pn * panel_dw + bnd_dw));
     };
     // Ckpt16Layout's index functions with the slots' spacing
     auto oct16_index = [&](uint32_t o, uint32_t g_) -> uint32_t { return o * oct_mul + g_; };
@@ -734,9 +735,20 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         c16                = (ec.flags & kEndCompact) != 0;
         uint32_t const ovf = (uint32_t)ec.flags >> kEndOverflowShift;
         slot               = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
+        uint32_t steps_e   = p.steps_cap;
+        if (p.split_n != 0 && !ovf)
+        {
+            bool const reg2 = se >= p.split_n;
+            steps_e         = reg2 ? p.steps_cap2 : p.steps_cap1;
+            if (reg2)
+                slot = p.trace2 + (se - p.split_n) * p.slot_stride2;
+        }
+        panel_dw           = Lay::slot_dwords(steps_e);
+        panel16_dw         = L16::slot_dwords(steps_e);
+        bnd_dw             = Lay::bnd_dwords(steps_e);
         oct_mul            = G;
         ck_mul             = G * (L16::kCkDw / 4);
-        ck16_off           = L16::bnd_dwords(p.steps_cap);
+        ck16_off           = L16::bnd_dwords(steps_e);
         if (!ovf && (ec.flags & kEndWaveSlots))
         {
             constexpr uint32_t kW = 128 / G; // windows of a packed-half wavefront
@@ -744,7 +756,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
             slot     = p.trace + (se - w) * p.slot_stride + w * (G * 4);
             oct_mul  = kW * G;
             ck_mul   = kW * G * (L16::kCkDw / 4);
-            ck16_off = (uint64_t)kW * L16::bnd_dwords(p.steps_cap) - w * (G * 4) + w * (G * L16::kCkDw);
+            ck16_off = (uint64_t)kW * L16::bnd_dwords(steps_e) - w * (G * 4) + w * (G * L16::kCkDw);
         }
         q                  = p.q_res + x.q_off;
         s                  = p.s_res + x.s_off;

@@ -78,6 +78,16 @@ struct ScoreParams
     int32_t            pair_share;     // packed-half kernel: lane groups per LDS profile (0 = the whole wavefront)
     int32_t            narrow;         // multi-query sweep: 1 = a query's last panel may run narrower strips (kEndNarrowShift)
     int32_t            solo;           // multi-query sweep: 1 = every window has a profile of its own (16 per wavefront: the small alphabets)
+    int32_t            wide;           // multi-query sweep: 1 = int16-pair slots (scores beyond the compact codes' 2046 at sweep speed)
+    uint32_t *         stat_beyond;    // multi-query sweep: optional counter of the windows that are beyond the compact codes (declined, or scoring > 2046)
+    // multi-query sweep: TWO slot regions in one launch -- extensions [0, split_n) (the plan's pool: the long merged windows) have the
+    // slots ckpt / ckpt_stride / steps_cap / panels_cap, those from split_n on (+ the spare slot n) ckpt2 / ... -- so that one launch
+    // can hold windows of very different lengths without sizing every slot for the longest.  split_n = 0: one region; else a
+    // multiple of 16 (whole wavefronts).
+    uint64_t           split_n;
+    uint32_t *         ckpt2;
+    uint64_t           ckpt_stride2;
+    uint32_t           steps_cap2, panels_cap2;
     // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
     // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
     uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)
@@ -195,6 +205,12 @@ struct TraceParams
     uint32_t *           rle_len;     // [list capacity]: code bytes of every position (0 for padding slots / no alignment)
     int32_t            bt_tile_at, bt_refill_at; // checkpoint backtrace scheduling thresholds (0 = the compiled defaults)
     uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
+    // single-sweep backtrace: the batch's slots in TWO regions (ScoreParams::split_n): extensions (original index) from split_n on
+    // have their slots at trace2 + (index - split_n) * slot_stride2, laid out for steps_cap2 steps; 0 = one region
+    uint64_t           split_n;
+    uint32_t *         trace2;
+    uint64_t           slot_stride2;
+    uint32_t           steps_cap2, steps_cap1; // steps_cap1: region 1's (steps_cap stays what the overflow slots are laid out for)
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

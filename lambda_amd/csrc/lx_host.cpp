@@ -652,6 +652,7 @@ struct XbPrep // what the host keeps about a chunk until its results are back
 {
     uint64_t              k0 = 0, k1 = 0; // positions in the ordered list
     uint64_t              slots = 0, cap_sel = 0;
+    bool                  wide = false;   // multi-query chunk: the sweep wrote int16-pair slots
     std::vector<uint32_t> slot_src;       // original index of every slot (0xffffffff = padding)
 };
 
@@ -1394,6 +1395,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             (void)hipStreamSynchronize(h->stream2);
             (void)hipStreamSynchronize(h->stream3);
             h->mq_cfg_call   = 0;
+            h->mq_wide_call  = false;
+            h->mq_split      = lx_handle::MqSplit{};
             h->opt_max_qlen  = qlen;
             h->opt_max_slen  = slen;
             h->opt_query_run = run;
@@ -1631,6 +1634,23 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         h->xb_stats[1] += slots;
         uint64_t const max_q = (max_pan + panel / 8 - 1) / (panel / 8) * panel; // (whole panels: the slots have one part per panel)
+        // a chunk that begins in the pool and goes on behind it: two slot regions
+        h->mq_split = lx_handle::MqSplit{};
+        if (!use_solo && w0 < pool_wf && pool_wf < w1)
+        {
+            uint64_t m[2][2] = {{1, 1}, {1, 1}}; // [region][columns per lane, rows]
+            for (uint64_t w = w0; w < w1; ++w)
+            {
+                int const r = w < pool_wf ? 0 : 1;
+                m[r][0]     = std::max<uint64_t>(m[r][0], wf_pan[w]);
+                m[r][1]     = std::max<uint64_t>(m[r][1], wf_maxs[w]);
+            }
+            h->mq_split.n1 = (pool_wf - w0) * kWave;
+            h->mq_split.q1 = (m[0][0] + panel / 8 - 1) / (panel / 8) * panel;
+            h->mq_split.s1 = m[0][1];
+            h->mq_split.q2 = (m[1][0] + panel / 8 - 1) / (panel / 8) * panel;
+            h->mq_split.s2 = m[1][1];
+        }
         t_prep += ms(t0, now());
 
         auto const t1 = now();
@@ -1639,8 +1659,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             (rc2 = ensure(h, ln.d_min, slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_score, slots * sizeof(int32_t))) ||
             (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) || (rc2 = ensure(h, ln.d_ops, pr.cap_sel * stride + 16)) ||
             (rc2 = ensure(h, ln.d_rle, pr.cap_sel * stride + 16)) || (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) ||
-            (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 4 * sizeof(uint64_t))) ||
-            (rc2 = ensure_pinned(h, ln.p_cnt, 4 * sizeof(uint64_t))))
+            (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 5 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_cnt, 5 * sizeof(uint64_t))))
             return rc2;
         // (a device plan: the chunk's slots are a piece of it)
         uint32_t const * const d_orig = preplanned ? ri->d_plan + w0 * kWave : static_cast<uint32_t const *>(ln.d_orig.ptr);
@@ -1657,6 +1677,12 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         h->opt_max_qlen  = max_q;
         h->opt_max_slen  = max_s;
         h->opt_query_run = use_solo ? 1 : 2; // (the solo packing: no promise; the free packing: pairs of one query, at most four queries per wavefront)
+        // Compact codes hold scores up to 2046; a window beyond them is redone by the int32 launch, one profile per pair, at a tenth
+        // of the sweep's speed.  Where the last chunks had more than a few such windows (long queries with strong hits: a 600-residue
+        // query against its homologue scores ~3 000) the sweep writes int16 pairs itself (lx_sweep_mq.hip: WIDE) -- twice the
+        // checkpoint bytes, no second launch; it goes back to the codes when fewer than 1 % of a chunk's windows need more.
+        h->mq_wide_call = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03);
+        pr.wide         = h->mq_wide_call;
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
         fx.ops_stride = stride;
@@ -1671,9 +1697,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, lx::launch_slot_scatter(d_orig, slots, static_cast<int32_t const *>(ln.d_score.ptr),
                                           static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
         LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // this chunk's error word
+        LX_HIP(h, hipMemcpyAsync(d_cnt + 4, h->d_ws_top + 6, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // ... its windows beyond the compact codes
         LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
         LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
-        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
         LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
         in_flight[L] = true;
         t_issue += ms(t1, now());
@@ -1743,6 +1770,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
 
     // ---- results of a multi-query chunk: the survivors' records and ops, addressed by caller index (the device translated the
     // list); the scores of every extension come back once, in caller order, at the end of the call
+    std::vector<std::pair<uint64_t, uint64_t>> redo; // chunks (wavefront ranges) to run again with int16-pair slots
     auto collect_mq = [&](int L) -> int
     {
         lx_handle::XbLane & ln = h->xb[L];
@@ -1755,6 +1783,18 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             uint32_t flags[2];
             std::memcpy(flags, cnt + 3, sizeof(flags));
+            if (hm.on)
+                fprintf(stderr, "[lx host ms]   chunk %llu-%llu: %llu slots%s, error word %u, %u beyond the codes, %llu survivors\n", (unsigned long long)pr.k0,
+                        (unsigned long long)pr.k1, (unsigned long long)pr.slots, pr.wide ? " (wide)" : "", flags[1], (uint32_t)cnt[4], (unsigned long long)cnt[1]);
+            if (flags[1] == 4 && !pr.wide && mq_cfg == 1 && !lx::dev_aids().mq_no_wide)
+            {
+                // More windows beyond the compact codes than the overflow area holds int16-pair slots for (its slots are sized for the
+                // chunk's longest window): the chunk runs again with int16 pairs from the sweep itself, which needs no overflow area.
+                // Nothing of this attempt is kept (the scores it scattered are written again).
+                redo.push_back({pr.k0, pr.k1});
+                h->mq_decl_frac = 1.0;
+                return LX_OK;
+            }
             int const rcf = error_for_flag(h, flags[1]);
             if (rcf)
                 return rcf;
@@ -1762,7 +1802,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         if (count > pr.cap_sel)
             return fail(h, LX_ESTATE, "survivor list longer than its capacity");
         if (pr.slots)
-            h->surv_frac = (double)cnt[1] / (double)pr.slots;
+        {
+            h->surv_frac    = (double)cnt[1] / (double)pr.slots;
+            h->mq_decl_frac = (double)(uint32_t)cnt[4] / (double)pr.slots;
+        }
         int rc2;
         if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
             (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) || (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
@@ -2037,6 +2080,22 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         bool     rows_cleared = false, stream_planned = use_solo; // (the solo plan is whole before the first chunk)
         uint64_t w0           = 0;
+        // ONE launch for the pool and what follows it (the slots in two regions: lx_handle::MqSplit): the pool is a tenth of the list
+        // in wavefronts that run up to three times as long as the others -- launched by itself it leaves most of the chip idle behind
+        // its longest windows (ragged list of bench.py: 5 000 of 37 000 wavefronts, but 5.9 of 11.8 ms), launched with the rest
+        // behind it the short wavefronts fill in.  The plan of the streamed part is then made before the first launch.
+        // (lists of up to ~200 000 windows: a dozen rounds of the chip's wavefront slots.  Beyond that the pool by itself is several
+        // rounds and the streamed part's plan is better made beside its kernels: 596 k windows 18.6 ms merged, 17.5 ms not;
+        // 64 k windows of 300-500-residue queries 11.9 ms merged, 16.3 ms not)
+        bool const merge_pool = !use_solo && !lx::dev_aids().mq_no_merge && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
+        if (merge_pool && !stream_planned)
+        {
+            auto const tp0 = now();
+            plan_stream();
+            stream_planned = true;
+            t_prep += ms(tp0, now());
+        }
+        uint64_t const pool_end = use_solo ? 0 : pool_wf; // wavefronts before it: the pool (region 1 of a chunk that spans it)
         for (;;)
         {
             if (w0 >= nwf)
@@ -2053,17 +2112,30 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is sized
             // for the chunk's widest query and longest window, plus room for the int32 overflow slots of what the sweep may
             // decline -- the chunk ends where one more wavefront would break the budget
-            uint64_t w1 = w0, pmax = 1, smax = 1;
+            uint64_t w1 = w0, pmax[2] = {1, 1}, smax[2] = {1, 1};
+            uint64_t const pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+            // (compact codes + room for the int32 overflow slots of a few declined windows; int16 pairs where the chunk may run WIDE)
+            bool const maybe_wide = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && h->mq_decl_frac > 0.01;
+            auto slot_bytes = [&](uint64_t pan, uint64_t maxs) -> uint64_t
+            {
+                uint64_t const steps = (maxs + 8 - 1 + 15) & ~15ull;
+                return (pan + pc - 1) / pc * (maybe_wide ? lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8
+                                                         : lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
+            };
             while (w1 < nwf && w1 - w0 < per_chunk)
             {
-                uint64_t const p2 = std::max<uint64_t>(pmax, wf_pan[w1]), s2 = std::max<uint64_t>(smax, wf_maxs[w1]);
-                uint64_t const steps  = (s2 + 8 - 1 + 15) & ~15ull;
-                uint64_t const pc     = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
-                uint64_t const stride = (p2 + pc - 1) / pc * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
-                if (w1 > w0 && (w1 + 1 - w0) * kWave * stride > h->opt_trace_bytes)
+                if (!merge_pool && w0 < pool_end && w1 == pool_end)
+                    break; // (A/B aid: the pool in chunks of its own, as before)
+                int const      r = w1 < pool_end ? 0 : 1; // the region this wavefront's slots lie in
+                uint64_t const p2 = std::max<uint64_t>(pmax[r], wf_pan[w1]), s2 = std::max<uint64_t>(smax[r], wf_maxs[w1]);
+                uint64_t const n1 = w0 < pool_end ? std::min(w1 + 1, pool_end) - w0 : 0, n2 = w1 + 1 - w0 - n1;
+                uint64_t const bytes = n1 * kWave * slot_bytes(r == 0 ? p2 : pmax[0], r == 0 ? s2 : smax[0]) + n2 * kWave * slot_bytes(r == 1 ? p2 : pmax[1], r == 1 ? s2 : smax[1]);
+                // ... and the survivors' ops slots, one size per chunk: its widest query + its longest window
+                uint64_t const ops = (w1 + 1 - w0) * kWave * (std::max(p2, std::max(pmax[0], pmax[1])) * 8 + std::max(s2, std::max(smax[0], smax[1])));
+                if (w1 > w0 && (bytes > h->opt_trace_bytes || ops > (8ull << 30)))
                     break;
-                pmax = p2;
-                smax = s2;
+                pmax[r] = p2;
+                smax[r] = s2;
                 ++w1;
             }
             int const L = c & 1;
@@ -2093,6 +2165,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         for (int L : {c & 1, (c & 1) ^ 1})
             if (in_flight[L] && (rc = collect_mq(L)))
                 return rc;
+        while (!redo.empty()) // (one at a time; a WIDE chunk cannot ask again)
+        {
+            auto const r = redo.back();
+            redo.pop_back();
+            if ((rc = enqueue_mq(0, r.first, r.second)) || (rc = collect_mq(0)))
+                return rc;
+            ++c;
+        }
         // the scores of every extension, in caller order
         {
             auto const ts0 = now();

@@ -181,6 +181,12 @@ struct lx_handle
     bool        count_pending    = false;
     double      plan_surv_frac   = -1.0;   // the share phase 1 of the current step planned with (phase 2 follows it)
     uint64_t    opt_adapt        = 30;     // LX_OPT_ADAPT_PERMILLE
+    struct MqSplit // lx_extend_batch: the chunk's slots lie in two regions -- [0, n1) sized for (q1, s1), the rest for (q2, s2); n1 = 0: one region
+    {
+        uint64_t n1 = 0, q1 = 0, s1 = 0, q2 = 0, s2 = 0;
+    } mq_split;
+    bool     mq_wide_call  = false; // lx_extend_batch: this chunk's sweep writes int16-pair slots (many windows of the last chunks scored beyond the compact codes)
+    double   mq_decl_frac  = 0.0;   // ... the share of the last multi-panel chunk's windows that the compact sweep declined
     int      mq_cfg_call   = 0; // lx_extend_batch: the strip geometry (trace cfg) it chose for this call's chunks (0 = fused_impl picks per chunk)
     uint64_t opt_extend_chunk = 0; // LX_OPT_EXTEND_CHUNK: extensions per chunk of lx_extend_batch's pipeline (0 = default)
     uint64_t opt_band      = 0; // LX_OPT_BAND: half width in diagonals, 0 = full rectangle (the reference's BandOff)
@@ -298,6 +304,7 @@ struct StepOptions
 {
     uint64_t max_qlen = 0, max_slen = 0, query_run = 0, pass2 = 2, mq = 1, f16 = 1, band = 0, trace_bytes = 0, n = 0, adapt = 0;
     int      mq_cfg_call = 0;
+    bool     mq_wide     = false; // the multi-query sweep writes int16-pair slots (lx_sweep_mq.hip: WIDE)
     double   surv_frac   = -1.0;
 };
 enum SweepFamily
@@ -312,6 +319,8 @@ enum SweepFamily
 struct StepPlan
 {
     bool        shared = false, sweep = false, adapted = false, compact = false, may_decline = true;
+    bool        packed = false; // a packed sweep's launch structure: a spare slot behind the batch's, an overflow area for what it declines
+    bool        wide   = false; // the multi-query sweep with int16-pair slots
     SweepFamily family = kNoSweep;
     int         cfg = 0, share = 0;
     uint32_t    steps = 0, panels = 1;

@@ -73,6 +73,10 @@ struct MqGeo
     static constexpr int kN4 = kD / 4, kN2 = (kD % 4) / 2, kN1 = kD % 2;
     static constexpr int kBase2 = 4 * G * kN4, kBase1 = kBase2 + 2 * G * kN2;
     static_assert(kD <= 7, "at most 28 columns per strip");
+    // int16-pair slots (the layout of lx_ckpt.hip's CkptLayout<G, C>, what the int32 kernel writes): WIDE sweeps
+    static constexpr int kCkDwW = (C + 3) / 4 * 4;
+    __host__ __device__ static constexpr uint64_t bnd_dwords_w(uint32_t steps_cap) { return (uint64_t)steps_cap * G; }
+    __host__ __device__ static constexpr uint64_t slot_dwords_w(uint32_t steps_cap) { return bnd_dwords_w(steps_cap) + (uint64_t)(steps_cap / 16) * G * kCkDwW; }
     __host__ __device__ static constexpr int dw_index(int d, int g)
     {
         return d < 4 * kN4 ? g * 4 + d : d < 4 * kN4 + 2 * kN2 ? kBase2 + g * 2 + (d - 4 * kN4) : kBase1 + g;
@@ -83,7 +87,10 @@ struct MqGeo
 
 // MULTI: queries wider than one panel -- the panels are swept one after the other, the (A, E) pair of the last strip per
 // subject row goes through lx_score.hip's carry workspace, every panel writes its own part of the extension's slot.
-template <int C, bool MULTI>
+// WIDE: the slots hold int16 pairs (the int32 kernel's layout) instead of the compact codes: scores up to the 16-bit patterns'
+// range (29 695) at sweep speed -- long queries with strong hits, whose windows score beyond the codes' 2046 (a 600-residue
+// query against its homologue: ~3 000) and would otherwise be redone one by one by the int32 launch.
+template <int C, bool MULTI, bool WIDE = false>
 __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
 {
     using Geo = MqGeo<C>;
@@ -103,6 +110,12 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     uint64_t const pair = (uint64_t)blockIdx.x * Geo::kGroups + grp;
     uint64_t const eA   = 2 * pair, eB = 2 * pair + 1;
     bool const     actA = eA < p.n, actB = eB < p.n;
+
+    // the slot region of this wavefront (ScoreParams::split_n: wave-uniform, the split is a multiple of 16)
+    bool const       reg2       = p.split_n != 0 && eA >= p.split_n;
+    uint32_t const   steps_cap  = reg2 ? p.steps_cap2 : p.steps_cap, panels_cap = reg2 ? p.panels_cap2 : p.panels_cap;
+    uint32_t * const ckpt_base  = reg2 ? p.ckpt2 : p.ckpt;
+    uint64_t const   ckpt_step  = reg2 ? p.ckpt_stride2 : p.ckpt_stride, ckpt_first = reg2 ? p.split_n : 0;
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge    = sc->ge;
@@ -241,9 +254,9 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         boundB += __shfl_xor(boundB, off);
     }
     bound = max(bound, boundB);
-    bool const broken  = (lq_max > (MULTI ? (int)p.panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > p.steps_cap;
+    bool const broken  = (lq_max > (MULTI ? (int)panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > steps_cap;
     // (free packing with a fifth query: declined as a whole -- the int32 launch shares profiles by pairs and copes)
-    bool const too_big = broken || too_many || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > (MULTI ? kMqLimit : 2046)) != 0 ||
+    bool const too_big = broken || too_many || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > ((MULTI || WIDE) ? kMqLimit : 2046)) != 0 ||
                          (-ge) * (G + 2) + (-sc->g2) * 2 + 256 > kMqBias;
     if (too_big)
     {
@@ -265,6 +278,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 p.out_score[eB] = -1;
                 p.ends[eB]      = none;
             }
+            if (p.stat_beyond && actA)
+                atomicAdd(p.stat_beyond, actB ? 2u : 1u);
         }
         return;
     }
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
     uint32_t const     slot_dw   = (uint32_t)(solo_mode ? 2 * grp : blk) * (uint32_t)(nrows * Geo::kRowDw);
     uint32_t const     slot_dwB  = (solo_mode && actB) ? slot_dw + (uint32_t)(nrows * Geo::kRowDw) : slot_dw;
     uint32_t const     slot_byte = slot_dw * 4u, slot_byteB = slot_dwB * 4u;
-    uint64_t const     panel_dw  = L16::slot_dwords(p.steps_cap);
+    uint64_t const     panel_dw  = WIDE ? Geo::slot_dwords_w(steps_cap) : L16::slot_dwords(steps_cap);
     uint32_t * const   stage     = lds + nslots * (nrows * Geo::kRowDw) + lane; // [step % 8][lane]: lane-minor, conflict-free
 
     q2 const GE = qsplat(ge), G2 = qsplat(sc->g2), NGE = qsplat(-ge);
@@ -432,8 +447,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
         bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
         // (an idle half owns the spare slot p.n -- the stores are unconditional)
-        uint32_t * const slotA = p.ckpt + (actA ? eA : p.n) * p.ckpt_stride + (uint64_t)panel * panel_dw;
-        uint32_t * const slotB = p.ckpt + (actB ? eB : p.n) * p.ckpt_stride + (uint64_t)panel * panel_dw;
+        uint32_t * const slotA = ckpt_base + ((actA ? eA : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
+        uint32_t * const slotB = ckpt_base + ((actB ? eB : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
 
         q2 Z = qsplat(ge * g + kMqBias); // z_i of the first processed row i = -g, biased
         q2 Arow[C], F0[C];               // A = H + (go - ge) of the previous row (its frame), folded F of this row
@@ -553,7 +568,15 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             cmax = qmax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
             // Ckpt16Layout codes of both extensions: H | (H - E) << 11
-            stage[((k & 4) + u) * 64] = (qbits(h - Ecur) << 11) | qbits(h - Z);
+            if constexpr (WIDE)
+            {
+                // ... as int16 pairs (H, E), re-paired per extension
+                q2 const hb = h - Z, eb = Ecur - Z;
+                stage[u * 64]       = __builtin_amdgcn_perm(qbits(eb), qbits(hb), 0x05040100u);
+                stage[(4 + u) * 64] = __builtin_amdgcn_perm(qbits(eb), qbits(hb), 0x07060302u);
+            }
+            else
+                stage[((k & 4) + u) * 64] = (qbits(h - Ecur) << 11) | qbits(h - Z);
             Z = ZN;
         };
         // the staged codes of the eight steps up to k0 + 3 leave, re-paired per extension (whole 128-byte lines per lane
@@ -576,11 +599,38 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             // Arow - (go - ge) = H is in the frame of the row just processed (z_i = Z + ge after the update), F0 in the next
             // row's:  H - F un-skewed = (H - z_i) - (F0 - Z) = H - F0 - ge
             q2 const ziA = Z + GE + G2, geA = GE + G2;
+            if constexpr (WIDE)
+            {
+                // int16 pairs (H, folded F), one dword per column and extension (lx_ckpt.hip: rowck_quad_index, lane-major)
+                uint64_t const base = Geo::bnd_dwords_w(steps_cap) / 4 + ((uint64_t)((k0 + 3) / 16) * G + (uint64_t)g) * (Geo::kCkDwW / 4);
+                uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
+#pragma unroll
+                for (int x = 0; x < Geo::kCkDwW / 4; ++x)
+                {
+                    uint32_t wa[4], wb[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                    {
+                        int const c = 4 * x + b;
+                        if (c < CE)
+                        {
+                            q2 const hu = Arow[c < CE ? c : 0] - ziA, fu = F0[c < CE ? c : 0] - Z;
+                            wa[b] = __builtin_amdgcn_perm(qbits(fu), qbits(hu), 0x05040100u);
+                            wb[b] = __builtin_amdgcn_perm(qbits(fu), qbits(hu), 0x07060302u);
+                        }
+                        else
+                            wa[b] = wb[b] = 0;
+                    }
+                    dA[x] = make_uint4(wa[0], wa[1], wa[2], wa[3]);
+                    dB[x] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+                }
+                return;
+            }
             uint32_t code[2 * L16::kCkDw];
 #pragma unroll
             for (int c = 0; c < 2 * L16::kCkDw; ++c)
                 code[c] = c < CE ? ((qbits((Arow[c < CE ? c : 0] - F0[c < CE ? c : 0]) - geA) << 11) | qbits(Arow[c < CE ? c : 0] - ziA)) : 0u;
-            uint32_t const base = (uint32_t)(L16::bnd_dwords(p.steps_cap) / 4);
+            uint32_t const base = (uint32_t)(L16::bnd_dwords(steps_cap) / 4);
             uint4 * const  dA = reinterpret_cast<uint4 *>(slotA) + base, * const dB = reinterpret_cast<uint4 *>(slotB) + base;
 #pragma unroll
             for (int x = 0; x < L16::kCkDw / 4; ++x)
@@ -614,7 +664,14 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
             best = nb;
             cmax = qsplat(0);
-            if (k0 & 4)
+            if constexpr (WIDE)
+            {
+                // the four steps' boundary pairs leave as one quad per extension (lx_ckpt.hip: bnd_quad_index)
+                uint32_t const qi = ((uint32_t)k0 / 4) * G + (uint32_t)g;
+                reinterpret_cast<uint4 *>(slotA)[qi] = make_uint4(stage[0], stage[64], stage[128], stage[192]);
+                reinterpret_cast<uint4 *>(slotB)[qi] = make_uint4(stage[256], stage[320], stage[384], stage[448]);
+            }
+            else if (k0 & 4)
                 flush_codes(k0);
             if constexpr (MULTI)
             {
@@ -738,7 +795,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         }
         if (steps != 0 && (steps & 15) == 0)
             rowck_codes(steps - 4);
-        if (steps & 4)
+        if (!WIDE && (steps & 4))
             flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
 
         // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first).
@@ -790,7 +847,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         if (is_first && act)
         {
             EndCell ec{};
-            bool const declined = MULTI && run > 2046; // beyond what the codes hold: the int32 launch redoes it
+            bool const declined = MULTI && !WIDE && run > 2046; // beyond what the codes hold: the int32 launch redoes it
             if (!writable || declined)
                 ec.score = -1;
             else if (run > 0)
@@ -798,10 +855,12 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 ec.score = run;
                 ec.q_end = -(rstrip + 1); // the backtrace finds the column inside this strip
                 ec.s_end = rrow + 1;
-                ec.flags = (rtie ? kEndAmbiguous : 0) | kEndCompact | (code << kEndNarrowShift);
+                ec.flags = (rtie ? kEndAmbiguous : 0) | (WIDE ? 0 : kEndCompact) | (code << kEndNarrowShift);
             }
             p.ends[e]      = ec;
             p.out_score[e] = (writable && !declined) ? run : -1;
+            if (p.stat_beyond && run > 2046) // (what decides between compact codes and int16 pairs for the next chunks: lx_host.cpp)
+                atomicAdd(p.stat_beyond, 1u);
         }
     };
     finish(runA, stripA, rrowA, rtieA, actA, eA, my_code);
@@ -814,10 +873,18 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
     using Geo = MqGeo<C>;
     uint64_t const blocks = (p.n + 2ull * Geo::kGroups - 1) / (2ull * Geo::kGroups);
     int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
-    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0)
+    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0 ||
+        (p.split_n != 0 && (p.split_n % 16 != 0 || p.split_n > p.n || !p.ckpt2 || p.steps_cap2 % 16 != 0)))
         return hipErrorInvalidValue;
     size_t const lds = ((size_t)(p.solo ? 2 * Geo::kGroups : p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
-    if (p.panels_cap > 1)
+    if (p.wide)
+    {
+        if constexpr (C == 19)
+            hipLaunchKernelGGL((sweep_mq_kernel<C, true, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
+        else
+            return hipErrorInvalidValue; // (int16-pair slots: the 19-column strips only)
+    }
+    else if (p.panels_cap > 1 || (p.split_n != 0 && p.panels_cap2 > 1))
         hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((sweep_mq_kernel<C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);

@@ -463,3 +463,48 @@ def test_host_plan_solo_on_read_lists(handle, oracle, scheme):
             done += (int(codes[c]) & 63) + 1
             c += 1
         assert capi.Handle.expand_ops(codes[int(off[k]): c], n_ops) == oops
+
+
+def test_host_plan_wide_slots_for_long_strong_hits(handle, oracle):
+    """Long queries whose homologous windows score beyond the compact codes' 2046 (500-800 residues, half of the windows):
+    the first call learns it from the sweep's own count and its later chunks / the next calls run the WIDE form of the multi-query
+    sweep -- int16-pair slots, no int32 launch for these windows --; scores, end cells and ops stay the oracle's in both forms, and a
+    list of ordinary windows goes back to the codes."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q, s, ext = synth.make_ragged_lists_np(400, seed=5, lq_range=(500, 800), mean_windows=8.0)
+    handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 1024)  # several chunks per call
+    try:
+        names = []
+        for rep in range(2):
+            names.append(_check_host_list(handle, oracle, q, s, ext, 91, sample=150))
+        assert "sweep_mq_kernel<19,true,true>" in names[1], names
+        score = handle.extend_batch_list(q, s, ext, 91)[0]
+        assert (score > 2046).mean() > 0.2 and score.max() > 2500
+        # ordinary windows again: two calls later the codes are back
+        q2, s2, e2 = synth.make_ragged_lists_np(200, seed=6, lq_range=(160, 400), mean_windows=6.0)
+        back = [_check_host_list(handle, oracle, q2, s2, e2, 60, sample=100) for _ in range(2)]
+        assert "sweep_mq_kernel<19,true>" in back[1] and "true,true" not in back[1], back
+    finally:
+        handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
+
+
+def test_overflow_area_exhausted_runs_the_chunk_again_with_wide_slots(handle, oracle):
+    """A tight slot budget and a list whose windows mostly score beyond the compact codes: the overflow area (sized for an eighth of a
+    chunk) runs out of int16-pair slots, and the chunk is run again with int16 pairs from the sweep itself instead of failing the
+    call (round 3: LX_EOVERFLOW)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    q2, s2, e2 = synth.make_ragged_lists_np(200, seed=6, lq_range=(160, 400), mean_windows=6.0)
+    for _ in range(2):  # (the handle forgets what earlier tests taught it about strong hits)
+        _check_host_list(handle, oracle, q2, s2, e2, 60, sample=50)
+    q, s, ext = synth.make_ragged_lists_np(300, seed=15, lq_range=(500, 700), mean_windows=8.0)
+    q[:] = 22  # tryptophan everywhere: every window scores 11 x min(Lq, Ls) > 2046
+    s[:] = 22
+    handle.set_option(capi.LX_OPT_TRACE_BYTES, 600 << 20)
+    try:
+        name = _check_host_list(handle, oracle, q, s, ext, 91, sample=60)
+    finally:
+        handle.set_option(capi.LX_OPT_TRACE_BYTES, 64 << 30)
+    # (the chunk that ran out is run again -- with int16 pairs from the sweep where they fit the budget, else on the per-survivor path)
+    assert "sweep_mq_kernel<19,true>" not in name or "true,true" in name, name

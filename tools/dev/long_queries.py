@@ -9,6 +9,7 @@ from lambda_amd import capi, synth
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (500, 800)
 h = capi.Handle(0)
 h.set_scoring(capi.builtin_scoring(62), 0)
+h.set_option(capi.LX_OPT_TRACE_BYTES, 160 << 30)  # (as bench.py: the slots of such a list in one chunk need ~70 GB of the 288)
 q, s, ext = synth.make_ragged_lists_np(8000, seed=5, lq_range=(lo, hi), mean_windows=8.0)
 cells = float((ext["q_len"].astype(np.float64) * ext["s_len"]).sum())
 h.set_subjects(s)
