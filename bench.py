@@ -203,23 +203,28 @@ def kernel_instantiation(name: str) -> str:
     return (base + (m.group(2) or "")).replace(" ", "")
 
 
-def pmc_traffic(kernel_name: str):
+def pmc_traffic(kernel_name: str, command_has: str | None = None):
     """HBM bytes per launch of ONE kernel instantiation (kernel_name in the library's or rocprofv3's spelling, compared by
     `kernel_instantiation`: full template argument list, not a substring) from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json, newest name first): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950
     correction in MI355X_MICROARCH.md.  PMC counters cannot be read from inside a timed run, so this is the figure of the
     profiled run of the same command.  Returns (bytes or None, note); files of another shape (no "kernels" table) are skipped
-    and a file that cannot be read is NAMED in the note instead of being swallowed."""
+    and a file that cannot be read is NAMED in the note instead of being swallowed.  `command_has`: only profiles of a command line
+    that contains it (the secondary lines: "--ragged", "--host-path"); None: only profiles of the default command."""
     want = kernel_instantiation(kernel_name)
     skipped = []
     for f in sorted((ROOT / "profiles").glob("*_pmc.json"), reverse=True):
         try:
-            kernels = json.loads(f.read_text()).get("kernels")
+            doc = json.loads(f.read_text())
+            kernels = doc.get("kernels")
         except Exception as e:  # unreadable / not JSON: say so, go on to the older profiles
             skipped.append(f"{f.name}: {type(e).__name__}: {e}")
             continue
         if not isinstance(kernels, dict):
             continue  # a profile of something else (e.g. the front end's seeding kernel): no per-kernel table
+        cmd = str(doc.get("command", ""))
+        if (command_has is None and any(k in cmd for k in ("--ragged", "--host-path", "--iterate"))) or (command_has is not None and command_has not in cmd):
+            continue  # the profile of another workload
         for name, d in kernels.items():
             if not isinstance(d, dict) or kernel_instantiation(name) != want:
                 continue
@@ -350,6 +355,13 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
         step()
     dt = time.perf_counter() - t0
     survivors = sum(counts) if args.entry == "list" else sum(int((k[1]["n_ops"] > 0).sum()) for k in keep)
+    # the sweep of the LAST call of the last step (the library's HIP events around every launch of the call: lx_last_phase_ms sums a
+    # call's chunks), its executed cells (lx_last_extend_stats) and its algorithmic bytes
+    st_last = h.last_extend_stats()
+    sweep_ms, sweep_launches = h.last_phase_ms(0)
+    bt_ms, bt_launches = h.last_phase_ms(3)
+    sweep_name = h.last_kernel_name()
+    last_slot, last_q, last_ext = parts[-1]
     tot = torch.tensor([dt, cells_rank, float(sum(len(e) for _, _, e in parts)), float(survivors)], dtype=torch.float64, device=dev)
     if use_dist:
         mx = tot.clone()
@@ -379,8 +391,10 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
                        "step": f"lx_extend_batch per device call: host grouping + padding -> chunk pipeline (upload, single sweep, selection, "
                                f"backtrace, run-length ops) -> scores, records and ops back in the caller's arrays; cut-off score>={min_score}"},
             "alignments_per_s": round(total_ext * args.steps / dt, 1), "traced_per_s": round(total_surv * args.steps / dt, 1),
-            "roofline": None, "cpu_baseline": None,
-            "note": "secondary line: the kernels are those of the headline line (see its roofline); this one prices the boundary a binding crosses",
+            "roofline": host_roofline(args, sweep_name, sweep_ms, sweep_launches, bt_ms, bt_launches, st_last, last_q, last_ext),
+            "cpu_baseline": host_cpu_baseline(args, w, last_q, np.concatenate(s_all), last_ext) if (world == 1 and not args.no_cpu_baseline) else None,
+            "note": "secondary line: this one prices the boundary a binding crosses; its roofline is the sweep of the last device call of the step "
+                    "(all its launches), on the cells of the list and on the cells the wavefronts execute (padding included)",
         }), flush=True)
     h.close()
     if use_dist:
@@ -468,6 +482,63 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
     h.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext):
+    """Roofline of the sweep of ONE host-buffer call (all its launches: a call is a pipeline of chunks): integer-VALU bound as the headline
+    line's; `achieved` counts the LIST's cells (10 algorithmic ops each), `frac_executed` what the wavefronts execute
+    (padded columns and rows included: lx_last_extend_stats) -- the distance between the two is the padding of the plan."""
+    if ms <= 0:
+        return None
+    cells, executed = float(st[2]), float(st[3])
+    packed = "pair" in kernel or "sweep_mq" in kernel
+    peak = PEAK_PACKED16_TOPS if packed else PEAK_INT32_TOPS
+    tops = cells / (ms * 1e-3) * ALGO_OPS_PER_CELL / 1e12
+    tops_x = executed / (ms * 1e-3) * ALGO_OPS_PER_CELL / 1e12
+    # algorithmic bytes (SURVEY.md section 8d): every window once, every query once, one 24-byte record + one score per extension
+    qkeys = np.unique(ext["q_off"])
+    algo = float(ext["s_len"].sum()) + float(len(q) if len(qkeys) else 0) + len(ext) * ALGO_BYTES_PER_EXT_EXTRA
+    flag = "--ragged" if args.ragged else "--host-path"
+    # (the PMC passes profile the kernel instantiation the sweep ran as; its name in the library's spelling ends at the first blank)
+    traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag)
+    ceil = issue_ceiling() if packed else None
+    return {
+        **({"issue_ceiling_frac": ceil["issue_ceiling_frac"]} if ceil else {}),
+        "bound": "valu", "kernel": kernel, "achieved": round(tops, 3), "peak": round(peak, 2),
+        "unit": "Tops/s (%s lane-ops; 10 algorithmic ops per cell of the list)" % ("packed 16-bit" if packed else "int32"),
+        "frac": round(tops / peak, 4), "frac_executed": round(tops_x / peak, 4),
+        "kernel_ms_per_call": round(ms, 4), "launches_per_call": launches, "kernel_gcups": round(cells / (ms * 1e-3) / 1e9, 1),
+        "kernel_gcups_executed": round(executed / (ms * 1e-3) / 1e9, 1), "cells_per_call": cells, "executed_cells_per_call": executed,
+        "backtrace_ms_per_call": round(bt_ms, 4), "backtrace_launches_per_call": bt_launches,
+        "hbm": {"bound": "hbm", "algorithmic_bytes_per_call": algo, "achieved": round(algo / (ms * 1e-3) / 1e9, 2), "peak": 8000, "unit": "GB/s",
+                "frac": round(algo / (ms * 1e-3) / 1e9 / 8000, 5)},
+        "traffic": traffic, "traffic_over_algorithmic": round(traffic / algo, 2) if traffic else None, "traffic_note": note,
+    }
+
+
+def host_cpu_baseline(args, w, q, s, ext):
+    """The oracle's inter-sequence int16 SIMD scorer on a bounded sample of the SAME list (its first queries' windows, ~20 Gcells), on this
+    box's host cores."""
+    from lambda_amd import capi
+    from tests import oracle_lib
+
+    cores, note = usable_cpus()
+    orc = oracle_lib.load()
+    d = w.directions[0]
+    m, ma, mi, go, ge = d.scoring
+    sc = oracle_lib.scoring_from(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge))
+    cum = np.cumsum(ext["q_len"].astype(np.float64) * ext["s_len"])
+    k = int(np.searchsorted(cum, 20e9)) + 1
+    sample = np.ascontiguousarray(ext[:k])
+    cells = float(cum[min(k, len(cum)) - 1])
+    best = float("inf")
+    for _ in range(2):
+        t0 = time.perf_counter()
+        orc.score_batch(q, s, sample, sc, threads=cores, simd=True)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(cells / best / 1e9, 3), "unit": "GCUPS", "cores": cores, "kind": "port",
+            "sample": f"the first {len(sample)} extensions of this list ({cells / 1e9:.2f} Gcells), oracle inter-sequence int16 SIMD restatement (NOT SeqAn), "
+                      f"OpenMP with {cores} threads ({note}), best of 2, {best:.3f} s"}
 
 
 class DevBatch:

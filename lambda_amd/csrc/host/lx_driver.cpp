@@ -432,11 +432,34 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     if (!h || !out || !params || (!matches && n_matches))
         return LX_EINVAL;
     *out = nullptr;
-    for (uint64_t i = 0; i < n_matches; ++i)
-        if (matches[i].qryId >= n_qseq || matches[i].subjId >= n_sseq)
-            return LX_EINVAL;
+    {
+        std::vector<uint8_t> bad(std::max(1u, lxi::pool_width()), 0);
+        lambda_amd::parallelRanges(n_matches,
+                                   [&](unsigned t, uint64_t lo, uint64_t hi)
+                                   {
+                                       for (uint64_t i = lo; i < hi; ++i)
+                                           if (matches[i].qryId >= n_qseq || matches[i].subjId >= n_sseq)
+                                               bad[t] = 1;
+                                   });
+        for (uint8_t b : bad)
+            if (b)
+                return LX_EINVAL;
+    }
     auto res = new lx_iterate_result();
     int  rc;
+    // a large list: widen, sort, merge and unique on the device, like lx_iterate_matches_dev (the same records either way)
+    rc = lxi::iterate_host_list_on_device(h, slot, q_res, q_bytes, q_seq_off, q_seq_len, n_qseq, q_orig_len, s_res, s_bytes, s_seq_off, s_seq_len, n_sseq, matches,
+                                          n_matches, params, res);
+    if (rc != lxi::kNotTaken)
+    {
+        if (rc != LX_OK)
+        {
+            delete res;
+            return rc;
+        }
+        *out = res;
+        return LX_OK;
+    }
     // band mode for the duration of the call (default centres: the windows are built here, by _widenMatch's rule)
     uint64_t bandBefore = 0;
     (void)lx_get_option(h, LX_OPT_BAND, &bandBefore);

@@ -67,6 +67,19 @@ struct lx_iterate_result
     lx_iterate_stats                   stats{};
 };
 
+// lx_level2_host.cpp: lx_iterate_matches' large lists go to the Level-2 kernels -- the sequence sets become resident (once: a later
+// call with the same sets finds them there), the matches go up as sort words (16 bytes each instead of 48), the window list comes
+// back into `matches` (the span the reference shrinks).  Returns kNotTaken when the call is not one the device path serves (small
+// lists, band mode, subjects that are not resident): the caller then runs the host form.
+namespace lxi
+{
+constexpr int kNotTaken = 1;
+int iterate_host_list_on_device(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off, uint64_t const * q_seq_len,
+                                uint64_t n_qseq, uint64_t const * q_orig_len, uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off,
+                                uint64_t const * s_seq_len, uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                                lx_iterate_result * res);
+} // namespace lxi
+
 namespace lambda_amd
 {
 

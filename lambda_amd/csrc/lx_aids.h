@@ -31,6 +31,7 @@ struct DevAids
     bool     mq_no_wide;        // LX_MQ_NO_WIDE         multi-query sweep: compact codes always (what scores beyond them goes to the int32 launch)  off
     bool     mq_no_merge;       // LX_MQ_NO_MERGE        lx_extend_batch: the pool's wavefronts in launches of their own (no two-region chunk)  off
     uint64_t mq_merge_below;    // LX_MQ_MERGE_BELOW     lx_extend_batch: lists of at most this many windows launch the pool with the rest (0 = 200 000)  0
+    bool     iterate_on_host;   // LX_ITERATE_ON_HOST    lx_iterate_matches: widen / sort / merge on the host threads whatever the list's size  off
     bool     extend_no_mq;      // LX_EXTEND_NO_MQ       lx_extend_batch: ragged lists on the one-query-per-wavefront kernels      off
     uint64_t extend_run;        // LX_EXTEND_RUN         lx_extend_batch: pad query runs to 8 or 16 slots (0 = by estimated work)  0
     uint64_t extend_chunk;      // LX_EXTEND_CHUNK       default of LX_OPT_EXTEND_CHUNK (extensions per pipeline chunk)    640 Ki

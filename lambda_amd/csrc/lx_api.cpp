@@ -50,6 +50,7 @@ lx::DevAids const & lx::dev_aids()
         a.mq_no_solo        = set("LX_MQ_NO_SOLO");
         a.mq_no_wide        = set("LX_MQ_NO_WIDE");
         a.mq_no_merge       = set("LX_MQ_NO_MERGE");
+        a.iterate_on_host   = set("LX_ITERATE_ON_HOST");
         a.mq_merge_below    = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
         a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
@@ -744,8 +745,11 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
 
     if (phases & 1)
     {
-        h->phase_ev.clear();
-        h->ev_pool_used = 0;
+        if (!h->keep_phase_events) // (lx_extend_batch's pipeline collects the events of all its chunks)
+        {
+            h->phase_ev.clear();
+            h->ev_pool_used = 0;
+        }
         LX_HIP(h, hipEventRecord(h->ev0, stream));
     }
     // how this step runs: plan_step() decides, this function follows

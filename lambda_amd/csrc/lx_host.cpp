@@ -1385,12 +1385,16 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     hm.mark("plan");
 
     // ---- the caller's option values come back on every exit; the streams are drained before anything is torn down
+    h->phase_ev.clear();
+    h->ev_pool_used      = 0;
+    h->keep_phase_events = true;
     struct Guard
     {
         lx_handle * h;
         uint64_t    qlen, slen, run;
         ~Guard()
         {
+            h->keep_phase_events = false;
             (void)hipStreamSynchronize(h->stream);
             (void)hipStreamSynchronize(h->stream2);
             (void)hipStreamSynchronize(h->stream3);

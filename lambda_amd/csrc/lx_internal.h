@@ -201,6 +201,7 @@ struct lx_handle
     {
         std::vector<uint64_t> q_off, s_off, s_len;
         std::vector<uint32_t> q_len, q_evlen, evlens; // evlens: the distinct e-value lengths of the query set
+        uint64_t              q_hash = 0, s_hash = 0, dup_before = 0; // content hashes of the sets lx_iterate_matches made resident; hits_duplicate before the last list
         uint64_t              q_bytes = 0, max_slen = 0, s_extent = 0; // s_extent: where the last subject ends in the residue buffer
         uint32_t              max_evlen = 0;
         int                   q_frames  = 1;
@@ -212,6 +213,7 @@ struct lx_handle
         std::vector<uint32_t>     wf_pan, wf_maxs; // a device plan's wavefronts
         hipEvent_t                ev_win = nullptr; // the window list has arrived on the host
     } l2;
+    bool     keep_phase_events = false; // lx_extend_batch: the phase events of every chunk of the call stay (lx_last_phase_ms sums them)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
 };
 
@@ -259,7 +261,7 @@ struct PhaseTimer
     hipEvent_t  a = nullptr, b = nullptr;
     PhaseTimer(lx_handle * h_, hipStream_t s_, int phase_) : h(h_), s(s_), phase(phase_)
     {
-        if (h->phase_ev.size() < 64)
+        if (h->phase_ev.size() < 512)
         {
             a = pool_event(h);
             b = pool_event(h);

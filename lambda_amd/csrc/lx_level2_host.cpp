@@ -80,6 +80,7 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
     auto & l2   = h->l2;
     int const f = std::max(1, qry_num_frames);
     l2.q_bytes  = 0; // (nothing resident until everything is)
+    l2.q_hash   = 0; // (lx_iterate_matches knows the content of what IT made resident, nothing else's)
     l2.q_off.assign(q_seq_off, q_seq_off + n_qseq);
     l2.q_len.resize(n_qseq);
     l2.q_evlen.resize(n_qseq);
@@ -125,6 +126,7 @@ int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t cons
     if (rc)
         return rc;
     auto & l2 = h->l2;
+    l2.s_hash = 0;
     l2.s_off.assign(s_seq_off, s_seq_off + n_sseq);
     l2.s_len.assign(s_seq_len, s_seq_len + n_sseq);
     l2.max_slen = l2.s_extent = 0;
@@ -237,6 +239,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     uint64_t nw = 0, nEven = 0;
     if ((rc = level2_windows(h, n_matches, params->bisulfite != 0, table, nw, nEven)))
         return rc;
+    l2.dup_before = res->stats.hits_duplicate;
     res->stats.hits_duplicate += n_matches - nw;
     hm.mark("sort+merge");
     if (nw == 0)
@@ -366,6 +369,136 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     }
     if (params->bisulfite) // the HSPs are stably re-sorted by query (:1379); the ops offsets stay valid: only the records move
         std::stable_sort(res->matches.begin(), res->matches.end(), [](lx_blast_match const & a, lx_blast_match const & b) { return a.n_qid < b.n_qid; });
+    return LX_OK;
+}
+
+namespace
+{
+
+// 64-bit content hash of a buffer over the host threads: pieces of 1 MiB, each folded with a multiply-xorshift, combined in order
+// (never 0: that is "no hash")
+uint64_t content_hash(void const * data, uint64_t bytes, uint64_t seed)
+{
+    uint8_t const * const p       = static_cast<uint8_t const *>(data);
+    uint64_t const        piece   = 1ull << 20, npieces = (bytes + piece - 1) / piece;
+    std::vector<uint64_t> hp(npieces, 0);
+    unsigned const        nt = npieces >= 8 ? std::max(1u, lxi::pool_width()) : 1u;
+    auto fold = [&](unsigned t)
+    {
+        for (uint64_t k = t; k < npieces; k += nt)
+        {
+            uint64_t const a = k * piece, b = std::min(bytes, a + piece);
+            uint64_t       x = 0x9E3779B97F4A7C15ull ^ k, i = a;
+            for (; i + 8 <= b; i += 8)
+            {
+                uint64_t w;
+                std::memcpy(&w, p + i, 8);
+                x = (x ^ w) * 0xD6E8FEB86659FD93ull;
+                x ^= x >> 32;
+            }
+            for (; i < b; ++i)
+                x = (x ^ p[i]) * 0xD6E8FEB86659FD93ull;
+            hp[k] = x;
+        }
+    };
+    if (nt <= 1)
+        fold(0);
+    else
+        lxi::pool_run(nt, fold);
+    uint64_t x = seed ^ (bytes * 0x9E3779B97F4A7C15ull);
+    for (uint64_t v : hp)
+    {
+        x = (x ^ v) * 0xD6E8FEB86659FD93ull;
+        x ^= x >> 29;
+    }
+    return x ? x : 1;
+}
+
+} // namespace
+
+int lxi::iterate_host_list_on_device(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off, uint64_t const * q_seq_len,
+                                     uint64_t n_qseq, uint64_t const * q_orig_len, uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off,
+                                     uint64_t const * s_seq_len, uint64_t n_sseq, lx_match * matches, uint64_t n_matches, lx_search_params const * params,
+                                     lx_iterate_result * res)
+{
+    using namespace lambda_amd;
+    // what this path serves: lists large enough to pay for the hand-over, the reference's full rectangle, resident subjects
+    if (n_matches < 4 * kParallelFrom || params->band > 0 || h->opt_band || s_res != nullptr || s_bytes != 0 || !h->db_bytes || n_qseq >= (1ull << 31) ||
+        n_sseq >= (1ull << 32) || lx::dev_aids().iterate_on_host)
+        return kNotTaken;
+    if (!params->bisulfite && (slot < 0 || slot > 1 || !h->have_sc[slot]))
+        return kNotTaken; // (the host form reports it)
+    if (params->bisulfite && (!h->have_sc[0] || !h->have_sc[1]))
+        return kNotTaken;
+    auto &    l2 = h->l2;
+    HostMarks hm("lx_iterate_matches (device list work)");
+    int       rc;
+    if ((rc = bind(h)))
+        return rc;
+    // ---- the sequence sets: resident already (the same content as last time) or set now
+    int const      frames = std::max(1, params->qry_num_frames);
+    uint64_t const n_orig = q_orig_len ? (n_qseq + (uint64_t)frames - 1) / (uint64_t)frames : 0;
+    uint64_t const qh     = (content_hash(q_res, q_bytes, 1) ^ content_hash(q_seq_off, n_qseq * 8, 2) ^ content_hash(q_seq_len, n_qseq * 8, 3) ^
+                         content_hash(q_orig_len, n_orig * 8, 4) ^ (uint64_t)frames) | 1;
+    if (l2.q_len.size() != n_qseq || l2.q_bytes != q_bytes || l2.q_frames != frames || l2.q_hash != qh || n_qseq == 0)
+    {
+        if ((rc = lx_set_queries(h, q_res, q_bytes, q_seq_off, q_seq_len, n_qseq, q_orig_len, frames)))
+            return rc == LX_EINVAL ? kNotTaken : rc; // (a set the resident form does not take: the host form copes or reports)
+        l2.q_hash = qh;
+    }
+    uint64_t const sh = (content_hash(s_seq_off, n_sseq * 8, 5) ^ content_hash(s_seq_len, n_sseq * 8, 6)) | 1;
+    if (l2.s_len.size() != n_sseq || l2.s_hash != sh || n_sseq == 0)
+    {
+        if ((rc = lx_set_subject_seqs(h, s_seq_off, s_seq_len, n_sseq)))
+            return rc == LX_EINVAL ? kNotTaken : rc;
+        l2.s_hash = sh;
+    }
+    if (l2.s_extent > h->db_bytes)
+        return kNotTaken;
+    hm.mark("sets");
+    // ---- the matches as sort words (lx_level2.h), made by the host threads straight into pinned memory, 16 bytes each
+    if ((rc = ensure_pinned(h, l2.p_up, n_matches * 16 + 16)) || (rc = ensure(h, l2.d_pair[0], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], n_matches * 8 + 16)) ||
+        (rc = ensure(h, l2.d_cnt, 16 * sizeof(uint64_t))))
+        return rc;
+    uint64_t * const      pair = static_cast<uint64_t *>(l2.p_up.ptr), * const s0 = pair + n_matches;
+    std::vector<uint8_t>  bad(std::max(1u, lxi::pool_width()), 0);
+    bool const            bs = params->bisulfite != 0;
+    parallelRanges(n_matches,
+                   [&](unsigned t, uint64_t lo, uint64_t hi)
+                   {
+                       for (uint64_t i = lo; i < hi; ++i)
+                       {
+                           lx_match const & m = matches[i];
+                           uint64_t const   d = m.subjStart < m.qryStart ? 0 : m.subjStart - m.qryStart; // _widenMatch's first line, :923
+                           if (d >= s_seq_len[m.subjId])
+                               bad[t] = 1;
+                           pair[i] = ((bs ? (m.subjId & 1) : 0ull) << 63) | (m.qryId << 32) | m.subjId;
+                           s0[i]   = d;
+                       }
+                   });
+    for (uint8_t b : bad)
+        if (b)
+            return fail(h, LX_EINVAL, "a match lies beyond the end of its subject sequence");
+    LX_HIP(h, hipMemsetAsync(l2.d_cnt.ptr, 0, 4 * sizeof(uint64_t), h->stream));
+    LX_HIP(h, hipMemcpyAsync(l2.d_pair[0].ptr, pair, n_matches * 8, hipMemcpyHostToDevice, h->stream));
+    LX_HIP(h, hipMemcpyAsync(l2.d_s0[0].ptr, s0, n_matches * 8, hipMemcpyHostToDevice, h->stream));
+    hm.mark("sort words");
+    uint64_t const ruleBefore = h->opt_bs_rule;
+    if (bs)
+        h->opt_bs_rule = 1; // the bisulfite overload of computeAlignmentStats for the duration of the call
+    rc             = level2_sorted_tail(h, slot, n_matches, params, res);
+    h->opt_bs_rule = ruleBefore;
+    if (rc)
+        return rc;
+    // ---- the reference's span now holds the windows (:1173-1174 shrinks it): the first n_windows records of `matches`
+    uint64_t const             nw  = n_matches - (res->stats.hits_duplicate - l2.dup_before);
+    lx::L2Window const * const win = static_cast<lx::L2Window const *>(l2.p_win.ptr);
+    parallelRanges(nw,
+                   [&](unsigned, uint64_t lo, uint64_t hi)
+                   {
+                       for (uint64_t i = lo; i < hi; ++i)
+                           matches[i] = lx_match{win[i].q, win[i].s, 0, l2.q_len[win[i].q], win[i].beg, win[i].end};
+                   });
     return LX_OK;
 }
 

@@ -236,3 +236,51 @@ def test_iterate_matches_dev_bisulfite_and_frames(handle, oracle):
         assert getattr(ds, f) == getattr(hs, f), f
     with pytest.raises(capi.LambdaExtError):  # the queries were set with four frames
         handle.iterate_matches_dev(_to_device(m), len(m), capi.SearchParams(1e-3, -1, 0, 1000, 0, 2, 2, 1, capi.LX_FRAMES_BISULFITE, capi.LX_FRAMES_BISULFITE, ka))
+
+
+def test_iterate_matches_hands_large_host_lists_to_the_device(handle, oracle):
+    """lx_iterate_matches on a list beyond 131 072 matches: the list work runs on the device (sort words up, window list back into the
+    caller's span) -- the records are what the host form gives for the same matches handed over in pieces of queries that stay below
+    that size, and the span holds the oracle's window list afterwards."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    rng = np.random.default_rng(99)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 9000, 400, 12)
+    assert len(m) > 140_000
+    m = m[rng.permutation(len(m))]
+    ka = capi.karlin_params(62)
+    params = capi.SearchParams(1e-2, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    lib = capi.load()
+    import ctypes as C
+
+    mm = np.ascontiguousarray(m, dtype=capi.MATCH_DTYPE).copy()
+    res = C.c_void_p()
+    handle._check(lib.lx_iterate_matches(handle.h, 0, capi._ptr(q), q.size, capi._ptr(qoff), capi._ptr(qlen), len(qoff), capi._ptr(qlen), None, 0,
+                                         capi._ptr(soff), capi._ptr(slen), len(soff), capi._ptr(mm), len(mm), C.byref(params), C.byref(res)))
+    big, bigops, bigstats = handle._take_iterate_result(res)
+    want_windows = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlen, slen)
+    assert bigstats.hits_duplicate == len(m) - len(want_windows)
+    assert (mm[:len(want_windows)].view(np.uint64) == want_windows.view(np.uint64)).all()  # the span, shrunk to the windows (:1173-1174)
+    pieces, pops, dup = [], [], 0
+    for lo in range(0, 9000, 3000):  # three pieces of queries, each below the hand-over size: the host form
+        part = m[(m["qryId"] >= lo) & (m["qryId"] < lo + 3000)]
+        assert len(part) < 131_072
+        b, o, st = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, part, params)
+        pieces.append(b)
+        pops += o
+        dup += st.hits_duplicate
+    small = np.concatenate(pieces)
+    assert dup == bigstats.hits_duplicate and len(small) == len(big) and len(big) > 2000
+    for f in small.dtype.names:
+        if f != "ops_off":
+            assert (small[f] == big[f]).all(), f
+    assert pops == bigops
+    # a second call with the same sets finds them resident (same records), another query set replaces them
+    b2, o2, _ = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, m, params)
+    assert b2.tobytes() == big.tobytes() and o2 == bigops
+    q3 = q.copy()
+    k = int(qoff[7000])
+    q3[k:] = np.roll(q[k:], 7)  # the last 2 000 queries (where the planted homologies survive in the subjects) read differently now
+    b3, _, _ = handle.iterate_matches(q3, qoff, qlen, qlen, None, soff, slen, m, params)
+    assert len(b3) > 2000 and b3.tobytes() != big.tobytes()

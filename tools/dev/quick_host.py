@@ -2,7 +2,7 @@
 subject windows uploaded per call and with resident subjects.  Development aid for DESIGN.md section 5."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 

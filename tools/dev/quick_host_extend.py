@@ -1,7 +1,7 @@
 """lx_extend_batch / lx_extend_batch_rle on the headline batch with resident subjects (development aid)."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 

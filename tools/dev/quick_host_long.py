@@ -2,7 +2,7 @@
 checked against the oracle.  Development aid."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 from tests import oracle_lib

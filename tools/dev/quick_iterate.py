@@ -3,7 +3,7 @@ realistic size: how much of the call is the driver's host work (widen + merge, s
 extension.  Development aid; LX_HOST_TIMING=1 prints the extension's own breakdown."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 

@@ -2,7 +2,7 @@
 batch k's backtrace).  Development aid; prints sequential vs two-stream throughput."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from lambda_amd import capi, synth
 

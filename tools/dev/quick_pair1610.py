@@ -1,7 +1,7 @@
 """Pass-1 rate of the (16,10) packed-half geometry on the headline batch (QUERY_RUN = 8 selects it).  Development aid."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from lambda_amd import capi, synth
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Throughput probe of lx_prefilter_batch (seedLooksPromising on the GPU).  Development aid."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 

@@ -2,7 +2,7 @@
 share of executed cells that is padding.  Development aid for DESIGN.md section 5; `bench.py --ragged` prints the line."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 from lambda_amd import capi, synth
 

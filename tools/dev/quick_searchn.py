@@ -2,7 +2,7 @@
 the 1 M reads) -- pass 1 alone and the fused step.  Development aid, not a bench line."""
 import sys
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np, torch
 from lambda_amd import capi, synth
 

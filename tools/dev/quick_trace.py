@@ -1,7 +1,7 @@
 """Quick single-GPU throughput probe of pass 2 (development aid)."""
 import sys, time
 from pathlib import Path
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import numpy as np
 import torch
 from lambda_amd import capi, synth
