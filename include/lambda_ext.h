@@ -573,6 +573,9 @@ void lx_output_options_default(lx_output_options * o);
 int lx_write_records_ex(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
                         uint64_t n, uint8_t const * ops, lx_seq_names const * names, uint8_t const * q_res_ascii,
                         uint64_t const * q_ascii_off, lx_output_options const * opt);
+/* What lx_write_records_ex refuses before it touches a file -- an unknown format, column specifier or SAM tag -- so that a front
+ * end can fail while it parses its options, as the reference does (src/search_options.hpp:684-816), not after the search. */
+int lx_check_output_options(int format, lx_output_options const * opt);
 /* myWriteFooter (src/search_output.hpp:739-750): .m9 ends with "# BLAST processed N queries" (N = records written), the other
  * formats have no footer. */
 int lx_write_footer(char const * path, int format, uint64_t n_records);

@@ -16,6 +16,7 @@ LIB_PATH = Path(os.environ.get("LX_LIB_PATH") or Path(__file__).resolve().parent
 
 LX_ALPH = 32
 LX_OK = 0
+LX_EINVAL = -1
 LX_OPT_MAX_QLEN = 1
 LX_OPT_QUERY_RUN = 2
 LX_OPT_WORKSPACE_BYTES = 3
@@ -29,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
-    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_extend_batch_list", "lx_write_records_ex", "lx_write_footer", "lx_output_options_default", "lx_last_output_error", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
+    "lx_set_subjects", "lx_extend_batch", "lx_extend_batch_rle", "lx_extend_batch_list", "lx_write_records_ex", "lx_check_output_options", "lx_write_footer", "lx_output_options_default", "lx_last_output_error", "lx_expand_ops", "lx_last_extend_stats", "lx_set_frames", "lx_untrue_qry_id", "lx_untrue_subj_id", "lx_translate_six_frames",
     "lx_plan_step",
 ]
 

@@ -520,6 +520,21 @@ Options parse(int argc, char ** argv)
     if (o.seedLength < 2 || o.seedLength0 < 2 || o.seedOffset < 1 || o.seedOffset0 < 1 || o.seedDelta < 0 || o.seedDelta > 3 || o.seedDelta0 < 0 ||
         o.seedDelta0 > 5)
         throw std::runtime_error("seed length / offset / delta out of range");
+    {
+        // the output format and what the writers are asked for, before anything is read or searched (:684-816: the reference fails
+        // while it parses its options)
+        auto ends = [&](char const * suf)
+        { return o.output.size() >= std::strlen(suf) && o.output.compare(o.output.size() - std::strlen(suf), std::string::npos, suf) == 0; };
+        int const fmt = ends(".m9") ? LX_OUT_BLAST_TAB_COMMENTS : ends(".sam") ? LX_OUT_SAM : ends(".m8") ? LX_OUT_BLAST_TAB : -1;
+        if (fmt < 0)
+            throw std::runtime_error("output format is chosen by the extension: .m8, .m9 or .sam"); // :684-710
+        lx_output_options oo;
+        lx_output_options_default(&oo);
+        oo.columns  = o.outputColumns.c_str();
+        oo.sam_tags = o.samTags.c_str();
+        if (lx_check_output_options(fmt, &oo) != LX_OK)
+            throw std::runtime_error(lx_last_output_error());
+    }
     return o;
 }
 
@@ -629,11 +644,20 @@ void readIndexHead(std::string const & path, IndexFileOptions & io, SeqSet & db,
     db.res.resize(n);
     if (!read(db.res.data(), n))
         throw bad("truncated");
-    if (db.orig_len.size() != db.ids.size() || db.off.empty() || db.off.size() % db.ids.size() != 0)
+    if (db.ids.empty() || db.orig_len.size() != db.ids.size() || db.off.empty() || db.off.size() % db.ids.size() != 0)
         throw bad("inconsistent sequence tables");
     for (size_t i = 0; i < db.off.size(); ++i)
         if (db.len[i] > db.res.size() || db.off[i] > db.res.size() - db.len[i])
             throw bad("a sequence lies outside the residues");
+    {
+        // the residues index the scoring and reduction tables: none beyond the translated alphabet (aa27: 27 ranks, dna5: 5)
+        unsigned const size = io.transAlph == kAlphAminoAcid ? 27u : io.transAlph == kAlphDna5 ? 5u : 0u;
+        uint8_t        top  = 0;
+        for (uint8_t r : db.res)
+            top = std::max(top, r);
+        if (size == 0 || (!db.res.empty() && top >= size))
+            throw bad("residues outside the index's alphabet");
+    }
     *fp = f;
 }
 

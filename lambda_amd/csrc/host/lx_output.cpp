@@ -437,9 +437,31 @@ int lx_write_footer(char const * path, int format, uint64_t n_records)
     std::FILE * f = std::fopen(path, "a");
     if (!f)
         return LX_EINVAL;
-    std::fprintf(f, "# BLAST processed %llu queries\n", (unsigned long long)n_records); // [UPSTREAM-RECALL] seqan::writeFooter
-    std::fclose(f);
-    return LX_OK;
+    bool ok = std::fprintf(f, "# BLAST processed %llu queries\n", (unsigned long long)n_records) >= 0; // [UPSTREAM-RECALL] seqan::writeFooter
+    ok      = (std::fclose(f) == 0) && ok;
+    if (!ok)
+        g_output_error = std::string("error while writing ") + path;
+    return ok ? LX_OK : LX_EINVAL;
+}
+
+// what lx_write_records_ex would refuse before it touches a file: the format, the column specifiers / SAM tags
+int lx_check_output_options(int format, lx_output_options const * opt_in)
+{
+    g_output_error.clear();
+    if (format != LX_OUT_BLAST_TAB && format != LX_OUT_BLAST_TAB_COMMENTS && format != LX_OUT_SAM)
+    {
+        g_output_error = "unknown output format";
+        return LX_EINVAL;
+    }
+    lx_output_options opt;
+    lx_output_options_default(&opt);
+    if (opt_in)
+        opt = *opt_in;
+    std::vector<int> cols;
+    bool             tags[kNumSamTags] = {};
+    if (format == LX_OUT_SAM)
+        return resolveTags(opt.sam_tags, tags) ? LX_OK : LX_EINVAL;
+    return resolveColumns(opt.columns, cols) ? LX_OK : LX_EINVAL;
 }
 
 int lx_write_records(char const * path, int format, int write_header, char const * program, lx_blast_match const * m,
@@ -477,7 +499,11 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
         return LX_EINVAL;
     std::FILE * f = std::fopen(path, write_header ? "w" : "a");
     if (!f)
+    {
+        g_output_error = std::string("cannot open ") + path;
         return LX_EINVAL;
+    }
+    bool        io_ok = true;
     std::string upper(program);
     for (char & c : upper)
         c = (char)std::toupper((unsigned char)c);
@@ -782,17 +808,33 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
                 // a plain table of many records: the lines are made on the library's host threads, piece by piece, and written in order
                 unsigned const           nt = lxi::pool_width();
                 std::vector<std::string> piece(nt);
+                std::vector<uint8_t>     failed(nt, 0);
                 uint64_t const           step = (n + nt - 1) / nt;
                 lxi::pool_run(nt,
                               [&](unsigned t)
                               {
-                                  std::string & out = piece[t];
-                                  out.reserve((size_t)(std::min(n, (t + 1) * step) - std::min(n, t * step)) * 96);
-                                  for (uint64_t k = std::min(n, t * step); k < std::min(n, (t + 1) * step); ++k)
-                                      formatRecord(m[k], 0u, out);
+                                  try // (an exception must not leave a pool thread: out of memory is reported below)
+                                  {
+                                      std::string & out = piece[t];
+                                      out.reserve((size_t)(std::min(n, (t + 1) * step) - std::min(n, t * step)) * 96);
+                                      for (uint64_t k = std::min(n, t * step); k < std::min(n, (t + 1) * step); ++k)
+                                          formatRecord(m[k], 0u, out);
+                                  }
+                                  catch (...)
+                                  {
+                                      failed[t] = 1;
+                                  }
                               });
-                for (std::string const & out : piece)
-                    std::fwrite(out.data(), 1, out.size(), f);
+                for (unsigned t = 0; t < nt; ++t)
+                {
+                    if (failed[t])
+                    {
+                        std::fclose(f);
+                        g_output_error = "out of memory while formatting the records";
+                        return LX_ENOMEM;
+                    }
+                    io_ok = (std::fwrite(piece[t].data(), 1, piece[t].size(), f) == piece[t].size()) && io_ok;
+                }
                 break;
             }
             std::string line;
@@ -800,12 +842,19 @@ int lx_write_records_ex(char const * path, int format, int write_header, char co
             {
                 line.clear();
                 formatRecord(m[k], lca, line);
-                std::fwrite(line.data(), 1, line.size(), f);
+                io_ok = (std::fwrite(line.data(), 1, line.size(), f) == line.size()) && io_ok;
             }
             lo = hi;
         }
     }
-    std::fclose(f);
+    // (the fprintf paths set the stream's error indicator: one look at the end covers them)
+    io_ok = !std::ferror(f) && io_ok;
+    io_ok = (std::fclose(f) == 0) && io_ok;
+    if (!io_ok)
+    {
+        g_output_error = std::string("error while writing ") + path + " (disk full?)";
+        return LX_EINVAL;
+    }
     return LX_OK;
 }
 

@@ -618,14 +618,18 @@ inline void seedQueries(ReducedIndex const & ix, SeedingInput const & in, SeedPa
     for (size_t w = 0; w < which.size(); ++w)
     {
         uint64_t const i = which[w];
-        if (in.qLen[i] < (uint64_t)so.seedLength) // :640-641 (before the reset and without the bookkeeping below, as there)
-            continue;
-        if (i % (uint64_t)in.qNumFrames == 0) // reset on every "real" new read (:643-650)
+        // reset on every "real" new read (:643-650).  The reference tests the length first (:640-641) and so would carry the previous
+        // read's counts into a read whose FIRST frame is shorter than the seed while a later one is not -- no frame layout produces
+        // that (frame 0 is never the shortest), and a read's seeds must not depend on its neighbours here: the reads are dealt to
+        // threads and to GPU lanes, every one starts from zero
+        if (i % (uint64_t)in.qNumFrames == 0)
         {
             hitsThisSeq = needlesSum = needlesPos = 0;
             for (int j = 0; j < in.qNumFrames && i + (uint64_t)j < in.nQSeq; ++j)
                 needlesSum += in.qLen[i + (uint64_t)j];
         }
+        if (in.qLen[i] < (uint64_t)so.seedLength) // :640-641 (without the bookkeeping below, as there)
+            continue;
         uint64_t const        L   = in.qLen[i];
         uint8_t const * const red = in.qRed + in.qOff[i];
         uint8_t const * const res = in.qRes + in.qOff[i];

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
     if (r >= p.nReads)
         return;
     uint64_t const read0 = p.reads[r];
-    size_t         hitsThisSeq = 0, needlesSum = 0, needlesPos = 0;
+    size_t         foundForRead = 0, framesTotal = 0, framesDone = 0;
     size_t const   kOccFactor  = 10;
     unsigned long long nHits = 0, nFailed = 0;
     bool               ok    = true;
@@ -188,26 +188,26 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
         uint64_t seedLength = (uint64_t)p.seedLength;
         if (p.adaptive)
         {
-            size_t const left        = (needlesSum - needlesPos - seedBegin) / (size_t)p.seedOffset;
-            size_t       desiredOccs = hitsThisSeq >= p.maxMatches ? 1 : (p.maxMatches - hitsThisSeq) * kOccFactor / (left > 1 ? left : 1);
-            if (desiredOccs == 0)
-                desiredOccs = 1;
-            DevCursor old_cursor = cursor;
-            size_t    old_count  = dev_count(cursor, p.keyLen);
+            size_t const left        = (framesTotal - framesDone - seedBegin) / (size_t)p.seedOffset;
+            size_t       wanted = foundForRead >= p.maxMatches ? 1 : (p.maxMatches - foundForRead) * kOccFactor / (left > 1 ? left : 1);
+            if (wanted == 0)
+                wanted = 1;
+            DevCursor kept = cursor;
+            size_t    keptCount  = dev_count(cursor, p.keyLen);
             while (seedBegin + seedLength < L)
             {
                 cursor = dev_extend(p, cursor, red[seedBegin + seedLength], ok);
                 if (!ok)
                     return;
-                size_t const new_count = dev_count(cursor, p.keyLen);
-                if (new_count < desiredOccs && new_count < old_count)
+                size_t const count = dev_count(cursor, p.keyLen);
+                if (count < wanted && count < keptCount)
                 {
-                    cursor = old_cursor;
+                    cursor = kept;
                     break;
                 }
                 ++seedLength;
-                old_count  = new_count;
-                old_cursor = cursor;
+                keptCount  = count;
+                kept = cursor;
             }
         }
         uint32_t const cnt = dev_count(cursor, p.keyLen);
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
                     p.out[at] = lx_match{i, x.seq, seedBegin, seedBegin + seedLength, x.pos, x.pos + seedLength};
                 else
                     atomicExch(p.counters + 3, 1ull);
-                ++hitsThisSeq;
+                ++foundForRead;
             }
         }
     };
@@ -241,14 +241,14 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
         uint64_t const i = read0 + (uint64_t)f;
         if (i >= p.nQSeq)
             break;
+        if (f == 0) // (the per-read reset of seedQueries, before the length test like there)
+        {
+            foundForRead = framesTotal = framesDone = 0;
+            for (int j = 0; j < p.qNumFrames && i + (uint64_t)j < p.nQSeq; ++j)
+                framesTotal += p.qLen[i + (uint64_t)j];
+        }
         if (p.qLen[i] < (uint64_t)p.seedLength)
             continue;
-        if (f == 0)
-        {
-            hitsThisSeq = needlesSum = needlesPos = 0;
-            for (int j = 0; j < p.qNumFrames && i + (uint64_t)j < p.nQSeq; ++j)
-                needlesSum += p.qLen[i + (uint64_t)j];
-        }
         uint64_t const        L   = p.qLen[i];
         uint8_t const * const red = p.qRed + p.qOff[i];
         uint8_t const * const res = p.qRes + p.qOff[i];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void seed_reads_kernel(SeedDev p)
                 ++level;
             }
         }
-        needlesPos += L;
+        framesDone += L;
     }
     if (!ok)
     {

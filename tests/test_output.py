@@ -341,3 +341,31 @@ def test_large_table_written_on_several_threads_equals_small_pieces(tmp_path):
     for a in range(0, n, 10_000):
         capi.write_records(pieces, capi.LX_OUT_BLAST_TAB, m[a:a + 10_000], b"", q_ids, q_lens, s_ids, s_lens, program="blastn", write_header=(a == 0))
     assert whole.read_bytes() == pieces.read_bytes() and len(whole.read_text().splitlines()) == n
+
+
+def test_output_options_are_checked_without_a_file_and_io_errors_are_reported(tmp_path):
+    """lx_check_output_options: what a front end calls while it parses its options (the reference throws there,
+    /root/reference/src/search_options.hpp:755-758, :803-806) -- and a writer that cannot write says so instead of returning a truncated
+    file with LX_OK."""
+    import ctypes as C
+    import os
+
+    lib = capi.load()
+    lib.lx_check_output_options.argtypes = [C.c_int32, C.c_void_p]
+    ok = capi.output_options(columns="qseqid sseqid bitscore")
+    assert lib.lx_check_output_options(capi.LX_OUT_BLAST_TAB, C.byref(ok)) == capi.LX_OK
+    assert lib.lx_check_output_options(capi.LX_OUT_SAM, C.byref(capi.output_options(sam_tags="AS NM"))) == capi.LX_OK
+    assert lib.lx_check_output_options(capi.LX_OUT_BLAST_TAB, None) == capi.LX_OK
+    bad = capi.output_options(columns="qseqid nosuchcolumn")
+    assert lib.lx_check_output_options(capi.LX_OUT_BLAST_TAB_COMMENTS, C.byref(bad)) == capi.LX_EINVAL
+    assert "nosuchcolumn" in capi.last_output_error()
+    assert lib.lx_check_output_options(capi.LX_OUT_SAM, C.byref(capi.output_options(sam_tags="AS zz"))) == capi.LX_EINVAL
+    assert lib.lx_check_output_options(99, None) == capi.LX_EINVAL
+    bms = np.array([rec(0, 0, 0, 50, 0, 50, 60.0, n_ops=0)], dtype=capi.BLAST_MATCH_DTYPE)
+    if os.path.exists("/dev/full"):
+        with pytest.raises(capi.LambdaExtError) as ei:
+            capi.write_records("/dev/full", capi.LX_OUT_BLAST_TAB, np.repeat(bms, 5000), b"", ["q"], [50], ["s"], [50])
+        assert "error while writing" in str(ei.value)
+    with pytest.raises(capi.LambdaExtError) as ei:
+        capi.write_records(tmp_path / "no" / "such" / "dir.m8", capi.LX_OUT_BLAST_TAB, bms, b"", ["q"], [50], ["s"], [50])
+    assert "cannot open" in str(ei.value)
