@@ -376,8 +376,12 @@ typedef struct lx_search_params
     lx_karlin karlin;
     int32_t   band;             /* 0: full rectangle, what the reference computes; b > 0: band mode (LX_OPT_BAND) with the default
                                    centres for the duration of the call -- not a parity mode                               */
-    int32_t   reserved;
+    int32_t   flags;            /* LX_ITERATE_*; 0 = the reference's behaviour                                                     */
 } lx_search_params;
+/* lx_search_params.flags: the result carries no alignment columns -- lx_iterate_result_ops() is NULL, every record's n_ops is still the
+ * alignment's length and ops_off is 0.  For callers whose output needs none (BLAST-tabular: every column comes from the counts; the
+ * SAM writer needs them for its CIGAR): a million HSPs are 110 MB of column bytes that nobody reads. */
+#define LX_ITERATE_NO_OPS 1
 
 /* ---- frame bookkeeping (_setFrames, _untrueQryId, _untrueSubjId; src/search_algo.hpp:768-814, :940-996) ------------
  * The reference expands every sequence into its frames (translate_join: 6, add_reverse_complement: 2, bisulfite

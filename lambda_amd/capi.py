@@ -54,7 +54,10 @@ class SearchParams(C.Structure):
     _fields_ = [("max_evalue", C.c_double), ("min_bitscore", C.c_int32), ("id_cutoff", C.c_int32),
                 ("db_total_length", C.c_uint64), ("query_translated", C.c_int32), ("qry_num_frames", C.c_int32),
                 ("sbj_num_frames", C.c_int32), ("bisulfite", C.c_int32), ("q_frame_mode", C.c_int32),
-                ("s_frame_mode", C.c_int32), ("karlin", Karlin), ("band", C.c_int32), ("reserved", C.c_int32)]
+                ("s_frame_mode", C.c_int32), ("karlin", Karlin), ("band", C.c_int32), ("flags", C.c_int32)]
+
+
+LX_ITERATE_NO_OPS = 1
 
 
 class IterateStats(C.Structure):
@@ -608,6 +611,8 @@ class Handle:
             buf = (C.c_char * (n * BLAST_MATCH_DTYPE.itemsize)).from_address(self.lib.lx_iterate_result_matches(res))
             bms = np.frombuffer(buf, dtype=BLAST_MATCH_DTYPE).copy()
             total = int((bms["ops_off"].astype(np.uint64) + bms["n_ops"].astype(np.uint64)).max())  # (not the last record's: bisulfite runs two passes)
+            if not self.lib.lx_iterate_result_ops(res):  # LX_ITERATE_NO_OPS
+                return bms, [], stats
             obuf = (C.c_char * max(total, 1)).from_address(self.lib.lx_iterate_result_ops(res))
             allops = bytes(obuf)
             ops = [allops[o:o + k] for o, k in zip(bms["ops_off"].tolist(), bms["n_ops"].tolist())]  # (record scalars one by one cost 0.7 ms per thousand)

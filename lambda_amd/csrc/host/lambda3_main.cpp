@@ -937,6 +937,9 @@ int main(int argc, char ** argv)
         sp.q_frame_mode     = bs ? LX_FRAMES_BISULFITE : blastx ? LX_FRAMES_TRANSLATED : prot ? LX_FRAMES_NONE : LX_FRAMES_REVCOMP; // _setFrames, :768-814
         sp.s_frame_mode     = bs ? LX_FRAMES_BISULFITE : sTrans ? LX_FRAMES_TRANSLATED : LX_FRAMES_NONE;
         sp.karlin           = ka;
+        // only the SAM writer reads alignment columns (its CIGAR); the tables are made from the counts
+        bool const wantOps  = opt.output.size() >= 4 && opt.output.compare(opt.output.size() - 4, std::string::npos, ".sam") == 0;
+        sp.flags            = wantOps ? 0 : LX_ITERATE_NO_OPS;
 
         lambda_amd::SeedParams const so1{opt.seedLength, opt.seedOffset, opt.seedDelta}, so0{opt.seedLength0, opt.seedOffset0, opt.seedDelta0};
         // what a worker keeps for its range of reads
@@ -1053,7 +1056,7 @@ int main(int argc, char ** argv)
                     lx_blast_match const * bm = lx_iterate_result_matches(res);
                     uint64_t const         ob = pt.ops.size();
                     uint64_t opsEnd = 0; // (the records are ordered by query, their ops as the passes produced them: bisulfite runs two)
-                    for (uint64_t k = 0; k < n; ++k)
+                    for (uint64_t k = 0; k < n && wantOps; ++k)
                         opsEnd = std::max<uint64_t>(opsEnd, bm[k].ops_off + bm[k].n_ops);
                     if (opsEnd)
                         pt.ops.insert(pt.ops.end(), lx_iterate_result_ops(res), lx_iterate_result_ops(res) + opsEnd);

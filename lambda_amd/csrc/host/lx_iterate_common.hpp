@@ -271,6 +271,7 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
         else
             lxi::pool_run(nts, [&](unsigned t) { body(t, std::min(ns, t * stepS), std::min(ns, (t + 1) * stepS)); });
     };
+    bool const wantOps = !(params->flags & LX_ITERATE_NO_OPS);
     auto identityOf = [](lx_hsp const & a) { return a.n_ops ? (float)(100.0 * static_cast<float>(a.num_matches) / static_cast<float>(a.n_ops)) : 0.0f; };
     overSurvivors([&](unsigned t, uint64_t lo, uint64_t hi)
                   {
@@ -280,7 +281,7 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                           lx_hsp const & a = list.hsp[listAt[surv[x]]];
                           keep[x]          = !(identityOf(a) < params->id_cutoff);
                           nk += keep[x];
-                          no += keep[x] ? (uint64_t)a.n_ops : 0;
+                          no += (keep[x] && wantOps) ? (uint64_t)a.n_ops : 0;
                       }
                       keptOf[t + 1] = nk;
                       opsOf[t + 1]  = no;
@@ -335,10 +336,13 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                           bm.bit_score = (params->karlin.lambda * (double)a.score - logK) / log2; // (computeBitScore's expression, its two logarithms taken once)
                           bm.e_value   = ev(a.score, m.qLength);
                           bm.n_ops     = (uint32_t)a.n_ops;
-                          bm.ops_off   = o;
-                          (void)lx_expand_ops(list.codes + list.codes_off[at], a.n_ops, res->ops.data() + o);
+                          bm.ops_off   = wantOps ? o : 0;
+                          if (wantOps)
+                          {
+                              (void)lx_expand_ops(list.codes + list.codes_off[at], a.n_ops, res->ops.data() + o);
+                              o += bm.n_ops;
+                          }
                           res->matches[r++] = bm;
-                          o += bm.n_ops;
                       }
                   });
     return LX_OK;

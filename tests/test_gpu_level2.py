@@ -208,6 +208,13 @@ def test_iterate_matches_dev_large_list_equals_host_entry(handle, scheme, order)
     for f in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity", "num_ext_score", "num_ext_ali"):
         assert getattr(ds, f) == getattr(hs, f), f
     assert ds.hits_duplicate > 1000
+    # LX_ITERATE_NO_OPS: the same records without alignment columns (what a tabular writer needs)
+    no_ops = capi.SearchParams(1e-2, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka, 0, capi.LX_ITERATE_NO_OPS)
+    nb, no, _ = handle.iterate_matches_dev(_to_device(m[perm]), n, no_ops)
+    assert no == [] and len(nb) == len(db) and (nb["ops_off"] == 0).all()
+    for f in nb.dtype.names:
+        if f != "ops_off":
+            assert (nb[f] == db[f]).all(), f
 
 
 def test_iterate_matches_dev_bisulfite_and_frames(handle, oracle):
