@@ -87,6 +87,11 @@ def parse(argv=None):
     ap.add_argument("--ragged", action="store_true", help="--host-path on a ragged seed list as lambda really produces them (query lengths "
                     "50-400, windows per query geometric with mean 12, 10 %% merged windows of up to 3 Lq): GCUPS and the padded share")
     ap.add_argument("--ragged-queries", type=int, default=50_000)
+    ap.add_argument("--lq-range", type=int, nargs=2, default=None, metavar=("LO", "HI"), help="--ragged: query lengths (default 50 400)")
+    ap.add_argument("--ragged-mean-windows", type=float, default=None, help="--ragged: mean windows per query (default 12)")
+    ap.add_argument("--strong", action="store_true", help="--ragged --lq-range 500 800 --strong: the long strong-hit list of VERDICT r3 / "
+                    "tools/dev/long_queries.py -- 8 000 queries, 8 windows each on average, half of them homologous at the workload's substitution "
+                    "rate, i.e. scoring 2 000-3 500: beyond the compact checkpoint codes")
     ap.add_argument("--iterate", action="store_true", help="time lx_iterate_matches_dev -- the whole of iterateMatchesFullSimd on a DEVICE match "
                     "list (widen, sort, merge, unique, both passes, records) -- on a synthetic seed list of configs[2]'s size; --entry host: "
                     "lx_iterate_matches on the same list in host memory")
@@ -315,8 +320,14 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
     # host copies of the synthetic batches; all windows of the rank form its resident "database"
     parts, s_all, s_at = [], [], 0
     if args.ragged:
-        q_np, s_np, ext = synth.make_ragged_lists_np(args.ragged_queries, seed=0x1A3BDA07 + rank, alphabet=workloads.alphabet_array(w),
-                                                      sub_rate=w.sub_rate, indel_rate=w.indel_rate)
+        if args.strong:  # tools/dev/long_queries.py's list
+            nq, mw, seed = (8000 if args.ragged_queries == 50_000 else args.ragged_queries), args.ragged_mean_windows or 8.0, 5
+        else:
+            nq, mw, seed = args.ragged_queries, args.ragged_mean_windows or 12.0, 0x1A3BDA07 + rank
+        q_np, s_np, ext = synth.make_ragged_lists_np(nq, seed=seed, alphabet=workloads.alphabet_array(w), lq_range=tuple(args.lq_range or (50, 400)),
+                                                      mean_windows=mw, sub_rate=0.25 if args.strong else w.sub_rate,
+                                                      indel_rate=0.02 if args.strong else w.indel_rate)
+        args.ragged_queries = nq
         s_all.append(s_np)
         parts.append((0, q_np, ext))
     for b in ([] if args.ragged else pl.batches):
@@ -378,8 +389,10 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
             "warmup": max(args.warmup, 1), "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": pl.scaling,
             "vs_baseline": None, "dtype": "f16x2 (exact small integers) + int32", "data": "synthetic",
             "config": {"workload": workloads.describe(w) if not args.ragged else
-                       f"RAGGED seed list, {w.program} scheme of configs[{w.key}]: {args.ragged_queries} queries of 50-400 residues, windows per query "
-                       f"geometric (mean 12), 10 % merged windows of up to 3 Lq, half homologous; cells = sum Lq*Ls",
+                       f"RAGGED seed list, {w.program} scheme of configs[{w.key}]: {args.ragged_queries} queries of {(args.lq_range or (50, 400))[0]}-"
+                       f"{(args.lq_range or (50, 400))[1]} residues, windows per query geometric (mean {args.ragged_mean_windows or (8 if args.strong else 12):g}), "
+                       f"10 % merged windows of up to 3 Lq, half homologous" + (" (strong hits: scores beyond the compact codes' 2046)" if args.strong else "") +
+                       "; cells = sum Lq*Ls",
                        "baseline_config": args.config, "host_path": True, "ragged": bool(args.ragged),
                        "padding": (lambda st: {"extensions": st[0], "slots": st[1], "cells": st[2], "executed_cells": st[3],
                                                "padded_share_of_executed_cells": round(1 - st[2] / max(st[3], 1), 4)})(h.last_extend_stats()),

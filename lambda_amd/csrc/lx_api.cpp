@@ -696,7 +696,7 @@ void lxi::describe_plan(StepPlan const & pl, char * buf, size_t len)
     switch (pl.family)
     {
         case kMqSweep:
-            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.wide ? "true,true" : pl.panels > 1 ? "true" : "false",
+            snprintf(buf, len, "lx::sweep_mq_kernel<%d,%s> (single sweep, %s%d queries per wavefront%s)", nameC, pl.wide ? "true,true" : pl.panels > 1 ? "true,false" : "false,false",
                      pl.share < 0 ? "solo packing: up to " : pl.share == 1 ? "free packing: up to " : "", pl.share < 0 ? 16 : pl.share == 1 ? 4 : 8 / std::max(1, pl.share),
                      pl.may_decline ? "; + int32 fix-up lx::ckpt_forward_kernel" : "");
             break;

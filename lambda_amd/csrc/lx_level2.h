@@ -72,9 +72,10 @@ hipError_t l2_launch_keys(void const * d_matches, L2Params const & p, uint64_t *
 // end up in *pair / *s0 (the two buffers of a word swap roles); ghist: [(tiles + 1) * 256 + 256] uint32
 hipError_t l2_launch_sort(uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t n, uint64_t pair_bits, uint64_t s0_bits,
                           uint32_t * ghist, hipStream_t stream);
-// merge passes + unique + windows; head / tail: [n] uint32, block_tot: [tiles of kL2ScanTile + 1] uint32
-hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint32_t * head, uint32_t * tail, uint32_t * block_tot,
-                           hipStream_t stream);
+// merge passes + unique + windows; mrg_* / fin_*: [n] uint64 each (the span after merge right / after swallow left), block_tot: [tiles of
+// kL2ScanTile + 1] uint32
+hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint64_t * mrg_beg, uint64_t * mrg_end, uint64_t * fin_beg,
+                           uint64_t * fin_end, uint32_t * block_tot, hipStream_t stream);
 // the solo plan of the multi-query sweep for a window list: cost sums per part and strip geometry (out[8]: part 0's
 // cost at 19 / 13 / 11 columns and cells, then part 1's; cnt = {windows, first window of part 1} in device memory), and the plan
 hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream);

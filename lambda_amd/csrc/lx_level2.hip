@@ -381,60 +381,57 @@ struct HeadVal
     Sorted s;
     __device__ uint32_t operator()(uint64_t i) const { return (i == 0 || !s.chained(i - 1)) ? (uint32_t)i + 1u : 0u; }
 };
+// after merge right element i holds (beg0[head(i)], chained(i) ? end0[i + 1] : end0[i]): written once (the later passes read it
+// instead of walking the tables again); bit 63 of the end = "chained to its right neighbour"
+constexpr uint64_t kChainedBit = 1ull << 63;
 struct HeadOut
 {
-    uint32_t * head;
-    __device__ void operator()(uint64_t i, uint32_t incl, uint32_t) const { head[i] = incl - 1u; }
-};
-
-// after merge right: element i holds (beg0[head(i)], chained(i) ? end0[i + 1] : end0[i])
-struct Merged
-{
-    Sorted           s;
-    uint32_t const * head;
-    __device__ __forceinline__ Win0 at(uint64_t i) const
+    Sorted     s;
+    uint64_t * mrg_beg;
+    uint64_t * mrg_end;
+    __device__ void operator()(uint64_t i, uint32_t incl, uint32_t) const
     {
-        Win0 w;
-        w.beg = s.win(head[i]).beg;
-        w.end = s.chained(i) ? s.win(i + 1).end : s.win(i).end;
-        return w;
-    }
-    // swallow left's test on (i, i + 1), src/search_algo.hpp:1164-1166: the right element's current subjStart is beg[i + 1]
-    // whatever was copied onto it (see the header), and it equals beg[i] when they are chained
-    __device__ __forceinline__ bool swallowed(uint64_t i) const
-    {
-        if (!s.chained(i))
-            return false;
-        Win0 const w = at(i);
-        return w.beg < w.end;
+        bool const ch = s.chained(i);
+        mrg_beg[i]    = s.win(incl - 1u).beg;
+        mrg_end[i]    = (ch ? s.win(i + 1).end : s.win(i).end) | (ch ? kChainedBit : 0ull);
     }
 };
 
+// swallow left's test on (i, i + 1), src/search_algo.hpp:1164-1166: the right element's current subjStart is beg[i + 1] whatever
+// was copied onto it (see the header), and it equals beg[i] when they are chained.
 // tail(i) = first k >= i that is not swallowed by its right neighbour: min-scan from the right over (swallowed ? inf : k)
 struct TailVal
 {
-    Merged m;
-    __device__ uint32_t operator()(uint64_t i) const { return m.swallowed(i) ? 0xffffffffu : (uint32_t)i; }
+    uint64_t const * mrg_beg;
+    uint64_t const * mrg_end;
+    __device__ uint32_t operator()(uint64_t i) const
+    {
+        uint64_t const e = mrg_end[i];
+        return ((e & kChainedBit) && mrg_beg[i] < (e & ~kChainedBit)) ? 0xffffffffu : (uint32_t)i;
+    }
 };
+// what the span holds at i after swallow left: the record of tail(i)
 struct TailOut
 {
-    uint32_t * tail;
-    __device__ void operator()(uint64_t i, uint32_t incl, uint32_t) const { tail[i] = incl; }
+    uint64_t const * mrg_beg;
+    uint64_t const * mrg_end;
+    uint64_t *       fin_beg;
+    uint64_t *       fin_end;
+    __device__ void operator()(uint64_t i, uint32_t incl, uint32_t) const
+    {
+        fin_beg[i] = mrg_beg[incl];
+        fin_end[i] = mrg_end[incl] & ~kChainedBit;
+    }
 };
 
 struct KeepVal
 {
-    Merged           m;
-    uint32_t const * tail;
-    __device__ __forceinline__ Win0 last(uint64_t i) const { return m.at(tail[i]); }
+    uint64_t const * pair;
+    uint64_t const * fin_beg;
+    uint64_t const * fin_end;
     __device__ uint32_t operator()(uint64_t i) const
     {
-        if (i == 0)
-            return 1u;
-        if (m.s.pair[i] != m.s.pair[i - 1])
-            return 1u;
-        Win0 const a = last(i), b = last(i - 1);
-        return (a.beg != b.beg || a.end != b.end) ? 1u : 0u;
+        return (i == 0 || pair[i] != pair[i - 1] || fin_beg[i] != fin_beg[i - 1] || fin_end[i] != fin_end[i - 1]) ? 1u : 0u;
     }
 };
 struct KeepOut
@@ -445,9 +442,9 @@ struct KeepOut
     {
         if (incl == ex)
             return; // a duplicate: removed by unique
-        uint64_t const pr = k.m.s.pair[i];
+        uint64_t const pr = k.pair[i];
         uint32_t const q = (uint32_t)(pr >> 32) & 0x7fffffffu, s = (uint32_t)pr;
-        Win0 const     w = k.last(i);
+        Win0 const     w{k.fin_beg[i], k.fin_end[i]};
         L2Window       o;
         o.q   = q;
         o.s   = s;
@@ -466,7 +463,7 @@ struct KeepOut
         p.ext_out[ex] = e;
         p.min_out[ex] = p.cut_by_len[p.sets.q_evlen[q]];
         // where the windows of odd subject frames begin (the list is sorted by the bisulfite flag first)
-        if (p.bisulfite && (pr >> 63) && (i == 0 || !(k.m.s.pair[i - 1] >> 63)))
+        if (p.bisulfite && (pr >> 63) && (i == 0 || !(k.pair[i - 1] >> 63)))
             p.count_out[1] = ex;
     }
 };
@@ -572,7 +569,7 @@ hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint
     hipError_t const e = hipMemsetAsync(out, 0, 8 * sizeof(unsigned long long), stream);
     if (e != hipSuccess || n_max == 0)
         return e;
-    unsigned const blocks = (unsigned)std::min<uint64_t>((n_max + 255) / 256, 2048);
+    unsigned const blocks = (unsigned)std::min<uint64_t>((n_max + 255) / 256, 256); // (eight same-address atomics per wavefront: few wavefronts)
     hipLaunchKernelGGL(l2_plan_cost_kernel, dim3(blocks), dim3(256), 0, stream, ext, cnt, no_narrow, out);
     return hipGetLastError();
 }
@@ -634,8 +631,8 @@ hipError_t l2_launch_sort(uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0
     return hipGetLastError();
 }
 
-hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint32_t * head, uint32_t * tail, uint32_t * block_tot,
-                           hipStream_t stream)
+hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint64_t * mrg_beg, uint64_t * mrg_end, uint64_t * fin_beg,
+                           uint64_t * fin_end, uint32_t * block_tot, hipStream_t stream)
 {
     uint64_t const n = p.n;
     hipError_t     e = hipMemsetAsync(p.count_out + 1, 0xff, sizeof(uint64_t), stream);
@@ -655,13 +652,12 @@ hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params 
     HeadVal const hv{s};
     hipLaunchKernelGGL((l2_scan_reduce_kernel<kOpMax, false, HeadVal>), grid, block, 0, stream, hv, n, block_tot);
     hipLaunchKernelGGL((l2_scan_tops_kernel<kOpMax>), dim3(1), block, 0, stream, block_tot, tiles);
-    hipLaunchKernelGGL((l2_scan_apply_kernel<kOpMax, false, HeadVal, HeadOut>), grid, block, 0, stream, hv, HeadOut{head}, n, block_tot);
-    Merged const  m{s, head};
-    TailVal const tv{m};
+    hipLaunchKernelGGL((l2_scan_apply_kernel<kOpMax, false, HeadVal, HeadOut>), grid, block, 0, stream, hv, HeadOut{s, mrg_beg, mrg_end}, n, block_tot);
+    TailVal const tv{mrg_beg, mrg_end};
     hipLaunchKernelGGL((l2_scan_reduce_kernel<kOpMin, true, TailVal>), grid, block, 0, stream, tv, n, block_tot);
     hipLaunchKernelGGL((l2_scan_tops_kernel<kOpMin>), dim3(1), block, 0, stream, block_tot, tiles);
-    hipLaunchKernelGGL((l2_scan_apply_kernel<kOpMin, true, TailVal, TailOut>), grid, block, 0, stream, tv, TailOut{tail}, n, block_tot);
-    KeepVal const kv{m, tail};
+    hipLaunchKernelGGL((l2_scan_apply_kernel<kOpMin, true, TailVal, TailOut>), grid, block, 0, stream, tv, TailOut{mrg_beg, mrg_end, fin_beg, fin_end}, n, block_tot);
+    KeepVal const kv{pair, fin_beg, fin_end};
     hipLaunchKernelGGL((l2_scan_reduce_kernel<kOpSum, false, KeepVal>), grid, block, 0, stream, kv, n, block_tot);
     hipLaunchKernelGGL((l2_scan_tops_kernel<kOpSum>), dim3(1), block, 0, stream, block_tot, tiles);
     hipLaunchKernelGGL((l2_scan_apply_kernel<kOpSum, false, KeepVal, KeepOut>), grid, block, 0, stream, kv, KeepOut{kv, p}, n, block_tot);

@@ -158,8 +158,8 @@ static int level2_windows(lx_handle * h, uint64_t n_matches, bool bisulfite, std
     LX_HIP(h, hipMemcpyAsync(l2.d_cut.ptr, cut_table.data(), cut_table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     uint64_t const tiles = lx::l2_sort_tiles(n_matches), stiles = lx::l2_scan_tiles(n_matches);
     if ((rc = ensure(h, l2.d_pair[1], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[1], n_matches * 8 + 16)) ||
-        (rc = ensure(h, l2.d_hist, (tiles + 2) * 256 * sizeof(uint32_t))) || (rc = ensure(h, l2.d_head, n_matches * 4 + 16)) ||
-        (rc = ensure(h, l2.d_tail, n_matches * 4 + 16)) || (rc = ensure(h, l2.d_tot, (stiles + 2) * sizeof(uint32_t))) ||
+        (rc = ensure(h, l2.d_hist, (tiles + 2) * 256 * sizeof(uint32_t))) || (rc = ensure(h, l2.d_head, n_matches * 16 + 16)) ||
+        (rc = ensure(h, l2.d_tot, (stiles + 2) * sizeof(uint32_t))) ||
         (rc = ensure(h, l2.d_win, n_matches * sizeof(lx::L2Window) + 16)) || (rc = ensure(h, h->d_ext_all, n_matches * sizeof(lx_extension) + 16)) ||
         (rc = ensure(h, h->d_min_all, n_matches * sizeof(int32_t) + 16)) || (rc = ensure_pinned(h, l2.p_cnt, 16 * sizeof(uint64_t))))
         return rc;
@@ -180,7 +180,8 @@ static int level2_windows(lx_handle * h, uint64_t n_matches, bool bisulfite, std
     p.cut_by_len = static_cast<int32_t const *>(l2.d_cut.ptr);
     p.count_out  = static_cast<uint64_t *>(l2.d_cnt.ptr);
     p.bisulfite  = bisulfite ? 1 : 0;
-    LX_HIP(h, lx::l2_launch_merge(pair, s0, p, static_cast<uint32_t *>(l2.d_head.ptr), static_cast<uint32_t *>(l2.d_tail.ptr),
+    // (the span after merge right goes where the sort's spare buffers are, the span after swallow left into d_head)
+    LX_HIP(h, lx::l2_launch_merge(pair, s0, p, pair_tmp, s0_tmp, static_cast<uint64_t *>(l2.d_head.ptr), static_cast<uint64_t *>(l2.d_head.ptr) + n_matches,
                                   static_cast<uint32_t *>(l2.d_tot.ptr), st));
     // what the plan of the sweep will want to know about the list (the strip geometry that sweeps it cheapest, its cells), behind
     // the same synchronisation

@@ -20,7 +20,7 @@
 //     hand A of their last column to the right.  7.5 packed instructions per two cells, as before;
 //   * pad letters (rows beyond the window, columns beyond the query) have entry 0, i.e. score like a gap's first character:
 //     such a cell is never above its neighbours, so it can neither start, nor extend, nor end a best local alignment.
-// Two refinements of the unit (DESIGN.md section 3.1c):
+// Two refinements of the unit (DESIGN.md section 3.3):
 //   * free packing (pair_share = 1, LX_OPT_QUERY_RUN = 2): what the LDS limits is the number of profiles per wavefront (four),
 //     not how the lane groups are dealt to them -- a lane group's two windows share a query, the eight lane groups hold windows
 //     of up to four queries in any split, numbered in order of appearance;

@@ -90,11 +90,11 @@ def check_against_oracle(oracle, osc, q, s, slots, cutoff, got_score, hsp, ops, 
 
 
 @pytest.mark.parametrize("run", [4, 8, 16])
-@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((89, 104), "sweep_mq_kernel<13,false>"),
-                                             ((105, 152), "sweep_mq_kernel<19,false>"), ((153, 176), "sweep_mq_kernel<11,true>"),
-                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((265, 304), "sweep_mq_kernel<19,true>"),
-                                             ((313, 352), "sweep_mq_kernel<11,true>"), ((417, 440), "sweep_mq_kernel<19,true>"),
-                                             ((60, 456), "sweep_mq_kernel<19,true>")])
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false,false>"), ((89, 104), "sweep_mq_kernel<13,false,false>"),
+                                             ((105, 152), "sweep_mq_kernel<19,false,false>"), ((153, 176), "sweep_mq_kernel<11,true,false>"),
+                                             ((177, 208), "sweep_mq_kernel<13,true,false>"), ((265, 304), "sweep_mq_kernel<19,true,false>"),
+                                             ((313, 352), "sweep_mq_kernel<11,true,false>"), ((417, 440), "sweep_mq_kernel<19,true,false>"),
+                                             ((60, 456), "sweep_mq_kernel<19,true,false>")])
 def test_mq_sweep_ragged_lists(handle, oracle, run, lq_range, expect):
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)
@@ -253,8 +253,8 @@ def pack_free(ext, rng, max_queries=4):
     return np.array(slots, dtype=ext.dtype), np.array(src)
 
 
-@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((105, 152), "sweep_mq_kernel<19,false>"),
-                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((60, 456), "sweep_mq_kernel<19,true>")])
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false,false>"), ((105, 152), "sweep_mq_kernel<19,false,false>"),
+                                             ((177, 208), "sweep_mq_kernel<13,true,false>"), ((60, 456), "sweep_mq_kernel<19,true,false>")])
 def test_mq_sweep_free_packing(handle, oracle, lq_range, expect):
     """LX_OPT_QUERY_RUN = 2: pairs of one query, up to four queries per wavefront in any split of its eight lane groups (5 + 2 + 1,
     7 + 1, ...), profile slots in order of appearance -- what lx_extend_batch's plan streams the windows of a ragged list into."""
@@ -387,8 +387,8 @@ def test_host_plan_with_a_window_beyond_the_checkpoint_rows(handle, oracle):
 
 
 @pytest.mark.parametrize("scheme", ["nucl", "bs_fwd", "bs_rev"])
-@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false>"), ((105, 152), "sweep_mq_kernel<19,false>"), ((140, 160), "sweep_mq_kernel"),
-                                             ((177, 208), "sweep_mq_kernel<13,true>"), ((60, 456), "sweep_mq_kernel<19,true>")])
+@pytest.mark.parametrize("lq_range,expect", [((30, 88), "sweep_mq_kernel<11,false,false>"), ((105, 152), "sweep_mq_kernel<19,false,false>"), ((140, 160), "sweep_mq_kernel"),
+                                             ((177, 208), "sweep_mq_kernel<13,true,false>"), ((60, 456), "sweep_mq_kernel<19,true,false>")])
 def test_mq_sweep_solo_packing(handle, oracle, scheme, lq_range, expect):
     """LX_OPT_QUERY_RUN = 1, the solo packing: no promise at all -- every window has its query and its byte profile, 16 windows of
     up to 16 queries per wavefront in ANY order (lx_sweep_mq.hip); for the alphabets whose 16 profiles fit a wavefront's LDS share
@@ -484,7 +484,7 @@ def test_host_plan_wide_slots_for_long_strong_hits(handle, oracle):
         # ordinary windows again: two calls later the codes are back
         q2, s2, e2 = synth.make_ragged_lists_np(200, seed=6, lq_range=(160, 400), mean_windows=6.0)
         back = [_check_host_list(handle, oracle, q2, s2, e2, 60, sample=100) for _ in range(2)]
-        assert "sweep_mq_kernel<19,true>" in back[1] and "true,true" not in back[1], back
+        assert "sweep_mq_kernel<19,true,false>" in back[1], back
     finally:
         handle.set_option(capi.LX_OPT_EXTEND_CHUNK, 0)
 
@@ -507,4 +507,4 @@ def test_overflow_area_exhausted_runs_the_chunk_again_with_wide_slots(handle, or
     finally:
         handle.set_option(capi.LX_OPT_TRACE_BYTES, 64 << 30)
     # (the chunk that ran out is run again -- with int16 pairs from the sweep where they fit the budget, else on the per-survivor path)
-    assert "sweep_mq_kernel<19,true>" not in name or "true,true" in name, name
+    assert "sweep_mq_kernel<19,true,false>" not in name, name

@@ -76,7 +76,7 @@ if rs.exists():
         for r in rows[1:]:
             if "lx::" in r[0]:
                 w.writerow(r)
-hs = src / "stats_host" / "host_kernel_stats.csv"  # the five chunks of lx_extend_batch_list on the headline batch (DESIGN.md section 8.7)
+hs = src / "stats_host" / "host_kernel_stats.csv"  # the five chunks of lx_extend_batch_list on the headline batch (DESIGN.md section 8.8)
 if hs.exists():
     rows = list(csv.reader(open(hs)))
     with open(out / f"{tag}_host_path_kernel_stats.csv", "w", newline="") as f:
@@ -98,3 +98,47 @@ if lw.exists():
                "write_kib_per_launch": {k: acc[k] / len(n[k]) for k in acc}}, open(out / f"{tag}_pmc_write_survivors_0.02.json", "w"), indent=1)
 for k, d in kern.items():
     print(k[:60], {c: "%.4g" % x for c, x in d["counters_per_step_mean"].items()})
+
+# round 4: PMC passes of the ragged list (the multi-query sweep and its backtrace), the Level-2 driver's kernels, the front end at scale
+kern = {}
+for name in ("pmc_ragged_sq", "pmc_ragged_sq_wait", "pmc_ragged_fetch", "pmc_ragged_write"):
+    f = src / name / "pmc_counter_collection.csv"
+    if not f.exists():
+        continue
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    meta, launches = {}, collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "lx::" not in k:
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k].add(r["Dispatch_Id"])
+        meta[k] = {x: r[x] for x in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    for k, v in acc.items():
+        d = kern.setdefault(k, {"dispatch": meta[k], "counters_per_step_mean": {}, "counters_per_launch_mean": {}})
+        for c, x in v.items():
+            d["counters_per_step_mean"][c] = x / steps_profiled
+            d["counters_per_launch_mean"][c] = x / len(launches[k])
+if kern:
+    json.dump({
+        "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --ragged --entry list --steps 2 --warmup 1 --no-cpu-baseline "
+                   "(separate passes: SQ_* instruction counts, SQ_* wave-cycle breakdown, FETCH_SIZE, WRITE_SIZE)",
+        "note": "the ragged list of bench.py (50 000 queries of 50-400 aa, 596 k windows, 44.3 G real / 57.8 G executed cells per call): per-STEP means "
+                "are per lx_extend_batch_list call (two sweep launches: pool, stream).  FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled before use.",
+        "kernels": kern}, open(out / f"{tag}_ragged_pmc.json", "w"), indent=1)
+rs = src / "stats_iterate" / "iterate_kernel_stats.csv"
+if rs.exists():
+    rows = list(csv.reader(open(rs)))
+    with open(out / f"{tag}_iterate_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "lx::" in r[0]:
+                w.writerow(r)
+lines = []
+for log in ("cli_nucl.log", "cli_nucl_host_list.log"):
+    if (src / log).exists():
+        lines += [f"== {log} (tools/cli_scale_nucl.py 1000000 100" + ("; LAMBDA3_HOST_LIST=1 LX_ITERATE_ON_HOST=1: the list on the host, as round 3)" if "host" in log else ")")]
+        lines += [l.rstrip() for l in open(src / log) if l.startswith(("lambda3 ", "output sha256", "rc ")) or "lx_iterate_matches_dev:" in l or "iterateMatchesFullSimd (" in l]
+if lines:
+    (out / f"{tag}_cli_end_to_end.txt").write_text("\n".join(lines) + "\n")

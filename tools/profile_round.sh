@@ -23,4 +23,19 @@ cd /tmp; export TMPDIR=/tmp
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_ragged -o ragged -- python $R/bench.py --ragged --entry list --steps 5 --warmup 2) > $R/$D/stats_ragged.log 2>&1
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_host -o host -- python $R/bench.py --host-path --entry list --steps 5 --warmup 2) > $R/$D/stats_host.log 2>&1
 (timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/$D/pmc_write_lowsurv -o pmc -- python $R/bench.py --steps 2 --warmup 3 --survivor-rate 0.02 --no-cpu-baseline) > $R/$D/pmc_write_lowsurv.log 2>&1
-cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -40
+# round 4: the Level-2 driver, the long strong-hit list, PMC passes of the multi-query sweep on the ragged list
+cd $R
+(timeout 900 python bench.py --iterate --steps 5 --warmup 2) > $D/bench_iterate_dev.log 2>&1
+(timeout 900 python bench.py --iterate --entry host --steps 3 --warmup 2) > $D/bench_iterate_host.log 2>&1
+(timeout 900 python bench.py --ragged --entry list --lq-range 500 800 --strong --steps 5 --warmup 3) > $D/bench_ragged_long_strong.log 2>&1
+(LX_MQ_NO_WIDE=1 timeout 900 python bench.py --ragged --entry list --lq-range 500 800 --strong --steps 3 --warmup 2 --no-cpu-baseline) > $D/bench_ragged_long_strong_codes_only.log 2>&1
+(timeout 900 python bench.py --ragged --entry list --config 2 --steps 5 --warmup 2) > $D/bench_ragged_nucl.log 2>&1
+(LX_HOST_TIMING=1 timeout 900 python tools/cli_scale_nucl.py 1000000 100) > $D/cli_nucl.log 2>&1
+(LAMBDA3_HOST_LIST=1 LX_ITERATE_ON_HOST=1 timeout 900 python tools/cli_scale_nucl.py 1000000 100) > $D/cli_nucl_host_list.log 2>&1
+cd /tmp
+for p in "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "sq_wait:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  n=${p%%:*}; c=${p#*:}
+  (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_ragged_$n -o pmc -- python $R/bench.py --ragged --entry list --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_ragged_$n.log 2>&1
+done
+(timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_iterate -o iterate -- python $R/bench.py --iterate --steps 3 --warmup 2) > $R/$D/stats_iterate.log 2>&1
+cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -60
