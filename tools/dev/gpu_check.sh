@@ -1,5 +1,5 @@
 #!/bin/bash
-D=gpurun_out/r4j; mkdir -p $D
+D=gpurun_out/check; mkdir -p $D
 (timeout 2400 python -m pytest tests -m gpu -x -q) > $D/pytest.log 2>&1; tail -6 $D/pytest.log
 (timeout 600 python bench.py --ragged --entry list --steps 5 --warmup 2) > $D/bench_ragged_list.log 2>&1; tail -1 $D/bench_ragged_list.log | python -c "
 import json,sys
