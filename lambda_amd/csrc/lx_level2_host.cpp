@@ -522,8 +522,8 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
                     (unsigned long long)h->db_bytes);
     if (std::max(1, params->qry_num_frames) != l2.q_frames)
         return fail(h, LX_EINVAL, "qry_num_frames = %d, but the queries were set with %d frames", params->qry_num_frames, l2.q_frames);
-    if (params->band > 0)
-        return fail(h, LX_EINVAL, "lx_iterate_matches_dev: band mode goes through lx_iterate_matches");
+    if (params->band > 0 || h->opt_band)
+        return fail(h, LX_EINVAL, "lx_iterate_matches_dev: band mode (lx_search_params.band, LX_OPT_BAND) goes through lx_iterate_matches");
     if (!params->bisulfite && (slot < 0 || slot > 1 || !h->have_sc[slot]))
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (params->bisulfite && (!h->have_sc[0] || !h->have_sc[1]))

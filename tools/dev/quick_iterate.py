@@ -42,3 +42,14 @@ for rep in range(4):
     bms, ops, stats = h.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, m, params)
     best = min(best, time.perf_counter() - t0)
 print(f"lx_iterate_matches: {nq} queries, {nh} seeds -> {len(bms)} HSPs in {best * 1e3:.1f} ms (duplicates {stats.hits_duplicate}, failed e-value {stats.failed_evalue})")
+# the same list from device memory (lx_iterate_matches_dev over resident sets)
+import torch
+h.set_subject_seqs(soff, slen)
+h.set_queries(q, qoff, qlen, qlen, 1)
+d_m = torch.from_numpy(m.view(np.uint8).copy()).to("cuda:0")
+best = 1e9
+for rep in range(4):
+    t0 = time.perf_counter()
+    bms2, ops2, stats2 = h.iterate_matches_dev(d_m, len(m), params)
+    best = min(best, time.perf_counter() - t0)
+print(f"lx_iterate_matches_dev: {len(bms2)} HSPs in {best * 1e3:.1f} ms; same records: {bms2.tobytes() == bms.tobytes()}")
