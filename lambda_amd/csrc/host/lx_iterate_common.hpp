@@ -5,13 +5,19 @@
 // score and e-value (:1318-1322) -- and the filter itself as an integer cut-off per query length.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <string>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "../../../include/lambda_ext.h"
 #include "blast_stats.hpp"
@@ -25,9 +31,62 @@ void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
 
 namespace lambda_amd
 {
-// A growing array of trivially copyable records that is never value-initialised: a result of a million HSPs is 80 MB of records
-// and 110 MB of alignment columns, every byte of which is written by the threads that make them -- a std::vector would first
-// zero all of it on the calling thread.
+// Blocks of result memory kept between calls: a result of a million HSPs is 96 MB of records and 110 MB of alignment columns, and a
+// block the allocator has just mapped costs a page fault per 4 KB when the threads write it (measured: 7 ms of a 22-ms call) -- a
+// block a freed result hands back is mapped already.  Process-wide, a handful of blocks, 1 GiB at most; everything else is free()d.
+struct BlockCache
+{
+    static constexpr size_t kMinBytes = 1u << 20, kMaxBlocks = 6, kMaxTotal = 1u << 30;
+    std::mutex mu;
+    struct Block
+    {
+        void * p;
+        size_t bytes;
+    };
+    std::vector<Block> blocks;
+    size_t             total = 0;
+    ~BlockCache()
+    {
+        for (Block const & b : blocks)
+            std::free(b.p);
+    }
+    void * take(size_t bytes, size_t & got) // the smallest kept block that holds `bytes`, or nullptr
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        size_t                      best = blocks.size();
+        for (size_t k = 0; k < blocks.size(); ++k)
+            if (blocks[k].bytes >= bytes && (best == blocks.size() || blocks[k].bytes < blocks[best].bytes))
+                best = k;
+        if (best == blocks.size() || blocks[best].bytes > 4 * bytes + (64u << 20))
+            return nullptr;
+        void * const p = blocks[best].p;
+        got            = blocks[best].bytes;
+        total -= got;
+        blocks.erase(blocks.begin() + (long)best);
+        return p;
+    }
+    void give(void * p, size_t bytes)
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (bytes >= kMinBytes && blocks.size() < kMaxBlocks && total + bytes <= kMaxTotal)
+            {
+                blocks.push_back(Block{p, bytes});
+                total += bytes;
+                return;
+            }
+        }
+        std::free(p);
+    }
+};
+inline BlockCache & block_cache()
+{
+    static BlockCache cache;
+    return cache;
+}
+
+// A growing array of trivially copyable records that is never value-initialised: every byte of a result is written by the threads
+// that make it -- a std::vector would first zero all of it on the calling thread.
 template <class T>
 struct RawVec
 {
@@ -36,7 +95,11 @@ struct RawVec
     RawVec()   = default;
     RawVec(RawVec const &)             = delete;
     RawVec & operator=(RawVec const &) = delete;
-    ~RawVec() { std::free(p); }
+    ~RawVec()
+    {
+        if (p)
+            block_cache().give(static_cast<void *>(p), cap * sizeof(T));
+    }
     size_t    size() const { return n; }
     T *       data() { return p; }
     T const * data() const { return p; }
@@ -47,10 +110,26 @@ struct RawVec
     {
         if (m > cap)
         {
-            size_t const want = std::max(m, cap + cap / 2);
-            void * const np   = std::realloc(static_cast<void *>(p), std::max<size_t>(want, 1) * sizeof(T));
+            size_t const want = std::max(m, cap + cap / 2), bytes = std::max<size_t>(want, 1) * sizeof(T);
+            if (!p && bytes >= BlockCache::kMinBytes)
+            {
+                size_t       got  = 0;
+                void * const kept = block_cache().take(bytes, got);
+                if (kept)
+                {
+                    p   = static_cast<T *>(kept);
+                    cap = got / sizeof(T);
+                    n   = m;
+                    return true;
+                }
+            }
+            void * const np = std::realloc(static_cast<void *>(p), bytes);
             if (!np)
                 return false;
+#ifdef MADV_HUGEPAGE
+            if (bytes >= (8u << 20)) // (a fresh block: 2 MiB pages where the system grants them -- 512 times fewer faults)
+                (void)madvise(reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(np) + 4095) & ~(uintptr_t)4095), bytes & ~(size_t)4095, MADV_HUGEPAGE);
+#endif
             p   = static_cast<T *>(np);
             cap = want;
         }
@@ -159,6 +238,19 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
 {
     int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
     unsigned const nt = n >= kParallelFrom ? std::max(1u, lxi::pool_width()) : 1u;
+    static bool const timing = std::getenv("LX_HOST_TIMING") != nullptr; // (development aid: where this function's time goes)
+    auto              tlast  = std::chrono::steady_clock::now();
+    std::string       tline;
+    auto mark = [&](char const * what)
+    {
+        if (!timing)
+            return;
+        auto const now = std::chrono::steady_clock::now();
+        char       buf[64];
+        std::snprintf(buf, sizeof(buf), " %s %.1f", what, std::chrono::duration<double, std::milli>(now - tlast).count());
+        tline += buf;
+        tlast = now;
+    };
     // where match i stands in the survivor list
     std::vector<uint32_t> listAt(n);
     parallelRanges(n, [&](unsigned, uint64_t lo, uint64_t hi) { std::fill(listAt.begin() + lo, listAt.begin() + hi, 0xffffffffu); });
@@ -167,6 +259,7 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                        for (uint64_t k = lo; k < hi; ++k)
                            listAt[list.index[k]] = (uint32_t)k;
                    });
+    mark("listAt");
     // the filter's statistics (:1260, :1274) from the scores of pass 1; the ranges are cut where n_qid changes
     std::vector<uint64_t> cut(nt + 1, n), nSurv(nt + 1, 0), failBit(nt, 0), failEv(nt, 0);
     std::vector<uint8_t>  descends(nt, 0);
@@ -217,6 +310,7 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
         if (t > 0 && cut[t] > 0 && cut[t] < n && window(cut[t]).qryId / qFrames < window(cut[t] - 1).qryId / qFrames)
             sorted = false;
     }
+    mark("statistics");
     uint64_t const ns = nSurv[nt];
     if (ns == 0)
         return LX_OK;
@@ -255,6 +349,7 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                       return std::make_tuple(x.qryId / qFrames, x.qLen, x.sLen, a) < std::make_tuple(y.qryId / qFrames, y.qLen, y.sLen, b);
                   });
 
+    mark("order");
     // compute the rest of the match properties (:1302-1325).  Two passes over the survivors, each spread over the host threads:
     // which of them pass the identity cut-off (:1310-1315) and how many columns they have, then -- the offsets known -- the
     // records and their ops, written where they stay.
@@ -278,6 +373,8 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                       uint64_t nk = 0, no = 0;
                       for (uint64_t x = lo; x < hi; ++x)
                       {
+                          if (x + 16 < hi) // (the survivors stand in the list in the order the device finished them: every record a cache miss)
+                              __builtin_prefetch(&list.hsp[listAt[surv[x + 16]]]);
                           lx_hsp const & a = list.hsp[listAt[surv[x]]];
                           keep[x]          = !(identityOf(a) < params->id_cutoff);
                           nk += keep[x];
@@ -291,10 +388,12 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
         keptOf[t + 1] += keptOf[t];
         opsOf[t + 1] += opsOf[t];
     }
+    mark("identity");
     uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size(), nkeep = keptOf[nts], nops = opsOf[nts];
     res->stats.failed_identity += ns - nkeep;
     if (!res->matches.resize(rec0 + nkeep) || !res->ops.resize(ops0 + nops))
         return LX_ENOMEM;
+    mark("allocate");
     overSurvivors([&](unsigned t, uint64_t lo, uint64_t hi)
                   {
                       EValueContext ev = evalue; // (its cache of length adjustments is not shared)
@@ -303,6 +402,14 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                       {
                           if (!keep[x])
                               continue;
+                          if (x + 16 < hi)
+                          {
+                              uint32_t const ahead = listAt[surv[x + 16]];
+                              __builtin_prefetch(&list.hsp[ahead]);
+                              __builtin_prefetch(&list.codes_off[ahead]);
+                          }
+                          if (x + 4 < hi && wantOps)
+                              __builtin_prefetch(list.codes + list.codes_off[listAt[surv[x + 4]]]);
                           uint32_t const   k  = surv[x];
                           uint32_t const   at = listAt[k];
                           WindowView const m  = window(k);
@@ -345,6 +452,9 @@ inline int finishSurvivors(uint64_t n, GetWindow && window, int32_t const * scor
                           res->matches[r++] = bm;
                       }
                   });
+    mark("records");
+    if (timing)
+        std::fprintf(stderr, "[lx host ms]   finishSurvivors (%llu windows, %llu survivors):%s\n", (unsigned long long)n, (unsigned long long)ns, tline.c_str());
     return LX_OK;
 }
 
