@@ -472,6 +472,22 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
     n_hsp, st = stats
     n_win = len(m) - st.hits_duplicate
     xs = h.last_extend_stats()
+    # (pass 1 of the last call: all launches of its sweep; the window list again, through the widen entry point, for the byte count and the
+    # CPU sample -- outside the timed region)
+    sweep_ms, sweep_launches = h.last_phase_ms(0)
+    bt_ms, bt_launches = h.last_phase_ms(3)
+    sweep_name = h.last_kernel_name()
+    roof = base = None
+    if rank == 0 and on_dev:
+        win = h.widen_and_preprocess_dev(d_m, len(m))
+        ext = np.zeros(len(win), dtype=capi.EXT_DTYPE)
+        ext["q_off"], ext["q_len"] = qoff[win["qryId"]], qlen[win["qryId"]]
+        ext["s_off"] = soff[win["subjId"]] + win["subjStart"]
+        ext["s_len"] = win["subjEnd"] - win["subjStart"]
+        roof = host_roofline(args, sweep_name, sweep_ms, sweep_launches, bt_ms, bt_launches, xs, q, ext, flag="--iterate")
+        if world == 1 and not args.no_cpu_baseline:
+            base = host_cpu_baseline(args, w, q, s, ext)
+            base["sample"] += "; pass 1 of the driver only (the sort, pass 2 and the records are not in it)"
     if rank == 0:
         print(json.dumps({
             "metric": "ms per call of the Level-2 driver (iterateMatchesFullSimd: widen + sort + merge + unique, pass 1, filter, pass 2, records) on a "
@@ -489,15 +505,16 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
                        "padding": {"extensions": xs[0], "slots": xs[1], "cells": xs[2], "executed_cells": xs[3]}},
             "gcups_of_window_cells": round(xs[2] * args.steps / dt / 1e9, 1),
             "matches_per_s": round(len(m) * args.steps / dt, 1),
-            "roofline": None, "cpu_baseline": None,
-            "note": "secondary line: prices the whole driver call around the kernels of the headline line",
+            "roofline": roof, "cpu_baseline": base,
+            "note": "secondary line: prices the whole driver call around the kernels of the headline line; its roofline is pass 1's sweep (all "
+                    "launches of the last call)",
         }), flush=True)
     h.close()
     if use_dist:
         dist.destroy_process_group()
 
 
-def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext):
+def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext, flag=None):
     """Roofline of the sweep of ONE host-buffer call (all its launches: a call is a pipeline of chunks): integer-VALU bound as the headline
     line's; `achieved` counts the LIST's cells (10 algorithmic ops each), `frac_executed` what the wavefronts execute
     (padded columns and rows included: lx_last_extend_stats) -- the distance between the two is the padding of the plan."""
@@ -511,7 +528,7 @@ def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext):
     # algorithmic bytes: every window once, every query once, one 24-byte record + one score per extension
     qkeys = np.unique(ext["q_off"])
     algo = float(ext["s_len"].sum()) + float(len(q) if len(qkeys) else 0) + len(ext) * ALGO_BYTES_PER_EXT_EXTRA
-    flag = "--ragged" if args.ragged else "--host-path"
+    flag = flag or ("--ragged" if args.ragged else "--host-path")
     # (the PMC passes profile the kernel instantiation the sweep ran as; its name in the library's spelling ends at the first blank)
     traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag)
     ceil = issue_ceiling() if packed else None
