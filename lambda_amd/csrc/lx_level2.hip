@@ -288,17 +288,21 @@ __device__ __forceinline__ uint64_t elem_of(uint64_t j, uint64_t n)
     return REV ? n - 1 - j : j;
 }
 
-// (a) the combined value of every tile
+// (a) the combined value of every tile (the operations commute: the elements are taken workgroup-wide, consecutive lanes on
+// consecutive elements)
 template <int OP, bool REV, class Val>
 __global__ __launch_bounds__(kL2ScanBlock) void l2_scan_reduce_kernel(Val val, uint64_t n, uint32_t * block_tot)
 {
     __shared__ uint32_t wave_tot[kL2ScanBlock / 64];
-    uint64_t const      j0 = (uint64_t)blockIdx.x * kL2ScanTile + (uint64_t)threadIdx.x * kL2ScanItems;
+    uint64_t const      j0 = (uint64_t)blockIdx.x * kL2ScanTile + threadIdx.x;
     uint32_t            acc = op_ident<OP>();
 #pragma unroll
     for (int k = 0; k < kL2ScanItems; ++k)
-        if (j0 + k < n)
-            acc = op_apply<OP>(acc, val(elem_of<REV>(j0 + k, n)));
+    {
+        uint64_t const j = j0 + (uint64_t)k * kL2ScanBlock;
+        if (j < n)
+            acc = op_apply<OP>(acc, val(elem_of<REV>(j, n)));
+    }
     uint32_t total;
     (void)block_inclusive<OP>(acc, wave_tot, total);
     if (threadIdx.x == 0)
@@ -329,33 +333,58 @@ __global__ __launch_bounds__(kL2ScanBlock) void l2_scan_tops_kernel(uint32_t * b
         block_tot[tiles] = carry;
 }
 
-// (c) every element's scan value: out(element, inclusive value, exclusive value)
+// (c) every element's scan value: out(element, inclusive value, exclusive value).  Values in and results out go through LDS so that
+// both the reads of `val` and the writes of `out` run over consecutive elements in consecutive lanes; in between every thread scans
+// its kL2ScanItems consecutive values (position j stands at j + j / 8: a thread's run of eight starts in a bank of its own).
+__device__ __forceinline__ uint32_t scan_pos(uint32_t j)
+{
+    return j + (j >> 3);
+}
 template <int OP, bool REV, class Val, class Out>
 __global__ __launch_bounds__(kL2ScanBlock) void l2_scan_apply_kernel(Val val, Out out, uint64_t n, uint32_t const * block_tot)
 {
+    static_assert(kL2ScanItems == 8, "scan_pos spreads runs of eight");
     __shared__ uint32_t wave_tot[kL2ScanBlock / 64];
     __shared__ uint32_t incl_all[kL2ScanBlock];
-    uint64_t const      j0 = (uint64_t)blockIdx.x * kL2ScanTile + (uint64_t)threadIdx.x * kL2ScanItems;
-    uint32_t            v[kL2ScanItems];
-    uint32_t            acc = op_ident<OP>();
+    __shared__ uint32_t stage[kL2ScanTile + kL2ScanTile / 8 + 2]; // values, then the inclusive results behind the tile's carry-in
+    uint64_t const      t0 = (uint64_t)blockIdx.x * kL2ScanTile;
 #pragma unroll
     for (int k = 0; k < kL2ScanItems; ++k)
     {
-        v[k] = j0 + k < n ? val(elem_of<REV>(j0 + k, n)) : op_ident<OP>();
+        uint32_t const j = (uint32_t)k * kL2ScanBlock + threadIdx.x;
+        stage[scan_pos(j)] = t0 + j < n ? val(elem_of<REV>(t0 + j, n)) : op_ident<OP>();
+    }
+    __syncthreads();
+    uint32_t v[kL2ScanItems];
+    uint32_t acc = op_ident<OP>();
+#pragma unroll
+    for (int k = 0; k < kL2ScanItems; ++k)
+    {
+        v[k] = stage[scan_pos(threadIdx.x * kL2ScanItems + k)];
         acc  = op_apply<OP>(acc, v[k]);
     }
     uint32_t       total;
-    uint32_t const incl = block_inclusive<OP>(acc, wave_tot, total);
+    uint32_t const incl = block_inclusive<OP>(acc, wave_tot, total); // (its barriers also end the reads of `stage`)
     incl_all[threadIdx.x] = incl;
     __syncthreads();
-    uint32_t run = op_apply<OP>(block_tot[blockIdx.x], threadIdx.x == 0 ? op_ident<OP>() : incl_all[threadIdx.x - 1]);
+    uint32_t const carry = block_tot[blockIdx.x];
+    uint32_t run = op_apply<OP>(carry, threadIdx.x == 0 ? op_ident<OP>() : incl_all[threadIdx.x - 1]);
+    // stage[scan_pos(j + 1)] = inclusive value of j; stage[scan_pos(0)] = what precedes the tile
+    if (threadIdx.x == 0)
+        stage[0] = carry;
 #pragma unroll
     for (int k = 0; k < kL2ScanItems; ++k)
     {
-        uint32_t const ex = run;
-        run               = op_apply<OP>(run, v[k]);
-        if (j0 + k < n)
-            out(elem_of<REV>(j0 + k, n), run, ex);
+        run = op_apply<OP>(run, v[k]);
+        stage[scan_pos(threadIdx.x * kL2ScanItems + k + 1)] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kL2ScanItems; ++k)
+    {
+        uint32_t const j = (uint32_t)k * kL2ScanBlock + threadIdx.x;
+        if (t0 + j < n)
+            out(elem_of<REV>(t0 + j, n), stage[scan_pos(j + 1)], stage[scan_pos(j)]);
     }
 }
 
@@ -369,9 +398,13 @@ struct Sorted
     L2Sets           sets;
     __device__ __forceinline__ Win0 win(uint64_t i) const { return widen(sets, pair[i], s0[i]); }
     // merge right's test on (i, i + 1), src/search_algo.hpp:1149-1151
+    // (all loads issued whatever the earlier tests say: a chain of dependent round trips costs more than the bytes)
     __device__ __forceinline__ bool chained(uint64_t i) const
     {
-        return i + 1 < n && pair[i] == pair[i + 1] && win(i).end >= win(i + 1).beg;
+        uint64_t const r  = min(i + 1, n - 1);
+        uint64_t const pa = pair[i], pb = pair[r];
+        Win0 const     a = widen(sets, pa, s0[i]), b = widen(sets, pb, s0[r]);
+        return (i + 1 < n) & (pa == pb) & (a.end >= b.beg);
     }
 };
 
@@ -406,8 +439,8 @@ struct TailVal
     uint64_t const * mrg_end;
     __device__ uint32_t operator()(uint64_t i) const
     {
-        uint64_t const e = mrg_end[i];
-        return ((e & kChainedBit) && mrg_beg[i] < (e & ~kChainedBit)) ? 0xffffffffu : (uint32_t)i;
+        uint64_t const e = mrg_end[i], b = mrg_beg[i];
+        return (((e & kChainedBit) != 0) & (b < (e & ~kChainedBit))) ? 0xffffffffu : (uint32_t)i;
     }
 };
 // what the span holds at i after swallow left: the record of tail(i)
@@ -431,7 +464,8 @@ struct KeepVal
     uint64_t const * fin_end;
     __device__ uint32_t operator()(uint64_t i) const
     {
-        return (i == 0 || pair[i] != pair[i - 1] || fin_beg[i] != fin_beg[i - 1] || fin_end[i] != fin_end[i - 1]) ? 1u : 0u;
+        uint64_t const l = i ? i - 1 : 0;
+        return ((i == 0) | (pair[i] != pair[l]) | (fin_beg[i] != fin_beg[l]) | (fin_end[i] != fin_end[l])) ? 1u : 0u;
     }
 };
 struct KeepOut
@@ -512,6 +546,8 @@ __global__ __launch_bounds__(256) void l2_plan_cost_kernel(Extension const * ext
         }
         v[part + 3] += (uint64_t)x.q_len * x.s_len;
     }
+    // one atomic per workgroup and sum (same-address atomics from every wavefront of the grid were most of this kernel's time)
+    __shared__ unsigned long long part[4][8];
 #pragma unroll
     for (int k = 0; k < 8; ++k)
     {
@@ -519,8 +555,15 @@ __global__ __launch_bounds__(256) void l2_plan_cost_kernel(Extension const * ext
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1)
             x += (uint64_t)__shfl_xor((long long)x, off);
-        if ((threadIdx.x & 63) == 0 && x)
-            atomicAdd(out + k, (unsigned long long)x);
+        if ((threadIdx.x & 63) == 0)
+            part[threadIdx.x >> 6][k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8)
+    {
+        unsigned long long const x = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        if (x)
+            atomicAdd(out + threadIdx.x, x);
     }
 }
 

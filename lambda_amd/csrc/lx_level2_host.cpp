@@ -251,10 +251,20 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
         return rc;
     if (!l2.ev_win)
         LX_HIP(h, hipEventCreateWithFlags(&l2.ev_win, hipEventDisableTiming));
-    LX_HIP(h, hipEventRecord(l2.ev_win, st));
-    LX_HIP(h, hipStreamWaitEvent(h->stream2, l2.ev_win, 0));
-    LX_HIP(h, hipMemcpyAsync(l2.p_win.ptr, l2.d_win.ptr, nw * sizeof(lx::L2Window), hipMemcpyDeviceToHost, h->stream2));
-    LX_HIP(h, hipEventRecord(l2.ev_win, h->stream2));
+    // (queued behind what `st` holds at that moment: where the plan is made on the device, behind the plan's kernels -- beside them
+    // the copy's writes over PCIe held the first of them up for the whole 0.5 ms it takes -- and so beside the sweep)
+    bool win_queued = false;
+    auto queue_windows = [&]() -> int
+    {
+        if (win_queued)
+            return LX_OK;
+        win_queued = true;
+        LX_HIP(h, hipEventRecord(l2.ev_win, st));
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, l2.ev_win, 0));
+        LX_HIP(h, hipMemcpyAsync(l2.p_win.ptr, l2.d_win.ptr, nw * sizeof(lx::L2Window), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(l2.ev_win, h->stream2));
+        return LX_OK;
+    };
     bool                       win_here = false;
     lx::L2Window const * const win      = static_cast<lx::L2Window const *>(l2.p_win.ptr);
     l2.score.resize(nw);
@@ -318,6 +328,8 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             l2.wf_maxs.resize(nwf);
             LX_HIP(h, hipMemcpyAsync(l2.wf_pan.data(), d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             LX_HIP(h, hipMemcpyAsync(l2.wf_maxs.data(), d_maxs, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            if ((rc = queue_windows()))
+                return rc;
             LX_HIP(h, hipStreamSynchronize(st));
             ri.d_plan  = static_cast<uint32_t const *>(l2.d_plan.ptr);
             ri.nwf     = nwf;
@@ -332,6 +344,8 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
         else
         {
             // the plan is made on the host (lx_host.cpp): its copies of the slices and cut-offs
+            if ((rc = queue_windows()))
+                return rc;
             if (!win_here)
             {
                 LX_HIP(h, hipEventSynchronize(l2.ev_win));
