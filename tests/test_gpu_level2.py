@@ -108,6 +108,43 @@ def test_device_list_errors_are_loud(handle):
             handle.widen_and_preprocess_dev(_to_device(np.array([ok[0], bad], dtype=capi.MATCH_DTYPE)), 2)
 
 
+def test_device_list_empty_single_and_after_an_error(handle, oracle):
+    """Edge cases of the device entry points: an empty list, one match, one match many times over, and a good call right after a
+    refused one (a failed call leaves nothing behind that the next one trips over)."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    rng = np.random.default_rng(12)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 40, 5, 3)
+    ka = capi.karlin_params(62)
+    params = capi.SearchParams(10.0, -1, 0, int(slen.sum()), 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    import torch
+
+    empty = torch.zeros(48, dtype=torch.uint8, device="cuda:0")
+    bms, ops, stats = handle.iterate_matches_dev(empty, 0, params)
+    assert len(bms) == 0 and ops == [] and stats.num_ext_score == 0 and stats.hits_duplicate == 0
+    assert len(handle.widen_and_preprocess_dev(empty, 0)) == 0
+    want_all, _, _ = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, m.copy(), params)
+    for k in (1, 2, len(m)):
+        one = np.repeat(m[:1], k) if k > 1 and k < len(m) else m[:k]
+        db, do, ds = handle.iterate_matches_dev(_to_device(one), len(one), params)
+        hb, ho, hs = handle.iterate_matches(q, qoff, qlen, qlen, None, soff, slen, one.copy(), params)
+        _assert_records_equal(db, do, hb, ho)
+        assert ds.hits_duplicate == hs.hits_duplicate == (k - 1 if 1 < k < len(m) else hs.hits_duplicate)
+    bad = m.copy()
+    bad["subjId"][len(bad) // 2] = len(slen)  # no such subject
+    with pytest.raises(capi.LambdaExtError):
+        handle.iterate_matches_dev(_to_device(bad), len(bad), params)
+    db, do, _ = handle.iterate_matches_dev(_to_device(m), len(m), params)
+    assert len(db) == len(want_all) and db.tobytes() == want_all.tobytes()
+    with pytest.raises(capi.LambdaExtError):  # the device entry point has no band mode (include/lambda_ext.h)
+        handle.iterate_matches_dev(_to_device(m), len(m), capi.SearchParams(10.0, -1, 0, int(slen.sum()), 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka, 16))
+    db, do, _ = handle.iterate_matches_dev(_to_device(m), len(m), params)
+    assert db.tobytes() == want_all.tobytes()
+
+
 def _assert_records_equal(a, ao, b, bo):
     assert len(a) == len(b)
     assert a.tobytes() == b.tobytes()
