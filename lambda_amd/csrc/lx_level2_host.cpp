@@ -79,12 +79,21 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
         return rc;
     auto & l2   = h->l2;
     int const f = std::max(1, qry_num_frames);
-    l2.q_bytes  = 0; // (nothing resident until everything is)
-    l2.q_hash   = 0; // (lx_iterate_matches knows the content of what IT made resident, nothing else's)
-    l2.q_off.assign(q_seq_off, q_seq_off + n_qseq);
-    l2.q_len.resize(n_qseq);
-    l2.q_evlen.resize(n_qseq);
-    std::vector<uint32_t> band(n_qseq);
+    // Validated into locals, committed to the handle only after the uploads succeeded: a failing call leaves NOTHING resident
+    // (q_bytes 0, empty tables -- what the device entry points test), never host tables of the new set over device arrays of the old.
+    auto drop = [&]()
+    {
+        l2.q_bytes = 0;
+        l2.q_hash  = 0;
+        l2.q_off.clear();
+        l2.q_len.clear();
+        l2.q_evlen.clear();
+        l2.evlens.clear();
+        l2.max_evlen = 0;
+    };
+    drop();
+    std::vector<uint64_t> q_off(q_seq_off, q_seq_off + n_qseq);
+    std::vector<uint32_t> q_len(n_qseq), q_evlen(n_qseq), band(n_qseq);
     for (uint64_t i = 0; i < n_qseq; ++i)
     {
         if (q_seq_len[i] > 0xffffffffull || !lx_slice_ok(q_seq_off[i], q_seq_len[i], q_bytes))
@@ -92,24 +101,31 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
         uint64_t const ev = q_orig_len ? q_orig_len[i / (uint64_t)f] : q_seq_len[i];
         if (ev > (1ull << 26))
             return fail(h, LX_EINVAL, "query %llu: a length of %llu is beyond the cut-off table", (unsigned long long)i, (unsigned long long)ev);
-        l2.q_len[i]   = (uint32_t)q_seq_len[i];
-        l2.q_evlen[i] = (uint32_t)ev;
-        band[i]       = (uint32_t)bandSize(q_seq_len[i]);
+        q_len[i]   = (uint32_t)q_seq_len[i];
+        q_evlen[i] = (uint32_t)ev;
+        band[i]    = (uint32_t)bandSize(q_seq_len[i]);
     }
-    l2.evlens = l2.q_evlen;
-    std::sort(l2.evlens.begin(), l2.evlens.end());
-    l2.evlens.erase(std::unique(l2.evlens.begin(), l2.evlens.end()), l2.evlens.end());
-    l2.max_evlen = l2.evlens.empty() ? 0 : l2.evlens.back();
-    l2.q_frames  = f;
+    std::vector<uint32_t> evlens = q_evlen;
+    std::sort(evlens.begin(), evlens.end());
+    evlens.erase(std::unique(evlens.begin(), evlens.end()), evlens.end());
     if ((rc = ensure(h, l2.d_qres, q_bytes + kSlack)))
         return rc;
     if (q_bytes)
         LX_HIP(h, hipMemcpyAsync(l2.d_qres.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemsetAsync(static_cast<uint8_t *>(l2.d_qres.ptr) + q_bytes, 0, kSlack, h->stream));
-    if ((rc = upload(h, l2.d_qoff, l2.q_off)) || (rc = upload(h, l2.d_qlen, l2.q_len)) || (rc = upload(h, l2.d_qband, band)) ||
-        (rc = upload(h, l2.d_qevlen, l2.q_evlen)))
+    if ((rc = upload(h, l2.d_qoff, q_off)) || (rc = upload(h, l2.d_qlen, q_len)) || (rc = upload(h, l2.d_qband, band)) ||
+        (rc = upload(h, l2.d_qevlen, q_evlen)))
+    {
+        (void)hipStreamSynchronize(h->stream); // (the uploads queued so far read this function's locals)
         return rc;
+    }
     LX_HIP(h, hipStreamSynchronize(h->stream)); // (the uploads read the caller's arrays and this function's locals)
+    l2.max_evlen = evlens.empty() ? 0 : evlens.back();
+    l2.evlens.swap(evlens);
+    l2.q_off.swap(q_off);
+    l2.q_len.swap(q_len);
+    l2.q_evlen.swap(q_evlen);
+    l2.q_frames = f;
     l2.q_bytes = q_bytes;
     return LX_OK;
 }
@@ -126,20 +142,30 @@ int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t cons
     if (rc)
         return rc;
     auto & l2 = h->l2;
+    // (as lx_set_queries: nothing of the old set stays visible while the new one is validated and uploaded)
     l2.s_hash = 0;
-    l2.s_off.assign(s_seq_off, s_seq_off + n_sseq);
-    l2.s_len.assign(s_seq_len, s_seq_len + n_sseq);
+    l2.s_off.clear();
+    l2.s_len.clear();
     l2.max_slen = l2.s_extent = 0;
+    std::vector<uint64_t> s_off(s_seq_off, s_seq_off + n_sseq), s_len(s_seq_len, s_seq_len + n_sseq);
+    uint64_t              max_slen = 0, s_extent = 0;
     for (uint64_t i = 0; i < n_sseq; ++i)
     {
         if (s_seq_off[i] + s_seq_len[i] < s_seq_off[i])
             return fail(h, LX_EINVAL, "subject sequence %llu: offset + length overflows", (unsigned long long)i);
-        l2.max_slen = std::max(l2.max_slen, s_seq_len[i]);
-        l2.s_extent = std::max(l2.s_extent, s_seq_off[i] + s_seq_len[i]);
+        max_slen = std::max(max_slen, s_seq_len[i]);
+        s_extent = std::max(s_extent, s_seq_off[i] + s_seq_len[i]);
     }
-    if ((rc = upload(h, l2.d_soff, l2.s_off)) || (rc = upload(h, l2.d_slen, l2.s_len)))
+    if ((rc = upload(h, l2.d_soff, s_off)) || (rc = upload(h, l2.d_slen, s_len)))
+    {
+        (void)hipStreamSynchronize(h->stream);
         return rc;
+    }
     LX_HIP(h, hipStreamSynchronize(h->stream));
+    l2.s_off.swap(s_off);
+    l2.s_len.swap(s_len);
+    l2.max_slen = max_slen;
+    l2.s_extent = s_extent;
     return LX_OK;
 }
 
