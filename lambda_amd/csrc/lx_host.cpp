@@ -653,6 +653,7 @@ struct XbPrep // what the host keeps about a chunk until its results are back
     uint64_t              k0 = 0, k1 = 0; // positions in the ordered list
     uint64_t              slots = 0, cap_sel = 0;
     bool                  wide = false;   // multi-query chunk: the sweep wrote int16-pair slots
+    uint64_t              exec_cells = 0, max_s = 0, max_pan = 0; // (LX_HOST_TIMING: what the chunk's wavefronts execute)
     std::vector<uint32_t> slot_src;       // original index of every slot (0xffffffff = padding)
 };
 
@@ -1630,13 +1631,17 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                         });
         // the promises of the chunk: its widest query (as a panel count) and its longest window
         uint64_t max_s = 1, max_pan = 1;
+        pr.exec_cells = 0;
         for (unsigned t = 0; t < nthreads; ++t)
         {
+            pr.exec_cells += tpad[t];
             h->xb_stats[3] += tpad[t];
             max_s   = std::max(max_s, tmaxs[t]);
             max_pan = std::max(max_pan, tpan[t]);
         }
         h->xb_stats[1] += slots;
+        pr.max_s   = max_s;
+        pr.max_pan = max_pan;
         uint64_t const max_q = (max_pan + panel / 8 - 1) / (panel / 8) * panel; // (whole panels: the slots have one part per panel)
         // a chunk that begins in the pool and goes on behind it: two slot regions
         h->mq_split = lx_handle::MqSplit{};
@@ -1788,8 +1793,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             uint32_t flags[2];
             std::memcpy(flags, cnt + 3, sizeof(flags));
             if (hm.on)
-                fprintf(stderr, "[lx host ms]   chunk %llu-%llu: %llu slots%s, error word %u, %u beyond the codes, %llu survivors\n", (unsigned long long)pr.k0,
-                        (unsigned long long)pr.k1, (unsigned long long)pr.slots, pr.wide ? " (wide)" : "", flags[1], (uint32_t)cnt[4], (unsigned long long)cnt[1]);
+                fprintf(stderr, "[lx host ms]   chunk %llu-%llu: %llu slots%s (%.2f G executed cells, longest window %llu, <= %llu columns per lane), error word %u, %u beyond the codes, %llu survivors\n",
+                        (unsigned long long)pr.k0, (unsigned long long)pr.k1, (unsigned long long)pr.slots, pr.wide ? " (wide)" : "", (double)pr.exec_cells / 1e9,
+                        (unsigned long long)pr.max_s, (unsigned long long)pr.max_pan, flags[1], (uint32_t)cnt[4], (unsigned long long)cnt[1]);
             if (flags[1] == 4 && !pr.wide && mq_cfg == 1 && !lx::dev_aids().mq_no_wide)
             {
                 // More windows beyond the compact codes than the overflow area holds int16-pair slots for (its slots are sized for the

@@ -450,6 +450,17 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
     uint8_t const * spA = sA - g;
     uint8_t const * spB = sB - g;
 
+    // The letters of the NEXT chunk are loaded at a chunk's top and taken over behind its steps, IN FRONT of its checkpoint stores:
+    // gfx950 counts loads and stores with one in-order counter, so a wait for a load that stands behind stores is a wait for the
+    // stores' acknowledgements from HBM (rounds 1-4 took the letters over at the loop's end, behind the stores: `s_waitcnt vmcnt(0)`
+    // straight after them in every chunk -- a fifth of the sweep's wave cycles parked there).  The empty asm is the use that pins
+    // the wait; the row checkpoint follows the chunk it belongs to instead of opening the next one.
+    auto chunk_stores = [&](int k0)
+    {
+        chunk_done(k0);
+        if (((k0 + 4) & 15) == 0)
+            rowck_store(k0);
+    };
     int      k0 = 0;
     uint32_t na[4], nb[4];
     fetch_checked(0, na, nb);
@@ -458,25 +469,25 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
         bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
         if (!cur_steady)
         {
-            if (k0 != 0 && (k0 & 15) == 0)
-                rowck_store(k0 - 4);
             uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
             mask_checked(k0, ca, cb);
             fetch_checked(k0 + 4, na, nb);
 #pragma unroll 1
             for (int u = 0; u < 4; ++u)
                 step(ca[u], cb[u], (k0 & 4) + u);
-            chunk_done(k0);
+            if constexpr (CKPT)
+                asm volatile("" : "+v"(na[0]), "+v"(na[1]), "+v"(na[2]), "+v"(na[3]), "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3])::"memory");
+            chunk_stores(k0);
             k0 += 4;
         }
         else
         {
             uint32_t wa = *reinterpret_cast<unaligned_u32 const *>(spA + k0);
             uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
+            if constexpr (CKPT) // (here, once, and not as a pending load that the loop's first use waits for in every iteration)
+                asm volatile("" : "+v"(wa), "+v"(wb)::"memory");
             while (k0 < steady_hi)
             {
-                if ((k0 & 15) == 0) // (k0 >= steady_lo > 0)
-                    rowck_store(k0 - 4);
                 uint32_t const ca = wa, cb = wb;
                 int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                 wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
@@ -484,14 +495,14 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
 LX_UNROLL(LX_F16_UNROLL)
                 for (int u = 0; u < 4; ++u)
                     step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), (k0 & 4) + u);
-                chunk_done(k0);
+                if constexpr (CKPT)
+                    asm volatile("" : "+v"(wa), "+v"(wb)::"memory");
+                chunk_stores(k0);
                 k0 += 4;
             }
             fetch_checked(k0, na, nb);
         }
     }
-    if (steps != 0 && (steps & 15) == 0)
-        rowck_store(steps - 4);
     if (steps & 4)
         flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
 

@@ -693,14 +693,29 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         // ramps; the chunks between the shortest and the longest window of the wavefront): ONE dword per window from inside it --
         // shifted to where the rows stand -- instead of four byte loads; mask_checked turns what is not a row of the window into
         // the pad letter (round 3 fetched bytes: a wavefront with one shorter window ran at 5.4 instead of 6.0 TCUPS)
-        auto fetch_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
+        // (two halves: the loads -- one clamped dword per window, issued a chunk ahead -- and, once the chunk's steps are through and
+        // BEFORE its checkpoint stores are issued, the shift to where the rows stand.  gfx950 counts loads and stores with ONE in-order
+        // counter: a wait for a load that stands behind stores waits for the stores' acknowledgements from HBM as well -- round 4's
+        // loops consumed their prefetches at the loop's end, behind the chunk's stores, and spent two fifths of their wave cycles there)
+        auto fetch_checked_raw = [&](int k0, uint32_t & wA, uint32_t & wB)
         {
             int const i0 = k0 - g;
-            auto one = [&](uint8_t const * sp, uint32_t lsc, uint32_t (&t)[4])
+            auto one = [&](uint8_t const * sp, uint32_t lsc) -> uint32_t
             {
-                int const      hi = max((int)lsc - 3, 0);            // last position a whole dword starts at (the buffers carry slack for windows of < 4 rows)
+                int const hi = max((int)lsc - 3, 0);            // last position a whole dword starts at (the buffers carry slack for windows of < 4 rows)
+                int const a0 = min(max(i0, 0), hi);
+                return *reinterpret_cast<unaligned_u32 const *>(sp + a0);
+            };
+            wA = one(sA, lscA);
+            wB = one(sB, lscB);
+        };
+        auto expand_checked = [&](int k0, uint32_t wA, uint32_t wB, uint32_t (&ta)[4], uint32_t (&tb)[4])
+        {
+            int const i0 = k0 - g;
+            auto one = [&](uint32_t w, uint32_t lsc, uint32_t (&t)[4])
+            {
+                int const      hi = max((int)lsc - 3, 0);
                 int const      a0 = min(max(i0, 0), hi);
-                uint32_t const w  = *reinterpret_cast<unaligned_u32 const *>(sp + a0);
                 int const      sh = i0 - a0;                         // row i0 is byte `sh` of the dword
                 uint32_t const x  = sh >= 0 ? (sh < 4 ? w >> (8 * sh) : 0u) : (sh > -4 ? w << (8 * -sh) : 0u);
                 t[0] = x & 0xffu;
@@ -708,8 +723,8 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 t[2] = (x >> 16) & 0xffu;
                 t[3] = x >> 24;
             };
-            one(sA, lscA, ta);
-            one(sB, lscB, tb);
+            one(wA, lscA, ta);
+            one(wB, lscB, tb);
         };
         auto mask_checked = [&](int k0, uint32_t (&ta)[4], uint32_t (&tb)[4])
         {
@@ -727,8 +742,15 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
         uint8_t const * spA = sA - g;
         uint8_t const * spB = sB - g;
 
-        auto carry_rotate = [&](int k0)
+        // the prefetches of the NEXT chunk are taken over here: behind the chunk's steps, in front of its stores (see fetch_checked_raw).
+        // The empty asm is the use that pins the wait to this place.
+        auto take_over = [&](uint32_t & wA, uint32_t & wB)
         {
+            if constexpr (MULTI)
+                asm volatile("" : "+v"(wA), "+v"(wB), "+v"(ninA[0]), "+v"(ninA[1]), "+v"(ninA[2]), "+v"(ninA[3]), "+v"(ninE[0]), "+v"(ninE[1]), "+v"(ninE[2]),
+                             "+v"(ninE[3])::"memory");
+            else
+                asm volatile("" : "+v"(wA), "+v"(wB)::"memory");
             if constexpr (MULTI)
             {
 #pragma unroll
@@ -737,24 +759,34 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     cinA[u] = ninA[u];
                     cinE[u] = ninE[u];
                 }
-                carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE); // (Z is the chunk's first step's here)
             }
+        };
+        // the chunk's stores: boundary codes, carry-out, and the row checkpoint behind every fourth chunk
+        auto chunk_stores = [&](int k0)
+        {
+            chunk_done(k0);
+            if (((k0 + 4) & 15) == 0)
+                rowck_codes(k0);
         };
         int      k0 = 0;
         uint32_t na[4], nb[4];
-        fetch_checked(0, na, nb);
-        carry_fetch(0, Z, ninA, ninE);
+        {
+            uint32_t rA, rB;
+            fetch_checked_raw(0, rA, rB);
+            carry_fetch(0, Z, ninA, ninE);
+            take_over(rA, rB);
+            expand_checked(0, rA, rB, na, nb);
+        }
         while (k0 < steps)
         {
             bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
             if (!cur_steady)
             {
-                if (k0 != 0 && (k0 & 15) == 0)
-                    rowck_codes(k0 - 4);
                 uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
                 mask_checked(k0, ca, cb);
-                fetch_checked(k0 + 4, na, nb);
-                carry_rotate(k0);
+                uint32_t rA, rB;
+                fetch_checked_raw(k0 + 4, rA, rB);
+                carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE); // (Z is the chunk's first step's here)
                 if constexpr (MULTI)
                 {
                     step(ca[0], cb[0], k0, 0);
@@ -769,22 +801,24 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     for (int u = 0; u < 4; ++u)
                         step(ca[u], cb[u], k0 + u, u);
                 }
-                chunk_done(k0);
+                take_over(rA, rB);
+                expand_checked(k0 + 4, rA, rB, na, nb);
+                chunk_stores(k0);
                 k0 += 4;
             }
             else
             {
                 uint32_t wa = *reinterpret_cast<unaligned_u32 const *>(spA + k0);
                 uint32_t wb = *reinterpret_cast<unaligned_u32 const *>(spB + k0);
+                // (here, once per panel, and not as a pending load that the loop's first use would have to wait for in every iteration)
+                asm volatile("" : "+v"(wa), "+v"(wb)::"memory");
                 while (k0 < steady_hi)
                 {
-                    if ((k0 & 15) == 0) // (k0 >= steady_lo > 0)
-                        rowck_codes(k0 - 4);
                     uint32_t const ca = wa, cb = wb;
                     int const      kn = max(min(k0 + 4, ls_min - 4), 0);
                     wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
                     wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
-                    carry_rotate(k0);
+                    carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE);
                     if constexpr (MULTI)
                     {
                         step(ca & (kAlph - 1), cb & (kAlph - 1), k0, 0);
@@ -799,14 +833,15 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                         for (int u = 0; u < 4; ++u)
                             step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), k0 + u, u);
                     }
-                    chunk_done(k0);
+                    take_over(wa, wb);
+                    chunk_stores(k0);
                     k0 += 4;
                 }
-                fetch_checked(k0, na, nb);
+                uint32_t rA, rB;
+                fetch_checked_raw(k0, rA, rB);
+                expand_checked(k0, rA, rB, na, nb);
             }
         }
-        if (steps != 0 && (steps & 15) == 0)
-            rowck_codes(steps - 4);
         if (!WIDE && (steps & 4))
             flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
 
