@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LX_ABI_VERSION 2
+#define LX_ABI_VERSION 3
 #define LX_ALPH 32 /* matrix stride; alphabet_size <= 31, rank 31 is reserved as padding */
 
 enum
@@ -151,6 +151,11 @@ enum
                                    the survivors only (mode 1) instead of checkpoints for every window -- the reference's own
                                    order, src/search_algo.hpp:1246 / :1251-1283 / :1296; default 30, 0 = always the single sweep.
                                    Results are identical either way */
+    LX_OPT_ITERATE_RECORDS = 13, /* where lx_iterate_matches_dev (and lx_iterate_matches on lists it hands to the device) makes the result
+                                   records behind the two passes (src/search_algo.hpp:1287-1325: statistics, order, identity cut-off, bit
+                                   score, e-value): 0 (default) = kernels on the survivors where the backtrace left them, finished rows come
+                                   down in one copy; 1 = the host threads, from the survivors' alignments (rounds 1-4).  The records are the
+                                   same to the bit either way (tests/test_gpu_level2.py) */
     LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
                                    says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
                                    parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of

@@ -42,6 +42,7 @@ LX_OPT_PASS2_MODE = 8
 LX_OPT_BAND = 9
 LX_OPT_EXTEND_CHUNK = 10
 LX_OPT_MQ_SWEEP = 11
+LX_OPT_ITERATE_RECORDS = 13
 LX_OPT_ADAPT_PERMILLE = 12
 
 

@@ -1213,10 +1213,12 @@ void lx_destroy(lx_handle * h)
     {
         auto & l2 = h->l2;
         for (DevBuf * b : {&l2.d_qres, &l2.d_qoff, &l2.d_qlen, &l2.d_qband, &l2.d_qevlen, &l2.d_soff, &l2.d_slen, &l2.d_pair[0], &l2.d_pair[1], &l2.d_s0[0],
-                           &l2.d_s0[1], &l2.d_hist, &l2.d_head, &l2.d_tail, &l2.d_tot, &l2.d_win, &l2.d_cut, &l2.d_cnt, &l2.d_up, &l2.d_plan, &l2.d_wf})
+                           &l2.d_s0[1], &l2.d_hist, &l2.d_head, &l2.d_tail, &l2.d_tot, &l2.d_win, &l2.d_cut, &l2.d_cnt, &l2.d_up, &l2.d_plan, &l2.d_wf, &l2.d_qevidx,
+                           &l2.d_surv_hsp, &l2.d_surv_src, &l2.d_surv_codes, &l2.d_listat, &l2.d_rec, &l2.d_reccodes, &l2.d_reccnt, &l2.d_tilekeep, &l2.d_tileops,
+                           &l2.d_pre, &l2.d_exp})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up})
+        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         if (l2.ev_win)
@@ -1261,6 +1263,7 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_EXTEND_CHUNK: h->opt_extend_chunk = value; return LX_OK;
         case LX_OPT_MQ_SWEEP: h->opt_mq = value > 2 ? 1 : value; return LX_OK;
         case LX_OPT_ADAPT_PERMILLE: h->opt_adapt = std::min<uint64_t>(value, 1000); h->surv_frac = -1.0; return LX_OK;
+        case LX_OPT_ITERATE_RECORDS: h->opt_iterate_records = value ? 1 : 0; return LX_OK;
         case LX_OPT_BAND:
             if (value > (1u << 20))
                 return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
@@ -1288,6 +1291,7 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_EXTEND_CHUNK: *value = h->opt_extend_chunk; return LX_OK;
         case LX_OPT_MQ_SWEEP: *value = h->opt_mq; return LX_OK;
         case LX_OPT_ADAPT_PERMILLE: *value = h->opt_adapt; return LX_OK;
+        case LX_OPT_ITERATE_RECORDS: *value = h->opt_iterate_records; return LX_OK;
         default: return LX_EINVAL;
     }
 }

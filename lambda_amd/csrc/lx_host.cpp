@@ -3,6 +3,7 @@
 // lx_extend_batch runs the fused step as a pipeline of chunks (pinned staging, two chunks in flight, run-length coded ops on
 // the wire), band mode takes a plain path.  The device entry points they drive live in lx_api.cpp; no DP arithmetic here.
 #include "lx_internal.h"
+#include "lx_level2.h"
 using namespace lxi;
 
 // a few host threads for the per-extension loops of the host-buffer entry point (none below a quarter million items)
@@ -714,7 +715,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
-    h->res_count = 0;
+    bool       dev_list = false, want_codes = true; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
+    h->res_count         = 0;
+    h->l2.surv_on_device = false;
     int rc = bind(h);
     if (rc)
         return rc;
@@ -1787,6 +1790,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         in_flight[L]           = false;
         auto const t0          = now();
         LX_HIP(h, hipEventSynchronize(ln.ev_cnt));
+        auto const t_ev        = now();
         uint64_t const * const cnt = static_cast<uint64_t const *>(ln.p_cnt.ptr);
         uint64_t const count = cnt[0], nrle = cnt[2];
         {
@@ -1817,6 +1821,36 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             h->mq_decl_frac = (double)(uint32_t)cnt[4] / (double)pr.slots;
         }
         int rc2;
+        if (dev_list)
+        {
+            // The survivors stay where the backtrace left them (lx_records.hip makes the result records from them): the chunk's list
+            // joins the call's on the device -- a copy kernel in stream order, so that this lane's buffers are free for the chunk after
+            // next --, only the run-length codes come down, into the call's code bytes.
+            auto & l2 = h->l2;
+            if (l2.surv_total + count > l2.surv_cap)
+                return fail(h, LX_ESTATE, "the call's survivor list is longer than its capacity");
+            LX_HIP(h, lx::rec_launch_append(static_cast<lx::Hsp const *>(ln.d_hsp.ptr), static_cast<uint32_t const *>(ln.d_src.ptr),
+                                            static_cast<uint64_t const *>(ln.d_cnt.ptr), count, ops_total, static_cast<lx::Hsp *>(l2.d_surv_hsp.ptr) + l2.surv_total,
+                                            static_cast<uint32_t *>(l2.d_surv_src.ptr) + l2.surv_total, static_cast<uint64_t *>(l2.d_surv_codes.ptr) + l2.surv_total,
+                                            h->stream));
+            l2.surv_total += count;
+            if (nrle && want_codes)
+            {
+                if (!h->ext_bytes.grow(ops_total + nrle + 16))
+                    return fail(h, LX_ENOMEM, "out of host memory for %llu bytes of alignment codes", (unsigned long long)(ops_total + nrle));
+                // (straight into the call's code bytes: a copy of this size into ordinary memory runs at the link's rate)
+                LX_HIP(h, hipMemcpyAsync(h->ext_bytes.data() + ops_total, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
+                LX_HIP(h, hipStreamSynchronize(h->stream3));
+            }
+            ops_total += nrle;
+            h->res_count = l2.surv_total;
+            auto const t1 = now();
+            t_wait += ms(t0, t1);
+            if (hm.on)
+                fprintf(stderr, "[lx host ms]     ... its counts came after %.2f ms of waiting, its %llu code bytes in %.2f more; the %llu records stay on the device\n",
+                        ms(t0, t_ev), (unsigned long long)nrle, ms(t_ev, t1), (unsigned long long)count);
+            return LX_OK;
+        }
         if ((rc2 = ensure_pinned(h, ln.p_hsp, count * sizeof(lx_hsp) + 16)) || (rc2 = ensure_pinned(h, ln.p_src, count * sizeof(uint32_t) + 16)) ||
             (rc2 = ensure_pinned(h, ln.p_len, count * sizeof(uint32_t) + 16)) || (rc2 = ensure_pinned(h, ln.p_rle, nrle + 16)))
             return rc2;
@@ -1835,6 +1869,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             rc2 = append_list(L, count, nrle, nullptr);
             t_unpack += ms(t1, now());
+            if (hm.on)
+                fprintf(stderr, "[lx host ms]     ... its counts came after %.2f ms of waiting, its %llu records + %llu code bytes in %.2f more, appended in %.2f\n", ms(t0, t_ev),
+                        (unsigned long long)count, (unsigned long long)nrle, ms(t_ev, t1), ms(t1, now()));
             return rc2;
         }
         lx_hsp const * const   hs       = static_cast<lx_hsp const *>(ln.p_hsp.ptr);
@@ -2088,6 +2125,20 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
             t_prep += ms(tu0, now());
         }
+        if (as_list && ri && ri->keep_on_device)
+        {
+            // the Level-2 driver makes its records on the device (lx_records.hip): room for every chunk's survivor list, padding included
+            auto &         l2  = h->l2;
+            uint64_t const cap = nwf * kWave + 4096;
+            if ((rc = ensure(h, l2.d_surv_hsp, cap * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, cap * sizeof(uint32_t))) ||
+                (rc = ensure(h, l2.d_surv_codes, cap * sizeof(uint64_t))))
+                return rc;
+            l2.surv_cap       = cap;
+            l2.surv_total     = 0;
+            l2.surv_on_device = true;
+            dev_list          = true;
+            want_codes        = ri->want_codes;
+        }
         bool     rows_cleared = false, stream_planned = use_solo; // (the solo plan is whole before the first chunk)
         uint64_t w0           = 0;
         // ONE launch for the pool and what follows it (the slots in two regions: lx_handle::MqSplit): the pool is a tenth of the list
@@ -2183,7 +2234,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 return rc;
             ++c;
         }
-        // the scores of every extension, in caller order
+        // the scores of every extension, in caller order (a device list's scores stay on the device as well: h->d_score_all)
+        if (!dev_list)
         {
             auto const ts0 = now();
             LX_HIP(h, hipMemcpyAsync(h->p_score_all.ptr, h->d_score_all.ptr, n * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));

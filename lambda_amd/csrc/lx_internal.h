@@ -170,6 +170,7 @@ struct lx_handle
     uint64_t opt_bs_rule   = 0;
     uint64_t opt_f16       = 1;
     uint64_t opt_mq        = 1; // LX_OPT_MQ_SWEEP
+    uint64_t opt_iterate_records = 0; // LX_OPT_ITERATE_RECORDS: 0 = the Level-2 driver's records on the device (lx_records.hip), 1 = on the host threads
     // Adaptive pass 2 (LX_OPT_PASS2_MODE = 2): the share of the last batch's extensions that passed the cut-off.  Below
     // LX_OPT_ADAPT_PERMILLE the single sweep's checkpoints are mostly written for nothing, and the step runs as plain pass 1 +
     // checkpoints for the survivors only (mode 1) until the share rises again.  The device entry point never synchronises: it
@@ -212,6 +213,16 @@ struct lx_handle
         std::vector<int32_t>      min, score;
         std::vector<uint32_t>     wf_pan, wf_maxs; // a device plan's wavefronts
         hipEvent_t                ev_win = nullptr; // the window list has arrived on the host
+        // records on the device (lx_records.hip): the call's survivors as the pipeline's chunks left them (alignment, window, where the
+        // codes begin), the key / scan / record buffers, the host-made tables of the e-value
+        uint32_t              max_qlen = 0;
+        DevBuf                d_qevidx, d_surv_hsp, d_surv_src, d_surv_codes, d_listat, d_rec, d_reccodes, d_reccnt, d_tilekeep, d_tileops, d_pre, d_exp;
+        Pinned                p_reccnt, p_reccodes;
+        std::vector<uint64_t> rec_codes;              // where the records' run-length codes begin (host copy)
+        uint64_t              surv_total = 0, surv_cap = 0;
+        bool                  surv_on_device = false; // the last pipeline call kept its survivors on the device
+        double                exp_lambda = 0;         // the scheme d_exp was made for
+        uint32_t              exp_n      = 0;
     } l2;
     bool     keep_phase_events = false; // lx_extend_batch: the phase events of every chunk of the call stay (lx_last_phase_ms sums them)
     bool     in_fused      = false; // lx_extend_batch_dev is driving the sub-steps (it owns ev0/ev1 and the phase list)
@@ -387,6 +398,9 @@ struct ResidentInput
     uint32_t const * wf_maxs = nullptr;
     int              mq_cfg  = 0;
     uint64_t         cells   = 0;
+    // the survivors stay on the device (lx_handle::Level2::d_surv_*; taken where the plan above is served: surv_on_device says so),
+    // the scores too (h->d_score_all); want_codes: their run-length codes come down into the handle's code bytes
+    bool keep_on_device = false, want_codes = true;
 };
 bool solo_plan_applies(lx_handle const * h, int slot);
 int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,

@@ -84,4 +84,66 @@ hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narro
 uint64_t   l2_sort_tiles(uint64_t n);
 uint64_t   l2_scan_tiles(uint64_t n);
 
+// ---- the tail of iterateMatchesFullSimd on the device (lx_records.hip): statistics, order, records ------------------------------
+
+// lx_blast_match (include/lambda_ext.h) as the device writes it; the host asserts the two layouts equal
+struct BlastMatchDev
+{
+    uint64_t qry_id, subj_id, n_qid, n_sid, q_start, q_end, s_start, s_end;
+    int32_t  score, alignment_length, num_matches, num_mismatches, num_positives, num_gap_opens, num_gap_extensions;
+    float    identity;
+    double   bit_score, e_value;
+    uint64_t ops_off;
+    uint32_t n_ops;
+    int16_t  q_frame, s_frame;
+};
+static_assert(sizeof(BlastMatchDev) == 128, "BlastMatchDev layout");
+
+enum
+{
+    kRecSurvivors = 0, // stored entries that are survivors (the rest is padding of the chunks' lists)
+    kRecFailedBit = 1, // :1260
+    kRecFailedEv  = 2, // :1274
+    kRecKept      = 3, // records behind the identity cut-off
+    kRecOps       = 4, // their alignment columns
+    kRecErr       = 5, // bit 0: an entry that could not be traced, bit 1: an entry names a window outside the list
+    kRecCounters  = 8
+};
+
+struct RecParams
+{
+    // the survivors as the extension pipeline left them (all chunks of the call): alignment, window, where the codes begin
+    Hsp const *      hsp;
+    uint32_t const * src;
+    uint64_t const * codes_off;
+    uint64_t         n_entries;
+    // the windows of this part of the list, their scores of pass 1 and the filter's cut-offs
+    L2Window const * win;
+    int32_t const *  score;
+    int32_t const *  min_score;
+    uint64_t         n_win;
+    uint32_t const * q_len;   // [n_qseq]
+    uint32_t const * q_evidx; // [n_qseq] index of the query's e-value length among the distinct ones (pre_by_len)
+    uint32_t         q_frames, s_frames, n_qid_end; // n_qid_end: one past the largest true query id
+    int              q_mode, s_mode;
+    int32_t          bit_cut;   // scores below it fail the bit-score test (INT32_MIN: no such test)
+    int32_t          id_cutoff;
+    int              want_ops;
+    double           lambda, log_k, log_2;
+    double const *   pre_by_len; // K * (ql - adj) * (dl - adj) per distinct e-value length, the host's doubles
+    double const *   exp_tab;    // exp(-lambda s), s < exp_n, the host's doubles
+    uint32_t         exp_n;
+    uint64_t         ops_base;   // first column of this part in the result's ops
+    // work and results
+    uint32_t *       list_at;    // [n_win]
+    uint64_t *       counters;   // [kRecCounters]
+    BlastMatchDev *  rec;        // [<= survivors]
+    uint64_t *       rec_codes;  // [3 x (<= survivors)] per record: where its codes begin, where its columns go, how many columns
+};
+
+hipError_t rec_launch_append(Hsp const * hsp, uint32_t const * src, uint64_t const * count_ptr, uint64_t cap, uint64_t code_base, Hsp * out_hsp, uint32_t * out_src,
+                             uint64_t * out_codes, hipStream_t stream);
+hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t pair_bits, uint64_t s0_bits,
+                      uint32_t * ghist, uint32_t * tile_keep, uint64_t * tile_ops, hipStream_t stream);
+
 } // namespace lx

@@ -7,6 +7,7 @@
 // them.  What follows the two passes -- statistics, order, records (:1287-1325) -- is host/lx_iterate_common.hpp, shared with
 // lx_iterate_matches.  lx_iterate_matches itself hands its lists to this path when they are large (host/lx_driver.cpp).
 #include <cmath>
+#include <thread>
 
 #include "lx_internal.h"
 #include "lx_level2.h"
@@ -108,13 +109,21 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
     std::vector<uint32_t> evlens = q_evlen;
     std::sort(evlens.begin(), evlens.end());
     evlens.erase(std::unique(evlens.begin(), evlens.end()), evlens.end());
+    // (for the records kernel, lx_records.hip: which of the distinct e-value lengths a query has; the longest query bounds a sort digit)
+    std::vector<uint32_t> evidx(n_qseq);
+    uint32_t              max_qlen = 0;
+    for (uint64_t i = 0; i < n_qseq; ++i)
+    {
+        evidx[i] = (uint32_t)(std::lower_bound(evlens.begin(), evlens.end(), q_evlen[i]) - evlens.begin());
+        max_qlen = std::max(max_qlen, q_len[i]);
+    }
     if ((rc = ensure(h, l2.d_qres, q_bytes + kSlack)))
         return rc;
     if (q_bytes)
         LX_HIP(h, hipMemcpyAsync(l2.d_qres.ptr, q_res, q_bytes, hipMemcpyHostToDevice, h->stream));
     LX_HIP(h, hipMemsetAsync(static_cast<uint8_t *>(l2.d_qres.ptr) + q_bytes, 0, kSlack, h->stream));
     if ((rc = upload(h, l2.d_qoff, q_off)) || (rc = upload(h, l2.d_qlen, q_len)) || (rc = upload(h, l2.d_qband, band)) ||
-        (rc = upload(h, l2.d_qevlen, q_evlen)))
+        (rc = upload(h, l2.d_qevlen, q_evlen)) || (rc = upload(h, l2.d_qevidx, evidx)))
     {
         (void)hipStreamSynchronize(h->stream); // (the uploads queued so far read this function's locals)
         return rc;
@@ -126,7 +135,8 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
     l2.q_len.swap(q_len);
     l2.q_evlen.swap(q_evlen);
     l2.q_frames = f;
-    l2.q_bytes = q_bytes;
+    l2.max_qlen = max_qlen;
+    l2.q_bytes  = q_bytes;
     return LX_OK;
 }
 
@@ -249,8 +259,180 @@ static int level2_keys(lx_handle * h, void const * d_matches, uint64_t n_matches
     return LX_OK;
 }
 
+static_assert(sizeof(lx::BlastMatchDev) == sizeof(lx_blast_match) && offsetof(lx::BlastMatchDev, bit_score) == offsetof(lx_blast_match, bit_score) &&
+                  offsetof(lx::BlastMatchDev, ops_off) == offsetof(lx_blast_match, ops_off) && offsetof(lx::BlastMatchDev, q_frame) == offsetof(lx_blast_match, q_frame) &&
+                  offsetof(lx::BlastMatchDev, identity) == offsetof(lx_blast_match, identity) && offsetof(lx::BlastMatchDev, s_end) == offsetof(lx_blast_match, s_end),
+              "the device writes lx_blast_match rows");
+
+// The tail of iterateMatchesFullSimd (src/search_algo.hpp:1287-1325) for a part of the window list whose survivors the extension
+// pipeline left on the device (lx_handle::Level2::d_surv_*): statistics, order, identity cut-off, records as kernels (lx_records.hip),
+// then ONE copy of finished lx_blast_match rows into the result and the alignment columns expanded from the run-length codes by the
+// host threads.  What host/lx_iterate_common.hpp's finishSurvivors does for lists in host memory, with the same results to the bit.
+static int level2_records_on_device(lx_handle * h, uint64_t part_lo, uint64_t n_win, lx_search_params const * params, lambda_amd::CutOffs & cutOffFor,
+                                    lx_iterate_result * res, HostMarks & hm)
+{
+    using namespace lambda_amd;
+    auto &            l2 = h->l2;
+    hipStream_t const st = h->stream;
+    int               rc;
+    uint64_t const    n_entries = l2.surv_total;
+    bool const        want_ops  = !(params->flags & LX_ITERATE_NO_OPS);
+    int const         qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
+    // ---- the host's share of the arithmetic, made once per call with the host's libm: per distinct e-value length the factor
+    // K * (ql - adj) * (dl - adj) of computeEValue (blast_stats.hpp), exp(-lambda s) for every score until it is zero, the bit-score
+    // test as an integer cut-off
+    std::vector<double> pre(std::max<size_t>(l2.evlens.size(), 1), 0.0);
+    for (size_t i = 0; i < l2.evlens.size(); ++i)
+    {
+        uint64_t const ql  = (uint64_t)l2.evlens[i] / (params->query_translated ? 3 : 1);
+        auto           it  = cutOffFor.evalue.cachedLengthAdjustments.find(ql);
+        uint64_t const adj = it != cutOffFor.evalue.cachedLengthAdjustments.end() ? it->second : lengthAdjustment(params->db_total_length, ql, params->karlin);
+        pre[i]             = params->karlin.K * (double)(ql - adj) * (double)(params->db_total_length - adj);
+    }
+    if (l2.exp_lambda != params->karlin.lambda || l2.exp_n == 0)
+    {
+        std::vector<double> tab;
+        for (uint32_t sc = 0; sc < (1u << 20); ++sc)
+        {
+            double const v = std::exp(-params->karlin.lambda * (double)sc);
+            tab.push_back(v);
+            if (v == 0.0)
+                break;
+        }
+        if ((rc = upload(h, l2.d_exp, tab)))
+            return rc;
+        LX_HIP(h, hipStreamSynchronize(st)); // (`tab` is a local)
+        l2.exp_lambda = params->karlin.lambda;
+        l2.exp_n      = (uint32_t)tab.size();
+    }
+    int32_t bit_cut = INT32_MIN;
+    if (params->min_bitscore >= 0)
+    {
+        auto const fails = [&](int32_t sc) { return computeBitScore(sc, params->karlin) < params->min_bitscore; };
+        int64_t    lo = -(1ll << 30), hi = 1ll << 30; // fails(lo), !fails(hi)
+        if (!fails((int32_t)lo))
+            bit_cut = INT32_MIN;
+        else if (fails((int32_t)hi))
+            bit_cut = INT32_MAX;
+        else
+        {
+            while (hi - lo > 1)
+            {
+                int64_t const mid = lo + (hi - lo) / 2;
+                (fails((int32_t)mid) ? lo : hi) = mid;
+            }
+            bit_cut = (int32_t)hi;
+        }
+    }
+    uint64_t const tiles = (n_entries + 255) / 256, sort_n = std::max<uint64_t>(n_entries, 1);
+    if ((rc = upload(h, l2.d_pre, pre)) || (rc = ensure(h, l2.d_listat, n_win * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_reccnt, lx::kRecCounters * sizeof(uint64_t))) ||
+        (rc = ensure(h, l2.d_rec, n_entries * sizeof(lx_blast_match) + 16)) || (rc = ensure(h, l2.d_reccodes, 3 * n_entries * sizeof(uint64_t) + 16)) ||
+        (rc = ensure(h, l2.d_tilekeep, (tiles + 1) * sizeof(uint32_t))) || (rc = ensure(h, l2.d_tileops, (tiles + 1) * sizeof(uint64_t))) ||
+        (rc = ensure(h, l2.d_pair[0], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_pair[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], sort_n * 8 + 16)) ||
+        (rc = ensure(h, l2.d_s0[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_hist, (lx::l2_sort_tiles(sort_n) + 2) * 256 * sizeof(uint32_t))) ||
+        (rc = ensure_pinned(h, l2.p_reccnt, lx::kRecCounters * sizeof(uint64_t))))
+    {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    LX_HIP(h, hipMemsetAsync(l2.d_reccnt.ptr, 0, lx::kRecCounters * sizeof(uint64_t), st));
+    LX_HIP(h, hipMemsetAsync(l2.d_listat.ptr, 0xff, n_win * sizeof(uint32_t), st));
+    uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size();
+    lx::RecParams  p{};
+    p.hsp        = static_cast<lx::Hsp const *>(l2.d_surv_hsp.ptr);
+    p.src        = static_cast<uint32_t const *>(l2.d_surv_src.ptr);
+    p.codes_off  = static_cast<uint64_t const *>(l2.d_surv_codes.ptr);
+    p.n_entries  = n_entries;
+    p.win        = static_cast<lx::L2Window const *>(l2.d_win.ptr) + part_lo;
+    p.score      = static_cast<int32_t const *>(h->d_score_all.ptr);
+    p.min_score  = static_cast<int32_t const *>(h->d_min_all.ptr) + part_lo;
+    p.n_win      = n_win;
+    p.q_len      = static_cast<uint32_t const *>(l2.d_qlen.ptr);
+    p.q_evidx    = static_cast<uint32_t const *>(l2.d_qevidx.ptr);
+    p.q_frames   = (uint32_t)qFrames;
+    p.s_frames   = (uint32_t)sFrames;
+    p.n_qid_end  = (uint32_t)((l2.q_len.size() + (uint64_t)qFrames - 1) / (uint64_t)qFrames);
+    p.q_mode     = params->q_frame_mode;
+    p.s_mode     = params->s_frame_mode;
+    p.bit_cut    = bit_cut;
+    p.id_cutoff  = params->id_cutoff;
+    p.want_ops   = want_ops ? 1 : 0;
+    p.lambda     = params->karlin.lambda;
+    p.log_k      = std::log(params->karlin.K);
+    p.log_2      = std::log(2.0);
+    p.pre_by_len = static_cast<double const *>(l2.d_pre.ptr);
+    p.exp_tab    = static_cast<double const *>(l2.d_exp.ptr);
+    p.exp_n      = l2.exp_n;
+    p.ops_base   = ops0;
+    p.list_at    = static_cast<uint32_t *>(l2.d_listat.ptr);
+    p.counters   = static_cast<uint64_t *>(l2.d_reccnt.ptr);
+    p.rec        = static_cast<lx::BlastMatchDev *>(l2.d_rec.ptr);
+    p.rec_codes  = static_cast<uint64_t *>(l2.d_reccodes.ptr);
+    uint64_t * pair = static_cast<uint64_t *>(l2.d_pair[0].ptr), * pair_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
+    uint64_t * s0 = static_cast<uint64_t *>(l2.d_s0[0].ptr), * s0_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
+    // the digits the keys can have set: (true query id | padding's id, query slice length), (subject slice length, window | entry)
+    uint64_t const pair_bits = (bits_below((uint64_t)p.n_qid_end + 1) << 32) | bits_below((uint64_t)l2.max_qlen + 1);
+    uint64_t const s0_bits   = (bits_below(std::min<uint64_t>(l2.max_slen, 0xfffffffeull) + 1) << 32) | bits_below(std::max(n_win, n_entries) + 1);
+    LX_HIP(h, lx::rec_launch(p, &pair, &pair_tmp, &s0, &s0_tmp, pair_bits, s0_bits, static_cast<uint32_t *>(l2.d_hist.ptr), static_cast<uint32_t *>(l2.d_tilekeep.ptr),
+                             static_cast<uint64_t *>(l2.d_tileops.ptr), st));
+    LX_HIP(h, hipMemcpyAsync(l2.p_reccnt.ptr, l2.d_reccnt.ptr, lx::kRecCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    LX_HIP(h, hipStreamSynchronize(st)); // (also: `pre` is a local)
+    uint64_t const * const cnt = static_cast<uint64_t const *>(l2.p_reccnt.ptr);
+    if (cnt[lx::kRecErr] & 1)
+        return fail(h, LX_EOVERFLOW, "an extension of the list could not be traced");
+    if (cnt[lx::kRecErr] & 2)
+        return fail(h, LX_ESTATE, "a survivor names a window outside the list");
+    uint64_t const ns = cnt[lx::kRecSurvivors], nkeep = cnt[lx::kRecKept], nops = cnt[lx::kRecOps];
+    if (ns > n_entries || nkeep > ns)
+        return fail(h, LX_ESTATE, "the records kernels report %llu records of %llu survivors of %llu entries", (unsigned long long)nkeep, (unsigned long long)ns,
+                    (unsigned long long)n_entries);
+    res->stats.failed_bitscore += cnt[lx::kRecFailedBit];
+    res->stats.failed_evalue += cnt[lx::kRecFailedEv];
+    hm.mark("statistics+order+records (kernels)");
+    if (ns == 0)
+        return LX_OK;
+    res->stats.num_ext_ali += ns; // :1287
+    res->stats.failed_identity += ns - nkeep;
+    if (!res->matches.resize(rec0 + nkeep) || !res->ops.resize(ops0 + nops))
+        return fail(h, LX_ENOMEM, "out of host memory for the result records");
+    if (nkeep == 0)
+        return LX_OK;
+    // where the records' codes begin and their columns go (24 bytes per record) first: the host threads expand the columns from the
+    // run-length codes WHILE the rows themselves come down (1.8 ms of copy beside 2.0 ms of expansion on a million reads)
+    std::vector<uint64_t> & codes_at = l2.rec_codes;
+    std::thread            expander;
+    if (want_ops)
+    {
+        codes_at.resize(3 * nkeep);
+        LX_HIP(h, hipMemcpy(codes_at.data(), l2.d_reccodes.ptr, 3 * nkeep * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        uint8_t const * const codes = h->ext_bytes.data();
+        uint8_t * const       ops   = res->ops.data();
+        expander = std::thread(
+            [&codes_at, codes, ops, nkeep]()
+            {
+                parallelRanges(nkeep,
+                               [&](unsigned, uint64_t lo, uint64_t hi)
+                               {
+                                   for (uint64_t r = lo; r < hi; ++r)
+                                   {
+                                       if (r + 8 < hi)
+                                           __builtin_prefetch(codes + codes_at[3 * (r + 8)]);
+                                       (void)lx_expand_ops(codes + codes_at[3 * r], (int32_t)codes_at[3 * r + 2], ops + codes_at[3 * r + 1]);
+                                   }
+                               });
+            });
+    }
+    hipError_t const e_rows = hipMemcpy(res->matches.data() + rec0, l2.d_rec.ptr, nkeep * sizeof(lx_blast_match), hipMemcpyDeviceToHost);
+    hm.mark("rows");
+    if (expander.joinable())
+        expander.join();
+    hm.mark("columns (the rest)");
+    LX_HIP(h, e_rows);
+    return LX_OK;
+}
+
 // The list work and the extension for matches that stand on the device as sort words already.  Appends to *res.
-static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_search_params const * params, lx_iterate_result * res)
+static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_search_params const * params, lx_iterate_result * res, bool windows_to_host)
 {
     using namespace lambda_amd;
     auto &            l2 = h->l2;
@@ -271,10 +453,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     hm.mark("sort+merge");
     if (nw == 0)
         return LX_OK;
-    // the window list comes down (24 B per window) on the copy stream, beside what follows: the records need it, and the plan of
-    // the sweep where it is made on the host
-    if ((rc = ensure_pinned(h, l2.p_win, nw * sizeof(lx::L2Window) + 16)))
-        return rc;
+    // The window list comes down (24 B per window) on the copy stream, beside what follows, where the host needs it: for the plan of
+    // the sweep where that is made on the host, for the records where they are (LX_OPT_ITERATE_RECORDS = 1), for a caller's span
+    // (lx_iterate_matches).  Records made on the device over a device plan need none of it.
+    bool const records_on_device = h->opt_iterate_records == 0;
     if (!l2.ev_win)
         LX_HIP(h, hipEventCreateWithFlags(&l2.ev_win, hipEventDisableTiming));
     // (queued behind what `st` holds at that moment: where the plan is made on the device, behind the plan's kernels -- beside them
@@ -285,15 +467,19 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
         if (win_queued)
             return LX_OK;
         win_queued = true;
+        int rcw;
+        if ((rcw = ensure_pinned(h, l2.p_win, nw * sizeof(lx::L2Window) + 16)))
+            return rcw;
         LX_HIP(h, hipEventRecord(l2.ev_win, st));
         LX_HIP(h, hipStreamWaitEvent(h->stream2, l2.ev_win, 0));
         LX_HIP(h, hipMemcpyAsync(l2.p_win.ptr, l2.d_win.ptr, nw * sizeof(lx::L2Window), hipMemcpyDeviceToHost, h->stream2));
         LX_HIP(h, hipEventRecord(l2.ev_win, h->stream2));
         return LX_OK;
     };
-    bool                       win_here = false;
-    lx::L2Window const * const win      = static_cast<lx::L2Window const *>(l2.p_win.ptr);
-    l2.score.resize(nw);
+    bool                 win_here = false;
+    lx::L2Window const * win      = nullptr; // (l2.p_win, once queue_windows has made room)
+    if (!records_on_device)
+        l2.score.resize(nw);
     uint64_t const * const cost = static_cast<uint64_t const *>(l2.p_cnt.ptr) + 3; // [part][19, 13, 11 columns, cells]
     auto const window = [&](uint64_t i)
     {
@@ -354,7 +540,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             l2.wf_maxs.resize(nwf);
             LX_HIP(h, hipMemcpyAsync(l2.wf_pan.data(), d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             LX_HIP(h, hipMemcpyAsync(l2.wf_maxs.data(), d_maxs, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            if ((rc = queue_windows()))
+            if ((windows_to_host || !records_on_device) && (rc = queue_windows()))
                 return rc;
             LX_HIP(h, hipStreamSynchronize(st));
             ri.d_plan  = static_cast<uint32_t const *>(l2.d_plan.ptr);
@@ -363,8 +549,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             ri.wf_maxs = l2.wf_maxs.data();
             ri.mq_cfg  = cfg;
             ri.cells   = cost[4 * pi + 3];
+            ri.keep_on_device = records_on_device;
+            ri.want_codes     = !(params->flags & LX_ITERATE_NO_OPS);
             hm.mark("plan");
-            if ((rc = extend_list_resident(h, pt.slot, ri, nullptr, n, nullptr, l2.score.data() + pt.lo, &list)))
+            if ((rc = extend_list_resident(h, pt.slot, ri, nullptr, n, nullptr, records_on_device ? nullptr : l2.score.data() + pt.lo, &list)))
                 return rc;
         }
         else
@@ -376,6 +564,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             {
                 LX_HIP(h, hipEventSynchronize(l2.ev_win));
                 win_here = true;
+                win      = static_cast<lx::L2Window const *>(l2.p_win.ptr);
                 l2.ext.resize(nw);
                 l2.min.resize(nw);
                 parallelRanges(nw,
@@ -394,14 +583,27 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                                });
                 hm.mark("windows");
             }
-            if ((rc = extend_list_resident(h, pt.slot, ri, l2.ext.data() + pt.lo, n, l2.min.data() + pt.lo, l2.score.data() + pt.lo, &list)))
+            ri.keep_on_device = records_on_device;
+            ri.want_codes     = !(params->flags & LX_ITERATE_NO_OPS);
+            if ((rc = extend_list_resident(h, pt.slot, ri, l2.ext.data() + pt.lo, n, l2.min.data() + pt.lo, records_on_device ? nullptr : l2.score.data() + pt.lo, &list)))
                 return rc;
         }
         hm.mark("extension");
+        if (l2.surv_on_device)
+        {
+            if ((rc = level2_records_on_device(h, pt.lo, n, params, cutOffFor, res, hm)))
+                return rc;
+            continue;
+        }
+        if (records_on_device) // (the pipeline served the list without the multi-query plan: its survivors and scores are on the host)
+            return fail(h, LX_ESTATE, "the extension pipeline did not keep the survivors on the device");
         if (!win_here)
         {
+            if ((rc = queue_windows()))
+                return rc;
             LX_HIP(h, hipEventSynchronize(l2.ev_win));
             win_here = true;
+            win      = static_cast<lx::L2Window const *>(l2.p_win.ptr);
         }
         uint64_t const base = pt.lo;
         if ((rc = finishSurvivors(n, [&](uint64_t i) { return window(base + i); }, l2.score.data() + pt.lo, [&](uint64_t i) { return minOf(base + i); }, list, params, res)))
@@ -410,6 +612,12 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     }
     if (params->bisulfite) // the HSPs are stably re-sorted by query (:1379); the ops offsets stay valid: only the records move
         std::stable_sort(res->matches.begin(), res->matches.end(), [](lx_blast_match const & a, lx_blast_match const & b) { return a.n_qid < b.n_qid; });
+    if (windows_to_host)
+    {
+        if ((rc = queue_windows()))
+            return rc;
+        LX_HIP(h, hipEventSynchronize(l2.ev_win));
+    }
     return LX_OK;
 }
 
@@ -527,7 +735,7 @@ int lxi::iterate_host_list_on_device(lx_handle * h, int slot, uint8_t const * q_
     uint64_t const ruleBefore = h->opt_bs_rule;
     if (bs)
         h->opt_bs_rule = 1; // the bisulfite overload of computeAlignmentStats for the duration of the call
-    rc             = level2_sorted_tail(h, slot, n_matches, params, res);
+    rc             = level2_sorted_tail(h, slot, n_matches, params, res, true);
     h->opt_bs_rule = ruleBefore;
     if (rc)
         return rc;
@@ -564,6 +772,8 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
         return fail(h, LX_EINVAL, "qry_num_frames = %d, but the queries were set with %d frames", params->qry_num_frames, l2.q_frames);
     if (params->band > 0 || h->opt_band)
         return fail(h, LX_EINVAL, "lx_iterate_matches_dev: band mode (lx_search_params.band, LX_OPT_BAND) goes through lx_iterate_matches");
+    if (params->flags & ~(int32_t)LX_ITERATE_NO_OPS)
+        return fail(h, LX_EINVAL, "lx_search_params.flags = 0x%x: unknown bits (this library knows LX_ITERATE_NO_OPS)", (unsigned)params->flags);
     if (!params->bisulfite && (slot < 0 || slot > 1 || !h->have_sc[slot]))
         return fail(h, LX_ESTATE, "scoring slot %d not set", slot);
     if (params->bisulfite && (!h->have_sc[0] || !h->have_sc[1]))
@@ -582,7 +792,7 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
     if (params->bisulfite)
         h->opt_bs_rule = 1;
     if ((rc = level2_keys(h, d_matches, n_matches, params->bisulfite != 0)) == LX_OK)
-        rc = level2_sorted_tail(h, slot, n_matches, params, res);
+        rc = level2_sorted_tail(h, slot, n_matches, params, res, false);
     h->opt_bs_rule = ruleBefore;
     if (rc != LX_OK)
     {

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(lx_lib):
     missing = [s for s in decl if not hasattr(lx_lib, s)]
     assert not missing, missing
     assert sorted(capi.EXPORTED_SYMBOLS) == decl
-    assert lx_lib.lx_abi_version() == 2
+    assert lx_lib.lx_abi_version() == 3
 
 
 def test_library_matches_the_source_tree(lx_lib):

@@ -328,3 +328,65 @@ def test_iterate_matches_hands_large_host_lists_to_the_device(handle, oracle):
     q3[k:] = np.roll(q[k:], 7)  # the last 2 000 queries (where the planted homologies survive in the subjects) read differently now
     b3, _, _ = handle.iterate_matches(q3, qoff, qlen, qlen, None, soff, slen, m, params)
     assert len(b3) > 2000 and b3.tobytes() != big.tobytes()
+
+
+@pytest.mark.parametrize("scheme,frames,id_cutoff,min_bits", [("blosum62", 1, 0, -1), ("blosum62", 1, 40, 25), ("nucl", 2, 0, -1), ("nucl", 2, 75, 30)])
+def test_records_made_on_the_device_equal_the_host_threads(handle, scheme, frames, id_cutoff, min_bits):
+    """The tail of iterateMatchesFullSimd (/root/reference/src/search_algo.hpp:1287-1325: statistics of the filter, the survivors' order,
+    _expandAlign, identity cut-off, bit score, e-value) as kernels (lx_records.hip, LX_OPT_ITERATE_RECORDS = 0, the default) against the
+    host threads' finishSurvivors on the same survivors (= 1): the same bytes -- records, columns, statistics -- with an identity
+    cut-off that drops records and a bit-score filter that splits the failures."""
+    sc_p = SCHEMES[scheme]
+    handle.set_scoring(sc_p, 0)
+    rng = np.random.default_rng(2024 + frames + id_cutoff)
+    dna = scheme == "nucl"
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 3000 * frames, 300, 10, lq_range=(140, 160) if dna else (50, 400),
+                                                 alphabet=np.arange(4, dtype=np.uint8) if dna else None)
+    qorig = qlen[::frames].copy()
+    ka = capi.karlin_params(0, 2, -3, -5, -2) if dna else capi.karlin_params(62)
+    mode = capi.LX_FRAMES_REVCOMP if frames == 2 else capi.LX_FRAMES_NONE
+    params = capi.SearchParams(1e-2, min_bits, id_cutoff, int(slen.sum()) * 50, 0, frames, 1, 0, mode, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qorig, frames)
+    d_m = _to_device(m[rng.permutation(len(m))])
+    try:
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 1)
+        hb, ho, hs = handle.iterate_matches_dev(d_m, len(m), params)
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 0)
+        db, do, ds = handle.iterate_matches_dev(d_m, len(m), params)
+    finally:
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 0)
+    assert len(hb) > 300
+    assert db.tobytes() == hb.tobytes()
+    assert do == ho
+    for f in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity", "num_ext_score", "num_ext_ali"):
+        assert getattr(ds, f) == getattr(hs, f), f
+    if id_cutoff:
+        assert hs.failed_identity > 0 and hs.failed_bitscore > 0 and hs.failed_evalue > 0
+
+
+def test_a_rejected_query_set_leaves_nothing_resident(handle):
+    """lx_set_queries / lx_set_subject_seqs validate before they commit: after a rejected set the device entry points report LX_ESTATE
+    instead of reading the previous set's device arrays with the new set's sizes."""
+    handle.set_scoring(SCHEMES["nucl"], 0)
+    rng = np.random.default_rng(5)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 200, 20, 4, lq_range=(100, 120), alphabet=np.arange(4, dtype=np.uint8))
+    ka = capi.karlin_params(0, 2, -3, -5, -2)
+    params = capi.SearchParams(1e-2, -1, 0, int(slen.sum()), 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    handle.iterate_matches_dev(_to_device(m), len(m), params)
+    bad_len = np.concatenate([qlen, qlen]).astype(np.uint64)  # twice the sequences, the second half beyond the residue buffer
+    bad_off = np.concatenate([qoff, qoff + np.uint64(q.size)]).astype(np.uint64)
+    with pytest.raises(capi.LambdaExtError):
+        handle.set_queries(q, bad_off, bad_len, bad_len, 1)
+    with pytest.raises(capi.LambdaExtError) as e:
+        handle.iterate_matches_dev(_to_device(m), len(m), params)
+    assert "resident" in str(e.value)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    assert len(handle.iterate_matches_dev(_to_device(m), len(m), params)[0]) >= 0
+    bad = capi.SearchParams(1e-2, -1, 0, int(slen.sum()), 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka, 0, 0x40)
+    with pytest.raises(capi.LambdaExtError):  # unknown flag bits (a caller built against ABI 2 with the word uninitialised)
+        handle.iterate_matches_dev(_to_device(m), len(m), bad)
