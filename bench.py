@@ -97,6 +97,8 @@ def parse(argv=None):
                     "lx_iterate_matches on the same list in host memory")
     ap.add_argument("--iterate-reads", type=int, default=1_000_000)
     ap.add_argument("--iterate-mbp", type=float, default=100.0)
+    ap.add_argument("--cold", action="store_true", help="--iterate: every timed call is the FIRST call of a fresh handle (lx_create, the sequence "
+                    "sets, lx_reserve with hints, then the one call a search makes): what `lambda3 searchn` pays, not the tenth call")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
     return ap.parse_args(argv)
 
@@ -456,20 +458,53 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
                                         capi._ptr(soff), capi._ptr(slen), len(soff), capi._ptr(mm), len(mm), C.byref(params), C.byref(r)))
         return r, time.perf_counter() - t0
 
+    def digest(r):
+        """count, statistics and a checksum of the records + columns of a result (xxhash of the library's own arrays)"""
+        import xxhash
+
+        n = int(lib.lx_iterate_result_count(r))
+        st_ = lib.lx_iterate_result_stats(r)
+        rows = C.string_at(lib.lx_iterate_result_matches(r), n * capi.BLAST_MATCH_DTYPE.itemsize) if n else b""
+        cols = b""
+        ops = lib.lx_iterate_result_ops(r)
+        if n and ops:
+            bm = np.frombuffer(rows, dtype=capi.BLAST_MATCH_DTYPE)
+            cols = C.string_at(ops, int(bm["ops_off"][-1]) + int(bm["n_ops"][-1]))
+        return n, st_, xxhash.xxh64(rows).hexdigest() + xxhash.xxh64(cols).hexdigest()
+
+    # hints a search has before the call: the seeding stage's match count; windows and records as a share of it (this list: 7.6 matches
+    # per window, 12.7 per record) with a margin -- estimates that fall short only move an allocation back into the call
+    hints = (len(m), len(m) // 7, len(m) // 12, (len(m) // 12) * 160)
     stats = None
     for _ in range(max(args.warmup, 1)):
         r, _ = timed_call()
-        stats = (int(lib.lx_iterate_result_count(r)), lib.lx_iterate_result_stats(r))
+        stats = digest(r)
         lib.lx_iterate_result_free(r)
     if use_dist:
         dist.barrier()
-    times = []
+    times, setup = [], []
     for _ in range(args.steps):
+        if args.cold and on_dev:
+            h.close()
+            t0 = time.perf_counter()
+            h = capi.Handle(local_rank)
+            h.set_scoring(capi.builtin_scoring(m_, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
+            h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+            h.set_subjects(s)
+            h.set_subject_seqs(soff, slen)
+            h.set_queries(q, qoff, qlen, qorig, 2)
+            h.reserve(*hints)
+            setup.append(time.perf_counter() - t0)
         r, dt = timed_call()
         times.append(dt)
+        got = digest(r)  # (outside the timed region)
         lib.lx_iterate_result_free(r)  # (the caller's to free: not part of the call)
+        if got[0] != stats[0] or got[2] != stats[2] or got[1].num_ext_ali != stats[1].num_ext_ali:
+            raise SystemExit(f"bench.py --iterate: a timed call returned other records than the warm-up call ({got[0]} / {stats[0]} records, checksums {got[2]} / {stats[2]})")
     dt = float(sum(times))
-    n_hsp, st = stats
+    n_hsp, st, checksum = stats
+    if n_hsp != st.num_ext_ali - st.failed_identity:
+        raise SystemExit(f"bench.py --iterate: {n_hsp} records of {st.num_ext_ali} traced windows and {st.failed_identity} below the identity cut-off")
     n_win = len(m) - st.hits_duplicate
     xs = h.last_extend_stats()
     # (pass 1 of the last call: all launches of its sweep; the window list again, through the widen entry point, for the byte count and the
@@ -490,7 +525,8 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
             base["sample"] += "; pass 1 of the driver only (the sort, pass 2 and the records are not in it)"
     if rank == 0:
         print(json.dumps({
-            "metric": "ms per call of the Level-2 driver (iterateMatchesFullSimd: widen + sort + merge + unique, pass 1, filter, pass 2, records) on a "
+            "metric": ("ms per FIRST call of a fresh handle" if args.cold and on_dev else "ms per call")
+                      + " of the Level-2 driver (iterateMatchesFullSimd: widen + sort + merge + unique, pass 1, filter, pass 2, records) on a "
                       + ("DEVICE match list, lx_iterate_matches_dev" if on_dev else "HOST match list, lx_iterate_matches") + "; searchn scheme of configs[2]",
             "value": round(dt / args.steps * 1e3, 3), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_min": round(min(times) * 1e3, 3), "ms_max": round(max(times) * 1e3, 3),
@@ -501,7 +537,10 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
                                    f"({xs[2] / 1e9:.1f} Gcells) -> {st.num_ext_ali} traced -> {n_hsp} HSPs; E <= {w.max_evalue:g}",
                        "entry_point": "lx_iterate_matches_dev (matches in device memory, sequence sets resident: lx_set_queries / lx_set_subjects / "
                                       "lx_set_subject_seqs)" if on_dev else "lx_iterate_matches (host buffers, subjects resident)",
-                       "matches": len(m), "windows": int(n_win), "traced": int(st.num_ext_ali), "hsps": n_hsp,
+                       "matches": len(m), "windows": int(n_win), "traced": int(st.num_ext_ali), "hsps": n_hsp, "records_checksum": checksum,
+                       **({"cold": "every timed call is the first call of a fresh handle: lx_create + lx_set_scoring / lx_set_subjects / lx_set_subject_seqs / "
+                                   "lx_set_queries + lx_reserve%r outside the timed region (%.1f ms on average), then ONE lx_iterate_matches_dev"
+                                   % (hints, 1e3 * sum(setup) / max(len(setup), 1))} if args.cold and on_dev else {}),
                        "padding": {"extensions": xs[0], "slots": xs[1], "cells": xs[2], "executed_cells": xs[3]}},
             "gcups_of_window_cells": round(xs[2] * args.steps / dt / 1e9, 1),
             "matches_per_s": round(len(m) * args.steps / dt, 1),

@@ -473,6 +473,13 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
 int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t const * s_seq_len, uint64_t n_sseq);
 int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint64_t n_matches, lx_search_params const * params,
                            lx_iterate_result ** out);
+/* Ahead of a handle's first lx_iterate_matches_dev (or large lx_iterate_matches) call: allocates -- and, on the host side, touches -- the
+ * buffers a call on up to n_matches matches needs when they become up to n_windows windows and n_hsps result records with n_columns
+ * alignment columns in all (0: results without columns, LX_ITERATE_NO_OPS).  Call it after lx_set_queries (the lanes are sized for the
+ * longest query).  A first call costs what the tenth costs then (bench.py --iterate --cold); nothing changes but when the memory is
+ * asked for, and estimates that fall short only mean that the call grows what is missing, as it does without lx_reserve.  The reference
+ * has no counterpart: its threads' LocalDataHolder grows inside the search loop (src/search_datastructures.hpp:386-468). */
+int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n_hsps, uint64_t n_columns);
 /* _widenAndPreprocessMatches (:1136-1175) alone on a device match list over the resident sets: the window list comes back as
  * lx_match records in `out` (room for n_matches), *out_n of them -- what lx_widen_and_preprocess leaves in its span.  bisulfite != 0:
  * ordered by subjId % 2 first, as iterateMatches' bisulfite branch sorts (:1369-1372). */

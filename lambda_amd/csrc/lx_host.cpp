@@ -2103,7 +2103,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             auto const tu0 = now();
             uint64_t const ext_bytes = n * sizeof(lx_extension), min_bytes = min_score ? n * sizeof(int32_t) : 0;
-            if ((rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) || (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16)))
+            // (the scores of a list whose records are made on the device stay there: no pinned block for their way down)
+            if ((rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) ||
+                (!(as_list && ri && ri->keep_on_device) && (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16))))
                 return rc;
             if (!ri) // (a resident list stands where the Level-2 kernels wrote it)
             {

@@ -803,6 +803,121 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
     return LX_OK;
 }
 
+// What the first lx_iterate_matches_dev call of a handle would otherwise allocate inside the call: 21.9 ms against 11.9 ms for the
+// calls behind it on a million reads (tools/dev/cold_iterate.py) -- 8.5 instead of 2.1 ms for the copy of the rows into result memory
+// that was never touched, 3 ms of allocations in the pipeline -- and a search makes ONE such call per run.  The sizes below are the
+// formulas of the call's own ensure()s (level2_windows, level2_sorted_tail, level2_records_on_device, extend_pipeline's lanes); what
+// falls short grows in the call as before.
+int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n_hsps, uint64_t n_columns)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (n_matches > 0x7ffffff0ull || n_windows > n_matches || n_hsps > n_windows)
+        return fail(h, LX_EINVAL, "lx_reserve: n_hsps <= n_windows <= n_matches <= 2^31");
+    int rc = bind(h);
+    if (rc || n_matches == 0)
+        return rc;
+    auto &         l2    = h->l2;
+    uint64_t const tiles = lx::l2_sort_tiles(n_matches), stiles = lx::l2_scan_tiles(n_matches);
+    // ---- the list work (level2_keys, level2_windows) and the device plan
+    if ((rc = ensure(h, l2.d_pair[0], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_cnt, 16 * sizeof(uint64_t))) ||
+        (rc = ensure(h, l2.d_pair[1], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[1], n_matches * 8 + 16)) ||
+        (rc = ensure(h, l2.d_hist, (tiles + 2) * 256 * sizeof(uint32_t))) || (rc = ensure(h, l2.d_head, n_matches * 16 + 16)) ||
+        (rc = ensure(h, l2.d_tot, (stiles + 2) * sizeof(uint32_t))) || (rc = ensure(h, l2.d_win, n_matches * sizeof(lx::L2Window) + 16)) ||
+        (rc = ensure(h, h->d_ext_all, n_matches * sizeof(lx_extension) + 16)) || (rc = ensure(h, h->d_min_all, n_matches * sizeof(int32_t) + 16)) ||
+        (rc = ensure_pinned(h, l2.p_cnt, 16 * sizeof(uint64_t))) || (rc = ensure(h, l2.d_cut, ((size_t)l2.max_evlen + 1) * sizeof(int32_t) + 16)))
+        return rc;
+    uint64_t const nwf = (n_windows + 15) / 16, entries = nwf * 16 + 4096;
+    if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 16)))
+        return rc;
+    l2.wf_pan.reserve(nwf);
+    l2.wf_maxs.reserve(nwf);
+    // ---- the records (level2_records_on_device)
+    if ((rc = ensure(h, l2.d_surv_hsp, entries * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, entries * sizeof(uint32_t))) ||
+        (rc = ensure(h, l2.d_surv_codes, entries * sizeof(uint64_t))) || (rc = ensure(h, l2.d_listat, n_windows * sizeof(uint32_t) + 16)) ||
+        (rc = ensure(h, l2.d_reccnt, lx::kRecCounters * sizeof(uint64_t))) || (rc = ensure(h, l2.d_rec, entries * sizeof(lx_blast_match) + 16)) ||
+        (rc = ensure(h, l2.d_reccodes, 3 * entries * sizeof(uint64_t) + 16)) || (rc = ensure(h, l2.d_tilekeep, ((entries + 255) / 256 + 1) * sizeof(uint32_t))) ||
+        (rc = ensure(h, l2.d_tileops, ((entries + 255) / 256 + 1) * sizeof(uint64_t))) || (rc = ensure_pinned(h, l2.p_reccnt, lx::kRecCounters * sizeof(uint64_t))) ||
+        (rc = ensure(h, l2.d_pre, std::max<size_t>(l2.evlens.size(), 1) * sizeof(double) + 16)) || (rc = ensure(h, l2.d_exp, (1u << 13) * sizeof(double))))
+        return rc;
+    if (n_columns)
+    {
+        l2.rec_codes.resize(3 * n_hsps); // (touched: value-initialised)
+        if (!h->ext_bytes.grow(n_hsps * 8 + 4096))
+            return fail(h, LX_ENOMEM, "lx_reserve: out of host memory");
+        std::memset(h->ext_bytes.data(), 0, n_hsps * 8 + 4096);
+    }
+    // ---- the extension pipeline's two lanes (extend_pipeline: enqueue_mq), for chunks of the default size and windows of up to three times
+    // the longest query (what a merged window comes to, src/search_algo.hpp:1153-1157)
+    {
+        uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
+        uint64_t const slots  = std::min<uint64_t>(nwf * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
+        uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(1);
+        uint64_t const max_q  = std::max<uint64_t>(1, ((uint64_t)l2.max_qlen + panel - 1) / panel) * panel;
+        uint64_t const max_s  = 3 * (uint64_t)std::max<uint32_t>(l2.max_qlen, 32) + 64, stride = (max_q + max_s + 3) & ~3ull;
+        uint64_t const steps  = (max_s + 8 - 1 + 15) & ~15ull;
+        uint64_t const slot_b = max_q / panel * (lx::ckpt16_slot_dwords(1, (uint32_t)steps) + lx::ckpt_slot_dwords(1, (uint32_t)steps) / 8) * 4;
+        if ((rc = ensure(h, h->d_score_all, n_windows * sizeof(int32_t) + 16)))
+            return rc;
+        unsigned const lanes = nwf * 16 > slots ? 2 : 1;
+        for (unsigned L = 0; L < lanes; ++L)
+        {
+            lx_handle::XbLane & ln = h->xb[L];
+            if ((rc = ensure(h, ln.d_ext, slots * sizeof(lx_extension))) || (rc = ensure(h, ln.d_min, slots * sizeof(int32_t))) ||
+                (rc = ensure(h, ln.d_score, slots * sizeof(int32_t))) || (rc = ensure(h, ln.d_hsp, cap_sel * sizeof(lx_hsp))) ||
+                (rc = ensure(h, ln.d_ops, cap_sel * stride + 16)) || (rc = ensure(h, ln.d_rle, cap_sel * stride + 16)) ||
+                (rc = ensure(h, ln.d_src, cap_sel * sizeof(uint32_t))) || (rc = ensure(h, ln.d_len, cap_sel * sizeof(uint32_t))) ||
+                (rc = ensure(h, ln.d_cnt, 5 * sizeof(uint64_t))) || (rc = ensure_pinned(h, ln.p_cnt, 5 * sizeof(uint64_t))))
+                return rc;
+        }
+        // the checkpoint slots of one chunk (what LX_OPT_TRACE_BYTES admits of them), its end cells, the survivor selection's lists
+        // (fused_impl in lx_api.cpp: room for every slot plus the padding of query runs), the carry workspace
+        uint64_t const trace = std::min<uint64_t>(slots * slot_b, h->opt_trace_bytes);
+        if ((rc = ensure(h, h->d_trace, trace)) || (rc = ensure(h, h->d_ends, slots * sizeof(lx::EndCell))) || (rc = ensure(h, h->d_sel_ext, 2 * slots * sizeof(lx_extension))) ||
+            (rc = ensure(h, h->d_sel_src, 2 * slots * sizeof(uint32_t))) || (rc = ensure(h, h->d_sel_score, 2 * slots * sizeof(int32_t))) ||
+            (rc = ensure(h, h->d_sel_runs, (2 * slots + 4096) * sizeof(uint64_t))) || (rc = ensure(h, h->d_ws, std::max(h->opt_ws_bytes, h->ws_grown))))
+            return rc;
+    }
+    // ---- every kernel of the call once, on a list of one match (query 0 against the start of subject 0, no filter: it survives and is
+    // traced): what a kernel's first launch costs the runtime (2-3 ms over the call's two dozen kernels) is paid here
+    if (!l2.q_len.empty() && !l2.s_len.empty() && h->db_bytes && l2.s_extent <= h->db_bytes && (h->have_sc[0] || h->have_sc[1]) && !h->opt_band && l2.s_len[0] > 0)
+    {
+        lx_match const one{0, 0, 0, std::min<uint64_t>(l2.q_len[0], l2.s_len[0]), 0, std::min<uint64_t>(l2.q_len[0], l2.s_len[0])};
+        if ((rc = ensure(h, l2.d_up, sizeof(lx_match) + 16)))
+            return rc;
+        LX_HIP(h, hipMemcpyAsync(l2.d_up.ptr, &one, sizeof(one), hipMemcpyHostToDevice, h->stream));
+        LX_HIP(h, hipStreamSynchronize(h->stream));
+        lx_search_params sp{};
+        sp.max_evalue      = -1;
+        sp.min_bitscore    = -1;
+        sp.db_total_length = 1000000;
+        sp.qry_num_frames  = l2.q_frames;
+        sp.sbj_num_frames  = 1;
+        sp.karlin          = lx_karlin{0.3, 0.1, 0.3, 1.0, -10.0};
+        sp.flags           = n_columns ? 0 : LX_ITERATE_NO_OPS;
+        lx_iterate_result * r = nullptr;
+        rc = lx_iterate_matches_dev(h, h->have_sc[0] ? 0 : 1, l2.d_up.ptr, 1, &sp, &r);
+        if (r)
+            lx_iterate_result_free(r);
+        if (rc)
+            return rc;
+        l2.exp_lambda = 0; // (the table of exp(-lambda s) the dummy call left is not the search's)
+    }
+    // ---- the result's memory: blocks of the sizes the first result will ask for, written once (a page the kernel has not handed out
+    // yet costs a fault when the rows' copy or the expanding threads reach it), kept where a result's arrays are taken from
+    for (uint64_t bytes : {n_hsps * (uint64_t)sizeof(lx_blast_match), n_columns})
+    {
+        if (bytes < lambda_amd::BlockCache::kMinBytes)
+            continue;
+        lambda_amd::RawVec<uint8_t> block;
+        if (!block.resize(bytes))
+            return fail(h, LX_ENOMEM, "lx_reserve: out of host memory for the result blocks");
+        uint8_t * const b = block.data();
+        lambda_amd::parallelRanges(bytes / 4096, [&](unsigned, uint64_t lo, uint64_t hi) { std::memset(b + lo * 4096, 0, (hi - lo) * 4096); });
+    } // (the destructor hands the block to the cache)
+    return LX_OK;
+}
+
 // _widenAndPreprocessMatches (src/search_algo.hpp:1136-1175) alone, on a device match list over the resident sets
 int lx_widen_and_preprocess_dev(lx_handle * h, void const * d_matches, uint64_t n_matches, int32_t bisulfite, lx_match * out, uint64_t * out_n)
 {

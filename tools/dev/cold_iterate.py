@@ -28,7 +28,7 @@ for hnum in range(3):
     h.set_queries(q, qoff, qlen, qorig, 2)
     t1 = time.perf_counter()
     if reserve and hasattr(lib, "lx_reserve"):
-        h._check(lib.lx_reserve(h.h, C.c_uint64(len(m)), C.c_uint64(len(m) // 6), C.c_uint64(len(m) // 8)))
+        h.reserve(len(m), len(m) // 7, len(m) // 12, (len(m) // 12) * 160)
     t2 = time.perf_counter()
     line = f"handle {hnum}: create + sets {1e3 * (t1 - t0):.1f} ms, reserve {1e3 * (t2 - t1):.1f} ms; calls"
     for call in range(4):
