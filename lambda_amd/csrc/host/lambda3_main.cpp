@@ -992,6 +992,15 @@ int main(int argc, char ** argv)
                 {
                     eng.check(lx_set_subject_seqs(eng.raw(), db.off.data(), db.len.data(), db.off.size()));
                     eng.check(lx_set_queries(eng.raw(), qs.res.data(), qs.res.size(), qs.off.data(), qs.len.data(), qs.off.size(), qs.orig_len.data(), qFrames));
+                    // this worker makes ONE Level-2 call per seeding pass: what that call would allocate and touch inside itself is asked
+                    // for here, before the seeding (a dozen promising seeds per read, a window per seven of them, a record per twelve --
+                    // what the read sets of tools/cli_scale_nucl.py come to; a short estimate only moves an allocation back into the call)
+                    uint64_t const est = std::min<uint64_t>(12 * (rHi - rLo), 0x7ffffff0ull);
+                    uint64_t       len = 0;
+                    for (uint64_t i = rLo * (uint64_t)qFrames; i < rHi * (uint64_t)qFrames && i < qs.len.size(); ++i)
+                        len = std::max<uint64_t>(len, qs.len[i]);
+                    if (est >= 100000)
+                        eng.check(lx_reserve(eng.raw(), est, est / 7, est / 12, wantOps ? est / 12 * (len + len / 16) : 0));
                 }
                 auto pass = [&](lambda_amd::SeedParams const & so, std::vector<uint64_t> const & which)
                 {

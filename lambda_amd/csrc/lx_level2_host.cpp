@@ -819,6 +819,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         return rc;
     auto &         l2    = h->l2;
     uint64_t const tiles = lx::l2_sort_tiles(n_matches), stiles = lx::l2_scan_tiles(n_matches);
+    HostMarks      hm("lx_reserve");
     // ---- the list work (level2_keys, level2_windows) and the device plan
     if ((rc = ensure(h, l2.d_pair[0], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_cnt, 16 * sizeof(uint64_t))) ||
         (rc = ensure(h, l2.d_pair[1], n_matches * 8 + 16)) || (rc = ensure(h, l2.d_s0[1], n_matches * 8 + 16)) ||
@@ -832,6 +833,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         return rc;
     l2.wf_pan.reserve(nwf);
     l2.wf_maxs.reserve(nwf);
+    hm.mark("list work");
     // ---- the records (level2_records_on_device)
     if ((rc = ensure(h, l2.d_surv_hsp, entries * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, entries * sizeof(uint32_t))) ||
         (rc = ensure(h, l2.d_surv_codes, entries * sizeof(uint64_t))) || (rc = ensure(h, l2.d_listat, n_windows * sizeof(uint32_t) + 16)) ||
@@ -847,14 +849,18 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
             return fail(h, LX_ENOMEM, "lx_reserve: out of host memory");
         std::memset(h->ext_bytes.data(), 0, n_hsps * 8 + 4096);
     }
-    // ---- the extension pipeline's two lanes (extend_pipeline: enqueue_mq), for chunks of the default size and windows of up to three times
-    // the longest query (what a merged window comes to, src/search_algo.hpp:1153-1157)
+    hm.mark("records");
+    // ---- the extension pipeline's two lanes (extend_pipeline: enqueue_mq), for chunks of the default size; the survivors' column slots for
+    // windows of up to three times the ordinary length (what a merged window comes to, src/search_algo.hpp:1153-1157)
     {
         uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
         uint64_t const slots  = std::min<uint64_t>(nwf * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
         uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(1);
         uint64_t const max_q  = std::max<uint64_t>(1, ((uint64_t)l2.max_qlen + panel - 1) / panel) * panel;
-        uint64_t const max_s  = 3 * (uint64_t)std::max<uint32_t>(l2.max_qlen, 32) + 64, stride = (max_q + max_s + 3) & ~3ull;
+        // (the longest ORDINARY window, query + band on either side, :919-938: a list whose merged windows are longer grows its first chunk's
+        // slots in the call -- three times the checkpoint bytes for every list would be 14 GB here, and a hipMalloc of that size can
+        // take a second)
+        uint64_t const max_s  = (uint64_t)l2.max_qlen + 2 * (uint64_t)bandSize(l2.max_qlen) + 16, stride = (max_q + 3 * max_s + 3) & ~3ull;
         uint64_t const steps  = (max_s + 8 - 1 + 15) & ~15ull;
         uint64_t const slot_b = max_q / panel * (lx::ckpt16_slot_dwords(1, (uint32_t)steps) + lx::ckpt_slot_dwords(1, (uint32_t)steps) / 8) * 4;
         if ((rc = ensure(h, h->d_score_all, n_windows * sizeof(int32_t) + 16)))
@@ -870,6 +876,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
                 (rc = ensure(h, ln.d_cnt, 5 * sizeof(uint64_t))) || (rc = ensure_pinned(h, ln.p_cnt, 5 * sizeof(uint64_t))))
                 return rc;
         }
+        hm.mark("lanes");
         // the checkpoint slots of one chunk (what LX_OPT_TRACE_BYTES admits of them), its end cells, the survivor selection's lists
         // (fused_impl in lx_api.cpp: room for every slot plus the padding of query runs), the carry workspace
         uint64_t const trace = std::min<uint64_t>(slots * slot_b, h->opt_trace_bytes);
@@ -878,6 +885,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
             (rc = ensure(h, h->d_sel_runs, (2 * slots + 4096) * sizeof(uint64_t))) || (rc = ensure(h, h->d_ws, std::max(h->opt_ws_bytes, h->ws_grown))))
             return rc;
     }
+    hm.mark("checkpoint slots + selection");
     // ---- every kernel of the call once, on a list of one match (query 0 against the start of subject 0, no filter: it survives and is
     // traced): what a kernel's first launch costs the runtime (2-3 ms over the call's two dozen kernels) is paid here
     if (!l2.q_len.empty() && !l2.s_len.empty() && h->db_bytes && l2.s_extent <= h->db_bytes && (h->have_sc[0] || h->have_sc[1]) && !h->opt_band && l2.s_len[0] > 0)
@@ -903,6 +911,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
             return rc;
         l2.exp_lambda = 0; // (the table of exp(-lambda s) the dummy call left is not the search's)
     }
+    hm.mark("one-match call");
     // ---- the result's memory: blocks of the sizes the first result will ask for, written once (a page the kernel has not handed out
     // yet costs a fault when the rows' copy or the expanding threads reach it), kept where a result's arrays are taken from
     for (uint64_t bytes : {n_hsps * (uint64_t)sizeof(lx_blast_match), n_columns})
@@ -915,6 +924,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         uint8_t * const b = block.data();
         lambda_amd::parallelRanges(bytes / 4096, [&](unsigned, uint64_t lo, uint64_t hi) { std::memset(b + lo * 4096, 0, (hi - lo) * 4096); });
     } // (the destructor hands the block to the cache)
+    hm.mark("result blocks");
     return LX_OK;
 }
 
