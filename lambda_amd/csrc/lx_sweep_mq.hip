@@ -501,11 +501,12 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             }
         };
         // one DP step at step index k = k0 + u (row k - g of this lane's strip)
-        auto step = [&](uint32_t tA, uint32_t tB, int k, int u)
+        // the profile rows of one step's two letters (LDS), and the step on them: the rows of step u + 1 are fetched before step u is
+        // computed (four_steps below) -- issued where they are used, a step began with the LDS latency in the open, four times a chunk
+        auto rows = [&](uint32_t tA, uint32_t tB, uint32_t (&pa)[Geo::kD], uint32_t (&pb)[Geo::kD])
         {
             char const * const ra = reinterpret_cast<char const *>(lds) + slot_byte + tA * kRowBytes;
             char const * const rb = reinterpret_cast<char const *>(lds) + slot_byteB + tB * kRowBytes;
-            uint32_t           pa[Geo::kD], pb[Geo::kD];
             if constexpr (Geo::kN4 != 0)
             {
                 uint4 const va = *reinterpret_cast<uint4 const *>(ra + g * 16), vb = *reinterpret_cast<uint4 const *>(rb + g * 16);
@@ -523,7 +524,9 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 pa[Geo::kD - 1] = *reinterpret_cast<uint32_t const *>(ra + Geo::kBase1 * 4 + g * 4);
                 pb[Geo::kD - 1] = *reinterpret_cast<uint32_t const *>(rb + Geo::kBase1 * 4 + g * 4);
             }
-
+        };
+        auto step = [&](uint32_t const (&pa)[Geo::kD], uint32_t const (&pb)[Geo::kD], int k, int u)
+        {
             // left boundary: H[i][-1] = 0 (skewed: z; as A: z + (go - ge)), E = -inf; or the previous panel's last column
             uint32_t bndA = qbits(Z + G2), bndE = 0u;
             if constexpr (MULTI)
@@ -768,6 +771,21 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
             if (((k0 + 4) & 15) == 0)
                 rowck_codes(k0);
         };
+        auto four_steps = [&](uint32_t const (&ta)[4], uint32_t const (&tb)[4], int k0)
+        {
+            uint32_t pa0[Geo::kD], pb0[Geo::kD], pa1[Geo::kD], pb1[Geo::kD];
+            rows(ta[0], tb[0], pa0, pb0);
+            rows(ta[1], tb[1], pa1, pb1);
+            __builtin_amdgcn_sched_barrier(0); // (pins the fetches in front of the step they overlap)
+            step(pa0, pb0, k0, 0);
+            rows(ta[2], tb[2], pa0, pb0);
+            __builtin_amdgcn_sched_barrier(0);
+            step(pa1, pb1, k0 + 1, 1);
+            rows(ta[3], tb[3], pa1, pb1);
+            __builtin_amdgcn_sched_barrier(0);
+            step(pa0, pb0, k0 + 2, 2);
+            step(pa1, pb1, k0 + 3, 3);
+        };
         int      k0 = 0;
         uint32_t na[4], nb[4];
         {
@@ -787,20 +805,7 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                 uint32_t rA, rB;
                 fetch_checked_raw(k0 + 4, rA, rB);
                 carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE); // (Z is the chunk's first step's here)
-                if constexpr (MULTI)
-                {
-                    step(ca[0], cb[0], k0, 0);
-                    step(ca[1], cb[1], k0 + 1, 1);
-                    __builtin_amdgcn_sched_barrier(0); // (two steps at a time in flight, as in the loops unrolled by 2)
-                    step(ca[2], cb[2], k0 + 2, 2);
-                    step(ca[3], cb[3], k0 + 3, 3);
-                }
-                else
-                {
-#pragma unroll 2
-                    for (int u = 0; u < 4; ++u)
-                        step(ca[u], cb[u], k0 + u, u);
-                }
+                four_steps(ca, cb, k0);
                 take_over(rA, rB);
                 expand_checked(k0 + 4, rA, rB, na, nb);
                 chunk_stores(k0);
@@ -819,20 +824,9 @@ __global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
                     wa                = *reinterpret_cast<unaligned_u32 const *>(spA + kn);
                     wb                = *reinterpret_cast<unaligned_u32 const *>(spB + kn);
                     carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE);
-                    if constexpr (MULTI)
-                    {
-                        step(ca & (kAlph - 1), cb & (kAlph - 1), k0, 0);
-                        step((ca >> 8) & (kAlph - 1), (cb >> 8) & (kAlph - 1), k0 + 1, 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        step((ca >> 16) & (kAlph - 1), (cb >> 16) & (kAlph - 1), k0 + 2, 2);
-                        step((ca >> 24) & (kAlph - 1), (cb >> 24) & (kAlph - 1), k0 + 3, 3);
-                    }
-                    else
-                    {
-#pragma unroll 2
-                        for (int u = 0; u < 4; ++u)
-                            step((ca >> (8 * u)) & (kAlph - 1), (cb >> (8 * u)) & (kAlph - 1), k0 + u, u);
-                    }
+                    uint32_t const la[4] = {ca & (kAlph - 1), (ca >> 8) & (kAlph - 1), (ca >> 16) & (kAlph - 1), (ca >> 24) & (kAlph - 1)};
+                    uint32_t const lb[4] = {cb & (kAlph - 1), (cb >> 8) & (kAlph - 1), (cb >> 16) & (kAlph - 1), (cb >> 24) & (kAlph - 1)};
+                    four_steps(la, lb, k0);
                     take_over(wa, wb);
                     chunk_stores(k0);
                     k0 += 4;
