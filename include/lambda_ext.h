@@ -473,6 +473,11 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
 int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t const * s_seq_len, uint64_t n_sseq);
 int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint64_t n_matches, lx_search_params const * params,
                            lx_iterate_result ** out);
+/* The library's own radix sort (least significant digit first, 8 bits per pass, only the digits set in key_bits; stable) for n (key, value)
+ * word pairs in device memory: key[0] / value[0] hold the input, key[1] / value[1] are scratch of the same size; *sorted_in says which of
+ * the two holds the sorted words afterwards.  Synchronises `stream`.  n < 2^32.  (The stand-alone front end sorts its word table with it;
+ * the Level-2 driver sorts matches and survivors with the same kernels.) */
+int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64_t n, uint64_t key_bits, void * stream, int * sorted_in);
 /* Ahead of a handle's first lx_iterate_matches_dev (or large lx_iterate_matches) call: allocates -- and, on the host side, touches -- the
  * buffers a call on up to n_matches matches needs when they become up to n_windows windows and n_hsps result records with n_columns
  * alignment columns in all (0: results without columns, LX_ITERATE_NO_OPS).  Call it after lx_set_queries (the lanes are sized for the

@@ -19,7 +19,6 @@
 //     the list carries no meaning.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdlib>
@@ -610,7 +609,7 @@ inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> 
     uint64_t total = 0;
     for (uint64_t l : len)
         total += l;
-    if (total == 0 || total >= 0x7fffffffull || off.size() >= 0xffffffffull) // (the sort takes an int count)
+    if (total == 0 || total >= 0xffffffffull || off.size() >= 0xffffffffull) // (lx_sort_words_dev ranks with 32 bits)
         return false;
     for (uint64_t l : len)
         if (l >= 0xffffffffull)
@@ -664,10 +663,18 @@ inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> 
     int bits = 1;
     while (bits < 64 && (ix.power(keyLen) - 1) >> bits)
         ++bits;
-    size_t tempBytes = 0;
-    LXS_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, k0, k1, v0, v1, (int)total, 0, bits));
-    void * temp = take(tempBytes);
-    LXS_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, k0, k1, v0, v1, (int)total, 0, bits));
+    {
+        // the library's own radix sort (lx_level2.hip through include/lambda_ext.h); whichever buffer ends up sorted becomes k1 / v1
+        uint64_t * kk[2] = {k0, k1}, * vv[2] = {v0, v1};
+        int        where = 0;
+        if (lx_sort_words_dev(device, kk, vv, total, bits >= 64 ? ~0ull : ((1ull << bits) - 1), nullptr, &where) != LX_OK)
+            throw std::runtime_error("lx_sort_words_dev failed on the word table");
+        if (where == 0)
+        {
+            std::swap(k0, k1);
+            std::swap(v0, v1);
+        }
+    }
     ReducedIndex::Entry * dEntries = static_cast<ReducedIndex::Entry *>(take(total * sizeof(ReducedIndex::Entry)));
     hipLaunchKernelGGL(table_entries_kernel, dim3(blocks), dim3(256), 0, 0, k1, v1, total, dEntries);
     LXS_HIP(hipGetLastError());

@@ -928,6 +928,29 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
     return LX_OK;
 }
 
+// The Level-2 radix sort (lx_level2.hip: l2_launch_sort) for a caller's own (key, value) words in device memory -- what the front end's
+// word table is sorted with (host/lx_seeding_gpu.hpp), instead of a library primitive.
+int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64_t n, uint64_t key_bits, void * stream, int * sorted_in)
+{
+    if (!key || !value || !sorted_in || (n && (!key[0] || !key[1] || !value[0] || !value[1])) || n >= 0xffffffffull)
+        return LX_EINVAL;
+    *sorted_in = 0;
+    if (n < 2)
+        return LX_OK;
+    if (hipSetDevice(device) != hipSuccess)
+        return LX_EHIP;
+    uint32_t * hist = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&hist), (lx::l2_sort_tiles(n) + 2) * 256 * sizeof(uint32_t)) != hipSuccess)
+        return LX_ENOMEM;
+    uint64_t * k = key[0], * kt = key[1], * v = value[0], * vt = value[1];
+    hipError_t e = lx::l2_launch_sort(&k, &kt, &v, &vt, n, key_bits, 0, hist, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // (the digit counts are this call's)
+    (void)hipFree(hist);
+    *sorted_in = k == key[0] ? 0 : 1;
+    return e == hipSuccess ? LX_OK : LX_EHIP;
+}
+
 // _widenAndPreprocessMatches (src/search_algo.hpp:1136-1175) alone, on a device match list over the resident sets
 int lx_widen_and_preprocess_dev(lx_handle * h, void const * d_matches, uint64_t n_matches, int32_t bisulfite, lx_match * out, uint64_t * out_n)
 {
