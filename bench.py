@@ -238,10 +238,48 @@ def pmc_traffic(kernel_name: str, command_has: str | None = None):
             c = d.get("counters_per_launch_mean") or d.get("counters_per_step_mean") or {}
             if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return ((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0,
-                        f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {name}"
+                        f"{f.name}: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch of {name}; {profile_sources_note(doc)}"
                         + (f"; skipped {'; '.join(skipped)}" if skipped else ""))
     return None, (f"no committed PMC profile holds FETCH_SIZE and WRITE_SIZE of {want}"
                   + (f"; skipped {'; '.join(skipped)}" if skipped else ""))
+
+
+def git_blob(path) -> str:
+    """the git blob id of a file's content (`git hash-object`)"""
+    import hashlib
+
+    data = Path(path).read_bytes()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def stale_profile_sources(doc) -> dict:
+    """{source: (blob id at profile time, blob id now)} for the kernel sources a PMC profile was made from that read differently today;
+    None when the profile does not say what it was made from (rounds 1-4)."""
+    srcs = doc.get("kernel_sources")
+    if not isinstance(srcs, dict):
+        return None
+    out = {}
+    for rel, then in srcs.items():
+        try:
+            now = git_blob(ROOT / rel)
+        except OSError:
+            now = "missing"
+        if now != then:
+            out[rel] = (then, now)
+    return out
+
+
+def profile_sources_note(doc) -> str:
+    stale = stale_profile_sources(doc)
+    if stale is None:
+        return "the profile does not record the kernel sources it was made from (made before round 5)"
+    srcs = doc["kernel_sources"]
+    txt = "kernel sources at profile time " + ", ".join(f"{Path(k).name} {v[:10]}" for k, v in sorted(srcs.items()))
+    if stale:
+        txt += " -- STALE: " + ", ".join(f"{Path(k).name} is {now[:10]} now" for k, (_, now) in sorted(stale.items())) + " (re-run tools/profile_round.sh)"
+    else:
+        txt += " (= the tree's)"
+    return txt
 
 
 def issue_ceiling():

@@ -124,3 +124,34 @@ def test_pmc_traffic_matches_the_full_instantiation_and_reports_what_it_skipped(
     t, note = bench.pmc_traffic("score_pair_kernel<8, 19, true>")
     assert t is not None and "r10_broken_pmc.json" in note and "r03_bench_pmc.json" in note
     assert bench.kernel_instantiation("lx::select_scan_kernel(lx::SelectParams, unsigned long)") == "select_scan_kernel"
+
+
+def test_newest_pmc_profiles_were_made_from_the_kernels_in_the_tree():
+    """bench.py reads `roofline.traffic` from the committed PMC passes, so a kernel that changed after its newest
+    profile would leave a stale ratio in a driver-stamped line.  Every profile of the newest round that records its kernel sources
+    (tools/collect_profiles.py, from round 5 on) must have been made from the sources in the tree: re-run tools/profile_round.sh +
+    tools/collect_profiles.py after touching lx_score_f16.hip / lx_sweep_mq.hip / lx_ckpt.hip."""
+    profs = sorted((ROOT / "profiles").glob("*_pmc.json"), reverse=True)
+    recorded = []
+    for f in profs:
+        try:
+            doc = json.loads(f.read_text())
+        except Exception:
+            continue
+        if isinstance(doc, dict) and isinstance(doc.get("kernel_sources"), dict):
+            recorded.append((f, doc))
+    if not recorded:
+        pytest.skip("no committed PMC profile records its kernel sources yet")
+    newest_round = recorded[0][0].name.split("_")[0]
+    for f, doc in recorded:
+        if f.name.split("_")[0] != newest_round:
+            continue
+        stale = bench.stale_profile_sources(doc)
+        assert not stale, f"{f.name} was profiled on other kernel sources than the tree's: {stale}"
+        assert "STALE" not in bench.profile_sources_note(doc)
+    # ... and the note names a change
+    doc = json.loads(recorded[0][0].read_text())
+    k = next(iter(doc["kernel_sources"]))
+    doc["kernel_sources"][k] = "0" * 40
+    assert "STALE" in bench.profile_sources_note(doc) and k in bench.stale_profile_sources(doc)
+

@@ -16,6 +16,44 @@ from pathlib import Path
 src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parent.parent / "profiles"
 out.mkdir(exist_ok=True)
+ROOT = out.parent
+
+
+def git_blob(path: Path) -> str:
+    """the git blob id of a file's content (what `git hash-object` prints)"""
+    import hashlib
+
+    data = path.read_bytes()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+# the sources of the kernels the PMC figures belong to, as they stood when the passes ran: bench.py names them beside the traffic it
+# reads from these files and tests/test_bench_cli.py fails when a kernel changed after its newest profile (VERDICT r4 item 6)
+KERNEL_SOURCES = {f"lambda_amd/csrc/{n}": git_blob(ROOT / "lambda_amd" / "csrc" / n)
+                  for n in ("lx_score_f16.hip", "lx_sweep_mq.hip", "lx_ckpt.hip", "lx_dp_common.h", "lx_device.h")}
+
+
+def condense(names, steps):
+    kern = {}
+    for name in names:
+        f = src / name / "pmc_counter_collection.csv"
+        if not f.exists():
+            continue
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        meta, launches = {}, collections.defaultdict(set)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"]
+            if "lx::" not in k:
+                continue
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            launches[k].add(r["Dispatch_Id"])
+            meta[k] = {x: r[x] for x in ("Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+        for k, v in acc.items():
+            d = kern.setdefault(k, {"dispatch": meta[k], "counters_per_step_mean": {}, "counters_per_launch_mean": {}})
+            for c, x in v.items():
+                d["counters_per_step_mean"][c] = x / steps
+                d["counters_per_launch_mean"][c] = x / len(launches[k])
+    return kern
 
 rows = list(csv.reader(open(src / "stats" / "bench_kernel_stats.csv")))
 with open(out / f"{tag}_bench_kernel_stats.csv", "w", newline="") as f:
@@ -125,7 +163,7 @@ if kern:
                    "(separate passes: SQ_* instruction counts, SQ_* wave-cycle breakdown, FETCH_SIZE, WRITE_SIZE)",
         "note": "the ragged list of bench.py (50 000 queries of 50-400 aa, 596 k windows, 44.3 G real / 57.8 G executed cells per call): per-STEP means "
                 "are per lx_extend_batch_list call (two sweep launches: pool, stream).  FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled before use.",
-        "kernels": kern}, open(out / f"{tag}_ragged_pmc.json", "w"), indent=1)
+        "kernel_sources": KERNEL_SOURCES, "kernels": kern}, open(out / f"{tag}_ragged_pmc.json", "w"), indent=1)
 rs = src / "stats_iterate" / "iterate_kernel_stats.csv"
 if rs.exists():
     rows = list(csv.reader(open(rs)))
@@ -142,3 +180,15 @@ for log in ("cli_nucl.log", "cli_nucl_host_list.log"):
         lines += [l.rstrip() for l in open(src / log) if l.startswith(("lambda3 ", "output sha256", "rc ")) or "lx_iterate_matches_dev:" in l or "iterateMatchesFullSimd (" in l]
 if lines:
     (out / f"{tag}_cli_end_to_end.txt").write_text("\n".join(lines) + "\n")
+
+# round 5: FETCH_SIZE / WRITE_SIZE of the solo sweep (sweep_mq_kernel<19,false,false>) on the Level-2 driver's list and on the configs[2]-sized
+# ragged list, so that those bench lines carry `traffic` too
+for passes, cmd, dst in ((("pmc_iterate_sq", "pmc_iterate_sq_wait", "pmc_iterate_fetch", "pmc_iterate_write"), "--iterate", "iterate_pmc"),
+                         (("pmc_ragged_nucl_fetch", "pmc_ragged_nucl_write"), "--ragged --entry list --config 2", "ragged_nucl_pmc")):
+    k = condense(passes, steps_profiled)
+    if k:
+        json.dump({"command": f"rocprofv3 --pmc <counters> --output-format csv -- python bench.py {cmd} --steps 2 --warmup 1 --no-cpu-baseline (separate passes)",
+                   "note": "per-STEP means are per call of the entry point (all launches of the kernel in it), per-LAUNCH means per kernel launch.  "
+                           "FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled before use.",
+                   "kernel_sources": KERNEL_SOURCES, "kernels": k}, open(out / f"{tag}_{dst}.json", "w"), indent=1)
+

@@ -38,4 +38,17 @@ for p in "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CY
   (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_ragged_$n -o pmc -- python $R/bench.py --ragged --entry list --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_ragged_$n.log 2>&1
 done
 (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_iterate -o iterate -- python $R/bench.py --iterate --steps 3 --warmup 2) > $R/$D/stats_iterate.log 2>&1
+# round 5: the Level-2 driver's first call of a fresh handle; PMC passes of the solo sweep (the lines that had no `traffic` in round 4)
+cd $R
+(timeout 900 python bench.py --iterate --cold --steps 5 --warmup 1 --no-cpu-baseline) > $D/bench_iterate_cold.log 2>&1
+(LX_HOST_TIMING=1 timeout 600 python tools/dev/cold_iterate.py 1000000 reserve) > $D/cold_iterate.log 2>&1
+cd /tmp
+for p in "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "sq_wait:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  n=${p%%:*}; c=${p#*:}
+  (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_iterate_$n -o pmc -- python $R/bench.py --iterate --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_iterate_$n.log 2>&1
+done
+for p in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  n=${p%%:*}; c=${p#*:}
+  (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_ragged_nucl_$n -o pmc -- python $R/bench.py --ragged --entry list --config 2 --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_ragged_nucl_$n.log 2>&1
+done
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -60
