@@ -79,11 +79,14 @@ def build_product(force: bool = False, verbose: bool = False) -> Path:
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", f"-I{ROOT / 'include'}", f"-I{CSRC}",
               "-Wall", "-Wno-unused-function", *os.environ.get("LX_EXTRA_DEFINES", "").split()]
     procs = []
+    variant = bool(os.environ.get("LX_EXTRA_DEFINES", "").split())
     for s in srcs:
-        o = s.with_suffix(".o")
+        # (a kernel variant -- LX_EXTRA_DEFINES -- gets objects of its own, always recompiled: an object made with other defines is
+        # newer than its source and would otherwise end up in the next default build)
+        o = s.with_suffix(".var.o" if variant else ".o")
         objs.append(o)
         is_api = s.name == "lx_api.cpp"  # carries the build id: recompiled whenever anything changed
-        if not force and not is_api and _newer(o, [s] + [d for d in deps if d.suffix in (".h", ".hpp")]):
+        if not force and not variant and not is_api and _newer(o, [s] + [d for d in deps if d.suffix in (".h", ".hpp")]):
             continue
         cmd = [hipcc, *common, *([f'-DLX_BUILD_ID="{sid}"'] if is_api else []), "-c", str(s), "-o", str(o)]
         if verbose:

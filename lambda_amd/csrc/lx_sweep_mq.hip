@@ -90,8 +90,12 @@ struct MqGeo
 // WIDE: the slots hold int16 pairs (the int32 kernel's layout) instead of the compact codes: scores up to the 16-bit patterns'
 // range (29 695) at sweep speed -- long queries with strong hits, whose windows score beyond the codes' 2046 (a 600-residue
 // query against its homologue: ~3 000) and would otherwise be redone one by one by the int32 launch.
+#ifndef LX_MQ_WAVES
+#define LX_MQ_WAVES 2 // wavefronts per SIMD the register budget is set for (four byte profiles + staging = 20 KB of LDS admit two; 3 was
+                      // measured with ONE profile per wavefront, where the LDS admits it: DESIGN.md section 3.3)
+#endif
 template <int C, bool MULTI, bool WIDE = false>
-__global__ __launch_bounds__(64, 2) void sweep_mq_kernel(ScoreParams p)
+__global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p)
 {
     using Geo = MqGeo<C>;
     using L16 = Ckpt16Layout<8, C>;
