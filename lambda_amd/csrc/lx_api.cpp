@@ -57,6 +57,7 @@ lx::DevAids const & lx::dev_aids()
         a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
         a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);
         a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
+        a.l2_ranges         = (uint64_t)std::min<long long>(std::max(0ll, num("LX_L2_RANGES", 0)), 64);
         a.host_timing       = set("LX_HOST_TIMING");
         return a;
     }();
@@ -1218,7 +1219,7 @@ void lx_destroy(lx_handle * h)
                            &l2.d_pre, &l2.d_exp})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes})
+        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes, &l2.p_rows})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         if (l2.ev_win)

@@ -655,6 +655,7 @@ struct XbPrep // what the host keeps about a chunk until its results are back
     uint64_t              slots = 0, cap_sel = 0;
     bool                  wide = false;   // multi-query chunk: the sweep wrote int16-pair slots
     uint64_t              exec_cells = 0, max_s = 0, max_pan = 0; // (LX_HOST_TIMING: what the chunk's wavefronts execute)
+    uint64_t              range = 0;      // records chunk by chunk (ResidentInput::ChunkRecords): the range this chunk is
     std::vector<uint32_t> slot_src;       // original index of every slot (0xffffffff = padding)
 };
 
@@ -715,9 +716,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
-    bool       dev_list = false, want_codes = true; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
+    bool       dev_list = false, want_codes = true, by_range = false; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
     h->res_count         = 0;
     h->l2.surv_on_device = false;
+    h->l2.surv_by_range  = false;
     int rc = bind(h);
     if (rc)
         return rc;
@@ -1710,6 +1712,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                           static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
         LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // this chunk's error word
         LX_HIP(h, hipMemcpyAsync(d_cnt + 4, h->d_ws_top + 6, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // ... its windows beyond the compact codes
+        if (by_range && (rc2 = ri->chunk_records->enqueue(pr.range, ln.d_hsp.ptr, ln.d_src.ptr, d_cnt, pr.cap_sel)))
+            return rc2; // (the records kernels of the range, behind the chunk's own: lx_level2_host.cpp)
         LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
         LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
         LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
@@ -1827,6 +1831,28 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // joins the call's on the device -- a copy kernel in stream order, so that this lane's buffers are free for the chunk after
             // next --, only the run-length codes come down, into the call's code bytes.
             auto & l2 = h->l2;
+            if (by_range)
+            {
+                uint64_t const code_base = ops_total;
+                if (nrle && want_codes)
+                {
+                    if (!h->ext_bytes.grow(ops_total + nrle + 16))
+                        return fail(h, LX_ENOMEM, "out of host memory for %llu bytes of alignment codes", (unsigned long long)(ops_total + nrle));
+                    LX_HIP(h, hipMemcpyAsync(h->ext_bytes.data() + ops_total, ln.d_rle.ptr, nrle, hipMemcpyDeviceToHost, h->stream3));
+                    LX_HIP(h, hipStreamSynchronize(h->stream3));
+                }
+                ops_total += nrle;
+                l2.surv_total += count;
+                h->res_count = l2.surv_total;
+                auto const t1 = now();
+                t_wait += ms(t0, t1);
+                rc2 = ri->chunk_records->collect(pr.range, code_base, in_flight[L ^ 1]);
+                t_unpack += ms(t1, now());
+                if (hm.on)
+                    fprintf(stderr, "[lx host ms]     ... its counts came after %.2f ms of waiting, its %llu code bytes in %.2f more; rows and columns of range %llu in %.2f\n",
+                            ms(t0, t_ev), (unsigned long long)nrle, ms(t_ev, t1), (unsigned long long)pr.range, ms(t1, now()));
+                return rc2;
+            }
             if (l2.surv_total + count > l2.surv_cap)
                 return fail(h, LX_ESTATE, "the call's survivor list is longer than its capacity");
             LX_HIP(h, lx::rec_launch_append(static_cast<lx::Hsp const *>(ln.d_hsp.ptr), static_cast<uint32_t const *>(ln.d_src.ptr),
@@ -2131,7 +2157,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             // the Level-2 driver makes its records on the device (lx_records.hip): room for every chunk's survivor list, padding included
             auto &         l2  = h->l2;
-            uint64_t const cap = nwf * kWave + 4096;
+            // (fillers never survive, a chunk's list is padded by less than 16 entries: the list's windows + a margin per chunk -- not the
+            // plan's slots: the streamed part of a host plan is made later)
+            uint64_t const cap = n + n / 64 + 8192;
             if ((rc = ensure(h, l2.d_surv_hsp, cap * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, cap * sizeof(uint32_t))) ||
                 (rc = ensure(h, l2.d_surv_codes, cap * sizeof(uint64_t))))
                 return rc;
@@ -2140,6 +2168,27 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             l2.surv_on_device = true;
             dev_list          = true;
             want_codes        = ri->want_codes;
+            // records chunk by chunk where every range of the plan is a chunk the budgets admit (else: the call's list, one chain at the end)
+            if (ri->chunk_records && ri->chunk_records->n_ranges >= 1 && use_solo && preplanned)
+            {
+                auto const &   cr = *ri->chunk_records;
+                uint64_t const pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+                by_range          = cr.cut_wf[0] == 0 && cr.cut_wf[cr.n_ranges] == nwf;
+                for (uint64_t r = 0; r < cr.n_ranges && by_range; ++r)
+                {
+                    uint64_t const a = cr.cut_wf[r], b = cr.cut_wf[r + 1];
+                    uint64_t       pm = 1, sm = 1;
+                    for (uint64_t w = a; w < b; ++w)
+                    {
+                        pm = std::max<uint64_t>(pm, wf_pan[w]);
+                        sm = std::max<uint64_t>(sm, wf_maxs[w]);
+                    }
+                    uint64_t const steps = (sm + 8 - 1 + 15) & ~15ull;
+                    uint64_t const slot  = (pm + pc - 1) / pc * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
+                    by_range = a < b && b - a <= 4 * per_chunk && (b - a) * kWave * slot <= h->opt_trace_bytes && (b - a) * kWave * (pm * 8 + sm) <= (8ull << 30);
+                }
+                l2.surv_by_range = by_range;
+            }
         }
         bool     rows_cleared = false, stream_planned = use_solo; // (the solo plan is whole before the first chunk)
         uint64_t w0           = 0;
@@ -2185,7 +2234,15 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 return (pan + pc - 1) / pc * (maybe_wide ? lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8
                                                          : lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
             };
-            while (w1 < nwf && w1 - w0 < per_chunk)
+            uint64_t range_now = 0;
+            if (by_range)
+            {
+                auto const & cr = *ri->chunk_records;
+                while (cr.cut_wf[range_now + 1] <= w0)
+                    ++range_now;
+                w1 = cr.cut_wf[range_now + 1]; // (the budgets were checked range by range when the mode was chosen)
+            }
+            while (!by_range && w1 < nwf && w1 - w0 < per_chunk)
             {
                 if (!merge_pool && w0 < pool_end && w1 == pool_end)
                     break; // (A/B aid: the pool in chunks of its own, as before)
@@ -2204,6 +2261,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             int const L = c & 1;
             if (in_flight[L] && (rc = collect_mq(L)))
                 return rc;
+            prep[L].range = range_now;
             if ((rc = enqueue_mq(L, w0, w1)))
                 return rc;
             if (!rows_cleared && !as_list)
@@ -2232,6 +2290,10 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         {
             auto const r = redo.back();
             redo.pop_back();
+            if (by_range) // (the range the chunk is: its records are made again behind the second sweep, and wait where the later ranges' stand)
+                for (uint64_t k = 0; k < ri->chunk_records->n_ranges; ++k)
+                    if (ri->chunk_records->cut_wf[k] == r.first)
+                        prep[0].range = k;
             if ((rc = enqueue_mq(0, r.first, r.second)) || (rc = collect_mq(0)))
                 return rc;
             ++c;

@@ -217,10 +217,12 @@ struct lx_handle
         // codes begin), the key / scan / record buffers, the host-made tables of the e-value
         uint32_t              max_qlen = 0;
         DevBuf                d_qevidx, d_surv_hsp, d_surv_src, d_surv_codes, d_listat, d_rec, d_reccodes, d_reccnt, d_tilekeep, d_tileops, d_pre, d_exp;
-        Pinned                p_reccnt, p_reccodes;
+        Pinned                p_reccnt, p_reccodes, p_rows; // p_rows: a range's finished rows on their way into the result
         std::vector<uint64_t> rec_codes;              // where the records' run-length codes begin (host copy)
         uint64_t              surv_total = 0, surv_cap = 0;
         bool                  surv_on_device = false; // the last pipeline call kept its survivors on the device
+        bool                  surv_by_range  = false; // ... and handed them over range by range (ResidentInput::ChunkRecords)
+        std::vector<uint64_t> cut_wf;                 // the ranges' first wavefronts
         double                exp_lambda = 0;         // the scheme d_exp was made for
         uint32_t              exp_n      = 0;
     } l2;
@@ -401,6 +403,18 @@ struct ResidentInput
     // the survivors stay on the device (lx_handle::Level2::d_surv_*; taken where the plan above is served: surv_on_device says so),
     // the scores too (h->d_score_all); want_codes: their run-length codes come down into the handle's code bytes
     bool keep_on_device = false, want_codes = true;
+    // Records chunk by chunk (lx_level2_host.cpp): the plan's chunks are RANGES of the query-sorted window list (cut_wf: the wavefront
+    // each range begins with, n_ranges + 1 entries), so a chunk's survivors are a contiguous piece of the result -- `enqueue` queues
+    // the records kernels behind the chunk's own (its survivor list stands in the lane's buffers: no copy), `collect` is called when
+    // they are through, while the NEXT chunk computes: rows and columns of all but the last range come down beside the sweeps.
+    struct ChunkRecords
+    {
+        uint64_t const * cut_wf   = nullptr;
+        uint64_t         n_ranges = 0;
+        std::function<int(uint64_t range, void const * d_hsp, void const * d_src, void const * d_count, uint64_t cap)> enqueue;
+        std::function<int(uint64_t range, uint64_t code_base, bool gpu_busy)>                                         collect; // gpu_busy: another chunk computes meanwhile
+    };
+    ChunkRecords const * chunk_records = nullptr;
 };
 bool solo_plan_applies(lx_handle const * h, int slot);
 int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,

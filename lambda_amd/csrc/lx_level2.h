@@ -80,7 +80,7 @@ hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params 
 // cost at 19 / 13 / 11 columns and cells, then part 1's; cnt = {windows, first window of part 1} in device memory), and the plan
 hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream);
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
-                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream);
+                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base = 0);
 uint64_t   l2_sort_tiles(uint64_t n);
 uint64_t   l2_scan_tiles(uint64_t n);
 
@@ -115,8 +115,10 @@ struct RecParams
     // the survivors as the extension pipeline left them (all chunks of the call): alignment, window, where the codes begin
     Hsp const *      hsp;
     uint32_t const * src;
-    uint64_t const * codes_off;
+    uint64_t const * codes_off; // NULL: the alignment's own ops_shift (offsets inside ONE chunk's code bytes)
+    uint64_t const * count_ptr; // NULL, or where the number of filled entries stands (a chunk's list: the rest of n_entries is stale)
     uint64_t         n_entries;
+    uint32_t         src_base;  // list position of win[0]: `src` counts from the list's start, the windows below from the range's
     // the windows of this part of the list, their scores of pass 1 and the filter's cut-offs
     L2Window const * win;
     int32_t const *  score;
@@ -143,6 +145,7 @@ struct RecParams
 
 hipError_t rec_launch_append(Hsp const * hsp, uint32_t const * src, uint64_t const * count_ptr, uint64_t cap, uint64_t code_base, Hsp * out_hsp, uint32_t * out_src,
                              uint64_t * out_codes, hipStream_t stream);
+hipError_t rec_launch_add_ops_base(BlastMatchDev * rec, uint64_t n, uint64_t base, hipStream_t stream);
 hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t pair_bits, uint64_t s0_bits,
                       uint32_t * ghist, uint32_t * tile_keep, uint64_t * tile_ops, hipStream_t stream);
 

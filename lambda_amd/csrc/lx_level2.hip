@@ -580,8 +580,8 @@ __global__ __launch_bounds__(256) void l2_plan_keys_kernel(Extension const * ext
 
 // slot o of the plan = the o-th window in that order (the last wavefront repeats the last window as filler: bit 31); per
 // wavefront the columns per lane of its widest query and its longest window
-__global__ __launch_bounds__(256) void l2_plan_slots_kernel(Extension const * ext, uint64_t const * idx_sorted, uint64_t n, int C, int no_narrow, uint32_t * plan,
-                                                             uint32_t * wf_pan, uint32_t * wf_maxs)
+__global__ __launch_bounds__(256) void l2_plan_slots_kernel(Extension const * ext, uint64_t const * idx_sorted, uint64_t n, int C, int no_narrow, uint32_t index_base,
+                                                             uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs)
 {
     uint64_t const o    = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t const nwf  = (n + 15) / 16;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void l2_plan_slots_kernel(Extension const * ex
     }
     if (!in)
         return;
-    plan[o] = (uint32_t)i | (o < n ? 0u : 0x80000000u);
+    plan[o] = ((uint32_t)i + index_base) | (o < n ? 0u : 0x80000000u); // (index_base: `ext` is a range of a longer list)
     if ((o & 15) == 0)
     {
         wf_pan[o / 16]  = pan;
@@ -619,7 +619,7 @@ hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint
 
 // the plan of ext[0 .. n): key / idx are sort words (two buffers each, as l2_launch_sort takes them); plan: [ceil(n / 16) * 16]
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
-                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream)
+                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base)
 {
     if (n == 0)
         return hipSuccess;
@@ -628,7 +628,7 @@ hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narro
     if (e != hipSuccess)
         return e;
     uint64_t const slots = (n + 15) / 16 * 16;
-    hipLaunchKernelGGL(l2_plan_slots_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, ext, *idx, n, C, no_narrow, plan, wf_pan, wf_maxs);
+    hipLaunchKernelGGL(l2_plan_slots_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, ext, *idx, n, C, no_narrow, index_base, plan, wf_pan, wf_maxs);
     return hipGetLastError();
 }
 

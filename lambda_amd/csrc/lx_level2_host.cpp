@@ -19,7 +19,7 @@ using namespace lxi;
 namespace
 {
 
-int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
+int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes, unsigned flags = hipHostMallocDefault)
 {
     if (bytes <= b.cap)
         return LX_OK;
@@ -30,7 +30,7 @@ int ensure_pinned(lx_handle * h, lx_handle::Pinned & b, size_t bytes)
         b.cap = 0;
     }
     size_t const want = bytes + bytes / 4 + 4096;
-    LX_HIP(h, hipHostMalloc(&b.ptr, want, hipHostMallocDefault));
+    LX_HIP(h, hipHostMalloc(&b.ptr, want, flags));
     b.cap = want;
     return LX_OK;
 }
@@ -265,171 +265,258 @@ static_assert(sizeof(lx::BlastMatchDev) == sizeof(lx_blast_match) && offsetof(lx
               "the device writes lx_blast_match rows");
 
 // The tail of iterateMatchesFullSimd (src/search_algo.hpp:1287-1325) for a part of the window list whose survivors the extension
-// pipeline left on the device (lx_handle::Level2::d_surv_*): statistics, order, identity cut-off, records as kernels (lx_records.hip),
-// then ONE copy of finished lx_blast_match rows into the result and the alignment columns expanded from the run-length codes by the
-// host threads.  What host/lx_iterate_common.hpp's finishSurvivors does for lists in host memory, with the same results to the bit.
-static int level2_records_on_device(lx_handle * h, uint64_t part_lo, uint64_t n_win, lx_search_params const * params, lambda_amd::CutOffs & cutOffFor,
-                                    lx_iterate_result * res, HostMarks & hm)
+// pipeline left on the device: statistics, order, identity cut-off, records as kernels (lx_records.hip), then ONE copy of finished
+// lx_blast_match rows into the result and the alignment columns expanded from the run-length codes by the host threads.  What
+// host/lx_iterate_common.hpp's finishSurvivors does for lists in host memory, with the same results to the bit.
+// A part is served as ONE range behind its last chunk (the survivors of all chunks in lx_handle::Level2::d_surv_*), or -- where the
+// plan's chunks are ranges of the query-sorted list (ResidentInput::ChunkRecords) -- range by range: a range's kernels are queued
+// behind its chunk's own, its rows and columns come down while the next chunk computes.
+struct RecordsJob
 {
-    using namespace lambda_amd;
-    auto &            l2 = h->l2;
-    hipStream_t const st = h->stream;
-    int               rc;
-    uint64_t const    n_entries = l2.surv_total;
-    bool const        want_ops  = !(params->flags & LX_ITERATE_NO_OPS);
-    int const         qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
-    // ---- the host's share of the arithmetic, made once per call with the host's libm: per distinct e-value length the factor
+    struct Range
+    {
+        uint64_t lo = 0, hi = 0;   // windows of the part
+        uint64_t code_base = 0;    // where the chunk's codes begin in h->ext_bytes
+        bool     done = false;
+    };
+    lx_handle *              h;
+    lx_search_params const * params;
+    lx_iterate_result *      res;
+    HostMarks &              hm;
+    uint64_t                 part_lo, n_part;
+    std::vector<Range>       ranges;
+    uint64_t                 next_flush = 0;
+    lx::RecParams            base{};
+    uint64_t                 pair_bits = 0, s0_bits = 0;
+    bool                     want_ops  = true;
+
+    RecordsJob(lx_handle * h_, lx_search_params const * p_, lx_iterate_result * r_, HostMarks & hm_, uint64_t part_lo_, uint64_t n_part_)
+        : h(h_), params(p_), res(r_), hm(hm_), part_lo(part_lo_), n_part(n_part_)
+    {
+    }
+
+    // the host's share of the arithmetic, made once per call with the host's libm -- per distinct e-value length the factor
     // K * (ql - adj) * (dl - adj) of computeEValue (blast_stats.hpp), exp(-lambda s) for every score until it is zero, the bit-score
-    // test as an integer cut-off
-    std::vector<double> pre(std::max<size_t>(l2.evlens.size(), 1), 0.0);
-    for (size_t i = 0; i < l2.evlens.size(); ++i)
+    // test as an integer cut-off -- and the buffers (entries: upper bound of the survivor entries of any range; every range has its
+    // own rows in d_rec: at most as many as it has windows)
+    int prepare(lambda_amd::CutOffs & cutOffFor, std::vector<Range> rs, uint64_t max_entries)
     {
-        uint64_t const ql  = (uint64_t)l2.evlens[i] / (params->query_translated ? 3 : 1);
-        auto           it  = cutOffFor.evalue.cachedLengthAdjustments.find(ql);
-        uint64_t const adj = it != cutOffFor.evalue.cachedLengthAdjustments.end() ? it->second : lengthAdjustment(params->db_total_length, ql, params->karlin);
-        pre[i]             = params->karlin.K * (double)(ql - adj) * (double)(params->db_total_length - adj);
-    }
-    if (l2.exp_lambda != params->karlin.lambda || l2.exp_n == 0)
-    {
-        std::vector<double> tab;
-        for (uint32_t sc = 0; sc < (1u << 20); ++sc)
+        using namespace lambda_amd;
+        auto &            l2 = h->l2;
+        hipStream_t const st = h->stream;
+        int               rc;
+        ranges   = std::move(rs);
+        want_ops = !(params->flags & LX_ITERATE_NO_OPS);
+        int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
+        std::vector<double> pre(std::max<size_t>(l2.evlens.size(), 1), 0.0);
+        for (size_t i = 0; i < l2.evlens.size(); ++i)
         {
-            double const v = std::exp(-params->karlin.lambda * (double)sc);
-            tab.push_back(v);
-            if (v == 0.0)
-                break;
+            uint64_t const ql  = (uint64_t)l2.evlens[i] / (params->query_translated ? 3 : 1);
+            auto           it  = cutOffFor.evalue.cachedLengthAdjustments.find(ql);
+            uint64_t const adj = it != cutOffFor.evalue.cachedLengthAdjustments.end() ? it->second : lengthAdjustment(params->db_total_length, ql, params->karlin);
+            pre[i]             = params->karlin.K * (double)(ql - adj) * (double)(params->db_total_length - adj);
         }
-        if ((rc = upload(h, l2.d_exp, tab)))
-            return rc;
-        LX_HIP(h, hipStreamSynchronize(st)); // (`tab` is a local)
-        l2.exp_lambda = params->karlin.lambda;
-        l2.exp_n      = (uint32_t)tab.size();
-    }
-    int32_t bit_cut = INT32_MIN;
-    if (params->min_bitscore >= 0)
-    {
-        auto const fails = [&](int32_t sc) { return computeBitScore(sc, params->karlin) < params->min_bitscore; };
-        int64_t    lo = -(1ll << 30), hi = 1ll << 30; // fails(lo), !fails(hi)
-        if (!fails((int32_t)lo))
-            bit_cut = INT32_MIN;
-        else if (fails((int32_t)hi))
-            bit_cut = INT32_MAX;
-        else
+        if (l2.exp_lambda != params->karlin.lambda || l2.exp_n == 0)
         {
-            while (hi - lo > 1)
+            std::vector<double> tab;
+            for (uint32_t sc = 0; sc < (1u << 20); ++sc)
             {
-                int64_t const mid = lo + (hi - lo) / 2;
-                (fails((int32_t)mid) ? lo : hi) = mid;
+                double const v = std::exp(-params->karlin.lambda * (double)sc);
+                tab.push_back(v);
+                if (v == 0.0)
+                    break;
             }
-            bit_cut = (int32_t)hi;
+            if ((rc = upload(h, l2.d_exp, tab)))
+                return rc;
+            LX_HIP(h, hipStreamSynchronize(st)); // (`tab` is a local)
+            l2.exp_lambda = params->karlin.lambda;
+            l2.exp_n      = (uint32_t)tab.size();
         }
+        int32_t bit_cut = INT32_MIN;
+        if (params->min_bitscore >= 0)
+        {
+            auto const fails = [&](int32_t sc) { return computeBitScore(sc, params->karlin) < params->min_bitscore; };
+            int64_t    lo = -(1ll << 30), hi = 1ll << 30; // fails(lo), !fails(hi)
+            if (!fails((int32_t)lo))
+                bit_cut = INT32_MIN;
+            else if (fails((int32_t)hi))
+                bit_cut = INT32_MAX;
+            else
+            {
+                while (hi - lo > 1)
+                {
+                    int64_t const mid = lo + (hi - lo) / 2;
+                    (fails((int32_t)mid) ? lo : hi) = mid;
+                }
+                bit_cut = (int32_t)hi;
+            }
+        }
+        uint64_t max_win = 1;
+        for (Range const & r : ranges)
+            max_win = std::max(max_win, r.hi - r.lo);
+        uint64_t const tiles = (max_entries + 255) / 256, sort_n = std::max<uint64_t>(max_entries, 1), nr = ranges.size();
+        if ((rc = upload(h, l2.d_pre, pre)) || (rc = ensure(h, l2.d_listat, max_win * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_reccnt, nr * lx::kRecCounters * sizeof(uint64_t))) ||
+            (rc = ensure(h, l2.d_rec, (n_part + 16) * sizeof(lx_blast_match) + 16)) || (rc = ensure(h, l2.d_reccodes, 3 * (n_part + 16) * sizeof(uint64_t) + 16)) ||
+            (rc = ensure(h, l2.d_tilekeep, (tiles + 1) * sizeof(uint32_t))) || (rc = ensure(h, l2.d_tileops, (tiles + 1) * sizeof(uint64_t))) ||
+            (rc = ensure(h, l2.d_pair[0], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_pair[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], sort_n * 8 + 16)) ||
+            (rc = ensure(h, l2.d_s0[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_hist, (lx::l2_sort_tiles(sort_n) + 2) * 256 * sizeof(uint32_t))) ||
+            (rc = ensure_pinned(h, l2.p_reccnt, nr * lx::kRecCounters * sizeof(uint64_t))))
+        {
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+        LX_HIP(h, hipMemsetAsync(l2.d_reccnt.ptr, 0, nr * lx::kRecCounters * sizeof(uint64_t), st));
+        LX_HIP(h, hipStreamSynchronize(st)); // (`pre` is a local)
+        base.q_len      = static_cast<uint32_t const *>(l2.d_qlen.ptr);
+        base.q_evidx    = static_cast<uint32_t const *>(l2.d_qevidx.ptr);
+        base.q_frames   = (uint32_t)qFrames;
+        base.s_frames   = (uint32_t)sFrames;
+        base.n_qid_end  = (uint32_t)((l2.q_len.size() + (uint64_t)qFrames - 1) / (uint64_t)qFrames);
+        base.q_mode     = params->q_frame_mode;
+        base.s_mode     = params->s_frame_mode;
+        base.bit_cut    = bit_cut;
+        base.id_cutoff  = params->id_cutoff;
+        base.want_ops   = want_ops ? 1 : 0;
+        base.lambda     = params->karlin.lambda;
+        base.log_k      = std::log(params->karlin.K);
+        base.log_2      = std::log(2.0);
+        base.pre_by_len = static_cast<double const *>(l2.d_pre.ptr);
+        base.exp_tab    = static_cast<double const *>(l2.d_exp.ptr);
+        base.exp_n      = l2.exp_n;
+        base.ops_base   = 0; // (the rows carry offsets inside their range; flush() knows where the range's columns begin)
+        base.list_at    = static_cast<uint32_t *>(l2.d_listat.ptr);
+        // the digits the keys can have set: (true query id | padding's id, query slice length), (subject slice length, window | entry)
+        pair_bits = (bits_below((uint64_t)base.n_qid_end + 1) << 32) | bits_below((uint64_t)l2.max_qlen + 1);
+        s0_bits   = (bits_below(std::min<uint64_t>(l2.max_slen, 0xfffffffeull) + 1) << 32) | bits_below(std::max(max_win, max_entries) + 1);
+        return LX_OK;
     }
-    uint64_t const tiles = (n_entries + 255) / 256, sort_n = std::max<uint64_t>(n_entries, 1);
-    if ((rc = upload(h, l2.d_pre, pre)) || (rc = ensure(h, l2.d_listat, n_win * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_reccnt, lx::kRecCounters * sizeof(uint64_t))) ||
-        (rc = ensure(h, l2.d_rec, n_entries * sizeof(lx_blast_match) + 16)) || (rc = ensure(h, l2.d_reccodes, 3 * n_entries * sizeof(uint64_t) + 16)) ||
-        (rc = ensure(h, l2.d_tilekeep, (tiles + 1) * sizeof(uint32_t))) || (rc = ensure(h, l2.d_tileops, (tiles + 1) * sizeof(uint64_t))) ||
-        (rc = ensure(h, l2.d_pair[0], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_pair[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_s0[0], sort_n * 8 + 16)) ||
-        (rc = ensure(h, l2.d_s0[1], sort_n * 8 + 16)) || (rc = ensure(h, l2.d_hist, (lx::l2_sort_tiles(sort_n) + 2) * 256 * sizeof(uint32_t))) ||
-        (rc = ensure_pinned(h, l2.p_reccnt, lx::kRecCounters * sizeof(uint64_t))))
+
+    // the kernels of range r over a survivor list of up to `cap` entries (count_ptr: how many are filled, NULL = all; codes_off: where
+    // each entry's codes begin, NULL = the alignment's own offset inside its chunk), on the handle's stream; the counters follow
+    int enqueue(uint64_t r, void const * d_hsp, void const * d_src, void const * d_count, void const * d_codes_off, uint64_t cap)
     {
-        (void)hipStreamSynchronize(st);
+        auto &            l2 = h->l2;
+        hipStream_t const st = h->stream;
+        Range const &     rg = ranges[r];
+        lx::RecParams     p  = base;
+        p.hsp       = static_cast<lx::Hsp const *>(d_hsp);
+        p.src       = static_cast<uint32_t const *>(d_src);
+        p.codes_off = static_cast<uint64_t const *>(d_codes_off);
+        p.count_ptr = static_cast<uint64_t const *>(d_count);
+        p.n_entries = cap;
+        p.src_base  = (uint32_t)rg.lo;
+        p.win       = static_cast<lx::L2Window const *>(l2.d_win.ptr) + part_lo + rg.lo;
+        p.score     = static_cast<int32_t const *>(h->d_score_all.ptr) + rg.lo;
+        p.min_score = static_cast<int32_t const *>(h->d_min_all.ptr) + part_lo + rg.lo;
+        p.n_win     = rg.hi - rg.lo;
+        p.counters  = static_cast<uint64_t *>(l2.d_reccnt.ptr) + r * lx::kRecCounters;
+        p.rec       = static_cast<lx::BlastMatchDev *>(l2.d_rec.ptr) + rg.lo;
+        p.rec_codes = static_cast<uint64_t *>(l2.d_reccodes.ptr) + 3 * rg.lo;
+        LX_HIP(h, hipMemsetAsync(p.counters, 0, lx::kRecCounters * sizeof(uint64_t), st)); // (a range whose chunk runs again starts over)
+        LX_HIP(h, hipMemsetAsync(l2.d_listat.ptr, 0xff, p.n_win * sizeof(uint32_t), st));
+        uint64_t * pair = static_cast<uint64_t *>(l2.d_pair[0].ptr), * pair_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
+        uint64_t * s0 = static_cast<uint64_t *>(l2.d_s0[0].ptr), * s0_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
+        LX_HIP(h, lx::rec_launch(p, &pair, &pair_tmp, &s0, &s0_tmp, pair_bits, s0_bits, static_cast<uint32_t *>(l2.d_hist.ptr), static_cast<uint32_t *>(l2.d_tilekeep.ptr),
+                                 static_cast<uint64_t *>(l2.d_tileops.ptr), st));
+        LX_HIP(h, hipMemcpyAsync(static_cast<uint64_t *>(l2.p_reccnt.ptr) + r * lx::kRecCounters, p.counters, lx::kRecCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        return LX_OK;
+    }
+
+    // range r's kernels are through (the caller synchronised with them): every range up to the first unfinished one goes to the result
+    int collect(uint64_t r, uint64_t code_base, bool gpu_busy)
+    {
+        ranges[r].done      = true;
+        ranges[r].code_base = code_base;
+        int rc = LX_OK;
+        while (rc == LX_OK && next_flush < ranges.size() && ranges[next_flush].done)
+            rc = flush(next_flush++, gpu_busy);
         return rc;
     }
-    LX_HIP(h, hipMemsetAsync(l2.d_reccnt.ptr, 0, lx::kRecCounters * sizeof(uint64_t), st));
-    LX_HIP(h, hipMemsetAsync(l2.d_listat.ptr, 0xff, n_win * sizeof(uint32_t), st));
-    uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size();
-    lx::RecParams  p{};
-    p.hsp        = static_cast<lx::Hsp const *>(l2.d_surv_hsp.ptr);
-    p.src        = static_cast<uint32_t const *>(l2.d_surv_src.ptr);
-    p.codes_off  = static_cast<uint64_t const *>(l2.d_surv_codes.ptr);
-    p.n_entries  = n_entries;
-    p.win        = static_cast<lx::L2Window const *>(l2.d_win.ptr) + part_lo;
-    p.score      = static_cast<int32_t const *>(h->d_score_all.ptr);
-    p.min_score  = static_cast<int32_t const *>(h->d_min_all.ptr) + part_lo;
-    p.n_win      = n_win;
-    p.q_len      = static_cast<uint32_t const *>(l2.d_qlen.ptr);
-    p.q_evidx    = static_cast<uint32_t const *>(l2.d_qevidx.ptr);
-    p.q_frames   = (uint32_t)qFrames;
-    p.s_frames   = (uint32_t)sFrames;
-    p.n_qid_end  = (uint32_t)((l2.q_len.size() + (uint64_t)qFrames - 1) / (uint64_t)qFrames);
-    p.q_mode     = params->q_frame_mode;
-    p.s_mode     = params->s_frame_mode;
-    p.bit_cut    = bit_cut;
-    p.id_cutoff  = params->id_cutoff;
-    p.want_ops   = want_ops ? 1 : 0;
-    p.lambda     = params->karlin.lambda;
-    p.log_k      = std::log(params->karlin.K);
-    p.log_2      = std::log(2.0);
-    p.pre_by_len = static_cast<double const *>(l2.d_pre.ptr);
-    p.exp_tab    = static_cast<double const *>(l2.d_exp.ptr);
-    p.exp_n      = l2.exp_n;
-    p.ops_base   = ops0;
-    p.list_at    = static_cast<uint32_t *>(l2.d_listat.ptr);
-    p.counters   = static_cast<uint64_t *>(l2.d_reccnt.ptr);
-    p.rec        = static_cast<lx::BlastMatchDev *>(l2.d_rec.ptr);
-    p.rec_codes  = static_cast<uint64_t *>(l2.d_reccodes.ptr);
-    uint64_t * pair = static_cast<uint64_t *>(l2.d_pair[0].ptr), * pair_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
-    uint64_t * s0 = static_cast<uint64_t *>(l2.d_s0[0].ptr), * s0_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
-    // the digits the keys can have set: (true query id | padding's id, query slice length), (subject slice length, window | entry)
-    uint64_t const pair_bits = (bits_below((uint64_t)p.n_qid_end + 1) << 32) | bits_below((uint64_t)l2.max_qlen + 1);
-    uint64_t const s0_bits   = (bits_below(std::min<uint64_t>(l2.max_slen, 0xfffffffeull) + 1) << 32) | bits_below(std::max(n_win, n_entries) + 1);
-    LX_HIP(h, lx::rec_launch(p, &pair, &pair_tmp, &s0, &s0_tmp, pair_bits, s0_bits, static_cast<uint32_t *>(l2.d_hist.ptr), static_cast<uint32_t *>(l2.d_tilekeep.ptr),
-                             static_cast<uint64_t *>(l2.d_tileops.ptr), st));
-    LX_HIP(h, hipMemcpyAsync(l2.p_reccnt.ptr, l2.d_reccnt.ptr, lx::kRecCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    LX_HIP(h, hipStreamSynchronize(st)); // (also: `pre` is a local)
-    uint64_t const * const cnt = static_cast<uint64_t const *>(l2.p_reccnt.ptr);
-    if (cnt[lx::kRecErr] & 1)
-        return fail(h, LX_EOVERFLOW, "an extension of the list could not be traced");
-    if (cnt[lx::kRecErr] & 2)
-        return fail(h, LX_ESTATE, "a survivor names a window outside the list");
-    uint64_t const ns = cnt[lx::kRecSurvivors], nkeep = cnt[lx::kRecKept], nops = cnt[lx::kRecOps];
-    if (ns > n_entries || nkeep > ns)
-        return fail(h, LX_ESTATE, "the records kernels report %llu records of %llu survivors of %llu entries", (unsigned long long)nkeep, (unsigned long long)ns,
-                    (unsigned long long)n_entries);
-    res->stats.failed_bitscore += cnt[lx::kRecFailedBit];
-    res->stats.failed_evalue += cnt[lx::kRecFailedEv];
-    hm.mark("statistics+order+records (kernels)");
-    if (ns == 0)
-        return LX_OK;
-    res->stats.num_ext_ali += ns; // :1287
-    res->stats.failed_identity += ns - nkeep;
-    if (!res->matches.resize(rec0 + nkeep) || !res->ops.resize(ops0 + nops))
-        return fail(h, LX_ENOMEM, "out of host memory for the result records");
-    if (nkeep == 0)
-        return LX_OK;
-    // where the records' codes begin and their columns go (24 bytes per record) first: the host threads expand the columns from the
-    // run-length codes WHILE the rows themselves come down (1.8 ms of copy beside 2.0 ms of expansion on a million reads)
-    std::vector<uint64_t> & codes_at = l2.rec_codes;
-    std::thread            expander;
-    if (want_ops)
+
+    int flush(uint64_t r, bool gpu_busy)
     {
-        codes_at.resize(3 * nkeep);
-        LX_HIP(h, hipMemcpy(codes_at.data(), l2.d_reccodes.ptr, 3 * nkeep * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        uint8_t const * const codes = h->ext_bytes.data();
-        uint8_t * const       ops   = res->ops.data();
-        expander = std::thread(
-            [&codes_at, codes, ops, nkeep]()
-            {
-                parallelRanges(nkeep,
-                               [&](unsigned, uint64_t lo, uint64_t hi)
-                               {
-                                   for (uint64_t r = lo; r < hi; ++r)
+        using namespace lambda_amd;
+        auto &                 l2  = h->l2;
+        Range const &          rg  = ranges[r];
+        uint64_t const * const cnt = static_cast<uint64_t const *>(l2.p_reccnt.ptr) + r * lx::kRecCounters;
+        if (cnt[lx::kRecErr] & 1)
+            return fail(h, LX_EOVERFLOW, "an extension of the list could not be traced");
+        if (cnt[lx::kRecErr] & 2)
+            return fail(h, LX_ESTATE, "a survivor names a window outside its range of the list");
+        uint64_t const ns = cnt[lx::kRecSurvivors], nkeep = cnt[lx::kRecKept], nops = cnt[lx::kRecOps];
+        if (ns > rg.hi - rg.lo || nkeep > ns)
+            return fail(h, LX_ESTATE, "the records kernels report %llu records of %llu survivors of %llu windows", (unsigned long long)nkeep, (unsigned long long)ns,
+                        (unsigned long long)(rg.hi - rg.lo));
+        res->stats.failed_bitscore += cnt[lx::kRecFailedBit];
+        res->stats.failed_evalue += cnt[lx::kRecFailedEv];
+        if (ns == 0)
+            return LX_OK;
+        res->stats.num_ext_ali += ns; // :1287
+        res->stats.failed_identity += ns - nkeep;
+        uint64_t const rec0 = res->matches.size(), ops0 = res->ops.size();
+        if (!res->matches.resize(rec0 + nkeep) || !res->ops.resize(ops0 + nops))
+            return fail(h, LX_ENOMEM, "out of host memory for the result records");
+        if (nkeep == 0)
+            return LX_OK;
+        // On the copy stream, beside whatever the handle's stream computes (the next chunk's sweep): the rows' column offsets become
+        // the result's, then -- 24 bytes per record -- where the records' codes begin and their columns go: the host threads expand the
+        // columns from the run-length codes WHILE the rows themselves come down (1.8 ms of copy beside 2.0 ms of expansion on a million reads)
+        hipStream_t const      cs = h->stream3;
+        lx::BlastMatchDev *    d_rows = static_cast<lx::BlastMatchDev *>(l2.d_rec.ptr) + rg.lo;
+        std::vector<uint64_t> & codes_at = l2.rec_codes;
+        std::thread             expander;
+        if (want_ops)
+        {
+            if (ops0)
+                LX_HIP(h, lx::rec_launch_add_ops_base(d_rows, nkeep, ops0, cs));
+            codes_at.resize(3 * nkeep);
+            LX_HIP(h, hipMemcpyAsync(codes_at.data(), static_cast<uint64_t const *>(l2.d_reccodes.ptr) + 3 * rg.lo, 3 * nkeep * sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+            LX_HIP(h, hipStreamSynchronize(cs));
+            uint8_t const * const codes = h->ext_bytes.data() + rg.code_base;
+            uint8_t * const       ops   = res->ops.data() + ops0;
+            expander = std::thread(
+                [&codes_at, codes, ops, nkeep]()
+                {
+                    parallelRanges(nkeep,
+                                   [&](unsigned, uint64_t lo, uint64_t hi)
                                    {
-                                       if (r + 8 < hi)
-                                           __builtin_prefetch(codes + codes_at[3 * (r + 8)]);
-                                       (void)lx_expand_ops(codes + codes_at[3 * r], (int32_t)codes_at[3 * r + 2], ops + codes_at[3 * r + 1]);
-                                   }
-                               });
-            });
+                                       for (uint64_t k = lo; k < hi; ++k)
+                                       {
+                                           if (k + 8 < hi)
+                                               __builtin_prefetch(codes + codes_at[3 * (k + 8)]);
+                                           (void)lx_expand_ops(codes + codes_at[3 * k], (int32_t)codes_at[3 * k + 2], ops + codes_at[3 * k + 1]);
+                                       }
+                                   });
+                });
+        }
+        // The rows.  While another chunk computes: into pinned memory (a copy engine's transfer, at the link's rate whatever the handle's
+        // stream does -- a copy into the result's ordinary memory is staged by the runtime with the compute units the sweep is using:
+        // 4.1 instead of 1.1 ms for half a million rows) and from there into the result by the host threads (2.0 ms with the columns,
+        // hidden behind the chunk).  With the GPU idle -- the last range -- straight into the result (1.1 ms).
+        hipError_t e_rows = hipSuccess;
+        int        rc_pin = gpu_busy ? ensure_pinned(h, l2.p_rows, nkeep * sizeof(lx_blast_match) + 16, hipHostMallocNonCoherent) : LX_OK;
+        if (rc_pin == LX_OK)
+        {
+            e_rows = hipMemcpyAsync(gpu_busy ? l2.p_rows.ptr : static_cast<void *>(res->matches.data() + rec0), d_rows, nkeep * sizeof(lx_blast_match), hipMemcpyDeviceToHost, cs);
+            if (e_rows == hipSuccess)
+                e_rows = hipStreamSynchronize(cs);
+        }
+        if (expander.joinable())
+            expander.join();
+        if (rc_pin)
+            return rc_pin;
+        LX_HIP(h, e_rows);
+        if (gpu_busy)
+        {
+            uint8_t const * const from = static_cast<uint8_t const *>(l2.p_rows.ptr);
+            uint8_t * const       to   = reinterpret_cast<uint8_t *>(res->matches.data() + rec0);
+            uint64_t const        bytes = nkeep * sizeof(lx_blast_match);
+            // (pieces of 256 bytes: parallelRanges spreads lists of 32 768 items and more)
+            parallelRanges((bytes + 255) / 256, [&](unsigned, uint64_t lo, uint64_t hi) { std::memcpy(to + lo * 256, from + lo * 256, std::min(bytes, hi * 256) - lo * 256); });
+        }
+        return LX_OK;
     }
-    hipError_t const e_rows = hipMemcpy(res->matches.data() + rec0, l2.d_rec.ptr, nkeep * sizeof(lx_blast_match), hipMemcpyDeviceToHost);
-    hm.mark("rows");
-    if (expander.joinable())
-        expander.join();
-    hm.mark("columns (the rest)");
-    LX_HIP(h, e_rows);
-    return LX_OK;
-}
+};
 
 // The list work and the extension for matches that stand on the device as sort words already.  Appends to *res.
 static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_search_params const * params, lx_iterate_result * res, bool windows_to_host)
@@ -528,14 +615,56 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     cfg  = cand[k];
                 }
             }
-            uint64_t const nwf = (n + 15) / 16;
+            // Ranges of the query-sorted list, each planned by itself and served as one chunk of the pipeline: a range's records are made
+            // behind its chunk and come down while the next range computes (RecordsJob).  The cuts stand where the true query id changes
+            // (the result is ordered by it): the windows around n / R, 2 n / R, ... come down for that, 12 KB each.
+            std::vector<RecordsJob::Range> ranges;
+            {
+                uint64_t const forced = lx::dev_aids().l2_ranges;
+                uint64_t const R      = !records_on_device ? 1 : forced ? forced : n < 300000 ? 1 : std::min<uint64_t>(4, n / 1000000 + 2);
+                // (measured on 1.25 M windows, bench.py --iterate: 1 range 11.8, 2 ranges 10.8-11.4, 3 ranges 11.3-11.9, 4 ranges 11.9 ms: a
+                // range costs a sweep's tail, a backtrace's tail and the records kernels' thirty launches)
+                uint64_t       lo     = 0;
+                int const      qF     = std::max(1, params->qry_num_frames);
+                for (uint64_t k = 1; k < R; ++k)
+                {
+                    uint64_t const target = n * k / R, from = target > 256 ? target - 256 : 0, upto = std::min(n, target + 256);
+                    if (from <= lo || upto - from < 2)
+                        continue;
+                    lx::L2Window probe[512];
+                    LX_HIP(h, hipMemcpyAsync(probe, static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo + from, (upto - from) * sizeof(lx::L2Window), hipMemcpyDeviceToHost, st));
+                    LX_HIP(h, hipStreamSynchronize(st));
+                    uint64_t cut = 0;
+                    for (uint64_t w = std::max<uint64_t>(target, from + 1); w < upto && !cut; ++w)
+                        if (probe[w - from].q / (uint32_t)qF != probe[w - from - 1].q / (uint32_t)qF)
+                            cut = w;
+                    if (cut && cut > lo && cut < n)
+                    {
+                        ranges.push_back(RecordsJob::Range{lo, cut});
+                        lo = cut;
+                    }
+                }
+                ranges.push_back(RecordsJob::Range{lo, n});
+            }
+            uint64_t nwf = 0;
+            l2.cut_wf.assign(1, 0);
+            for (auto const & rg : ranges)
+            {
+                nwf += (rg.hi - rg.lo + 15) / 16;
+                l2.cut_wf.push_back(nwf);
+            }
             if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 16)))
                 return rc;
-            uint64_t * key = static_cast<uint64_t *>(l2.d_pair[0].ptr), * key_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
-            uint64_t * idx = static_cast<uint64_t *>(l2.d_s0[0].ptr), * idx_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
             uint32_t * const d_pan = static_cast<uint32_t *>(l2.d_wf.ptr), * const d_maxs = d_pan + nwf;
-            LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all), n, lx::trace_cfg_panel(cfg) / 8, lx::dev_aids().mq_no_narrow ? 1 : 0, &key,
-                                         &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr), static_cast<uint32_t *>(l2.d_plan.ptr), d_pan, d_maxs, st));
+            for (size_t r = 0; r < ranges.size(); ++r)
+            {
+                uint64_t * key = static_cast<uint64_t *>(l2.d_pair[0].ptr), * key_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
+                uint64_t * idx = static_cast<uint64_t *>(l2.d_s0[0].ptr), * idx_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
+                uint64_t const w0 = l2.cut_wf[r];
+                LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all) + ranges[r].lo, ranges[r].hi - ranges[r].lo, lx::trace_cfg_panel(cfg) / 8,
+                                             lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
+                                             static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo));
+            }
             l2.wf_pan.resize(nwf);
             l2.wf_maxs.resize(nwf);
             LX_HIP(h, hipMemcpyAsync(l2.wf_pan.data(), d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -551,9 +680,32 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             ri.cells   = cost[4 * pi + 3];
             ri.keep_on_device = records_on_device;
             ri.want_codes     = !(params->flags & LX_ITERATE_NO_OPS);
+            RecordsJob                  job(h, params, res, hm, pt.lo, n);
+            ResidentInput::ChunkRecords cr;
+            if (records_on_device)
+            {
+                uint64_t max_entries = 0;
+                for (size_t r = 0; r < ranges.size(); ++r)
+                    max_entries = std::max(max_entries, (l2.cut_wf[r + 1] - l2.cut_wf[r]) * 16 + 16);
+                if ((rc = job.prepare(cutOffFor, ranges, max_entries)))
+                    return rc;
+                cr.cut_wf   = l2.cut_wf.data();
+                cr.n_ranges = ranges.size();
+                cr.enqueue  = [&job](uint64_t r, void const * d_hsp, void const * d_src, void const * d_count, uint64_t cap) { return job.enqueue(r, d_hsp, d_src, d_count, nullptr, cap); };
+                cr.collect  = [&job](uint64_t r, uint64_t code_base, bool gpu_busy) { return job.collect(r, code_base, gpu_busy); };
+                ri.chunk_records = &cr;
+            }
             hm.mark("plan");
             if ((rc = extend_list_resident(h, pt.slot, ri, nullptr, n, nullptr, records_on_device ? nullptr : l2.score.data() + pt.lo, &list)))
                 return rc;
+            if (l2.surv_on_device && l2.surv_by_range)
+            {
+                if (job.next_flush != job.ranges.size())
+                    return fail(h, LX_ESTATE, "the pipeline finished with %llu of %llu ranges' records made", (unsigned long long)job.next_flush,
+                                (unsigned long long)job.ranges.size());
+                hm.mark("extension + records (range by range)");
+                continue;
+            }
         }
         else
         {
@@ -591,8 +743,16 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
         hm.mark("extension");
         if (l2.surv_on_device)
         {
-            if ((rc = level2_records_on_device(h, pt.lo, n, params, cutOffFor, res, hm)))
+            // the survivors of all chunks stand in l2.d_surv_*: one range, its kernels now
+            RecordsJob whole(h, params, res, hm, pt.lo, n);
+            if ((rc = whole.prepare(cutOffFor, {RecordsJob::Range{0, n}}, l2.surv_total)) ||
+                (rc = whole.enqueue(0, l2.d_surv_hsp.ptr, l2.d_surv_src.ptr, nullptr, l2.d_surv_codes.ptr, l2.surv_total)))
                 return rc;
+            LX_HIP(h, hipStreamSynchronize(st));
+            hm.mark("statistics+order+records (kernels)");
+            if ((rc = whole.collect(0, 0, false)))
+                return rc;
+            hm.mark("rows + columns");
             continue;
         }
         if (records_on_device) // (the pipeline served the list without the multi-query plan: its survivors and scores are on the host)
@@ -806,7 +966,7 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
 // What the first lx_iterate_matches_dev call of a handle would otherwise allocate inside the call: 21.9 ms against 11.9 ms for the
 // calls behind it on a million reads (tools/dev/cold_iterate.py) -- 8.5 instead of 2.1 ms for the copy of the rows into result memory
 // that was never touched, 3 ms of allocations in the pipeline -- and a search makes ONE such call per run.  The sizes below are the
-// formulas of the call's own ensure()s (level2_windows, level2_sorted_tail, level2_records_on_device, extend_pipeline's lanes); what
+// formulas of the call's own ensure()s (level2_windows, level2_sorted_tail, RecordsJob::prepare, extend_pipeline's lanes); what
 // falls short grows in the call as before.
 int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n_hsps, uint64_t n_columns)
 {
@@ -828,19 +988,19 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         (rc = ensure(h, h->d_ext_all, n_matches * sizeof(lx_extension) + 16)) || (rc = ensure(h, h->d_min_all, n_matches * sizeof(int32_t) + 16)) ||
         (rc = ensure_pinned(h, l2.p_cnt, 16 * sizeof(uint64_t))) || (rc = ensure(h, l2.d_cut, ((size_t)l2.max_evlen + 1) * sizeof(int32_t) + 16)))
         return rc;
-    uint64_t const nwf = (n_windows + 15) / 16, entries = nwf * 16 + 4096;
+    uint64_t const nwf = (n_windows + 15) / 16, entries = n_windows + n_windows / 64 + 8192;
     if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 16)))
         return rc;
     l2.wf_pan.reserve(nwf);
     l2.wf_maxs.reserve(nwf);
     hm.mark("list work");
-    // ---- the records (level2_records_on_device)
+    // ---- the records (RecordsJob)
     if ((rc = ensure(h, l2.d_surv_hsp, entries * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, entries * sizeof(uint32_t))) ||
         (rc = ensure(h, l2.d_surv_codes, entries * sizeof(uint64_t))) || (rc = ensure(h, l2.d_listat, n_windows * sizeof(uint32_t) + 16)) ||
         (rc = ensure(h, l2.d_reccnt, lx::kRecCounters * sizeof(uint64_t))) || (rc = ensure(h, l2.d_rec, entries * sizeof(lx_blast_match) + 16)) ||
         (rc = ensure(h, l2.d_reccodes, 3 * entries * sizeof(uint64_t) + 16)) || (rc = ensure(h, l2.d_tilekeep, ((entries + 255) / 256 + 1) * sizeof(uint32_t))) ||
-        (rc = ensure(h, l2.d_tileops, ((entries + 255) / 256 + 1) * sizeof(uint64_t))) || (rc = ensure_pinned(h, l2.p_reccnt, lx::kRecCounters * sizeof(uint64_t))) ||
-        (rc = ensure(h, l2.d_pre, std::max<size_t>(l2.evlens.size(), 1) * sizeof(double) + 16)) || (rc = ensure(h, l2.d_exp, (1u << 13) * sizeof(double))))
+        (rc = ensure(h, l2.d_tileops, ((entries + 255) / 256 + 1) * sizeof(uint64_t))) || (rc = ensure_pinned(h, l2.p_reccnt, 8 * lx::kRecCounters * sizeof(uint64_t))) ||
+        (rc = ensure_pinned(h, l2.p_rows, (n_hsps * 2 / 3) * sizeof(lx_blast_match) + 16, hipHostMallocNonCoherent)) || (rc = ensure(h, l2.d_pre, std::max<size_t>(l2.evlens.size(), 1) * sizeof(double) + 16)) || (rc = ensure(h, l2.d_exp, (1u << 13) * sizeof(double))))
         return rc;
     if (n_columns)
     {

@@ -74,11 +74,13 @@ __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64
     bool           valid = false;
     if (e < p.n_entries)
     {
-        uint32_t const w = p.src[e];
+        bool const     filled = !p.count_ptr || e < *p.count_ptr;
+        uint32_t const ws     = filled ? p.src[e] : 0xffffffffu;
+        uint32_t const w      = ws - p.src_base; // (position among THIS call's windows: a chunk's range of the list)
         uint64_t       kp = ((uint64_t)p.n_qid_end << 32), ks = e;
-        if (w != 0xffffffffu)
+        if (ws != 0xffffffffu)
         {
-            if (w >= p.n_win)
+            if (ws < p.src_base || w >= p.n_win)
                 atomicOr(reinterpret_cast<unsigned long long *>(p.counters + kRecErr), 2ull);
             else if (p.hsp[e].score < 0)
                 atomicOr(reinterpret_cast<unsigned long long *>(p.counters + kRecErr), 1ull); // an extension that could not be traced
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(kRecBlock) void rec_write_kernel(RecParams p, uint6
     bm.s_frame = (int16_t)frame_of(p.s_mode, W.s, true);
     p.rec[r] = bm;
     // (what the host threads need to expand the record's columns while the rows are still on their way: codes, columns, where to)
-    p.rec_codes[3 * r]     = p.codes_off[c.entry];
+    p.rec_codes[3 * r]     = p.codes_off ? p.codes_off[c.entry] : (uint64_t)(uint32_t)a.ops_shift;
     p.rec_codes[3 * r + 1] = bm.ops_off;
     p.rec_codes[3 * r + 2] = (uint64_t)bm.n_ops;
 }
@@ -316,7 +318,23 @@ __global__ __launch_bounds__(kRecBlock) void rec_append_kernel(Hsp const * hsp, 
         out_src[e] = 0xffffffffu; // (behind the chunk's count: nothing)
 }
 
+// a range's rows carry column offsets inside the range: `base` makes them the result's
+__global__ __launch_bounds__(kRecBlock) void rec_add_ops_base_kernel(BlastMatchDev * rec, uint64_t n, uint64_t base)
+{
+    uint64_t const r = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x;
+    if (r < n)
+        rec[r].ops_off += base;
+}
+
 } // namespace
+
+hipError_t rec_launch_add_ops_base(BlastMatchDev * rec, uint64_t n, uint64_t base, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(rec_add_ops_base_kernel, dim3((unsigned)((n + kRecBlock - 1) / kRecBlock)), dim3(kRecBlock), 0, stream, rec, n, base);
+    return hipGetLastError();
+}
 
 hipError_t rec_launch_append(Hsp const * hsp, uint32_t const * src, uint64_t const * count_ptr, uint64_t cap, uint64_t code_base, Hsp * out_hsp, uint32_t * out_src,
                              uint64_t * out_codes, hipStream_t stream)
