@@ -565,8 +565,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     };
     bool                 win_here = false;
     lx::L2Window const * win      = nullptr; // (l2.p_win, once queue_windows has made room)
-    if (!records_on_device)
-        l2.score.resize(nw);
+    l2.score.resize(nw); // (written only where the pipeline hands the survivors to the host: lists it serves without the multi-query plan)
     uint64_t const * const cost = static_cast<uint64_t const *>(l2.p_cnt.ptr) + 3; // [part][19, 13, 11 columns, cells]
     auto const window = [&](uint64_t i)
     {
@@ -696,7 +695,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 ri.chunk_records = &cr;
             }
             hm.mark("plan");
-            if ((rc = extend_list_resident(h, pt.slot, ri, nullptr, n, nullptr, records_on_device ? nullptr : l2.score.data() + pt.lo, &list)))
+            if ((rc = extend_list_resident(h, pt.slot, ri, nullptr, n, nullptr, l2.score.data() + pt.lo, &list)))
                 return rc;
             if (l2.surv_on_device && l2.surv_by_range)
             {
@@ -737,7 +736,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             }
             ri.keep_on_device = records_on_device;
             ri.want_codes     = !(params->flags & LX_ITERATE_NO_OPS);
-            if ((rc = extend_list_resident(h, pt.slot, ri, l2.ext.data() + pt.lo, n, l2.min.data() + pt.lo, records_on_device ? nullptr : l2.score.data() + pt.lo, &list)))
+            if ((rc = extend_list_resident(h, pt.slot, ri, l2.ext.data() + pt.lo, n, l2.min.data() + pt.lo, l2.score.data() + pt.lo, &list)))
                 return rc;
         }
         hm.mark("extension");
@@ -755,8 +754,8 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             hm.mark("rows + columns");
             continue;
         }
-        if (records_on_device) // (the pipeline served the list without the multi-query plan: its survivors and scores are on the host)
-            return fail(h, LX_ESTATE, "the extension pipeline did not keep the survivors on the device");
+        // (else the pipeline served the list without the multi-query plan -- a handful of windows, LX_OPT_MQ_SWEEP = 0 -- and its survivors
+        // and scores are on the host: the host threads finish them, as for LX_OPT_ITERATE_RECORDS = 1)
         if (!win_here)
         {
             if ((rc = queue_windows()))

@@ -469,3 +469,27 @@ def test_level2_at_the_size_it_is_benched_at(handle, oracle):
                (st.num_matches, st.num_mismatches, st.num_positives, st.num_gap_opens, st.num_gap_extensions), r
         wb, we = oracle.bitscore(hsp.score, oka), oracle.evalue(hsp.score, ql - adj, db_total - adj, oka)
         assert abs(g["bit_score"] - wb) <= 1e-6 * abs(wb) and abs(g["e_value"] - we) <= 1e-6 * abs(we), r  # the contract: 1e-6 relative
+
+
+def test_device_list_without_the_multi_query_plan_falls_back_to_the_host_threads(handle):
+    """LX_OPT_MQ_SWEEP = 0 (or a list the pipeline serves with the one-query-per-wavefront kernels): the survivors come down and the host
+    threads make the records -- the same bytes as with the sweep's plan and the records kernels."""
+    handle.set_scoring(SCHEMES["blosum62"], 0)
+    rng = np.random.default_rng(8)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 300, 40, 6)
+    ka = capi.karlin_params(62)
+    params = capi.SearchParams(1e-2, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    d_m = _to_device(m)
+    want, wops, wst = handle.iterate_matches_dev(d_m, len(m), params)
+    try:
+        handle.set_option(capi.LX_OPT_MQ_SWEEP, 0)
+        got, gops, gst = handle.iterate_matches_dev(d_m, len(m), params)
+        one, oops, _ = handle.iterate_matches_dev(_to_device(m[:1]), 1, params)
+    finally:
+        handle.set_option(capi.LX_OPT_MQ_SWEEP, 1)
+    assert len(want) > 100 and got.tobytes() == want.tobytes() and gops == wops
+    assert (gst.failed_evalue, gst.num_ext_ali) == (wst.failed_evalue, wst.num_ext_ali)
+    assert len(one) <= 1
