@@ -131,6 +131,9 @@ def test_newest_pmc_profiles_were_made_from_the_kernels_in_the_tree():
     profile would leave a stale ratio in a driver-stamped line.  Every profile of the newest round that records its kernel sources
     (tools/collect_profiles.py, from round 5 on) must have been made from the sources in the tree: re-run tools/profile_round.sh +
     tools/collect_profiles.py after touching lx_score_f16.hip / lx_sweep_mq.hip / lx_ckpt.hip."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
     profs = sorted((ROOT / "profiles").glob("*_pmc.json"), reverse=True)
     recorded = []
     for f in profs:
