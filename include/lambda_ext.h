@@ -108,8 +108,11 @@ char const * lx_last_error(lx_handle const * h); /* h may be NULL: error of the 
  *                          that share one query slice (a multiple of 8, or 4 for the multi-query sweep; 0 = no promise).  Lets a wavefront
  *                          build one LDS profile instead of one per extension.  2 = the multi-query sweep's free packing:
  *                          entries 2k and 2k + 1 share a query slice and every aligned block of 16 entries holds windows of
- *                          at most four query slices, in any split (what lx_extend_batch streams a ragged list into).  A
- *                          violated promise is detected on the device and reported as LX_ESTATE by lx_synchronize().
+ *                          at most four query slices, in any split (what lx_extend_batch streams a ragged list into).  1 = the
+ *                          sweep's SOLO packing: no promise at all, every window has its own byte profile, 16 windows per
+ *                          wavefront -- for the schemes whose profiles are small enough (nucleotide, bisulfite; what
+ *                          lx_extend_batch and the Level-2 driver plan read sets with).  A violated promise is detected on
+ *                          the device and reported as LX_ESTATE by lx_synchronize().
  *   LX_OPT_WORKSPACE_BYTES carry workspace for queries wider than one panel in the *_dev calls (default 64 MiB; with
  *                          LX_OPT_MAX_SLEN set it grows by itself to 8 bytes per subject row of the batch)
  *   (LX_OPT_BS_MATCH_RULE is the one option that is not a tuning knob: it selects which of the reference's two
@@ -449,6 +452,10 @@ typedef struct lx_iterate_result lx_iterate_result;
  * sequence coordinates, apply the identity cut-off.  q_seq_off/q_seq_len (s_*) give, per frame-expanded sequence
   * id, where that sequence lives in q_res (s_res).  q_orig_len[n_qid] is the untranslated query length used for
  * the e-value (bm.qLength, src/search_algo.hpp:1213).  `matches` is modified in place (like the reference's span). */
+/* Lists of 131 072 matches and more (at most 2^31 - 16) over resident subjects are handed to the Level-2 kernels (lx_iterate_matches_dev's
+ * path): same records and statistics; two differences a caller can see -- a seed on a diagonal beyond its subject's end is LX_EINVAL there
+ * (the host form widens it to an empty window), and after a bisulfite call `matches[0 .. windows)` holds the window list contiguously (even
+ * subject frames first), where the host form leaves its two halves where the sort put them. */
 int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
                        uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,
                        uint8_t const * s_res, uint64_t s_bytes, uint64_t const * s_seq_off, uint64_t const * s_seq_len,
@@ -494,6 +501,9 @@ lx_blast_match const * lx_iterate_result_matches(lx_iterate_result const * r);
 uint8_t const *        lx_iterate_result_ops(lx_iterate_result const * r);
 lx_iterate_stats       lx_iterate_result_stats(lx_iterate_result const * r);
 void                   lx_iterate_result_free(lx_iterate_result * r);
+/* A freed result's large arrays are kept for the next result (a block the allocator has just mapped costs a page fault per 4 KB when the
+ * threads write it): a handful of blocks, at most 1 GiB per process.  This call gives them back; returns the bytes released. */
+uint64_t               lx_trim_result_cache(void);
 
 
 /* ---- record post-processing and writers (row N2: _writeRecord + BLAST-tabular / SAM output) --------------- */

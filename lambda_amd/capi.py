@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_set_band_centres", "lx_set_band_centres_dev",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
-    "lx_iterate_matches", "lx_set_queries", "lx_set_subject_seqs", "lx_iterate_matches_dev", "lx_widen_and_preprocess_dev", "lx_reserve", "lx_sort_words_dev",
+    "lx_iterate_matches", "lx_set_queries", "lx_set_subject_seqs", "lx_iterate_matches_dev", "lx_widen_and_preprocess_dev", "lx_reserve", "lx_sort_words_dev", "lx_trim_result_cache",
     "lx_iterate_result_count", "lx_iterate_result_matches", "lx_iterate_result_ops", "lx_iterate_result_stats",
     "lx_iterate_result_free", "lx_karlin_params", "lx_length_adjustment", "lx_evalue", "lx_bitscore",
     "lx_widen_and_preprocess", "lx_postprocess_records", "lx_compute_lca", "lx_write_records", "lx_convert_ranks",
@@ -196,6 +196,8 @@ def load():
     lib.lx_set_queries.argtypes = [vp, vp, u64, vp, vp, u64, vp, i32]
     lib.lx_set_subject_seqs.argtypes = [vp, vp, vp, u64]
     lib.lx_iterate_matches_dev.argtypes = [vp, i32, vp, u64, C.POINTER(SearchParams), C.POINTER(vp)]
+    lib.lx_trim_result_cache.restype = u64
+    lib.lx_trim_result_cache.argtypes = []
     lib.lx_reserve.restype = i32
     lib.lx_reserve.argtypes = [vp, u64, u64, u64, u64]
     lib.lx_widen_and_preprocess_dev.argtypes = [vp, vp, u64, i32, vp, C.POINTER(u64)]

@@ -422,6 +422,12 @@ static int iterateMatchesFullSimd(lx_handle * h, int slot, uint8_t const * q_res
 
 extern "C" {
 
+// the blocks of result memory kept between calls (host/lx_iterate_common.hpp: BlockCache, up to 1 GiB per process) go back to the allocator
+uint64_t lx_trim_result_cache(void)
+{
+    return (uint64_t)lambda_amd::trim_block_cache();
+}
+
 // iterateMatches, src/search_algo.hpp:1364-1385
 int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_bytes, uint64_t const * q_seq_off,
                        uint64_t const * q_seq_len, uint64_t n_qseq, uint64_t const * q_orig_len,

@@ -81,8 +81,25 @@ struct BlockCache
 };
 inline BlockCache & block_cache()
 {
-    static BlockCache cache;
-    return cache;
+    // (never destroyed: a result freed from a static destructor or an atexit handler still finds it; lx_trim_result_cache() gives the
+    // blocks back before that)
+    static BlockCache * const cache = new BlockCache();
+    return *cache;
+}
+inline size_t trim_block_cache() // frees every kept block; returns the bytes released
+{
+    BlockCache &                cache = block_cache();
+    std::vector<BlockCache::Block> mine;
+    size_t                      bytes = 0;
+    {
+        std::lock_guard<std::mutex> lock(cache.mu);
+        mine.swap(cache.blocks);
+        bytes       = cache.total;
+        cache.total = 0;
+    }
+    for (BlockCache::Block const & b : mine)
+        std::free(b.p);
+    return bytes;
 }
 
 // A growing array of trivially copyable records that is never value-initialised: every byte of a result is written by the threads
@@ -128,7 +145,12 @@ struct RawVec
                 return false;
 #ifdef MADV_HUGEPAGE
             if (bytes >= (8u << 20)) // (a fresh block: 2 MiB pages where the system grants them -- 512 times fewer faults)
-                (void)madvise(reinterpret_cast<void *>((reinterpret_cast<uintptr_t>(np) + 4095) & ~(uintptr_t)4095), bytes & ~(size_t)4095, MADV_HUGEPAGE);
+            {
+                // whole pages INSIDE the block only: [align_up(np), align_down(np + bytes))
+                uintptr_t const a = (reinterpret_cast<uintptr_t>(np) + 4095) & ~(uintptr_t)4095, b = (reinterpret_cast<uintptr_t>(np) + bytes) & ~(uintptr_t)4095;
+                if (b > a)
+                    (void)madvise(reinterpret_cast<void *>(a), b - a, MADV_HUGEPAGE);
+            }
 #endif
             p   = static_cast<T *>(np);
             cap = want;

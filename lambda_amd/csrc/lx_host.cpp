@@ -1600,7 +1600,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // records on the device, kernels, scatter of the scores into caller order.  The plan's order is a permutation of the caller's
     // list (+ fillers): the host only touches 4 bytes per slot here (the 24-byte records and their cut-offs are gathered from the
     // device copy of the list at HBM speed, not by cache misses of a few host threads).
-    auto enqueue_mq = [&](int L, uint64_t w0, uint64_t w1) -> int
+    auto enqueue_mq = [&](int L, uint64_t w0, uint64_t w1, bool force_wide = false) -> int
     {
         auto const          t0 = now();
         lx_handle::XbLane & ln = h->xb[L];
@@ -1695,7 +1695,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // of the sweep's speed.  Where the last chunks had more than a few such windows (long queries with strong hits: a 600-residue
         // query against its homologue scores ~3 000) the sweep writes int16 pairs itself (lx_sweep_mq.hip: WIDE) -- twice the
         // checkpoint bytes, no second launch; it goes back to the codes when fewer than 1 % of a chunk's windows need more.
-        h->mq_wide_call = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03);
+        // (force_wide: a chunk that runs again because its overflow area filled up -- said by the caller, not inferred from the fraction
+        // the OTHER lane's collect may have overwritten meanwhile)
+        h->mq_wide_call = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (force_wide || (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03));
         pr.wide         = h->mq_wide_call;
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
@@ -2294,7 +2296,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 for (uint64_t k = 0; k < ri->chunk_records->n_ranges; ++k)
                     if (ri->chunk_records->cut_wf[k] == r.first)
                         prep[0].range = k;
-            if ((rc = enqueue_mq(0, r.first, r.second)) || (rc = collect_mq(0)))
+            if ((rc = enqueue_mq(0, r.first, r.second, true)) || (rc = collect_mq(0)))
                 return rc;
             ++c;
         }

@@ -831,7 +831,7 @@ int lxi::iterate_host_list_on_device(lx_handle * h, int slot, uint8_t const * q_
 {
     using namespace lambda_amd;
     // what this path serves: lists large enough to pay for the hand-over, the reference's full rectangle, resident subjects
-    if (n_matches < 4 * kParallelFrom || params->band > 0 || h->opt_band || s_res != nullptr || s_bytes != 0 || !h->db_bytes || n_qseq >= (1ull << 31) ||
+    if (n_matches < 4 * kParallelFrom || n_matches > 0x7ffffff0ull || params->band > 0 || h->opt_band || s_res != nullptr || s_bytes != 0 || !h->db_bytes || n_qseq >= (1ull << 31) ||
         n_sseq >= (1ull << 32) || lx::dev_aids().iterate_on_host)
         return kNotTaken;
     if (!params->bisulfite && (slot < 0 || slot > 1 || !h->have_sc[slot]))

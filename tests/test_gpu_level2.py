@@ -493,3 +493,31 @@ def test_device_list_without_the_multi_query_plan_falls_back_to_the_host_threads
     assert len(want) > 100 and got.tobytes() == want.tobytes() and gops == wops
     assert (gst.failed_evalue, gst.num_ext_ali) == (wst.failed_evalue, wst.num_ext_ali)
     assert len(one) <= 1
+
+
+def test_reserve_then_first_call_gives_the_same_records(lx_lib):
+    """lx_reserve changes WHEN the buffers of a handle's first Level-2 call are asked for, nothing else: a fresh handle with and without
+    it returns the same bytes; short hints, zero hints and hints before the sets are set are all fine; lx_trim_result_cache gives the kept
+    result blocks back."""
+    rng = np.random.default_rng(3)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, 4000, 60, 10, lq_range=(140, 160), alphabet=np.arange(4, dtype=np.uint8))
+    ka = capi.karlin_params(0, 2, -3, -5, -2)
+    params = capi.SearchParams(1e-2, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    d_m = _to_device(m)
+    results = []
+    for hints in (None, (len(m), len(m) // 2, len(m) // 4, len(m) * 40), (len(m), 16, 1, 0)):
+        with capi.Handle(0) as h:
+            h.set_scoring(SCHEMES["nucl"], 0)
+            if hints:
+                h.reserve(*hints)  # (before the sets: sizes what it can)
+            h.set_subjects(s)
+            h.set_subject_seqs(soff, slen)
+            h.set_queries(q, qoff, qlen, qlen, 1)
+            if hints:
+                h.reserve(*hints)
+            b, o, st = h.iterate_matches_dev(d_m, len(m), params)
+            results.append((b.tobytes(), o, st.num_ext_ali))
+            with pytest.raises(capi.LambdaExtError):
+                h.reserve(10, 20, 5, 0)  # more windows than matches
+    assert len(results[0][1]) > 500 and results[1] == results[0] and results[2] == results[0]
+    assert lx_lib.lx_trim_result_cache() >= 0 and lx_lib.lx_trim_result_cache() == 0
