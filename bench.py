@@ -210,7 +210,7 @@ def kernel_instantiation(name: str) -> str:
     return (base + (m.group(2) or "")).replace(" ", "")
 
 
-def pmc_traffic(kernel_name: str, command_has: str | None = None):
+def pmc_traffic(kernel_name: str, command_has: str | None = None, command_also: str | None = None, command_lacks: str | None = None):
     """HBM bytes per launch of ONE kernel instantiation (kernel_name in the library's or rocprofv3's spelling, compared by
     `kernel_instantiation`: full template argument list, not a substring) from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json, newest name first): (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950
@@ -232,6 +232,8 @@ def pmc_traffic(kernel_name: str, command_has: str | None = None):
         cmd = str(doc.get("command", ""))
         if (command_has is None and any(k in cmd for k in ("--ragged", "--host-path", "--iterate"))) or (command_has is not None and command_has not in cmd):
             continue  # the profile of another workload
+        if (command_also is not None and command_also not in cmd) or (command_lacks is not None and command_lacks in cmd):
+            continue  # ... of another list of the same entry point (--ragged --config 2 against the protein list)
         for name, d in kernels.items():
             if not isinstance(d, dict) or kernel_instantiation(name) != want:
                 continue
@@ -607,7 +609,9 @@ def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext, fl
     algo = float(ext["s_len"].sum()) + float(len(q) if len(qkeys) else 0) + len(ext) * ALGO_BYTES_PER_EXT_EXTRA
     flag = flag or ("--ragged" if args.ragged else "--host-path")
     # (the PMC passes profile the kernel instantiation the sweep ran as; its name in the library's spelling ends at the first blank)
-    traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag)
+    other_config = getattr(args, "config", 1) not in (None, 1) and flag in ("--ragged", "--host-path")
+    traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag, command_also=f"--config {args.config}" if other_config else None,
+                                command_lacks=None if other_config or flag == "--iterate" else "--config")
     ceil = issue_ceiling() if packed else None
     return {
         **({"issue_ceiling_frac": ceil["issue_ceiling_frac"]} if ceil else {}),
