@@ -791,27 +791,30 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
             step(pa1, pb1, k0 + 3, 3);
         };
         int      k0 = 0;
-        uint32_t na[4], nb[4];
+        // (what the chunk loop carries of the subject is two raw dwords, in the checked path as in the steady one: the letters of the four
+        // rows are cut out where the chunk starts -- eight expanded letters carried across the iteration were eight more registers in a
+        // kernel that stands at 256, and their spills were reloaded behind the chunk's stores: a wait for the stores again)
+        uint32_t curA, curB;
         {
-            uint32_t rA, rB;
-            fetch_checked_raw(0, rA, rB);
+            fetch_checked_raw(0, curA, curB);
             carry_fetch(0, Z, ninA, ninE);
-            take_over(rA, rB);
-            expand_checked(0, rA, rB, na, nb);
+            take_over(curA, curB);
         }
         while (k0 < steps)
         {
             bool const cur_steady = (k0 >= steady_lo) && (k0 < steady_hi);
             if (!cur_steady)
             {
-                uint32_t ca[4] = {na[0], na[1], na[2], na[3]}, cb[4] = {nb[0], nb[1], nb[2], nb[3]};
+                uint32_t ca[4], cb[4];
+                expand_checked(k0, curA, curB, ca, cb);
                 mask_checked(k0, ca, cb);
                 uint32_t rA, rB;
                 fetch_checked_raw(k0 + 4, rA, rB);
                 carry_fetch(k0 + 4, Z + qsplat(-4 * ge), ninA, ninE); // (Z is the chunk's first step's here)
                 four_steps(ca, cb, k0);
                 take_over(rA, rB);
-                expand_checked(k0 + 4, rA, rB, na, nb);
+                curA = rA;
+                curB = rB;
                 chunk_stores(k0);
                 k0 += 4;
             }
@@ -835,9 +838,8 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
                     chunk_stores(k0);
                     k0 += 4;
                 }
-                uint32_t rA, rB;
-                fetch_checked_raw(k0, rA, rB);
-                expand_checked(k0, rA, rB, na, nb);
+                fetch_checked_raw(k0, curA, curB);
+                asm volatile("" : "+v"(curA), "+v"(curB)::"memory"); // (as above: once per transition, not a pending load at the loop's top)
             }
         }
         if (!WIDE && (steps & 4))
