@@ -50,6 +50,7 @@ lx::DevAids const & lx::dev_aids()
         a.mq_no_solo        = set("LX_MQ_NO_SOLO");
         a.mq_no_wide        = set("LX_MQ_NO_WIDE");
         a.mq_no_merge       = set("LX_MQ_NO_MERGE");
+        a.mq_no_wfslots     = set("LX_MQ_NO_WFSLOTS");
         a.iterate_on_host   = set("LX_ITERATE_ON_HOST");
         a.mq_merge_below    = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
@@ -744,7 +745,9 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         return rc;
     hipStream_t stream = stream_ ? static_cast<hipStream_t>(stream_) : h->stream;
 
-    if (phases & 1)
+    lx_handle::MqTab const tab = h->mq_tab; // (slots by wavefront: lx_extend_batch's multi-query chunks)
+    bool       tab_on = tab.dev != nullptr;
+    if ((phases & 1) && !(tab_on && tab.part == 2))
     {
         if (!h->keep_phase_events) // (lx_extend_batch's pipeline collects the events of all its chunks)
         {
@@ -810,7 +813,26 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         }
         so.n = n;
     }
-    if (!split_on)
+    if (tab_on)
+    {
+        // the chunk's maxima decide the kernel (family, geometry, multi-panel or not) and the layout of the overflow slots; the slots
+        // themselves are the table's
+        so.n = 1;
+        plan = plan_step(facts, so);
+        so.n = n;
+        if (plan.family != kMqSweep)
+        {
+            // (a chunk the sweep does not take -- a window beyond the 65 535 rows its slots address: the per-survivor paths, as without a table)
+            if (tab.part != 0)
+                return fail(h, LX_ESTATE, "a chunk swept in two calls must be the multi-query sweep's");
+            tab_on = false;
+            plan   = plan_step(facts, so);
+        }
+        else
+            plan.ovf_cap = (plan.may_decline && plan.stride32 != 0) ? tab.ovf_cap : 0;
+        split_on = false;
+    }
+    else if (!split_on)
         plan = plan_step(facts, so);
     bool const     shared = plan.shared;
     bool const     sweep = plan.sweep, mq = plan.family == kMqSweep, wide_compact = plan.family == kI16CompactWide;
@@ -824,17 +846,25 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     bool const     wave_slots = half_sweep && !mq && !wide_compact; // (= launch_score_pair: always one panel)
     uint64_t const wave_w     = 128 / (uint64_t)lx::trace_cfg_group(sweep_cfg); // windows of a packed-half wavefront
     // the batch's slots (+ the spare slot of the compact layouts; whole wavefronts of slots when they are interleaved)
-    uint64_t const batch_dw = split_on     ? split.n1 * stride1 + (n - split.n1 + 1) * stride2
+    // (slots by wavefront: [the wavefronts before slot n0][overflow slots][the wavefronts from n0 on])
+    uint64_t const tab_ovf_dw = tab_on ? ovf_cap * sweep_stride32 : 0;
+    uint64_t const batch_dw = tab_on       ? tab.dw0
+                              : split_on   ? split.n1 * stride1 + (n - split.n1 + 1) * stride2
                               : wave_slots ? (n + wave_w - 1) / wave_w * wave_w * sweep_stride
                               : half_sweep ? (n + 1) * sweep_stride
                                            : n * sweep_stride;
     if (sweep && (phases & 1))
     {
-        if ((rc = ensure(h, h->d_trace, (batch_dw + ovf_cap * sweep_stride32) * 4)) || (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell))))
+        bool const second = tab_on && tab.part == 2; // (the first call sized the buffers and reset the counters: its sweep may still be running)
+        if (tab_on && std::max(tab.total_dw, tab.dw0 + tab_ovf_dw + tab.dw1) * 4 > h->d_trace.cap && second)
+            return fail(h, LX_ESTATE, "the second sweep of a chunk needs more slot memory than its first reserved");
+        if (!second && ((rc = ensure(h, h->d_trace, (tab_on ? std::max(tab.total_dw, tab.dw0 + tab_ovf_dw + tab.dw1) : batch_dw + ovf_cap * sweep_stride32) * 4)) ||
+                        (rc = ensure(h, h->d_ends, n * sizeof(lx::EndCell)))))
             return rc;
-        if ((rc = prepare_workspace(h, stream, sweep_panels > 1 ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
+        if (!second && (rc = prepare_workspace(h, stream, sweep_panels > 1 ? n * ((h->opt_max_slen + 3) & ~3ull) : 0)))
             return rc;
-        LX_HIP(h, hipMemsetAsync(h->d_ws_top + 4, 0, sizeof(uint32_t), stream));
+        if (!second)
+            LX_HIP(h, hipMemsetAsync(h->d_ws_top + 4, 0, sizeof(uint32_t), stream));
         lx::TraceParams p{};
         p.q_res          = static_cast<uint8_t const *>(d_q_res);
         p.s_res          = static_cast<uint8_t const *>(d_s_res);
@@ -892,9 +922,17 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
                     sp1.steps_cap2   = steps2;
                     sp1.panels_cap2  = panels2;
                 }
+                if (tab_on)
+                {
+                    sp1.wf_tab = static_cast<lx::WfSlots const *>(tab.dev);
+                    sp1.wf_lo  = tab.part == 2 ? (uint32_t)(tab.n0 / 16) : 0u;
+                    sp1.n      = tab.part == 1 ? tab.n0 : n;
+                    sp1.ckpt   = tab.part == 2 ? p.trace + tab.dw0 + tab_ovf_dw : p.trace;
+                }
                 sp1.wide        = plan.wide ? 1 : 0;
                 sp1.stat_beyond = h->d_ws_top + 6;
-                LX_HIP(h, hipMemsetAsync(h->d_ws_top + 6, 0, sizeof(uint32_t), stream));
+                if (!second)
+                    LX_HIP(h, hipMemsetAsync(h->d_ws_top + 6, 0, sizeof(uint32_t), stream));
                 if (sweep_share < 0) // the solo packing: rows for the alphabet's letters and the pad letter, no more
                 {
                     sp1.solo  = 1;
@@ -906,6 +944,12 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
                 sp1.ws_cap     = p.ws_cap;
                 sp1.panels_cap = split_on ? panels1 : sweep_panels;
                 LX_HIP(h, lx::launch_sweep_mq(sweep_cfg, sp1, stream));
+                if (tab_on && tab.part == 1)
+                {
+                    // the first of a chunk's two sweeps: the rest of the chunk is still being planned -- the second call goes on from here
+                    pt0.close();
+                    return LX_OK;
+                }
                 if (sweep_panels > 1) // the fix-up launch starts with an empty carry workspace
                     LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
             }
@@ -1057,6 +1101,12 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             p.slot_stride2 = stride2;
             p.steps_cap2   = steps2;
         }
+        if (tab_on)
+        {
+            p.wf_tab  = static_cast<lx::WfSlots const *>(tab.dev);
+            p.split_n = tab.dw1 ? tab.n0 : 0;
+            p.trace2  = p.trace + tab.dw0 + tab_ovf_dw;
+        }
         PhaseTimer ptb(h, stream, 3);
         LX_HIP(h, lx::launch_ckpt_backtrace(p, stream));
         ptb.close();
@@ -1198,10 +1248,10 @@ void lx_destroy(lx_handle * h)
         }
     for (auto & ln : h->xb)
     {
-        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt, &ln.d_len, &ln.d_orig})
+        for (DevBuf * b : {&ln.d_ext, &ln.d_min, &ln.d_score, &ln.d_hsp, &ln.d_ops, &ln.d_rle, &ln.d_src, &ln.d_cnt, &ln.d_len, &ln.d_orig, &ln.d_wft})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len, &ln.p_orig})
+        for (lx_handle::Pinned * b : {&ln.p_ext, &ln.p_min, &ln.p_score, &ln.p_cnt, &ln.p_hsp, &ln.p_src, &ln.p_rle, &ln.p_len, &ln.p_orig, &ln.p_wft})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         for (hipEvent_t ev : {ln.ev_up, ln.ev_k, ln.ev_cnt})
@@ -1262,7 +1312,11 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
         case LX_OPT_PACKED_HALF: h->opt_f16 = value ? 1 : 0; return LX_OK;
         case LX_OPT_PASS2_MODE: h->opt_pass2 = value > 2 ? 1 : value; return LX_OK;
         case LX_OPT_EXTEND_CHUNK: h->opt_extend_chunk = value; return LX_OK;
-        case LX_OPT_MQ_SWEEP: h->opt_mq = value > 2 ? 1 : value; return LX_OK;
+        case LX_OPT_MQ_SWEEP:
+            h->opt_mq       = value > 2 ? 1 : value;
+            h->mq_decl_frac = 0.0; // (what the last chunks taught about compact codes against int16 pairs starts over)
+            h->mq_wide_call = false;
+            return LX_OK;
         case LX_OPT_ADAPT_PERMILLE: h->opt_adapt = std::min<uint64_t>(value, 1000); h->surv_frac = -1.0; return LX_OK;
         case LX_OPT_ITERATE_RECORDS: h->opt_iterate_records = value ? 1 : 0; return LX_OK;
         case LX_OPT_BAND:

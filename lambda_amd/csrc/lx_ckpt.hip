@@ -736,7 +736,15 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         uint32_t const ovf = (uint32_t)ec.flags >> kEndOverflowShift;
         slot               = ovf ? p.ovf + (uint64_t)(ovf - 1) * p.ovf_stride : p.trace + se * p.slot_stride;
         uint32_t steps_e   = p.steps_cap;
-        if (p.split_n != 0 && !ovf)
+        if (p.wf_tab && !ovf)
+        {
+            // the sweep's slots by wavefront (WfSlots): slot se % 16 of wavefront se / 16, laid out for that wavefront's steps and panels
+            WfSlots const  t      = p.wf_tab[se / 16];
+            uint64_t const stride = (uint64_t)t.panels_cap * (c16 ? L16::slot_dwords(t.steps_cap) : Lay::slot_dwords(t.steps_cap));
+            slot                  = ((p.split_n != 0 && se >= p.split_n) ? p.trace2 : p.trace) + t.off_dw + (se % 16) * stride;
+            steps_e               = t.steps_cap;
+        }
+        else if (p.split_n != 0 && !ovf)
         {
             bool const reg2 = se >= p.split_n;
             steps_e         = reg2 ? p.steps_cap2 : p.steps_cap1;

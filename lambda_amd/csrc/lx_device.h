@@ -59,6 +59,17 @@ struct Hsp
     int32_t ops_shift;
 };
 
+// Multi-query sweep, slots by WAVEFRONT (round 5): the 16 slots of wavefront w begin at off_dw (in uint32 from the launch's slot
+// base) and are laid out for steps_cap steps and panels_cap panels -- what w's own longest window and widest query need, not the
+// chunk's.  A chunk of a ragged list then takes the sum of what its wavefronts need (a tenth of them are three times as long as the
+// rest) instead of slots x the chunk's maximum, and one chunk -- one backtrace launch -- holds what took three.
+struct WfSlots
+{
+    uint64_t off_dw;
+    uint32_t steps_cap;
+    uint32_t panels_cap;
+};
+
 struct ScoreParams
 {
     uint8_t const *    q_res;
@@ -88,6 +99,10 @@ struct ScoreParams
     uint32_t *         ckpt2;
     uint64_t           ckpt_stride2;
     uint32_t           steps_cap2, panels_cap2;
+    // multi-query sweep: slots by wavefront (WfSlots) -- wf_tab[w] for wavefront w of the chunk, slots relative to `ckpt`; the launch
+    // covers the wavefronts from wf_lo on (a chunk may be swept by two launches: the plan's pool while the rest is still being planned)
+    WfSlots const *    wf_tab;
+    uint32_t           wf_lo;
     // single sweep (lx_ckpt.hip layout): when set, the packed-half kernel also writes strip boundaries, row checkpoints
     // (as the compact 16-bit codes of Ckpt16Layout) and the end cell of every extension
     uint32_t *         ckpt;        // [n + 1] slots of ckpt_stride uint32 (the last one is the spare slot idle halves write to)
@@ -211,6 +226,9 @@ struct TraceParams
     uint32_t *         trace2;
     uint64_t           slot_stride2;
     uint32_t           steps_cap2, steps_cap1; // steps_cap1: region 1's (steps_cap stays what the overflow slots are laid out for)
+    // ... or by wavefront (ScoreParams::wf_tab): extension se has slot se % 16 of wavefront se / 16; wavefronts from split_n / 16 on
+    // count their offsets from trace2 (the second launch's slots), the others from trace
+    WfSlots const *    wf_tab;
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

@@ -716,6 +716,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
+    bool const wf_slots = !lx::dev_aids().mq_no_wfslots; // multi-query chunks: checkpoint slots by wavefront (lx::WfSlots) instead of by region
     bool       dev_list = false, want_codes = true, by_range = false; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
     h->res_count         = 0;
     h->l2.surv_on_device = false;
@@ -1650,7 +1651,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint64_t const max_q = (max_pan + panel / 8 - 1) / (panel / 8) * panel; // (whole panels: the slots have one part per panel)
         // a chunk that begins in the pool and goes on behind it: two slot regions
         h->mq_split = lx_handle::MqSplit{};
-        if (!use_solo && w0 < pool_wf && pool_wf < w1)
+        if (!wf_slots && !use_solo && w0 < pool_wf && pool_wf < w1)
         {
             uint64_t m[2][2] = {{1, 1}, {1, 1}}; // [region][columns per lane, rows]
             for (uint64_t w = w0; w < w1; ++w)
@@ -1699,6 +1700,30 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // the OTHER lane's collect may have overwritten meanwhile)
         h->mq_wide_call = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (force_wide || (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03));
         pr.wide         = h->mq_wide_call;
+        h->mq_tab       = lx_handle::MqTab{};
+        if (wf_slots)
+        {
+            // the chunk's slots by wavefront (lx::WfSlots): every wavefront's sixteen laid out for ITS longest window and widest query
+            uint64_t const nw = w1 - w0, pc = panel / 8;
+            if ((rc2 = ensure_pinned(h, ln.p_wft, nw * sizeof(lx::WfSlots))) || (rc2 = ensure(h, ln.d_wft, nw * sizeof(lx::WfSlots))))
+                return rc2;
+            lx::WfSlots * const tab = static_cast<lx::WfSlots *>(ln.p_wft.ptr);
+            uint64_t            off = 0;
+            for (uint64_t w = 0; w < nw; ++w)
+            {
+                uint32_t const steps  = (uint32_t)(((uint64_t)wf_maxs[w0 + w] + 8 - 1 + 15) & ~15ull);
+                uint32_t const panels = (uint32_t)std::max<uint64_t>(1, ((uint64_t)wf_pan[w0 + w] + pc - 1) / pc);
+                tab[w]                = lx::WfSlots{off, steps, panels};
+                off += kWave * (uint64_t)panels * (pr.wide ? lx::ckpt_slot_dwords(mq_cfg, steps) : lx::ckpt16_slot_dwords(mq_cfg, steps));
+            }
+            LX_HIP(h, hipMemcpyAsync(ln.d_wft.ptr, tab, nw * sizeof(lx::WfSlots), hipMemcpyHostToDevice, h->stream3));
+            LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+            LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+            h->mq_tab.dev     = ln.d_wft.ptr;
+            h->mq_tab.n0      = slots;
+            h->mq_tab.dw0     = off;
+            h->mq_tab.ovf_cap = std::min<uint64_t>(slots, slots / 8 + 64); // (what the chunk's budget reserved: an eighth of its slots)
+        }
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
         fx.ops_stride = stride;
@@ -1709,7 +1734,11 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
         if ((rc2 = fused_impl(h, slot, d_qptr, sref.dev, ln.d_ext.ptr, slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr,
                               d_cnt, h->stream, 3, true, &fx)))
+        {
+            h->mq_tab = lx_handle::MqTab{};
             return rc2;
+        }
+        h->mq_tab = lx_handle::MqTab{};
         LX_HIP(h, lx::launch_slot_scatter(d_orig, slots, static_cast<int32_t const *>(ln.d_score.ptr),
                                           static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
         LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // this chunk's error word
@@ -2244,7 +2273,19 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                     ++range_now;
                 w1 = cr.cut_wf[range_now + 1]; // (the budgets were checked range by range when the mode was chosen)
             }
-            while (!by_range && w1 < nwf && w1 - w0 < per_chunk)
+            uint64_t run_bytes = 0, run_q = 1, run_s = 1; // (slots by wavefront: what the chunk's wavefronts need, each for itself)
+            while (!by_range && wf_slots && w1 < nwf && w1 - w0 < per_chunk)
+            {
+                if (!merge_pool && w0 < pool_end && w1 == pool_end)
+                    break;
+                uint64_t const b2 = run_bytes + kWave * slot_bytes(wf_pan[w1], wf_maxs[w1]);
+                uint64_t const q2 = std::max<uint64_t>(run_q, wf_pan[w1]), s2 = std::max<uint64_t>(run_s, wf_maxs[w1]);
+                if (w1 > w0 && (b2 > h->opt_trace_bytes || (w1 + 1 - w0) * kWave * (q2 * 8 + s2) > (8ull << 30)))
+                    break;
+                run_bytes = b2, run_q = q2, run_s = s2;
+                ++w1;
+            }
+            while (!by_range && !wf_slots && w1 < nwf && w1 - w0 < per_chunk)
             {
                 if (!merge_pool && w0 < pool_end && w1 == pool_end)
                     break; // (A/B aid: the pool in chunks of its own, as before)

@@ -129,8 +129,8 @@ struct lx_handle
     };
     struct XbLane
     {
-        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len, p_orig;
-        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len, d_orig;
+        Pinned     p_ext, p_min, p_score, p_cnt, p_hsp, p_src, p_rle, p_len, p_orig, p_wft;
+        DevBuf     d_ext, d_min, d_score, d_hsp, d_ops, d_rle, d_src, d_cnt, d_len, d_orig, d_wft; // (wft: the chunk's lx::WfSlots table)
         hipEvent_t ev_up = nullptr, ev_k = nullptr, ev_cnt = nullptr;
     } xb[2];
     // multi-query plan: the caller's whole list, its cut-offs and the scores in caller order, on the device / in pinned staging
@@ -186,6 +186,17 @@ struct lx_handle
     {
         uint64_t n1 = 0, q1 = 0, s1 = 0, q2 = 0, s2 = 0;
     } mq_split;
+    // lx_extend_batch: the chunk's slots BY WAVEFRONT (lx::WfSlots, lx_device.h) instead of by region: `dev` = the table of the chunk's
+    // wavefronts on the device; the slots of the wavefronts before slot n0 take dw0 uint32 at the trace buffer's start, room for ovf_cap
+    // int16-pair overflow slots follows, then the dw1 uint32 of the wavefronts from n0 on.  part: 0 = the chunk in one call, 1 = the
+    // first of two calls (sweep of the slots before n0, nothing else), 2 = the second (sweep of the rest, then what follows a sweep,
+    // over all slots).  total_dw: what the trace buffer must hold (fixed by the first call).
+    struct MqTab
+    {
+        void const * dev = nullptr;
+        uint64_t     n0 = 0, dw0 = 0, dw1 = 0, ovf_cap = 0, total_dw = 0;
+        int          part = 0;
+    } mq_tab;
     bool     mq_wide_call  = false; // lx_extend_batch: this chunk's sweep writes int16-pair slots (many windows of the last chunks scored beyond the compact codes)
     double   mq_decl_frac  = 0.0;   // ... the share of the last multi-panel chunk's windows that the compact sweep declined
     int      mq_cfg_call   = 0; // lx_extend_batch: the strip geometry (trace cfg) it chose for this call's chunks (0 = fused_impl picks per chunk)

@@ -111,15 +111,21 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
     bool const is_first = (g == 0);
     bool const is_last  = (g == G - 1);
 
-    uint64_t const pair = (uint64_t)blockIdx.x * Geo::kGroups + grp;
+    uint64_t const wf   = (uint64_t)blockIdx.x + p.wf_lo; // (wavefront of the chunk)
+    uint64_t const pair = wf * Geo::kGroups + grp;
     uint64_t const eA   = 2 * pair, eB = 2 * pair + 1;
     bool const     actA = eA < p.n, actB = eB < p.n;
 
     // the slot region of this wavefront (ScoreParams::split_n: wave-uniform, the split is a multiple of 16)
-    bool const       reg2       = p.split_n != 0 && eA >= p.split_n;
-    uint32_t const   steps_cap  = reg2 ? p.steps_cap2 : p.steps_cap, panels_cap = reg2 ? p.panels_cap2 : p.panels_cap;
-    uint32_t * const ckpt_base  = reg2 ? p.ckpt2 : p.ckpt;
-    uint64_t const   ckpt_step  = reg2 ? p.ckpt_stride2 : p.ckpt_stride, ckpt_first = reg2 ? p.split_n : 0;
+    // ... or the slots of this wavefront by themselves (ScoreParams::wf_tab: sized for its own longest window and widest query)
+    bool const       by_wf      = p.wf_tab != nullptr;
+    WfSlots const    wfs        = by_wf ? p.wf_tab[wf] : WfSlots{0, 0, 0};
+    bool const       reg2       = !by_wf && p.split_n != 0 && eA >= p.split_n;
+    uint32_t const   steps_cap  = by_wf ? wfs.steps_cap : reg2 ? p.steps_cap2 : p.steps_cap, panels_cap = by_wf ? wfs.panels_cap : reg2 ? p.panels_cap2 : p.panels_cap;
+    uint32_t * const ckpt_base  = by_wf ? p.ckpt + wfs.off_dw : reg2 ? p.ckpt2 : p.ckpt;
+    uint64_t const   ckpt_step  = by_wf ? (uint64_t)wfs.panels_cap * (WIDE ? Geo::slot_dwords_w(wfs.steps_cap) : L16::slot_dwords(wfs.steps_cap))
+                                        : reg2 ? p.ckpt_stride2 : p.ckpt_stride;
+    uint64_t const   ckpt_first = by_wf ? 2 * Geo::kGroups * wf : reg2 ? p.split_n : 0;
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge    = sc->ge;
@@ -451,8 +457,9 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
         bool const use_carry_in = MULTI && is_first && panel > 0 && carry != nullptr;
         bool const do_carry_out = MULTI && is_last && panel + 1 < npanels && carry != nullptr;
         // (an idle half owns the spare slot p.n -- the stores are unconditional)
-        uint32_t * const slotA = ckpt_base + ((actA ? eA : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
-        uint32_t * const slotB = ckpt_base + ((actB ? eB : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
+        // (... or, with slots by wavefront, its own slot of the wavefront's sixteen)
+        uint32_t * const slotA = ckpt_base + (((actA || by_wf) ? eA : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
+        uint32_t * const slotB = ckpt_base + (((actB || by_wf) ? eB : p.n) - ckpt_first) * ckpt_step + (uint64_t)panel * panel_dw;
 
         q2 Z = qsplat(ge * g + kMqBias); // z_i of the first processed row i = -g, biased
         q2 Arow[C], F0[C];               // A = H + (go - ge) of the previous row (its frame), folded F of this row
@@ -918,9 +925,14 @@ template <int C>
 static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
 {
     using Geo = MqGeo<C>;
-    uint64_t const blocks = (p.n + 2ull * Geo::kGroups - 1) / (2ull * Geo::kGroups);
+    uint64_t const all_wf = (p.n + 2ull * Geo::kGroups - 1) / (2ull * Geo::kGroups);
+    if (p.wf_lo > all_wf)
+        return hipErrorInvalidValue;
+    uint64_t const blocks = all_wf - p.wf_lo; // (p.n = the slots up to the END of the launch's range: a first launch of two passes fewer)
+    if (blocks == 0)
+        return hipSuccess;
     int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
-    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || p.steps_cap % 16 != 0 || Geo::kGroups % share != 0 ||
+    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || (!p.wf_tab && p.steps_cap % 16 != 0) || Geo::kGroups % share != 0 || (p.wf_tab && p.split_n) ||
         (p.split_n != 0 && (p.split_n % 16 != 0 || p.split_n > p.n || !p.ckpt2 || p.steps_cap2 % 16 != 0)))
         return hipErrorInvalidValue;
     size_t const lds = ((size_t)(p.solo ? 2 * Geo::kGroups : p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
@@ -931,7 +943,7 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
         else
             return hipErrorInvalidValue; // (int16-pair slots: the 19-column strips only)
     }
-    else if (p.panels_cap > 1 || (p.split_n != 0 && p.panels_cap2 > 1))
+    else if (p.panels_cap > 1 || (p.split_n != 0 && p.panels_cap2 > 1)) // (slots by wavefront: panels_cap = the launch's largest)
         hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((sweep_mq_kernel<C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);

@@ -30,8 +30,12 @@ def check_list_against_rle(handle, q, s, ext, mins, chunk, expect_kernel=None):
     handle.set_option(capi.LX_OPT_PASS2_MODE, 2)
     handle.set_option(capi.LX_OPT_EXTEND_CHUNK, chunk)
     try:
+        # (both calls from the same start: the pipeline remembers whether its last chunks needed int16-pair slots, and a test that
+        # ran before this one may have taught it so)
+        handle.set_option(capi.LX_OPT_MQ_SWEEP, 1)
         score, hsp, off, codes = handle.extend_batch_rle(q, s, ext, mins)
         name_rle = handle.last_trace_kernel_name()
+        handle.set_option(capi.LX_OPT_MQ_SWEEP, 1)
         score_l, index, hsp_l, off_l, codes_l = handle.extend_batch_list(q, s, ext, mins)
         name_list = handle.last_trace_kernel_name()
     finally:
