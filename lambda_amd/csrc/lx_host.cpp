@@ -18,8 +18,8 @@ unsigned lxi::host_threads(uint64_t n)
         cpu_set_t set;
         CPU_ZERO(&set);
         unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
-        if (lx::dev_aids().host_threads)
-            c = lx::dev_aids().host_threads;
+        if (lx::dev_aids().host_threads) // (A/B aid: up to 64)
+            return std::max(1u, std::min(lx::dev_aids().host_threads, 64u));
         return std::max(1u, std::min(c, 16u));
     }();
     return n >= 250000 ? avail : std::min<unsigned>(avail, std::max<unsigned>(2u, (unsigned)(n / 24000)));
@@ -877,6 +877,41 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         use_mq = h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap &&
                  sh.gap_open <= sh.gap_extend && !lx::dev_aids().extend_no_mq;
     }
+    // the caller's list and cut-offs onto the device (pinned staging, filled by the host threads; scores in caller order zeroed) -- as
+    // soon as the multi-query path is known to be taken: the copy runs beside the planning of the pool
+    double t_upload      = 0;
+    bool   list_uploaded = false;
+    auto   upload_list   = [&]() -> int
+    {
+        int rc2;
+        auto const tu0 = std::chrono::steady_clock::now();
+        uint64_t const ext_bytes = n * sizeof(lx_extension), min_bytes = min_score ? n * sizeof(int32_t) : 0;
+        // (the scores of a list whose records are made on the device stay there: no pinned block for their way down)
+        if ((rc2 = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) ||
+            (!(as_list && ri && ri->keep_on_device) && (rc2 = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16))))
+            return rc2;
+        if (!ri) // (a resident list stands where the Level-2 kernels wrote it)
+        {
+            if ((rc2 = ensure_pinned(h, h->p_all, ext_bytes + min_bytes + 16)) || (rc2 = ensure(h, h->d_ext_all, ext_bytes + 16)) ||
+                (rc2 = ensure(h, h->d_min_all, min_bytes + 16)))
+                return rc2;
+            uint8_t * const stage_all = static_cast<uint8_t *>(h->p_all.ptr);
+            parallel_ranges(n, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                std::memcpy(stage_all + lo * sizeof(lx_extension), ext + lo, (hi - lo) * sizeof(lx_extension));
+                                if (min_score)
+                                    std::memcpy(stage_all + ext_bytes + lo * sizeof(int32_t), min_score + lo, (hi - lo) * sizeof(int32_t));
+                            });
+            LX_HIP(h, hipMemcpyAsync(h->d_ext_all.ptr, stage_all, ext_bytes, hipMemcpyHostToDevice, h->stream));
+            if (min_score)
+                LX_HIP(h, hipMemcpyAsync(h->d_min_all.ptr, stage_all + ext_bytes, min_bytes, hipMemcpyHostToDevice, h->stream));
+        }
+        LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
+        t_upload      = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
+        list_uploaded = true;
+        return LX_OK;
+    };
     // The SOLO packing of that sweep (lx_sweep_mq.hip, LX_OPT_QUERY_RUN = 1): a byte profile per window, 16 windows of any queries
     // per wavefront -- where 16 profiles fit a wavefront's share of the LDS, i.e. the alphabets of at most six rows (nucleotides,
     // bisulfite).  A read set's seed list has one or two windows per read: at four queries per wavefront three slots in four
@@ -940,6 +975,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             if (all16)
                 use_mq = false;
         }
+        if (use_mq && (rc = upload_list()))
+            return rc;
         if (cmin != cmax && !no_classes && !use_mq)
         {
             std::vector<uint64_t> at(cmax + 2, 0);
@@ -1723,6 +1760,42 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             h->mq_tab.n0      = slots;
             h->mq_tab.dw0     = off;
             h->mq_tab.ovf_cap = std::min<uint64_t>(slots, slots / 8 + 64); // (what the chunk's budget reserved: an eighth of its slots)
+            if (hm.on && !use_solo)
+            {
+                // (what in-order dispatch to 2 048 wavefront slots makes of the chunk, in cells: the even share, the longest wavefront, the makespan)
+                std::vector<uint64_t> slot_free(2048, 0);
+                std::make_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
+                uint64_t longest = 0, span = 0, above = 0;
+                for (uint64_t w = w0; w < w1; ++w)
+                {
+                    uint64_t const d = kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7);
+                    std::pop_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
+                    slot_free.back() += d;
+                    span    = std::max(span, slot_free.back());
+                    longest = std::max(longest, d);
+                    above += d > pr.exec_cells / 2048 ? 1 : 0;
+                    std::push_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
+                }
+                {
+                    std::vector<uint64_t> ds;
+                    for (uint64_t w = w0; w < w1; ++w)
+                        ds.push_back(kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7));
+                    std::sort(ds.begin(), ds.end(), std::greater<uint64_t>());
+                    std::vector<uint64_t> sf(2048, 0);
+                    std::make_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
+                    uint64_t lpt = 0;
+                    for (uint64_t d : ds)
+                    {
+                        std::pop_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
+                        sf.back() += d;
+                        lpt = std::max(lpt, sf.back());
+                        std::push_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
+                    }
+                    fprintf(stderr, "[lx host ms]   ... longest-first makespan %.2f M\n", (double)lpt / 1e6);
+                }
+                fprintf(stderr, "[lx host ms]   chunk %llu-%llu: even share %.2f M cells per wavefront slot, longest wavefront %.2f M, %llu above the share, in-order makespan %.2f M\n",
+                        (unsigned long long)w0, (unsigned long long)w1, (double)(pr.exec_cells / 2048) / 1e6, (double)longest / 1e6, (unsigned long long)above, (double)span / 1e6);
+            }
         }
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;
@@ -1745,6 +1818,188 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         LX_HIP(h, hipMemcpyAsync(d_cnt + 4, h->d_ws_top + 6, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream)); // ... its windows beyond the compact codes
         if (by_range && (rc2 = ri->chunk_records->enqueue(pr.range, ln.d_hsp.ptr, ln.d_src.ptr, d_cnt, pr.cap_sel)))
             return rc2; // (the records kernels of the range, behind the chunk's own: lx_level2_host.cpp)
+        LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
+        LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
+        LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
+        LX_HIP(h, hipEventRecord(ln.ev_cnt, h->stream2));
+        in_flight[L] = true;
+        t_issue += ms(t1, now());
+        return LX_OK;
+    };
+
+    // ---- ONE chunk in TWO calls (slots by wavefront): the plan's pool goes to the GPU -- its slot list, its table, its sweep -- while
+    // the streamed part of the plan is still being made on the host threads; the second call sweeps the streamed wavefronts into slots
+    // behind the pool's and runs what follows a sweep ONCE over all of them: one selection, one backtrace, one result list.  (Rounds
+    // 3-4: the pool as a chunk of its own -- its backtrace is the latency of its longest walks, 1.6 ms for a fifth of the survivors --
+    // or, for small lists, everything planned before the first launch.)
+    struct TwoCall
+    {
+        uint64_t n1 = 0, nw1 = 0, dw0 = 0, ovf_cap = 0, ovf_dw = 0, total_dw = 0, stride = 0, max_q = 0, max_s = 0, cap_slots = 0;
+    } two;
+    auto wf_dwords = [&](uint64_t w, bool wide) -> uint64_t // what wavefront w's sixteen slots take
+    {
+        uint64_t const pc     = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+        uint32_t const steps  = (uint32_t)(((uint64_t)wf_maxs[w] + 8 - 1 + 15) & ~15ull);
+        uint64_t const panels = std::max<uint64_t>(1, ((uint64_t)wf_pan[w] + pc - 1) / pc);
+        return kWave * panels * (wide ? lx::ckpt_slot_dwords(mq_cfg, steps) : lx::ckpt16_slot_dwords(mq_cfg, steps));
+    };
+    auto fill_table = [&](lx::WfSlots * tab, uint64_t wlo, uint64_t whi, bool wide) -> uint64_t // offsets from 0; returns the dwords
+    {
+        uint64_t const pc  = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+        uint64_t       off = 0;
+        for (uint64_t w = wlo; w < whi; ++w)
+        {
+            uint32_t const steps  = (uint32_t)(((uint64_t)wf_maxs[w] + 8 - 1 + 15) & ~15ull);
+            uint32_t const panels = (uint32_t)std::max<uint64_t>(1, ((uint64_t)wf_pan[w] + pc - 1) / pc);
+            tab[w - wlo]          = lx::WfSlots{off, steps, panels};
+            off += wf_dwords(w, wide);
+        }
+        return off;
+    };
+    auto chunk_stats = [&](XbPrep & pr, uint64_t wlo, uint64_t whi)
+    {
+        uint64_t padded = 0;
+        for (uint64_t w = wlo; w < whi; ++w)
+            padded += kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7);
+        pr.exec_cells += padded;
+        h->xb_stats[3] += padded;
+        h->xb_stats[1] += (whi - wlo) * kWave;
+    };
+    // first call: wavefronts [0, w1) = the pool; cap_slots bounds the chunk's slots, (cap_pan, cap_s) its widest query and longest window,
+    // rest_dw is what the second call's slots are expected to take
+    auto enqueue_mq_first = [&](int L, uint64_t w1, uint64_t cap_slots, uint64_t cap_pan, uint64_t cap_s, uint64_t rest_dw) -> int
+    {
+        auto const          t0 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        uint64_t const      panel = (uint64_t)lx::trace_cfg_panel(mq_cfg), slots1 = w1 * kWave;
+        pr.k0 = 0, pr.k1 = w1, pr.slots = slots1, pr.cap_sel = (cap_slots + 7) / 8 * 8 + 8, pr.exec_cells = 0, pr.max_s = cap_s, pr.max_pan = cap_pan;
+        int rc2;
+        if ((rc2 = ensure_pinned(h, ln.p_orig, cap_slots * sizeof(uint32_t))) || (rc2 = ensure_pinned(h, ln.p_wft, (cap_slots / kWave + 1) * sizeof(lx::WfSlots))))
+            return rc2;
+        uint32_t * const slot_orig = static_cast<uint32_t *>(ln.p_orig.ptr);
+        std::memcpy(slot_orig, plan_slot.data(), slots1 * sizeof(uint32_t));
+        chunk_stats(pr, 0, w1);
+        two           = TwoCall{};
+        two.max_q     = (cap_pan + panel / 8 - 1) / (panel / 8) * panel;
+        two.max_s     = cap_s;
+        two.stride    = (two.max_q + two.max_s + 3) & ~3ull;
+        two.cap_slots = cap_slots;
+        two.n1        = slots1;
+        two.nw1       = w1;
+        t_prep += ms(t0, now());
+        auto const t1 = now();
+        if ((rc2 = ensure(h, ln.d_orig, cap_slots * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_ext, cap_slots * sizeof(lx_extension))) ||
+            (rc2 = ensure(h, ln.d_min, cap_slots * sizeof(int32_t))) || (rc2 = ensure(h, ln.d_score, cap_slots * sizeof(int32_t))) ||
+            (rc2 = ensure(h, ln.d_hsp, pr.cap_sel * sizeof(lx_hsp))) || (rc2 = ensure(h, ln.d_ops, pr.cap_sel * two.stride + 16)) ||
+            (rc2 = ensure(h, ln.d_rle, pr.cap_sel * two.stride + 16)) || (rc2 = ensure(h, ln.d_src, pr.cap_sel * sizeof(uint32_t))) ||
+            (rc2 = ensure(h, ln.d_len, pr.cap_sel * sizeof(uint32_t))) || (rc2 = ensure(h, ln.d_cnt, 5 * sizeof(uint64_t))) ||
+            (rc2 = ensure_pinned(h, ln.p_cnt, 5 * sizeof(uint64_t))) || (rc2 = ensure(h, ln.d_wft, (cap_slots / kWave + 1) * sizeof(lx::WfSlots))))
+            return rc2;
+        h->opt_max_qlen  = two.max_q;
+        h->opt_max_slen  = two.max_s;
+        h->opt_query_run = 2;
+        h->mq_split      = lx_handle::MqSplit{};
+        h->mq_wide_call  = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03);
+        pr.wide          = h->mq_wide_call;
+        lx::WfSlots * const tab = static_cast<lx::WfSlots *>(ln.p_wft.ptr);
+        two.dw0          = fill_table(tab, 0, w1, pr.wide);
+        {
+            // (overflow slots have the size of the chunk's widest query and longest window: an eighth of the slots, within 16 GiB)
+            uint64_t const steps = (two.max_s + 8 - 1 + 15) & ~15ull, s32 = (two.max_q / panel) * lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps);
+            two.ovf_cap          = std::min<uint64_t>(std::min<uint64_t>(cap_slots, cap_slots / 8 + 64), std::max<uint64_t>(1024, (4ull << 30) / std::max<uint64_t>(s32, 1)));
+            two.ovf_dw           = two.ovf_cap * s32;
+        }
+        // (reserved now: the pool's slots, the overflow slots, what the caller expects the second call's slots to take -- within the budget)
+        two.total_dw = std::max<uint64_t>(two.dw0 + two.ovf_dw, std::min<uint64_t>(h->opt_trace_bytes / 4, two.dw0 + two.ovf_dw + rest_dw));
+        LX_HIP(h, hipMemcpyAsync(ln.d_orig.ptr, slot_orig, slots1 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipMemcpyAsync(ln.d_wft.ptr, tab, w1 * sizeof(lx::WfSlots), hipMemcpyHostToDevice, h->stream3));
+        LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+        LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+        LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(ri ? ri->d_ext_all : h->d_ext_all.ptr),
+                                         (min_score || (ri && ri->d_min_all)) ? static_cast<int32_t const *>(ri ? ri->d_min_all : h->d_min_all.ptr) : nullptr,
+                                         min_score_all, static_cast<uint32_t const *>(ln.d_orig.ptr), slots1, static_cast<lx::Extension *>(ln.d_ext.ptr),
+                                         static_cast<int32_t *>(ln.d_min.ptr), h->stream));
+        h->mq_tab          = lx_handle::MqTab{};
+        h->mq_tab.dev      = ln.d_wft.ptr;
+        h->mq_tab.n0       = slots1;
+        h->mq_tab.dw0      = two.dw0;
+        h->mq_tab.ovf_cap  = two.ovf_cap;
+        h->mq_tab.total_dw = two.total_dw;
+        h->mq_tab.part     = 1;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = two.stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * two.stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
+        rc2 = fused_impl(h, slot, d_qptr, sref.dev, ln.d_ext.ptr, cap_slots, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr, d_cnt, h->stream, 3,
+                         true, &fx);
+        h->mq_tab = lx_handle::MqTab{};
+        t_issue += ms(t1, now());
+        return rc2;
+    };
+    // second call: wavefronts [w_mid, w1) of the plan (none: the pool stays a chunk of its own) behind the first call's
+    auto enqueue_mq_second = [&](int L, uint64_t w_mid, uint64_t w1) -> int
+    {
+        auto const          t0 = now();
+        lx_handle::XbLane & ln = h->xb[L];
+        XbPrep &            pr = prep[L];
+        uint64_t const      slots2 = (w1 - w_mid) * kWave, total = two.n1 + slots2;
+        int rc2;
+        uint32_t * const    slot_orig = static_cast<uint32_t *>(ln.p_orig.ptr);
+        lx::WfSlots * const tab       = static_cast<lx::WfSlots *>(ln.p_wft.ptr) + two.nw1;
+        if (slots2)
+            std::memcpy(slot_orig + two.n1, plan_slot.data() + w_mid * kWave, slots2 * sizeof(uint32_t));
+        chunk_stats(pr, w_mid, w1);
+        uint64_t const dw1 = fill_table(tab, w_mid, w1, pr.wide);
+        pr.k1    = w1;
+        pr.slots = total;
+        t_prep += ms(t0, now());
+        auto const t1 = now();
+        if (slots2)
+        {
+            LX_HIP(h, hipMemcpyAsync(static_cast<uint32_t *>(ln.d_orig.ptr) + two.n1, slot_orig + two.n1, slots2 * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream3));
+            LX_HIP(h, hipMemcpyAsync(static_cast<lx::WfSlots *>(ln.d_wft.ptr) + two.nw1, tab, (w1 - w_mid) * sizeof(lx::WfSlots), hipMemcpyHostToDevice, h->stream3));
+            LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));
+            LX_HIP(h, hipStreamWaitEvent(h->stream, ln.ev_up, 0));
+            LX_HIP(h, lx::launch_slot_gather(static_cast<lx::Extension const *>(ri ? ri->d_ext_all : h->d_ext_all.ptr),
+                                             (min_score || (ri && ri->d_min_all)) ? static_cast<int32_t const *>(ri ? ri->d_min_all : h->d_min_all.ptr) : nullptr,
+                                             min_score_all, static_cast<uint32_t const *>(ln.d_orig.ptr) + two.n1, slots2,
+                                             static_cast<lx::Extension *>(ln.d_ext.ptr) + two.n1, static_cast<int32_t *>(ln.d_min.ptr) + two.n1, h->stream));
+        }
+        h->opt_max_qlen    = two.max_q;
+        h->opt_max_slen    = two.max_s;
+        h->opt_query_run   = 2;
+        h->mq_split        = lx_handle::MqSplit{};
+        h->mq_wide_call    = pr.wide;
+        h->mq_tab          = lx_handle::MqTab{};
+        h->mq_tab.dev      = ln.d_wft.ptr;
+        h->mq_tab.n0       = two.n1;
+        h->mq_tab.dw0      = two.dw0;
+        h->mq_tab.dw1      = dw1;
+        h->mq_tab.ovf_cap  = two.ovf_cap;
+        h->mq_tab.total_dw = two.total_dw;
+        h->mq_tab.part     = 2;
+        uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
+        FusedExtra       fx;
+        fx.ops_stride = two.stride;
+        fx.d_rle      = static_cast<uint8_t *>(ln.d_rle.ptr);
+        fx.d_rle_top  = reinterpret_cast<unsigned long long *>(d_cnt + 2);
+        fx.rle_cap    = pr.cap_sel * two.stride;
+        fx.d_src_out  = static_cast<uint32_t *>(ln.d_src.ptr);
+        fx.d_rle_len  = static_cast<uint32_t *>(ln.d_len.ptr);
+        rc2 = fused_impl(h, slot, d_qptr, sref.dev, ln.d_ext.ptr, total, ln.d_min.ptr, 0, ln.d_score.ptr, ln.d_hsp.ptr, ln.d_ops.ptr, nullptr, d_cnt, h->stream, 3, true,
+                         &fx);
+        h->mq_tab = lx_handle::MqTab{};
+        if (rc2)
+            return rc2;
+        LX_HIP(h, lx::launch_slot_scatter(static_cast<uint32_t const *>(ln.d_orig.ptr), total, static_cast<int32_t const *>(ln.d_score.ptr),
+                                          static_cast<int32_t *>(h->d_score_all.ptr), static_cast<uint32_t *>(ln.d_src.ptr), d_cnt, pr.cap_sel, h->stream));
+        LX_HIP(h, hipMemcpyAsync(d_cnt + 3, h->d_ws_top, 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+        LX_HIP(h, hipMemcpyAsync(d_cnt + 4, h->d_ws_top + 6, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
         LX_HIP(h, hipEventRecord(ln.ev_k, h->stream));
         LX_HIP(h, hipStreamWaitEvent(h->stream2, ln.ev_k, 0));
         LX_HIP(h, hipMemcpyAsync(ln.p_cnt.ptr, d_cnt, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream2));
@@ -2158,31 +2413,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         h->xb_stats[2] = mq_cells;
         // the caller's list and cut-offs onto the device (pinned staging, filled by the pool), scores in caller order zeroed
         {
-            auto const tu0 = now();
-            uint64_t const ext_bytes = n * sizeof(lx_extension), min_bytes = min_score ? n * sizeof(int32_t) : 0;
-            // (the scores of a list whose records are made on the device stay there: no pinned block for their way down)
-            if ((rc = ensure(h, h->d_score_all, n * sizeof(int32_t) + 16)) ||
-                (!(as_list && ri && ri->keep_on_device) && (rc = ensure_pinned(h, h->p_score_all, n * sizeof(int32_t) + 16))))
+            if (!list_uploaded && (rc = upload_list()))
                 return rc;
-            if (!ri) // (a resident list stands where the Level-2 kernels wrote it)
-            {
-                if ((rc = ensure_pinned(h, h->p_all, ext_bytes + min_bytes + 16)) || (rc = ensure(h, h->d_ext_all, ext_bytes + 16)) ||
-                    (rc = ensure(h, h->d_min_all, min_bytes + 16)))
-                    return rc;
-                uint8_t * const stage_all = static_cast<uint8_t *>(h->p_all.ptr);
-                parallel_ranges(n, nthreads,
-                                [&](unsigned, uint64_t lo, uint64_t hi)
-                                {
-                                    std::memcpy(stage_all + lo * sizeof(lx_extension), ext + lo, (hi - lo) * sizeof(lx_extension));
-                                    if (min_score)
-                                        std::memcpy(stage_all + ext_bytes + lo * sizeof(int32_t), min_score + lo, (hi - lo) * sizeof(int32_t));
-                                });
-                LX_HIP(h, hipMemcpyAsync(h->d_ext_all.ptr, stage_all, ext_bytes, hipMemcpyHostToDevice, h->stream));
-                if (min_score)
-                    LX_HIP(h, hipMemcpyAsync(h->d_min_all.ptr, stage_all + ext_bytes, min_bytes, hipMemcpyHostToDevice, h->stream));
-            }
-            LX_HIP(h, hipMemsetAsync(h->d_score_all.ptr, 0, n * sizeof(int32_t), h->stream));
-            t_prep += ms(tu0, now());
+            t_prep += t_upload;
         }
         if (as_list && ri && ri->keep_on_device)
         {
@@ -2239,6 +2472,76 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             t_prep += ms(tp0, now());
         }
         uint64_t const pool_end = use_solo ? 0 : pool_wf; // wavefronts before it: the pool (region 1 of a chunk that spans it)
+        auto clear_rows = [&]()
+        {
+            // (beside the first chunk's kernels) every row starts as "no alignment"; the survivors' rows are written by
+            // collect_mq, the scores of all rows at the end of the call
+            auto const tz0 = now();
+            parallel_ranges(n, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                std::memset(static_cast<void *>(out_hsp + lo), 0, (hi - lo) * sizeof(lx_hsp));
+                                std::memset(out_ops_off + lo, 0, (hi - lo) * sizeof(uint64_t));
+                            });
+            rows_cleared = true;
+            t_unpack += ms(tz0, now());
+        };
+        // ---- the pool and what follows it as ONE chunk in two calls (enqueue_mq_first / enqueue_mq_second)
+        if (wf_slots && !lx::dev_aids().mq_no_two_calls && !use_solo && !merge_pool && !stream_planned && !by_range && pool_wf > 0)
+        {
+            auto const     tp0   = now();
+            uint64_t const nruns = starts.size() - 1, pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
+            // what the streamed part may come to: its windows in pairs (a run's last pair may be half empty), a wavefront closed
+            // early for every fifth run, one per planning thread; its slot bytes from every run's own panels and longest window
+            uint64_t nstream = 0, nstream_runs = 0, cap_pan = 1, cap_s = 1, dw1_est = 0;
+            bool const maybe_wide = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && h->mq_decl_frac > 0.01;
+            for (uint64_t r = 0; r < nruns; ++r)
+                if (pool_at[r] != starts[r])
+                {
+                    uint64_t const cnt = pool_at[r] - starts[r], pan = 0xfffu - (run_key[r] >> 16), maxs = ext[idx[pool_at[r] - 1]].s_len;
+                    uint32_t const steps = (uint32_t)((maxs + 8 - 1 + 15) & ~15ull);
+                    nstream += cnt;
+                    ++nstream_runs;
+                    cap_pan = std::max(cap_pan, pan);
+                    cap_s   = std::max(cap_s, maxs);
+                    dw1_est += (cnt + 1) / 2 * 2 * ((pan + pc - 1) / pc) * (maybe_wide ? lx::ckpt_slot_dwords(mq_cfg, steps) : lx::ckpt16_slot_dwords(mq_cfg, steps));
+                }
+            uint64_t dw0_est = 0;
+            for (uint64_t w = 0; w < pool_wf; ++w)
+            {
+                cap_pan = std::max<uint64_t>(cap_pan, wf_pan[w]);
+                cap_s   = std::max<uint64_t>(cap_s, wf_maxs[w]);
+                dw0_est += wf_dwords(w, maybe_wide);
+            }
+            uint64_t const cap_slots = pool_wf * kWave + nstream + 5 * nstream_runs + kWave * (nthreads + 2);
+            uint64_t const rest_dw   = dw1_est + dw1_est / 4 + (1u << 20); // (wavefronts share the largest of up to four runs' sizes)
+            t_prep += ms(tp0, now());
+            // (the budgets of a chunk: its checkpoint slots, its survivors' ops slots)
+            if (nstream != 0 && cap_slots < (1ull << 31) && (cap_slots + 16) * (cap_pan * 8 + cap_s + 4) <= (8ull << 30) && dw0_est * 4 <= h->opt_trace_bytes / 2)
+            {
+                if ((rc = enqueue_mq_first(0, pool_wf, cap_slots, cap_pan, cap_s, rest_dw)))
+                    return rc;
+                auto const tp1 = now();
+                plan_stream();
+                stream_planned = true;
+                // the wavefronts of the streamed part that fit behind the pool's (all of them, unless the estimate was short)
+                uint64_t w_end = pool_wf, dw1 = 0;
+                while (w_end < nwf && two.n1 + (w_end + 1 - pool_wf) * kWave <= two.cap_slots && wf_pan[w_end] <= cap_pan && wf_maxs[w_end] <= cap_s &&
+                       two.dw0 + two.ovf_dw + dw1 + wf_dwords(w_end, prep[0].wide) <= two.total_dw)
+                    dw1 += wf_dwords(w_end++, prep[0].wide);
+                t_prep += ms(tp1, now());
+                if (hm.on)
+                    fprintf(stderr, "[lx host ms]   one chunk in two calls: pool %llu wavefronts, then %llu of %llu (slots: %llu of at most %llu; dwords %llu + %llu + %llu of %llu)\n",
+                            (unsigned long long)pool_wf, (unsigned long long)(w_end - pool_wf), (unsigned long long)(nwf - pool_wf), (unsigned long long)(w_end * kWave),
+                            (unsigned long long)two.cap_slots, (unsigned long long)two.dw0, (unsigned long long)two.ovf_dw, (unsigned long long)dw1, (unsigned long long)two.total_dw);
+                if ((rc = enqueue_mq_second(0, pool_wf, w_end)))
+                    return rc;
+                if (!as_list)
+                    clear_rows();
+                w0 = w_end;
+                c  = 1;
+            }
+        }
         for (;;)
         {
             if (w0 >= nwf)
@@ -2308,19 +2611,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             if ((rc = enqueue_mq(L, w0, w1)))
                 return rc;
             if (!rows_cleared && !as_list)
-            {
-                // (beside the first chunk's kernels) every row starts as "no alignment"; the survivors' rows are written by
-                // collect_mq, the scores of all rows at the end of the call
-                auto const tz0 = now();
-                parallel_ranges(n, nthreads,
-                                [&](unsigned, uint64_t lo, uint64_t hi)
-                                {
-                                    std::memset(static_cast<void *>(out_hsp + lo), 0, (hi - lo) * sizeof(lx_hsp));
-                                    std::memset(out_ops_off + lo, 0, (hi - lo) * sizeof(uint64_t));
-                                });
-                rows_cleared = true;
-                t_unpack += ms(tz0, now());
-            }
+                clear_rows();
             if (in_flight[L ^ 1] && (rc = collect_mq(L ^ 1)))
                 return rc;
             w0 = w1;
