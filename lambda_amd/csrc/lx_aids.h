@@ -31,6 +31,7 @@ struct DevAids
     bool     mq_no_wide;        // LX_MQ_NO_WIDE         multi-query sweep: compact codes always (what scores beyond them goes to the int32 launch)  off
     bool     mq_no_wfslots;     // LX_MQ_NO_WFSLOTS      lx_extend_batch: the multi-query chunks' checkpoint slots by region (rounds 3-4) instead of by wavefront  off
     bool     mq_no_two_calls;   // LX_MQ_NO_TWO_CALLS    lx_extend_batch: the pool a chunk of its own (round 4) instead of the first of a chunk's two calls  off
+    bool     mq_no_longest_first; // LX_MQ_NO_LONGEST_FIRST lx_extend_batch: the pool's wavefronts launched in packing order (panels, window length) instead of longest first  off
     bool     mq_no_merge;       // LX_MQ_NO_MERGE        lx_extend_batch: the pool's wavefronts in launches of their own (no two-region chunk)  off
     uint64_t mq_merge_below;    // LX_MQ_MERGE_BELOW     lx_extend_batch: lists of at most this many windows launch the pool with the rest (0 = 200 000)  0
     bool     iterate_on_host;   // LX_ITERATE_ON_HOST    lx_iterate_matches: widen / sort / merge on the host threads whatever the list's size  off

@@ -52,6 +52,7 @@ lx::DevAids const & lx::dev_aids()
         a.mq_no_merge       = set("LX_MQ_NO_MERGE");
         a.mq_no_wfslots     = set("LX_MQ_NO_WFSLOTS");
         a.mq_no_two_calls   = set("LX_MQ_NO_TWO_CALLS");
+        a.mq_no_longest_first = set("LX_MQ_NO_LONGEST_FIRST");
         a.iterate_on_host   = set("LX_ITERATE_ON_HOST");
         a.mq_merge_below    = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
         a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;

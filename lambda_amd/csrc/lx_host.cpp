@@ -1316,6 +1316,14 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             wf_pan.resize(nwf);
             wf_maxs.resize(nwf);
         }
+        // The wavefronts are made of neighbours in that order (a wavefront runs as many columns per lane as its widest query has and as
+        // many steps as its longest window) and LAUNCHED longest first: what a wavefront executes is columns x steps, and the blocks of a
+        // launch are dealt to the chip's wavefront slots in index order -- with two or three wavefronts per slot (a list of long queries)
+        // the launch is as long as its unluckiest slot, which longest-first keeps at the longest wavefront itself.
+        std::vector<uint32_t> & pool_pan = h->xb_pool_pan, & pool_maxs = h->xb_pool_maxs, & pool_place = h->xb_pool_place;
+        pool_pan.resize(pool_wf);
+        pool_maxs.resize(pool_wf);
+        pool_place.resize(pool_wf);
         parallel_ranges(pool_wf, nthreads,
                         [&](unsigned, uint64_t wlo, uint64_t whi)
                         {
@@ -1324,20 +1332,52 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                 uint32_t pan = 0, maxs = 0;
                                 for (uint64_t o = 4 * w; o < 4 * w + 4; ++o)
                                 {
+                                    uint32_t const sb    = sb_order[std::min(o, nsb - 1)];
+                                    uint64_t const first = sb_first[sb], cnt = sb_cnt[sb];
+                                    pan = std::max(pan, 0xfffu - (sb_key[sb] >> 16));
+                                    for (uint64_t j = 0; j < cnt; ++j)
+                                        maxs = std::max(maxs, ext[idx[first + j]].s_len);
+                                }
+                                pool_pan[w]  = pan;
+                                pool_maxs[w] = maxs;
+                            }
+                        });
+        {
+            std::vector<uint32_t> & by_len = h->xb_pool_order;
+            by_len.resize(pool_wf);
+            for (uint64_t w = 0; w < pool_wf; ++w)
+                by_len[w] = (uint32_t)w;
+            if (!lx::dev_aids().mq_no_longest_first)
+            {
+                std::vector<uint32_t> & len_key = h->xb_pool_key, & len_tmp = h->xb_pool_tmp;
+                len_key.resize(pool_wf);
+                len_tmp.resize(pool_wf);
+                for (uint64_t w = 0; w < pool_wf; ++w)
+                    len_key[w] = 0x3fffffffu - (uint32_t)std::min<uint64_t>((uint64_t)pool_pan[w] * (pool_maxs[w] + 7), 0x3fffffffu);
+                radix_sort(by_len, len_tmp, len_key, pool_wf);
+            }
+            for (uint64_t k = 0; k < pool_wf; ++k)
+                pool_place[by_len[k]] = (uint32_t)k;
+        }
+        parallel_ranges(pool_wf, nthreads,
+                        [&](unsigned, uint64_t wlo, uint64_t whi)
+                        {
+                            for (uint64_t w = wlo; w < whi; ++w)
+                            {
+                                uint64_t const at = pool_place[w]; // (its place in the launch)
+                                for (uint64_t o = 4 * w; o < 4 * w + 4; ++o)
+                                {
                                     // (a wavefront that the pool cannot fill repeats its last sub-block as fillers)
                                     bool const     real  = o < nsb;
                                     uint32_t const sb    = sb_order[std::min(o, nsb - 1)];
                                     uint64_t const first = sb_first[sb], cnt = sb_cnt[sb];
                                     // (the longest window first, like the streamed pairs; the last one is repeated as filler)
                                     for (uint64_t j = 0; j < kSub; ++j)
-                                        plan_slot[w * kWave + (o - 4 * w) * kSub + j] =
+                                        plan_slot[at * kWave + (o - 4 * w) * kSub + j] =
                                           idx[first + cnt - 1 - std::min(j, cnt - 1)] | ((real && j < cnt) ? 0u : 0x80000000u);
-                                    pan  = std::max(pan, 0xfffu - (sb_key[sb] >> 16));
-                                    for (uint64_t j = 0; j < cnt; ++j)
-                                        maxs = std::max(maxs, ext[idx[first + j]].s_len);
                                 }
-                                wf_pan[w]  = pan;
-                                wf_maxs[w] = maxs;
+                                wf_pan[at]  = pool_pan[w];
+                                wf_maxs[at] = pool_maxs[w];
                             }
                         });
         hm.mark("pool");
@@ -2464,11 +2504,51 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // rounds and the streamed part's plan is better made beside its kernels: 596 k windows 18.6 ms merged, 17.5 ms not;
         // 64 k windows of 300-500-residue queries 11.9 ms merged, 16.3 ms not)
         bool const merge_pool = !use_solo && !lx::dev_aids().mq_no_merge && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
+        // wavefronts [wlo, whi) of the plan in launch order = longest first (what a wavefront executes is columns x steps; the blocks of a
+        // launch are dealt to the chip's wavefront slots in index order, so a long wavefront late in the order ends the launch late)
+        auto longest_first = [&](uint64_t wlo, uint64_t whi)
+        {
+            if (!wf_slots || lx::dev_aids().mq_no_longest_first || whi <= wlo + 1)
+                return;
+            uint64_t const cnt = whi - wlo;
+            std::vector<uint32_t> & by_len = h->xb_pool_order, & tmp_slot = h->xb_pool_place, & tmp_pan = h->xb_pool_pan, & tmp_maxs = h->xb_pool_maxs;
+            std::vector<uint32_t> & len_key = h->xb_pool_key, & len_tmp = h->xb_pool_tmp;
+            by_len.resize(cnt);
+            len_tmp.resize(cnt);
+            len_key.resize(whi);
+            for (uint64_t k = 0; k < cnt; ++k)
+            {
+                by_len[k]        = (uint32_t)(wlo + k);
+                len_key[wlo + k] = 0x3fffffffu - (uint32_t)std::min<uint64_t>((uint64_t)wf_pan[wlo + k] * (wf_maxs[wlo + k] + 7), 0x3fffffffu);
+            }
+            radix_sort(by_len, len_tmp, len_key, cnt);
+            tmp_slot.resize(cnt * kWave);
+            tmp_pan.resize(cnt);
+            tmp_maxs.resize(cnt);
+            parallel_ranges(cnt, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                for (uint64_t k = lo; k < hi; ++k)
+                                {
+                                    std::memcpy(tmp_slot.data() + k * kWave, plan_slot.data() + (uint64_t)by_len[k] * kWave, kWave * sizeof(uint32_t));
+                                    tmp_pan[k]  = wf_pan[by_len[k]];
+                                    tmp_maxs[k] = wf_maxs[by_len[k]];
+                                }
+                            });
+            parallel_ranges(cnt, nthreads,
+                            [&](unsigned, uint64_t lo, uint64_t hi)
+                            {
+                                std::memcpy(plan_slot.data() + (wlo + lo) * kWave, tmp_slot.data() + lo * kWave, (hi - lo) * kWave * sizeof(uint32_t));
+                                std::memcpy(wf_pan.data() + wlo + lo, tmp_pan.data() + lo, (hi - lo) * sizeof(uint32_t));
+                                std::memcpy(wf_maxs.data() + wlo + lo, tmp_maxs.data() + lo, (hi - lo) * sizeof(uint32_t));
+                            });
+        };
         if (merge_pool && !stream_planned)
         {
             auto const tp0 = now();
             plan_stream();
             stream_planned = true;
+            longest_first(0, nwf); // (one launch for the whole plan: the streamed part's long wavefronts would start late)
             t_prep += ms(tp0, now());
         }
         uint64_t const pool_end = use_solo ? 0 : pool_wf; // wavefronts before it: the pool (region 1 of a chunk that spans it)
@@ -2524,6 +2604,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 auto const tp1 = now();
                 plan_stream();
                 stream_planned = true;
+                longest_first(pool_wf, nwf); // (the second launch's wavefronts)
                 // the wavefronts of the streamed part that fit behind the pool's (all of them, unless the estimate was short)
                 uint64_t w_end = pool_wf, dw1 = 0;
                 while (w_end < nwf && two.n1 + (w_end + 1 - pool_wf) * kWave <= two.cap_slots && wf_pan[w_end] <= cap_pan && wf_maxs[w_end] <= cap_s &&
@@ -2551,6 +2632,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                     break;
                 auto const tp0 = now();
                 plan_stream();
+                longest_first(w0, nwf);
                 stream_planned = true;
                 t_prep += ms(tp0, now());
                 continue;

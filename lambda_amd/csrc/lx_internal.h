@@ -86,6 +86,7 @@ struct lx_handle
     std::string error;
     // lx_extend_batch: host staging that keeps its pages between calls
     std::vector<uint32_t>     xb_idx, xb_src, xb_sel, xb_pos;
+    std::vector<uint32_t>     xb_pool_pan, xb_pool_maxs, xb_pool_place, xb_pool_order, xb_pool_key, xb_pool_tmp; // the pool's wavefronts before they are put in launch order
     std::vector<uint8_t>      xb_newrun;
     uint64_t                  xb_stats[4] = {0, 0, 0, 0}; // lx_extend_batch: extensions, slots, cells, cells executed (padding included)
     std::vector<uint64_t>     xb_grp, xb_off, xb_starts;
