@@ -192,3 +192,7 @@ for passes, cmd, dst in ((("pmc_iterate_sq", "pmc_iterate_sq_wait", "pmc_iterate
                            "FETCH_SIZE/WRITE_SIZE in KiB, FETCH_SIZE doubled before use.",
                    "kernel_sources": KERNEL_SOURCES, "kernels": k}, open(out / f"{tag}_{dst}.json", "w"), indent=1)
 
+
+# round 5: the spread of the secondary lines over runs and boxes (tools/dev/rerun_lines.sh writes it)
+if (src / "line_spread.txt").exists():
+    (out / f"{tag}_line_spread.txt").write_text((src / "line_spread.txt").read_text())
