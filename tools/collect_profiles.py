@@ -89,7 +89,7 @@ json.dump({
             "(MI355X_MICROARCH.md, HBM) -> doubled before use.  The score kernels are launched once per step, the trace "
             "kernels once per chunk, so per-step means are the comparable figures.  SQ_WAVE_CYCLES ~ SQ_WAIT_ANY (parked on "
             "s_waitcnt) + SQ_WAIT_INST_ANY (issue stall) + SQ_ACTIVE_INST_ANY, in quad-cycles summed over wavefronts.",
-    "kernels": kern}, open(out / f"{tag}_bench_pmc.json", "w"), indent=1)
+    "kernel_sources": KERNEL_SOURCES, "kernels": kern}, open(out / f"{tag}_bench_pmc.json", "w"), indent=1)
 
 for log, dst in (("bench.log", f"{tag}_bench_line.json"), ("bench_pass1.log", f"{tag}_bench_line_pass1_only.json"),
                  ("stats.log", f"{tag}_bench_line_under_rocprof.json")):
