@@ -20,10 +20,10 @@ pytestmark = pytest.mark.gpu
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def run_case(tmp_path, name, env_extra, trace_bytes=None):
+def run_case(tmp_path, name, env_extra, trace_bytes=None, which="ragged"):
     env = dict(os.environ, LX_MQ_MERGE_BELOW="1", LX_HOST_TIMING="1", **env_extra)
     out = tmp_path / (name + ".npz")
-    argv = [sys.executable, str(ROOT / "tests" / "two_calls_case.py"), str(out)] + ([str(trace_bytes)] if trace_bytes else [])
+    argv = [sys.executable, str(ROOT / "tests" / "two_calls_case.py"), str(out), which] + ([str(trace_bytes)] if trace_bytes else [])
     r = subprocess.run(argv, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(out), r.stderr
@@ -55,3 +55,17 @@ def test_two_calls_give_what_the_pool_as_its_own_chunk_gives(tmp_path, oracle):
     m2 = re.findall(r"one chunk in two calls: pool (\d+) wavefronts, then (\d+) of (\d+) ", log2)
     assert m2 and 0 < int(m2[0][1]) < int(m2[0][2]), log2[-2000:]
     same(part, one)
+
+
+def test_two_calls_whose_overflow_area_runs_out_are_run_again_with_wide_slots(tmp_path, oracle):
+    """Every window beyond the compact codes on a handle that has not learned so: the chunk's overflow area (an eighth of its slots)
+    runs out in the two calls' sweeps, the whole chunk is run again with int16 pairs from the sweep -- same results as the pool as
+    a chunk of its own, and the oracle's scores."""
+    two, log = run_case(tmp_path, "two_s", {}, which="strong")
+    assert "one chunk in two calls" in log, log[-2000:]
+    assert "(wide)" in log, log[-2000:]  # (the chunk that was run again)
+    one, _ = run_case(tmp_path, "one_s", {"LX_MQ_NO_TWO_CALLS": "1"}, which="strong")
+    same(two, one)
+    q, s, ext, mins = case("strong")
+    want = oracle.score_batch(q, s, ext, oracle_lib.scoring_from(SCHEMES["blosum62"]), threads=8)
+    assert (two["score"] == want).all() and (want > 2046).mean() > 0.9
