@@ -2710,9 +2710,24 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 for (uint64_t k = 0; k < ri->chunk_records->n_ranges; ++k)
                     if (ri->chunk_records->cut_wf[k] == r.first)
                         prep[0].range = k;
-            if ((rc = enqueue_mq(0, r.first, r.second, true)) || (rc = collect_mq(0)))
-                return rc;
-            ++c;
+            // (int16-pair slots are twice the codes': the range is run again in pieces that fit the slot budget -- a range whose records
+            // are made chunk by chunk stays whole)
+            for (uint64_t a = r.first; a < r.second;)
+            {
+                uint64_t b = a, bytes = 0;
+                while (b < r.second)
+                {
+                    uint64_t const wb = wf_dwords(b, true) * 4;
+                    if (!by_range && b > a && bytes + wb > h->opt_trace_bytes)
+                        break;
+                    bytes += wb;
+                    ++b;
+                }
+                if ((rc = enqueue_mq(0, a, b, true)) || (rc = collect_mq(0)))
+                    return rc;
+                ++c;
+                a = b;
+            }
         }
         // the scores of every extension, in caller order (a device list's scores stay on the device as well: h->d_score_all)
         if (!dev_list)
