@@ -299,7 +299,7 @@ struct RecordsJob
     // K * (ql - adj) * (dl - adj) of computeEValue (blast_stats.hpp), exp(-lambda s) for every score until it is zero, the bit-score
     // test as an integer cut-off -- and the buffers (entries: upper bound of the survivor entries of any range; every range has its
     // own rows in d_rec: at most as many as it has windows)
-    int prepare(lambda_amd::CutOffs & cutOffFor, std::vector<Range> rs, uint64_t max_entries)
+    int prepare(lambda_amd::CutOffs & cutOffFor, std::vector<Range> rs, uint64_t max_entries, uint64_t max_wlen = 0 /* longest window of the part, 0 = unknown */)
     {
         using namespace lambda_amd;
         auto &            l2 = h->l2;
@@ -387,7 +387,8 @@ struct RecordsJob
         base.list_at    = static_cast<uint32_t *>(l2.d_listat.ptr);
         // the digits the keys can have set: (true query id | padding's id, query slice length), (subject slice length, window | entry)
         pair_bits = (bits_below((uint64_t)base.n_qid_end + 1) << 32) | bits_below((uint64_t)l2.max_qlen + 1);
-        s0_bits   = (bits_below(std::min<uint64_t>(l2.max_slen, 0xfffffffeull) + 1) << 32) | bits_below(std::max(max_win, max_entries) + 1);
+        // (a window is as long as its subject at most; the plan knows the part's longest window: one digit instead of three on a genome)
+        s0_bits   = (bits_below(std::min<uint64_t>(max_wlen ? max_wlen : l2.max_slen, 0xfffffffeull) + 1) << 32) | bits_below(std::max(max_win, max_entries) + 1);
         return LX_OK;
     }
 
@@ -686,7 +687,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 uint64_t max_entries = 0;
                 for (size_t r = 0; r < ranges.size(); ++r)
                     max_entries = std::max(max_entries, (l2.cut_wf[r + 1] - l2.cut_wf[r]) * 16 + 16);
-                if ((rc = job.prepare(cutOffFor, ranges, max_entries)))
+                uint64_t max_wlen = 1; // (the plan's per-wavefront maxima: every window of the part stands in one of them)
+                for (uint64_t w = 0; w < nwf; ++w)
+                    max_wlen = std::max<uint64_t>(max_wlen, l2.wf_maxs[w]);
+                if ((rc = job.prepare(cutOffFor, ranges, max_entries, max_wlen)))
                     return rc;
                 cr.cut_wf   = l2.cut_wf.data();
                 cr.n_ranges = ranges.size();
