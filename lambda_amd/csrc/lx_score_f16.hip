@@ -156,18 +156,24 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
     int const steps = (ls_max + G - 1 + 3) & ~3;
 
     // ---- exactness test (wave-uniform): an upper bound of every intermediate must stay <= 2046
-    int const col0 = g * C;
-    int       bound = 0;
-#pragma unroll
-    for (int c = 0; c < C; ++c)
+    // (first the bound no query of this length exceeds -- every column at the matrix' largest entry: where that passes for the whole
+    // wavefront, the residues need not be looked at: two dependent loads per column in front of everything else)
+    int const col0  = g * C;
+    int       bound = lq * sc->smax;
+    if (__ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046) != 0)
     {
-        int const j = col0 + c;
-        if (j < lq)
-            bound += sc->rowmax[q[j] & (kAlph - 1)];
-    }
+        bound = 0;
 #pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1)
-        bound += __shfl_xor(bound, off);
+        for (int c = 0; c < C; ++c)
+        {
+            int const j = col0 + c;
+            if (j < lq)
+                bound += sc->rowmax[q[j] & (kAlph - 1)];
+        }
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1)
+            bound += __shfl_xor(bound, off);
+    }
     // (every group summed its own query; one block over the limit sends the whole wavefront to the fix-up launch)
     bool too_big = __ballot((lq > Geo::kPanel) || (bound + (-ge) * (steps + G + 2) + sc->smax + 2 > 2046)) != 0;
     if constexpr (CKPT)

@@ -250,20 +250,27 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
 
     // ---- range test (wave-uniform): an upper bound of every finite intermediate must stay below the limit -- the codes'
     // 2046 for one panel (tested up front), the 16-bit patterns' for wider queries (their codes are tested afterwards)
-    int bound = 0;
-    for (int j = g; j < lq; j += G) // (every column of the query once, whichever strip sweeps it)
-        bound += sc->rowmax[q[j] & (kAlph - 1)];
-    int boundB = 0;
-    if (solo_mode && actB)
-        for (int j = g; j < lqB; j += G)
-            boundB += sc->rowmax[qB[j] & (kAlph - 1)];
-#pragma unroll
-    for (int off = G / 2; off >= 1; off >>= 1)
+    // (first the bound no query of this length exceeds -- every column at the matrix' largest entry: where that passes, the
+    // residues need not be looked at: two dependent loads per column, 40 per lane in front of everything else)
+    int        bound       = lq_max * sc->smax;
+    bool const quick_fits  = bound + (-ge) * (steps + G + 2) + sc->smax + 2 <= ((MULTI || WIDE) ? kMqLimit : 2046);
+    if (!quick_fits)
     {
-        bound += __shfl_xor(bound, off);
-        boundB += __shfl_xor(boundB, off);
+        bound = 0;
+        for (int j = g; j < lq; j += G) // (every column of the query once, whichever strip sweeps it)
+            bound += sc->rowmax[q[j] & (kAlph - 1)];
+        int boundB = 0;
+        if (solo_mode && actB)
+            for (int j = g; j < lqB; j += G)
+                boundB += sc->rowmax[qB[j] & (kAlph - 1)];
+#pragma unroll
+        for (int off = G / 2; off >= 1; off >>= 1)
+        {
+            bound += __shfl_xor(bound, off);
+            boundB += __shfl_xor(boundB, off);
+        }
+        bound = max(bound, boundB);
     }
-    bound = max(bound, boundB);
     bool const broken  = (lq_max > (MULTI ? (int)panels_cap : 1) * Geo::kPanel) || (uint32_t)steps > steps_cap;
     // (free packing with a fifth query: declined as a whole -- the int32 launch shares profiles by pairs and copes)
     bool const too_big = broken || too_many || __ballot(bound + (-ge) * (steps + G + 2) + sc->smax + 2 > ((MULTI || WIDE) ? kMqLimit : 2046)) != 0 ||
