@@ -93,6 +93,8 @@ json.dump({
 
 for log, dst in (("bench.log", f"{tag}_bench_line.json"), ("bench_pass1.log", f"{tag}_bench_line_pass1_only.json"),
                  ("stats.log", f"{tag}_bench_line_under_rocprof.json")):
+    if not (src / log).exists():  # (tools/profile_round.sh <dir> profiles: the passes first, the bench lines once they are condensed)
+        continue
     lines = [l for l in open(src / log) if l.startswith('{"metric"')]
     if lines:
         (out / dst).write_text(lines[-1])
