@@ -18,7 +18,7 @@ M=${2:-all}
 [ $M = profiles ] || { (timeout 600 python bench.py --steps 10 --warmup 3 --survivor-rate 0.02 --adapt-permille 0 --no-cpu-baseline) > $D/bench_survivors_0.02_sweep.log 2>&1 ; }
 [ $M = profiles ] || { (timeout 600 python tools/host_curve.py 100) > $D/host_curve.jsonl 2>&1 ; }
 cd /tmp; export TMPDIR=/tmp
-[ $M = lines ] || { (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline) > $R/$D/stats.log 2>&1 ; }
+[ $M = lines ] || { (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats -o bench -- python $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline) > $R/$D/stats.log 2>&1 ; }
 [ $M = lines ] || { (timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $R/$D/pmc_sq -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq.log 2>&1 ; }
 [ $M = lines ] || { (timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES --output-format csv -d $R/$D/pmc_sq_wait -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_sq_wait.log 2>&1 ; }
 [ $M = lines ] || { (timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/$D/pmc_fetch -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_fetch.log 2>&1 ; }
