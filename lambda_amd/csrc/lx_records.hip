@@ -22,6 +22,8 @@
 //   * the bit-score test of the statistics is an integer cut-off found by bisection over the host's formula, like the filter's own.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "lx_level2.h"
 
 namespace lx
@@ -70,9 +72,11 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 // survivor list sort behind every real one (query id = the number of queries).
 __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64_t * pair, uint64_t * s0)
 {
-    uint64_t const e = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x;
-    bool           valid = false;
-    if (e < p.n_entries)
+    // (a few hundred workgroups over all entries, one atomic per workgroup: one per wavefront was ten thousand atomics on ONE counter,
+    // 0.08 ms of a kernel that streams 15 MB)
+    __shared__ uint32_t part[kRecBlock / 64];
+    uint32_t            mine = 0;
+    for (uint64_t e = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x; e < p.n_entries; e += (uint64_t)gridDim.x * kRecBlock)
     {
         bool const     filled = !p.count_ptr || e < *p.count_ptr;
         uint32_t const ws     = filled ? p.src[e] : 0xffffffffu;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64
             else
             {
                 L2Window const W = p.win[w];
-                valid            = true;
+                ++mine;
                 p.list_at[w]     = (uint32_t)e;
                 kp               = ((uint64_t)(W.q / p.q_frames) << 32) | p.q_len[W.q];
                 ks               = ((W.end > W.beg ? W.end - W.beg : 0ull) << 32) | w;
@@ -96,36 +100,58 @@ __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64
         pair[e] = kp;
         s0[e]   = ks;
     }
-    uint32_t const n = wave_sum(valid ? 1u : 0u);
-    if ((threadIdx.x & 63) == 0 && n)
-        atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecSurvivors), (unsigned long long)n);
+    uint32_t const n = wave_sum(mine);
+    if ((threadIdx.x & 63) == 0)
+        part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        uint32_t tot = 0;
+        for (int k = 0; k < kRecBlock / 64; ++k)
+            tot += part[k];
+        if (tot)
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecSurvivors), (unsigned long long)tot);
+    }
 }
 
 // (2) the filter's statistics from the scores of pass 1 (:1260, :1274): a window that is no survivor failed the bit score or, else, the
 // e-value -- unless it is an empty window (score 0 against a cut-off of 0: nothing to trace)
 __global__ __launch_bounds__(kRecBlock) void rec_stats_kernel(RecParams p)
 {
-    uint64_t const w  = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x;
-    uint32_t       fb = 0, fe = 0;
-    if (w < p.n_win && p.list_at[w] == 0xffffffffu)
-    {
-        int32_t const sc = p.score[w];
-        if (sc < p.min_score[w])
+    __shared__ uint32_t part[2][kRecBlock / 64];
+    uint32_t            fb = 0, fe = 0;
+    for (uint64_t w = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x; w < p.n_win; w += (uint64_t)gridDim.x * kRecBlock)
+        if (p.list_at[w] == 0xffffffffu)
         {
-            if (sc < p.bit_cut)
-                fb = 1;
-            else
-                fe = 1;
+            int32_t const sc = p.score[w];
+            if (sc < p.min_score[w])
+            {
+                if (sc < p.bit_cut)
+                    ++fb;
+                else
+                    ++fe;
+            }
         }
-    }
     fb = wave_sum(fb);
     fe = wave_sum(fe);
     if ((threadIdx.x & 63) == 0)
     {
-        if (fb)
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecFailedBit), (unsigned long long)fb);
-        if (fe)
-            atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecFailedEv), (unsigned long long)fe);
+        part[0][threadIdx.x >> 6] = fb;
+        part[1][threadIdx.x >> 6] = fe;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) // (one pair of atomics per workgroup, as in rec_keys_kernel)
+    {
+        uint32_t tb = 0, te = 0;
+        for (int k = 0; k < kRecBlock / 64; ++k)
+        {
+            tb += part[0][k];
+            te += part[1][k];
+        }
+        if (tb)
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecFailedBit), (unsigned long long)tb);
+        if (te)
+            atomicAdd(reinterpret_cast<unsigned long long *>(p.counters + kRecFailedEv), (unsigned long long)te);
     }
 }
 
@@ -353,8 +379,8 @@ hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tm
     if (p.n_win)
     {
         if (p.n_entries)
-            hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)((p.n_entries + kRecBlock - 1) / kRecBlock)), dim3(kRecBlock), 0, stream, p, *pair, *s0);
-        hipLaunchKernelGGL(rec_stats_kernel, dim3((unsigned)((p.n_win + kRecBlock - 1) / kRecBlock)), dim3(kRecBlock), 0, stream, p);
+            hipLaunchKernelGGL(rec_keys_kernel, dim3((unsigned)std::min<uint64_t>((p.n_entries + kRecBlock - 1) / kRecBlock, 1024)), dim3(kRecBlock), 0, stream, p, *pair, *s0);
+        hipLaunchKernelGGL(rec_stats_kernel, dim3((unsigned)std::min<uint64_t>((p.n_win + kRecBlock - 1) / kRecBlock, 1024)), dim3(kRecBlock), 0, stream, p);
     }
     if (p.n_entries == 0)
         return hipGetLastError();
