@@ -42,6 +42,7 @@ struct DevAids
     int      bt_tile_at;        // LX_BT_TILE_AT         lanes waiting for a tile that start the tile phase (0 = default)  0
     int      bt_refill_at;      // LX_BT_REFILL_AT       retired lanes that trigger a queue refill (0 = default)           0
     uint64_t l2_ranges;         // LX_L2_RANGES          Level-2 driver: ranges of the window list whose records are made chunk by chunk (0 = by size: 2 from 300 000 windows, one more per two million, at most 4)  0
+    uint64_t l2_first_pct;      // LX_L2_FIRST_PCT       Level 2, two ranges: the first range's share of the windows in percent                          0 = 66
     bool     host_timing;       // LX_HOST_TIMING        print where the host-buffer entry points spend their time         off
 };
 

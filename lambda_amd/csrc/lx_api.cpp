@@ -61,6 +61,7 @@ lx::DevAids const & lx::dev_aids()
         a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);
         a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
         a.l2_ranges         = (uint64_t)std::min<long long>(std::max(0ll, num("LX_L2_RANGES", 0)), 64);
+        a.l2_first_pct      = (uint64_t)std::max(0ll, num("LX_L2_FIRST_PCT", 0));
         a.host_timing       = set("LX_HOST_TIMING");
         return a;
     }();
