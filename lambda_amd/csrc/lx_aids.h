@@ -43,6 +43,7 @@ struct DevAids
     int      bt_refill_at;      // LX_BT_REFILL_AT       retired lanes that trigger a queue refill (0 = default)           0
     uint64_t l2_ranges;         // LX_L2_RANGES          Level-2 driver: ranges of the window list whose records are made chunk by chunk (0 = by size: 2 from 300 000 windows, one more per two million, at most 4)  0
     uint64_t l2_first_pct;      // LX_L2_FIRST_PCT       Level 2, two ranges: the first range's share of the windows in percent                          0 = 66
+    bool     l2_no_rank;        // LX_L2_NO_RANK         Level 2: a range's survivors sorted by (query id, slice lengths, window) words instead of their windows' ranks  off
     bool     host_timing;       // LX_HOST_TIMING        print where the host-buffer entry points spend their time         off
 };
 

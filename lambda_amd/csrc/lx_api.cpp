@@ -62,6 +62,7 @@ lx::DevAids const & lx::dev_aids()
         a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
         a.l2_ranges         = (uint64_t)std::min<long long>(std::max(0ll, num("LX_L2_RANGES", 0)), 64);
         a.l2_first_pct      = (uint64_t)std::max(0ll, num("LX_L2_FIRST_PCT", 0));
+        a.l2_no_rank        = set("LX_L2_NO_RANK");
         a.host_timing       = set("LX_HOST_TIMING");
         return a;
     }();
@@ -1269,7 +1270,7 @@ void lx_destroy(lx_handle * h)
         for (DevBuf * b : {&l2.d_qres, &l2.d_qoff, &l2.d_qlen, &l2.d_qband, &l2.d_qevlen, &l2.d_soff, &l2.d_slen, &l2.d_pair[0], &l2.d_pair[1], &l2.d_s0[0],
                            &l2.d_s0[1], &l2.d_hist, &l2.d_head, &l2.d_tail, &l2.d_tot, &l2.d_win, &l2.d_cut, &l2.d_cnt, &l2.d_up, &l2.d_plan, &l2.d_wf, &l2.d_qevidx,
                            &l2.d_surv_hsp, &l2.d_surv_src, &l2.d_surv_codes, &l2.d_listat, &l2.d_rec, &l2.d_reccodes, &l2.d_reccnt, &l2.d_tilekeep, &l2.d_tileops,
-                           &l2.d_pre, &l2.d_exp})
+                           &l2.d_pre, &l2.d_exp, &l2.d_rank})
             if (b->ptr)
                 (void)hipFree(b->ptr);
         for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes, &l2.p_rows})

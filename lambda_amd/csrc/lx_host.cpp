@@ -1785,13 +1785,19 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             if ((rc2 = ensure_pinned(h, ln.p_wft, nw * sizeof(lx::WfSlots))) || (rc2 = ensure(h, ln.d_wft, nw * sizeof(lx::WfSlots))))
                 return rc2;
             lx::WfSlots * const tab = static_cast<lx::WfSlots *>(ln.p_wft.ptr);
-            uint64_t            off = 0;
+            uint64_t            off = 0, slot_dw = 0;
+            uint32_t            last_steps = 0; // (a sorted plan repeats its step counts: the layout's slot size is asked for once per run of them)
             for (uint64_t w = 0; w < nw; ++w)
             {
                 uint32_t const steps  = (uint32_t)(((uint64_t)wf_maxs[w0 + w] + 8 - 1 + 15) & ~15ull);
                 uint32_t const panels = (uint32_t)std::max<uint64_t>(1, ((uint64_t)wf_pan[w0 + w] + pc - 1) / pc);
-                tab[w]                = lx::WfSlots{off, steps, panels};
-                off += kWave * (uint64_t)panels * (pr.wide ? lx::ckpt_slot_dwords(mq_cfg, steps) : lx::ckpt16_slot_dwords(mq_cfg, steps));
+                if (steps != last_steps)
+                {
+                    slot_dw    = pr.wide ? lx::ckpt_slot_dwords(mq_cfg, steps) : lx::ckpt16_slot_dwords(mq_cfg, steps);
+                    last_steps = steps;
+                }
+                tab[w] = lx::WfSlots{off, steps, panels};
+                off += kWave * (uint64_t)panels * slot_dw;
             }
             LX_HIP(h, hipMemcpyAsync(ln.d_wft.ptr, tab, nw * sizeof(lx::WfSlots), hipMemcpyHostToDevice, h->stream3));
             LX_HIP(h, hipEventRecord(ln.ev_up, h->stream3));

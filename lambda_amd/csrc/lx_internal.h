@@ -228,7 +228,8 @@ struct lx_handle
         // records on the device (lx_records.hip): the call's survivors as the pipeline's chunks left them (alignment, window, where the
         // codes begin), the key / scan / record buffers, the host-made tables of the e-value
         uint32_t              max_qlen = 0;
-        DevBuf                d_qevidx, d_surv_hsp, d_surv_src, d_surv_codes, d_listat, d_rec, d_reccodes, d_reccnt, d_tilekeep, d_tileops, d_pre, d_exp;
+        DevBuf                d_qevidx, d_surv_hsp, d_surv_src, d_surv_codes, d_listat, d_rec, d_reccodes, d_reccnt, d_tilekeep, d_tileops, d_pre, d_exp, d_rank;
+        uint32_t              rank_too_long = 0; // (lx_records.hip: rec_launch_rank's flag, downloaded with the plan)
         Pinned                p_reccnt, p_reccodes, p_rows; // p_rows: a range's finished rows on their way into the result
         std::vector<uint64_t> rec_codes;              // where the records' run-length codes begin (host copy)
         uint64_t              surv_total = 0, surv_cap = 0;

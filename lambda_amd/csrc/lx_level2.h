@@ -136,6 +136,10 @@ struct RecParams
     double const *   exp_tab;    // exp(-lambda s), s < exp_n, the host's doubles
     uint32_t         exp_n;
     uint64_t         ops_base;   // first column of this part in the result's ops
+    // the windows' places in the records' order (rec_launch_rank), from this range's first window on: the survivors are then sorted by
+    // ONE three-digit word instead of (true query id, query slice length | subject slice length, window).  NULL: by those words.
+    uint32_t const * rank;
+    uint32_t         rank_pad;   // what an entry that is no survivor sorts by: one past the largest rank
     // work and results
     uint32_t *       list_at;    // [n_win]
     uint64_t *       counters;   // [kRecCounters]
@@ -146,6 +150,12 @@ struct RecParams
 hipError_t rec_launch_append(Hsp const * hsp, uint32_t const * src, uint64_t const * count_ptr, uint64_t cap, uint64_t code_base, Hsp * out_hsp, uint32_t * out_src,
                              uint64_t * out_codes, hipStream_t stream);
 hipError_t rec_launch_add_ops_base(BlastMatchDev * rec, uint64_t n, uint64_t base, hipStream_t stream);
+constexpr uint32_t kRecRankGroup = 256; // a query's windows on either side of one of them that rec_launch_rank looks at
+// rank[w] = the place of window w of win[0 .. n) in the records' order (true query id = q / q_frames, query slice length, subject slice
+// length, list position) -- for a list whose true query ids never descend: a window's place among the windows of its query, counted,
+// + where the query's windows begin.  *too_long (zeroed by the caller) becomes non-zero where a query has more windows than the
+// kernel looks at: the ranks are then not to be used.
+hipError_t rec_launch_rank(L2Window const * win, uint64_t n, uint32_t q_frames, uint32_t const * q_len, uint32_t * rank, uint32_t * too_long, hipStream_t stream);
 hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t pair_bits, uint64_t s0_bits,
                       uint32_t * ghist, uint32_t * tile_keep, uint64_t * tile_ops, hipStream_t stream);
 

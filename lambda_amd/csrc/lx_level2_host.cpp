@@ -289,6 +289,8 @@ struct RecordsJob
     lx::RecParams            base{};
     uint64_t                 pair_bits = 0, s0_bits = 0;
     bool                     want_ops  = true;
+    std::vector<double>      pre_host; // the e-value factors per distinct length, until their upload is through
+    bool                     use_rank = false; // the survivors are sorted by their windows' ranks (l2.d_rank: rec_launch_rank over the part)
 
     RecordsJob(lx_handle * h_, lx_search_params const * p_, lx_iterate_result * r_, HostMarks & hm_, uint64_t part_lo_, uint64_t n_part_)
         : h(h_), params(p_), res(r_), hm(hm_), part_lo(part_lo_), n_part(n_part_)
@@ -308,7 +310,8 @@ struct RecordsJob
         ranges   = std::move(rs);
         want_ops = !(params->flags & LX_ITERATE_NO_OPS);
         int const qFrames = std::max(1, params->qry_num_frames), sFrames = std::max(1, params->sbj_num_frames);
-        std::vector<double> pre(std::max<size_t>(l2.evlens.size(), 1), 0.0);
+        std::vector<double> & pre = pre_host; // (a member: the upload below is asynchronous, the job outlives it)
+        pre.assign(std::max<size_t>(l2.evlens.size(), 1), 0.0);
         for (size_t i = 0; i < l2.evlens.size(); ++i)
         {
             uint64_t const ql  = (uint64_t)l2.evlens[i] / (params->query_translated ? 3 : 1);
@@ -366,7 +369,6 @@ struct RecordsJob
             return rc;
         }
         LX_HIP(h, hipMemsetAsync(l2.d_reccnt.ptr, 0, nr * lx::kRecCounters * sizeof(uint64_t), st));
-        LX_HIP(h, hipStreamSynchronize(st)); // (`pre` is a local)
         base.q_len      = static_cast<uint32_t const *>(l2.d_qlen.ptr);
         base.q_evidx    = static_cast<uint32_t const *>(l2.d_qevidx.ptr);
         base.q_frames   = (uint32_t)qFrames;
@@ -413,11 +415,14 @@ struct RecordsJob
         p.counters  = static_cast<uint64_t *>(l2.d_reccnt.ptr) + r * lx::kRecCounters;
         p.rec       = static_cast<lx::BlastMatchDev *>(l2.d_rec.ptr) + rg.lo;
         p.rec_codes = static_cast<uint64_t *>(l2.d_reccodes.ptr) + 3 * rg.lo;
+        p.rank      = use_rank ? static_cast<uint32_t const *>(l2.d_rank.ptr) + rg.lo : nullptr;
+        p.rank_pad  = (uint32_t)n_part;
         LX_HIP(h, hipMemsetAsync(p.counters, 0, lx::kRecCounters * sizeof(uint64_t), st)); // (a range whose chunk runs again starts over)
         LX_HIP(h, hipMemsetAsync(l2.d_listat.ptr, 0xff, p.n_win * sizeof(uint32_t), st));
         uint64_t * pair = static_cast<uint64_t *>(l2.d_pair[0].ptr), * pair_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
         uint64_t * s0 = static_cast<uint64_t *>(l2.d_s0[0].ptr), * s0_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
-        LX_HIP(h, lx::rec_launch(p, &pair, &pair_tmp, &s0, &s0_tmp, pair_bits, s0_bits, static_cast<uint32_t *>(l2.d_hist.ptr), static_cast<uint32_t *>(l2.d_tilekeep.ptr),
+        LX_HIP(h, lx::rec_launch(p, &pair, &pair_tmp, &s0, &s0_tmp, use_rank ? 0ull : pair_bits, use_rank ? bits_below(n_part + 1) : s0_bits, static_cast<uint32_t *>(l2.d_hist.ptr),
+                                 static_cast<uint32_t *>(l2.d_tilekeep.ptr),
                                  static_cast<uint64_t *>(l2.d_tileops.ptr), st));
         LX_HIP(h, hipMemcpyAsync(static_cast<uint64_t *>(l2.p_reccnt.ptr) + r * lx::kRecCounters, p.counters, lx::kRecCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         return LX_OK;
@@ -670,6 +675,18 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                                              lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
                                              static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo));
             }
+            // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by it)
+            bool const try_rank = records_on_device && n < 0xfffffff0ull && !lx::dev_aids().l2_no_rank;
+            if (try_rank)
+            {
+                if ((rc = ensure(h, l2.d_rank, (n + 1) * sizeof(uint32_t) + 16)))
+                    return rc;
+                uint32_t * const d_rank = static_cast<uint32_t *>(l2.d_rank.ptr);
+                LX_HIP(h, hipMemsetAsync(d_rank + n, 0, sizeof(uint32_t), st));
+                LX_HIP(h, lx::rec_launch_rank(static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo, n, (uint32_t)std::max(1, params->qry_num_frames),
+                                              static_cast<uint32_t const *>(l2.d_qlen.ptr), d_rank, d_rank + n, st));
+                LX_HIP(h, hipMemcpyAsync(&l2.rank_too_long, d_rank + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            }
             l2.wf_pan.resize(nwf);
             l2.wf_maxs.resize(nwf);
             LX_HIP(h, hipMemcpyAsync(l2.wf_pan.data(), d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -697,6 +714,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     max_wlen = std::max<uint64_t>(max_wlen, l2.wf_maxs[w]);
                 if ((rc = job.prepare(cutOffFor, ranges, max_entries, max_wlen)))
                     return rc;
+                job.use_rank = try_rank && l2.rank_too_long == 0; // (a query with more windows than the rank kernel counts: the full sort words)
                 cr.cut_wf   = l2.cut_wf.data();
                 cr.n_ranges = ranges.size();
                 cr.enqueue  = [&job](uint64_t r, void const * d_hsp, void const * d_src, void const * d_count, uint64_t cap) { return job.enqueue(r, d_hsp, d_src, d_count, nullptr, cap); };

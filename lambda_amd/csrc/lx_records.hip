@@ -68,6 +68,35 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// (0) once per call: every window's place in the records' order.  The window list is sorted by query already (Match's order), so the
+// reference's order -- true query id, then the lengths of the two slices, then the list position (search_algo.hpp:1229-1235 and :1299,
+// two stable sorts) -- moves a window only among the windows of its own query: a handful.  Counting those that come before it gives
+// its place; the survivors of a range are then sorted by that one word (three radix passes instead of eight or nine per range).
+__global__ __launch_bounds__(kRecBlock) void rec_rank_kernel(L2Window const * win, uint64_t n, uint32_t q_frames, uint32_t const * q_len, uint32_t * rank, uint32_t * too_long)
+{
+    uint64_t const w = (uint64_t)blockIdx.x * kRecBlock + threadIdx.x;
+    if (w >= n)
+        return;
+    L2Window const W   = win[w];
+    uint32_t const qid = W.q / q_frames;
+    uint64_t const ql  = q_len[W.q], sl = W.end > W.beg ? W.end - W.beg : 0ull;
+    uint64_t       lo  = w, hi = w + 1;
+    while (lo > 0 && w - lo < kRecRankGroup && win[lo - 1].q / q_frames == qid)
+        --lo;
+    while (hi < n && hi - w < kRecRankGroup && win[hi].q / q_frames == qid)
+        ++hi;
+    if ((w - lo >= kRecRankGroup && lo > 0 && win[lo - 1].q / q_frames == qid) || (hi - w >= kRecRankGroup && hi < n && win[hi].q / q_frames == qid))
+        atomicOr(too_long, 1u); // (a query with more windows than one thread counts: the caller sorts by the full words)
+    uint32_t before = 0;
+    for (uint64_t v = lo; v < hi; ++v)
+    {
+        L2Window const V  = win[v];
+        uint64_t const vq = q_len[V.q], vs = V.end > V.beg ? V.end - V.beg : 0ull;
+        before += (vq < ql || (vq == ql && (vs < sl || (vs == sl && v < w)))) ? 1u : 0u;
+    }
+    rank[w] = (uint32_t)lo + before;
+}
+
 // (1) every stored survivor: where it stands (list_at: window -> entry) and its sort words.  Entries that are padding of a chunk's
 // survivor list sort behind every real one (query id = the number of queries).
 __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64_t * pair, uint64_t * s0)
@@ -82,6 +111,7 @@ __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64
         uint32_t const ws     = filled ? p.src[e] : 0xffffffffu;
         uint32_t const w      = ws - p.src_base; // (position among THIS call's windows: a chunk's range of the list)
         uint64_t       kp = ((uint64_t)p.n_qid_end << 32), ks = e;
+        bool           valid_e = false;
         if (ws != 0xffffffffu)
         {
             if (ws < p.src_base || w >= p.n_win)
@@ -90,12 +120,26 @@ __global__ __launch_bounds__(kRecBlock) void rec_keys_kernel(RecParams p, uint64
                 atomicOr(reinterpret_cast<unsigned long long *>(p.counters + kRecErr), 1ull); // an extension that could not be traced
             else
             {
-                L2Window const W = p.win[w];
                 ++mine;
-                p.list_at[w]     = (uint32_t)e;
-                kp               = ((uint64_t)(W.q / p.q_frames) << 32) | p.q_len[W.q];
-                ks               = ((W.end > W.beg ? W.end - W.beg : 0ull) << 32) | w;
+                p.list_at[w] = (uint32_t)e;
+                if (p.rank)
+                {
+                    kp = w; // (travels with the key: the kernels behind the sort read the window from it)
+                    ks = p.rank[w];
+                }
+                else
+                {
+                    L2Window const W = p.win[w];
+                    kp               = ((uint64_t)(W.q / p.q_frames) << 32) | p.q_len[W.q];
+                    ks               = ((W.end > W.beg ? W.end - W.beg : 0ull) << 32) | w;
+                }
+                valid_e = true;
             }
+        }
+        if (p.rank && !valid_e)
+        {
+            kp = 0;
+            ks = p.rank_pad;
         }
         pair[e] = kp;
         s0[e]   = ks;
@@ -372,6 +416,14 @@ hipError_t rec_launch_append(Hsp const * hsp, uint32_t const * src, uint64_t con
     return hipGetLastError();
 }
 
+hipError_t rec_launch_rank(L2Window const * win, uint64_t n, uint32_t q_frames, uint32_t const * q_len, uint32_t * rank, uint32_t * too_long, hipStream_t stream)
+{
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(rec_rank_kernel, dim3((unsigned)((n + kRecBlock - 1) / kRecBlock)), dim3(kRecBlock), 0, stream, win, n, q_frames, q_len, rank, too_long);
+    return hipGetLastError();
+}
+
 // p.counters must be zeroed, p.list_at filled with 0xff by the caller (stream order).  pair / s0: two buffers of n_entries words each.
 hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0, uint64_t ** s0_tmp, uint64_t pair_bits, uint64_t s0_bits,
                       uint32_t * ghist, uint32_t * tile_keep, uint64_t * tile_ops, hipStream_t stream)
@@ -390,9 +442,10 @@ hipError_t rec_launch(RecParams const & p, uint64_t ** pair, uint64_t ** pair_tm
     // (the number of real survivors stands in device memory: the grids cover every entry, the kernels stop at the count)
     uint64_t const * const n_ptr = p.counters + kRecSurvivors;
     unsigned const         tiles = (unsigned)((p.n_entries + kRecBlock - 1) / kRecBlock);
-    hipLaunchKernelGGL(rec_tile_kernel, dim3(tiles), dim3(kRecBlock), 0, stream, p, *s0, n_ptr, tile_keep, tile_ops);
+    uint64_t const * const order = p.rank ? *pair : *s0; // (the word whose low half names the window)
+    hipLaunchKernelGGL(rec_tile_kernel, dim3(tiles), dim3(kRecBlock), 0, stream, p, order, n_ptr, tile_keep, tile_ops);
     hipLaunchKernelGGL(rec_tops_kernel, dim3(1), dim3(kRecBlock), 0, stream, p, n_ptr, tile_keep, tile_ops);
-    hipLaunchKernelGGL(rec_write_kernel, dim3(tiles), dim3(kRecBlock), 0, stream, p, *s0, n_ptr, tile_keep, tile_ops);
+    hipLaunchKernelGGL(rec_write_kernel, dim3(tiles), dim3(kRecBlock), 0, stream, p, order, n_ptr, tile_keep, tile_ops);
     return hipGetLastError();
 }
 

@@ -366,6 +366,39 @@ def test_records_made_on_the_device_equal_the_host_threads(handle, scheme, frame
         assert hs.failed_identity > 0 and hs.failed_bitscore > 0 and hs.failed_evalue > 0
 
 
+@pytest.mark.parametrize("nq,hits,least,most", [(20, 1500, 2 * 256 + 1, 10 ** 9), (120, 130, 60, 255)])
+def test_records_of_queries_with_hundreds_of_windows_each(handle, nq, hits, least, most):
+    """The records kernels order a range's survivors by their windows' ranks -- a window's place among the windows of its query, counted
+    by one thread over at most 256 neighbours on either side (lx_records.hip: rec_rank_kernel).  Queries with more windows than that
+    (a repeat family) send the call back to the full sort words: the same bytes as the host threads' either way -- with every query
+    beyond that, and with a hundred or two windows per query, all of them counted."""
+    sc_p = SCHEMES["blosum62"]
+    handle.set_scoring(sc_p, 0)
+    rng = np.random.default_rng(4711)
+    q, qoff, qlen, s, soff, slen, m = _seed_list(rng, nq, 900, hits, lq_range=(50, 120))
+    params = capi.SearchParams(10.0, -1, 0, int(slen.sum()) * 50, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, capi.karlin_params(62))
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qlen, 1)
+    d_m = _to_device(m[rng.permutation(len(m))])
+    try:
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 1)
+        hb, ho, hs = handle.iterate_matches_dev(d_m, len(m), params)
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 0)
+        db, do, ds = handle.iterate_matches_dev(d_m, len(m), params)
+    finally:
+        handle.set_option(capi.LX_OPT_ITERATE_RECORDS, 0)
+    windows = handle.widen_and_preprocess_dev(d_m, len(m))
+    per_query = np.bincount(windows["qryId"].astype(np.int64))
+    # (first case: more windows of every query than the rank kernel looks at on both sides; second: a hundred or two, all counted)
+    assert least <= per_query.min() and per_query.max() <= most, (per_query.min(), per_query.max())
+    assert len(hb) > 3000
+    assert db.tobytes() == hb.tobytes()
+    assert do == ho
+    for f in ("hits_duplicate", "failed_bitscore", "failed_evalue", "failed_identity", "num_ext_score", "num_ext_ali"):
+        assert getattr(ds, f) == getattr(hs, f), f
+
+
 def test_a_rejected_query_set_leaves_nothing_resident(handle):
     """lx_set_queries / lx_set_subject_seqs validate before they commit: after a rejected set the device entry points report LX_ESTATE
     instead of reading the previous set's device arrays with the new set's sizes."""
