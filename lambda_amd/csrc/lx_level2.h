@@ -80,7 +80,8 @@ hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params 
 // cost at 19 / 13 / 11 columns and cells, then part 1's; cnt = {windows, first window of part 1} in device memory), and the plan
 hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream);
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
-                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base = 0);
+                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base = 0, uint64_t key_bits = 0x0fffffffull);
+uint64_t   l2_plan_key_bits(uint64_t max_qlen, uint64_t max_wlen);
 uint64_t   l2_sort_tiles(uint64_t n);
 uint64_t   l2_scan_tiles(uint64_t n);
 

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(256) void l2_plan_cost_kernel(Extension const * ext
 {
     uint64_t const nw = cnt[0], n_even = cnt[1];
     uint64_t       v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t       longest[2] = {0, 0}; // the part's longest window: out[8], out[9] (the plan's sort skips the key digits no window sets)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (uint64_t)gridDim.x * blockDim.x)
     {
         Extension const x    = ext[i];
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(256) void l2_plan_cost_kernel(Extension const * ext
             v[part + k] += (uint64_t)(P - 1) * (15u * (uint32_t)cand[k] + 48u) + 15u * (uint32_t)narrow_strip_cols(cand[k], code) + 48u;
         }
         v[part + 3] += (uint64_t)x.q_len * x.s_len;
+        longest[part / 4] = max(longest[part / 4], x.s_len);
     }
     // one atomic per workgroup and sum (same-address atomics from every wavefront of the grid were most of this kernel's time)
     __shared__ unsigned long long part[4][8];
@@ -564,6 +566,16 @@ __global__ __launch_bounds__(256) void l2_plan_cost_kernel(Extension const * ext
         unsigned long long const x = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
         if (x)
             atomicAdd(out + threadIdx.x, x);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+    {
+        uint32_t m = longest[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            m = max(m, (uint32_t)__shfl_xor((int)m, off));
+        if ((threadIdx.x & 63) == 0 && m)
+            atomicMax(out + 8 + k, (unsigned long long)m);
     }
 }
 
@@ -609,7 +621,7 @@ __global__ __launch_bounds__(256) void l2_plan_slots_kernel(Extension const * ex
 
 hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream)
 {
-    hipError_t const e = hipMemsetAsync(out, 0, 8 * sizeof(unsigned long long), stream);
+    hipError_t const e = hipMemsetAsync(out, 0, 10 * sizeof(unsigned long long), stream);
     if (e != hipSuccess || n_max == 0)
         return e;
     unsigned const blocks = (unsigned)std::min<uint64_t>((n_max + 255) / 256, 256); // (eight same-address atomics per wavefront: few wavefronts)
@@ -619,17 +631,26 @@ hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint
 
 // the plan of ext[0 .. n): key / idx are sort words (two buffers each, as l2_launch_sort takes them); plan: [ceil(n / 16) * 16]
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
-                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base)
+                          uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base, uint64_t key_bits)
 {
     if (n == 0)
         return hipSuccess;
     hipLaunchKernelGGL(l2_plan_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ext, n, C, no_narrow, *key, *idx);
-    hipError_t const e = l2_launch_sort(key, key_tmp, idx, idx_tmp, n, 0x0fffffffull, 0ull, ghist, stream);
+    // (key_bits: the digits in which two keys of the list can differ -- l2_plan_key_bits; a digit all keys share is not sorted by)
+    hipError_t const e = l2_launch_sort(key, key_tmp, idx, idx_tmp, n, key_bits & 0x0fffffffull, 0ull, ghist, stream);
     if (e != hipSuccess)
         return e;
     uint64_t const slots = (n + 15) / 16 * 16;
     hipLaunchKernelGGL(l2_plan_slots_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, ext, *idx, n, C, no_narrow, index_base, plan, wf_pan, wf_maxs);
     return hipGetLastError();
+}
+
+// the digits of the plan's keys -- (0xfff - columns per lane) << 16 | (0xffff - min(window length, 0xffff)) -- that differ somewhere
+// in a list of queries up to max_qlen residues and windows up to max_wlen: the complements keep the high digit of either field
+// at all ones while the value stays below 256
+uint64_t l2_plan_key_bits(uint64_t max_qlen, uint64_t max_wlen)
+{
+    return 0xffull | (max_wlen >= 256 ? 0xff00ull : 0ull) | 0xff0000ull | (max_qlen / 8 + 32 >= 256 ? 0x0f000000ull : 0ull);
 }
 
 uint64_t l2_sort_tiles(uint64_t n)

@@ -223,7 +223,7 @@ static int level2_windows(lx_handle * h, uint64_t n_matches, bool bisulfite, std
     // the same synchronisation
     LX_HIP(h, lx::l2_launch_plan_cost(p.ext_out, p.count_out, n_matches, lx::dev_aids().mq_no_narrow ? 1 : 0,
                                       reinterpret_cast<unsigned long long *>(p.count_out + 3), st));
-    LX_HIP(h, hipMemcpyAsync(l2.p_cnt.ptr, l2.d_cnt.ptr, 11 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    LX_HIP(h, hipMemcpyAsync(l2.p_cnt.ptr, l2.d_cnt.ptr, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     LX_HIP(h, hipStreamSynchronize(st)); // (also: `cut_table` is the caller's)
     uint64_t const * const cnt = static_cast<uint64_t const *>(l2.p_cnt.ptr);
     uint64_t const         flag = cnt[2];
@@ -673,7 +673,8 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 uint64_t const w0 = l2.cut_wf[r];
                 LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all) + ranges[r].lo, ranges[r].hi - ranges[r].lo, lx::trace_cfg_panel(cfg) / 8,
                                              lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
-                                             static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo));
+                                             static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo,
+                                             lx::l2_plan_key_bits(l2.max_qlen, cost[8 + pi])));
             }
             // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by it)
             bool const try_rank = records_on_device && n < 0xfffffff0ull && !lx::dev_aids().l2_no_rank;
