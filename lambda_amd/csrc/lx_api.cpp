@@ -1273,7 +1273,7 @@ void lx_destroy(lx_handle * h)
                            &l2.d_pre, &l2.d_exp, &l2.d_rank})
             if (b->ptr)
                 (void)hipFree(b->ptr);
-        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes, &l2.p_rows})
+        for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes, &l2.p_rows, &l2.p_plan})
             if (b->ptr)
                 (void)hipHostFree(b->ptr);
         if (l2.ev_win)

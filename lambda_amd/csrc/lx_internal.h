@@ -231,6 +231,7 @@ struct lx_handle
         DevBuf                d_qevidx, d_surv_hsp, d_surv_src, d_surv_codes, d_listat, d_rec, d_reccodes, d_reccnt, d_tilekeep, d_tileops, d_pre, d_exp, d_rank;
         uint32_t              rank_too_long = 0; // (lx_records.hip: rec_launch_rank's flag, downloaded with the plan)
         Pinned                p_reccnt, p_reccodes, p_rows; // p_rows: a range's finished rows on their way into the result
+        Pinned                p_plan; // what the host reads of a device plan: [rank flag + probe windows][columns per lane][longest window] per wavefront
         std::vector<uint64_t> rec_codes;              // where the records' run-length codes begin (host copy)
         uint64_t              surv_total = 0, surv_cap = 0;
         bool                  surv_on_device = false; // the last pipeline call kept its survivors on the device

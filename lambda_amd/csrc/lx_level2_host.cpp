@@ -271,6 +271,8 @@ static_assert(sizeof(lx::BlastMatchDev) == sizeof(lx_blast_match) && offsetof(lx
 // A part is served as ONE range behind its last chunk (the survivors of all chunks in lx_handle::Level2::d_surv_*), or -- where the
 // plan's chunks are ranges of the query-sorted list (ResidentInput::ChunkRecords) -- range by range: a range's kernels are queued
 // behind its chunk's own, its rows and columns come down while the next chunk computes.
+constexpr size_t kPlanHead = 64 + 512 * sizeof(lx::L2Window); // l2.p_plan: [flag][probe windows] in front of the per-wavefront arrays
+
 struct RecordsJob
 {
     struct Range
@@ -641,7 +643,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     uint64_t const target = R == 2 ? n / 100 * pct : n * k / R, from = target > 256 ? target - 256 : 0, upto = std::min(n, target + 256);
                     if (from <= lo || upto - from < 2)
                         continue;
-                    lx::L2Window probe[512];
+                    // (into pinned memory: a copy into ordinary memory is staged by the runtime, 40 us of an idle GPU each)
+                    if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead)))
+                        return rc;
+                    lx::L2Window * const probe = reinterpret_cast<lx::L2Window *>(static_cast<uint8_t *>(l2.p_plan.ptr) + 64);
                     LX_HIP(h, hipMemcpyAsync(probe, static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo + from, (upto - from) * sizeof(lx::L2Window), hipMemcpyDeviceToHost, st));
                     LX_HIP(h, hipStreamSynchronize(st));
                     uint64_t cut = 0;
@@ -686,19 +691,25 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 LX_HIP(h, hipMemsetAsync(d_rank + n, 0, sizeof(uint32_t), st));
                 LX_HIP(h, lx::rec_launch_rank(static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo, n, (uint32_t)std::max(1, params->qry_num_frames),
                                               static_cast<uint32_t const *>(l2.d_qlen.ptr), d_rank, d_rank + n, st));
-                LX_HIP(h, hipMemcpyAsync(&l2.rank_too_long, d_rank + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
-            l2.wf_pan.resize(nwf);
-            l2.wf_maxs.resize(nwf);
-            LX_HIP(h, hipMemcpyAsync(l2.wf_pan.data(), d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            LX_HIP(h, hipMemcpyAsync(l2.wf_maxs.data(), d_maxs, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            // what the host reads of the plan, in pinned memory: the rank kernel's flag, columns per lane and longest window per wavefront
+            // (one copy: they stand side by side on the device)
+            if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead + 2 * nwf * sizeof(uint32_t))))
+                return rc;
+            uint32_t * const h_flag = static_cast<uint32_t *>(l2.p_plan.ptr);
+            uint32_t * const h_pan  = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanHead), * const h_maxs = h_pan + nwf;
+            *h_flag = 0;
+            if (try_rank)
+                LX_HIP(h, hipMemcpyAsync(h_flag, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            LX_HIP(h, hipMemcpyAsync(h_pan, d_pan, 2 * nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             if ((windows_to_host || !records_on_device) && (rc = queue_windows()))
                 return rc;
             LX_HIP(h, hipStreamSynchronize(st));
             ri.d_plan  = static_cast<uint32_t const *>(l2.d_plan.ptr);
             ri.nwf     = nwf;
-            ri.wf_pan  = l2.wf_pan.data();
-            ri.wf_maxs = l2.wf_maxs.data();
+            ri.wf_pan  = h_pan;
+            ri.wf_maxs = h_maxs;
+            l2.rank_too_long = *h_flag;
             ri.mq_cfg  = cfg;
             ri.cells   = cost[4 * pi + 3];
             ri.keep_on_device = records_on_device;
@@ -712,7 +723,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     max_entries = std::max(max_entries, (l2.cut_wf[r + 1] - l2.cut_wf[r]) * 16 + 16);
                 uint64_t max_wlen = 1; // (the plan's per-wavefront maxima: every window of the part stands in one of them)
                 for (uint64_t w = 0; w < nwf; ++w)
-                    max_wlen = std::max<uint64_t>(max_wlen, l2.wf_maxs[w]);
+                    max_wlen = std::max<uint64_t>(max_wlen, h_maxs[w]);
                 if ((rc = job.prepare(cutOffFor, ranges, max_entries, max_wlen)))
                     return rc;
                 job.use_rank = try_rank && l2.rank_too_long == 0; // (a query with more windows than the rank kernel counts: the full sort words)
@@ -1027,7 +1038,8 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         (rc = ensure(h, l2.d_reccnt, lx::kRecCounters * sizeof(uint64_t))) || (rc = ensure(h, l2.d_rec, entries * sizeof(lx_blast_match) + 16)) ||
         (rc = ensure(h, l2.d_reccodes, 3 * entries * sizeof(uint64_t) + 16)) || (rc = ensure(h, l2.d_tilekeep, ((entries + 255) / 256 + 1) * sizeof(uint32_t))) ||
         (rc = ensure(h, l2.d_tileops, ((entries + 255) / 256 + 1) * sizeof(uint64_t))) || (rc = ensure_pinned(h, l2.p_reccnt, 8 * lx::kRecCounters * sizeof(uint64_t))) ||
-        (rc = ensure_pinned(h, l2.p_rows, (n_hsps * 2 / 3) * sizeof(lx_blast_match) + 16, hipHostMallocNonCoherent)) || (rc = ensure(h, l2.d_pre, std::max<size_t>(l2.evlens.size(), 1) * sizeof(double) + 16)) || (rc = ensure(h, l2.d_exp, (1u << 13) * sizeof(double))))
+        (rc = ensure_pinned(h, l2.p_rows, (n_hsps * 3 / 4) * sizeof(lx_blast_match) + 16, hipHostMallocNonCoherent)) ||
+        (rc = ensure(h, l2.d_rank, (n_windows + 1) * sizeof(uint32_t) + 16)) || (rc = ensure_pinned(h, l2.p_plan, kPlanHead + 2 * (nwf + 8) * sizeof(uint32_t))) || (rc = ensure(h, l2.d_pre, std::max<size_t>(l2.evlens.size(), 1) * sizeof(double) + 16)) || (rc = ensure(h, l2.d_exp, (1u << 13) * sizeof(double))))
         return rc;
     if (n_columns)
     {
