@@ -12,6 +12,8 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -444,36 +446,56 @@ inline bool lx_slice_ok(uint64_t off, uint64_t len, uint64_t bytes)
 
 
 // A few persistent host threads (started on first use): the per-extension loops of the host-buffer entry points are spread
-// over them; spawning threads per loop would cost more than the loops of a pipeline chunk.
+// over them; spawning threads per loop would cost more than the loops of a pipeline chunk.  A call runs fifteen to twenty such loops
+// within a millisecond or two, so a worker that has finished its share SPINS on the generation counter for a while before it goes to
+// sleep on the condition variable: handing a loop to sleeping threads and collecting them again costs 30-60 us each time (0.8 ms of a
+// 16-ms call), handing it to spinning ones about one.
 class HostPool
 {
     std::vector<std::thread>       workers_;
     std::mutex                     m_;
-    std::condition_variable        cv_, done_;
-    std::function<void(unsigned)>  job_;
-    unsigned                       want_ = 0, gen_ = 0, running_ = 0;
-    bool                           stop_ = false;
+    std::condition_variable        cv_;
+    std::function<void(unsigned)>  job_; // (written before gen_ moves on, read by the loop's participants until running_ is back at 0)
+    std::atomic<unsigned>          gen_{0}, want_{0}, running_{0};
+    std::atomic<int>               sleepers_{0};
+    std::atomic<bool>              stop_{false};
 
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
     void loop(unsigned id)
     {
         unsigned seen = 0;
         for (;;)
         {
-            std::function<void(unsigned)> job;
+            // a new generation: spin first (the next loop of the same call is microseconds away), then sleep
+            auto const t0 = std::chrono::steady_clock::now();
+            unsigned   g  = gen_.load();
+            for (unsigned k = 0; g == seen && !stop_.load(); ++k)
+            {
+                relax();
+                if ((k & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
+                    break;
+                g = gen_.load();
+            }
+            if (g == seen && !stop_.load())
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && id < want_); });
-                if (stop_)
-                    return;
-                seen = gen_;
-                job  = job_;
+                sleepers_.fetch_add(1); // (before the test: run() moves gen_ on and THEN looks for sleepers -- one of the two sees the other)
+                cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+                sleepers_.fetch_sub(1);
+                g = gen_.load();
             }
-            job(id);
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (--running_ == 0)
-                    done_.notify_all();
-            }
+            if (stop_.load())
+                return;
+            seen = g;
+            if (id >= want_.load())
+                continue; // (a loop for fewer threads)
+            job_(id);
+            running_.fetch_sub(1);
         }
     }
 
@@ -482,7 +504,7 @@ public:
     {
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
+            stop_.store(true);
         }
         cv_.notify_all();
         for (std::thread & t : workers_)
@@ -498,17 +520,22 @@ public:
             unsigned const id = (unsigned)workers_.size() + 1;
             workers_.emplace_back([this, id] { loop(id); });
         }
+        job_ = std::move(f);
+        want_.store(nthreads);
+        running_.store(nthreads - 1);
+        gen_.fetch_add(1);
+        if (sleepers_.load() > 0)
         {
-            std::lock_guard<std::mutex> lk(m_);
-            job_     = f;
-            want_    = nthreads;
-            running_ = nthreads - 1;
-            ++gen_;
+            { std::lock_guard<std::mutex> lk(m_); } // (a sleeper between its test and its wait holds the mutex: wait for it to be asleep)
+            cv_.notify_all();
         }
-        cv_.notify_all();
-        f(0);
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [&] { return running_ == 0; });
+        job_(0);
+        for (unsigned k = 0; running_.load() != 0; ++k)
+        {
+            relax();
+            if ((k & 4095) == 4095)
+                std::this_thread::yield();
+        }
     }
 };
 HostPool & host_pool();
