@@ -159,6 +159,12 @@ enum
                                    score, e-value): 0 (default) = kernels on the survivors where the backtrace left them, finished rows come
                                    down in one copy; 1 = the host threads, from the survivors' alignments (rounds 1-4).  The records are the
                                    same to the bit either way (tests/test_gpu_level2.py) */
+    LX_OPT_HOST_THREADS    = 14, /* parts the host loops of the host-buffer entry points and of the Level-2 driver are cut into (= the host
+                                   threads that can work on one loop).  PROCESS-WIDE, whichever handle it is set through: the library keeps
+                                   ONE set of host threads, and the loops of all handles -- one handle per host thread is the intended use,
+                                   as the reference keeps one LocalDataHolder per OpenMP thread, src/search.cpp:379-385 -- share them part
+                                   by part, side by side.  0 (default) = min(CPU affinity mask, cgroup CPU quota) / LOCAL_WORLD_SIZE (the
+                                   ranks of a node, one process per GPU, share its CPUs), at most 16; at most 64.  Never changes results */
     LX_OPT_BAND            = 9  /* band mode -- NOT the reference's configuration (src/search_algo.hpp:1081 runs BandOff, :1102
                                    says why; _bandSize only pads the window, src/search_misc.hpp:46-50) and therefore not a
                                    parity mode: 0 (default) = full rectangle; b > 0 = only cells whose diagonal i - j (row i of
@@ -175,6 +181,10 @@ enum
                                    throughput leaves the band off, which is also what the reference computes */
 };
 int lx_set_option(lx_handle * h, int option, uint64_t value);
+/* The host threads as the library sized them (no handle, no device needed): parts per loop (LX_OPT_HOST_THREADS or the default),
+ * the CPUs granted to the process (affinity mask and cgroup quota), LOCAL_WORLD_SIZE as read from the environment.  Any pointer
+ * may be NULL. */
+int lx_host_threads_info(uint32_t * width, uint32_t * granted_cpus, uint32_t * local_world_size);
 
 /* Introspection, no device needed: how lx_extend_batch_dev would run a batch of n extensions of queries up to max_qlen and
  * windows up to max_slen under the given options (the LX_OPT_* of the same names; survivor_share < 0 = unknown).  The
@@ -482,7 +492,7 @@ int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint
                            lx_iterate_result ** out);
 /* The library's own radix sort (least significant digit first, 8 bits per pass, only the digits set in key_bits; stable) for n (key, value)
  * word pairs in device memory: key[0] / value[0] hold the input, key[1] / value[1] are scratch of the same size; *sorted_in says which of
- * the two holds the sorted words afterwards.  Synchronises `stream`.  n < 2^32.  (The stand-alone front end sorts its word table with it;
+ * the two holds the sorted words afterwards.  Synchronises `stream`; the caller's current device is left as it was.  n < 2^31.  (The stand-alone front end sorts its word table with it;
  * the Level-2 driver sorts matches and survivors with the same kernels.) */
 int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64_t n, uint64_t key_bits, void * stream, int * sorted_in);
 /* Ahead of a handle's first lx_iterate_matches_dev (or large lx_iterate_matches) call: allocates -- and, on the host side, touches -- the

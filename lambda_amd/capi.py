@@ -23,7 +23,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 
 # every symbol include/lambda_ext.h declares (tests/test_abi.py checks that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_set_band_centres", "lx_set_band_centres_dev",
+    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_host_threads_info", "lx_set_band_centres", "lx_set_band_centres_dev",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
     "lx_iterate_matches", "lx_set_queries", "lx_set_subject_seqs", "lx_iterate_matches_dev", "lx_widen_and_preprocess_dev", "lx_reserve", "lx_sort_words_dev", "lx_trim_result_cache",
@@ -43,6 +43,7 @@ LX_OPT_BAND = 9
 LX_OPT_EXTEND_CHUNK = 10
 LX_OPT_MQ_SWEEP = 11
 LX_OPT_ITERATE_RECORDS = 13
+LX_OPT_HOST_THREADS = 14
 LX_OPT_ADAPT_PERMILLE = 12
 
 
@@ -149,6 +150,7 @@ def load():
     lib.lx_last_error.restype = C.c_char_p
     lib.lx_set_option.argtypes = [vp, i32, u64]
     lib.lx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
+    lib.lx_host_threads_info.argtypes = [C.POINTER(C.c_uint32)] * 3
     lib.lx_set_band_centres.argtypes = [vp, vp, u64]
     lib.lx_set_band_centres_dev.argtypes = [vp, vp]
     lib.lx_set_scoring.argtypes = [vp, i32, C.POINTER(Scoring)]

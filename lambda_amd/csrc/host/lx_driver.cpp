@@ -440,6 +440,7 @@ int lx_iterate_matches(lx_handle * h, int slot, uint8_t const * q_res, uint64_t 
     *out = nullptr;
     if (params->flags & ~(int32_t)LX_ITERATE_NO_OPS) // (a caller built against ABI 2 that left the then-reserved word uninitialised)
         return LX_EINVAL;
+    lxi::HostPool::Call const in_flight_call;
     {
         std::vector<uint8_t> bad(std::max(1u, lxi::pool_width()), 0);
         lambda_amd::parallelRanges(n_matches,

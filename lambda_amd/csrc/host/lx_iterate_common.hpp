@@ -22,12 +22,7 @@
 #include "../../../include/lambda_ext.h"
 #include "blast_stats.hpp"
 
-// the library's host threads (lx_host.cpp): width of the pool, and f(0) ... f(nthreads - 1) run side by side
-namespace lxi
-{
-unsigned pool_width();
-void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
-} // namespace lxi
+#include "../lx_host_pool.h" // the library's host threads: parts per loop, and f(0) ... f(nparts - 1) taken by whatever threads are free
 
 namespace lambda_amd
 {

@@ -25,11 +25,7 @@
 #include "../../../include/lambda_ext.h"
 #include "scoring_tables.hpp"
 
-namespace lxi // the library's host threads (lx_host.cpp)
-{
-unsigned pool_width();
-void     pool_run(unsigned nthreads, std::function<void(unsigned)> f);
-} // namespace lxi
+#include "../lx_host_pool.h" // the library's host threads
 
 namespace
 {

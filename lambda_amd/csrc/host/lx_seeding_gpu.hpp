@@ -609,7 +609,7 @@ inline bool buildTableOnGpu(int device, ReducedIndex & ix, std::vector<uint8_t> 
     uint64_t total = 0;
     for (uint64_t l : len)
         total += l;
-    if (total == 0 || total >= 0xffffffffull || off.size() >= 0xffffffffull) // (lx_sort_words_dev ranks with 32 bits)
+    if (total == 0 || total > 0x7fffffffull || off.size() >= 0xffffffffull) // (lx_sort_words_dev ranks with 32 bits; no test covers lists beyond 2^31 words)
         return false;
     for (uint64_t l : len)
         if (l >= 0xffffffffull)

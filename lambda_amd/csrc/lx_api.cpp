@@ -1185,6 +1185,8 @@ int lx_create(int device_id, lx_handle ** out)
     lx_handle * h = new lx_handle();
     if (lx::dev_aids().pass2_mode >= 0) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
         h->opt_pass2 = (uint64_t)lx::dev_aids().pass2_mode;
+    if (lx::dev_aids().host_threads) // (measurement aid of tools/host_curve.py; a caller uses LX_OPT_HOST_THREADS)
+        lxi::HostPool::instance().set_width(lx::dev_aids().host_threads);
     h->device     = device_id;
     auto bail     = [&](char const * what, hipError_t err)
     {
@@ -1301,6 +1303,18 @@ char const * lx_last_error(lx_handle const * h)
     return h ? h->error.c_str() : g_create_error.c_str();
 }
 
+int lx_host_threads_info(uint32_t * width, uint32_t * granted_cpus, uint32_t * local_world_size)
+{
+    lxi::HostPool const & p = lxi::HostPool::instance();
+    if (width)
+        *width = p.width();
+    if (granted_cpus)
+        *granted_cpus = p.granted_cpus();
+    if (local_world_size)
+        *local_world_size = p.local_world();
+    return LX_OK;
+}
+
 int lx_set_option(lx_handle * h, int option, uint64_t value)
 {
     if (!h)
@@ -1323,6 +1337,11 @@ int lx_set_option(lx_handle * h, int option, uint64_t value)
             return LX_OK;
         case LX_OPT_ADAPT_PERMILLE: h->opt_adapt = std::min<uint64_t>(value, 1000); h->surv_frac = -1.0; return LX_OK;
         case LX_OPT_ITERATE_RECORDS: h->opt_iterate_records = value ? 1 : 0; return LX_OK;
+        case LX_OPT_HOST_THREADS:
+            if (value > lxi::HostPool::kMaxParts)
+                return fail(h, LX_EINVAL, "LX_OPT_HOST_THREADS: at most %u", lxi::HostPool::kMaxParts);
+            lxi::HostPool::instance().set_width((unsigned)value); // (the host threads are the process's, not the handle's)
+            return LX_OK;
         case LX_OPT_BAND:
             if (value > (1u << 20))
                 return fail(h, LX_EINVAL, "LX_OPT_BAND: at most 2^20 diagonals on either side");
@@ -1351,6 +1370,7 @@ int lx_get_option(lx_handle const * h, int option, uint64_t * value)
         case LX_OPT_MQ_SWEEP: *value = h->opt_mq; return LX_OK;
         case LX_OPT_ADAPT_PERMILLE: *value = h->opt_adapt; return LX_OK;
         case LX_OPT_ITERATE_RECORDS: *value = h->opt_iterate_records; return LX_OK;
+        case LX_OPT_HOST_THREADS: *value = lxi::HostPool::instance().width(); return LX_OK;
         default: return LX_EINVAL;
     }
 }

@@ -6,44 +6,6 @@
 #include "lx_level2.h"
 using namespace lxi;
 
-// a few host threads for the per-extension loops of the host-buffer entry point (none below a quarter million items)
-unsigned lxi::host_threads(uint64_t n)
-{
-    // (a loop over fewer than ~24 000 extensions is shorter than waking the pool; between that and the batch sizes the pipeline
-    // is built for, one thread per 24 000 -- a 3 000-query batch spent 1.3 of its 3.0 ms unpacking on one thread)
-    if (n < 24000)
-        return 1;
-    static unsigned const avail = []()
-    {
-        cpu_set_t set;
-        CPU_ZERO(&set);
-        unsigned c = sched_getaffinity(0, sizeof(set), &set) == 0 ? (unsigned)CPU_COUNT(&set) : std::thread::hardware_concurrency();
-        if (lx::dev_aids().host_threads) // (A/B aid: up to 64)
-            return std::max(1u, std::min(lx::dev_aids().host_threads, 64u));
-        return std::max(1u, std::min(c, 16u));
-    }();
-    return n >= 250000 ? avail : std::min<unsigned>(avail, std::max<unsigned>(2u, (unsigned)(n / 24000)));
-}
-
-lxi::HostPool & lxi::host_pool()
-{
-    static HostPool p;
-    return p;
-}
-
-// for the Level-2 driver (host/lx_driver.cpp), which is written against the C ABI and borrows only the threads
-namespace lxi
-{
-unsigned pool_width()
-{
-    return host_threads(1u << 30);
-}
-void pool_run(unsigned nthreads, std::function<void(unsigned)> f)
-{
-    host_pool().run(nthreads, std::move(f));
-}
-} // namespace lxi
-
 static int host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
                        lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score,
                        int32_t min_score_all, int32_t * out_score, lx_hsp * out_hsp, uint8_t * caller_ops,
@@ -91,6 +53,7 @@ int lx_score_batch(lx_handle * h, int slot, uint8_t const * q_res, uint64_t q_by
         return a < b;
     };
     // (the loops over the list are spread over a few host threads, as in lx_extend_batch)
+    HostPool::Call const in_flight_call;
     unsigned const nthreads = host_threads(n);
     struct Part
     {
@@ -716,6 +679,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // mode 0: column bytes, 1: run-length codes, 2: the survivors as a list in the handle's buffers (out_hsp, out_ops_off,
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
+    HostPool::Call const in_flight_call; // (the host threads look for this call's next loop instead of going to sleep between two)
     bool const wf_slots = !lx::dev_aids().mq_no_wfslots; // multi-query chunks: checkpoint slots by wavefront (lx::WfSlots) instead of by region
     bool       dev_list = false, want_codes = true, by_range = false; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
     h->res_count         = 0;
@@ -2495,7 +2459,9 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                     }
                     uint64_t const steps = (sm + 8 - 1 + 15) & ~15ull;
                     uint64_t const slot  = (pm + pc - 1) / pc * (lx::ckpt16_slot_dwords(mq_cfg, (uint32_t)steps) + lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) / 8) * 4;
-                    by_range = a < b && b - a <= 4 * per_chunk && (b - a) * kWave * slot <= h->opt_trace_bytes && (b - a) * kWave * (pm * 8 + sm) <= (8ull << 30);
+                    // (a range whose sweep overflows runs again WHOLE with int16-pair slots, about twice the codes': admitted against those too)
+                    uint64_t const slot_w = mq_cfg == 1 && !lx::dev_aids().mq_no_wide ? (pm + pc - 1) / pc * lx::ckpt_slot_dwords(mq_cfg, (uint32_t)steps) * 4 : 0;
+                    by_range = a < b && b - a <= 4 * per_chunk && (b - a) * kWave * std::max(slot, slot_w) <= h->opt_trace_bytes && (b - a) * kWave * (pm * 8 + sm) <= (8ull << 30);
                 }
                 l2.surv_by_range = by_range;
             }

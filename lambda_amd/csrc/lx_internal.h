@@ -26,6 +26,7 @@
 #include "host/scoring_tables.hpp"
 #include "lx_aids.h"
 #include "lx_device.h"
+#include "lx_host_pool.h"
 
 
 namespace lx
@@ -436,121 +437,10 @@ bool solo_plan_applies(lx_handle const * h, int slot);
 int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,
                          int32_t * out_score, lx_survivor_list * out);
 
-unsigned host_threads(uint64_t n);
-
 // [off, off + len) inside a buffer of `bytes`, written so that offsets near 2^64 cannot wrap past the test
 inline bool lx_slice_ok(uint64_t off, uint64_t len, uint64_t bytes)
 {
     return len <= bytes && off <= bytes - len;
-}
-
-
-// A few persistent host threads (started on first use): the per-extension loops of the host-buffer entry points are spread
-// over them; spawning threads per loop would cost more than the loops of a pipeline chunk.  A call runs fifteen to twenty such loops
-// within a millisecond or two, so a worker that has finished its share SPINS on the generation counter for a while before it goes to
-// sleep on the condition variable: handing a loop to sleeping threads and collecting them again costs 30-60 us each time (0.8 ms of a
-// 16-ms call), handing it to spinning ones about one.
-class HostPool
-{
-    std::vector<std::thread>       workers_;
-    std::mutex                     m_;
-    std::condition_variable        cv_;
-    std::function<void(unsigned)>  job_; // (written before gen_ moves on, read by the loop's participants until running_ is back at 0)
-    std::atomic<unsigned>          gen_{0}, want_{0}, running_{0};
-    std::atomic<int>               sleepers_{0};
-    std::atomic<bool>              stop_{false};
-
-    static void relax()
-    {
-#if defined(__x86_64__) || defined(__i386__)
-        __builtin_ia32_pause();
-#endif
-    }
-    void loop(unsigned id)
-    {
-        unsigned seen = 0;
-        for (;;)
-        {
-            // a new generation: spin first (the next loop of the same call is microseconds away), then sleep
-            auto const t0 = std::chrono::steady_clock::now();
-            unsigned   g  = gen_.load();
-            for (unsigned k = 0; g == seen && !stop_.load(); ++k)
-            {
-                relax();
-                if ((k & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(300))
-                    break;
-                g = gen_.load();
-            }
-            if (g == seen && !stop_.load())
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                sleepers_.fetch_add(1); // (before the test: run() moves gen_ on and THEN looks for sleepers -- one of the two sees the other)
-                cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
-                sleepers_.fetch_sub(1);
-                g = gen_.load();
-            }
-            if (stop_.load())
-                return;
-            seen = g;
-            if (id >= want_.load())
-                continue; // (a loop for fewer threads)
-            job_(id);
-            running_.fetch_sub(1);
-        }
-    }
-
-public:
-    ~HostPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            stop_.store(true);
-        }
-        cv_.notify_all();
-        for (std::thread & t : workers_)
-            t.join();
-    }
-    // runs f(1) .. f(nthreads - 1) on the workers and f(0) on the caller; returns when all are done
-    void run(unsigned nthreads, std::function<void(unsigned)> f)
-    {
-        static std::mutex           callers; // one parallel loop at a time (handles on several host threads share the pool)
-        std::lock_guard<std::mutex> one(callers);
-        while (workers_.size() + 1 < nthreads)
-        {
-            unsigned const id = (unsigned)workers_.size() + 1;
-            workers_.emplace_back([this, id] { loop(id); });
-        }
-        job_ = std::move(f);
-        want_.store(nthreads);
-        running_.store(nthreads - 1);
-        gen_.fetch_add(1);
-        if (sleepers_.load() > 0)
-        {
-            { std::lock_guard<std::mutex> lk(m_); } // (a sleeper between its test and its wait holds the mutex: wait for it to be asleep)
-            cv_.notify_all();
-        }
-        job_(0);
-        for (unsigned k = 0; running_.load() != 0; ++k)
-        {
-            relax();
-            if ((k & 4095) == 4095)
-                std::this_thread::yield();
-        }
-    }
-};
-HostPool & host_pool();
-
-template <typename F>
-inline void parallel_ranges(uint64_t n, unsigned nthreads, F && body)
-{
-    if (nthreads <= 1 || n < 2 * (uint64_t)nthreads)
-    {
-        for (unsigned t = 0; t < nthreads; ++t) // keep the per-thread slots of the callers meaningful
-            body(t, t == 0 ? 0 : n, n);
-        return;
-    }
-    uint64_t const step = (n + nthreads - 1) / nthreads;
-    host_pool().run(nthreads, [&body, step, n](unsigned t) { body(t, std::min(n, t * step), std::min(n, (t + 1) * step)); });
 }
 
 

@@ -533,6 +533,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
     auto &            l2 = h->l2;
     hipStream_t const st = h->stream;
     HostMarks         hm("lx_iterate_matches_dev");
+    HostPool::Call const in_flight_call;
     int               rc;
     res->stats.num_ext_score += n_matches; // lH.stats.numExtScore (:1187)
     // the cut-off of every query length of the resident set (one bisection each, :1251-1283 as an integer test)
@@ -879,6 +880,7 @@ int lxi::iterate_host_list_on_device(lx_handle * h, int slot, uint8_t const * q_
         return kNotTaken;
     auto &    l2 = h->l2;
     HostMarks hm("lx_iterate_matches (device list work)");
+    HostPool::Call const in_flight_call;
     int       rc;
     if ((rc = bind(h)))
         return rc;
@@ -1103,7 +1105,19 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         sp.karlin          = lx_karlin{0.3, 0.1, 0.3, 1.0, -10.0};
         sp.flags           = n_columns ? 0 : LX_ITERATE_NO_OPS;
         lx_iterate_result * r = nullptr;
+        // (the dummy call must not teach the handle anything: what the adaptive pass 2 and the wide sweep learnt from real lists stays)
+        double const   surv_before = h->surv_frac, plan_before = h->plan_surv_frac, decl_before = h->mq_decl_frac;
+        bool const     wide_before = h->mq_wide_call, pending_before = h->count_pending;
+        uint64_t const res_before  = h->res_count;
         rc = lx_iterate_matches_dev(h, h->have_sc[0] ? 0 : 1, l2.d_up.ptr, 1, &sp, &r);
+        h->surv_frac      = surv_before;
+        h->plan_surv_frac = plan_before;
+        h->mq_decl_frac   = decl_before;
+        h->mq_wide_call   = wide_before;
+        h->count_pending  = pending_before;
+        h->res_count      = res_before;
+        h->phase_ev.clear();
+        h->ev_pool_used   = 0;
         if (r)
             lx_iterate_result_free(r);
         if (rc)
@@ -1131,21 +1145,48 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
 // word table is sorted with (host/lx_seeding_gpu.hpp), instead of a library primitive.
 int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64_t n, uint64_t key_bits, void * stream, int * sorted_in)
 {
-    if (!key || !value || !sorted_in || (n && (!key[0] || !key[1] || !value[0] || !value[1])) || n >= 0xffffffffull)
+    if (!key || !value || !sorted_in || (n && (!key[0] || !key[1] || !value[0] || !value[1])) || n > 0x7fffffffull || device < 0 || device >= 64)
         return LX_EINVAL;
     *sorted_in = 0;
     if (n < 2)
         return LX_OK;
+    // (the caller's current device is the caller's: restored on every exit)
+    int before = -1;
+    if (hipGetDevice(&before) != hipSuccess)
+        before = -1;
+    struct Restore
+    {
+        int dev;
+        ~Restore()
+        {
+            if (dev >= 0)
+                (void)hipSetDevice(dev);
+        }
+    } const restore{before == device ? -1 : before};
     if (hipSetDevice(device) != hipSuccess)
         return LX_EHIP;
-    uint32_t * hist = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&hist), (lx::l2_sort_tiles(n) + 2) * 256 * sizeof(uint32_t)) != hipSuccess)
-        return LX_ENOMEM;
+    // the digit counts: one allocation per (process, device), kept and grown -- a hipMalloc + hipFree per call synchronises the device
+    static std::mutex  hist_m;
+    static uint32_t *  hist_buf[64] = {nullptr};
+    static size_t      hist_cap[64] = {0};
+    std::lock_guard<std::mutex> lk(hist_m); // (also: one sort at a time per process on these buffers)
+    size_t const want = (lx::l2_sort_tiles(n) + 2) * 256 * sizeof(uint32_t);
+    int const    d    = device & 63;
+    if (hist_cap[d] < want)
+    {
+        if (hist_buf[d])
+            (void)hipFree(hist_buf[d]);
+        hist_buf[d] = nullptr;
+        hist_cap[d] = 0;
+        if (hipMalloc(reinterpret_cast<void **>(&hist_buf[d]), want + want / 2) != hipSuccess)
+            return LX_ENOMEM;
+        hist_cap[d] = want + want / 2;
+    }
+    uint32_t * const hist = hist_buf[d];
     uint64_t * k = key[0], * kt = key[1], * v = value[0], * vt = value[1];
     hipError_t e = lx::l2_launch_sort(&k, &kt, &v, &vt, n, key_bits, 0, hist, static_cast<hipStream_t>(stream));
     if (e == hipSuccess)
-        e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // (the digit counts are this call's)
-    (void)hipFree(hist);
+        e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // (the digit counts are shared: the sort is over before the next one starts)
     *sorted_in = k == key[0] ? 0 : 1;
     return e == hipSuccess ? LX_OK : LX_EHIP;
 }
