@@ -490,6 +490,18 @@ int lx_set_queries(lx_handle * h, uint8_t const * q_res, uint64_t q_bytes, uint6
 int lx_set_subject_seqs(lx_handle * h, uint64_t const * s_seq_off, uint64_t const * s_seq_len, uint64_t n_sseq);
 int lx_iterate_matches_dev(lx_handle * h, int slot, void const * d_matches, uint64_t n_matches, lx_search_params const * params,
                            lx_iterate_result ** out);
+/* Introspection: the plan lx_iterate_matches_dev makes for a PROTEIN window list -- the multi-query sweep's free packing (LX_OPT_QUERY_RUN
+ * = 2: the two windows of a lane group share a query slice, a wavefront's 16 slots hold windows of at most four slices) -- for a list
+ * of n lx_extension records in device memory that is grouped by query slice, as kernels (what the reference does with its sort by slice
+ * lengths, src/search_algo.hpp:1229-1235, so that a SIMD batch's windows take about as many steps), brought to the host.
+ * strip_cols: 19, 13 or 11 (columns per lane of a strip).  Ranges: cut[0] = 0 < ... < cut[nranges] = n, every cut where the query
+ * changes; the plan's wavefronts are laid out range by range.  out_plan: [bound * 16] slots -- position in the list, bit 31 = filler (a
+ * copy that never survives), 0xffffffff beyond the plan's wavefronts --, out_pan / out_maxs: [bound] columns per lane of a wavefront's
+ * widest query / its longest window, bound = lx_plan_free_packing_bound(n, n_qseq, nranges); out_report: [16] = {wavefronts, error
+ * flag (0), runs, quads of the pool, first wavefront of range 0, 1, ..., nranges}.  tests/test_gpu_plan.py checks every slot. */
+uint64_t lx_plan_free_packing_bound(uint64_t n, uint64_t n_qseq, uint32_t nranges);
+int      lx_plan_free_packing_dev(lx_handle * h, void const * d_ext, uint64_t n, uint64_t n_qseq, int32_t strip_cols, uint32_t nranges, uint64_t const * cut,
+                                  uint32_t * out_plan, uint32_t * out_pan, uint32_t * out_maxs, uint32_t * out_report);
 /* The library's own radix sort (least significant digit first, 8 bits per pass, only the digits set in key_bits; stable) for n (key, value)
  * word pairs in device memory: key[0] / value[0] hold the input, key[1] / value[1] are scratch of the same size; *sorted_in says which of
  * the two holds the sorted words afterwards.  Synchronises `stream`; the caller's current device is left as it was.  n < 2^31.  (The stand-alone front end sorts its word table with it;

@@ -23,7 +23,7 @@ LX_OPT_WORKSPACE_BYTES = 3
 
 # every symbol include/lambda_ext.h declares (tests/test_abi.py checks that the library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_host_threads_info", "lx_set_band_centres", "lx_set_band_centres_dev",
+    "lx_abi_version", "lx_build_id", "lx_device_count", "lx_create", "lx_destroy", "lx_last_error", "lx_set_option", "lx_get_option", "lx_host_threads_info", "lx_plan_free_packing_bound", "lx_plan_free_packing_dev", "lx_set_band_centres", "lx_set_band_centres_dev",
     "lx_set_scoring", "lx_builtin_scoring", "lx_score_batch", "lx_score_batch_dev", "lx_align_batch",
     "lx_align_batch_dev", "lx_extend_batch_dev", "lx_prefilter_batch", "lx_synchronize", "lx_last_kernel_ms", "lx_last_kernel_name", "lx_last_trace_kernel_name", "lx_last_phase_ms",
     "lx_iterate_matches", "lx_set_queries", "lx_set_subject_seqs", "lx_iterate_matches_dev", "lx_widen_and_preprocess_dev", "lx_reserve", "lx_sort_words_dev", "lx_trim_result_cache",
@@ -151,6 +151,9 @@ def load():
     lib.lx_set_option.argtypes = [vp, i32, u64]
     lib.lx_get_option.argtypes = [vp, i32, C.POINTER(u64)]
     lib.lx_host_threads_info.argtypes = [C.POINTER(C.c_uint32)] * 3
+    lib.lx_plan_free_packing_bound.argtypes = [u64, u64, C.c_uint32]
+    lib.lx_plan_free_packing_bound.restype = u64
+    lib.lx_plan_free_packing_dev.argtypes = [vp, vp, u64, u64, i32, C.c_uint32, C.POINTER(u64), vp, vp, vp, vp]
     lib.lx_set_band_centres.argtypes = [vp, vp, u64]
     lib.lx_set_band_centres_dev.argtypes = [vp, vp]
     lib.lx_set_scoring.argtypes = [vp, i32, C.POINTER(Scoring)]
@@ -605,6 +608,18 @@ class Handle:
         res = C.c_void_p()
         self._check(self.lib.lx_iterate_matches_dev(self.h, slot, d_matches.data_ptr() if n else None, n, C.byref(params), C.byref(res)))
         return self._take_iterate_result(res)
+
+    def plan_free_packing_dev(self, d_ext, n: int, n_qseq: int, strip_cols: int = 19, cuts=None):
+        """lx_plan_free_packing_dev: (plan [nwf, 16], wf_pan [nwf], wf_maxs [nwf], report [16]) for n lx_extension records in a device tensor."""
+        cuts = np.ascontiguousarray([0, n] if cuts is None else cuts, dtype=np.uint64)
+        nranges = len(cuts) - 1
+        cap = int(self.lib.lx_plan_free_packing_bound(n, n_qseq, nranges))
+        plan, pan, maxs, rep = np.zeros(cap * 16, np.uint32), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32), np.zeros(16, np.uint32)
+        self._check(self.lib.lx_plan_free_packing_dev(self.h, d_ext.data_ptr(), n, n_qseq, strip_cols, nranges, cuts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      _ptr(plan), _ptr(pan), _ptr(maxs), _ptr(rep)))
+        nwf = int(rep[0])
+        assert nwf <= cap, (nwf, cap)
+        return plan[:nwf * 16].reshape(nwf, 16).copy(), pan[:nwf].copy(), maxs[:nwf].copy(), rep
 
     def widen_and_preprocess_dev(self, d_matches, n: int, bisulfite: bool = False):
         """lx_widen_and_preprocess_dev: the window list of a device match list (n lx_match records) as a MATCH_DTYPE array."""

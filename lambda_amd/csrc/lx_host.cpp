@@ -881,7 +881,8 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // bisulfite).  A read set's seed list has one or two windows per read: at four queries per wavefront three slots in four
     // were fillers (configs[2]-sized list: 4.1 M slots for 1.25 M windows).  The plan is then a sort: all windows by (columns per
     // lane, length), longest first, 16 to a wavefront.
-    bool const use_solo = preplanned || (use_mq && !lx::dev_aids().mq_no_solo && lx::sweep_mq_lds_bytes(1, h->sc_host[slot].alphabet_size + 1, -1) <= 20 * 1024);
+    bool const use_solo = preplanned ? !ri->free_packing
+                                     : (use_mq && !lx::dev_aids().mq_no_solo && lx::sweep_mq_lds_bytes(1, h->sc_host[slot].alphabet_size + 1, -1) <= 20 * 1024);
     if (preplanned)
     {
         if (!use_mq || !as_list)
@@ -2443,7 +2444,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             dev_list          = true;
             want_codes        = ri->want_codes;
             // records chunk by chunk where every range of the plan is a chunk the budgets admit (else: the call's list, one chain at the end)
-            if (ri->chunk_records && ri->chunk_records->n_ranges >= 1 && use_solo && preplanned)
+            if (ri->chunk_records && ri->chunk_records->n_ranges >= 1 && preplanned)
             {
                 auto const &   cr = *ri->chunk_records;
                 uint64_t const pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
@@ -2466,7 +2467,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 l2.surv_by_range = by_range;
             }
         }
-        bool     rows_cleared = false, stream_planned = use_solo; // (the solo plan is whole before the first chunk)
+        bool     rows_cleared = false, stream_planned = use_solo || preplanned; // (the solo plan and a device plan are whole before the first chunk)
         uint64_t w0           = 0;
         // ONE launch for the pool and what follows it (the slots in two regions: lx_handle::MqSplit): the pool is a tenth of the list
         // in wavefronts that run up to three times as long as the others -- launched by itself it leaves most of the chip idle behind
@@ -2475,7 +2476,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // (lists of up to ~200 000 windows: a dozen rounds of the chip's wavefront slots.  Beyond that the pool by itself is several
         // rounds and the streamed part's plan is better made beside its kernels: 596 k windows 18.6 ms merged, 17.5 ms not;
         // 64 k windows of 300-500-residue queries 11.9 ms merged, 16.3 ms not)
-        bool const merge_pool = !use_solo && !lx::dev_aids().mq_no_merge && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
+        bool const merge_pool = !use_solo && !preplanned && !lx::dev_aids().mq_no_merge && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
         // wavefronts [wlo, whi) of the plan in launch order = longest first (what a wavefront executes is columns x steps; the blocks of a
         // launch are dealt to the chip's wavefront slots in index order, so a long wavefront late in the order ends the launch late)
         auto longest_first = [&](uint64_t wlo, uint64_t whi)
@@ -2523,7 +2524,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             longest_first(0, nwf); // (one launch for the whole plan: the streamed part's long wavefronts would start late)
             t_prep += ms(tp0, now());
         }
-        uint64_t const pool_end = use_solo ? 0 : pool_wf; // wavefronts before it: the pool (region 1 of a chunk that spans it)
+        uint64_t const pool_end = (use_solo || preplanned) ? 0 : pool_wf; // wavefronts before it: the pool (region 1 of a chunk that spans it)
         auto clear_rows = [&]()
         {
             // (beside the first chunk's kernels) every row starts as "no alignment"; the survivors' rows are written by
@@ -2852,6 +2853,14 @@ int lx_extend_batch_list(lx_handle * h, int slot, uint8_t const * q_res, uint64_
 }
 
 } // extern "C"
+
+// does the multi-query sweep serve this slot's lists at all (free packing: what protein lists are planned for)?
+bool lxi::free_plan_applies(lx_handle const * h, int slot)
+{
+    lx_scoring const & sh = h->sc_host[slot];
+    return h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap && sh.gap_open <= sh.gap_extend &&
+           !lx::dev_aids().extend_no_mq && !h->opt_band;
+}
 
 // does lx_extend_batch* serve this slot's lists with the solo packing of the multi-query sweep (a byte profile per window)?
 bool lxi::solo_plan_applies(lx_handle const * h, int slot)

@@ -222,7 +222,7 @@ struct lx_handle
         uint32_t              max_evlen = 0;
         int                   q_frames  = 1;
         DevBuf                d_qres, d_qoff, d_qlen, d_qband, d_qevlen, d_soff, d_slen;
-        DevBuf                d_pair[2], d_s0[2], d_hist, d_head, d_tail, d_tot, d_win, d_cut, d_cnt, d_up, d_plan, d_wf;
+        DevBuf                d_pair[2], d_s0[2], d_hist, d_head, d_tail, d_tot, d_win, d_cut, d_cnt, d_up, d_plan, d_wf, d_fp; // (d_fp: workspace of the free-packing plan)
         Pinned                p_cnt, p_win, p_up;
         std::vector<lx_extension> ext;   // host copies of the window list, its cut-offs and scores
         std::vector<int32_t>      min, score;
@@ -416,6 +416,7 @@ struct ResidentInput
     uint32_t const * wf_pan  = nullptr;
     uint32_t const * wf_maxs = nullptr;
     int              mq_cfg  = 0;
+    bool             free_packing = false; // the device plan is the free packing (pairs of one query, at most four queries per wavefront), not the solo one
     uint64_t         cells   = 0;
     // the survivors stay on the device (lx_handle::Level2::d_surv_*; taken where the plan above is served: surv_on_device says so),
     // the scores too (h->d_score_all); want_codes: their run-length codes come down into the handle's code bytes
@@ -434,6 +435,7 @@ struct ResidentInput
     ChunkRecords const * chunk_records = nullptr;
 };
 bool solo_plan_applies(lx_handle const * h, int slot);
+bool free_plan_applies(lx_handle const * h, int slot);
 int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,
                          int32_t * out_score, lx_survivor_list * out);
 

@@ -82,6 +82,34 @@ hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
                           uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base = 0, uint64_t key_bits = 0x0fffffffull);
 uint64_t   l2_plan_key_bits(uint64_t max_qlen, uint64_t max_wlen);
+// The FREE-PACKING plan of the multi-query sweep for a window list (lx_plan_free.hip): a lane group's two windows
+// share a query, a wavefront's sixteen slots hold windows of at most four queries -- the long windows of every query pooled in
+// quads, the rest streamed pair by pair --, laid out range by range (cut[0] = 0 < cut[1] < ... < cut[nranges] = n, every cut where
+// the query changes).  plan: [cap_wf * 16] slots (position in ext[], bit 31 = filler), wf_pan / wf_maxs: [cap_wf]; report: [16]
+// uint32 in device memory -- [0] wavefronts, [1] non-zero = the bound was broken (a bug: the plan is not to be used), [2] runs,
+// [3] quads, [4 + r] first wavefront of range r (r <= nranges).
+constexpr uint32_t kFpMaxRanges = 8;
+struct FpArgs
+{
+    Extension const * ext;
+    uint64_t          n;
+    uint64_t          n_qseq;    // query sequences of the resident set (bounds the runs)
+    int               C;         // columns per lane of a whole strip
+    int               no_narrow;
+    uint32_t          nranges;
+    uint64_t          cut[kFpMaxRanges + 1];
+    void *            work;      // fp_workspace_bytes(n, n_qseq, nranges)
+    size_t            work_bytes;
+    uint32_t *        plan;
+    uint64_t          cap_wf;    // >= fp_wavefront_bound(n, n_qseq, nranges)
+    uint32_t *        wf_pan;
+    uint32_t *        wf_maxs;
+    uint32_t *        report;
+};
+uint64_t   fp_run_bound(uint64_t n, uint64_t n_qseq);
+uint64_t   fp_wavefront_bound(uint64_t n, uint64_t n_qseq, uint32_t nranges);
+size_t     fp_workspace_bytes(uint64_t n, uint64_t n_qseq, uint32_t nranges);
+hipError_t fp_launch_plan(FpArgs const & p, hipStream_t stream);
 uint64_t   l2_sort_tiles(uint64_t n);
 uint64_t   l2_scan_tiles(uint64_t n);
 

@@ -271,7 +271,8 @@ static_assert(sizeof(lx::BlastMatchDev) == sizeof(lx_blast_match) && offsetof(lx
 // A part is served as ONE range behind its last chunk (the survivors of all chunks in lx_handle::Level2::d_surv_*), or -- where the
 // plan's chunks are ranges of the query-sorted list (ResidentInput::ChunkRecords) -- range by range: a range's kernels are queued
 // behind its chunk's own, its rows and columns come down while the next chunk computes.
-constexpr size_t kPlanHead = 64 + 512 * sizeof(lx::L2Window); // l2.p_plan: [flag][probe windows] in front of the per-wavefront arrays
+constexpr size_t kPlanProbe = 128;                                 // l2.p_plan: [rank flag: 64 B][the free-packing plan's report: 64 B][probe windows] ...
+constexpr size_t kPlanHead  = kPlanProbe + 512 * sizeof(lx::L2Window); // ... in front of the per-wavefront arrays
 
 struct RecordsJob
 {
@@ -602,7 +603,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
         ri.d_ext_all = static_cast<lx_extension const *>(h->d_ext_all.ptr) + pt.lo;
         ri.d_min_all = static_cast<int32_t const *>(h->d_min_all.ptr) + pt.lo;
         lx_survivor_list list{};
-        if (solo_plan_applies(h, pt.slot))
+        // The plan of the sweep on the device: the solo packing where 16 profiles fit a wavefront's share of the LDS (nucleotides,
+        // bisulfite), else the free packing (protein lists: four queries per wavefront) -- nothing of size n comes to the host either way
+        bool const solo = solo_plan_applies(h, pt.slot), free_packing = !solo && free_plan_applies(h, pt.slot);
+        if (solo || free_packing)
         {
             // The plan of the sweep on the device (the solo packing of lx_sweep_mq.hip: every window its own profile): ONE strip
             // geometry per call, the one that sweeps the list cheapest (lx_host.cpp has the measurement behind "one" and behind
@@ -647,7 +651,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     // (into pinned memory: a copy into ordinary memory is staged by the runtime, 40 us of an idle GPU each)
                     if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead)))
                         return rc;
-                    lx::L2Window * const probe = reinterpret_cast<lx::L2Window *>(static_cast<uint8_t *>(l2.p_plan.ptr) + 64);
+                    lx::L2Window * const probe = reinterpret_cast<lx::L2Window *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanProbe);
                     LX_HIP(h, hipMemcpyAsync(probe, static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo + from, (upto - from) * sizeof(lx::L2Window), hipMemcpyDeviceToHost, st));
                     LX_HIP(h, hipStreamSynchronize(st));
                     uint64_t cut = 0;
@@ -662,25 +666,60 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 }
                 ranges.push_back(RecordsJob::Range{lo, n});
             }
-            uint64_t nwf = 0;
+            uint64_t nwf = 0, cap_wf = 0; // (cap_wf: what the per-wavefront arrays are spaced by on the device)
             l2.cut_wf.assign(1, 0);
-            for (auto const & rg : ranges)
+            if (solo)
             {
-                nwf += (rg.hi - rg.lo + 15) / 16;
-                l2.cut_wf.push_back(nwf);
+                for (auto const & rg : ranges)
+                {
+                    nwf += (rg.hi - rg.lo + 15) / 16;
+                    l2.cut_wf.push_back(nwf);
+                }
+                cap_wf = nwf;
             }
-            if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 16)))
+            else
+                cap_wf = lx::fp_wavefront_bound(n, l2.q_len.size(), (uint32_t)ranges.size());
+            if ((rc = ensure(h, l2.d_plan, cap_wf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * cap_wf * sizeof(uint32_t) + 64)) ||
+                (rc = ensure_pinned(h, l2.p_plan, kPlanHead)))
                 return rc;
-            uint32_t * const d_pan = static_cast<uint32_t *>(l2.d_wf.ptr), * const d_maxs = d_pan + nwf;
-            for (size_t r = 0; r < ranges.size(); ++r)
+            uint32_t * const d_pan = static_cast<uint32_t *>(l2.d_wf.ptr), * const d_maxs = d_pan + cap_wf;
+            uint32_t * const h_flag = static_cast<uint32_t *>(l2.p_plan.ptr), * const h_report = h_flag + 16;
+            if (solo)
+                for (size_t r = 0; r < ranges.size(); ++r)
+                {
+                    uint64_t * key = static_cast<uint64_t *>(l2.d_pair[0].ptr), * key_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
+                    uint64_t * idx = static_cast<uint64_t *>(l2.d_s0[0].ptr), * idx_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
+                    uint64_t const w0 = l2.cut_wf[r];
+                    LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all) + ranges[r].lo, ranges[r].hi - ranges[r].lo, lx::trace_cfg_panel(cfg) / 8,
+                                                 lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
+                                                 static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo,
+                                                 lx::l2_plan_key_bits(l2.max_qlen, cost[8 + pi])));
+                }
+            else
             {
-                uint64_t * key = static_cast<uint64_t *>(l2.d_pair[0].ptr), * key_tmp = static_cast<uint64_t *>(l2.d_pair[1].ptr);
-                uint64_t * idx = static_cast<uint64_t *>(l2.d_s0[0].ptr), * idx_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
-                uint64_t const w0 = l2.cut_wf[r];
-                LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all) + ranges[r].lo, ranges[r].hi - ranges[r].lo, lx::trace_cfg_panel(cfg) / 8,
-                                             lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
-                                             static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo,
-                                             lx::l2_plan_key_bits(l2.max_qlen, cost[8 + pi])));
+                // the free packing (lx_plan_free.hip): ONE plan over the part, laid out range by range; how many wavefronts it takes is
+                // the plan's to say (its report comes down with the rank kernel's flag)
+                lx::FpArgs fa{};
+                fa.ext        = static_cast<lx::Extension const *>(ri.d_ext_all);
+                fa.n          = n;
+                fa.n_qseq     = l2.q_len.size();
+                fa.C          = lx::trace_cfg_panel(cfg) / 8;
+                fa.no_narrow  = lx::dev_aids().mq_no_narrow ? 1 : 0;
+                fa.nranges    = (uint32_t)ranges.size();
+                for (size_t r = 0; r < ranges.size(); ++r)
+                    fa.cut[r] = ranges[r].lo;
+                fa.cut[ranges.size()] = n;
+                fa.work_bytes = lx::fp_workspace_bytes(n, fa.n_qseq, fa.nranges);
+                if ((rc = ensure(h, l2.d_fp, fa.work_bytes + 64)))
+                    return rc;
+                fa.work    = l2.d_fp.ptr;
+                fa.plan    = static_cast<uint32_t *>(l2.d_plan.ptr);
+                fa.cap_wf  = cap_wf;
+                fa.wf_pan  = d_pan;
+                fa.wf_maxs = d_maxs;
+                fa.report  = d_pan + 2 * cap_wf; // (16 words behind the per-wavefront arrays)
+                LX_HIP(h, lx::fp_launch_plan(fa, st));
+                LX_HIP(h, hipMemcpyAsync(h_report, fa.report, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
             // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by it)
             bool const try_rank = records_on_device && n < 0xfffffff0ull && !lx::dev_aids().l2_no_rank;
@@ -694,24 +733,44 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                                               static_cast<uint32_t const *>(l2.d_qlen.ptr), d_rank, d_rank + n, st));
             }
             // what the host reads of the plan, in pinned memory: the rank kernel's flag, columns per lane and longest window per wavefront
-            // (one copy: they stand side by side on the device)
+            uint32_t flag_now = 0;
+            if (!solo)
+            {
+                *h_flag = 0;
+                if (try_rank)
+                    LX_HIP(h, hipMemcpyAsync(h_flag, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                LX_HIP(h, hipStreamSynchronize(st));
+                flag_now = *h_flag;
+                nwf      = h_report[0];
+                if (h_report[1] || nwf == 0 || nwf > cap_wf)
+                    return fail(h, LX_ESTATE, "the free-packing plan of %llu windows reports %llu wavefronts (at most %llu), flag %u", (unsigned long long)n,
+                                (unsigned long long)nwf, (unsigned long long)cap_wf, h_report[1]);
+                for (size_t r = 0; r < ranges.size(); ++r)
+                    l2.cut_wf.push_back(h_report[4 + r + 1]);
+                if (l2.cut_wf.back() != nwf)
+                    return fail(h, LX_ESTATE, "the free-packing plan's ranges end at wavefront %llu of %llu", (unsigned long long)l2.cut_wf.back(), (unsigned long long)nwf);
+            }
+            // (no copy into the block is pending here: it may move)
             if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead + 2 * nwf * sizeof(uint32_t))))
                 return rc;
-            uint32_t * const h_flag = static_cast<uint32_t *>(l2.p_plan.ptr);
-            uint32_t * const h_pan  = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanHead), * const h_maxs = h_pan + nwf;
-            *h_flag = 0;
-            if (try_rank)
-                LX_HIP(h, hipMemcpyAsync(h_flag, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            LX_HIP(h, hipMemcpyAsync(h_pan, d_pan, 2 * nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            uint32_t * const h_flag2 = static_cast<uint32_t *>(l2.p_plan.ptr);
+            uint32_t * const h_pan   = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanHead), * const h_maxs = h_pan + nwf;
+            *h_flag2 = flag_now;
+            if (solo && try_rank)
+                LX_HIP(h, hipMemcpyAsync(h_flag2, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            LX_HIP(h, hipMemcpyAsync(h_pan, d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            LX_HIP(h, hipMemcpyAsync(h_maxs, d_maxs, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             if ((windows_to_host || !records_on_device) && (rc = queue_windows()))
                 return rc;
             LX_HIP(h, hipStreamSynchronize(st));
+            uint32_t * const h_flag_final = h_flag2;
             ri.d_plan  = static_cast<uint32_t const *>(l2.d_plan.ptr);
             ri.nwf     = nwf;
             ri.wf_pan  = h_pan;
             ri.wf_maxs = h_maxs;
-            l2.rank_too_long = *h_flag;
+            l2.rank_too_long = *h_flag_final;
             ri.mq_cfg  = cfg;
+            ri.free_packing = !solo;
             ri.cells   = cost[4 * pi + 3];
             ri.keep_on_device = records_on_device;
             ri.want_codes     = !(params->flags & LX_ITERATE_NO_OPS);
@@ -1189,6 +1248,58 @@ int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64
         e = hipStreamSynchronize(static_cast<hipStream_t>(stream)); // (the digit counts are shared: the sort is over before the next one starts)
     *sorted_in = k == key[0] ? 0 : 1;
     return e == hipSuccess ? LX_OK : LX_EHIP;
+}
+
+// The free-packing plan (lx_plan_free.hip) of a window list in device memory, brought to the host: what tests/test_gpu_plan.py checks
+// slot by slot.  out_plan: [lx_plan_free_packing_bound(n, n_qseq, nranges) * 16], out_pan / out_maxs: [that bound], out_report: [16].
+uint64_t lx_plan_free_packing_bound(uint64_t n, uint64_t n_qseq, uint32_t nranges)
+{
+    return lx::fp_wavefront_bound(n, n_qseq, nranges);
+}
+
+int lx_plan_free_packing_dev(lx_handle * h, void const * d_ext, uint64_t n, uint64_t n_qseq, int32_t strip_cols, uint32_t nranges, uint64_t const * cut, uint32_t * out_plan,
+                             uint32_t * out_pan, uint32_t * out_maxs, uint32_t * out_report)
+{
+    if (!h)
+        return LX_EINVAL;
+    if (!d_ext || !cut || !out_plan || !out_pan || !out_maxs || !out_report || n == 0 || nranges == 0 || nranges > lx::kFpMaxRanges || n >= 0x7ffffff0ull ||
+        (strip_cols != 19 && strip_cols != 13 && strip_cols != 11))
+        return fail(h, LX_EINVAL, "lx_plan_free_packing_dev: arguments");
+    for (uint32_t r = 0; r < nranges; ++r)
+        if (cut[r] >= cut[r + 1])
+            return fail(h, LX_EINVAL, "lx_plan_free_packing_dev: range %u is empty", r);
+    if (cut[0] != 0 || cut[nranges] != n)
+        return fail(h, LX_EINVAL, "lx_plan_free_packing_dev: the ranges must cover the list");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    auto &         l2  = h->l2;
+    uint64_t const cap = lx::fp_wavefront_bound(n, n_qseq, nranges);
+    lx::FpArgs     fa{};
+    fa.ext        = static_cast<lx::Extension const *>(d_ext);
+    fa.n          = n;
+    fa.n_qseq     = n_qseq;
+    fa.C          = strip_cols;
+    fa.no_narrow  = lx::dev_aids().mq_no_narrow ? 1 : 0;
+    fa.nranges    = nranges;
+    for (uint32_t r = 0; r <= nranges; ++r)
+        fa.cut[r] = cut[r];
+    fa.work_bytes = lx::fp_workspace_bytes(n, n_qseq, nranges);
+    if ((rc = ensure(h, l2.d_fp, fa.work_bytes + 64)) || (rc = ensure(h, l2.d_plan, cap * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * cap * sizeof(uint32_t) + 64)))
+        return rc;
+    fa.work    = l2.d_fp.ptr;
+    fa.plan    = static_cast<uint32_t *>(l2.d_plan.ptr);
+    fa.cap_wf  = cap;
+    fa.wf_pan  = static_cast<uint32_t *>(l2.d_wf.ptr);
+    fa.wf_maxs = fa.wf_pan + cap;
+    fa.report  = fa.wf_pan + 2 * cap;
+    LX_HIP(h, lx::fp_launch_plan(fa, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_report, fa.report, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_plan, fa.plan, cap * 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_pan, fa.wf_pan, cap * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipMemcpyAsync(out_maxs, fa.wf_maxs, cap * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+    LX_HIP(h, hipStreamSynchronize(h->stream));
+    return LX_OK;
 }
 
 // _widenAndPreprocessMatches (src/search_algo.hpp:1136-1175) alone, on a device match list over the resident sets
