@@ -93,14 +93,20 @@ def parse(argv=None):
                     "tools/dev/long_queries.py -- 8 000 queries, 8 windows each on average, half of them homologous at the workload's substitution "
                     "rate, i.e. scoring 2 000-3 500: beyond the compact checkpoint codes")
     ap.add_argument("--iterate", action="store_true", help="time lx_iterate_matches_dev -- the whole of iterateMatchesFullSimd on a DEVICE match "
-                    "list (widen, sort, merge, unique, both passes, records) -- on a synthetic seed list of configs[2]'s size; --entry host: "
+                    "list (widen, sort, merge, unique, both passes, records) -- on a synthetic seed list of configs[2]'s size, or with --config 1 "
+                    "of configs[1]'s (searchp BLOSUM62: 100 000 queries x ~32 windows); --entry host: "
                     "lx_iterate_matches on the same list in host memory")
     ap.add_argument("--iterate-reads", type=int, default=1_000_000)
     ap.add_argument("--iterate-mbp", type=float, default=100.0)
+    ap.add_argument("--iterate-queries", type=int, default=100_000, help="--iterate --config 1: queries of the protein seed list (configs[1]: 100 000 x 150 aa, "
+                    "~32 windows each after merging)")
     ap.add_argument("--cold", action="store_true", help="--iterate: every timed call is the FIRST call of a fresh handle (lx_create, the sequence "
                     "sets, lx_reserve with hints, then the one call a search makes): what `lambda3 searchn` pays, not the tenth call")
     ap.add_argument("--dry-run", action="store_true", help="launch + rendezvous (gloo) + sharding only; no GPU, value = null")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    # (--iterate without --config keeps timing the read set of configs[2]; `--iterate --config 1` is the metric's own program: the protein list)
+    args.config_given = any(a == "--config" or a.startswith("--config=") for a in (sys.argv[1:] if argv is None else argv))
+    return args
 
 
 def workload_of(args):
@@ -317,7 +323,16 @@ def dry_run(args, w, world, rank):
     from lambda_amd import workloads
 
     pl = workloads.plan(w, world, rank, args.total_queries, args.queries, args.batch_queries)
-    mine = {"rank": rank, "q_lo": pl.q_lo, "q_hi": pl.q_hi, "calls": [[b.direction.slot, b.n_queries] for b in pl.batches]}
+    # the library's host threads as THIS rank's process sizes them (no device needed): parts per host loop = min(affinity, cgroup quota)
+    # / LOCAL_WORLD_SIZE -- the ranks of a node share its CPUs
+    import ctypes as C
+
+    from lambda_amd import capi
+
+    wdt, granted, lws = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    capi.load().lx_host_threads_info(C.byref(wdt), C.byref(granted), C.byref(lws))
+    mine = {"rank": rank, "q_lo": pl.q_lo, "q_hi": pl.q_hi, "calls": [[b.direction.slot, b.n_queries] for b in pl.batches],
+            "host_threads": wdt.value, "granted_cpus": granted.value, "local_world_size": lws.value}
     plans = [mine]
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -466,20 +481,32 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
 
     from lambda_amd import capi, synth, workloads
 
-    w = workloads.WORKLOADS[2]
+    # --config 1: the protein list of the metric's own program (searchp BLOSUM62, configs[1]: 100 000 queries x ~32 windows);
+    # default (and --config 2): the read set of configs[2]
+    protein = getattr(args, "config", None) == 1 and getattr(args, "config_given", False)
+    w = workloads.WORKLOADS[1 if protein else 2]
     d = w.directions[0]
     h = capi.Handle(local_rank)
     m_, ma, mi, go, ge = d.scoring
     h.set_scoring(capi.builtin_scoring(m_, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
     h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
     ka = capi.karlin_params(*w.karlin)
-    q, qoff, qlen, qorig, s, soff, slen, m = synth.make_seed_list_np(args.iterate_reads, args.iterate_mbp, seed=0x1A3BDA03 + rank)
-    params = capi.SearchParams(w.max_evalue, -1, 0, int(slen.sum()), 0, 2, 1, 0, capi.LX_FRAMES_REVCOMP, capi.LX_FRAMES_NONE, ka)
+    if protein:
+        n_q = args.iterate_queries
+        q, qoff, qlen, qorig, s, soff, slen, m = synth.make_protein_seed_list_np(n_q, seed=w.seed + rank, lq=w.lq, homologs=w.windows // 2, spurious=w.windows // 2)
+        frames = 1
+        # (dbTotalLength is configs[1]'s -- a Swiss-Prot-sized database, SURVEY.md section 8d -- whatever the resident subject set holds: the
+        # database only enters through it, src/search_algo.hpp:317-319)
+        params = capi.SearchParams(w.max_evalue, -1, 0, w.db_length, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    else:
+        q, qoff, qlen, qorig, s, soff, slen, m = synth.make_seed_list_np(args.iterate_reads, args.iterate_mbp, seed=0x1A3BDA03 + rank)
+        frames = 2
+        params = capi.SearchParams(w.max_evalue, -1, 0, int(slen.sum()), 0, 2, 1, 0, capi.LX_FRAMES_REVCOMP, capi.LX_FRAMES_NONE, ka)
     h.set_subjects(s)
     on_dev = args.entry != "host"
     if on_dev:
         h.set_subject_seqs(soff, slen)
-        h.set_queries(q, qoff, qlen, qorig, 2)
+        h.set_queries(q, qoff, qlen, qorig, frames)
         d_m = torch.from_numpy(m.view(np.uint8).copy()).to(dev)
         torch.cuda.synchronize()
     import ctypes as C
@@ -514,7 +541,7 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
 
     # hints a search has before the call: the seeding stage's match count; windows and records as a share of it (this list: 7.6 matches
     # per window, 12.7 per record) with a margin -- estimates that fall short only move an allocation back into the call
-    hints = (len(m), len(m) // 7, len(m) // 12, (len(m) // 12) * 160)
+    hints = (len(m), len(m) // 2, len(m) // 4, (len(m) // 4) * 160) if protein else (len(m), len(m) // 7, len(m) // 12, (len(m) // 12) * 160)
     stats = None
     for _ in range(max(args.warmup, 1)):
         r, _ = timed_call()
@@ -532,7 +559,7 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
             h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
             h.set_subjects(s)
             h.set_subject_seqs(soff, slen)
-            h.set_queries(q, qoff, qlen, qorig, 2)
+            h.set_queries(q, qoff, qlen, qorig, frames)
             h.reserve(*hints)
             setup.append(time.perf_counter() - t0)
         r, dt = timed_call()
@@ -567,14 +594,19 @@ def iterate_path(args, world, rank, local_rank, dev, use_dist):
         print(json.dumps({
             "metric": ("ms per FIRST call of a fresh handle" if args.cold and on_dev else "ms per call")
                       + " of the Level-2 driver (iterateMatchesFullSimd: widen + sort + merge + unique, pass 1, filter, pass 2, records) on a "
-                      + ("DEVICE match list, lx_iterate_matches_dev" if on_dev else "HOST match list, lx_iterate_matches") + "; searchn scheme of configs[2]",
+                      + ("DEVICE match list, lx_iterate_matches_dev" if on_dev else "HOST match list, lx_iterate_matches")
+                      + ("; searchp BLOSUM62 scheme of configs[1]" if protein else "; searchn scheme of configs[2]"),
             "value": round(dt / args.steps * 1e3, 3), "unit": "ms", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
             "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_min": round(min(times) * 1e3, 3), "ms_max": round(max(times) * 1e3, 3),
             "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f16x2 (exact small integers) + int32 + u64 sort words",
             "data": "synthetic",
-            "config": {"workload": f"seed list of {args.iterate_reads} reads x {int(qorig[0])} bp (two query frames each) against {args.iterate_mbp:g} Mbp in "
-                                   f"{len(soff)} contigs: {len(m)} matches in the order a seeding kernel's lanes emit them -> {n_win} windows "
+            "config": {"workload": (f"seed list of {len(qoff)} queries x {int(qorig[0])} aa against {len(soff)} proteins ({s.size / 1e6:.1f} M residues resident; "
+                                    f"dbTotalLength {w.db_length} as configs[1] states): " if protein else
+                                    f"seed list of {args.iterate_reads} reads x {int(qorig[0])} bp (two query frames each) against {args.iterate_mbp:g} Mbp in "
+                                    f"{len(soff)} contigs: ")
+                                   + f"{len(m)} matches in the order a seeding kernel's lanes emit them -> {n_win} windows "
                                    f"({xs[2] / 1e9:.1f} Gcells) -> {st.num_ext_ali} traced -> {n_hsp} HSPs; E <= {w.max_evalue:g}",
+                       "baseline_config": w.key,
                        "entry_point": "lx_iterate_matches_dev (matches in device memory, sequence sets resident: lx_set_queries / lx_set_subjects / "
                                       "lx_set_subject_seqs)" if on_dev else "lx_iterate_matches (host buffers, subjects resident)",
                        "matches": len(m), "windows": int(n_win), "traced": int(st.num_ext_ali), "hsps": n_hsp, "records_checksum": checksum,

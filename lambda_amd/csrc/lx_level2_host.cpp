@@ -1087,11 +1087,17 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         (rc = ensure(h, h->d_ext_all, n_matches * sizeof(lx_extension) + 16)) || (rc = ensure(h, h->d_min_all, n_matches * sizeof(int32_t) + 16)) ||
         (rc = ensure_pinned(h, l2.p_cnt, 16 * sizeof(uint64_t))) || (rc = ensure(h, l2.d_cut, ((size_t)l2.max_evlen + 1) * sizeof(int32_t) + 16)))
         return rc;
-    uint64_t const nwf = (n_windows + 15) / 16, entries = n_windows + n_windows / 64 + 8192;
-    if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 16)))
+    // (the plan: the solo packing takes a wavefront per 16 windows; the free packing of a protein list is bounded by its own formula and
+    // has a workspace)
+    int const      slot_set    = h->have_sc[0] ? 0 : h->have_sc[1] ? 1 : -1;
+    bool const     free_plan   = slot_set >= 0 && !solo_plan_applies(h, slot_set) && free_plan_applies(h, slot_set) && n_windows > 0;
+    uint64_t const nwf_solo    = (n_windows + 15) / 16;
+    uint64_t const nwf         = free_plan ? lx::fp_wavefront_bound(n_windows, l2.q_len.size(), 4) : nwf_solo, entries = n_windows + n_windows / 64 + 8192;
+    if ((rc = ensure(h, l2.d_plan, nwf * 16 * sizeof(uint32_t) + 16)) || (rc = ensure(h, l2.d_wf, 2 * nwf * sizeof(uint32_t) + 64)) ||
+        (free_plan && (rc = ensure(h, l2.d_fp, lx::fp_workspace_bytes(n_windows, l2.q_len.size(), 4) + 64))))
         return rc;
-    l2.wf_pan.reserve(nwf);
-    l2.wf_maxs.reserve(nwf);
+    l2.wf_pan.reserve(nwf_solo);
+    l2.wf_maxs.reserve(nwf_solo);
     hm.mark("list work");
     // ---- the records (RecordsJob)
     if ((rc = ensure(h, l2.d_surv_hsp, entries * sizeof(lx_hsp))) || (rc = ensure(h, l2.d_surv_src, entries * sizeof(uint32_t))) ||
@@ -1114,7 +1120,8 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
     // windows of up to three times the ordinary length (what a merged window comes to, src/search_algo.hpp:1153-1157)
     {
         uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
-        uint64_t const slots  = std::min<uint64_t>(nwf * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
+        uint64_t const nwf_x  = free_plan ? nwf_solo + nwf_solo / 8 + 64 : nwf_solo; // (what a free-packing plan comes to, not its bound)
+        uint64_t const slots  = std::min<uint64_t>(nwf_x * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
         uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(1);
         uint64_t const max_q  = std::max<uint64_t>(1, ((uint64_t)l2.max_qlen + panel - 1) / panel) * panel;
         // (the longest ORDINARY window, query + band on either side, :919-938: a list whose merged windows are longer grows its first chunk's
@@ -1125,7 +1132,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
         uint64_t const slot_b = max_q / panel * (lx::ckpt16_slot_dwords(1, (uint32_t)steps) + lx::ckpt_slot_dwords(1, (uint32_t)steps) / 8) * 4;
         if ((rc = ensure(h, h->d_score_all, n_windows * sizeof(int32_t) + 16)))
             return rc;
-        unsigned const lanes = nwf * 16 > slots ? 2 : 1;
+        unsigned const lanes = nwf_x * 16 > slots ? 2 : 1;
         for (unsigned L = 0; L < lanes; ++L)
         {
             lx_handle::XbLane & ln = h->xb[L];

@@ -277,3 +277,78 @@ def make_seed_list_np(n_reads: int, genome_mbp: float, seed: int, read_len: int 
     # lanes own reads and finish in no particular order: blocks of a few thousand reads' matches, shuffled
     blk = np.argsort(rng.permutation(len(m) // 4096 + 1).repeat(4096)[:len(m)] * (1 << 32) + m["qryId"] // 128, kind="stable")
     return q_res, q_off, q_len, q_orig_len, s_res, s_off, s_len, m[blk]
+
+
+def make_protein_seed_list_np(n_queries: int, seed: int, lq: int = 150, homologs: int = 16, spurious: int = 16, seeds_per_homolog: int = 4,
+                              alphabet: np.ndarray = STD20, sub_rate: float = 0.13, indel_rate: float = 0.02):
+    """A seed list of the kind `lambda3 searchp` hands to iterateMatches (/root/reference/src/search_algo.hpp:1364-1385) at BASELINE
+    configs[1]'s size -- make_seed_list_np's protein twin: queries of `lq` residues in families of `homologs` members (an ancestor
+    with `sub_rate` substitutions each); a subject set of as many proteins (lengths log-normal around 300), each
+    holding one family member with substitutions AND indels (query against region: ~25 % substitutions, 2 % indels) between random
+    flanks.  Per query: `seeds_per_homolog` seed hits on the diagonal of each of its family's `homologs` regions (shifted where an
+    indel lies before them) and `spurious` single hits anywhere -- after _widenAndPreprocessMatches (:1136-1175) about homologs +
+    spurious = 32 windows per query, half of them homologous: the list the headline batch stands for.  Returns q_res, q_off, q_len,
+    q_orig_len, s_res, s_off, s_len, matches (MATCH_DTYPE, in the arbitrary order a seeding kernel's lanes emit them)."""
+    from .capi import MATCH_DTYPE
+
+    rng = np.random.default_rng(seed)
+    na = len(alphabet)
+    nf = (n_queries + homologs - 1) // homologs
+    anc = rng.integers(0, na, (nf, lq), dtype=np.uint8)
+    fam = np.arange(n_queries) // homologs
+    # queries: substitutions only (they keep the length)
+    q_idx = anc[fam]
+    sub = rng.integers(0, 65536, q_idx.shape, dtype=np.uint16) < np.uint16(sub_rate * 65536)
+    q_idx[sub] = rng.integers(0, na, int(sub.sum()), dtype=np.uint8)
+    q_res = alphabet[q_idx].reshape(-1).astype(np.uint8)
+    q_len = np.full(n_queries, lq, dtype=np.uint64)
+    q_off = np.arange(n_queries, dtype=np.uint64) * np.uint64(lq)
+    # subjects: one region each (region j belongs to family j // homologs), random elsewhere
+    n_subj = nf * homologs
+    lr = lq + 8  # region slots: room for the net shift of the indels
+    s_len = np.clip(rng.lognormal(math.log(300.0), 0.6, n_subj), lr + 24, 2000).astype(np.uint64)
+    s_off = np.concatenate([[0], np.cumsum(s_len)[:-1]]).astype(np.uint64)
+    s_idx = rng.integers(0, na, int(s_len.sum()), dtype=np.uint8)
+    pos = (rng.random(n_subj) * (s_len - lr).astype(np.float64)).astype(np.int64)  # where the region begins in its subject
+    src_all = np.empty((n_subj, lr), dtype=np.int16)  # ancestor position copied to each region position (-1: none)
+    for lo in range(0, n_subj, 1 << 16):
+        hi = min(n_subj, lo + (1 << 16))
+        ev = rng.random((hi - lo, lr))
+        dele = ev < indel_rate / 2
+        ins = (ev >= indel_rate / 2) & (ev < indel_rate)
+        src = np.arange(lr)[None, :] + np.cumsum(dele, axis=1) - np.cumsum(ins, axis=1)
+        inside = (src >= 0) & (src < lq) & ~ins
+        copied = anc[(np.arange(lo, hi) // homologs)[:, None], np.clip(src, 0, lq - 1)]
+        keep = inside & (rng.integers(0, 65536, src.shape, dtype=np.uint16) >= np.uint16(sub_rate * 65536))
+        at = (s_off[lo:hi].astype(np.int64) + pos[lo:hi])[:, None] + np.arange(lr)[None, :]
+        s_idx[at[keep]] = copied[keep]
+        src_all[lo:hi] = np.where(inside, src, -1)
+    s_res = alphabet[s_idx].astype(np.uint8)
+    # seed hits: query q against region 16 fam(q) + h, at region positions whose ancestor position is known
+    L = 10
+    k = seeds_per_homolog
+    reg = (fam[:, None] * homologs + np.arange(homologs)[None, :]).reshape(-1)  # [n_queries * homologs]
+    qq = np.repeat(np.arange(n_queries), homologs)
+    m1 = np.zeros(len(reg) * k, dtype=MATCH_DTYPE)
+    rp = rng.integers(4, lr - L - 4, (len(reg), k))
+    qs = src_all[reg[:, None], rp].astype(np.int64)
+    ok = ((qs >= 0) & (qs <= lq - L)).reshape(-1)
+    m1["qryId"] = np.repeat(qq, k)
+    m1["subjId"] = np.repeat(reg, k)
+    m1["qryStart"] = np.clip(qs.reshape(-1), 0, lq - L)
+    m1["qryEnd"] = m1["qryStart"] + L
+    m1["subjStart"] = np.repeat(pos[reg], k) + rp.reshape(-1)
+    m1["subjEnd"] = m1["subjStart"] + L
+    m1 = m1[ok]
+    ns = n_queries * spurious
+    m2 = np.zeros(ns, dtype=MATCH_DTYPE)
+    m2["qryId"] = np.repeat(np.arange(n_queries), spurious)
+    m2["subjId"] = rng.integers(0, n_subj, ns)
+    m2["qryStart"] = rng.integers(0, lq - L, ns)
+    m2["qryEnd"] = m2["qryStart"] + L
+    m2["subjStart"] = (rng.random(ns) * (s_len[m2["subjId"]] - L).astype(np.float64)).astype(np.uint64)
+    m2["subjEnd"] = m2["subjStart"] + L
+    m = np.concatenate([m1, m2])
+    # lanes own queries and finish in no particular order: blocks of a few thousand matches, shuffled
+    blk = np.argsort(rng.permutation(len(m) // 4096 + 1).repeat(4096)[:len(m)] * (1 << 32) + m["qryId"] // 128, kind="stable")
+    return q_res, q_off, q_len, q_len.copy(), s_res, s_off, s_len, m[blk]

@@ -30,6 +30,16 @@ def test_plain_launch_with_two_gpus_spawns_two_ranks():
     assert "configs[3]" in d["config"]["workload"] and "200 aa" in d["config"]["workload"]
 
 
+def test_ranks_of_a_node_share_its_cpus():
+    """One process per GPU: every rank's library sizes its host threads to the granted CPUs divided by LOCAL_WORLD_SIZE (eight
+    ranks must not start eight full pools on the CPUs of one box)."""
+    d = run_bench("--gpus", "8", "--config", "3", "--dry-run", "--total-queries", "8000")
+    assert d["n_gpus"] == 8 and len(d["ranks"]) == 8
+    for r in d["ranks"]:
+        assert r["local_world_size"] == 8 and 1 <= r["host_threads"] <= max(1, r["granted_cpus"] // 8), r
+    assert sum(r["host_threads"] for r in d["ranks"]) <= max(8, d["ranks"][0]["granted_cpus"])
+
+
 def test_single_rank_default_is_the_headline_config():
     d = run_bench("--dry-run")
     assert d["n_gpus"] == 1 and d["scaling"] == "weak"

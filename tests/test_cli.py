@@ -480,19 +480,20 @@ def test_devices_split_gives_identical_output(tmp_path):
     db, qry = tmp_path / "db.fasta", tmp_path / "q.fasta"
     outs = {}
     for tag, extra in (("one", ["--devices", "0", "-t", "1"]), ("two", ["--devices", "0,0"]), ("three", ["--devices", "0", "-t", "3"]),
-                       ("two-five", ["--devices", "0,0", "-t", "5"])):
+                       ("two-five", ["--devices", "0,0", "-t", "5"]), ("eight", ["--devices", "0,0,0,0,0,0,0,0"])):
         for ext in ("m8", "sam"):
             out = tmp_path / f"{tag}.{ext}"
             # (--version-to-outputfile 0, as the reference's own CLI tests pass it: no @PG line with the command line in the SAM header)
             r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(out), "--version-to-outputfile", "0"] + extra,
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr
+            assert ("8 handle(s)" in r.stderr) == (tag == "eight")
             assert ("2 handle(s)" in r.stderr) == tag.startswith("two") and ("3 host thread(s)" in r.stderr) == (tag == "three"), r.stderr
             assert ("1 host thread(s)" in r.stderr) == (tag == "one") and "lambda3 times [ms]" in r.stderr, r.stderr
             outs[(tag, ext)] = out.read_bytes()
     assert len(outs[("one", "m8")].splitlines()) >= 50
     for ext in ("m8", "sam"):
-        assert outs[("one", ext)] == outs[("two", ext)] == outs[("three", ext)] == outs[("two-five", ext)]
+        assert outs[("one", ext)] == outs[("two", ext)] == outs[("three", ext)] == outs[("two-five", ext)] == outs[("eight", ext)]
     r = subprocess.run([str(_cli()), "searchp", "-q", str(qry), "-d", str(db), "-o", str(tmp_path / "x.m8"), "--devices", "7"], capture_output=True, text=True)
     assert r.returncode != 0 and "device_id 7 out of range" in r.stderr
 

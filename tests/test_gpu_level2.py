@@ -504,6 +504,80 @@ def test_level2_at_the_size_it_is_benched_at(handle, oracle):
         assert abs(g["bit_score"] - wb) <= 1e-6 * abs(wb) and abs(g["e_value"] - we) <= 1e-6 * abs(we), r  # the contract: 1e-6 relative
 
 
+def test_level2_on_the_protein_list_at_the_size_it_is_benched_at(handle, oracle):
+    """bench.py --iterate --config 1's list (synth.make_protein_seed_list_np: BASELINE configs[1] -- 100 000 queries x 150 aa, 7.8 M matches ->
+    3.2 M windows, 32 per query -- searchp BLOSUM62, the metric's own program): the plan of the sweep is made on the device
+    (lx_plan_free.hip: four queries per wavefront), nothing of the window list comes to the host.  Against the oracle: ALL windows of
+    _widenAndPreprocessMatches (/root/reference/src/search_algo.hpp:1136-1175), the filter's statistics and the survivors against the oracle's
+    scores of all windows (:1251-1283), order and scores of every record (:1229-1235, :1299), 4 000 sampled records field by field against
+    the oracle's alignments (:1296-1325)."""
+    from lambda_amd import workloads
+
+    w = workloads.WORKLOADS[1]
+    d = w.directions[0]
+    m_, ma, mi, go, ge = d.scoring
+    sc_p = capi.builtin_scoring(m_, match=ma, mismatch=mi, gap_open=go, gap_extend=ge)
+    handle.set_scoring(sc_p, d.slot)
+    osc = oracle_lib.scoring_from(sc_p)
+    ka = capi.karlin_params(*w.karlin)
+    oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
+    q, qoff, qlen, qorig, s, soff, slen, m = synth.make_protein_seed_list_np(w.queries_total, seed=w.seed, lq=w.lq, homologs=w.windows // 2, spurious=w.windows // 2)
+    db_total = w.db_length
+    params = capi.SearchParams(w.max_evalue, -1, 0, db_total, 0, 1, 1, 0, capi.LX_FRAMES_NONE, capi.LX_FRAMES_NONE, ka)
+    handle.set_subjects(s)
+    handle.set_subject_seqs(soff, slen)
+    handle.set_queries(q, qoff, qlen, qorig, 1)
+    d_m = _to_device(m)
+    want = oracle.widen_and_preprocess(m.astype(oracle_lib.MATCH_DTYPE), qlen, slen)
+    got = handle.widen_and_preprocess_dev(d_m, len(m))
+    assert len(got) == len(want) and 3_100_000 < len(want) < 3_300_000
+    for f in ("qryId", "subjId", "qryStart", "qryEnd", "subjStart", "subjEnd"):
+        assert (got[f] == want[f]).all(), f
+    bms, ops, stats = handle.iterate_matches_dev(d_m, len(m), params)
+    assert "sweep_mq_kernel" in handle.last_kernel_name()  # (the multi-query sweep over the device plan, not the host-planned path)
+    assert stats.num_ext_score == len(m) and stats.hits_duplicate == len(m) - len(want)
+    ext = np.zeros(len(want), dtype=capi.EXT_DTYPE)
+    ext["q_off"], ext["q_len"] = qoff[want["qryId"]], qlen[want["qryId"]]
+    ext["s_off"] = soff[want["subjId"]] + want["subjStart"]
+    ext["s_len"] = want["subjEnd"] - want["subjStart"]
+    scores = oracle.score_batch(q, s, ext, osc, threads=8, simd=True)
+    ql = int(qorig[0])
+    adj = oracle.length_adjustment(db_total, ql, oka)
+    smax = int(scores.max())
+    passes = np.array([oracle.evalue(sc_, ql - adj, db_total - adj, oka) <= w.max_evalue for sc_ in range(smax + 1)])
+    cut = int(np.argmax(passes))
+    assert passes[cut:].all() and not passes[:cut].any()
+    surv = np.nonzero(scores >= cut)[0]
+    assert stats.num_ext_ali == len(surv) and stats.failed_evalue == len(want) - len(surv) and stats.failed_bitscore == 0 and stats.failed_identity == 0
+    assert len(bms) == len(surv) > 1_400_000
+    key = np.lexsort((surv, ext["s_len"][surv], ext["q_len"][surv], want["qryId"][surv]))
+    order = surv[key]
+    assert (bms["qry_id"] == want["qryId"][order]).all() and (bms["subj_id"] == want["subjId"][order]).all()
+    assert (bms["score"] == scores[order]).all()
+    assert (bms["n_qid"] == bms["qry_id"]).all() and (bms["q_frame"] == 0).all() and (bms["s_frame"] == 0).all()
+    n_ops = bms["n_ops"].astype(np.int64)
+    assert (bms["alignment_length"] == n_ops).all()
+    assert (bms["num_matches"] + bms["num_mismatches"] + bms["num_gap_opens"] + bms["num_gap_extensions"] == n_ops).all()
+    assert (bms["num_positives"] >= bms["num_matches"]).all()
+    assert (bms["q_end"] - bms["q_start"] + bms["s_end"] - bms["s_start"] == 2 * (bms["num_matches"] + bms["num_mismatches"]) + bms["num_gap_opens"] + bms["num_gap_extensions"]).all()
+    assert (bms["s_start"] >= want["subjStart"][order]).all() and (bms["s_end"] <= want["subjEnd"][order]).all() and (bms["q_end"] <= ql).all()
+    assert (np.diff(bms["ops_off"].astype(np.int64)) == n_ops[:-1]).all() and len(ops) == len(bms)
+    rng = np.random.default_rng(12)
+    for r in np.sort(rng.choice(len(bms), 4000, replace=False)):
+        x = ext[order[r]]
+        qs, ss = q[int(x["q_off"]): int(x["q_off"]) + int(x["q_len"])], s[int(x["s_off"]): int(x["s_off"]) + int(x["s_len"])]
+        hsp, oops = oracle.align(qs, ss, osc)
+        st = oracle.alignment_stats(qs, ss, hsp, oops, osc, 0)
+        g = bms[r]
+        assert (int(g["score"]), int(g["q_start"]), int(g["q_end"]), int(g["s_start"]) - int(want["subjStart"][order[r]]), int(g["s_end"]) - int(want["subjStart"][order[r]])) == \
+               (hsp.score, hsp.q_begin, hsp.q_end, hsp.s_begin, hsp.s_end), r
+        assert ops[r] == oops, r
+        assert (int(g["num_matches"]), int(g["num_mismatches"]), int(g["num_positives"]), int(g["num_gap_opens"]), int(g["num_gap_extensions"])) == \
+               (st.num_matches, st.num_mismatches, st.num_positives, st.num_gap_opens, st.num_gap_extensions), r
+        wb, we = oracle.bitscore(hsp.score, oka), oracle.evalue(hsp.score, ql - adj, db_total - adj, oka)
+        assert abs(g["bit_score"] - wb) <= 1e-6 * abs(wb) and abs(g["e_value"] - we) <= 1e-6 * abs(we), r
+
+
 def test_device_list_without_the_multi_query_plan_falls_back_to_the_host_threads(handle):
     """LX_OPT_MQ_SWEEP = 0 (or a list the pipeline serves with the one-query-per-wavefront kernels): the survivors come down and the host
     threads make the records -- the same bytes as with the sweep's plan and the records kernels."""
