@@ -633,9 +633,10 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             std::vector<RecordsJob::Range> ranges;
             {
                 uint64_t const forced = lx::dev_aids().l2_ranges;
-                uint64_t const R      = !records_on_device ? 1 : forced ? forced : n < 300000 ? 1 : std::min<uint64_t>(4, n / 2000000 + 2);
+                uint64_t const R      = !records_on_device ? 1 : forced ? forced : n < 300000 ? 1 : std::min<uint64_t>(4, n / 4000000 + 2);
                 // (measured on 1.25 M windows, bench.py --iterate: 1 range 11.8, 2 ranges 10.8-11.4, 3 ranges 11.3-11.9, 4 ranges 11.9 ms: a
-                // range costs a sweep's tail, a backtrace's tail and the records kernels' thirty launches)
+                // range costs a sweep's tail, a backtrace's tail and the records kernels' thirty launches; the protein list of bench.py --iterate
+                // --config 1, 3.2 M windows: 1 range 29.1, 2 ranges 24.6, 3 ranges 24.9, 4 ranges 25.5 ms)
                 uint64_t       lo     = 0;
                 int const      qF     = std::max(1, params->qry_num_frames);
                 for (uint64_t k = 1; k < R; ++k)
