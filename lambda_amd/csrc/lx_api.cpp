@@ -29,41 +29,14 @@ lx::DevAids const & lx::dev_aids()
         };
         auto set = [](char const * name) { return getenv(name) != nullptr; };
         DevAids a{};
-        a.pair_lds_limit    = (size_t)num("LX_PAIR_LDS_LIMIT", 24 * 1024);
-        a.force_score_cfg   = (int)num("LX_FORCE_SCORE_CFG", -1);
-        a.force_ckpt_cfg    = (int)num("LX_FORCE_CKPT_CFG", 0);
-        a.force_mq_cfg      = (int)num("LX_FORCE_MQ_CFG", 0);
-        a.mq_set            = (int)num("LX_MQ_SET", 7) & 7;
-        if (a.mq_set == 0)
-            a.mq_set = 7;
-        a.trace_overlap     = num("LX_TRACE_OVERLAP", 0) != 0;
-        a.trace_chunks      = (uint64_t)std::max(1ll, num("LX_TRACE_CHUNKS", 1));
-        a.no_wide_strips    = set("LX_NO_WIDE_STRIPS");
-        a.no_wide_compact   = set("LX_NO_WIDE_COMPACT");
-        a.no_i16_sweep      = set("LX_NO_I16_SWEEP");
-        a.pass2_mode        = set("LX_PASS2_MODE") ? (int)std::min(std::max(num("LX_PASS2_MODE", 2), 0ll), 2ll) : -1;
-        a.host_threads      = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
-        a.extend_no_classes = set("LX_EXTEND_NO_CLASSES");
-        a.extend_no_sort    = set("LX_EXTEND_NO_SORT");
-        a.extend_no_mq      = set("LX_EXTEND_NO_MQ");
-        a.mq_no_narrow      = set("LX_MQ_NO_NARROW");
-        a.mq_no_solo        = set("LX_MQ_NO_SOLO");
-        a.mq_no_wide        = set("LX_MQ_NO_WIDE");
-        a.mq_no_merge       = set("LX_MQ_NO_MERGE");
-        a.mq_no_wfslots     = set("LX_MQ_NO_WFSLOTS");
-        a.mq_no_two_calls   = set("LX_MQ_NO_TWO_CALLS");
-        a.mq_no_longest_first = set("LX_MQ_NO_LONGEST_FIRST");
-        a.iterate_on_host   = set("LX_ITERATE_ON_HOST");
-        a.mq_merge_below    = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
-        a.extend_run        = (num("LX_EXTEND_RUN", 0) == 8 || num("LX_EXTEND_RUN", 0) == 16) ? (uint64_t)num("LX_EXTEND_RUN", 0) : 0;
-        a.extend_chunk      = (uint64_t)std::max(1024ll, num("LX_EXTEND_CHUNK", 640 << 10));
-        a.bt_waves_per_cu   = (int)std::max(0ll, num("LX_BT_WAVES_PER_CU", 0));
-        a.bt_tile_at        = (int)num("LX_BT_TILE_AT", 0);
-        a.bt_refill_at      = (int)num("LX_BT_REFILL_AT", 0);
-        a.l2_ranges         = (uint64_t)std::min<long long>(std::max(0ll, num("LX_L2_RANGES", 0)), 64);
-        a.l2_first_pct      = (uint64_t)std::max(0ll, num("LX_L2_FIRST_PCT", 0));
-        a.l2_no_rank        = set("LX_L2_NO_RANK");
-        a.host_timing       = set("LX_HOST_TIMING");
+        a.host_threads    = (unsigned)std::max(0ll, num("LX_HOST_THREADS", 0));
+        a.mq_no_wide      = set("LX_MQ_NO_WIDE");
+        a.mq_merge_below  = (uint64_t)std::max(0ll, num("LX_MQ_MERGE_BELOW", 0));
+        a.iterate_on_host = set("LX_ITERATE_ON_HOST");
+        a.bt_tile_at      = (int)num("LX_BT_TILE_AT", 0);
+        a.bt_refill_at    = (int)num("LX_BT_REFILL_AT", 0);
+        a.l2_ranges       = (uint64_t)std::min<long long>(std::max(0ll, num("LX_L2_RANGES", 0)), 64);
+        a.host_timing     = set("LX_HOST_TIMING");
         return a;
     }();
     return aids;
@@ -131,14 +104,11 @@ int bind(lx_handle * h)
 // (24 KiB; protein profiles too: 12.8 vs 14.0 ms (pass 1), 16.6 vs 19.1 ms (sweep) for runs of 8)
 size_t pair_lds_limit()
 {
-    return lx::dev_aids().pair_lds_limit;
+    return 24 * 1024;
 }
 
 int pick_cfg(uint32_t qlen, bool shared)
 {
-    int const forced = lx::dev_aids().force_score_cfg; // development aid: measure a geometry on a shape it is not picked for
-    if (forced >= 0)
-        return forced;
     if (shared)
     {
         if (qlen <= 64)
@@ -192,9 +162,6 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
         return 1;
     if (max_q <= p2)
         return 2;
-    int const forced = lx::dev_aids().force_ckpt_cfg; // development aid
-    if (forced == 1 || forced == 2)
-        return forced;
     // (the packed 16-bit sweep is bound by its checkpoint bytes: the 19-column strips of (8,19) store fewer boundary
     // columns -- 400 aa: 0.0134 ms per padded column against 0.0156 for (16,13) with int16-pair slots; with compact codes,
     // which only the (8,19) panels have, 0.0108)
@@ -209,16 +176,10 @@ int ckpt_cfg_for(uint64_t max_q, bool packed16)
 // ragged lists to classes with the same function, so a chunk's geometry is the one its class was formed for.
 int mq_cfg_for(uint64_t max_q)
 {
-    int const forced = lx::dev_aids().force_mq_cfg; // development aid
-    if (forced == 1 || forced == 3 || forced == 5)
-        return forced;
     int    best = 1;
     double best_cost = 1e30;
-    int const set = lx::dev_aids().mq_set; // development aid: bit 0 = (8,19), 1 = (8,13), 2 = (8,11)
     for (int cfg : {1, 5, 3})
     {
-        if (!(set & (cfg == 1 ? 1 : cfg == 3 ? 2 : 4)))
-            continue;
         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cfg);
         double const   C     = (double)panel / 8.0;
         double const   cost  =(double)((std::max<uint64_t>(max_q, 1) + panel - 1) / panel * panel) * (3.75 * C + 12.0) / C;
@@ -413,44 +374,34 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
             return rc0;
         d_score_in = static_cast<int32_t const *>(h->d_trace_score.ptr);
     }
-    // Two trace buffers, so that the backtrace of chunk k may run on stream2 while the forward kernel of chunk k+1
-    // runs on `stream`.  Measured on MI355X (config 2) the overlap buys nothing -- both kernels saturate the chip
-    // (46.5 ms/step serial vs 46.9 ms overlapped) -- so it is off unless LX_TRACE_OVERLAP=1.
-    // Without the overlap one buffer is enough, so a chunk may use the whole budget: as few launches (and kernel
-    // tails) as the budget allows.  In the fused path `n` is the capacity of the survivor list; launches beyond the
-    // device-side count exit at once.
-    bool const     overlap     = lx::dev_aids().trace_overlap;
-    uint64_t const nbuf        = overlap ? 2 : 1;
-    uint64_t       chunk       = std::max<uint64_t>(1, h->opt_trace_bytes / nbuf / std::max<uint64_t>(per_ext, 1));
-    uint64_t const want_chunks = lx::dev_aids().trace_chunks;
-    chunk                      = std::min<uint64_t>(chunk, n / std::max<uint64_t>(want_chunks, 1) + 8);
-    hipStream_t const bstream  = overlap ? h->stream2 : stream;
+    // One trace buffer, forward kernel and backtrace of a chunk one after the other on `stream`: a chunk may use the whole budget --
+    // as few launches (and kernel tails) as the budget allows.  (A backtrace on a second stream beside the next chunk's forward
+    // kernel was measured on config 2: 46.9 against 46.5 ms per step -- both kernels saturate the chip -- and is gone.)  In the fused
+    // path `n` is the capacity of the survivor list; launches beyond the device-side count exit at once.
+    uint64_t chunk = std::max<uint64_t>(1, h->opt_trace_bytes / std::max<uint64_t>(per_ext, 1));
+    chunk          = std::min<uint64_t>(chunk, n + 8);
     // a trace buffer that is already there and holds a fair chunk is used as it is: the fused step sizes this list for the
     // worst case (every extension survives), and growing a buffer of tens of GB costs seconds -- the adaptive mode-1 step
     // after a run of single sweeps would pay that once; chunks beyond the device-side count exit at once
-    if (d_count && h->d_trace.cap / nbuf / std::max<uint64_t>(per_ext, 1) >= 65536)
-        chunk = std::min<uint64_t>(chunk, h->d_trace.cap / nbuf / per_ext / 8 * 8);
+    if (d_count && h->d_trace.cap / std::max<uint64_t>(per_ext, 1) >= 65536)
+        chunk = std::min<uint64_t>(chunk, h->d_trace.cap / per_ext / 8 * 8);
     chunk                      = std::max<uint64_t>(8, (chunk + 7) / 8 * 8);
     int rc;
-    if ((rc = ensure(h, h->d_trace, nbuf * chunk * per_ext)) || (rc = ensure(h, h->d_ends, nbuf * chunk * sizeof(lx::EndCell))))
+    if ((rc = ensure(h, h->d_trace, chunk * per_ext)) || (rc = ensure(h, h->d_ends, chunk * sizeof(lx::EndCell))))
         return rc;
-    LX_HIP(h, hipEventRecord(h->evS, stream));
-    LX_HIP(h, hipStreamWaitEvent(h->stream2, h->evS, 0));
-    uint64_t nchunks = 0;
-    for (uint64_t c0 = 0; c0 < n; c0 += chunk, ++nchunks)
+    for (uint64_t c0 = 0; c0 < n; c0 += chunk)
     {
-        int const       b = overlap ? (int)(nchunks & 1) : 0; // one buffer without the overlap (stream order protects it)
         lx::TraceParams p{};
         p.q_res          = static_cast<uint8_t const *>(d_q);
         p.s_res          = static_cast<uint8_t const *>(d_s);
         p.ext            = d_ext + c0;
         p.n              = std::min<uint64_t>(chunk, n - c0);
         p.sc             = h->sc_dev[slot];
-        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr) + (uint64_t)b * chunk * stride;
+        p.trace          = static_cast<uint32_t *>(h->d_trace.ptr);
         p.slot_stride    = stride;
         p.steps_cap      = steps_cap;
         p.panels_cap     = panels_cap;
-        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr) + (uint64_t)b * chunk;
+        p.ends           = static_cast<lx::EndCell *>(h->d_ends.ptr);
         p.out_hsp        = (d_src && !by_pos) ? d_hsp : d_hsp + c0;
         p.out_ops        = d_ops;
         p.ops_off        = !d_ops_off ? nullptr : (d_src && !by_pos) ? d_ops_off : d_ops_off + c0;
@@ -473,19 +424,14 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
         p.band_diag      = h->band_dev ? (d_src ? h->band_dev : h->band_dev + c0) : nullptr; // indexed like the caller's list
         p.shared_profile = (h->opt_band && cfg == 0) ? 0 : share_slots;
         p.cfg            = cfg;
-        if (nchunks >= 2) // buffer b is free once the backtrace of chunk k-2 has finished
-            LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
         if (panels_cap > 1) // each chunk starts with an empty carry workspace
             LX_HIP(h, hipMemsetAsync(h->d_ws_top, 0, sizeof(uint32_t), stream));
         PhaseTimer ptf(h, stream, 2);
         LX_HIP(h, ckpt ? lx::launch_ckpt_forward(p, stream) : lx::launch_trace_forward(p, stream));
         ptf.close();
-        LX_HIP(h, hipEventRecord(h->evF[b], stream));
-        LX_HIP(h, hipStreamWaitEvent(bstream, h->evF[b], 0));
-        PhaseTimer ptb(h, bstream, 3);
-        LX_HIP(h, ckpt ? lx::launch_ckpt_backtrace(p, bstream) : lx::launch_backtrace(p, bstream));
+        PhaseTimer ptb(h, stream, 3);
+        LX_HIP(h, ckpt ? lx::launch_ckpt_backtrace(p, stream) : lx::launch_backtrace(p, stream));
         ptb.close();
-        LX_HIP(h, hipEventRecord(h->evB[b], bstream));
         {
             char buf[96];
             if (ckpt)
@@ -495,9 +441,6 @@ int lxi::align_dev_impl(lx_handle * h, int slot, void const * d_q, void const * 
             h->last_trace_kernel = buf;
         }
     }
-    // rejoin: everything queued on `stream` after this call sees the finished backtraces
-    for (int b = 0; b < 2 && (uint64_t)b < nchunks; ++b)
-        LX_HIP(h, hipStreamWaitEvent(stream, h->evB[b], 0));
     return LX_OK;
 }
 
@@ -617,7 +560,7 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             sweep_cfg = 3;
         // 153 - 200 columns: 25-column strips of 8-lane groups (16 extensions of one query per wavefront, 7 steps of skew
         // instead of 15, no padded column at 200) where the packed-half sweep applies
-        if (sweep_cfg == 2 && half_ok && !lx::dev_aids().no_wide_strips && o.max_qlen <= (uint64_t)lx::trace_cfg_panel(4) &&
+        if (sweep_cfg == 2 && half_ok && o.max_qlen <= (uint64_t)lx::trace_cfg_panel(4) &&
             o.query_run % 16 == 0)
             sweep_cfg = 4;
         sweep_panels = (uint32_t)std::max<uint64_t>(1, (o.max_qlen + lx::trace_cfg_panel(sweep_cfg) - 1) / lx::trace_cfg_panel(sweep_cfg));
@@ -637,8 +580,7 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
             // Queries wider than a panel: compact codes as well, one part per (8,19) panel, written by the packed int16 kernel
             // (the half-precision one has no carry between panels); what scores beyond the codes' 2046 goes to the int32 launch
             wide_compact = o.f16 && sweep_panels > 1 && sweep_cfg == 1 && o.query_run % 16 == 0 &&
-                           -sc.gap_open <= lx::kC16MaxGap && sc.gap_open <= sc.gap_extend &&
-                           !lx::dev_aids().no_wide_compact && !lx::dev_aids().no_i16_sweep;
+                           -sc.gap_open <= lx::kC16MaxGap && sc.gap_open <= sc.gap_extend;
             half_sweep = half_sweep || wide_compact;
             if (o.f16 && sweep_panels == 1 && -sc.gap_open <= lx::kC16MaxGap &&
                 sc.gap_open <= sc.gap_extend && (sweep_cfg == 1 || sweep_cfg == 3) && !half_sweep && o.query_run % 8 == 0 &&
@@ -671,7 +613,7 @@ lxi::StepPlan lxi::plan_step(SchemeFacts const & sc, StepOptions const & o)
     // No packed-half sweep (queries wider than a panel, gap costs beyond the compact codes, ...): the packed int16 kernel
     // writes the int16-pair slots of the int32 kernel, two extensions per lane group; what fails its range test is left to
     // the int32 launch.  16 extensions of one query per wavefront at (8,19), 8 at (16,13).
-    bool const i16_sweep = sweep && !half_sweep && o.f16 && !lx::dev_aids().no_i16_sweep && o.query_run % (sweep_cfg == 1 ? 16 : 8) == 0 &&
+    bool const i16_sweep = sweep && !half_sweep && o.f16 && o.query_run % (sweep_cfg == 1 ? 16 : 8) == 0 &&
                            sweep_cfg != 3 && sweep_cfg != 4;
     // Adaptive choice (the one-query-per-wavefront sweep; lx_extend_batch's multi-query plan keeps its sweep): few survivors
     // last time -> plain pass 1, checkpoints for the survivors only (mode 1).
@@ -778,45 +720,7 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     if (phases & 1)
         h->plan_surv_frac = h->surv_frac;
     so.surv_frac = h->plan_surv_frac;
-    // Two slot regions (lx_extend_batch's multi-query plan: the pool's long windows first, the streamed ones behind them): the slots
-    // of [0, split.n1) are sized for (q1, s1), those behind for (q2, s2) -- the budget test sees the list as so many slots of the
-    // larger size
-    lx_handle::MqSplit const split = h->mq_split;
-    auto region = [&](StepPlan const & pl, uint64_t max_q, uint64_t max_s, uint32_t & steps, uint32_t & panels) -> uint64_t // dwords per slot
-    {
-        uint64_t const panel = (uint64_t)lx::trace_cfg_panel(pl.cfg);
-        steps  = (uint32_t)((max_s + 8 - 1 + 15) & ~15ull);
-        panels = (uint32_t)std::max<uint64_t>(1, (max_q + panel - 1) / panel);
-        return (uint64_t)panels * (pl.wide ? lx::ckpt_slot_dwords(pl.cfg, steps) : lx::ckpt16_slot_dwords(pl.cfg, steps));
-    };
     StepPlan plan{};
-    uint32_t steps1 = 0, panels1 = 0, steps2 = 0, panels2 = 0;
-    uint64_t stride1 = 0, stride2 = 0;
-    bool     split_on = false;
-    if (split.n1 != 0 && split.n1 < n && split.n1 % 16 == 0)
-    {
-        so.n = 1; // (which sweep, which slot sizes -- the budget test comes with the real footprint)
-        StepPlan const probe = plan_step(facts, so);
-        if (probe.family == kMqSweep && probe.stride != 0)
-        {
-            stride1 = region(probe, split.q1, split.s1, steps1, panels1);
-            stride2 = region(probe, split.q2, split.s2, steps2, panels2);
-            uint64_t const dw = split.n1 * stride1 + (n - split.n1 + 1) * stride2;
-            so.n     = std::max<uint64_t>(1, std::min<uint64_t>(n, dw / probe.stride));
-            StepPlan const again = plan_step(facts, so);
-            // (the same sweep, only a smaller slot count in its budget test -- anything else: one region)
-            if (again.family == kMqSweep && again.cfg == probe.cfg && again.wide == probe.wide && again.share == probe.share && steps1 <= again.steps &&
-                steps2 <= again.steps && panels1 <= again.panels && panels2 <= again.panels && dw * 4 <= so.trace_bytes)
-            {
-                plan     = again;
-                split_on = true;
-                // (room for what the sweep declines: whatever the budget leaves behind the two regions -- not capped by the slot count
-                // the budget test was given)
-                plan.ovf_cap = (plan.may_decline && plan.stride32 != 0) ? std::min<uint64_t>(n, (so.trace_bytes - dw * 4) / (plan.stride32 * 4)) : 0;
-            }
-        }
-        so.n = n;
-    }
     if (tab_on)
     {
         // the chunk's maxima decide the kernel (family, geometry, multi-panel or not) and the layout of the overflow slots; the slots
@@ -834,9 +738,8 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
         }
         else
             plan.ovf_cap = (plan.may_decline && plan.stride32 != 0) ? tab.ovf_cap : 0;
-        split_on = false;
     }
-    else if (!split_on)
+    else
         plan = plan_step(facts, so);
     bool const     shared = plan.shared;
     bool const     sweep = plan.sweep, mq = plan.family == kMqSweep, wide_compact = plan.family == kI16CompactWide;
@@ -853,7 +756,6 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
     // (slots by wavefront: [the wavefronts before slot n0][overflow slots][the wavefronts from n0 on])
     uint64_t const tab_ovf_dw = tab_on ? ovf_cap * sweep_stride32 : 0;
     uint64_t const batch_dw = tab_on       ? tab.dw0
-                              : split_on   ? split.n1 * stride1 + (n - split.n1 + 1) * stride2
                               : wave_slots ? (n + wave_w - 1) / wave_w * wave_w * sweep_stride
                               : half_sweep ? (n + 1) * sweep_stride
                                            : n * sweep_stride;
@@ -916,16 +818,6 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             sp1.pair_share  = std::max(sweep_share, 0);
             if (mq)
             {
-                if (split_on)
-                {
-                    sp1.ckpt_stride  = stride1;
-                    sp1.steps_cap    = steps1;
-                    sp1.split_n      = split.n1;
-                    sp1.ckpt2        = p.trace + split.n1 * stride1;
-                    sp1.ckpt_stride2 = stride2;
-                    sp1.steps_cap2   = steps2;
-                    sp1.panels_cap2  = panels2;
-                }
                 if (tab_on)
                 {
                     sp1.wf_tab = static_cast<lx::WfSlots const *>(tab.dev);
@@ -942,11 +834,11 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
                     sp1.solo  = 1;
                     sp1.nrows = h->sc_host[slot].alphabet_size + 1;
                 }
-                sp1.narrow     = lx::dev_aids().mq_no_narrow ? 0 : 1;
+                sp1.narrow     = 1;
                 sp1.ws         = p.ws;
                 sp1.ws_top     = p.ws_top;
                 sp1.ws_cap     = p.ws_cap;
-                sp1.panels_cap = split_on ? panels1 : sweep_panels;
+                sp1.panels_cap = sweep_panels;
                 LX_HIP(h, lx::launch_sweep_mq(sweep_cfg, sp1, stream));
                 if (tab_on && tab.part == 1)
                 {
@@ -1096,15 +988,6 @@ int lxi::fused_impl(lx_handle * h, int slot, void const * d_q_res, void const * 
             p.ovf        = p.trace + batch_dw; // int16-pair slots of what the packed kernel declined
             p.ovf_stride = sweep_stride32;
         }
-        if (split_on)
-        {
-            p.slot_stride  = stride1;
-            p.steps_cap1   = steps1;
-            p.split_n      = split.n1;
-            p.trace2       = p.trace + split.n1 * stride1;
-            p.slot_stride2 = stride2;
-            p.steps_cap2   = steps2;
-        }
         if (tab_on)
         {
             p.wf_tab  = static_cast<lx::WfSlots const *>(tab.dev);
@@ -1183,8 +1066,6 @@ int lx_create(int device_id, lx_handle ** out)
                     prop.gcnArchName);
 
     lx_handle * h = new lx_handle();
-    if (lx::dev_aids().pass2_mode >= 0) // default of LX_OPT_PASS2_MODE, for A/B runs of unmodified callers
-        h->opt_pass2 = (uint64_t)lx::dev_aids().pass2_mode;
     if (lx::dev_aids().host_threads) // (measurement aid of tools/host_curve.py; a caller uses LX_OPT_HOST_THREADS)
         lxi::HostPool::instance().set_width(lx::dev_aids().host_threads);
     h->device     = device_id;
@@ -1207,9 +1088,6 @@ int lx_create(int device_id, lx_handle ** out)
         for (hipEvent_t * ev : {&ln.ev_up, &ln.ev_k, &ln.ev_cnt})
             if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
                 return bail("hipEventCreate", e);
-    for (hipEvent_t * ev : {&h->evF[0], &h->evF[1], &h->evB[0], &h->evB[1], &h->evS})
-        if ((e = hipEventCreateWithFlags(ev, hipEventDisableTiming)) != hipSuccess)
-            return bail("hipEventCreate", e);
     if ((e = hipMalloc(reinterpret_cast<void **>(&h->d_ws_top), 8 * sizeof(uint32_t))) != hipSuccess)
         return bail("hipMalloc", e);
     if ((e = hipMemset(h->d_ws_top, 0, 8 * sizeof(uint32_t))) != hipSuccess)
@@ -1272,7 +1150,7 @@ void lx_destroy(lx_handle * h)
         for (DevBuf * b : {&l2.d_qres, &l2.d_qoff, &l2.d_qlen, &l2.d_qband, &l2.d_qevlen, &l2.d_soff, &l2.d_slen, &l2.d_pair[0], &l2.d_pair[1], &l2.d_s0[0],
                            &l2.d_s0[1], &l2.d_hist, &l2.d_head, &l2.d_tail, &l2.d_tot, &l2.d_win, &l2.d_cut, &l2.d_cnt, &l2.d_up, &l2.d_plan, &l2.d_wf, &l2.d_qevidx,
                            &l2.d_surv_hsp, &l2.d_surv_src, &l2.d_surv_codes, &l2.d_listat, &l2.d_rec, &l2.d_reccodes, &l2.d_reccnt, &l2.d_tilekeep, &l2.d_tileops,
-                           &l2.d_pre, &l2.d_exp, &l2.d_rank})
+                           &l2.d_pre, &l2.d_exp, &l2.d_rank, &l2.d_fp})
             if (b->ptr)
                 (void)hipFree(b->ptr);
         for (lx_handle::Pinned * b : {&l2.p_cnt, &l2.p_win, &l2.p_up, &l2.p_reccnt, &l2.p_reccodes, &l2.p_rows, &l2.p_plan})
@@ -1284,9 +1162,6 @@ void lx_destroy(lx_handle * h)
     for (lx_handle::Pinned * b : {&h->p_all, &h->p_score_all})
         if (b->ptr)
             (void)hipHostFree(b->ptr);
-    for (hipEvent_t ev : {h->evF[0], h->evF[1], h->evB[0], h->evB[1], h->evS})
-        if (ev)
-            (void)hipEventDestroy(ev);
     for (hipEvent_t ev : h->ev_pool)
         (void)hipEventDestroy(ev);
     if (h->ev0)

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
     }
     int const ge = p.sc->ge, g2 = p.sc->g2;                 // a gap of k characters costs g2 + k ge
     int const ge4 = 4 * p.sc->ge, go4 = 4 * p.sc->go;       // tile DP: values x 4 (go = first gap character)
-    // (per extension since the sweep's slots may lie in two regions of different geometry: TraceParams::split_n)
+    // (per extension: the sweep's slots may be laid out wavefront by wavefront, TraceParams::wf_tab)
     uint64_t panel_dw = Lay::slot_dwords(p.steps_cap), panel16_dw = L16::slot_dwords(p.steps_cap), bnd_dw = Lay::bnd_dwords(p.steps_cap);
 
     // ---- state of the extension this lane is working on
@@ -743,13 +743,6 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
             uint64_t const stride = (uint64_t)t.panels_cap * (c16 ? L16::slot_dwords(t.steps_cap) : Lay::slot_dwords(t.steps_cap));
             slot                  = ((p.split_n != 0 && se >= p.split_n) ? p.trace2 : p.trace) + t.off_dw + (se % 16) * stride;
             steps_e               = t.steps_cap;
-        }
-        else if (p.split_n != 0 && !ovf)
-        {
-            bool const reg2 = se >= p.split_n;
-            steps_e         = reg2 ? p.steps_cap2 : p.steps_cap1;
-            if (reg2)
-                slot = p.trace2 + (se - p.split_n) * p.slot_stride2;
         }
         panel_dw           = Lay::slot_dwords(steps_e);
         panel16_dw         = L16::slot_dwords(steps_e);
@@ -1479,7 +1472,7 @@ static int backtrace_resident_waves()
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess)
             (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        int const per_cu = dev_aids().bt_waves_per_cu > 0 ? dev_aids().bt_waves_per_cu : 4 * LX_BT_WAVES; // 4 SIMDs per CU
+        int const per_cu = 4 * LX_BT_WAVES; // 4 SIMDs per CU
         return std::max(1, cus) * per_cu;
     }();
     return v;

@@ -91,14 +91,6 @@ struct ScoreParams
     int32_t            solo;           // multi-query sweep: 1 = every window has a profile of its own (16 per wavefront: the small alphabets)
     int32_t            wide;           // multi-query sweep: 1 = int16-pair slots (scores beyond the compact codes' 2046 at sweep speed)
     uint32_t *         stat_beyond;    // multi-query sweep: optional counter of the windows that are beyond the compact codes (declined, or scoring > 2046)
-    // multi-query sweep: TWO slot regions in one launch -- extensions [0, split_n) (the plan's pool: the long merged windows) have the
-    // slots ckpt / ckpt_stride / steps_cap / panels_cap, those from split_n on (+ the spare slot n) ckpt2 / ... -- so that one launch
-    // can hold windows of very different lengths without sizing every slot for the longest.  split_n = 0: one region; else a
-    // multiple of 16 (whole wavefronts).
-    uint64_t           split_n;
-    uint32_t *         ckpt2;
-    uint64_t           ckpt_stride2;
-    uint32_t           steps_cap2, panels_cap2;
     // multi-query sweep: slots by wavefront (WfSlots) -- wf_tab[w] for wavefront w of the chunk, slots relative to `ckpt`; the launch
     // covers the wavefronts from wf_lo on (a chunk may be swept by two launches: the plan's pool while the rest is still being planned)
     WfSlots const *    wf_tab;
@@ -220,15 +212,12 @@ struct TraceParams
     uint32_t *           rle_len;     // [list capacity]: code bytes of every position (0 for padding slots / no alignment)
     int32_t            bt_tile_at, bt_refill_at; // checkpoint backtrace scheduling thresholds (0 = the compiled defaults)
     uint32_t *         work_counter;  // checkpoint backtrace: the queue its persistent lanes take list positions from (zeroed per launch)
-    // single-sweep backtrace: the batch's slots in TWO regions (ScoreParams::split_n): extensions (original index) from split_n on
-    // have their slots at trace2 + (index - split_n) * slot_stride2, laid out for steps_cap2 steps; 0 = one region
+    // single-sweep backtrace: the multi-query sweep's slots by wavefront (ScoreParams::wf_tab): extension se has slot se % 16 of
+    // wavefront se / 16; the wavefronts from split_n / 16 on (a chunk swept in two calls: the second launch's slots) count their
+    // offsets from trace2, the others from trace; split_n = 0: all from trace
+    WfSlots const *    wf_tab;
     uint64_t           split_n;
     uint32_t *         trace2;
-    uint64_t           slot_stride2;
-    uint32_t           steps_cap2, steps_cap1; // steps_cap1: region 1's (steps_cap stays what the overflow slots are laid out for)
-    // ... or by wavefront (ScoreParams::wf_tab): extension se has slot se % 16 of wavefront se / 16; wavefronts from split_n / 16 on
-    // count their offsets from trace2 (the second launch's slots), the others from trace
-    WfSlots const *    wf_tab;
 };
 
 // survivor selection between the passes (the filter loop of iterateMatchesFullSimd, src/search_algo.hpp:1251-1283,

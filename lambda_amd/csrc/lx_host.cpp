@@ -680,7 +680,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // out_ops, out_ops_bytes are NULL; lx_extend_batch_list hands the buffers out)
     bool const want_rle = mode >= 1, as_list = mode == 2;
     HostPool::Call const in_flight_call; // (the host threads look for this call's next loop instead of going to sleep between two)
-    bool const wf_slots = !lx::dev_aids().mq_no_wfslots; // multi-query chunks: checkpoint slots by wavefront (lx::WfSlots) instead of by region
     bool       dev_list = false, want_codes = true, by_range = false; // (set where the multi-query plan is known: ResidentInput::keep_on_device)
     h->res_count         = 0;
     h->l2.surv_on_device = false;
@@ -839,7 +838,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     {
         lx_scoring const & sh = h->sc_host[slot];
         use_mq = h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap &&
-                 sh.gap_open <= sh.gap_extend && !lx::dev_aids().extend_no_mq;
+                 sh.gap_open <= sh.gap_extend;
     }
     // the caller's list and cut-offs onto the device (pinned staging, filled by the host threads; scores in caller order zeroed) -- as
     // soon as the multi-query path is known to be taken: the copy runs beside the planning of the pool
@@ -882,7 +881,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // were fillers (configs[2]-sized list: 4.1 M slots for 1.25 M windows).  The plan is then a sort: all windows by (columns per
     // lane, length), longest first, 16 to a wavefront.
     bool const use_solo = preplanned ? !ri->free_packing
-                                     : (use_mq && !lx::dev_aids().mq_no_solo && lx::sweep_mq_lds_bytes(1, h->sc_host[slot].alphabet_size + 1, -1) <= 20 * 1024);
+                                     : (use_mq && lx::sweep_mq_lds_bytes(1, h->sc_host[slot].alphabet_size + 1, -1) <= 20 * 1024);
     if (preplanned)
     {
         if (!use_mq || !as_list)
@@ -929,7 +928,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 ragged_s = ragged_s || sc.ragged;
             }
         }
-        bool const no_classes = lx::dev_aids().extend_no_classes, no_sort = lx::dev_aids().extend_no_sort; // A/B aids
         if (use_mq && cmin == cmax && !ragged_s && h->opt_mq < 2)
         {
             // one geometry, one window length: uniform if every run fills whole wavefronts
@@ -942,7 +940,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         if (use_mq && (rc = upload_list()))
             return rc;
-        if (cmin != cmax && !no_classes && !use_mq)
+        if (cmin != cmax && !use_mq)
         {
             std::vector<uint64_t> at(cmax + 2, 0);
             for (uint64_t k = 0; k < live;)
@@ -975,7 +973,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     newrun[k] = (k == 0 || !same_slice(idx[k], idx[k - 1])) ? 1 : 0;
                             });
         }
-        if (ragged_s && !no_sort && !(use_mq && use_solo)) // (the solo plan sorts all windows itself)
+        if (ragged_s && !(use_mq && use_solo)) // (the solo plan sorts all windows itself)
         {
             run_starts(starts);
             parallel_ranges(starts.size() - 1, nthreads,
@@ -1019,7 +1017,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(mq_cfg);
         uint64_t const P     = std::max<uint64_t>(1, ((uint64_t)lq + panel - 1) / panel);
         int const      rem   = (int)((uint64_t)std::max<uint32_t>(lq, 1) - (P - 1) * panel);
-        int const      code  = lx::dev_aids().mq_no_narrow ? 0 : lx::narrow_code_for(C, 8, rem);
+        int const      code  = lx::narrow_code_for(C, 8, rem);
         return (uint32_t)std::min<uint64_t>(0xfff, (P - 1) * (uint64_t)C + (uint64_t)lx::narrow_strip_cols(C, code));
     };
     std::vector<uint64_t> & pool_at = h->xb_grp; // per run: first position of its pool part
@@ -1076,7 +1074,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     {
                                         uint64_t const panel = (uint64_t)lx::trace_cfg_panel(cand[k]), P = std::max<uint64_t>(1, (lq + panel - 1) / panel);
                                         int const      Cc = (int)panel / 8, rem = (int)(std::max<uint64_t>(lq, 1) - (P - 1) * panel);
-                                        int const      code = lx::dev_aids().mq_no_narrow ? 0 : lx::narrow_code_for(Cc, 8, rem);
+                                        int const      code = lx::narrow_code_for(Cc, 8, rem);
                                         // (a step costs 3.75 instructions per column and 12 besides, whatever the strip width)
                                         c[k] += (double)nw * ((double)(P - 1) * (3.75 * Cc + 12.0) + 3.75 * lx::narrow_strip_cols(Cc, code) + 12.0);
                                     }
@@ -1085,7 +1083,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                                     tc[3 * t + k] = c[k];
                             });
             double best = 1e300;
-            int const set = lx::dev_aids().mq_set, forced = lx::dev_aids().force_mq_cfg;
             for (int k = 0; k < 3; ++k)
             {
                 double c = 0;
@@ -1094,10 +1091,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 // (narrower strips: more panels -- carries, profile builds -- and more tiles per walk in the backtrace; measured on
                 // the ragged list of bench.py: 22.2 / 21.5 ms with 13 / 11 columns against 19.7 ms with 19, at 8 / 10 % fewer cells)
                 c *= cand[k] == 1 ? 1.0 : 1.15;
-                if (!(set & (1 << k)) && forced != cand[k])
-                    continue;
-                if (forced == cand[k])
-                    c = 0;
                 if (c < best)
                 {
                     best   = c;
@@ -1312,7 +1305,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             by_len.resize(pool_wf);
             for (uint64_t w = 0; w < pool_wf; ++w)
                 by_len[w] = (uint32_t)w;
-            if (!lx::dev_aids().mq_no_longest_first)
             {
                 std::vector<uint32_t> & len_key = h->xb_pool_key, & len_tmp = h->xb_pool_tmp;
                 len_key.resize(pool_wf);
@@ -1449,7 +1441,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             (void)hipStreamSynchronize(h->stream3);
             h->mq_cfg_call   = 0;
             h->mq_wide_call  = false;
-            h->mq_split      = lx_handle::MqSplit{};
             h->opt_max_qlen  = qlen;
             h->opt_max_slen  = slen;
             h->opt_query_run = run;
@@ -1470,7 +1461,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
     // headline batch 40.0 against 31.3 ms -- and a chunk's backtrace on a second stream beside the next chunk's sweep -- no gain on
     // the ragged list, 34.9 against 29.0 ms on the headline: kernels side by side cost more than their tails and latencies save)
 
-    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
+    uint64_t const chunk_target = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lxi::kExtendChunk;
     h->ext_bytes.clear();
     uint64_t ops_total = 0; // bytes handed out in h->ext_bytes so far
     double   t_prep = 0, t_issue = 0, t_wait = 0, t_unpack = 0, t_u1 = 0, t_u2 = 0; // LX_HOST_TIMING: where the host's time goes
@@ -1567,7 +1558,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         // padded columns and 0.0108 against 0.0156 ms per column, ckpt_cfg_for in lx_api.cpp, decide)
         double const cost16 = max_q > 208 ? (double)slots16 * (double)((max_q + 151) / 152 * 152) * 1.08 : (double)slots16 * 8.0;
         double const cost8  = max_q > 208 ? (double)slots8 * (double)((max_q + 207) / 208 * 208) * 1.56 : (double)slots8 * 9.0;
-        uint64_t const kRun = lx::dev_aids().extend_run ? lx::dev_aids().extend_run : cost8 < cost16 ? 8 : 16;
+        uint64_t const kRun = cost8 < cost16 ? 8 : 16;
         uint64_t       slots   = 0;
         for (uint64_t g = 0; g <= ngroups; ++g)
         {
@@ -1691,23 +1682,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         pr.max_s   = max_s;
         pr.max_pan = max_pan;
         uint64_t const max_q = (max_pan + panel / 8 - 1) / (panel / 8) * panel; // (whole panels: the slots have one part per panel)
-        // a chunk that begins in the pool and goes on behind it: two slot regions
-        h->mq_split = lx_handle::MqSplit{};
-        if (!wf_slots && !use_solo && w0 < pool_wf && pool_wf < w1)
-        {
-            uint64_t m[2][2] = {{1, 1}, {1, 1}}; // [region][columns per lane, rows]
-            for (uint64_t w = w0; w < w1; ++w)
-            {
-                int const r = w < pool_wf ? 0 : 1;
-                m[r][0]     = std::max<uint64_t>(m[r][0], wf_pan[w]);
-                m[r][1]     = std::max<uint64_t>(m[r][1], wf_maxs[w]);
-            }
-            h->mq_split.n1 = (pool_wf - w0) * kWave;
-            h->mq_split.q1 = (m[0][0] + panel / 8 - 1) / (panel / 8) * panel;
-            h->mq_split.s1 = m[0][1];
-            h->mq_split.q2 = (m[1][0] + panel / 8 - 1) / (panel / 8) * panel;
-            h->mq_split.s2 = m[1][1];
-        }
         t_prep += ms(t0, now());
 
         auto const t1 = now();
@@ -1743,7 +1717,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         h->mq_wide_call = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (force_wide || (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03));
         pr.wide         = h->mq_wide_call;
         h->mq_tab       = lx_handle::MqTab{};
-        if (wf_slots)
         {
             // the chunk's slots by wavefront (lx::WfSlots): every wavefront's sixteen laid out for ITS longest window and widest query
             uint64_t const nw = w1 - w0, pc = panel / 8;
@@ -1910,7 +1883,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         h->opt_max_qlen  = two.max_q;
         h->opt_max_slen  = two.max_s;
         h->opt_query_run = 2;
-        h->mq_split      = lx_handle::MqSplit{};
         h->mq_wide_call  = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && (h->mq_wide_call ? h->mq_decl_frac > 0.01 : h->mq_decl_frac > 0.03);
         pr.wide          = h->mq_wide_call;
         lx::WfSlots * const tab = static_cast<lx::WfSlots *>(ln.p_wft.ptr);
@@ -1984,7 +1956,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         h->opt_max_qlen    = two.max_q;
         h->opt_max_slen    = two.max_s;
         h->opt_query_run   = 2;
-        h->mq_split        = lx_handle::MqSplit{};
         h->mq_wide_call    = pr.wide;
         h->mq_tab          = lx_handle::MqTab{};
         h->mq_tab.dev      = ln.d_wft.ptr;
@@ -2469,19 +2440,19 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
         }
         bool     rows_cleared = false, stream_planned = use_solo || preplanned; // (the solo plan and a device plan are whole before the first chunk)
         uint64_t w0           = 0;
-        // ONE launch for the pool and what follows it (the slots in two regions: lx_handle::MqSplit): the pool is a tenth of the list
+        // ONE launch for the pool and what follows it: the pool is a tenth of the list
         // in wavefronts that run up to three times as long as the others -- launched by itself it leaves most of the chip idle behind
         // its longest windows (ragged list of bench.py: 5 000 of 37 000 wavefronts, but 5.9 of 11.8 ms), launched with the rest
         // behind it the short wavefronts fill in.  The plan of the streamed part is then made before the first launch.
         // (lists of up to ~200 000 windows: a dozen rounds of the chip's wavefront slots.  Beyond that the pool by itself is several
         // rounds and the streamed part's plan is better made beside its kernels: 596 k windows 18.6 ms merged, 17.5 ms not;
         // 64 k windows of 300-500-residue queries 11.9 ms merged, 16.3 ms not)
-        bool const merge_pool = !use_solo && !preplanned && !lx::dev_aids().mq_no_merge && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
+        bool const merge_pool = !use_solo && !preplanned && live <= (lx::dev_aids().mq_merge_below ? lx::dev_aids().mq_merge_below : 200000);
         // wavefronts [wlo, whi) of the plan in launch order = longest first (what a wavefront executes is columns x steps; the blocks of a
         // launch are dealt to the chip's wavefront slots in index order, so a long wavefront late in the order ends the launch late)
         auto longest_first = [&](uint64_t wlo, uint64_t whi)
         {
-            if (!wf_slots || lx::dev_aids().mq_no_longest_first || whi <= wlo + 1)
+            if (whi <= wlo + 1)
                 return;
             uint64_t const cnt = whi - wlo;
             std::vector<uint32_t> & by_len = h->xb_pool_order, & tmp_slot = h->xb_pool_place, & tmp_pan = h->xb_pool_pan, & tmp_maxs = h->xb_pool_maxs;
@@ -2540,7 +2511,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             t_unpack += ms(tz0, now());
         };
         // ---- the pool and what follows it as ONE chunk in two calls (enqueue_mq_first / enqueue_mq_second)
-        if (wf_slots && !lx::dev_aids().mq_no_two_calls && !use_solo && !merge_pool && !stream_planned && !by_range && pool_wf > 0)
+        if (!use_solo && !merge_pool && !stream_planned && !by_range && pool_wf > 0)
         {
             auto const     tp0   = now();
             uint64_t const nruns = starts.size() - 1, pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
@@ -2613,7 +2584,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // the chunk's checkpoint slots must fit the trace budget (fused_impl leaves the sweep otherwise): every slot is sized
             // for the chunk's widest query and longest window, plus room for the int32 overflow slots of what the sweep may
             // decline -- the chunk ends where one more wavefront would break the budget
-            uint64_t w1 = w0, pmax[2] = {1, 1}, smax[2] = {1, 1};
+            uint64_t w1 = w0;
             uint64_t const pc = (uint64_t)lx::trace_cfg_panel(mq_cfg) / 8;
             // (compact codes + room for the int32 overflow slots of a few declined windows; int16 pairs where the chunk may run WIDE)
             bool const maybe_wide = mq_cfg == 1 && !lx::dev_aids().mq_no_wide && h->mq_decl_frac > 0.01;
@@ -2632,7 +2603,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 w1 = cr.cut_wf[range_now + 1]; // (the budgets were checked range by range when the mode was chosen)
             }
             uint64_t run_bytes = 0, run_q = 1, run_s = 1; // (slots by wavefront: what the chunk's wavefronts need, each for itself)
-            while (!by_range && wf_slots && w1 < nwf && w1 - w0 < per_chunk)
+            while (!by_range && w1 < nwf && w1 - w0 < per_chunk)
             {
                 if (!merge_pool && w0 < pool_end && w1 == pool_end)
                     break;
@@ -2641,22 +2612,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
                 if (w1 > w0 && (b2 > h->opt_trace_bytes || (w1 + 1 - w0) * kWave * (q2 * 8 + s2) > (8ull << 30)))
                     break;
                 run_bytes = b2, run_q = q2, run_s = s2;
-                ++w1;
-            }
-            while (!by_range && !wf_slots && w1 < nwf && w1 - w0 < per_chunk)
-            {
-                if (!merge_pool && w0 < pool_end && w1 == pool_end)
-                    break; // (A/B aid: the pool in chunks of its own, as before)
-                int const      r = w1 < pool_end ? 0 : 1; // the region this wavefront's slots lie in
-                uint64_t const p2 = std::max<uint64_t>(pmax[r], wf_pan[w1]), s2 = std::max<uint64_t>(smax[r], wf_maxs[w1]);
-                uint64_t const n1 = w0 < pool_end ? std::min(w1 + 1, pool_end) - w0 : 0, n2 = w1 + 1 - w0 - n1;
-                uint64_t const bytes = n1 * kWave * slot_bytes(r == 0 ? p2 : pmax[0], r == 0 ? s2 : smax[0]) + n2 * kWave * slot_bytes(r == 1 ? p2 : pmax[1], r == 1 ? s2 : smax[1]);
-                // ... and the survivors' ops slots, one size per chunk: its widest query + its longest window
-                uint64_t const ops = (w1 + 1 - w0) * kWave * (std::max(p2, std::max(pmax[0], pmax[1])) * 8 + std::max(s2, std::max(smax[0], smax[1])));
-                if (w1 > w0 && (bytes > h->opt_trace_bytes || ops > (8ull << 30)))
-                    break;
-                pmax[r] = p2;
-                smax[r] = s2;
                 ++w1;
             }
             int const L = c & 1;
@@ -2732,7 +2687,7 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             // ... and never mix geometry classes (the list is class-major): cut where the class changes
             auto qclass = [](uint32_t lq) -> uint32_t { return lq <= 104 ? 0u : lq <= 152 ? 1u : lq <= 200 ? 2u : lq <= 208 ? 3u : 3u + (lq + 151) / 152; };
             uint32_t const c0 = qclass(ext[idx[k0]].q_len);
-            if (!lx::dev_aids().extend_no_classes && qclass(ext[idx[k1 - 1]].q_len) != c0)
+            if (qclass(ext[idx[k1 - 1]].q_len) != c0)
             {
                 uint64_t lo = k0, hi = k1 - 1; // first position of another class: the classes ascend
                 while (hi - lo > 1)
@@ -2859,7 +2814,7 @@ bool lxi::free_plan_applies(lx_handle const * h, int slot)
 {
     lx_scoring const & sh = h->sc_host[slot];
     return h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap && sh.gap_open <= sh.gap_extend &&
-           !lx::dev_aids().extend_no_mq && !h->opt_band;
+           !h->opt_band;
 }
 
 // does lx_extend_batch* serve this slot's lists with the solo packing of the multi-query sweep (a byte profile per window)?
@@ -2867,7 +2822,7 @@ bool lxi::solo_plan_applies(lx_handle const * h, int slot)
 {
     lx_scoring const & sh = h->sc_host[slot];
     return h->opt_mq >= 1 && h->opt_pass2 == 2 && h->opt_f16 && h->trace_ok[slot] && h->b8_ok[slot] && -sh.gap_open <= lx::kC16MaxGap && sh.gap_open <= sh.gap_extend &&
-           !lx::dev_aids().extend_no_mq && !lx::dev_aids().mq_no_solo && !h->opt_band && lx::sweep_mq_lds_bytes(1, sh.alphabet_size + 1, -1) <= 20 * 1024;
+           !h->opt_band && lx::sweep_mq_lds_bytes(1, sh.alphabet_size + 1, -1) <= 20 * 1024;
 }
 
 // lx_extend_batch_list for the Level-2 driver on the device (lx_level2_host.cpp): query residues, window list and cut-offs are resident

@@ -83,8 +83,7 @@ struct lx_handle
     int         device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t  ev0 = nullptr, ev1 = nullptr;
-    hipStream_t stream2 = nullptr;                       // backtrace of chunk k overlaps the forward kernel of chunk k+1
-    hipEvent_t  evF[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evS = nullptr;
+    hipStream_t stream2 = nullptr;                       // downloads of lx_extend_batch
     bool        timed = false;
     std::string error;
     // lx_extend_batch: host staging that keeps its pages between calls
@@ -186,10 +185,6 @@ struct lx_handle
     bool        count_pending    = false;
     double      plan_surv_frac   = -1.0;   // the share phase 1 of the current step planned with (phase 2 follows it)
     uint64_t    opt_adapt        = 30;     // LX_OPT_ADAPT_PERMILLE
-    struct MqSplit // lx_extend_batch: the chunk's slots lie in two regions -- [0, n1) sized for (q1, s1), the rest for (q2, s2); n1 = 0: one region
-    {
-        uint64_t n1 = 0, q1 = 0, s1 = 0, q2 = 0, s2 = 0;
-    } mq_split;
     // lx_extend_batch: the chunk's slots BY WAVEFRONT (lx::WfSlots, lx_device.h) instead of by region: `dev` = the table of the chunk's
     // wavefronts on the device; the slots of the wavefronts before slot n0 take dw0 uint32 at the trace buffer's start, room for ovf_cap
     // int16-pair overflow slots follows, then the dw1 uint32 of the wavefronts from n0 on.  part: 0 = the chunk in one call, 1 = the
@@ -367,6 +362,7 @@ int    prepare_workspace(lx_handle * h, hipStream_t stream, uint64_t pairs_hint 
 
 // padding of q/s staging buffers so that clamped / prefetching loads never leave the allocation
 constexpr size_t kSlack = 256;
+constexpr uint64_t kExtendChunk = 640ull << 10; // extensions per chunk of lx_extend_batch's pipeline unless LX_OPT_EXTEND_CHUNK says otherwise
 constexpr int kPair16    = 100; // launch_score_list's pair_cfg: the packed 16-bit integer kernel, any query width
 constexpr int kPair16Bin = 8;   // its bin among the packed geometries of lx_score_batch
 

@@ -221,7 +221,7 @@ static int level2_windows(lx_handle * h, uint64_t n_matches, bool bisulfite, std
                                   static_cast<uint32_t *>(l2.d_tot.ptr), st));
     // what the plan of the sweep will want to know about the list (the strip geometry that sweeps it cheapest, its cells), behind
     // the same synchronisation
-    LX_HIP(h, lx::l2_launch_plan_cost(p.ext_out, p.count_out, n_matches, lx::dev_aids().mq_no_narrow ? 1 : 0,
+    LX_HIP(h, lx::l2_launch_plan_cost(p.ext_out, p.count_out, n_matches, 0,
                                       reinterpret_cast<unsigned long long *>(p.count_out + 3), st));
     LX_HIP(h, hipMemcpyAsync(l2.p_cnt.ptr, l2.d_cnt.ptr, 13 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     LX_HIP(h, hipStreamSynchronize(st)); // (also: `cut_table` is the caller's)
@@ -611,16 +611,12 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             // The plan of the sweep on the device (the solo packing of lx_sweep_mq.hip: every window its own profile): ONE strip
             // geometry per call, the one that sweeps the list cheapest (lx_host.cpp has the measurement behind "one" and behind
             // the 15 % that narrower strips must save), then all windows by (columns per lane, length), 16 to a wavefront.
-            int const cand[3] = {1, 3, 5}, set = lx::dev_aids().mq_set, forced = lx::dev_aids().force_mq_cfg;
+            int const cand[3] = {1, 3, 5};
             int       cfg     = 1;
             double    best    = 1e300;
             for (int k = 0; k < 3; ++k)
             {
-                double c = (double)cost[4 * pi + k] * (cand[k] == 1 ? 1.0 : 1.15);
-                if (!(set & (1 << k)) && forced != cand[k])
-                    continue;
-                if (forced == cand[k])
-                    c = 0;
+                double const c = (double)cost[4 * pi + k] * (cand[k] == 1 ? 1.0 : 1.15);
                 if (c < best)
                 {
                     best = c;
@@ -645,7 +641,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     // its columns, is nobody's shadow, while the first range's comes down beside the second's kernels as long as those
                     // take longer; bench.py --iterate, fastest of eight calls at 50 / 62 / 66 / 70 / 75 / 80 %: 10.7 / 10.55 / 10.5 / 10.5 /
                     // 10.9 / 11.4 ms)
-                    uint64_t const pct    = lx::dev_aids().l2_first_pct ? std::min<uint64_t>(lx::dev_aids().l2_first_pct, 95) : 66;
+                    uint64_t const pct    = 66;
                     uint64_t const target = R == 2 ? n / 100 * pct : n * k / R, from = target > 256 ? target - 256 : 0, upto = std::min(n, target + 256);
                     if (from <= lo || upto - from < 2)
                         continue;
@@ -692,7 +688,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     uint64_t * idx = static_cast<uint64_t *>(l2.d_s0[0].ptr), * idx_tmp = static_cast<uint64_t *>(l2.d_s0[1].ptr);
                     uint64_t const w0 = l2.cut_wf[r];
                     LX_HIP(h, lx::l2_launch_plan(static_cast<lx::Extension const *>(ri.d_ext_all) + ranges[r].lo, ranges[r].hi - ranges[r].lo, lx::trace_cfg_panel(cfg) / 8,
-                                                 lx::dev_aids().mq_no_narrow ? 1 : 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
+                                                 0, &key, &key_tmp, &idx, &idx_tmp, static_cast<uint32_t *>(l2.d_hist.ptr),
                                                  static_cast<uint32_t *>(l2.d_plan.ptr) + w0 * 16, d_pan + w0, d_maxs + w0, st, (uint32_t)ranges[r].lo,
                                                  lx::l2_plan_key_bits(l2.max_qlen, cost[8 + pi])));
                 }
@@ -705,7 +701,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 fa.n          = n;
                 fa.n_qseq     = l2.q_len.size();
                 fa.C          = lx::trace_cfg_panel(cfg) / 8;
-                fa.no_narrow  = lx::dev_aids().mq_no_narrow ? 1 : 0;
+                fa.no_narrow  = 0;
                 fa.nranges    = (uint32_t)ranges.size();
                 for (size_t r = 0; r < ranges.size(); ++r)
                     fa.cut[r] = ranges[r].lo;
@@ -723,7 +719,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 LX_HIP(h, hipMemcpyAsync(h_report, fa.report, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
             // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by it)
-            bool const try_rank = records_on_device && n < 0xfffffff0ull && !lx::dev_aids().l2_no_rank;
+            bool const try_rank = records_on_device && n < 0xfffffff0ull;
             if (try_rank)
             {
                 if ((rc = ensure(h, l2.d_rank, (n + 1) * sizeof(uint32_t) + 16)))
@@ -1120,7 +1116,7 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
     // ---- the extension pipeline's two lanes (extend_pipeline: enqueue_mq), for chunks of the default size; the survivors' column slots for
     // windows of up to three times the ordinary length (what a merged window comes to, src/search_algo.hpp:1153-1157)
     {
-        uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lx::dev_aids().extend_chunk;
+        uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lxi::kExtendChunk;
         uint64_t const nwf_x  = free_plan ? nwf_solo + nwf_solo / 8 + 64 : nwf_solo; // (what a free-packing plan comes to, not its bound)
         uint64_t const slots  = std::min<uint64_t>(nwf_x * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
         uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(1);
@@ -1288,7 +1284,7 @@ int lx_plan_free_packing_dev(lx_handle * h, void const * d_ext, uint64_t n, uint
     fa.n          = n;
     fa.n_qseq     = n_qseq;
     fa.C          = strip_cols;
-    fa.no_narrow  = lx::dev_aids().mq_no_narrow ? 1 : 0;
+    fa.no_narrow  = 0;
     fa.nranges    = nranges;
     for (uint32_t r = 0; r <= nranges; ++r)
         fa.cut[r] = cut[r];

@@ -620,7 +620,7 @@ int score_pair_cfg_for(uint32_t max_qlen)
         return 0;
     if (max_qlen <= 192)
         return 4;
-    if (max_qlen <= 200 && !dev_aids().no_wide_strips)
+    if (max_qlen <= 200)
         return 7;
     if (max_qlen <= 208)
         return 5;

@@ -116,16 +116,14 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
     uint64_t const eA   = 2 * pair, eB = 2 * pair + 1;
     bool const     actA = eA < p.n, actB = eB < p.n;
 
-    // the slot region of this wavefront (ScoreParams::split_n: wave-uniform, the split is a multiple of 16)
     // ... or the slots of this wavefront by themselves (ScoreParams::wf_tab: sized for its own longest window and widest query)
     bool const       by_wf      = p.wf_tab != nullptr;
     WfSlots const    wfs        = by_wf ? p.wf_tab[wf] : WfSlots{0, 0, 0};
-    bool const       reg2       = !by_wf && p.split_n != 0 && eA >= p.split_n;
-    uint32_t const   steps_cap  = by_wf ? wfs.steps_cap : reg2 ? p.steps_cap2 : p.steps_cap, panels_cap = by_wf ? wfs.panels_cap : reg2 ? p.panels_cap2 : p.panels_cap;
-    uint32_t * const ckpt_base  = by_wf ? p.ckpt + wfs.off_dw : reg2 ? p.ckpt2 : p.ckpt;
+    uint32_t const   steps_cap  = by_wf ? wfs.steps_cap : p.steps_cap, panels_cap = by_wf ? wfs.panels_cap : p.panels_cap;
+    uint32_t * const ckpt_base  = by_wf ? p.ckpt + wfs.off_dw : p.ckpt;
     uint64_t const   ckpt_step  = by_wf ? (uint64_t)wfs.panels_cap * (WIDE ? Geo::slot_dwords_w(wfs.steps_cap) : L16::slot_dwords(wfs.steps_cap))
-                                        : reg2 ? p.ckpt_stride2 : p.ckpt_stride;
-    uint64_t const   ckpt_first = by_wf ? 2 * Geo::kGroups * wf : reg2 ? p.split_n : 0;
+                                        : p.ckpt_stride;
+    uint64_t const   ckpt_first = by_wf ? 2 * Geo::kGroups * wf : 0;
 
     ScoringDev const * __restrict__ sc = p.sc;
     int const      ge    = sc->ge;
@@ -939,8 +937,7 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
     if (blocks == 0)
         return hipSuccess;
     int const      share  = (p.pair_share > 0 && p.pair_share < Geo::kGroups) ? p.pair_share : Geo::kGroups;
-    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || (!p.wf_tab && p.steps_cap % 16 != 0) || Geo::kGroups % share != 0 || (p.wf_tab && p.split_n) ||
-        (p.split_n != 0 && (p.split_n % 16 != 0 || p.split_n > p.n || !p.ckpt2 || p.steps_cap2 % 16 != 0)))
+    if (blocks > 0x7fffffffull || !p.ckpt || !p.ends || (!p.wf_tab && p.steps_cap % 16 != 0) || Geo::kGroups % share != 0)
         return hipErrorInvalidValue;
     size_t const lds = ((size_t)(p.solo ? 2 * Geo::kGroups : p.pair_share == 1 ? 4 : Geo::kGroups / share) * (size_t)p.nrows * Geo::kRowDw + 64 * 8) * sizeof(uint32_t);
     if (p.wide)
@@ -950,7 +947,7 @@ static hipError_t launch_sweep_mq_cfg(ScoreParams const & p, hipStream_t stream)
         else
             return hipErrorInvalidValue; // (int16-pair slots: the 19-column strips only)
     }
-    else if (p.panels_cap > 1 || (p.split_n != 0 && p.panels_cap2 > 1)) // (slots by wavefront: panels_cap = the launch's largest)
+    else if (p.panels_cap > 1) // (slots by wavefront: panels_cap = the launch's largest)
         hipLaunchKernelGGL((sweep_mq_kernel<C, true>), dim3((unsigned)blocks), dim3(64), lds, stream, p);
     else
         hipLaunchKernelGGL((sweep_mq_kernel<C, false>), dim3((unsigned)blocks), dim3(64), lds, stream, p);

@@ -518,6 +518,8 @@ def test_level2_on_the_protein_list_at_the_size_it_is_benched_at(handle, oracle)
     m_, ma, mi, go, ge = d.scoring
     sc_p = capi.builtin_scoring(m_, match=ma, mismatch=mi, gap_open=go, gap_extend=ge)
     handle.set_scoring(sc_p, d.slot)
+    handle.set_option(capi.LX_OPT_PASS2_MODE, 2)  # (the library's defaults, whatever the tests before this one left on the session's handle)
+    handle.set_option(capi.LX_OPT_MQ_SWEEP, 1)
     osc = oracle_lib.scoring_from(sc_p)
     ka = capi.karlin_params(*w.karlin)
     oka = oracle_lib.Karlin(ka.lambda_, ka.K, ka.H, ka.alpha, ka.beta)
