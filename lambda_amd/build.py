@@ -20,7 +20,7 @@ LIB = CSRC / "liblambda_ext.so"
 ORACLE_DIR = ROOT / "oracle"
 ORACLE_LIB = ORACLE_DIR / "_build" / "liblx_oracle.so"
 
-HIP_SOURCES = ["lx_score.hip", "lx_score_f16.hip", "lx_score_i16.hip", "lx_sweep_mq.hip", "lx_trace.hip", "lx_ckpt.hip", "lx_select.hip", "lx_pack.hip", "lx_prefilter.hip", "lx_level2.hip", "lx_plan_free.hip", "lx_records.hip", "lx_level2_host.cpp", "lx_api.cpp", "lx_host.cpp", "lx_host_pool.cpp", "host/lx_driver.cpp", "host/lx_output.cpp", "host/lx_translate.cpp"]
+HIP_SOURCES = ["lx_score.hip", "lx_score_f16.hip", "lx_score_i16.hip", "lx_sweep_mq.hip", "lx_trace.hip", "lx_ckpt.hip", "lx_select.hip", "lx_pack.hip", "lx_prefilter.hip", "lx_level2.hip", "lx_plan_free.hip", "lx_records.hip", "lx_level2_host.cpp", "lx_api.cpp", "lx_host.cpp", "lx_host_batch.cpp", "lx_host_pool.cpp", "host/lx_driver.cpp", "host/lx_output.cpp", "host/lx_translate.cpp"]
 
 
 def _hipcc() -> str:

@@ -430,6 +430,10 @@ struct ResidentInput
     };
     ChunkRecords const * chunk_records = nullptr;
 };
+// band mode's plain path of the host-buffer entry points (lx_host_batch.cpp; what: 0 = scores, 1 = alignments of known scores, 2 = both)
+int  host_banded(lx_handle * h, int slot, int what, uint8_t const * q_res, uint64_t q_bytes, uint8_t const * s_res, uint64_t s_bytes,
+                 lx_extension const * ext, uint64_t n, int32_t const * known_score, int32_t const * min_score, int32_t min_score_all, int32_t * out_score,
+                 lx_hsp * out_hsp, uint8_t * caller_ops, uint64_t const * caller_ops_off, uint64_t * out_ops_off, uint8_t const ** out_ops, uint64_t * out_ops_bytes);
 bool solo_plan_applies(lx_handle const * h, int slot);
 bool free_plan_applies(lx_handle const * h, int slot);
 int  extend_list_resident(lx_handle * h, int slot, ResidentInput const & ri, lx_extension const * ext, uint64_t n, int32_t const * min_score,
