@@ -8,9 +8,11 @@
 //   * RUNS: the windows of one query slice (the list is sorted by query), cut every 512 list positions so that the per-run work
 //     below is bounded -- inside a run the windows are ranked by length, longest first, by counting;
 //   * POOL: a run's windows clearly longer than its median (the merged windows, up to three times the ordinary length,
-//     :1153-1157), filled up with its longest ordinary windows to QUADS of four; the quads of the whole list are sorted by
-//     (columns per lane their query sweeps, length) and dealt four to a wavefront: a long window stretches three companions, not
-//     fifteen;
+//     :1153-1157) and those clearly shorter (windows clipped at their subject's end, :919-938 -- a tenth of a protein list), each
+//     kind filled up with the run's nearest ordinary windows to QUADS of four; the quads of the whole list are sorted by (columns
+//     per lane their query sweeps, length) and dealt four to a wavefront: a long window stretches three companions, not fifteen,
+//     and a short one is swept beside windows of its own length instead of idling -- and forcing the sweep's checked steps on its
+//     wavefront -- for the rest of a long one's rows;
 //   * STREAM: everything else, run by run in order of (columns per lane, longest streamed window), PAIR by pair into wavefronts
 //     that close at eight pairs or before a fifth query.  The closing rule is sequential; it runs per SHARE of 64 runs (one
 //     wavefront of the plan kernel per share, a share starts a new wavefront), which leaves one wavefront per share partly empty;
@@ -56,7 +58,7 @@ struct FpWork
     uint32_t * rid;       // [n]   run of list position i (= of sorted position i: a run's windows keep its positions)
     uint32_t * ord;       // [n]   window at sorted position k (longest first inside a run)
     uint32_t * run_start; // [rm + 1]
-    uint32_t * run_npool; // [rm]  windows of the run that stand in the pool
+    uint32_t * run_npool; // [rm]  windows of the run that stand in the pool: its longest (low half) and its shortest (high half)
     uint32_t * run_nq;    // [rm]  its quads
     uint32_t * run_qoff;  // [rm]  first quad (in run order)
     uint32_t * run_np;    // [rm]  its streamed pairs
@@ -173,23 +175,31 @@ __global__ __launch_bounds__(256) void fp_run_kernel(Extension const * ext, uint
     }
     uint32_t const a = w.run_start[r], b = w.run_start[r + 1], c = b - a;
     auto const     len = [&](uint32_t d) { return ext[w.ord[a + d]].s_len; };
-    uint32_t const med = len(c / 2), thr = med + max(8u, med / 8u);
-    uint32_t       lo = 0, hi = c; // first place whose window is not longer than thr (the run is sorted, longest first)
-    while (lo < hi)
+    uint32_t const med = len(c / 2), slack = max(8u, med / 8u);
+    // first place whose window is not longer than `bound` (the run is sorted, longest first)
+    auto const first_not_above = [&](uint32_t bound)
     {
-        uint32_t const mid = (lo + hi) / 2;
-        if (len(mid) > thr)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    uint32_t const npool = min(c, (lo + 3u) / 4u * 4u), nq = (npool + 3u) / 4u, np = (c - npool + 1u) / 2u;
-    uint32_t const pan   = fp_cols_per_lane(ext[w.ord[a]].q_len, C, no_narrow);
-    w.run_npool[r] = npool;
+        uint32_t lo = 0, hi = c;
+        while (lo < hi)
+        {
+            uint32_t const mid = (lo + hi) / 2;
+            if (len(mid) > bound)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    uint32_t const nlong  = first_not_above(med + slack);
+    uint32_t const nshort = med > slack ? c - first_not_above(med - slack - 1u) : 0u; // windows shorter than med - slack
+    uint32_t const phi = min(c, (nlong + 3u) / 4u * 4u), plo = min(c - phi, (nshort + 3u) / 4u * 4u);
+    uint32_t const nq = (phi + 3u) / 4u + (plo + 3u) / 4u, np = (c - phi - plo + 1u) / 2u;
+    uint32_t const pan = fp_cols_per_lane(ext[w.ord[a]].q_len, C, no_narrow);
+    w.run_npool[r] = phi | (plo << 16);
     w.run_nq[r]    = nq;
     w.run_np[r]    = np;
     // (a run that stands in the pool altogether sorts behind its width's streamed runs)
-    w.rkey[0][r] = ((uint64_t)fp_range_of(rg, a) << 16) | (np ? fp_key16(pan, len(npool)) : (fp_key16(pan, 0) | 0xffu));
+    w.rkey[0][r] = ((uint64_t)fp_range_of(rg, a) << 16) | (np ? fp_key16(pan, len(phi)) : (fp_key16(pan, 0) | 0xffu));
     w.ridx[0][r] = r;
 }
 
@@ -230,11 +240,17 @@ __global__ __launch_bounds__(256) void fp_quad_keys_kernel(Extension const * ext
     uint32_t const k = blockIdx.x * blockDim.x + threadIdx.x; // sorted position
     if (k >= n)
         return;
-    uint32_t const r = w.rid[k], a = w.run_start[r], d = k - a;
-    if (d >= w.run_npool[r] || (d & 3u))
+    uint32_t const r = w.rid[k], a = w.run_start[r], d = k - a, c = w.run_start[r + 1] - a;
+    uint32_t const phi = w.run_npool[r] & 0xffffu, plo = w.run_npool[r] >> 16, d0 = c - plo; // [0, phi): the long quads, [d0, c): the short ones
+    uint32_t       quad;
+    if (d < phi && (d & 3u) == 0)
+        quad = d / 4u;
+    else if (d >= d0 && ((d - d0) & 3u) == 0)
+        quad = (phi + 3u) / 4u + (d - d0) / 4u;
+    else
         return;
     Extension const x = ext[w.ord[k]];
-    w.qkey[0][w.run_qoff[r] + d / 4u] = ((uint64_t)fp_range_of(rg, a) << 16) | fp_key16(fp_cols_per_lane(x.q_len, C, no_narrow), x.s_len);
+    w.qkey[0][w.run_qoff[r] + quad] = ((uint64_t)fp_range_of(rg, a) << 16) | fp_key16(fp_cols_per_lane(x.q_len, C, no_narrow), x.s_len);
 }
 __global__ __launch_bounds__(256) void fp_quad_inverse_kernel(uint64_t const * qidx_sorted, uint32_t qm, FpWork w)
 {
@@ -346,17 +362,19 @@ __global__ __launch_bounds__(256) void fp_place_kernel(uint32_t n, FpRanges rg, 
     FpLayout const & L = *w.layout;
     if (L.overflow)
         return;
-    uint32_t const r = w.rid[k], a = w.run_start[r], d = k - a, npool = w.run_npool[r];
+    uint32_t const r = w.rid[k], a = w.run_start[r], d = k - a, c = w.run_start[r + 1] - a;
+    uint32_t const phi = w.run_npool[r] & 0xffffu, plo = w.run_npool[r] >> 16, d0 = c - plo;
     uint32_t const rng = fp_range_of(rg, a);
     uint64_t       slot;
-    if (d < npool)
+    if (d < phi || d >= d0)
     {
-        uint32_t const p = w.qinv[w.run_qoff[r] + d / 4u] - L.quad_first[rng]; // place among the range's quads
-        slot             = 16ull * (L.pool_wf0[rng] + p / 4u) + 4u * (p & 3u) + (d & 3u);
+        uint32_t const quad = d < phi ? d / 4u : (phi + 3u) / 4u + (d - d0) / 4u, e = d < phi ? (d & 3u) : ((d - d0) & 3u);
+        uint32_t const p    = w.qinv[w.run_qoff[r] + quad] - L.quad_first[rng]; // place among the range's quads
+        slot                = 16ull * (L.pool_wf0[rng] + p / 4u) + 4u * (p & 3u) + e;
     }
     else
     {
-        uint32_t const sp = d - npool;
+        uint32_t const sp = d - phi;
         slot              = 16ull * (L.stream_wf0[rng] + w.wfoff[w.run_spos[r]]) + 2ull * (w.run_g[r] + sp / 2u) + (sp & 1u);
     }
     if (slot < 16ull * cap_wf)
@@ -453,7 +471,7 @@ FpSizes fp_sizes(uint64_t n, uint64_t n_qseq, uint32_t nranges)
 {
     FpSizes z;
     z.rm    = fp_run_bound(n, n_qseq);
-    z.qm    = n / 4 + z.rm + 4;
+    z.qm    = n / 4 + 2 * z.rm + 4; // (a run's long quads and its short ones: a partly filled one each)
     z.sm    = z.rm / kFpShare + nranges + 2;
     z.tiles = l2_scan_tiles(std::max<uint64_t>(n, z.qm));
     return z;

@@ -19,9 +19,9 @@ def cols_per_lane(lq, C=19):
     return min(0xfff, (P - 1) * C + last)
 
 
-def make_list(rng, n_queries, windows, qlen, merged_share=0.1):
+def make_list(rng, n_queries, windows, qlen, merged_share=0.1, clipped_share=0.1):
     """A window list as _widenAndPreprocessMatches leaves it: grouped by query; a query's windows are its length + 2 bands long, a share of
-    them merged ones of up to three times that.  windows / qlen: callables of the rng."""
+    them merged ones of up to three times that, a share clipped at their subject's end.  windows / qlen: callables of the rng."""
     ext = []
     q_off = 0
     for q in range(n_queries):
@@ -30,7 +30,8 @@ def make_list(rng, n_queries, windows, qlen, merged_share=0.1):
         band = int(np.sqrt(lq)) + 1
         base = lq + 2 * band
         for _ in range(w):
-            ls = base if rng.random() >= merged_share else int(base * rng.uniform(1.2, 3.0))
+            u = rng.random()
+            ls = int(base * rng.uniform(1.2, 3.0)) if u < merged_share else int(base * rng.uniform(0.1, 0.9)) if u < merged_share + clipped_share else base
             ext.append((q_off, int(rng.integers(0, 1 << 20)), lq, max(1, ls - int(rng.integers(0, 4)))))
         q_off += lq
     return np.array(ext, dtype=capi.EXT_DTYPE)
@@ -100,7 +101,7 @@ def test_every_slot_of_the_device_plan(handle, case):
     ratio, distinct, real = check_plan(ext, plan, pan, maxs, rep, [0, n])
     print(f"{case}: {n} windows in {len(plan)} wavefronts, executed / list cells {ratio:.3f}, {distinct:.2f} queries per wavefront, {real:.3f} of the slots real")
     if case == "headline_32_windows_of_150":
-        assert real > 0.99 and ratio < 1.45  # (152 columns for 150, 183 steps for 176 rows: 1.05 x 1.04 + the strips' skew)
+        assert real > 0.95 and ratio < 1.2  # (152 columns for 150, 183 steps for 176 rows; the clipped windows swept beside their likes)
     if case == "a_dozen_windows_ragged":
         assert real > 0.90
 
