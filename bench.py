@@ -642,8 +642,11 @@ def host_roofline(args, kernel, ms, launches, bt_ms, bt_launches, st, q, ext, fl
     flag = flag or ("--ragged" if args.ragged else "--host-path")
     # (the PMC passes profile the kernel instantiation the sweep ran as; its name in the library's spelling ends at the first blank)
     other_config = getattr(args, "config", 1) not in (None, 1) and flag in ("--ragged", "--host-path")
-    traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag, command_also=f"--config {args.config}" if other_config else None,
-                                command_lacks=None if other_config or flag == "--iterate" else "--config")
+    # (--iterate: the read set of configs[2] unless --config 1 asks for the protein list)
+    iterate_protein = flag == "--iterate" and getattr(args, "config", None) == 1 and getattr(args, "config_given", False)
+    traffic, note = pmc_traffic(kernel.split(" (")[0], command_has=flag,
+                                command_also=f"--config {args.config}" if other_config else "--config 1" if iterate_protein else None,
+                                command_lacks=None if other_config or iterate_protein else "--config")
     ceil = issue_ceiling() if packed else None
     return {
         **({"issue_ceiling_frac": ceil["issue_ceiling_frac"]} if ceil else {}),

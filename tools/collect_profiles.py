@@ -175,6 +175,15 @@ if rs.exists():
         for r in rows[1:]:
             if "lx::" in r[0]:
                 w.writerow(r)
+rs = src / "stats_iterate_protein" / "iterate_kernel_stats.csv"
+if rs.exists():
+    rows = list(csv.reader(open(rs)))
+    with open(out / f"{tag}_iterate_protein_kernel_stats.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "lx::" in r[0]:
+                w.writerow(r)
 lines = []
 for log in ("cli_nucl.log", "cli_nucl_host_list.log"):
     if (src / log).exists():
@@ -186,7 +195,12 @@ if lines:
 # round 5: FETCH_SIZE / WRITE_SIZE of the solo sweep (sweep_mq_kernel<19,false,false>) on the Level-2 driver's list and on the configs[2]-sized
 # ragged list, so that those bench lines carry `traffic` too
 for passes, cmd, dst in ((("pmc_iterate_sq", "pmc_iterate_sq_wait", "pmc_iterate_fetch", "pmc_iterate_write"), "--iterate", "iterate_pmc"),
-                         (("pmc_ragged_nucl_fetch", "pmc_ragged_nucl_write"), "--ragged --entry list --config 2", "ragged_nucl_pmc")):
+                         (("pmc_ragged_nucl_fetch", "pmc_ragged_nucl_write"), "--ragged --entry list --config 2", "ragged_nucl_pmc"),
+                         # round 6: the Level-2 driver on the protein list of configs[1]; the long strong-hit list
+                         (("pmc_iterate_protein_sq", "pmc_iterate_protein_sq_wait", "pmc_iterate_protein_fetch", "pmc_iterate_protein_write"), "--iterate --config 1",
+                          "iterate_protein_pmc"),
+                         (("pmc_strong_sq", "pmc_strong_sq_wait", "pmc_strong_fetch", "pmc_strong_write"), "--ragged --entry list --lq-range 500 800 --strong",
+                          "ragged_long_strong_pmc")):
     k = condense(passes, steps_profiled)
     if k:
         json.dump({"command": f"rocprofv3 --pmc <counters> --output-format csv -- python bench.py {cmd} --steps 2 --warmup 1 --no-cpu-baseline (separate passes)",

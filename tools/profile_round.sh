@@ -54,4 +54,16 @@ for p in "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
   n=${p%%:*}; c=${p#*:}
 [ $M = lines ] || {   (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_ragged_nucl_$n -o pmc -- python $R/bench.py --ragged --entry list --config 2 --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_ragged_nucl_$n.log 2>&1 ; }
 done
+# round 6: the Level-2 driver on the protein list of configs[1] (the plan of the free packing made on the device): lines, kernel stats, PMC
+# passes; the PMC passes of the long strong-hit list (sweep_mq_kernel<19,true,true>: the line that had no `traffic`)
+cd $R
+[ $M = profiles ] || { (timeout 900 python bench.py --iterate --config 1 --steps 8 --warmup 2) > $D/bench_iterate_protein.log 2>&1 ; }
+[ $M = profiles ] || { (timeout 900 python bench.py --iterate --config 1 --cold --steps 4 --warmup 1 --no-cpu-baseline) > $D/bench_iterate_protein_cold.log 2>&1 ; }
+cd /tmp
+[ $M = lines ] || { (timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$D/stats_iterate_protein -o iterate -- python $R/bench.py --iterate --config 1 --steps 3 --warmup 2 --no-cpu-baseline) > $R/$D/stats_iterate_protein.log 2>&1 ; }
+for p in "sq:SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "sq_wait:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "fetch:FETCH_SIZE" "write:WRITE_SIZE"; do
+  n=${p%%:*}; c=${p#*:}
+[ $M = lines ] || {   (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_iterate_protein_$n -o pmc -- python $R/bench.py --iterate --config 1 --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_iterate_protein_$n.log 2>&1 ; }
+[ $M = lines ] || {   (timeout 600 rocprofv3 --pmc $c --output-format csv -d $R/$D/pmc_strong_$n -o pmc -- python $R/bench.py --ragged --entry list --lq-range 500 800 --strong --steps 2 --warmup 1 --no-cpu-baseline) > $R/$D/pmc_strong_$n.log 2>&1 ; }
+done
 cd $R; tail -1 $D/bench.log | cut -c1-300; ls $D $D/stats | head -60
