@@ -42,7 +42,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 # integer-VALU roofline: 10 algorithmic integer ops per cell (4 add + 6 max, score-only
-# Gotoh) against 256 CU x 128 lanes x 2.4 GHz = 78.6 T int32 lane-ops/s.  See DESIGN.md "Roofline" for the
+# Gotoh) against 256 CU x 128 lanes x 2.4 GHz = 78.6 T int32 lane-ops/s.  See DESIGN.md section 4.2 / 6 for the
 # measured per-instruction issue rates (tools/ubench.hip) this peak is compared with.
 ALGO_OPS_PER_CELL = 10
 PEAK_INT32_TOPS = 256 * 128 * 2.4e9 / 1e12

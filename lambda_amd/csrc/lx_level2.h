@@ -76,13 +76,13 @@ hipError_t l2_launch_sort(uint64_t ** pair, uint64_t ** pair_tmp, uint64_t ** s0
 // kL2ScanTile + 1] uint32
 hipError_t l2_launch_merge(uint64_t const * pair, uint64_t const * s0, L2Params const & p, uint64_t * mrg_beg, uint64_t * mrg_end, uint64_t * fin_beg,
                            uint64_t * fin_end, uint32_t * block_tot, hipStream_t stream);
-// the solo plan of the multi-query sweep for a window list (DESIGN.md section 4): cost sums per part and strip geometry (out[8]: part 0's
+// the solo plan of the multi-query sweep for a window list (DESIGN.md section 4.6): cost sums per part and strip geometry (out[8]: part 0's
 // cost at 19 / 13 / 11 columns and cells, then part 1's; cnt = {windows, first window of part 1} in device memory), and the plan
 hipError_t l2_launch_plan_cost(Extension const * ext, uint64_t const * cnt, uint64_t n_max, int no_narrow, unsigned long long * out, hipStream_t stream);
 hipError_t l2_launch_plan(Extension const * ext, uint64_t n, int C, int no_narrow, uint64_t ** key, uint64_t ** key_tmp, uint64_t ** idx, uint64_t ** idx_tmp,
                           uint32_t * ghist, uint32_t * plan, uint32_t * wf_pan, uint32_t * wf_maxs, hipStream_t stream, uint32_t index_base = 0, uint64_t key_bits = 0x0fffffffull);
 uint64_t   l2_plan_key_bits(uint64_t max_qlen, uint64_t max_wlen);
-// The FREE-PACKING plan of the multi-query sweep for a window list (lx_plan_free.hip; DESIGN.md section 4): a lane group's two windows
+// The FREE-PACKING plan of the multi-query sweep for a window list (lx_plan_free.hip; DESIGN.md section 4.6): a lane group's two windows
 // share a query, a wavefront's sixteen slots hold windows of at most four queries -- the long windows of every query pooled in
 // quads, the rest streamed pair by pair --, laid out range by range (cut[0] = 0 < cut[1] < ... < cut[nranges] = n, every cut where
 // the query changes).  plan: [cap_wf * 16] slots (position in ext[], bit 31 = filler), wf_pan / wf_maxs: [cap_wf]; report: [16]

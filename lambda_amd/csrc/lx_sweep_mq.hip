@@ -20,7 +20,7 @@
 //     hand A of their last column to the right.  7.5 packed instructions per two cells, as before;
 //   * pad letters (rows beyond the window, columns beyond the query) have entry 0, i.e. score like a gap's first character:
 //     such a cell is never above its neighbours, so it can neither start, nor extend, nor end a best local alignment.
-// Two refinements of the unit:
+// Two refinements of the unit (DESIGN_LOG.md section 3.3):
 //   * free packing (pair_share = 1, LX_OPT_QUERY_RUN = 2): what the LDS limits is the number of profiles per wavefront (four),
 //     not how the lane groups are dealt to them -- a lane group's two windows share a query, the eight lane groups hold windows
 //     of up to four queries in any split, numbered in order of appearance;
@@ -92,7 +92,7 @@ struct MqGeo
 // query against its homologue: ~3 000) and would otherwise be redone one by one by the int32 launch.
 #ifndef LX_MQ_WAVES
 #define LX_MQ_WAVES 2 // wavefronts per SIMD the register budget is set for (four byte profiles + staging = 20 KB of LDS admit two; 3 was
-                      // measured with ONE profile per wavefront, where the LDS admits it: DESIGN.md section 3.3)
+                      // measured with ONE profile per wavefront, where the LDS admits it: DESIGN_LOG.md section 3.3)
 #endif
 template <int C, bool MULTI, bool WIDE = false>
 __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p)

@@ -2,7 +2,7 @@
 
     python tools/collect_profiles.py gpurun_out/r1b r01
 
-Inputs (made on the GPU box, see DESIGN.md section 5):
+Inputs (made on the GPU box, see DESIGN.md section 6):
     <dir>/stats/bench_kernel_stats.csv          rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py ...
     <dir>/pmc_sq|pmc_sq_wait|pmc_fetch|pmc_write/pmc_counter_collection.csv   separate --pmc passes
     <dir>/bench.log, bench_pass1.log, stats.log  the bench JSON lines of the plain / pass-1-only / profiled runs
@@ -116,7 +116,7 @@ if rs.exists():
         for r in rows[1:]:
             if "lx::" in r[0]:
                 w.writerow(r)
-hs = src / "stats_host" / "host_kernel_stats.csv"  # the five chunks of lx_extend_batch_list on the headline batch
+hs = src / "stats_host" / "host_kernel_stats.csv"  # the five chunks of lx_extend_batch_list on the headline batch (DESIGN_LOG.md section 8.8)
 if hs.exists():
     rows = list(csv.reader(open(hs)))
     with open(out / f"{tag}_host_path_kernel_stats.csv", "w", newline="") as f:

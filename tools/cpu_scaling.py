@@ -1,4 +1,4 @@
-"""How the cpu_baseline leg scales with threads on this box (development aid for DESIGN.md section 5)."""
+"""How the cpu_baseline leg scales with threads on this box (development aid for DESIGN.md section 6)."""
 import os, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
