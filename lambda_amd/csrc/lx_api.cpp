@@ -78,6 +78,7 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
 {
     if (bytes <= b.cap)
         return LX_OK;
+    size_t const had = b.cap;
     if (b.ptr)
     {
         LX_HIP(h, hipDeviceSynchronize()); // (kernels on a caller's stream may still read the old block)
@@ -85,7 +86,11 @@ int ensure(lx_handle * h, DevBuf & b, size_t bytes)
         b.ptr = nullptr;
         b.cap = 0;
     }
-    size_t const want = bytes + bytes / 4 + 4096;
+    // (room to grow into, less of it for the large blocks: fresh device memory costs 40 ms per GB)
+    size_t const want = bytes + (bytes >= ((size_t)1 << 30) ? bytes / 16 : bytes / 4) + 4096;
+    if (lx::dev_aids().host_timing && want >= (64u << 20)) // (LX_HOST_TIMING: which buffer a call still had to grow -- what lx_reserve did not cover)
+        fprintf(stderr, "[lx host ms]   device buffer %+ld in the handle grows from %.1f to %.1f MB\n", (long)(reinterpret_cast<char *>(&b) - reinterpret_cast<char *>(h)),
+                (double)had / 1e6, (double)want / 1e6);
     LX_HIP(h, hipMalloc(&b.ptr, want));
     b.cap = want;
     return LX_OK;

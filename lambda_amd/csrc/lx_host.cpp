@@ -1150,42 +1150,6 @@ static int extend_pipeline(lx_handle * h, int slot, uint8_t const * q_res, uint6
             h->mq_tab.n0      = slots;
             h->mq_tab.dw0     = off;
             h->mq_tab.ovf_cap = std::min<uint64_t>(slots, slots / 8 + 64); // (what the chunk's budget reserved: an eighth of its slots)
-            if (hm.on && !use_solo)
-            {
-                // (what in-order dispatch to 2 048 wavefront slots makes of the chunk, in cells: the even share, the longest wavefront, the makespan)
-                std::vector<uint64_t> slot_free(2048, 0);
-                std::make_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
-                uint64_t longest = 0, span = 0, above = 0;
-                for (uint64_t w = w0; w < w1; ++w)
-                {
-                    uint64_t const d = kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7);
-                    std::pop_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
-                    slot_free.back() += d;
-                    span    = std::max(span, slot_free.back());
-                    longest = std::max(longest, d);
-                    above += d > pr.exec_cells / 2048 ? 1 : 0;
-                    std::push_heap(slot_free.begin(), slot_free.end(), std::greater<uint64_t>());
-                }
-                {
-                    std::vector<uint64_t> ds;
-                    for (uint64_t w = w0; w < w1; ++w)
-                        ds.push_back(kWave * ((uint64_t)wf_pan[w] * 8) * ((uint64_t)wf_maxs[w] + 7));
-                    std::sort(ds.begin(), ds.end(), std::greater<uint64_t>());
-                    std::vector<uint64_t> sf(2048, 0);
-                    std::make_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
-                    uint64_t lpt = 0;
-                    for (uint64_t d : ds)
-                    {
-                        std::pop_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
-                        sf.back() += d;
-                        lpt = std::max(lpt, sf.back());
-                        std::push_heap(sf.begin(), sf.end(), std::greater<uint64_t>());
-                    }
-                    fprintf(stderr, "[lx host ms]   ... longest-first makespan %.2f M\n", (double)lpt / 1e6);
-                }
-                fprintf(stderr, "[lx host ms]   chunk %llu-%llu: even share %.2f M cells per wavefront slot, longest wavefront %.2f M, %llu above the share, in-order makespan %.2f M\n",
-                        (unsigned long long)w0, (unsigned long long)w1, (double)(pr.exec_cells / 2048) / 1e6, (double)longest / 1e6, (unsigned long long)above, (double)span / 1e6);
-            }
         }
         uint64_t * const d_cnt = static_cast<uint64_t *>(ln.d_cnt.ptr);
         FusedExtra       fx;

@@ -272,7 +272,8 @@ static_assert(sizeof(lx::BlastMatchDev) == sizeof(lx_blast_match) && offsetof(lx
 // plan's chunks are ranges of the query-sorted list (ResidentInput::ChunkRecords) -- range by range: a range's kernels are queued
 // behind its chunk's own, its rows and columns come down while the next chunk computes.
 constexpr size_t kPlanProbe = 128;                                 // l2.p_plan: [rank flag: 64 B][the free-packing plan's report: 64 B][probe windows] ...
-constexpr size_t kPlanHead  = kPlanProbe + 512 * sizeof(lx::L2Window); // ... in front of the per-wavefront arrays
+constexpr size_t kPlanProbes = lx::kFpMaxRanges;                                    // cuts a part's ranges may have: 512 probe windows each
+constexpr size_t kPlanHead   = kPlanProbe + kPlanProbes * 512 * sizeof(lx::L2Window); // ... in front of the per-wavefront arrays
 
 struct RecordsJob
 {
@@ -629,36 +630,67 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             std::vector<RecordsJob::Range> ranges;
             {
                 uint64_t const forced = lx::dev_aids().l2_ranges;
-                uint64_t const R      = !records_on_device ? 1 : forced ? forced : n < 300000 ? 1 : std::min<uint64_t>(4, n / 4000000 + 2);
                 // (measured on 1.25 M windows, bench.py --iterate: 1 range 11.8, 2 ranges 10.8-11.4, 3 ranges 11.3-11.9, 4 ranges 11.9 ms: a
                 // range costs a sweep's tail, a backtrace's tail and the records kernels' thirty launches; the protein list of bench.py --iterate
                 // --config 1, 3.2 M windows: 1 range 29.1, 2 ranges 24.6, 3 ranges 24.9, 4 ranges 25.5 ms)
+                uint64_t R = !records_on_device ? 1 : forced ? forced : n < 300000 ? 1 : std::min<uint64_t>(4, n / 4000000 + 2);
+                // ... but a range's checkpoint slots stand in HBM together, and FRESH device memory is dear: 40 ms per GB the first time a
+                // process touches it (tools/dev/malloc_probe: hipMalloc of 12 / 32 GB 0.6 / 1.3 s) -- 1.3 s for the two ranges of the protein
+                // list above against a call of 25 ms.  So the ranges also fit what the handle holds already, or 8 GiB: a search's one call
+                // pays 0.3 s instead, a handle whose slots are larger (LX_OPT_TRACE_BYTES-sized by earlier calls) keeps the fewer ranges.
+                if (records_on_device && !forced)
+                {
+                    uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(cfg);
+                    uint64_t const panels = std::max<uint64_t>(1, ((uint64_t)l2.max_qlen + panel - 1) / panel);
+                    uint64_t const steps  = ((uint64_t)cost[8 + pi] + 8 - 1 + 15) & ~15ull; // (the part's longest window)
+                    uint64_t const slot_b = panels * (lx::ckpt16_slot_dwords(cfg, (uint32_t)std::min<uint64_t>(steps, 65520)) + lx::ckpt_slot_dwords(cfg, (uint32_t)std::min<uint64_t>(steps, 65520)) / 8) * 4;
+                    // (every slot sized for the LONGEST window: an upper bound -- slots are laid out wavefront by wavefront; ordinary windows
+                    // are a half to a third of a merged one: half of it per slot is what a list takes at most)
+                    uint64_t const need   = (n + n / 8) * (slot_b / 2 + 1);
+                    uint64_t const have   = std::min<uint64_t>(h->opt_trace_bytes, std::max<uint64_t>(h->d_trace.cap, 8ull << 30));
+                    R = std::min<uint64_t>(lx::kFpMaxRanges, std::max<uint64_t>(R, (need + have - 1) / have));
+                }
                 uint64_t       lo     = 0;
                 int const      qF     = std::max(1, params->qry_num_frames);
-                for (uint64_t k = 1; k < R; ++k)
+                // the windows around every cut's target come down together (512 each), one synchronisation
+                // (two ranges: the first one two thirds of the windows -- what follows the LAST range's kernels, its rows on the PCIe link and
+                // its columns, is nobody's shadow, while the first range's comes down beside the second's kernels as long as those
+                // take longer; bench.py --iterate, fastest of eight calls at 50 / 62 / 66 / 70 / 75 / 80 %: 10.7 / 10.55 / 10.5 / 10.5 /
+                // 10.9 / 11.4 ms)
+                struct Probe
                 {
-                    // (two ranges: the first one two thirds of the windows -- what follows the LAST range's kernels, its rows on the PCIe link and
-                    // its columns, is nobody's shadow, while the first range's comes down beside the second's kernels as long as those
-                    // take longer; bench.py --iterate, fastest of eight calls at 50 / 62 / 66 / 70 / 75 / 80 %: 10.7 / 10.55 / 10.5 / 10.5 /
-                    // 10.9 / 11.4 ms)
-                    uint64_t const pct    = 66;
-                    uint64_t const target = R == 2 ? n / 100 * pct : n * k / R, from = target > 256 ? target - 256 : 0, upto = std::min(n, target + 256);
-                    if (from <= lo || upto - from < 2)
-                        continue;
+                    uint64_t target, from, upto;
+                };
+                std::vector<Probe> probes;
+                for (uint64_t k = 1; k < R && probes.size() < kPlanProbes; ++k)
+                {
+                    uint64_t const target = R == 2 ? n / 100 * 66 : n * k / R, from = target > 256 ? target - 256 : 0, upto = std::min(n, target + 256);
+                    if (upto - from >= 2 && (probes.empty() || from >= probes.back().upto))
+                        probes.push_back(Probe{target, from, upto});
+                }
+                if (!probes.empty())
+                {
                     // (into pinned memory: a copy into ordinary memory is staged by the runtime, 40 us of an idle GPU each)
                     if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead)))
                         return rc;
                     lx::L2Window * const probe = reinterpret_cast<lx::L2Window *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanProbe);
-                    LX_HIP(h, hipMemcpyAsync(probe, static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo + from, (upto - from) * sizeof(lx::L2Window), hipMemcpyDeviceToHost, st));
+                    for (size_t k = 0; k < probes.size(); ++k)
+                        LX_HIP(h, hipMemcpyAsync(probe + 512 * k, static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo + probes[k].from,
+                                                 (probes[k].upto - probes[k].from) * sizeof(lx::L2Window), hipMemcpyDeviceToHost, st));
                     LX_HIP(h, hipStreamSynchronize(st));
-                    uint64_t cut = 0;
-                    for (uint64_t w = std::max<uint64_t>(target, from + 1); w < upto && !cut; ++w)
-                        if (probe[w - from].q / (uint32_t)qF != probe[w - from - 1].q / (uint32_t)qF)
-                            cut = w;
-                    if (cut && cut > lo && cut < n)
+                    for (size_t k = 0; k < probes.size(); ++k)
                     {
-                        ranges.push_back(RecordsJob::Range{lo, cut});
-                        lo = cut;
+                        lx::L2Window const * const pw = probe + 512 * k;
+                        uint64_t const from = probes[k].from, upto = probes[k].upto;
+                        uint64_t cut = 0;
+                        for (uint64_t w = std::max<uint64_t>(probes[k].target, from + 1); w < upto && !cut; ++w)
+                            if (pw[w - from].q / (uint32_t)qF != pw[w - from - 1].q / (uint32_t)qF)
+                                cut = w;
+                        if (cut && cut > lo && cut < n)
+                        {
+                            ranges.push_back(RecordsJob::Range{lo, cut});
+                            lo = cut;
+                        }
                     }
                 }
                 ranges.push_back(RecordsJob::Range{lo, n});
@@ -1118,15 +1150,21 @@ int lx_reserve(lx_handle * h, uint64_t n_matches, uint64_t n_windows, uint64_t n
     {
         uint64_t const chunk  = h->opt_extend_chunk ? std::max<uint64_t>(h->opt_extend_chunk, 1024) : lxi::kExtendChunk;
         uint64_t const nwf_x  = free_plan ? nwf_solo + nwf_solo / 8 + 64 : nwf_solo; // (what a free-packing plan comes to, not its bound)
-        uint64_t const slots  = std::min<uint64_t>(nwf_x * 16, (chunk + 15) / 16 * 16), cap_sel = (slots + 7) / 8 * 8 + 8;
         uint64_t const panel  = (uint64_t)lx::trace_cfg_panel(1);
         uint64_t const max_q  = std::max<uint64_t>(1, ((uint64_t)l2.max_qlen + panel - 1) / panel) * panel;
         // (the longest ORDINARY window, query + band on either side, :919-938: a list whose merged windows are longer grows its first chunk's
-        // slots in the call -- three times the checkpoint bytes for every list would be 14 GB here, and a hipMalloc of that size can
-        // take a second)
+        // slots in the call)
         uint64_t const max_s  = (uint64_t)l2.max_qlen + 2 * (uint64_t)bandSize(l2.max_qlen) + 16, stride = (max_q + 3 * max_s + 3) & ~3ull;
         uint64_t const steps  = (max_s + 8 - 1 + 15) & ~15ull;
         uint64_t const slot_b = max_q / panel * (lx::ckpt16_slot_dwords(1, (uint32_t)steps) + lx::ckpt_slot_dwords(1, (uint32_t)steps) / 8) * 4;
+        // (a device plan's chunks are the RANGES of the list -- level2_sorted_tail: one below 300 000 windows, else two, one more per four
+        // million, and as many as keep a range's checkpoint slots within 8 GiB: fresh device memory costs 40 ms per GB --, admitted up to
+        // four default chunks: the lanes and the checkpoint slots are sized for the largest range, or the first call grows them)
+        uint64_t const R_rule = n_windows < 300000 ? 1 : std::min<uint64_t>(4, n_windows / 4000000 + 2);
+        uint64_t const R_est  = std::min<uint64_t>(lx::kFpMaxRanges, std::max<uint64_t>(R_rule, (nwf_x * 16 * slot_b + (8ull << 30) - 1) / (8ull << 30)));
+        uint64_t const range  = (R_est == 1 ? nwf_x : R_est == 2 ? nwf_x * 68 / 100 + 64 : nwf_x / R_est + nwf_x / (8 * R_est) + 64) * 16;
+        uint64_t const chunk16 = (chunk + 15) / 16 * 16;
+        uint64_t const slots  = std::min<uint64_t>(nwf_x * 16, std::max(chunk16, std::min(range, 4 * chunk16))), cap_sel = (slots + 7) / 8 * 8 + 8;
         if ((rc = ensure(h, h->d_score_all, n_windows * sizeof(int32_t) + 16)))
             return rc;
         unsigned const lanes = nwf_x * 16 > slots ? 2 : 1;
