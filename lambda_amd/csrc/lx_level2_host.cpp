@@ -1267,12 +1267,12 @@ int lx_sort_words_dev(int device, uint64_t * key[2], uint64_t * value[2], uint64
     if (hipSetDevice(device) != hipSuccess)
         return LX_EHIP;
     // the digit counts: one allocation per (process, device), kept and grown -- a hipMalloc + hipFree per call synchronises the device
-    static std::mutex  hist_m;
+    static std::mutex  hist_m[64];
     static uint32_t *  hist_buf[64] = {nullptr};
     static size_t      hist_cap[64] = {0};
-    std::lock_guard<std::mutex> lk(hist_m); // (also: one sort at a time per process on these buffers)
     size_t const want = (lx::l2_sort_tiles(n) + 2) * 256 * sizeof(uint32_t);
     int const    d    = device & 63;
+    std::lock_guard<std::mutex> lk(hist_m[d]); // (one sort at a time per DEVICE on its buffer; the devices of a node sort side by side)
     if (hist_cap[d] < want)
     {
         if (hist_buf[d])

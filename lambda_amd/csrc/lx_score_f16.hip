@@ -389,8 +389,10 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
                 best = nb;
                 cmax = as_h2(kHalfNegInf2);
             }
+#ifndef LX_EXP_NO_FLUSH
             if (k0 & 4)
                 flush_codes(k0);
+#endif
         }
     };
     // CKPT: the row checkpoint behind step k0 + 3 (k0 % 16 == 12).  Issued at the top of the next chunk, before that
@@ -464,8 +466,10 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
     auto chunk_stores = [&](int k0)
     {
         chunk_done(k0);
+#ifndef LX_EXP_NO_ROWCK
         if (((k0 + 4) & 15) == 0)
             rowck_store(k0);
+#endif
     };
     int      k0 = 0;
     uint32_t na[4], nb[4];
