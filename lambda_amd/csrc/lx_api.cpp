@@ -1163,6 +1163,9 @@ void lx_destroy(lx_handle * h)
                 (void)hipHostFree(b->ptr);
         if (l2.ev_win)
             (void)hipEventDestroy(l2.ev_win);
+        for (hipEvent_t ev : l2.ev_rank)
+            if (ev)
+                (void)hipEventDestroy(ev);
     }
     for (lx_handle::Pinned * b : {&h->p_all, &h->p_score_all})
         if (b->ptr)

@@ -223,6 +223,7 @@ struct lx_handle
         std::vector<int32_t>      min, score;
         std::vector<uint32_t>     wf_pan, wf_maxs; // a device plan's wavefronts
         hipEvent_t                ev_win = nullptr; // the window list has arrived on the host
+        hipEvent_t                ev_rank[2] = {nullptr, nullptr}; // the window list is complete / the rank kernel (second stream) is through
         // records on the device (lx_records.hip): the call's survivors as the pipeline's chunks left them (alignment, window, where the
         // codes begin), the key / scan / record buffers, the host-made tables of the e-value
         uint32_t              max_qlen = 0;

@@ -712,7 +712,28 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 (rc = ensure_pinned(h, l2.p_plan, kPlanHead)))
                 return rc;
             uint32_t * const d_pan = static_cast<uint32_t *>(l2.d_wf.ptr), * const d_maxs = d_pan + cap_wf;
-            uint32_t * const h_flag = static_cast<uint32_t *>(l2.p_plan.ptr), * const h_report = h_flag + 16;
+            uint32_t * const h_report = static_cast<uint32_t *>(l2.p_plan.ptr) + 16;
+            // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by
+            // it.  One large kernel that needs the window list only: on the second stream, beside the plan's three dozen small launches)
+            bool const       try_rank   = records_on_device && n < 0xfffffff0ull;
+            uint32_t * const h_rankflag = reinterpret_cast<uint32_t *>(static_cast<uint64_t *>(l2.p_cnt.ptr) + 15); // (pinned; level2_windows reads words 0-12)
+            *h_rankflag = 0;
+            if (try_rank)
+            {
+                if ((rc = ensure(h, l2.d_rank, (n + 1) * sizeof(uint32_t) + 16)))
+                    return rc;
+                for (hipEvent_t & ev : l2.ev_rank)
+                    if (!ev)
+                        LX_HIP(h, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                uint32_t * const d_rank = static_cast<uint32_t *>(l2.d_rank.ptr);
+                LX_HIP(h, hipEventRecord(l2.ev_rank[0], st)); // (the window list is complete behind what `st` holds now)
+                LX_HIP(h, hipStreamWaitEvent(h->stream2, l2.ev_rank[0], 0));
+                LX_HIP(h, hipMemsetAsync(d_rank + n, 0, sizeof(uint32_t), h->stream2));
+                LX_HIP(h, lx::rec_launch_rank(static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo, n, (uint32_t)std::max(1, params->qry_num_frames),
+                                              static_cast<uint32_t const *>(l2.d_qlen.ptr), d_rank, d_rank + n, h->stream2));
+                LX_HIP(h, hipMemcpyAsync(h_rankflag, d_rank + n, sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream2));
+                LX_HIP(h, hipEventRecord(l2.ev_rank[1], h->stream2));
+            }
             if (solo)
                 for (size_t r = 0; r < ranges.size(); ++r)
                 {
@@ -750,27 +771,13 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                 LX_HIP(h, lx::fp_launch_plan(fa, st));
                 LX_HIP(h, hipMemcpyAsync(h_report, fa.report, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
-            // (records on the device: every window's place in the records' order, once -- lx_records.hip: the ranges' survivors are sorted by it)
-            bool const try_rank = records_on_device && n < 0xfffffff0ull;
             if (try_rank)
-            {
-                if ((rc = ensure(h, l2.d_rank, (n + 1) * sizeof(uint32_t) + 16)))
-                    return rc;
-                uint32_t * const d_rank = static_cast<uint32_t *>(l2.d_rank.ptr);
-                LX_HIP(h, hipMemsetAsync(d_rank + n, 0, sizeof(uint32_t), st));
-                LX_HIP(h, lx::rec_launch_rank(static_cast<lx::L2Window const *>(l2.d_win.ptr) + pt.lo, n, (uint32_t)std::max(1, params->qry_num_frames),
-                                              static_cast<uint32_t const *>(l2.d_qlen.ptr), d_rank, d_rank + n, st));
-            }
-            // what the host reads of the plan, in pinned memory: the rank kernel's flag, columns per lane and longest window per wavefront
-            uint32_t flag_now = 0;
+                LX_HIP(h, hipStreamWaitEvent(st, l2.ev_rank[1], 0)); // (the records kernels on `st` read the ranks)
+            // what the host reads of the plan, in pinned memory: columns per lane and longest window per wavefront
             if (!solo)
             {
-                *h_flag = 0;
-                if (try_rank)
-                    LX_HIP(h, hipMemcpyAsync(h_flag, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 LX_HIP(h, hipStreamSynchronize(st));
-                flag_now = *h_flag;
-                nwf      = h_report[0];
+                nwf = h_report[0];
                 if (h_report[1] || nwf == 0 || nwf > cap_wf)
                     return fail(h, LX_ESTATE, "the free-packing plan of %llu windows reports %llu wavefronts (at most %llu), flag %u", (unsigned long long)n,
                                 (unsigned long long)nwf, (unsigned long long)cap_wf, h_report[1]);
@@ -782,22 +789,17 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
             // (no copy into the block is pending here: it may move)
             if ((rc = ensure_pinned(h, l2.p_plan, kPlanHead + 2 * nwf * sizeof(uint32_t))))
                 return rc;
-            uint32_t * const h_flag2 = static_cast<uint32_t *>(l2.p_plan.ptr);
-            uint32_t * const h_pan   = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanHead), * const h_maxs = h_pan + nwf;
-            *h_flag2 = flag_now;
-            if (solo && try_rank)
-                LX_HIP(h, hipMemcpyAsync(h_flag2, static_cast<uint32_t *>(l2.d_rank.ptr) + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            uint32_t * const h_pan = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(l2.p_plan.ptr) + kPlanHead), * const h_maxs = h_pan + nwf;
             LX_HIP(h, hipMemcpyAsync(h_pan, d_pan, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             LX_HIP(h, hipMemcpyAsync(h_maxs, d_maxs, nwf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             if ((windows_to_host || !records_on_device) && (rc = queue_windows()))
                 return rc;
-            LX_HIP(h, hipStreamSynchronize(st));
-            uint32_t * const h_flag_final = h_flag2;
+            LX_HIP(h, hipStreamSynchronize(st)); // (behind the rank kernel's event as well: its flag has arrived)
             ri.d_plan  = static_cast<uint32_t const *>(l2.d_plan.ptr);
             ri.nwf     = nwf;
             ri.wf_pan  = h_pan;
             ri.wf_maxs = h_maxs;
-            l2.rank_too_long = *h_flag_final;
+            l2.rank_too_long = *h_rankflag;
             ri.mq_cfg  = cfg;
             ri.free_packing = !solo;
             ri.cells   = cost[4 * pi + 3];
