@@ -69,6 +69,7 @@ def parse(argv=None):
     ap.add_argument("--max-evalue", type=float, default=None)
     ap.add_argument("--max-matches", type=int, default=25, help="HSPs kept per query for the final gather (maxMatches)")
     ap.add_argument("--trace-bytes", type=int, default=160 << 30, help="LX_OPT_TRACE_BYTES: HBM the checkpoint slots may take")
+    ap.add_argument("--extend-chunk", type=int, default=None, help="--host-path / --ragged: LX_OPT_EXTEND_CHUNK (extensions per chunk of the pipeline; default: the library's)")
     ap.add_argument("--band", type=int, default=0, help="band mode (LX_OPT_BAND, not the reference's configuration): half width in "
                     "diagonals around the window's seed diagonal; the metric then counts cells = sum Lq * min(Ls, 2 band + 1)")
     ap.add_argument("--host-path", action="store_true", help="time lx_extend_batch on HOST buffers (what a lambda3 binding calls, INTEGRATION.md "
@@ -368,6 +369,8 @@ def host_path(args, w, pl, world, rank, local_rank, dev, use_dist):
         h.set_scoring(capi.builtin_scoring(m, match=ma, mismatch=mi, gap_open=go, gap_extend=ge), d.slot)
     h.set_option(capi.LX_OPT_BS_MATCH_RULE, 1 if len(w.directions) > 1 else 0)
     h.set_option(capi.LX_OPT_TRACE_BYTES, args.trace_bytes)
+    if args.extend_chunk:
+        h.set_option(capi.LX_OPT_EXTEND_CHUNK, args.extend_chunk)
     ka = capi.karlin_params(*w.karlin)
     lib = capi.load()
     adj = lib.lx_length_adjustment(w.db_length, w.lq, C.byref(ka))

@@ -2,6 +2,10 @@
   (a) widen + sort + merge + unique against the CPU oracle's _widenAndPreprocessMatches restatement -- list sizes on and around the
       tile sizes of the sort / scan kernels, one to many queries and subjects, subjects shorter than the query's window and longer
       than 2^32, heavy duplication, every arrival order, the bisulfite order;
+  (c) the free-packing plan of protein window lists made on the device (lx_plan_free_packing_dev) slot by slot -- every window once, fillers
+      copies of their wavefront's windows, a lane group one query, at most four queries per wavefront, the wavefronts' widest query and longest
+      window, ranges contiguous (tests/test_gpu_plan.py's checker) -- for random run lengths, query lengths, merged / clipped shares, strip
+      widths and range cuts;
   (b) the whole driver call against lx_iterate_matches on the same list from host memory (below 131 072 matches that is the host's own
       list code: an independent implementation), byte for byte -- random schemes, filters, orders, LX_ITERATE_NO_OPS; small cases
       against the oracle driver (tests/oracle_driver.py) as well.
@@ -13,6 +17,7 @@ import numpy as np
 from lambda_amd import capi
 from tests import oracle_driver, oracle_lib
 from tests.test_gpu_level2 import _random_matches, _seed_list, _to_device
+from tests.test_gpu_plan import check_plan, make_list
 from tests.test_oracle import SCHEMES
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
@@ -22,7 +27,28 @@ h = capi.Handle(0)
 EDGES = [1, 2, 3, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4095, 4096, 4097, 8191, 8192, 8193, 12288, 65536, 65537]
 FIELDS = ("qryId", "subjId", "qryStart", "qryEnd", "subjStart", "subjEnd")
 t0 = time.time()
-case = bad = n_widen = n_driver = n_oracle_driver = 0
+case = bad = n_widen = n_driver = n_oracle_driver = n_plan = 0
+
+
+def plan_case(rng):
+    nq = int(rng.choice([1, 2, 5, 60, 700, 4000]))
+    mean_w = float(rng.choice([1.2, 3, 8, 30, 200])) if nq < 4000 else float(rng.choice([1.2, 3, 8]))
+    lq_hi = int(rng.choice([60, 150, 400, 1300]))
+    ext = make_list(rng, nq, lambda r: 1 + r.poisson(mean_w) if r.random() < 0.9 else 1 + r.poisson(20 * mean_w), lambda r: int(r.integers(20, lq_hi + 1)),
+                    merged_share=float(rng.choice([0, 0.1, 0.5])), clipped_share=float(rng.choice([0, 0.1, 0.4])))
+    n = len(ext)
+    change = np.nonzero(ext["q_off"][1:] != ext["q_off"][:-1])[0] + 1
+    R = int(rng.integers(1, 9))
+    cuts = [0] + sorted({int(change[i]) for i in rng.integers(0, len(change), R - 1)} if len(change) and R > 1 else set()) + [n]
+    C = int(rng.choice([19, 13, 11]))
+    plan, pan, maxs, rep = h.plan_free_packing_dev(_to_device(ext), n, nq, strip_cols=C, cuts=cuts)
+    try:
+        check_plan(ext, plan, pan, maxs, rep, cuts, C)
+        ok = True
+    except AssertionError as e:
+        ok = False
+        print("   ", repr(e)[:300])
+    return ok, f"plan n={n} nq={nq} mean windows {mean_w} lq <= {lq_hi} C={C} ranges {len(cuts) - 1} -> {len(plan)} wavefronts"
 
 
 def widen_case(rng):
@@ -104,6 +130,9 @@ while time.time() - t0 < budget:
     if case % 3 == 2:
         ok, what = driver_case(rng)
         n_driver += 1
+    elif case % 3 == 1 and case % 2 == 0:
+        ok, what = plan_case(rng)
+        n_plan += 1
     else:
         ok, what = widen_case(rng)
         n_widen += 1
@@ -111,6 +140,6 @@ while time.time() - t0 < budget:
         bad += 1
         print("MISMATCH case", case, "seed", seed0, what, flush=True)
     case += 1
-print(f"stress_level2: {case} cases ({n_widen} window lists against the oracle, {n_driver} driver calls against the host entry point, "
+print(f"stress_level2: {case} cases ({n_widen} window lists against the oracle, {n_plan} device plans slot by slot, {n_driver} driver calls against the host entry point, "
       f"{n_oracle_driver} of them against the oracle driver too), {bad} failures, seed {seed0}, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
