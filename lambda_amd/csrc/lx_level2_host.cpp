@@ -650,6 +650,7 @@ static int level2_sorted_tail(lx_handle * h, int slot, uint64_t n_matches, lx_se
                     uint64_t const have   = std::min<uint64_t>(h->opt_trace_bytes, std::max<uint64_t>(h->d_trace.cap, 8ull << 30));
                     R = std::min<uint64_t>(lx::kFpMaxRanges, std::max<uint64_t>(R, (need + have - 1) / have));
                 }
+                R = std::min<uint64_t>(R, lx::kFpMaxRanges); // (what the plan kernels and the probe block take; LX_L2_RANGES may ask for more)
                 uint64_t       lo     = 0;
                 int const      qF     = std::max(1, params->qry_num_frames);
                 // the windows around every cut's target come down together (512 each), one synchronisation
