@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         if (aj >= nar_j0)
         {
             int const jl = aj - nar_j0;
-            int const gl = nar_cw == (C + 1) / 2 ? jl / ((C + 1) / 2) : jl / ((C + 3) / 4);
+            int const gl = nar_cw == (3 * C + 3) / 4 ? jl / ((3 * C + 3) / 4) : nar_cw == (C + 1) / 2 ? jl / ((C + 1) / 2) : jl / ((C + 3) / 4);
             st = nar_st0 + gl;
             j0 = nar_j0 + gl * nar_cw;
             cw = nar_cw;

@@ -129,11 +129,12 @@ constexpr int     kEndOverflowShift = 8; // flags >> 8 = 1 + index of the extens
 constexpr int     kEndNarrowShift   = 2;
 // the compact slots of the extension's WAVEFRONT are interleaved (ScoreParams::wave_slots): bit 4
 constexpr int32_t kEndWaveSlots     = 16;
-__host__ __device__ constexpr int narrow_strip_cols(int C, int code) { return code == 0 ? C : code == 1 ? (C + 1) / 2 : (C + 3) / 4; }
+__host__ __device__ constexpr int narrow_strip_cols(int C, int code) { return code == 0 ? C : code == 1 ? (3 * C + 3) / 4 : code == 2 ? (C + 1) / 2 : (C + 3) / 4; }
+constexpr int kNarrowest = 3; // the code of the narrowest strips
 // the code for a panel that has `rem` columns of the query left (rem >= 1), G lanes per group
 __host__ __device__ constexpr int narrow_code_for(int C, int G, int rem)
 {
-    return rem <= G * ((C + 3) / 4) ? 2 : rem <= G * ((C + 1) / 2) ? 1 : 0;
+    return rem <= G * ((C + 3) / 4) ? 3 : rem <= G * ((C + 1) / 2) ? 2 : rem <= G * ((3 * C + 3) / 4) ? 1 : 0;
 }
 
 // Compact checkpoint slots of the packed-half single sweep (lx_score_f16.hip writes, lx_ckpt.hip's backtrace reads).

@@ -24,7 +24,7 @@
 //   * free packing (pair_share = 1, LX_OPT_QUERY_RUN = 2): what the LDS limits is the number of profiles per wavefront (four),
 //     not how the lane groups are dealt to them -- a lane group's two windows share a query, the eight lane groups hold windows
 //     of up to four queries in any split, numbered in order of appearance;
-//   * narrow last panel (ScoreParams::narrow): the panel body exists for C, (C + 1) / 2 and (C + 3) / 4 columns per lane; a
+//   * narrow last panel (ScoreParams::narrow): the panel body exists for C, (3 C + 3) / 4, (C + 1) / 2 and (C + 3) / 4 columns per lane; a
 //     wavefront runs a panel with the narrowest width that covers what any of its queries has left there, and records the width
 //     of an extension's last panel in its end cell (kEndNarrowShift) for the backtrace.
 // Slots are the compact 16-bit codes of Ckpt16Layout (one part per panel); an extension whose best score is beyond 2046
@@ -349,17 +349,17 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
     for (int panel = 0; panel < npanels; ++panel)
     {
         // The panel's strip width, one for the wavefront: full width while any of its queries goes on behind this panel, else
-        // the narrowest of C, (C + 1) / 2, (C + 3) / 4 columns per lane that covers what its queries have left.
+        // the narrowest of C, (3 C + 3) / 4, (C + 1) / 2, (C + 3) / 4 columns per lane that covers what its queries have left.
         int code = 0;
         if (p.narrow)
         {
             int const rem  = lq - panel * Geo::kPanel;
-            int       mine = panel < my_panels - 1 ? 0 : rem >= 1 ? narrow_code_for(C, G, rem) : 2; // (no column left: any width)
-            mine           = actA ? mine : 2;
+            int       mine = panel < my_panels - 1 ? 0 : rem >= 1 ? narrow_code_for(C, G, rem) : kNarrowest; // (no column left: any width)
+            mine           = actA ? mine : kNarrowest;
             if (solo_mode && actB)
             {
                 int const remB = lqB - panel * Geo::kPanel;
-                mine           = min(mine, panel < my_panelsB - 1 ? 0 : remB >= 1 ? narrow_code_for(C, G, remB) : 2);
+                mine           = min(mine, panel < my_panelsB - 1 ? 0 : remB >= 1 ? narrow_code_for(C, G, remB) : kNarrowest);
             }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1)
@@ -896,6 +896,8 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
         if (code == 0)
             panel_body(std::integral_constant<int, C>{});
         else if (code == 1)
+            panel_body(std::integral_constant<int, (3 * C + 3) / 4>{});
+        else if (code == 2)
             panel_body(std::integral_constant<int, (C + 1) / 2>{});
         else
             panel_body(std::integral_constant<int, (C + 3) / 4>{});

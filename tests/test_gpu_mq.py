@@ -300,11 +300,12 @@ def test_mq_sweep_free_packing_declined_and_broken_promises(handle, oracle):
         run_fused(handle, q2, s2, e3, 2, 50, mq=1)
 
 
-@pytest.mark.parametrize("lq_range", [(33, 40), (70, 80), (153, 160), (185, 192), (225, 232), (305, 312), (340, 344), (381, 384)])
+@pytest.mark.parametrize("lq_range", [(33, 40), (70, 80), (100, 120), (153, 160), (185, 192), (225, 232), (262, 272), (305, 312), (340, 344), (381, 384), (420, 424)])
 def test_mq_sweep_narrow_last_panel(handle, oracle, lq_range):
-    """A query's last panel runs the narrowest strips that cover what is left of it -- 19, 10 or 5 columns per lane at 152-column
-    panels (lx_device.h: narrow_code_for) --, recorded in the end cell's flags for the backtrace.  Query lengths that leave 1-40 /
-    41-80 / 81-152 columns for the last of one, two and three panels; all queries of a list in one width class, so that whole
+    """A query's last panel runs the narrowest strips that cover what is left of it -- 19, 15, 10 or 5 columns per lane at 152-column
+    panels (lx_device.h: narrow_code_for; the 15-column width since round 6) --, recorded in the end cell's flags for the backtrace.
+    Query lengths that leave 1-40 / 41-80 / 81-120 / 121-152 columns for the last of one, two and three panels; all queries of a list
+    in one width class, so that whole
     wavefronts take the narrow path (a wavefront runs the widest strips any of its queries needs)."""
     sc_p = SCHEMES["blosum62"]
     handle.set_scoring(sc_p, 0)

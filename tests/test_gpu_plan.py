@@ -15,7 +15,7 @@ def cols_per_lane(lq, C=19):
     panel = 8 * C
     P = max(1, -(-lq // panel))
     rem = max(lq, 1) - (P - 1) * panel
-    last = (C + 3) // 4 if rem <= 8 * ((C + 3) // 4) else (C + 1) // 2 if rem <= 8 * ((C + 1) // 2) else C
+    last = (C + 3) // 4 if rem <= 8 * ((C + 3) // 4) else (C + 1) // 2 if rem <= 8 * ((C + 1) // 2) else (3 * C + 3) // 4 if rem <= 8 * ((3 * C + 3) // 4) else C
     return min(0xfff, (P - 1) * C + last)
 
 
