@@ -1274,7 +1274,7 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
 #pragma unroll
                 for (int xw = 0; xw < kNibDw; ++xw)
                     tiles[(kk * kNibDw + xw) * 64 + lane] = w[xw];
-                if (need_col && (scan || row >= i - 3) && row <= i && row >= 0 && row < ls) // (a chunk may end behind the last row)
+                if (need_col && row <= i && row >= 0 && row < ls) // (every row of the tile up to the reported one: the sweeps report the block, not the row; a block may end behind the last row)
                 {
                     // lowest column of this row whose H equals the score (no H exceeds it: H - score <= 0, a multiple of 4
                     // after the tags are masked), as a maximum of keys without compares: key = (H - score) * 32 + (C - c)
@@ -1302,9 +1302,9 @@ __global__ __launch_bounds__(64, LX_BT_WAVES) void ckpt_backtrace_kernel(TracePa
         }
         else if (need_col)
         {
-            // the end row is one of the last four computed rows (the packed-half sweep reports the chunk, the int32 sweep
-            // the exact row -- earlier rows of the strip then do not carry the score), or one of those scanned: lowest
-            // column, then lowest row.  From the end cell the walk starts like anywhere else: with a diagonal shortcut.
+            // the end row is one of the tile's computed rows (the packed sweeps report the block of sixteen steps -- the tile --,
+            // the int32 sweep the exact row: earlier rows of the strip then do not carry the score), or one of those scanned:
+            // lowest column, then lowest row.  From the end cell the walk starts like anywhere else: with a diagonal shortcut.
             need_col = false;
             scan     = false;
             walk_ok  = false;

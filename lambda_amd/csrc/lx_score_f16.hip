@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
         h2 const cand = rowmax - Z;
         if constexpr (CKPT)
         {
-            cmax = hmax(cmax, cand); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
+            cmax = hmax(cmax, cand); // the rose / met-again logic runs once per block of sixteen steps (book)
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
             // Ckpt16Layout codes of both extensions, staged for one 16-byte store per extension every eight steps
             h2 const hc           = h * C24;
@@ -368,27 +368,34 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
                                                               __builtin_amdgcn_perm(cw[5], cw[4], 0x07060302u), __builtin_amdgcn_perm(cw[7], cw[6], 0x07060302u));
         }
     };
-    // CKPT: after every fourth step the best-value bookkeeping, after every eighth the staged boundary codes leave
+    // CKPT: the best-value bookkeeping, once per block of sixteen steps (the backtrace's tiles are these blocks: its first tile looks
+    // at every row of the block up to the one reported here -- lx_ckpt.hip, need_col).  Per four steps, as rounds 2-5 had it, the
+    // selects below were 3 % of the sweep's issue slots.
+    auto book = [&](int k0) // k0: the first of the block's last four steps
+    {
+        if constexpr (CKPT)
+        {
+            // per half: did the strip's best rise in this block (then its first row is one of the block's sixteen; the
+            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and
+            // columns beyond the query stay strictly below a positive best: no validity test.
+            h2 const       nb   = hmax(best, cmax);
+            uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
+            bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
+            bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
+            int const last = k0 + 3 - g; // the block's last row in this lane
+            rowA = gtA ? last : rowA;
+            rowB = gtB ? last : rowB;
+            tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
+            tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+            best = nb;
+            cmax = as_h2(kHalfNegInf2);
+        }
+    };
+    // CKPT: after every eighth step the staged boundary codes leave
     auto chunk_done = [&](int k0)
     {
         if constexpr (CKPT)
         {
-            // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
-            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and
-            // columns beyond the query stay strictly below a positive best: no validity test.
-            {
-                h2 const       nb   = hmax(best, cmax);
-                uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
-                bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
-                bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
-                int const last = k0 + 3 - g; // the chunk's last row in this lane
-                rowA = gtA ? last : rowA;
-                rowB = gtB ? last : rowB;
-                tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
-                tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
-                best = nb;
-                cmax = as_h2(kHalfNegInf2);
-            }
 #ifndef LX_EXP_NO_FLUSH
             if (k0 & 4)
                 flush_codes(k0);
@@ -466,10 +473,13 @@ __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) 
     auto chunk_stores = [&](int k0)
     {
         chunk_done(k0);
-#ifndef LX_EXP_NO_ROWCK
         if (((k0 + 4) & 15) == 0)
+        {
+            book(k0);
+#ifndef LX_EXP_NO_ROWCK
             rowck_store(k0);
 #endif
+        }
     };
     int      k0 = 0;
     uint32_t na[4], nb[4];
@@ -515,6 +525,8 @@ LX_UNROLL(LX_F16_UNROLL)
     }
     if (steps & 4)
         flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
+    if (steps & 15)
+        book(steps - 4); // the last, partial block
 
     if constexpr (!CKPT)
     {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
             }
             if constexpr (CKPT)
             {
-                cmax = smax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
+                cmax = smax(cmax, rowmax - Z); // the rose / met-again logic runs once per block of sixteen steps (book)
                 // un-skewed boundary pairs (H of the strip's last column, E as the next strip's first column uses it),
                 // re-paired per extension and staged for one 16-byte store per four steps
                 if constexpr (COMPACT)
@@ -435,27 +435,33 @@ __global__ __launch_bounds__(64, 3) void sweep_pair16_kernel(ScoreParams p)
                 }
             }
         };
+        // the best-value bookkeeping, once per block of sixteen steps (lx_score_f16.hip: book)
+        auto book = [&](int k0) // k0: the first of the block's last four steps
+        {
+            if constexpr (!CKPT)
+                return;
+            // per half: did the strip's best rise in this block (then its first row is one of the block's sixteen; the
+            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and columns
+            // beyond the query stay strictly below a positive best: no validity test.
+            s2 const       nb   = smax(best, cmax);
+            uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
+            bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
+            bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
+            int const      last = k0 + 3 - g; // the block's last row in this lane
+            rowA = gtA ? last : rowA;
+            rowB = gtB ? last : rowB;
+            tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
+            tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
+            best = nb;
+            cmax = ssplat(0);
+        };
         // after every fourth step the staged boundary quads leave; every 16th step the row checkpoint follows
         auto chunk_done = [&](int k0)
         {
             if constexpr (!CKPT)
                 return;
-            // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
-            // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and columns
-            // beyond the query stay strictly below a positive best: no validity test.
-            {
-                s2 const       nb   = smax(best, cmax);
-                uint32_t const rose = as_u32(nb) ^ as_u32(best), met = as_u32(cmax) ^ as_u32(best);
-                bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
-                bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
-                int const      last = k0 + 3 - g; // the chunk's last row in this lane
-                rowA = gtA ? last : rowA;
-                rowB = gtB ? last : rowB;
-                tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
-                tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
-                best = nb;
-                cmax = ssplat(0);
-            }
+            if (((k0 + 4) & 15) == 0)
+                book(k0);
             if constexpr (COMPACT)
             {
                 if (k0 & 4)
@@ -574,6 +580,8 @@ LX_I16_UNROLL_N(LX_I16_UNROLL)
             if (steps & 4)
                 flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
         }
+        if (steps & 15)
+            book(steps - 4); // the last, partial block
         // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first).
         // Over the panels a later one only wins with a strictly greater value (its columns come later).
         auto merge = [&](int lbest, int lrow, int ltie, int & run, int & rstrip, int & rrow, int & rtie)

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
                 outA[u] = qbits(sendA); // (stored by chunk_done: one branch per four steps)
                 outE[u] = qbits(sendE);
             }
-            cmax = qmax(cmax, rowmax - Z); // the rose / met-again logic runs once per chunk of four steps (chunk_done)
+            cmax = qmax(cmax, rowmax - Z); // the rose / met-again logic runs once per block of sixteen steps (book)
             // un-skewed boundary pair (H of the strip's last column, E as the next strip's first column uses it) as
             // Ckpt16Layout codes of both extensions: H | (H - E) << 11
             if constexpr (WIDE)
@@ -667,22 +667,26 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
                 dB[qi] = make_uint4(wb[0], wb[1], wb[2], wb[3]);
             }
         };
-        auto chunk_done = [&](int k0)
+        // the best-value bookkeeping, once per block of sixteen steps (lx_score_f16.hip: book)
+        auto book = [&](int k0) // k0: the first of the block's last four steps
         {
-            // per half: did the strip's best rise in this chunk (then its first row is one of the chunk's four; the
+            // per half: did the strip's best rise in this block (then its first row is one of the block's sixteen; the
             // backtrace finds it), or was it only met again (a tie for the end cell)?  Rows beyond the window and columns
             // beyond the query stay strictly below a positive best: no validity test.
             q2 const       nb   = qmax(best, cmax);
             uint32_t const rose = qbits(nb) ^ qbits(best), met = qbits(cmax) ^ qbits(best);
             bool const     gtA = (rose & 0xffffu) != 0, gtB = (rose >> 16) != 0;
             bool const     eqA = (met & 0xffffu) == 0, eqB = (met >> 16) == 0;
-            int const      last = k0 + 3 - g; // the chunk's last row in this lane
+            int const      last = k0 + 3 - g; // the block's last row in this lane
             rowA = gtA ? last : rowA;
             rowB = gtB ? last : rowB;
             tie  = (gtA ? (tie & ~1u) : (tie | (eqA ? 1u : 0u)));
             tie  = (gtB ? (tie & ~2u) : (tie | (eqB ? 2u : 0u)));
             best = nb;
             cmax = qsplat(0);
+        };
+        auto chunk_done = [&](int k0)
+        {
             if constexpr (WIDE)
             {
                 // the four steps' boundary pairs leave as one quad per extension (lx_ckpt.hip: bnd_quad_index)
@@ -785,7 +789,10 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
         {
             chunk_done(k0);
             if (((k0 + 4) & 15) == 0)
+            {
+                book(k0);
                 rowck_codes(k0);
+            }
         };
         auto four_steps = [&](uint32_t const (&ta)[4], uint32_t const (&tb)[4], int k0)
         {
@@ -856,6 +863,8 @@ __global__ __launch_bounds__(64, LX_MQ_WAVES) void sweep_mq_kernel(ScoreParams p
         }
         if (!WIDE && (steps & 4))
             flush_codes(steps); // the last four steps' codes (the other half of the group is stale: beyond every row)
+        if (steps & 15)
+            book(steps - 4); // the last, partial block
 
         // per extension: best strip value over the group; among equal ones the lowest strip (its columns come first).
         // Over the panels a later one only wins with a strictly greater value (its columns come later).
