@@ -139,6 +139,19 @@ DEF_KERNEL(k_addfc, I_ADDFC)
     "v_pk_maximum3_f16 " R ", " R ", %9, %8\n v_pk_maximum3_f16 " R ", " R ", %8, %8\n v_pk_add_u16 " R ", " R ", %8\n"       \
     "v_perm_b32 " R ", " R ", %8, %9\n"
 DEF_KERNEL(k_sweepmix, I_SWEEPMIX)
+// round 6: the diagonal operand's two halves added by two NON-packed half adds (the second one writes the high half: VOP3 op_sel, one wait
+// state before its result is read) instead of v_perm_b32 + v_pk_add -- are they full-rate like the VOP2 forms?
+// (gfx950 takes op_sel on the VOP3-only 16-bit forms: v_fma_f16, v_mad_u16, v_fma_mixhi_f16 ... not on v_add_f16)
+#define I_ADDF16HI(R) "v_fma_f16 " R ", " R ", 1.0, %8 op_sel:[1,0,1,1]\n"
+#define I_ADDF16SEL(R) "v_fma_f16 " R ", " R ", 1.0, %8\n"
+#define I_MADU16HI(R) "v_mad_u16 " R ", " R ", 1, %8 op_sel:[1,0,1,1]\n"
+#define I_MIXHI(R) "v_fma_mixhi_f16 " R ", " R ", 1.0, %8 op_sel:[1,0,1] op_sel_hi:[1,0,1]\n"
+#define I_MIXLO(R) "v_fma_mixlo_f16 " R ", " R ", 1.0, %8 op_sel_hi:[1,0,1]\n"
+#define I_SWEEPMIX2(R)                                                                                                      \
+    "v_add_f16 " R ", " R ", %8\n v_fma_f16 " R ", " R ", 1.0, %9 op_sel:[1,0,1,1]\n s_nop 0\n v_pk_maximum3_f16 " R ", " R ", %8, %9\n v_pk_add_u16 " R ", " R ", %9\n" \
+    "v_pk_maximum3_f16 " R ", " R ", %9, %8\n v_pk_maximum3_f16 " R ", " R ", %8, %8\n v_pk_add_u16 " R ", " R ", %8\n"
+DEF_KERNEL(k_addf16hi, I_ADDF16HI) DEF_KERNEL(k_addf16sel, I_ADDF16SEL) DEF_KERNEL(k_sweepmix2, I_SWEEPMIX2)
+DEF_KERNEL(k_madu16hi, I_MADU16HI) DEF_KERNEL(k_mixhi, I_MIXHI) DEF_KERNEL(k_mixlo, I_MIXLO)
 DEF_KERNEL(k_cnds, I_CNDS) DEF_KERNEL(k_bfi, I_BFI) DEF_KERNEL(k_pkaddsel, I_PKADDSEL) DEF_KERNEL(k_pkfma, I_PKFMA)
 
 // LDS: ds_read_b32 with a lane-linear address pattern
@@ -223,7 +236,8 @@ int main()
                {"v_add_co_u32", k_addco, 1}, {"v_max3_f16", k_max3f16, 2}, {"v_pk_min_i16", k_pkmin, 2},
                {"v_pk_add_u16", k_pkaddu, 2}, {"v_sad_u32", k_sad, 2}, {"v_add_f32_const", k_addfc, 1},
                {"v_cndmask_e64_sgpr", k_cnds, 1}, {"v_bfi_b32", k_bfi, 1}, {"pk_add_f16_opsel", k_pkaddsel, 2},
-               {"v_pk_fma_f16", k_pkfma, 4}};
+               {"v_pk_fma_f16", k_pkfma, 4}, {"v_fma_f16_hi(op_sel)", k_addf16hi, 1}, {"v_fma_f16", k_addf16sel, 1}, {"v_mad_u16_hi(op_sel)", k_madu16hi, 1},
+               {"v_fma_mixhi_f16", k_mixhi, 1}, {"v_fma_mixlo_f16", k_mixlo, 1}};
     for (int w : {8})
         for (auto & t : tab)
             run(t.n, t.k, d_out, w, t.ops);
@@ -236,6 +250,7 @@ int main()
         run("pk_maximum3_f16", k_pkmax3f, d_out, w, 4);
         run("v_perm_b32", k_perm, d_out, w, 1);
         run("sweep_mix(x7)", k_sweepmix, d_out, w, 7);
+        run("sweep_mix2(x7)", k_sweepmix2, d_out, w, 7);
     }
     return 0;
 }
