@@ -509,3 +509,35 @@ def test_overflow_area_exhausted_runs_the_chunk_again_with_wide_slots(handle, or
         handle.set_option(capi.LX_OPT_TRACE_BYTES, 64 << 30)
     # (the chunk that ran out is run again -- with int16 pairs from the sweep where they fit the budget, else on the per-survivor path)
     assert "sweep_mq_kernel<19,true,false>" not in name, name
+
+
+@pytest.mark.parametrize("run,mq,lq_range", [(4, 2, (100, 150)), (16, 2, (100, 150)), (8, 2, (280, 330)), (1, 1, (90, 150))])
+def test_mq_sweep_ties_two_letter_alphabet(handle, oracle, run, mq, lq_range):
+    """Two-letter sequences through the multi-query sweep: a strip's best value is reached in many rows -- of one block of sixteen steps and
+    of several --, so the block-wise bookkeeping of the sweep (first block that reached the best, "met again in a later block") and the
+    backtrace's search of the block's rows (lowest column, then lowest row; scan mode over the later blocks) decide every end cell: all
+    survivors against the oracle, one and several panels, free and solo packing, windows that end inside a block."""
+    sc_p = SCHEMES["nucl"]
+    handle.set_scoring(sc_p, 0)
+    osc = oracle_lib.scoring_from(sc_p)
+    rng = np.random.default_rng(77 + run + lq_range[0])
+    nq, wpq = 48, 8
+    lqs = rng.integers(lq_range[0], lq_range[1] + 1, nq)
+    q = rng.integers(0, 2, int(lqs.sum())).astype(np.uint8)
+    q_off = np.concatenate([[0], np.cumsum(lqs)[:-1]])
+    lss = rng.integers(60, 2 * lq_range[1], nq * wpq)
+    s = rng.integers(0, 2, int(lss.sum())).astype(np.uint8)
+    s_off = np.concatenate([[0], np.cumsum(lss)[:-1]])
+    ext = np.zeros(nq * wpq, dtype=capi.EXT_DTYPE)
+    ext["q_off"] = np.repeat(q_off, wpq)
+    ext["q_len"] = np.repeat(lqs, wpq)
+    ext["s_off"] = s_off
+    ext["s_len"] = lss
+    # a piece of the query in every third window: strong diagonals among the many equal-scoring alternatives
+    for k in range(0, len(ext), 3):
+        n = int(min(ext["q_len"][k], ext["s_len"][k]) // 2)
+        s[ext["s_off"][k] + 5: ext["s_off"][k] + 5 + n] = q[ext["q_off"][k] + 3: ext["q_off"][k] + 3 + n]
+    slots, _ = pack_runs(ext, run) if run > 1 else (ext[rng.permutation(len(ext))], None)
+    got = run_fused(handle, q, s, slots, run, 20, mq=mq)
+    assert "sweep_mq_kernel" in got[5], got[5]
+    check_against_oracle(oracle, osc, q, s, slots, 20, *got[:5])
