@@ -7,7 +7,7 @@ import numpy as np, torch
 from lambda_amd import capi, synth
 
 dev = torch.device("cuda:0")
-nq, lq, wpq = 100000, 150, 32
+nq, lq, wpq = (int(sys.argv[1]) if len(sys.argv) > 1 else 100000), 150, 32
 sets = []
 for k in range(2):
     h = capi.Handle(0)
