@@ -117,8 +117,10 @@ struct EndCell
 {
     int32_t score;
     int32_t q_end; // 1-based column of the best cell == half-open end; -(strip + 1) while only the strip is known
-    int32_t s_end;
-    int32_t flags; // kEndAmbiguous: the strip reaches the best score in more than one row
+    int32_t s_end; // 1-based row of the best cell; while only the strip is known: the last row of the block of sixteen steps whose rows
+                   // reached the best score first (packed sweeps) or the first such row itself (int32 sweep) -- the backtrace's first tile is
+                   // that block and finds the cell (lowest column, then lowest row)
+    int32_t flags; // kEndAmbiguous: the strip reaches the best score again in a later block (packed sweeps) / row (int32): the backtrace scans on
 };
 constexpr int32_t kEndAmbiguous = 1;
 constexpr int32_t kEndCompact      = 2; // the slot was written by the packed-half sweep: compact 16-bit codes (Ckpt16Layout)

@@ -82,7 +82,7 @@ struct PairGeo
 
 // CKPT = single sweep: the kernel additionally writes what pass 2's backtrace needs (layout and meaning as in
 // lx_ckpt.hip: strip boundaries per step, row checkpoints every 16 steps, here as the compact codes of Ckpt16Layout) and
-// keeps, per strip and extension, the best value, the first row that reached it and whether a later row tied.
+// keeps, per strip and extension, the best value, the block of sixteen steps whose rows reached it first and whether a later block tied.
 template <int G, int C, bool CKPT>
 __global__ __launch_bounds__(64, (CKPT ? (C > 19 ? 2 : LX_F16_CKPT_WAVES) : 1)) void score_pair_kernel(ScoreParams p) // (25-column strips: 168 VGPRs spill, and their LDS profile leaves 9 wavefronts per CU anyway)
 {
